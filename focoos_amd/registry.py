@@ -1,0 +1,59 @@
+"""Model registry of the engine: the RT-DETR entries of the reference's registry
+(focoos/model_registry/fai-detr-l-{obj365,coco}.json — config values are the spec
+for every shape on the hot path).  Weights URIs are remote in the reference;
+offline the engine is constructed with seeded synthetic weights (``synth.py``)
+or a local ``model_final.pth`` given by ``weights_uri``."""
+from __future__ import annotations
+
+import copy
+from typing import Dict, List
+
+_DETR_L_CONFIG = {
+    "num_classes": 365,
+    "backbone_config": {
+        "use_pretrained": False, "backbone_url": None, "model_type": "resnet", "in_chans": 3, "depth": 50,
+        "variant": "d", "freeze_at": -1, "num_stages": 4, "freeze_norm": False, "act": "relu", "pretrained": False,
+    },
+    "num_queries": 300, "resolution": 640,
+    "pixel_mean": [123.675, 116.28, 103.53], "pixel_std": [58.395, 57.12, 57.375], "size_divisibility": 0,
+    "pixel_decoder_out_dim": 256, "pixel_decoder_feat_dim": 256, "pixel_decoder_num_encoder_layers": 1,
+    "pixel_decoder_expansion": 1.0, "pixel_decoder_dim_feedforward": 1024,
+    "transformer_predictor_out_dim": 256, "transformer_predictor_hidden_dim": 256,
+    "transformer_predictor_dec_layers": 6, "transformer_predictor_dim_feedforward": 1024,
+    "head_out_dim": 256, "pixel_decoder_dropout": 0.0, "pixel_decoder_nhead": 8, "transformer_predictor_nhead": 8,
+    "threshold": 0.5, "top_k": 300,
+}
+
+
+def _entry(name: str, num_classes: int, description: str) -> Dict:
+    cfg = copy.deepcopy(_DETR_L_CONFIG)
+    cfg["num_classes"] = num_classes
+    return {
+        "name": name, "model_family": "fai_detr", "task": "detection", "im_size": 640,
+        "classes": [f"class_{i}" for i in range(num_classes)],  # class names are data of the reference registry
+        "config": cfg, "weights_uri": None, "description": description,
+    }
+
+
+_REGISTRY = {
+    "fai-detr-l-obj365": _entry("fai-detr-l-obj365", 365, "RT-DETR large (R50-vd), Objects365 head"),
+    "fai-detr-l-coco": _entry("fai-detr-l-coco", 80, "RT-DETR large (R50-vd), COCO head"),
+}
+
+
+class ModelRegistry:
+    """Mirror of focoos/model_registry/model_registry.py for the engine's entries."""
+
+    @classmethod
+    def list_models(cls) -> List[str]:
+        return sorted(_REGISTRY)
+
+    @classmethod
+    def exists(cls, name: str) -> bool:
+        return name in _REGISTRY
+
+    @classmethod
+    def get_model_info(cls, name: str) -> Dict:
+        if name not in _REGISTRY:
+            raise ValueError(f"⚠️ Model {name} not found. Available models: {cls.list_models()}")
+        return copy.deepcopy(_REGISTRY[name])

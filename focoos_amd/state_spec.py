@@ -1,0 +1,151 @@
+"""State-dict layout of the RT-DETR family (``fai-detr-*`` with a ResNet-vd backbone).
+
+The engine keeps the reference's checkpoint key names unchanged so that a
+``model_final.pth`` written by the reference loads into it and vice versa
+("state_dict() with unchanged key names").  The names below are
+what ``FAIDetr(config).state_dict()`` yields in the reference
+(focoos/models/fai_detr/modelling.py:1273-1334, focoos/nn/backbone/resnet.py:164-250);
+``tests/golden/detr_l_state_keys.json`` is a dump of the reference's own keys and
+``tests/test_state_spec.py`` pins this generator against it.
+
+kinds: conv_w, bn_w, bn_b, bn_mean, bn_var, bn_nbt, lin_w, lin_b, ln_w, ln_b, buf
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, Tuple
+
+Spec = "OrderedDict[str, Tuple[Tuple[int, ...], str]]"
+
+RESNET_BLOCKS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3]}
+
+
+def _conv_bn(spec, prefix, cin, cout, k, conv_name="conv", norm_name="norm"):
+    spec[f"{prefix}.{conv_name}.weight"] = ((cout, cin, k, k), "conv_w")
+    _bn(spec, f"{prefix}.{norm_name}", cout)
+
+
+def _bn(spec, prefix, c):
+    spec[f"{prefix}.weight"] = ((c,), "bn_w")
+    spec[f"{prefix}.bias"] = ((c,), "bn_b")
+    spec[f"{prefix}.running_mean"] = ((c,), "bn_mean")
+    spec[f"{prefix}.running_var"] = ((c,), "bn_var")
+    spec[f"{prefix}.num_batches_tracked"] = ((), "bn_nbt")
+
+
+def _linear(spec, prefix, cin, cout):
+    spec[f"{prefix}.weight"] = ((cout, cin), "lin_w")
+    spec[f"{prefix}.bias"] = ((cout,), "lin_b")
+
+
+def _ln(spec, prefix, c):
+    spec[f"{prefix}.weight"] = ((c,), "ln_w")
+    spec[f"{prefix}.bias"] = ((c,), "ln_b")
+
+
+def _mha(spec, prefix, c):
+    spec[f"{prefix}.in_proj_weight"] = ((3 * c, c), "lin_w")
+    spec[f"{prefix}.in_proj_bias"] = ((3 * c,), "lin_b")
+    _linear(spec, f"{prefix}.out_proj", c, c)
+
+
+def resnet_vd_spec(spec, prefix: str, depth: int, in_chans: int = 3):
+    """ResNet-vd (bottleneck) — focoos/nn/backbone/resnet.py:164-250."""
+    if depth not in RESNET_BLOCKS:
+        raise ValueError(f"unsupported resnet depth {depth} (engine covers bottleneck depths {sorted(RESNET_BLOCKS)})")
+    _conv_bn(spec, f"{prefix}.conv1.conv1_1", in_chans, 32, 3)
+    _conv_bn(spec, f"{prefix}.conv1.conv1_2", 32, 32, 3)
+    _conv_bn(spec, f"{prefix}.conv1.conv1_3", 32, 64, 3)
+    ch_in = 64
+    for si, (nblk, width) in enumerate(zip(RESNET_BLOCKS[depth], [64, 128, 256, 512])):
+        for bi in range(nblk):
+            p = f"{prefix}.res_layers.{si}.blocks.{bi}"
+            _conv_bn(spec, f"{p}.branch2a", ch_in, width, 1)
+            _conv_bn(spec, f"{p}.branch2b", width, width, 3)
+            _conv_bn(spec, f"{p}.branch2c", width, width * 4, 1)
+            if bi == 0:
+                if si == 0:  # stage 2: stride 1 -> plain 1x1 ConvNormLayer shortcut
+                    _conv_bn(spec, f"{p}.short", ch_in, width * 4, 1)
+                else:  # variant "d", stride 2: avgpool + 1x1 ConvNormLayer (resnet.py:89-100)
+                    _conv_bn(spec, f"{p}.short.conv", ch_in, width * 4, 1)
+                ch_in = width * 4
+    return [256, 512, 1024, 2048]
+
+
+def detr_state_spec(config: Dict) -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
+    """Ordered ``name -> (shape, kind)`` for a registry-style DETR config dict."""
+    bb = config["backbone_config"]
+    if bb.get("model_type", "resnet") != "resnet":
+        raise ValueError("engine state spec covers resnet backbones (fai-detr-l-*)")
+    nc = int(config["num_classes"])
+    fd = int(config.get("pixel_decoder_feat_dim", 256))
+    od = int(config.get("pixel_decoder_out_dim", 256))
+    ffe = int(config.get("pixel_decoder_dim_feedforward", 1024))
+    n_enc = int(config.get("pixel_decoder_num_encoder_layers", 1))
+    hd = int(config.get("transformer_predictor_hidden_dim", 256))
+    ffd = int(config.get("transformer_predictor_dim_feedforward", 1024))
+    nl = int(config.get("transformer_predictor_dec_layers", 6))
+    nh = int(config.get("transformer_predictor_nhead", 8))
+    n_levels, n_points = 3, 4
+
+    spec: "OrderedDict[str, Tuple[Tuple[int, ...], str]]" = OrderedDict()
+    chans = resnet_vd_spec(spec, "pixel_decoder.backbone", int(bb.get("depth", 50)), int(bb.get("in_chans", 3)))
+    # Encoder (modelling.py:195-291)
+    for i, c in enumerate(chans[1:]):
+        spec[f"pixel_decoder.input_proj.{i}.0.weight"] = ((fd, c, 1, 1), "conv_w")
+        _bn(spec, f"pixel_decoder.input_proj.{i}.1", fd)
+    for li in range(n_enc):
+        p = f"pixel_decoder.encoder.0.layers.{li}"
+        _mha(spec, f"{p}.self_attn", fd)
+        _linear(spec, f"{p}.linear1", fd, ffe)
+        _linear(spec, f"{p}.linear2", ffe, fd)
+        _ln(spec, f"{p}.norm1", fd)
+        _ln(spec, f"{p}.norm2", fd)
+
+    def csp(prefix):
+        _conv_bn(spec, f"{prefix}.conv1", 2 * fd, fd, 1)
+        _conv_bn(spec, f"{prefix}.conv2", 2 * fd, fd, 1)
+        for b in range(3):
+            _conv_bn(spec, f"{prefix}.bottlenecks.{b}.conv1", fd, fd, 3)
+            _conv_bn(spec, f"{prefix}.bottlenecks.{b}.conv2", fd, fd, 1)
+
+    for i in range(2):
+        _conv_bn(spec, f"pixel_decoder.lateral_convs.{i}", fd, fd, 1)
+    for i in range(2):
+        csp(f"pixel_decoder.fpn_blocks.{i}")
+    for i in range(2):
+        _conv_bn(spec, f"pixel_decoder.downsample_convs.{i}", fd, fd, 3)
+    for i in range(2):
+        csp(f"pixel_decoder.pan_blocks.{i}")
+    spec["pixel_decoder.mask_features.weight"] = ((od, fd, 3, 3), "conv_w")
+    spec["pixel_decoder.mask_features.bias"] = ((od,), "lin_b")
+    # criterion buffer (modelling.py SetCriterion.empty_weight)
+    spec["head.criterion.empty_weight"] = ((nc + 1,), "buf")
+    # TransformerPredictor (modelling.py:1023-1104)
+    for i in range(3):
+        _conv_bn(spec, f"head.predictor.input_proj.{i}", od, hd, 1)
+    for li in range(nl):
+        p = f"head.predictor.decoder.layers.{li}"
+        _mha(spec, f"{p}.self_attn", hd)
+        _ln(spec, f"{p}.norm1", hd)
+        _linear(spec, f"{p}.cross_attn.sampling_offsets", hd, nh * n_levels * n_points * 2)
+        _linear(spec, f"{p}.cross_attn.attention_weights", hd, nh * n_levels * n_points)
+        _linear(spec, f"{p}.cross_attn.value_proj", hd, hd)
+        _linear(spec, f"{p}.cross_attn.output_proj", hd, hd)
+        _ln(spec, f"{p}.norm2", hd)
+        _linear(spec, f"{p}.linear1", hd, ffd)
+        _linear(spec, f"{p}.linear2", ffd, hd)
+        _ln(spec, f"{p}.norm3", hd)
+    _linear(spec, "head.predictor.query_pos_head.layers.0", 4, 2 * hd)
+    _linear(spec, "head.predictor.query_pos_head.layers.1", 2 * hd, hd)
+    _linear(spec, "head.predictor.enc_output.0", hd, hd)
+    _ln(spec, "head.predictor.enc_output.1", hd)
+    _linear(spec, "head.predictor.enc_score_classifier", hd, nc)
+    for j, (a, b) in enumerate([(hd, hd), (hd, hd), (hd, 4)]):
+        _linear(spec, f"head.predictor.enc_bbox_classifier.layers.{j}", a, b)
+    for li in range(nl):
+        _linear(spec, f"head.predictor.dec_score_classifier.{li}", hd, nc)
+    for li in range(nl):
+        for j, (a, b) in enumerate([(hd, hd), (hd, hd), (hd, 4)]):
+            _linear(spec, f"head.predictor.dec_bbox_classifier.{li}.layers.{j}", a, b)
+    return spec

@@ -1,0 +1,154 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REAL reference (FocoosAI/focoos, imported
+from /root/reference through oracle/ref_import.py) on seeded synthetic weights/inputs.
+
+Run in the build container only (the GPU box has no /root/reference):
+    python scripts/make_golden.py
+The fixtures pin ``oracle/detr_oracle.py`` (tests/test_oracle_golden.py) and, through
+it, the HIP engine.  Everything is seeded: weights = focoos_amd.synth.synth_state_dict(cfg, seed),
+images = synth_image / synth_image_structured.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from focoos_amd.registry import ModelRegistry  # noqa: E402
+from focoos_amd.synth import synth_image, synth_image_structured, synth_state_dict  # noqa: E402
+from oracle import ref_import  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def strided_sample(t: torch.Tensor, n: int = 2048) -> np.ndarray:
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].to(torch.float32).numpy().copy()
+
+
+def stats(t: torch.Tensor) -> np.ndarray:
+    t = t.detach().to(torch.float64)
+    return np.array([t.mean().item(), t.abs().mean().item(), t.abs().max().item(), (t * t).mean().sqrt().item()])
+
+
+def run_case(model_name: str, seed: int, images, tag: str, threshold: float = 0.3):
+    info = ModelRegistry.get_model_info(model_name)
+    cfg = info["config"]
+    model, proc, _ = ref_import.build_reference_detr(cfg)
+    sd = synth_state_dict(cfg, seed=seed)
+    res = model.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+
+    cap = {}
+
+    def hook(name):
+        def f(m, i, o):
+            cap[name] = o
+        return f
+
+    model.pixel_decoder.backbone.register_forward_hook(hook("bb"))
+    model.pixel_decoder.register_forward_hook(hook("enc"))
+    model.pixel_decoder.encoder[0].register_forward_hook(hook("aifi"))
+    pred = model.head.predictor
+    orig = pred._get_decoder_input
+
+    def wrap(memory, shapes):
+        cap["memory"] = memory
+        r = orig(memory, shapes)
+        cap["dec_in"] = r
+        return r
+
+    pred._get_decoder_input = wrap
+    for i, layer in enumerate(pred.decoder.layers):
+        layer.register_forward_hook(hook(f"dec{i}"))
+    orig_topk = torch.topk
+    topk_calls = []
+
+    def my_topk(*a, **k):
+        r = orig_topk(*a, **k)
+        topk_calls.append(r)
+        return r
+
+    x, _ = proc.preprocess(images, device=torch.device("cpu"), dtype=torch.float32)
+    torch.topk = my_topk
+    try:
+        with torch.no_grad():
+            out = model(x)
+    finally:
+        torch.topk = orig_topk
+    enc_topk = topk_calls[0][1]  # modelling.py:1214
+
+    dets = proc.postprocess(out, images, threshold=threshold)
+    g = {
+        "seed": np.array(seed), "threshold": np.array(threshold),
+        "image_sizes": np.array([im.shape[:2] for im in images], dtype=np.int32),
+        "pre_sample": strided_sample(x, 4096), "pre_stats": stats(x),
+        "enc_topk": enc_topk.numpy().astype(np.int32),
+        "probs_max": out.logits.max(-1).values.numpy(), "probs_argmax": out.logits.argmax(-1).numpy().astype(np.int32),
+        "boxes": out.boxes.numpy(),
+        "memory_sample": strided_sample(cap["memory"], 8192), "memory_stats": stats(cap["memory"]),
+        "target_sample": strided_sample(cap["dec_in"][0], 4096),
+        "ref_unact": cap["dec_in"][1].numpy(),
+        "aifi_sample": strided_sample(cap["aifi"], 4096), "aifi_stats": stats(cap["aifi"]),
+    }
+    for k in ("res3", "res4", "res5"):
+        g[f"{k}_sample"] = strided_sample(cap["bb"][k], 4096)
+        g[f"{k}_stats"] = stats(cap["bb"][k])
+    for n, e in zip(("enc_s32", "enc_s16", "enc_s8"), cap["enc"][1]):
+        g[f"{n}_sample"] = strided_sample(e, 4096)
+        g[f"{n}_stats"] = stats(e)
+    for i in range(len(pred.decoder.layers)):
+        g[f"dec{i}_sample"] = strided_sample(cap[f"dec{i}"], 2048)
+    # flat top-k of the final scores (what processor.py:147 selects)
+    flat = out.logits.flatten(1)
+    v, idx = orig_topk(flat, 300, dim=-1)
+    g["post_topk_val"] = v.numpy()
+    g["post_topk_idx"] = idx.numpy().astype(np.int32)
+    n = max(len(d.detections) for d in dets)
+    db = np.full((len(dets), n, 4), -1, np.int32)
+    dl = np.full((len(dets), n), -1, np.int32)
+    ds = np.zeros((len(dets), n), np.float32)
+    dn = np.array([len(d.detections) for d in dets], np.int32)
+    for i, d in enumerate(dets):
+        for j, det in enumerate(d.detections):
+            db[i, j] = det.bbox
+            dl[i, j] = det.cls_id
+            ds[i, j] = det.conf
+    g.update(det_boxes=db, det_labels=dl, det_scores=ds, det_count=dn)
+    path = os.path.join(GOLDEN, f"{tag}.npz")
+    np.savez_compressed(path, **g)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB); detections/img: {dn.tolist()}")
+
+
+def deform_core_case():
+    """Golden vectors for the B4 seam (ms_deform_attn_core_pytorch, deformable.py:10-35)."""
+    ref_import.install()
+    from focoos.nn.layers.deformable import ms_deform_attn_core_pytorch
+
+    from tests._cases import MSDA_SHAPES, msda_case_inputs
+
+    shapes = MSDA_SHAPES
+    value, loc, w = (torch.from_numpy(a) for a in msda_case_inputs())
+    out = ms_deform_attn_core_pytorch(value, shapes, loc, w)
+    path = os.path.join(GOLDEN, "msda_core.npz")
+    np.savez_compressed(path, shapes=np.array(shapes, np.int32), out=out.numpy())
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def main():
+    torch.set_num_threads(os.cpu_count() or 1)
+    os.makedirs(GOLDEN, exist_ok=True)
+    run_case("fai-detr-l-obj365", 0, [synth_image(0), synth_image_structured(1)], "detr_l_obj365_b2", threshold=0.5)
+    # non-square inputs that are resized by the processor (base_processor.py:285-288)
+    run_case("fai-detr-l-coco", 1, [synth_image_structured(2, 480, 600)], "detr_l_coco_resize")
+    deform_core_case()
+
+
+if __name__ == "__main__":
+    main()
