@@ -1,0 +1,255 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of the focoos RT-DETR hot path on MI355X (BASELINE.json metric).
+
+A "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
+uint8 HWC images -> fused normalise+stem -> ResNet50-vd -> hybrid encoder -> query selection ->
+6 decoder layers -> sigmoid/xyxy -> device post-process (top-300, labels, int32 boxes, count) ->
+D2H of the packed (<=300x6 per image) results.  Workload at N=1: BASELINE configs[1]
+(fai-detr-l-obj365, bf16 MFMA, bs=32, 640x640, random-init weights, synthetic images).
+N>1: one process per GPU, independent replicas (inference shards by image, no data-path collective:
+SURVEY §8e) -> weak scaling; timing = barrier + synchronize, max over ranks.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel:
+the implicit-GEMM conv template, live HIP-event timing on the engine's stream) and `cpu_baseline`
+(the CPU fp32 oracle = "port" of the reference path, timed on this host's cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16 peak, MI355X_MICROARCH.md (2:1-sparse marketing figure NOT used)
+ALG_GFLOP_PER_IMAGE = 139.05  # RT-DETR-L inference @640^2, algorithmic (dead mask_features conv excluded)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
+    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--model", default="fai-detr-l-obj365")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--dry-run", action="store_true", help="CPU-only plumbing check (gloo): no GPU work, fake step")
+    ap.add_argument("--per-op", default="", help="write per-op timing table to this path")
+    return ap.parse_args()
+
+
+def dist_setup(args):
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        backend = "gloo" if args.dry_run else "nccl"
+        if not args.dry_run:
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return world, rank, local
+
+
+def barrier(world, dry):
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
+        dist.barrier()
+    if not dry:
+        torch.cuda.synchronize()
+
+
+def max_over_ranks(val: float, world: int, dry: bool) -> float:
+    import torch
+    import torch.distributed as dist
+
+    if world == 1:
+        return val
+    t = torch.tensor([val], dtype=torch.float64, device="cpu" if dry else "cuda")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def cpu_baseline(args):
+    """The reference's PyTorch-CPU path as restated by the oracle ("port"), on this host's cores."""
+    import torch
+
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.synth import synth_image, synth_state_dict
+    from oracle import detr_oracle as O
+
+    cfg = ModelRegistry.get_model_info(args.model)["config"]
+    sd = synth_state_dict(cfg, 0)
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    imgs = [synth_image(i, args.size, args.size) for i in range(args.cpu_batch)]
+    times = []
+    with torch.no_grad():
+        for it in range(args.cpu_iters + 1):
+            t0 = time.perf_counter()
+            x = O.get_torch_batch(imgs, (args.size, args.size))
+            p, b = O.detr_forward(sd, cfg, x)
+            O.postprocess(p, b, [(args.size, args.size)] * len(imgs), 300, 0.5)
+            dt = time.perf_counter() - t0
+            if it > 0:
+                times.append(dt)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": round(args.cpu_batch / med, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle/detr_oracle.py (CPU fp32 restatement of the reference path) preprocess+forward+postprocess, bs={args.cpu_batch}, "
+                      f"{args.size}x{args.size}, median of {args.cpu_iters} after 1 warm-up"}
+
+
+def per_op_timing(eng, pl, args):
+    """Live HIP-event timing of every launch of one forward, in sequence (cold-ish caches), on the engine's stream.
+    A spin kernel is queued first so the host enqueues the whole sequence ahead of the GPU (no launch gaps inside the
+    bracketed intervals)."""
+    import ctypes as C
+
+    import torch
+
+    from focoos_amd._lib import check
+
+    st = eng.stream
+    n = len(pl.ops)
+    with torch.cuda.stream(st):
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        acc = [0.0] * n
+        reps = 3
+        for _ in range(reps):
+            torch.cuda._sleep(int(4e7))
+            evs[0].record(st)
+            for i, (fn, a) in enumerate(pl.ops):
+                if fn is pl.lib.fx_detr_postprocess:
+                    a = a[:8] + (C.c_float(0.5),) + a[9:]
+                check(fn(*a, C.c_void_p(st.cuda_stream)), fn.__name__)
+                evs[i + 1].record(st)
+            st.synchronize()
+            for i in range(n):
+                acc[i] += evs[i].elapsed_time(evs[i + 1])
+    return [a / reps for a in acc]
+
+
+def main():
+    args = parse()
+    world, rank, local = dist_setup(args)
+    if args.dry_run:
+        # plumbing only: same sharding / barrier / max-over-ranks / JSON code path with a fake 1 ms step
+        barrier(world, True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            time.sleep(0.001)
+        barrier(world, True)
+        dt = max_over_ranks(time.perf_counter() - t0, world, True)
+        if rank == 0:
+            print(json.dumps({"metric": "dry-run", "value": world * args.batch * args.steps / dt, "unit": "images/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+                              "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none", "config": {"workload": "dry-run"}}))
+        return
+
+    import torch
+
+    from focoos_amd.model import FAIDetr
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.synth import synth_image
+
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    dev = f"cuda:{local}"
+    cfg = ModelRegistry.get_model_info(args.model)["config"]
+    B = args.batch
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+    model = FAIDetr(cfg, device=dev, seed=0)
+    eng = model.engine
+    # image i of rank r = synth_image(r*B + i): seeded uint8 HWC, resident in HBM before the timed region
+    imgs = torch.stack([torch.from_numpy(synth_image(rank * B + i, args.size, args.size)) for i in range(B)]).to(dev)
+    sizes = torch.tensor([[args.size, args.size]] * B, dtype=torch.int32, device=dev)
+    pl = eng.plan(B, args.size, args.size, False)
+    host = {k: torch.empty_like(getattr(pl, k), device="cpu").pin_memory() for k in ("det_scores", "det_labels", "det_boxes", "det_count")}
+    st = eng.stream
+
+    def step():
+        with torch.cuda.stream(st):
+            pl.input.copy_(imgs, non_blocking=True)       # device->device: hand the batch to the engine's input buffer
+            pl.sizes.copy_(sizes, non_blocking=True)
+            pl.run(st.cuda_stream, 0.5, None, True)
+            for k, h in host.items():                      # D2H of the packed results (<= 300 x 6 per image)
+                h.copy_(getattr(pl, k), non_blocking=True)
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+    st.synchronize()
+    barrier(world, False)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    st.synchronize()
+    barrier(world, False)
+    dt = max_over_ranks(time.perf_counter() - t0, world, False)
+    ms_step = 1e3 * dt / args.steps
+    value = world * B * args.steps / dt
+
+    out = {
+        "metric": "images/sec @ 640^2 (infer bs=32)", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"{args.model} inference, bf16 MFMA, bs={B}/GPU, {args.size}x{args.size}, random-init weights (seed 0), "
+                               "uint8 HWC images resident in HBM, device post-process + D2H of packed detections included",
+                   "global_batch": B * world, "parallelism": f"replicas x{world} (no data-path collective)", "steps_are": "hipGraph replays"},
+        "frac_of_bf16_mfma_roofline_whole_path": round(value / world * ALG_GFLOP_PER_IMAGE * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
+    }
+    if rank == 0:
+        # ---- roofline of the dominant kernel (live, in-sequence HIP-event timing; world==1 or rank 0 only)
+        ms = per_op_timing(eng, pl, args)
+        by = {}
+        for i, m in pl.meta.items():
+            d = by.setdefault(m["variant"], {"ms": 0.0, "flops": 0.0, "launches": 0})
+            d["ms"] += ms[i]
+            d["flops"] += m["flops"]
+            d["launches"] += 1
+        total_ms = sum(ms)
+        dom = max(by.items(), key=lambda kv: kv[1]["ms"])
+        name, d = dom
+        achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        out["roofline"] = {
+            "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches_per_step": d["launches"],
+            "avg_launch_ms": round(d["ms"] / d["launches"], 5), "alg_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
+            "share_of_step_time": round(d["ms"] / total_ms, 4),
+            "all_conv_variants": {k: {"ms": round(v["ms"], 4), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "launches": v["launches"]}
+                                  for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])},
+            "sum_of_kernel_ms_per_step": round(total_ms, 4),
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        if args.per_op:
+            names = []
+            for i, (fn, _) in enumerate(pl.ops):
+                m = pl.meta.get(i)
+                names.append((fn.__name__, m["variant"] + ":" + m["name"] + f" M={m['M']} N={m['N']} K={m['K']}" if m else "", ms[i],
+                              (m["flops"] / (ms[i] * 1e-3) / 1e12) if m else 0.0))
+            with open(args.per_op, "w") as f:
+                for nm, desc, t, tf in names:
+                    f.write(f"{t:9.4f} ms  {tf:8.1f} TF/s  {nm}  {desc}\n")
+        print(json.dumps(out))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,95 @@
+"""ctypes binding of libfocoos_amd.so (include/focoos_amd.h).
+
+The HIP library is the product: if it is missing or a call fails we raise — there
+is no PyTorch/CPU fallback anywhere in the package."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+from .build import LIB_PATH
+
+FX_ACT = {None: 0, "none": 0, "relu": 1, "silu": 2, "gelu": 3}
+
+
+class FocoosAmdError(RuntimeError):
+    pass
+
+
+class FxConvDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("w", C.c_void_p), ("bias", C.c_void_p), ("residual", C.c_void_p), ("y", C.c_void_p),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("ldx", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32), ("N", C.c_int32), ("ldy", C.c_int32), ("ldr", C.c_int32),
+        ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("pool2", C.c_int32), ("act", C.c_int32), ("out_f32", C.c_int32), ("residual_after_act", C.c_int32),
+        ("y_batch_stride", C.c_int64),
+    ]
+
+
+_vp, _i, _f = C.c_void_p, C.c_int, C.c_float
+
+# name -> argtypes (every function returns int unless noted); mirrors include/focoos_amd.h
+SIGNATURES = {
+    "fx_abi_version": [],
+    "fx_device_info": [_i, C.POINTER(C.c_int), C.c_char_p, _i],
+    "fx_conv2d_nhwc_bf16": [C.POINTER(FxConvDesc), _vp],
+    "fx_stem_conv3x3s2": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "fx_resize_bilinear_u8": [_vp, _i, _i, _vp, _i, _i, _vp],
+    "fx_maxpool3x3s2_nhwc_bf16": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "fx_resize_bilinear_nhwc_bf16": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "fx_add_rows_bf16": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp],
+    "fx_layernorm_bf16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "fx_mha_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "fx_msda_bf16": [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "fx_rowmax_f32": [_vp, _i, _vp, _i, _i, _vp],
+    "fx_topk_rows_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "fx_gather_rows_bf16": [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp],
+    "fx_fill_rows_bf16": [_vp, _i, _i, _vp, _i, _vp, _i, _i, _vp],
+    "fx_linear_k4_relu": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "fx_bbox_head": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp],
+    "fx_detr_head_out": [_vp, _i, _vp, _vp, _vp, _i, _i, _vp],
+    "fx_detr_postprocess": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
+    "fx_graph_begin": [_vp],
+    "fx_graph_end": [_vp, C.POINTER(C.c_void_p)],
+    "fx_graph_launch": [_vp, _vp],
+    "fx_graph_destroy": [_vp],
+    "fx_graph_time": [_vp, _vp, _i, C.POINTER(C.c_float)],
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib_path() -> str:
+    return os.environ.get("FOCOOS_AMD_LIB", LIB_PATH)
+
+
+def load() -> C.CDLL:
+    """Load the HIP library; raise loudly when it is absent (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if not os.path.exists(path):
+        raise FocoosAmdError(
+            f"{path} not found: the gfx950 HIP kernels are not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `python -m focoos_amd.build`). focoos_amd has no CPU/PyTorch fallback by design."
+        )
+    lib = C.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.fx_error_string.argtypes = [C.c_int]
+    lib.fx_error_string.restype = C.c_char_p
+    if lib.fx_abi_version() != 1:
+        raise FocoosAmdError(f"ABI version mismatch: library {lib.fx_abi_version()} != binding 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().fx_error_string(rc).decode()
+        raise FocoosAmdError(f"libfocoos_amd {what} failed: {msg} (code {rc})")

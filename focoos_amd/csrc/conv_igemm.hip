@@ -1,0 +1,308 @@
+// Implicit-GEMM convolution / linear layer for gfx950 (MI355X): bf16 operands on the MFMA matrix
+// cores (v_mfma_f32_32x32x16_bf16), fp32 accumulate, fused bias + residual + activation epilogue.
+//
+// GEMM view:  D[n][m] = sum_k Wt[n][k] * X[m][k]   with  m = output pixel (b,ho,wo), n = output
+// channel, k = (kh,kw,c).  Both operands are K-contiguous (NHWC activations, [N][KH][KW][C] weights),
+// so every MFMA fragment is one 16-byte ds_read_b128.  The weights are the MFMA "A" operand and the
+// pixels the "B" operand: the accumulator layout then gives each lane 4 CONSECUTIVE output channels of
+// one pixel, which the epilogue stages through LDS and writes back as full 16-byte channel vectors.
+//
+// Staging: global -> registers -> LDS (XOR-swizzled, conflict-free for ds_read_b128), double-buffered,
+// next tile's global loads issued before the MFMA block of the current tile (guide T14), one barrier
+// per K-step.  im2col addressing is done on the fly: a K-step never straddles a filter tap because
+// BK divides C.  Zero padding / M tails are predicated loads.
+#include "common.h"
+
+struct ConvArgs {
+  const bf16_t* x;
+  const bf16_t* w;
+  const float* bias;
+  const bf16_t* res;
+  void* y;
+  int B, H, W, C, ldx;
+  int Ho, Wo, N, ldy, ldr;
+  int KH, KW, stride, pad;
+  int act, out_f32, res_after;
+  int M, Ktot, nNt, Nstore;
+  int64_t y_bstride;  // 0: contiguous
+};
+
+template <int BK>
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  constexpr int CPR = BK / 8;        // 16-byte chunks per row
+  constexpr int R = 256 / (BK * 2);  // rows per 256-byte bank row
+  return row * (BK * 2) + ((chunk ^ ((row / R) & (CPR - 1))) << 4);
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool POOL>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
+  constexpr int CPR = BK / 8, RPP = 256 / CPR;
+  constexpr int A_PASS = BM / RPP, B_PASS = (BN + RPP - 1) / RPP;
+  constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int EPI_LD = BN + 4;
+  static_assert(WM * WN == 4, "4 waves");
+  static_assert(BM % RPP == 0, "A passes");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int bid = fx_xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = bid / p.nNt, nt = bid % p.nNt;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int kc = tid % CPR, r_in = tid / CPR;
+  int a_hi0[A_PASS], a_wi0[A_PASS], a_pix[A_PASS];
+  bool a_ok[A_PASS];
+  const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+  for (int i = 0; i < A_PASS; ++i) {
+    int m = m0 + r_in + i * RPP;
+    a_ok[i] = m < p.M;
+    int mm = a_ok[i] ? m : 0;
+    int b = mm / HoWo, rem = mm - b * HoWo;
+    int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+    a_hi0[i] = ho * p.stride - p.pad;
+    a_wi0[i] = wo * p.stride - p.pad;
+    a_pix[i] = b * p.H * p.W;
+  }
+  const bf16_t* wrow[B_PASS];
+#pragma unroll
+  for (int i = 0; i < B_PASS; ++i) wrow[i] = p.w + (int64_t)(n0 + r_in + i * RPP) * p.Ktot + kc * 8;
+
+  uint4 ra[A_PASS], rb[B_PASS];
+  const uint4 zero4 = make_uint4(0, 0, 0, 0);
+
+  auto load_tiles = [&](int kh, int kw, int c0, int kbase) {
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+      if constexpr (!POOL) {
+        int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;
+        bool ok = a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        const bf16_t* src = p.x + (int64_t)(a_pix[i] + hi * p.W + wi) * p.ldx + c0 + kc * 8;
+        ra[i] = ok ? *reinterpret_cast<const uint4*>(src) : zero4;
+      } else {
+        // 2x2/2 average pool (ceil mode: average over the in-bounds taps) of the source, on the fly
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int cnt = 0;
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+          for (int dx = 0; dx < 2; ++dx) {
+            int hi = a_hi0[i] * 2 + dy, wi = a_wi0[i] * 2 + dx;
+            bool ok = a_ok[i] && hi < p.H && wi < p.W;
+            if (ok) {
+              const bf16_t* src = p.x + (int64_t)(a_pix[i] + hi * p.W + wi) * p.ldx + c0 + kc * 8;
+              uint4 v = *reinterpret_cast<const uint4*>(src);
+              float f[8];
+              unpack_bf16x8(v, f);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) s[j] += f[j];
+              ++cnt;
+            }
+          }
+        float inv = cnt > 0 ? 1.0f / (float)cnt : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] *= inv;
+        ra[i] = pack_bf16x8(s);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASS; ++i) {
+      if (BN % RPP == 0 || r_in + i * RPP < BN) rb[i] = *reinterpret_cast<const uint4*>(wrow[i] + kbase);
+    }
+  };
+  auto store_tiles = [&](int s) {
+    unsigned char* A = smem + s * STAGE;
+    unsigned char* Bm = A + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) *reinterpret_cast<uint4*>(A + lds_off<BK>(r_in + i * RPP, kc)) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_PASS; ++i)
+      if (BN % RPP == 0 || r_in + i * RPP < BN) *reinterpret_cast<uint4*>(Bm + lds_off<BK>(r_in + i * RPP, kc)) = rb[i];
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  const int steps_per_tap = p.C / BK;
+  const int T = p.KH * p.KW * steps_per_tap;
+  int kh = 0, kw = 0, c0 = 0, kbase = 0;
+  load_tiles(kh, kw, c0, kbase);
+  store_tiles(0);
+  __syncthreads();
+
+  const int lrow = lane & 31, lhalf = lane >> 5;
+  for (int t = 0; t < T; ++t) {
+    const int cur = t & 1;
+    const bool more = (t + 1 < T);
+    if (more) {
+      c0 += BK;
+      kbase += BK;
+      if (c0 == p.C) {
+        c0 = 0;
+        if (++kw == p.KW) { kw = 0; ++kh; }
+      }
+      load_tiles(kh, kw, c0, kbase);
+    }
+    const unsigned char* A = smem + cur * STAGE;
+    const unsigned char* Bm = A + A_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < BK / 16; ++kk) {
+      const int chunk = kk * 2 + lhalf;
+      bf16x8 xa[TM], wb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(A + lds_off<BK>(wm * WTM + i * 32 + lrow, chunk));
+#pragma unroll
+      for (int i = 0; i < TN; ++i) wb[i] = *reinterpret_cast<const bf16x8*>(Bm + lds_off<BK>(wn * WTN + i * 32 + lrow, chunk));
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[a], xa[b], acc[a][b], 0, 0, 0);
+    }
+    if (more) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS (fp32) -> coalesced 16-byte channel vectors
+  float* stg = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int a = 0; a < TN; ++a)
+#pragma unroll
+    for (int b = 0; b < TM; ++b)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        int ml = wm * WTM + b * 32 + lrow;
+        int nl = wn * WTN + a * 32 + 8 * g + 4 * lhalf;
+        float4 v = make_float4(acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]);
+        *reinterpret_cast<float4*>(stg + ml * EPI_LD + nl) = v;
+      }
+  __syncthreads();
+  constexpr int TPR = BN / 8, RPP2 = 256 / TPR;
+  const int col8 = (tid % TPR) * 8;
+  const int n = n0 + col8;
+  if (n < p.Nstore) {
+    float bs[8];
+    if (p.bias) {
+      float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+      bs[0] = b0.x; bs[1] = b0.y; bs[2] = b0.z; bs[3] = b0.w; bs[4] = b1.x; bs[5] = b1.y; bs[6] = b1.z; bs[7] = b1.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bs[j] = 0.0f;
+    }
+    for (int r = tid / TPR; r < BM; r += RPP2) {
+      int m = m0 + r;
+      if (m >= p.M) break;
+      float4 v0 = *reinterpret_cast<const float4*>(stg + r * EPI_LD + col8);
+      float4 v1 = *reinterpret_cast<const float4*>(stg + r * EPI_LD + col8 + 4);
+      float v[8] = {v0.x + bs[0], v0.y + bs[1], v0.z + bs[2], v0.w + bs[3], v1.x + bs[4], v1.y + bs[5], v1.z + bs[6], v1.w + bs[7]};
+      float rf[8];
+      if (p.res) {
+        uint4 rv = *reinterpret_cast<const uint4*>(p.res + (int64_t)m * p.ldr + n);
+        unpack_bf16x8(rv, rf);
+        if (!p.res_after) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += rf[j];
+        }
+      }
+      if (p.act != FX_ACT_NONE) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fx_act(v[j], p.act);
+      }
+      if (p.res && p.res_after) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += rf[j];
+      }
+      int64_t yoff;
+      if (p.y_bstride) {
+        int bb = m / HoWo;
+        yoff = (int64_t)bb * p.y_bstride + (int64_t)(m - bb * HoWo) * p.ldy + n;
+      } else {
+        yoff = (int64_t)m * p.ldy + n;
+      }
+      if (p.out_f32) {
+        float* dst = reinterpret_cast<float*>(p.y) + yoff;
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      } else {
+        bf16_t* dst = reinterpret_cast<bf16_t*>(p.y) + yoff;
+        *reinterpret_cast<uint4*>(dst) = pack_bf16x8(v);
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int BK, int WM, int WN, bool POOL>
+static int launch_conv(ConvArgs& a, hipStream_t stream) {
+  constexpr int STAGE = (BM + BN) * BK * 2;
+  constexpr int EPI = BM * (BN + 4) * 4;
+  constexpr int SMEM = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+  static bool attr_set = false;
+  auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, POOL>;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
+      return FX_ERR_RUNTIME;
+    attr_set = true;
+  }
+  a.nNt = (a.N + BN - 1) / BN;
+  int nMt = (a.M + BM - 1) / BM;
+  dim3 grid(nMt * a.nNt), block(256);
+  hipLaunchKernelGGL(kern, grid, block, SMEM, stream, a);
+  return fx_launch_status();
+}
+
+extern "C" int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream_) {
+  FX_CHECK_ARG(d && d->x && d->w && d->y);
+  FX_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->N > 0);
+  FX_CHECK_ARG(d->C > 0 && d->C % 32 == 0 && d->ldx >= d->C && d->ldx % 8 == 0);
+  FX_CHECK_ARG(d->KH >= 1 && d->KW >= 1 && d->stride >= 1 && d->pad >= 0);
+  const int Nstore = (d->N + 7) / 8 * 8;
+  FX_CHECK_ARG(d->ldy >= Nstore && d->ldy % 8 == 0);
+  FX_CHECK_ARG(!d->residual || (d->ldr >= Nstore && d->ldr % 8 == 0));
+  FX_CHECK_ARG(((uintptr_t)d->x % 16) == 0 && ((uintptr_t)d->w % 16) == 0 && ((uintptr_t)d->y % 16) == 0);
+  FX_CHECK_ARG(!d->residual || ((uintptr_t)d->residual % 16) == 0);
+  FX_CHECK_ARG(!d->bias || ((uintptr_t)d->bias % 16) == 0);
+  if (d->pool2) {
+    FX_CHECK_ARG(d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0);
+    FX_CHECK_ARG(d->Ho == (d->H + 1) / 2 && d->Wo == (d->W + 1) / 2);
+  } else {
+    FX_CHECK_ARG(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1);
+    FX_CHECK_ARG(d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1);
+  }
+  if ((int64_t)d->B * d->H * d->W >= (1ll << 31) || (int64_t)d->B * d->Ho * d->Wo >= (1ll << 31)) return FX_ERR_UNSUPPORTED;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  ConvArgs a;
+  a.x = reinterpret_cast<const bf16_t*>(d->x);
+  a.w = reinterpret_cast<const bf16_t*>(d->w);
+  a.bias = d->bias;
+  a.res = reinterpret_cast<const bf16_t*>(d->residual);
+  a.y = d->y;
+  a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C; a.ldx = d->ldx;
+  a.Ho = d->Ho; a.Wo = d->Wo; a.N = d->N; a.ldy = d->ldy; a.ldr = d->ldr;
+  a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+  a.act = d->act; a.out_f32 = d->out_f32; a.res_after = d->residual_after_act;
+  a.y_bstride = d->y_batch_stride;
+  FX_CHECK_ARG(d->y_batch_stride >= 0 && d->y_batch_stride % 8 == 0);
+  a.M = d->B * d->Ho * d->Wo;
+  a.Ktot = d->KH * d->KW * d->C;
+  a.Nstore = Nstore;
+  a.nNt = 0;
+  const bool k64 = (d->C % 64 == 0);
+  if (d->pool2) {
+    if (!k64) return FX_ERR_UNSUPPORTED;
+    return launch_conv<128, 128, 64, 2, 2, true>(a, stream);
+  }
+  if (k64) {
+    if (d->N > 64) return launch_conv<128, 128, 64, 2, 2, false>(a, stream);
+    if (d->N > 32) return launch_conv<128, 64, 64, 2, 2, false>(a, stream);
+    return launch_conv<128, 32, 64, 4, 1, false>(a, stream);
+  }
+  if (d->N > 64) return launch_conv<128, 128, 32, 2, 2, false>(a, stream);
+  if (d->N > 32) return launch_conv<128, 64, 32, 2, 2, false>(a, stream);
+  return launch_conv<128, 32, 32, 4, 1, false>(a, stream);
+}

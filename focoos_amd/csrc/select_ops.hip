@@ -1,0 +1,356 @@
+// Selection / head kernels of the RT-DETR path (gfx950): row max, exact top-k (radix select + bitonic
+// sort in LDS), row gathers, the tiny K=4 / N=4 linear layers fused with the box update, the output
+// head and the device-side DETRProcessor.postprocess.  Index results are int32 and must be bit-exact
+// with the reference's int64 indices: top-k order is (value descending, index ascending).
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ x, int ldx, float* __restrict__ out, int rows, int cols) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (int64_t)row * ldx;
+  float m = -INFINITY;
+  for (int c = lane; c < cols; c += 64) m = fmaxf(m, xr[c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if (lane == 0) out[row] = m;
+}
+
+extern "C" int fx_rowmax_f32(const float* x, int ldx, float* out, int rows, int cols, fx_stream_t stream_) {
+  FX_CHECK_ARG(x && out && rows > 0 && cols > 0 && ldx >= cols);
+  hipLaunchKernelGGL(rowmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), x, ldx, out, rows, cols);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact top-k per row.  One 1024-thread workgroup per row:
+//  1. 4-pass MSB-first radix select (8-bit digits, LDS histogram) finds the key T of the k-th largest
+//     element and how many elements equal to T are needed;
+//  2. every element with key > T plus the needed number of key == T elements (lowest indices first,
+//     ordered block scan only when there are surplus ties) are collected into LDS;
+//  3. a bitonic sort of <= 1024 (key, ~index) pairs orders them (value desc, index asc).
+// Keys are the order-preserving unsigned image of the float bits.
+#define TOPK_THREADS 1024
+#define TOPK_MAXK 1024
+
+__device__ __forceinline__ uint32_t f32_key(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(uint32_t k) {
+  uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+__global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restrict__ scores, int ld, int n, int k, float* __restrict__ out_val,
+                                                             int32_t* __restrict__ out_idx) {
+  __shared__ uint32_t hist[256];
+  __shared__ unsigned long long sel[TOPK_MAXK];
+  __shared__ uint32_t s_prefix, s_remaining, s_count, s_base, s_wave_tot[16];
+  const int tid = threadIdx.x;
+  const float* row = scores + (int64_t)blockIdx.x * ld;
+
+  uint32_t prefix = 0, mask = 0;
+  if (tid == 0) s_remaining = (uint32_t)k;
+  for (int pass = 0; pass < 4; ++pass) {
+    const int shift = 24 - 8 * pass;
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += TOPK_THREADS) {
+      uint32_t key = f32_key(row[i]);
+      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      uint32_t rem = s_remaining, c = 0;
+      int bin = 0;
+      for (int bb = 255; bb >= 0; --bb) {
+        uint32_t hcount = hist[bb];
+        if (c + hcount >= rem) {
+          bin = bb;
+          rem -= c;
+          break;
+        }
+        c += hcount;
+      }
+      s_remaining = rem;  // still needed among keys whose digits so far equal prefix|bin
+      s_prefix = prefix | ((uint32_t)bin << shift);
+      s_count = hist[bin];  // after the last pass: number of elements with key == T
+    }
+    __syncthreads();
+    prefix = s_prefix;
+    mask |= 0xffu << shift;
+  }
+  const uint32_t T = prefix;
+  const uint32_t need_eq = s_remaining;  // 1..count_eq
+  const uint32_t count_eq = s_count;
+  __syncthreads();
+  if (tid == 0) {
+    s_count = 0;
+    s_base = 0;
+  }
+  for (int i = tid; i < TOPK_MAXK; i += TOPK_THREADS) sel[i] = 0ull;
+  __syncthreads();
+  // strictly greater: all selected (there are exactly k - need_eq of them)
+  const bool all_eq = (count_eq == need_eq);
+  for (int i = tid; i < n; i += TOPK_THREADS) {
+    uint32_t key = f32_key(row[i]);
+    if (key > T || (all_eq && key == T)) {
+      uint32_t pos = atomicAdd(&s_count, 1u);
+      if (pos < TOPK_MAXK) sel[pos] = ((unsigned long long)key << 32) | (uint32_t)(0xffffffffu - (uint32_t)i);
+    }
+  }
+  __syncthreads();
+  if (!all_eq) {
+    // surplus ties: take the need_eq lowest indices among key == T (ordered block scan)
+    const int lane = tid & 63, wv = tid >> 6;
+    for (int start = 0; start < n; start += TOPK_THREADS) {
+      int i = start + tid;
+      bool flag = (i < n) && (f32_key(row[i]) == T);
+      unsigned long long bal = __ballot(flag);
+      uint32_t wexcl = __popcll(bal & ((1ull << lane) - 1ull));
+      if (lane == 0) s_wave_tot[wv] = __popcll(bal);
+      __syncthreads();
+      uint32_t woff = 0, tot = 0;
+      for (int w = 0; w < 16; ++w) {
+        uint32_t tw = s_wave_tot[w];
+        if (w < wv) woff += tw;
+        tot += tw;
+      }
+      uint32_t rank = s_base + woff + wexcl;
+      if (flag && rank < need_eq) {
+        uint32_t pos = (uint32_t)(k - (int)need_eq) + rank;
+        if (pos < TOPK_MAXK) sel[pos] = ((unsigned long long)T << 32) | (uint32_t)(0xffffffffu - (uint32_t)i);
+      }
+      __syncthreads();
+      if (tid == 0) s_base += tot;
+      __syncthreads();
+      if (s_base >= need_eq) break;
+    }
+    __syncthreads();
+  }
+  // bitonic sort, descending, of the smallest power of two >= k entries (zeros pad at the end)
+  int ns = 1;
+  while (ns < k) ns <<= 1;
+  for (int size = 2; size <= ns; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < ns / 2; t += TOPK_THREADS) {
+        int lo = (t / stride) * (stride * 2) + (t % stride);
+        int hi = lo + stride;
+        bool desc = ((lo & size) == 0);
+        unsigned long long a = sel[lo], bq = sel[hi];
+        bool swap = desc ? (a < bq) : (a > bq);
+        if (swap) {
+          sel[lo] = bq;
+          sel[hi] = a;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < k; i += TOPK_THREADS) {
+    unsigned long long e = sel[i];
+    out_val[(int64_t)blockIdx.x * k + i] = key_f32((uint32_t)(e >> 32));
+    out_idx[(int64_t)blockIdx.x * k + i] = (int32_t)(0xffffffffu - (uint32_t)(e & 0xffffffffull));
+  }
+}
+
+extern "C" int fx_topk_rows_f32(const float* scores, int ld, int B, int n, int k, float* out_val, int32_t* out_idx, fx_stream_t stream_) {
+  FX_CHECK_ARG(scores && out_val && out_idx && B > 0 && n > 0 && k > 0 && k <= n && ld >= n);
+  if (k > TOPK_MAXK) return FX_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(TOPK_THREADS), 0, reinterpret_cast<hipStream_t>(stream_), scores, ld, n, k, out_val, out_idx);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ src, int lds, int rpb, const int32_t* __restrict__ idx,
+                                                           int k, bf16_t* __restrict__ out, int ldo, int B, int C8) {
+  int64_t total = (int64_t)B * k * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int c8 = (int)(i % C8);
+    int64_t r = i / C8;
+    int b = (int)(r / k);
+    int s = idx[r];
+    *reinterpret_cast<uint4*>(out + r * ldo + c8 * 8) = *reinterpret_cast<const uint4*>(src + ((int64_t)b * rpb + s) * lds + c8 * 8);
+  }
+}
+
+extern "C" int fx_gather_rows_bf16(const void* src, int lds, int rows_per_batch, const int32_t* idx, int k, void* out, int ldo, int B, int cols,
+                                   fx_stream_t stream_) {
+  FX_CHECK_ARG(src && idx && out && B > 0 && k > 0 && cols > 0 && cols % 8 == 0 && lds >= cols && ldo >= cols && lds % 8 == 0 && ldo % 8 == 0);
+  int64_t total = (int64_t)B * k * (cols / 8);
+  int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)src, lds,
+                     rows_per_batch, idx, k, (bf16_t*)out, ldo, B, cols / 8);
+  return fx_launch_status();
+}
+
+__global__ __launch_bounds__(256) void fill_rows_kernel(bf16_t* __restrict__ x, int ldx, int rpb, const int32_t* __restrict__ rows_idx, int n_idx,
+                                                         const bf16_t* __restrict__ rowv, int B, int C8) {
+  int64_t total = (int64_t)B * n_idx * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int c8 = (int)(i % C8);
+    int64_t r = i / C8;
+    int b = (int)(r / n_idx), j = (int)(r % n_idx);
+    *reinterpret_cast<uint4*>(x + ((int64_t)b * rpb + rows_idx[j]) * ldx + c8 * 8) = *reinterpret_cast<const uint4*>(rowv + c8 * 8);
+  }
+}
+
+extern "C" int fx_fill_rows_bf16(void* x, int ldx, int rows_per_batch, const int32_t* rows_idx, int n_idx, const void* row_bf16, int B, int cols,
+                                 fx_stream_t stream_) {
+  FX_CHECK_ARG(x && row_bf16 && B > 0 && cols > 0 && cols % 8 == 0 && ldx >= cols && ldx % 8 == 0 && n_idx >= 0);
+  if (n_idx == 0) return FX_OK;
+  FX_CHECK_ARG(rows_idx != nullptr);
+  int64_t total = (int64_t)B * n_idx * (cols / 8);
+  int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(fill_rows_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (bf16_t*)x, ldx, rows_per_batch,
+                     rows_idx, n_idx, (const bf16_t*)row_bf16, B, cols / 8);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// relu(ref[r,0:4] @ W^T + b): K = 4 is too thin for MFMA; 8 outputs per lane, fully coalesced stores.
+__global__ __launch_bounds__(256) void linear_k4_relu_kernel(const float* __restrict__ ref, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, bf16_t* __restrict__ out, int ldo, int rows, int N8) {
+  int64_t total = (int64_t)rows * N8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int n8 = (int)(i % N8);
+    int r = (int)(i / N8);
+    float4 x = *reinterpret_cast<const float4*>(ref + (int64_t)r * 4);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float4 wv = *reinterpret_cast<const float4*>(w + (int64_t)(n8 * 8 + j) * 4);
+      o[j] = fmaxf(bias[n8 * 8 + j] + x.x * wv.x + x.y * wv.y + x.z * wv.z + x.w * wv.w, 0.0f);
+    }
+    *reinterpret_cast<uint4*>(out + (int64_t)r * ldo + n8 * 8) = pack_bf16x8(o);
+  }
+}
+
+extern "C" int fx_linear_k4_relu(const float* ref, const float* w, const float* b, void* out, int ldo, int rows, int N, fx_stream_t stream_) {
+  FX_CHECK_ARG(ref && w && b && out && rows > 0 && N > 0 && N % 8 == 0 && ldo >= N && ldo % 8 == 0);
+  int64_t total = (int64_t)rows * (N / 8);
+  int grid = (int)((total + 255) / 256);
+  hipLaunchKernelGGL(linear_k4_relu_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), ref, w, b, (bf16_t*)out, ldo,
+                     rows, N / 8);
+  return fx_launch_status();
+}
+
+// N = 4 projection (one wave per row) fused with the reference-box update.
+__device__ __forceinline__ float inv_sigmoid(float x) {
+  x = fminf(fmaxf(x, 0.0f), 1.0f);
+  return __logf(fmaxf(x, 1e-5f) / fmaxf(1.0f - x, 1e-5f));
+}
+
+__global__ __launch_bounds__(256) void bbox_head_kernel(const bf16_t* __restrict__ h, int ldh, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, const float* __restrict__ ref,
+                                                         const float* __restrict__ anchors, const int32_t* __restrict__ idx, int rpb, int mode,
+                                                         float* __restrict__ new_ref, float* __restrict__ unact_out, int rows, int K) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int c = lane * 4; c < K; c += 256) {
+    uint2 hv = *reinterpret_cast<const uint2*>(h + (int64_t)row * ldh + c);
+    float x[4] = {__uint_as_float(hv.x << 16), __uint_as_float(hv.x & 0xffff0000u), __uint_as_float(hv.y << 16),
+                  __uint_as_float(hv.y & 0xffff0000u)};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float4 wv = *reinterpret_cast<const float4*>(w + (int64_t)j * K + c);
+      acc[j] += x[0] * wv.x + x[1] * wv.y + x[2] * wv.z + x[3] * wv.w;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc[j] += __shfl_xor(acc[j], o, 64);
+  if (lane < 4) {
+    float v = (lane == 0 ? acc[0] : lane == 1 ? acc[1] : lane == 2 ? acc[2] : acc[3]) + bias[lane];
+    float u;
+    if (mode == 0) {
+      u = v + inv_sigmoid(ref[(int64_t)row * 4 + lane]);
+    } else {
+      (void)rpb;
+      u = v + anchors[(int64_t)idx[row] * 4 + lane];
+    }
+    if (unact_out) unact_out[(int64_t)row * 4 + lane] = u;
+    new_ref[(int64_t)row * 4 + lane] = 1.0f / (1.0f + __expf(-u));
+  }
+}
+
+extern "C" int fx_bbox_head(const void* h, int ldh, const float* w, const float* b, const float* ref, const float* anchors, const int32_t* idx,
+                            int rows_per_batch, int mode, float* new_ref, float* unact_out, int rows, int K, fx_stream_t stream_) {
+  FX_CHECK_ARG(h && w && b && new_ref && rows > 0 && K > 0 && K % 4 == 0 && ldh >= K && ldh % 4 == 0);
+  FX_CHECK_ARG((mode == 0 && ref) || (mode == 1 && anchors && idx));
+  hipLaunchKernelGGL(bbox_head_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)h, ldh, w, b,
+                     ref, anchors, idx, rows_per_batch, mode, new_ref, unact_out, rows, K);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void detr_head_out_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ ref,
+                                                             float* __restrict__ probs, float* __restrict__ boxes, int rows, int K) {
+  int64_t total = (int64_t)rows * K;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int c = (int)(i % K);
+    int64_t r = i / K;
+    float x = logits[r * ldl + c];
+    probs[i] = 1.0f / (1.0f + expf(-x));
+    if (c < 4) {
+      float cx = ref[r * 4 + 0], cy = ref[r * 4 + 1], w = ref[r * 4 + 2], hh = ref[r * 4 + 3];
+      float v = c == 0 ? cx - 0.5f * w : c == 1 ? cy - 0.5f * hh : c == 2 ? cx + 0.5f * w : cy + 0.5f * hh;
+      boxes[r * 4 + c] = v;
+    }
+  }
+}
+
+extern "C" int fx_detr_head_out(const float* logits, int ldl, const float* ref_cxcywh, float* probs, float* boxes_xyxy, int rows, int K,
+                                fx_stream_t stream_) {
+  FX_CHECK_ARG(logits && ref_cxcywh && probs && boxes_xyxy && rows > 0 && K >= 4 && ldl >= K);
+  int64_t total = (int64_t)rows * K;
+  int64_t grid = (total + 255) / 256;
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(detr_head_out_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), logits, ldl, ref_cxcywh,
+                     probs, boxes_xyxy, rows, K);
+  return fx_launch_status();
+}
+
+// DETRProcessor.postprocess tail: label/query split, box scale + round-half-even (torch.round) -> int32,
+// count of scores above the threshold (scores are sorted, so the kept ones form a prefix).
+__global__ __launch_bounds__(256) void detr_postprocess_kernel(const float* __restrict__ tv, const int32_t* __restrict__ ti,
+                                                                const float* __restrict__ boxes, const int32_t* __restrict__ sizes, int Q, int K,
+                                                                int top_k, float thr, int32_t* __restrict__ labels, int32_t* __restrict__ queries,
+                                                                int32_t* __restrict__ obox, int32_t* __restrict__ count) {
+  const int b = blockIdx.x;
+  __shared__ int s_cnt;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  const float Hs = (float)sizes[2 * b], Ws = (float)sizes[2 * b + 1];
+  int local = 0;
+  for (int i = threadIdx.x; i < top_k; i += 256) {
+    int64_t o = (int64_t)b * top_k + i;
+    int id = ti[o];
+    int lab = id % K, qi = id / K;
+    labels[o] = lab;
+    queries[o] = qi;
+    const float* bx = boxes + ((int64_t)b * Q + qi) * 4;
+    obox[o * 4 + 0] = (int32_t)rintf(bx[0] * Ws);
+    obox[o * 4 + 1] = (int32_t)rintf(bx[1] * Hs);
+    obox[o * 4 + 2] = (int32_t)rintf(bx[2] * Ws);
+    obox[o * 4 + 3] = (int32_t)rintf(bx[3] * Hs);
+    if (tv[o] > thr) ++local;
+  }
+  atomicAdd(&s_cnt, local);
+  __syncthreads();
+  if (threadIdx.x == 0) count[b] = s_cnt;
+}
+
+extern "C" int fx_detr_postprocess(const float* topk_val, const int32_t* topk_idx, const float* boxes_xyxy, const int32_t* sizes, int B, int Q, int K,
+                                   int top_k, float threshold, int32_t* labels, int32_t* queries, int32_t* boxes_i32, int32_t* count,
+                                   fx_stream_t stream_) {
+  FX_CHECK_ARG(topk_val && topk_idx && boxes_xyxy && sizes && labels && queries && boxes_i32 && count && B > 0 && Q > 0 && K > 0 && top_k > 0);
+  hipLaunchKernelGGL(detr_postprocess_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), topk_val, topk_idx, boxes_xyxy, sizes,
+                     Q, K, top_k, threshold, labels, queries, boxes_i32, count);
+  return fx_launch_status();
+}

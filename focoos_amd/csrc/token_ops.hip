@@ -1,0 +1,246 @@
+// Token-space kernels of the RT-DETR encoder/decoder (gfx950): row add, LayerNorm(+residual),
+// softmax attention (head_dim 32), multi-scale deformable-attention sampling.
+// All are HBM/L2-bound wavefront kernels; rows are 256 channels = one 512-byte line per wave.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void add_rows_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ y, int ldy,
+                                                        int y_rows, bf16_t* __restrict__ out, int ldo, int rows, int C8) {
+  int64_t total = (int64_t)rows * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int c8 = (int)(i % C8);
+    int r = (int)(i / C8);
+    float a[8], b[8];
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(x + (int64_t)r * ldx + c8 * 8), a);
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(y + (int64_t)(r % y_rows) * ldy + c8 * 8), b);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += b[j];
+    *reinterpret_cast<uint4*>(out + (int64_t)r * ldo + c8 * 8) = pack_bf16x8(a);
+  }
+}
+
+extern "C" int fx_add_rows_bf16(const void* x, int ldx, const void* y, int ldy_, int y_rows, void* out, int ldo, int rows, int cols,
+                                fx_stream_t stream_) {
+  FX_CHECK_ARG(x && y && out && rows > 0 && cols > 0 && cols % 8 == 0 && y_rows > 0);
+  FX_CHECK_ARG(ldx >= cols && ldy_ >= cols && ldo >= cols && ldx % 8 == 0 && ldy_ % 8 == 0 && ldo % 8 == 0);
+  int64_t total = (int64_t)rows * (cols / 8);
+  int64_t grid = (total + 255) / 256;
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(add_rows_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)x, ldx,
+                     (const bf16_t*)y, ldy_, y_rows, (bf16_t*)out, ldo, rows, cols / 8);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over 256 channels, one wave per row (4 channels per lane), fp32 statistics
+// (two-pass mean / variance in registers, biased variance, eps inside the sqrt like nn.LayerNorm).
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__global__ __launch_bounds__(256) void layernorm256_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ res, int ldr,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            bf16_t* __restrict__ out, int ldo, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  uint2 xv = *reinterpret_cast<const uint2*>(x + (int64_t)row * ldx + lane * 4);
+  float v[4] = {__uint_as_float(xv.x << 16), __uint_as_float(xv.x & 0xffff0000u), __uint_as_float(xv.y << 16),
+                __uint_as_float(xv.y & 0xffff0000u)};
+  if (res) {
+    uint2 rv = *reinterpret_cast<const uint2*>(res + (int64_t)row * ldr + lane * 4);
+    v[0] += __uint_as_float(rv.x << 16);
+    v[1] += __uint_as_float(rv.x & 0xffff0000u);
+    v[2] += __uint_as_float(rv.y << 16);
+    v[3] += __uint_as_float(rv.y & 0xffff0000u);
+  }
+  float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+  float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+  float var = wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+  float rstd = rsqrtf(var + 1e-5f);
+  float4 g = *reinterpret_cast<const float4*>(gamma + lane * 4), bt = *reinterpret_cast<const float4*>(beta + lane * 4);
+  uint2 o;
+  o.x = pack_bf16x2(d0 * rstd * g.x + bt.x, d1 * rstd * g.y + bt.y);
+  o.y = pack_bf16x2(d2 * rstd * g.z + bt.z, d3 * rstd * g.w + bt.w);
+  *reinterpret_cast<uint2*>(out + (int64_t)row * ldo + lane * 4) = o;
+}
+
+extern "C" int fx_layernorm_bf16(const void* x, int ldx, const void* residual, int ldr, const float* gamma, const float* beta, void* out,
+                                 int ldo, int rows, int cols, fx_stream_t stream_) {
+  FX_CHECK_ARG(x && gamma && beta && out && rows > 0);
+  if (cols != 256) return FX_ERR_UNSUPPORTED;
+  FX_CHECK_ARG(ldx >= cols && ldo >= cols && ldx % 4 == 0 && ldo % 4 == 0 && (!residual || (ldr >= cols && ldr % 4 == 0)));
+  hipLaunchKernelGGL(layernorm256_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)x,
+                     ldx, (const bf16_t*)residual, ldr, gamma, beta, (bf16_t*)out, ldo, rows);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Softmax attention, head_dim 32.  One lane = one query row (q and the output accumulator live in
+// registers, fp32); the head's K and V ([Lk,32] bf16 each) are staged once per block in LDS and read
+// as broadcast 16-byte vectors (every lane reads the same key -> conflict-free).  Online softmax
+// (running max / sum), exp2 domain.  grid = (ceil(Lq/128), B*heads), 128 threads.
+template <int MAXLK>
+__global__ __launch_bounds__(128) void mha32_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+                                                     const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ out, int ldo, int Lq, int Lk,
+                                                     int heads) {
+  __shared__ __attribute__((aligned(16))) bf16_t ks[MAXLK * 32];
+  __shared__ __attribute__((aligned(16))) bf16_t vs[MAXLK * 32];
+  const int bh = blockIdx.y, b = bh / heads, h = bh % heads;
+  const bf16_t* kb = k + (int64_t)b * Lk * ldk + h * 32;
+  const bf16_t* vb = v + (int64_t)b * Lk * ldv + h * 32;
+  for (int i = threadIdx.x; i < Lk * 4; i += 128) {
+    int j = i >> 2, c = i & 3;
+    reinterpret_cast<uint4*>(ks)[i] = *reinterpret_cast<const uint4*>(kb + (int64_t)j * ldk + c * 8);
+    reinterpret_cast<uint4*>(vs)[i] = *reinterpret_cast<const uint4*>(vb + (int64_t)j * ldv + c * 8);
+  }
+  __syncthreads();
+  const int qi = blockIdx.x * 128 + threadIdx.x;
+  if (qi >= Lq) return;
+  const float scale = 0.17677669529663687f * 1.4426950408889634f;  // 1/sqrt(32) * log2(e)
+  float qf[32], o[32];
+  const bf16_t* qp = q + ((int64_t)b * Lq + qi) * ldq + h * 32;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(qp + c * 8), qf + c * 8);
+  }
+#pragma unroll
+  for (int d = 0; d < 32; ++d) {
+    qf[d] *= scale;
+    o[d] = 0.0f;
+  }
+  float m = -INFINITY, l = 0.0f;
+  for (int j = 0; j < Lk; ++j) {
+    float kf[32];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) unpack_bf16x8(reinterpret_cast<const uint4*>(ks)[j * 4 + c], kf + c * 8);
+    float s = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 32; ++d) s += qf[d] * kf[d];
+    float mn = fmaxf(m, s);
+    float alpha = exp2f(m - mn), pj = exp2f(s - mn);
+    l = l * alpha + pj;
+    m = mn;
+    float vf[32];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) unpack_bf16x8(reinterpret_cast<const uint4*>(vs)[j * 4 + c], vf + c * 8);
+#pragma unroll
+    for (int d = 0; d < 32; ++d) o[d] = o[d] * alpha + pj * vf[d];
+  }
+  float inv = 1.0f / l;
+#pragma unroll
+  for (int d = 0; d < 32; ++d) o[d] *= inv;
+  bf16_t* op = out + ((int64_t)b * Lq + qi) * ldo + h * 32;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) *reinterpret_cast<uint4*>(op + c * 8) = pack_bf16x8(o + c * 8);
+}
+
+extern "C" int fx_mha_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B, int Lq, int Lk,
+                           int heads, fx_stream_t stream_) {
+  FX_CHECK_ARG(q && k && v && out && B > 0 && Lq > 0 && Lk > 0 && heads > 0);
+  FX_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && ldq >= heads * 32 && ldo >= heads * 32);
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  dim3 grid((Lq + 127) / 128, B * heads), block(128);
+  if (Lk <= 448)
+    hipLaunchKernelGGL(mha32_kernel<448>, grid, block, 0, stream, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv,
+                       (bf16_t*)out, ldo, Lq, Lk, heads);
+  else
+    return FX_ERR_UNSUPPORTED;
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Multi-scale deformable attention sampling (M*D = 256): one wave per (batch, query); lane = (head =
+// lane>>3, 4 channels = (lane&7)*4).  Each tap is an 8-byte load; the 8 lanes of a head read one
+// contiguous 64-byte head slice of a value token, the wave touches 8 such slices per tap.  The value
+// map of one image (8400 x 256 bf16 = 4.3 MB) stays L2/MALL resident across its 300 queries.
+// Bilinear taps follow F.grid_sample(align_corners=False, padding_mode="zeros"):
+//   ix = ((2*loc_x - 1 + 1) * W - 1) / 2, taps outside the map contribute 0.
+template <int MODE>
+__global__ __launch_bounds__(256) void msda_kernel(const bf16_t* __restrict__ value, int ldv, const int32_t* __restrict__ shapes,
+                                                    const int32_t* __restrict__ lstart, int L, int P, const float* __restrict__ loc,
+                                                    int ld_loc, const float* __restrict__ attn, int ld_attn, const float* __restrict__ ref,
+                                                    bf16_t* __restrict__ out, int ldo, int B, int S, int Q, int M) {
+  const int lane = threadIdx.x & 63;
+  const int bq = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bq >= B * Q) return;
+  const int b = bq / Q;
+  const int h = lane >> 3, cg = lane & 7;
+  const int LP = L * P;
+  const bf16_t* vb = value + (int64_t)b * S * ldv + h * 32 + cg * 4;
+  const float* locp = loc + (int64_t)bq * ld_loc + h * LP * 2;
+  const float* attp = attn + (int64_t)bq * ld_attn + h * LP;
+  float rcx = 0.f, rcy = 0.f, rw = 0.f, rh = 0.f, amax = 0.f, ainv = 1.f;
+  if (MODE == 1) {
+    const float* rp = ref + (int64_t)bq * 4;
+    rcx = rp[0]; rcy = rp[1]; rw = rp[2]; rh = rp[3];
+    amax = -INFINITY;
+    for (int i = 0; i < LP; ++i) amax = fmaxf(amax, attp[i]);
+    float s = 0.f;
+    for (int i = 0; i < LP; ++i) s += __expf(attp[i] - amax);
+    ainv = 1.0f / s;
+  }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int l = 0; l < L; ++l) {
+    const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
+    const bf16_t* vl = vb + (int64_t)lstart[l] * ldv;
+    for (int pt = 0; pt < P; ++pt) {
+      const int i = l * P + pt;
+      float lx = locp[2 * i], ly = locp[2 * i + 1], aw = attp[i];
+      if (MODE == 1) {
+        lx = rcx + lx / (float)P * rw * 0.5f;
+        ly = rcy + ly / (float)P * rh * 0.5f;
+        aw = __expf(aw - amax) * ainv;
+      }
+      float gx = 2.0f * lx - 1.0f, gy = 2.0f * ly - 1.0f;
+      float ix = ((gx + 1.0f) * (float)Wl - 1.0f) * 0.5f, iy = ((gy + 1.0f) * (float)Hl - 1.0f) * 0.5f;
+      float fx0 = floorf(ix), fy0 = floorf(iy);
+      int x0 = (int)fx0, y0 = (int)fy0;
+      float tx = ix - fx0, ty = iy - fy0;
+      float w00 = (1.f - tx) * (1.f - ty), w01 = tx * (1.f - ty), w10 = (1.f - tx) * ty, w11 = tx * ty;
+      bool xin0 = (unsigned)x0 < (unsigned)Wl, xin1 = (unsigned)(x0 + 1) < (unsigned)Wl;
+      bool yin0 = (unsigned)y0 < (unsigned)Hl, yin1 = (unsigned)(y0 + 1) < (unsigned)Hl;
+      float s[4] = {0.f, 0.f, 0.f, 0.f};
+      auto tap = [&](bool ok, int yy, int xx, float w) {
+        if (ok) {
+          uint2 t = *reinterpret_cast<const uint2*>(vl + (int64_t)(yy * Wl + xx) * ldv);
+          s[0] += w * __uint_as_float(t.x << 16);
+          s[1] += w * __uint_as_float(t.x & 0xffff0000u);
+          s[2] += w * __uint_as_float(t.y << 16);
+          s[3] += w * __uint_as_float(t.y & 0xffff0000u);
+        }
+      };
+      tap(yin0 && xin0, y0, x0, w00);
+      tap(yin0 && xin1, y0, x0 + 1, w01);
+      tap(yin1 && xin0, y0 + 1, x0, w10);
+      tap(yin1 && xin1, y0 + 1, x0 + 1, w11);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[j] += aw * s[j];
+    }
+  }
+  uint2 o;
+  o.x = pack_bf16x2(acc[0], acc[1]);
+  o.y = pack_bf16x2(acc[2], acc[3]);
+  *reinterpret_cast<uint2*>(out + (int64_t)bq * ldo + h * 32 + cg * 4) = o;
+}
+
+extern "C" int fx_msda_bf16(const void* value, int ldv, const int32_t* spatial_shapes, const int32_t* level_start, int L, int P,
+                            const float* loc, int ld_loc, const float* attn, int ld_attn, const float* ref, int mode, void* out, int ldo,
+                            int B, int S, int Q, int M, fx_stream_t stream_) {
+  FX_CHECK_ARG(value && spatial_shapes && level_start && loc && attn && out && B > 0 && S > 0 && Q > 0 && L > 0 && P > 0);
+  if (M != 8) return FX_ERR_UNSUPPORTED;  // M*D = 256 = 64 lanes x 4 channels
+  FX_CHECK_ARG(ldv >= 256 && ldo >= 256 && ldv % 4 == 0 && ldo % 4 == 0);
+  FX_CHECK_ARG(mode == 0 || (mode == 1 && ref));
+  FX_CHECK_ARG(ld_loc >= M * L * P * 2 && ld_attn >= M * L * P);
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  dim3 grid((B * Q + 3) / 4), block(256);
+  if (mode == 0)
+    hipLaunchKernelGGL(msda_kernel<0>, grid, block, 0, stream, (const bf16_t*)value, ldv, spatial_shapes, level_start, L, P, loc, ld_loc,
+                       attn, ld_attn, ref, (bf16_t*)out, ldo, B, S, Q, M);
+  else
+    hipLaunchKernelGGL(msda_kernel<1>, grid, block, 0, stream, (const bf16_t*)value, ldv, spatial_shapes, level_start, L, P, loc, ld_loc,
+                       attn, ld_attn, ref, (bf16_t*)out, ldo, B, S, Q, M);
+  return fx_launch_status();
+}

@@ -1,0 +1,593 @@
+"""RT-DETR inference engine: packs a reference-layout state_dict for the gfx950 kernels and runs
+FAIDetr.forward (eval) + the device side of DETRProcessor.postprocess as one hipGraph of C-ABI calls.
+
+Reference path being replaced (file:line in FocoosAI/focoos):
+  FAIDetr.forward            focoos/models/fai_detr/modelling.py:1344-1358
+  ResNet.forward             focoos/nn/backbone/resnet.py:252-266
+  Encoder.forward            focoos/models/fai_detr/modelling.py:297-347
+  TransformerPredictor       focoos/models/fai_detr/modelling.py:1145-1263
+  TransformerDecoder(+Layer) focoos/models/fai_detr/modelling.py:924-1020
+  DETRHead.forward tail      focoos/models/fai_detr/modelling.py:392-401
+  DETRProcessor.postprocess  focoos/models/fai_detr/processor.py:146-197
+
+PyTorch is used for device memory (torch.empty), stream handles and host-side weight packing
+only; every FLOP of the forward goes through libfocoos_amd.so.
+
+Data layout in HBM: activations NHWC bf16, one buffer per layer output (288 GB HBM: no arena
+juggling; channel-concats are free because producers write channel slices of the concat buffer);
+weights [Npad][KH][KW][C] bf16 with eval-BatchNorm folded in (and RepVGG 3x3+1x1 branches
+re-parameterised into one 3x3), biases fp32; scores / boxes / sampling offsets fp32.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import FX_ACT, FxConvDesc, check
+from .state_spec import RESNET_BLOCKS
+
+BN_EPS = 1e-5
+
+
+class NT:
+    """View of an NHWC (or [rows, C]) device buffer for the C ABI: base tensor + channel offset + pixel stride."""
+
+    __slots__ = ("t", "B", "H", "W", "C", "ld", "off")
+
+    def __init__(self, t: torch.Tensor, B: int, H: int, W: int, Cc: int, ld: int, off: int = 0):
+        self.t, self.B, self.H, self.W, self.C, self.ld, self.off = t, B, H, W, Cc, ld, off
+
+    @property
+    def ptr(self) -> int:
+        return self.t.data_ptr() + self.off * self.t.element_size()
+
+    @property
+    def rows(self) -> int:
+        return self.B * self.H * self.W
+
+    def slice(self, off: int, Cc: int) -> "NT":
+        return NT(self.t, self.B, self.H, self.W, Cc, self.ld, self.off + off)
+
+    def as_rows(self) -> "NT":
+        return NT(self.t, self.rows, 1, 1, self.C, self.ld, self.off)
+
+    def torch_view(self) -> torch.Tensor:
+        """[B,H,W,C] strided view (tests / debugging)."""
+        base = self.t.reshape(-1)
+        return torch.as_strided(base, (self.B, self.H, self.W, self.C), (self.H * self.W * self.ld, self.W * self.ld, self.ld, 1), self.off)
+
+
+class PackedConv:
+    __slots__ = ("w", "b", "N", "C", "KH", "KW")
+
+    def __init__(self, w, b, N, Cc, KH, KW):
+        self.w, self.b, self.N, self.C, self.KH, self.KW = w, b, N, Cc, KH, KW
+
+
+def _fold_bn(sd, conv_w_key: str, bn_prefix: str) -> Tuple[torch.Tensor, torch.Tensor]:
+    """conv weight * gamma/sqrt(var+eps), bias = beta - mean*gamma/sqrt(var+eps)  (F.batch_norm eval, norm.py:49-57)."""
+    W = sd[conv_w_key].double()
+    g, bta = sd[f"{bn_prefix}.weight"].double(), sd[f"{bn_prefix}.bias"].double()
+    mu, var = sd[f"{bn_prefix}.running_mean"].double(), sd[f"{bn_prefix}.running_var"].double()
+    s = g / torch.sqrt(var + BN_EPS)
+    return (W * s.view(-1, 1, 1, 1)).float(), (bta - mu * s).float()
+
+
+class DetrEngine:
+    def __init__(self, config: Dict, state_dict: Dict[str, torch.Tensor], device: str = "cuda:0"):
+        if not torch.cuda.is_available():
+            raise _lib.FocoosAmdError("focoos_amd needs a ROCm GPU (gfx950); no CPU fallback exists")
+        self.lib = _lib.load()
+        self.cfg = dict(config)
+        self.dev = torch.device(device)
+        cu, arch = C.c_int(0), C.create_string_buffer(64)
+        check(self.lib.fx_device_info(self.dev.index or 0, C.byref(cu), arch, 64), "fx_device_info (gfx950 required)")
+        self.cu_count, self.arch = cu.value, arch.value.decode()
+        self.nc = int(config["num_classes"])
+        self.nq = int(config.get("num_queries", 300))
+        self.hd = int(config.get("transformer_predictor_hidden_dim", 256))
+        self.nl = int(config.get("transformer_predictor_dec_layers", 6))
+        self.nhead = int(config.get("transformer_predictor_nhead", 8))
+        self.n_enc = int(config.get("pixel_decoder_num_encoder_layers", 1))
+        self.depth = int(config["backbone_config"].get("depth", 50))
+        if self.hd != 256 or int(config.get("pixel_decoder_feat_dim", 256)) != 256 or self.nhead != 8:
+            raise _lib.FocoosAmdError("engine kernels are specialised for hidden_dim 256 / 8 heads (fai-detr-l)")
+        self.top_k = int(config.get("top_k", 300))
+        self.threshold = float(config.get("threshold", 0.5))
+        self.stream = torch.cuda.Stream(self.dev)
+        self.plans: Dict[Tuple[int, int, int, bool], "_Plan"] = {}
+        self.load_state_dict(state_dict)
+
+    # ------------------------------------------------------------------ weight packing
+    def _dev(self, t: torch.Tensor, dtype=None) -> torch.Tensor:
+        return t.to(device=self.dev, dtype=dtype or t.dtype).contiguous()
+
+    def _pack(self, W4: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedConv:
+        N, Cc, KH, KW = W4.shape
+        Np = (N + 127) // 128 * 128
+        w = torch.zeros(Np, KH, KW, Cc, dtype=torch.float32)
+        w[:N] = W4.permute(0, 2, 3, 1)
+        b = torch.zeros(Np, dtype=torch.float32)
+        if bias is not None:
+            b[:N] = bias
+        return PackedConv(self._dev(w, torch.bfloat16), self._dev(b), N, Cc, KH, KW)
+
+    def _pack_linear(self, W: torch.Tensor, b: Optional[torch.Tensor]) -> PackedConv:
+        return self._pack(W.float().view(W.shape[0], W.shape[1], 1, 1), None if b is None else b.float())
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        sd = {k: v.detach().cpu() for k, v in sd.items()}
+        P: Dict[str, PackedConv] = {}
+        bb = "pixel_decoder.backbone"
+
+        def cbn(name, conv="conv", norm="norm"):
+            P[name] = self._pack(*_fold_bn(sd, f"{name}.{conv}.weight", f"{name}.{norm}"))
+
+        # stem conv1_1 stays fp32 [n][kh][kw][c] (direct-conv kernel)
+        w, b = _fold_bn(sd, f"{bb}.conv1.conv1_1.conv.weight", f"{bb}.conv1.conv1_1.norm")
+        self.stem_w = self._dev(w.permute(0, 2, 3, 1).contiguous())
+        self.stem_b = self._dev(b)
+        mean = torch.tensor(self.cfg.get("pixel_mean", [123.675, 116.28, 103.53]), dtype=torch.float32)
+        std = torch.tensor(self.cfg.get("pixel_std", [58.395, 57.12, 57.375]), dtype=torch.float32)
+        self.px_mean, self.px_inv_std = self._dev(mean), self._dev(1.0 / std)
+        cbn(f"{bb}.conv1.conv1_2")
+        cbn(f"{bb}.conv1.conv1_3")
+        for si, n in enumerate(RESNET_BLOCKS[self.depth]):
+            for bi in range(n):
+                p = f"{bb}.res_layers.{si}.blocks.{bi}"
+                for br in ("branch2a", "branch2b", "branch2c"):
+                    cbn(f"{p}.{br}")
+                if bi == 0:
+                    cbn(f"{p}.short" if si == 0 else f"{p}.short.conv")
+        pd = "pixel_decoder"
+        for i in range(3):
+            P[f"{pd}.input_proj.{i}"] = self._pack(*_fold_bn(sd, f"{pd}.input_proj.{i}.0.weight", f"{pd}.input_proj.{i}.1"))
+        for li in range(self.n_enc):
+            p = f"{pd}.encoder.0.layers.{li}"
+            Wi, bi_ = sd[f"{p}.self_attn.in_proj_weight"], sd[f"{p}.self_attn.in_proj_bias"]
+            P[f"{p}.qk"] = self._pack_linear(Wi[:512], bi_[:512])
+            P[f"{p}.v"] = self._pack_linear(Wi[512:], bi_[512:])
+            P[f"{p}.out_proj"] = self._pack_linear(sd[f"{p}.self_attn.out_proj.weight"], sd[f"{p}.self_attn.out_proj.bias"])
+            for l in ("linear1", "linear2"):
+                P[f"{p}.{l}"] = self._pack_linear(sd[f"{p}.{l}.weight"], sd[f"{p}.{l}.bias"])
+            for nrm in ("norm1", "norm2"):
+                setattr(self, f"_ln_{p}.{nrm}", None)
+        self.ln: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+        def ln(name):
+            self.ln[name] = (self._dev(sd[f"{name}.weight"].float()), self._dev(sd[f"{name}.bias"].float()))
+
+        for li in range(self.n_enc):
+            ln(f"{pd}.encoder.0.layers.{li}.norm1")
+            ln(f"{pd}.encoder.0.layers.{li}.norm2")
+        for i in range(2):
+            cbn(f"{pd}.lateral_convs.{i}")
+            cbn(f"{pd}.downsample_convs.{i}")
+        for blk in ("fpn_blocks", "pan_blocks"):
+            for i in range(2):
+                p = f"{pd}.{blk}.{i}"
+                # conv1 and conv2 read the same input: one N=512 GEMM ([conv1 | conv2])
+                w1, b1 = _fold_bn(sd, f"{p}.conv1.conv.weight", f"{p}.conv1.norm")
+                w2, b2 = _fold_bn(sd, f"{p}.conv2.conv.weight", f"{p}.conv2.norm")
+                P[f"{p}.conv12"] = self._pack(torch.cat([w1, w2], 0), torch.cat([b1, b2], 0))
+                for j in range(3):
+                    q = f"{p}.bottlenecks.{j}"
+                    # RepVGG re-parameterisation (modelling.py:57-81): 3x3 + zero-padded 1x1, biases add
+                    w3, b3 = _fold_bn(sd, f"{q}.conv1.conv.weight", f"{q}.conv1.norm")
+                    w1_, b1_ = _fold_bn(sd, f"{q}.conv2.conv.weight", f"{q}.conv2.norm")
+                    w3 = w3.clone()
+                    w3[:, :, 1:2, 1:2] += w1_
+                    P[f"{q}.rep"] = self._pack(w3, b3 + b1_)
+        hp = "head.predictor"
+        for i in range(3):
+            cbn(f"{hp}.input_proj.{i}")
+        P[f"{hp}.enc_output.0"] = self._pack_linear(sd[f"{hp}.enc_output.0.weight"], sd[f"{hp}.enc_output.0.bias"])
+        ln(f"{hp}.enc_output.1")
+        P[f"{hp}.enc_score"] = self._pack_linear(sd[f"{hp}.enc_score_classifier.weight"], sd[f"{hp}.enc_score_classifier.bias"])
+        # constant output_memory row of masked (invalid-anchor) tokens: LN(Linear(0)) = LN(bias)
+        b0 = sd[f"{hp}.enc_output.0.bias"].float()
+        row = torch.nn.functional.layer_norm(b0.to(torch.bfloat16).float(), (self.hd,), sd[f"{hp}.enc_output.1.weight"].float(),
+                                             sd[f"{hp}.enc_output.1.bias"].float(), 1e-5)
+        self.invalid_row = self._dev(row, torch.bfloat16)
+
+        def mlp3(prefix, key):
+            P[f"{key}.0"] = self._pack_linear(sd[f"{prefix}.layers.0.weight"], sd[f"{prefix}.layers.0.bias"])
+            P[f"{key}.1"] = self._pack_linear(sd[f"{prefix}.layers.1.weight"], sd[f"{prefix}.layers.1.bias"])
+            return self._dev(sd[f"{prefix}.layers.2.weight"].float()), self._dev(sd[f"{prefix}.layers.2.bias"].float())
+
+        self.bbox_last: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self.bbox_last["enc"] = mlp3(f"{hp}.enc_bbox_classifier", f"{hp}.enc_bbox")
+        self.qpos0 = (self._dev(sd[f"{hp}.query_pos_head.layers.0.weight"].float()), self._dev(sd[f"{hp}.query_pos_head.layers.0.bias"].float()))
+        P[f"{hp}.qpos1"] = self._pack_linear(sd[f"{hp}.query_pos_head.layers.1.weight"], sd[f"{hp}.query_pos_head.layers.1.bias"])
+        vw, vb = [], []
+        for li in range(self.nl):
+            p = f"{hp}.decoder.layers.{li}"
+            Wi, bi_ = sd[f"{p}.self_attn.in_proj_weight"], sd[f"{p}.self_attn.in_proj_bias"]
+            P[f"{p}.qk"] = self._pack_linear(Wi[:512], bi_[:512])
+            P[f"{p}.v"] = self._pack_linear(Wi[512:], bi_[512:])
+            P[f"{p}.out_proj"] = self._pack_linear(sd[f"{p}.self_attn.out_proj.weight"], sd[f"{p}.self_attn.out_proj.bias"])
+            ca = f"{p}.cross_attn"
+            # sampling_offsets (192) and attention_weights (96) read the same query: one N=288 GEMM, fp32 out
+            P[f"{ca}.offaw"] = self._pack_linear(torch.cat([sd[f"{ca}.sampling_offsets.weight"], sd[f"{ca}.attention_weights.weight"]], 0),
+                                                 torch.cat([sd[f"{ca}.sampling_offsets.bias"], sd[f"{ca}.attention_weights.bias"]], 0))
+            vw.append(sd[f"{ca}.value_proj.weight"])
+            vb.append(sd[f"{ca}.value_proj.bias"])
+            P[f"{ca}.output_proj"] = self._pack_linear(sd[f"{ca}.output_proj.weight"], sd[f"{ca}.output_proj.bias"])
+            for l in ("linear1", "linear2"):
+                P[f"{p}.{l}"] = self._pack_linear(sd[f"{p}.{l}.weight"], sd[f"{p}.{l}.bias"])
+            for nrm in ("norm1", "norm2", "norm3"):
+                ln(f"{p}.{nrm}")
+            self.bbox_last[f"dec{li}"] = mlp3(f"{hp}.dec_bbox_classifier.{li}", f"{hp}.dec_bbox.{li}")
+        # the decoder memory is the same for all layers: all value_proj's as ONE N = 6*256 GEMM
+        P[f"{hp}.value_all"] = self._pack_linear(torch.cat(vw, 0), torch.cat(vb, 0))
+        last = self.nl - 1
+        P[f"{hp}.dec_score"] = self._pack_linear(sd[f"{hp}.dec_score_classifier.{last}.weight"], sd[f"{hp}.dec_score_classifier.{last}.bias"])
+        self.P = P
+        self.plans.clear()
+
+    # ------------------------------------------------------------------ constants that depend on the input size
+    @staticmethod
+    def _pos_embed_sine(h: int, w: int, npf: int, temperature: float = 10000.0) -> torch.Tensor:
+        """Sine position embedding of the AIFI layer, [h*w, 2*npf] = [y_sin | y_cos | x_sin | x_cos] (modelling.py:148-179)."""
+        ys = torch.arange(h, dtype=torch.float32).view(h, 1).expand(h, w)
+        xs = torch.arange(w, dtype=torch.float32).view(1, w).expand(h, w)
+        i = torch.arange(npf, dtype=torch.float32)
+        dim_t = temperature ** (2 * torch.div(i, 2, rounding_mode="floor") / npf)
+        px, py = xs[..., None] / dim_t, ys[..., None] / dim_t
+        out = torch.cat([py[..., 0::2].sin(), py[..., 1::2].cos(), px[..., 0::2].sin(), px[..., 1::2].cos()], dim=-1)
+        return out.reshape(h * w, 2 * npf)
+
+    @staticmethod
+    def _anchors(shapes: Sequence[Tuple[int, int]], grid_size: float = 0.05, eps: float = 1e-2):
+        """Anchors (logit space) + invalid-token list (modelling.py:1169-1189)."""
+        out = []
+        for lvl, (h, w) in enumerate(shapes):
+            gy, gx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+            xy = (torch.stack([gx, gy], -1) + 0.5) / torch.tensor([w, h], dtype=torch.float32)
+            wh = torch.ones_like(xy) * grid_size * (2.0 ** (2 - lvl))
+            out.append(torch.cat([xy, wh], -1).reshape(h * w, 4))
+        a = torch.cat(out, 0)
+        valid = ((a > eps) & (a < 1 - eps)).all(-1)
+        a = torch.log(a / (1 - a))
+        a = torch.where(valid[:, None], a, torch.zeros_like(a))
+        return a, torch.nonzero(~valid).flatten().to(torch.int32)
+
+    # ------------------------------------------------------------------ run
+    def plan(self, B: int, H: int, W: int, f32_input: bool = False) -> "_Plan":
+        key = (B, H, W, f32_input)
+        if key not in self.plans:
+            self.plans[key] = _Plan(self, B, H, W, f32_input)
+        return self.plans[key]
+
+    def forward(self, images: torch.Tensor, sizes: Optional[torch.Tensor] = None, threshold: Optional[float] = None,
+                forced_topk: Optional[torch.Tensor] = None, use_graph: bool = True) -> "_Plan":
+        """images: uint8 [B,H,W,3] (fused normalise path) or float32 [B,H,W,3] (0..255 scale), on the engine device.
+        Returns the plan whose output buffers (probs, boxes, det_*) hold the results (valid until the next call)."""
+        assert images.dim() == 4 and images.shape[-1] == 3 and images.is_contiguous() and images.device == self.dev
+        f32 = images.dtype == torch.float32
+        assert f32 or images.dtype == torch.uint8
+        B, H, W, _ = images.shape
+        pl = self.plan(B, H, W, f32)
+        cur = torch.cuda.current_stream(self.dev)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            pl.input.copy_(images, non_blocking=True)
+            if sizes is None:
+                pl.sizes.copy_(torch.tensor([[H, W]] * B, dtype=torch.int32), non_blocking=False)
+            else:
+                pl.sizes.copy_(sizes.to(torch.int32), non_blocking=True)
+            pl.run(self.stream.cuda_stream, threshold if threshold is not None else self.threshold, forced_topk, use_graph)
+        cur.wait_stream(self.stream)
+        return pl
+
+
+class _Plan:
+    """Buffers + the static launch sequence for one (batch, height, width)."""
+
+    def __init__(self, eng: DetrEngine, B: int, H: int, W: int, f32_input: bool):
+        if H % 32 or W % 32:
+            raise _lib.FocoosAmdError("input height/width must be multiples of 32")
+        self.eng, self.B, self.H, self.W, self.f32_input = eng, B, H, W, f32_input
+        self.lib = eng.lib
+        self.dev = eng.dev
+        self.ops: List[Tuple] = []        # (fn, args) ; stream appended at call time
+        self.split_at: Optional[int] = None  # ops[:split_at] end with the encoder top-k
+        self.keep: List = []              # ctypes structs kept alive
+        self.meta: Dict[int, dict] = {}   # op index -> {kind, variant, flops} for bench.py
+        self.bufs: Dict[str, NT] = {}
+        self.graph = None
+        self.graph_thr = None
+        self._thr_cell = None
+        self._build()
+
+    # -------------------------------------------------------------- helpers
+    def _new(self, name: str, B: int, H: int, W: int, Cc: int, dtype=torch.bfloat16) -> NT:
+        t = torch.empty(B * H * W * Cc, dtype=dtype, device=self.dev)
+        nt = NT(t, B, H, W, Cc, Cc, 0)
+        self.bufs[name] = nt
+        return nt
+
+    def _op(self, fn, *args):
+        self.ops.append((fn, args))
+
+    def conv(self, x: NT, pc: PackedConv, out: Optional[NT] = None, name: Optional[str] = None, stride: int = 1, act=None,
+             residual: Optional[NT] = None, res_after: bool = False, pool2: bool = False, out_f32: bool = False,
+             y_batch_stride: int = 0, extra_flops_per_pixel: float = 0.0) -> NT:
+        assert x.C == pc.C, (name, x.C, pc.C)
+        pad = (pc.KH - 1) // 2
+        if pool2:
+            Ho, Wo = (x.H + 1) // 2, (x.W + 1) // 2
+        else:
+            Ho, Wo = (x.H + 2 * pad - pc.KH) // stride + 1, (x.W + 2 * pad - pc.KW) // stride + 1
+        if out is None:
+            ncols = (pc.N + 7) // 8 * 8
+            out = self._new(name, x.B, Ho, Wo, ncols, torch.float32 if out_f32 else torch.bfloat16)
+            out.C = pc.N
+        assert out.H == Ho and out.W == Wo and out.C == pc.N, (name, out.H, Ho, out.C, pc.N)
+        d = FxConvDesc()
+        d.x, d.w, d.bias = x.ptr, pc.w.data_ptr(), pc.b.data_ptr()
+        d.residual = residual.ptr if residual is not None else None
+        d.y = out.ptr
+        d.B, d.H, d.W, d.C, d.ldx = x.B, x.H, x.W, x.C, x.ld
+        d.Ho, d.Wo, d.N, d.ldy = Ho, Wo, pc.N, out.ld
+        d.ldr = residual.ld if residual is not None else 0
+        d.KH, d.KW, d.stride, d.pad = pc.KH, pc.KW, stride, pad
+        d.pool2, d.act, d.out_f32 = int(pool2), FX_ACT[act], int(out_f32)
+        d.residual_after_act = int(res_after)
+        d.y_batch_stride = y_batch_stride
+        self.keep.append(d)
+        # bookkeeping for bench.py: which template instance runs and the ALGORITHMIC flops of the reference layer(s)
+        # this launch replaces (RepVGG 1x1 branch counted although it is re-parameterised away).
+        M = x.B * Ho * Wo
+        bk = 64 if pc.C % 64 == 0 else 32
+        bn = 128 if (pc.N > 64 or pool2) else (64 if pc.N > 32 else 32)
+        flops = 2.0 * M * pc.N * pc.KH * pc.KW * pc.C + extra_flops_per_pixel * M
+        self.meta[len(self.ops)] = {"kind": "conv", "variant": f"conv_igemm<128,{bn},{bk}{',pool' if pool2 else ''}>", "flops": flops,
+                                    "name": name or "slice", "M": M, "N": pc.N, "K": pc.KH * pc.KW * pc.C}
+        self._op(self.lib.fx_conv2d_nhwc_bf16, C.byref(d))
+        return out
+
+    def linear(self, x: NT, pc: PackedConv, **kw) -> NT:
+        return self.conv(x.as_rows() if (x.H != 1 or x.W != 1) else x, pc, **kw)
+
+    def layernorm(self, x: NT, name_ln: str, out_name: str, residual: Optional[NT] = None) -> NT:
+        g, b = self.eng.ln[name_ln]
+        out = self._new(out_name, x.rows, 1, 1, 256)
+        self._op(self.lib.fx_layernorm_bf16, x.ptr, x.ld, residual.ptr if residual is not None else None,
+                 residual.ld if residual is not None else 0, g.data_ptr(), b.data_ptr(), out.ptr, out.ld, x.rows, 256)
+        return out
+
+    def add_rows(self, x: NT, y: NT, y_rows: int, out_name: str) -> NT:
+        out = self._new(out_name, x.rows, 1, 1, x.C)
+        self._op(self.lib.fx_add_rows_bf16, x.ptr, x.ld, y.ptr, y.ld, y_rows, out.ptr, out.ld, x.rows, x.C)
+        return out
+
+    def resize(self, x: NT, out: NT):
+        self._op(self.lib.fx_resize_bilinear_nhwc_bf16, x.ptr, x.ld, out.ptr, out.ld, x.B, x.H, x.W, x.C, out.H, out.W)
+
+    def mha(self, qkv: NT, B: int, L: int, out_name: str) -> NT:
+        out = self._new(out_name, B * L, 1, 1, 256)
+        q, k, v = qkv.slice(0, 256), qkv.slice(256, 256), qkv.slice(512, 256)
+        self._op(self.lib.fx_mha_bf16, q.ptr, q.ld, k.ptr, k.ld, v.ptr, v.ld, out.ptr, out.ld, B, L, L, 8)
+        return out
+
+    # -------------------------------------------------------------- the network
+    def _build(self):
+        e, P, B, lib = self.eng, self.eng.P, self.B, self.lib
+        H, W = self.H, self.W
+        bb = "pixel_decoder.backbone"
+        self.input = torch.empty(B, H, W, 3, dtype=torch.float32 if self.f32_input else torch.uint8, device=self.dev)
+        self.sizes = torch.empty(B, 2, dtype=torch.int32, device=self.dev)
+        # ---- backbone (resnet.py:252-266)
+        c1 = self._new("conv1_1", B, H // 2, W // 2, 32)
+        self._op(lib.fx_stem_conv3x3s2, self.input.data_ptr(), int(self.f32_input), e.stem_w.data_ptr(), e.stem_b.data_ptr(),
+                 e.px_mean.data_ptr(), e.px_inv_std.data_ptr(), c1.ptr, B, H, W, 32)
+        x = self.conv(c1, P[f"{bb}.conv1.conv1_2"], name="conv1_2", act="relu")
+        x = self.conv(x, P[f"{bb}.conv1.conv1_3"], name="conv1_3", act="relu")
+        mp = self._new("maxpool", B, H // 4, W // 4, 64)
+        self._op(lib.fx_maxpool3x3s2_nhwc_bf16, x.ptr, x.ld, mp.ptr, mp.ld, B, x.H, x.W, 64)
+        x = mp
+        feats = {}
+        for si, n in enumerate(RESNET_BLOCKS[e.depth]):
+            for bi in range(n):
+                p = f"{bb}.res_layers.{si}.blocks.{bi}"
+                stride = 2 if (bi == 0 and si != 0) else 1
+                a = self.conv(x, P[f"{p}.branch2a"], name=f"{p}.a", act="relu")
+                bmid = self.conv(a, P[f"{p}.branch2b"], name=f"{p}.b", stride=stride, act="relu")
+                if bi == 0:
+                    if stride == 2:
+                        short = self.conv(x, P[f"{p}.short.conv"], name=f"{p}.s", pool2=True)
+                    else:
+                        short = self.conv(x, P[f"{p}.short"], name=f"{p}.s")
+                else:
+                    short = x
+                x = self.conv(bmid, P[f"{p}.branch2c"], name=f"{p}.c", residual=short, act="relu")
+            feats[si + 2] = x
+        self.bufs["res3"], self.bufs["res4"], self.bufs["res5"] = feats[3], feats[4], feats[5]
+        # ---- hybrid encoder (modelling.py:297-347)
+        pd = "pixel_decoder"
+        h8, w8, h16, w16, h32, w32 = H // 8, W // 8, H // 16, W // 16, H // 32, W // 32
+        cat80 = self._new("cat80", B, h8, w8, 512)     # [up(lat1) | proj(res3)]
+        cat40a = self._new("cat40a", B, h16, w16, 512)  # [up(lat0) | proj(res4)]
+        cat40b = self._new("cat40b", B, h16, w16, 512)  # [downconv0 | lat1]
+        cat20 = self._new("cat20", B, h32, w32, 512)    # [downconv1 | lat0]
+        self.conv(feats[3], P[f"{pd}.input_proj.0"], out=cat80.slice(256, 256))
+        self.conv(feats[4], P[f"{pd}.input_proj.1"], out=cat40a.slice(256, 256))
+        src = self.conv(feats[5], P[f"{pd}.input_proj.2"], name="proj5")
+        L = h32 * w32
+        if e.n_enc > 0:
+            pos = e._pos_embed_sine(h32, w32, 128).to(device=self.dev, dtype=torch.bfloat16).contiguous()
+            self.pos = NT(pos, L, 1, 1, 256, 256)
+            s = src.as_rows()
+            for li in range(e.n_enc):
+                p = f"{pd}.encoder.0.layers.{li}"
+                qk_in = self.add_rows(s, self.pos, L, f"aifi{li}.qk_in")
+                qkv = self._new(f"aifi{li}.qkv", B * L, 1, 1, 768)
+                self.linear(qk_in, P[f"{p}.qk"], out=qkv.slice(0, 512))
+                self.linear(s, P[f"{p}.v"], out=qkv.slice(512, 256))
+                att = self.mha(qkv, B, L, f"aifi{li}.att")
+                o = self.linear(att, P[f"{p}.out_proj"], name=f"aifi{li}.o", residual=s)
+                s1 = self.layernorm(o, f"{p}.norm1", f"aifi{li}.s1")
+                f1 = self.linear(s1, P[f"{p}.linear1"], name=f"aifi{li}.f1", act="gelu")
+                f2 = self.linear(f1, P[f"{p}.linear2"], name=f"aifi{li}.f2", residual=s1)
+                s = self.layernorm(f2, f"{p}.norm2", f"aifi{li}.s2")
+            self.bufs["aifi"] = s
+            src = NT(s.t, B, h32, w32, 256, 256)
+
+        def csp(xin: NT, p: str, out_name: str) -> NT:
+            c12 = self.conv(xin, P[f"{p}.conv12"], name=f"{p}.c12", act="silu")  # [x_1 | x_2]
+            x1 = c12.slice(0, 256)
+            for j in range(3):
+                last = j == 2
+                x1 = self.conv(x1, P[f"{p}.bottlenecks.{j}.rep"], name=out_name if last else f"{p}.rep{j}", act="silu",
+                               residual=c12.slice(256, 256) if last else None, res_after=True,
+                               extra_flops_per_pixel=2.0 * 256 * 256)  # the reference's separate 1x1 RepVGG branch
+            return x1
+
+        lat0 = self.conv(src, P[f"{pd}.lateral_convs.0"], out=cat20.slice(256, 256), act="silu")
+        self.resize(lat0, cat40a.slice(0, 256))
+        fpn0 = csp(cat40a, f"{pd}.fpn_blocks.0", "fpn0")
+        lat1 = self.conv(fpn0, P[f"{pd}.lateral_convs.1"], out=cat40b.slice(256, 256), act="silu")
+        self.resize(lat1, cat80.slice(0, 256))
+        out80 = csp(cat80, f"{pd}.fpn_blocks.1", "enc_s8")
+        d0 = self._new("down0", B, h16, w16, 256)
+        self.resize(out80, d0)
+        self.conv(d0, P[f"{pd}.downsample_convs.0"], out=cat40b.slice(0, 256), act="silu")
+        out40 = csp(cat40b, f"{pd}.pan_blocks.0", "enc_s16")
+        d1 = self._new("down1", B, h32, w32, 256)
+        self.resize(out40, d1)
+        self.conv(d1, P[f"{pd}.downsample_convs.1"], out=cat20.slice(0, 256), act="silu")
+        out20 = csp(cat20, f"{pd}.pan_blocks.1", "enc_s32")
+        # ---- predictor (modelling.py:1145-1263); memory rows in the reference order [s32 | s16 | s8]
+        hp = "head.predictor"
+        shapes = [(h32, w32), (h16, w16), (h8, w8)]
+        S = sum(a * b for a, b in shapes)
+        self.S = S
+        starts = [0, shapes[0][0] * shapes[0][1], shapes[0][0] * shapes[0][1] + shapes[1][0] * shapes[1][1]]
+        memory = self._new("memory", B, S, 1, 256)
+        for i, (f, st) in enumerate(zip((out20, out40, out80), starts)):
+            lvl = NT(memory.t, B, f.H, f.W, 256, 256, st * 256)
+            self.conv(f, P[f"{hp}.input_proj.{i}"], out=lvl, y_batch_stride=S * 256)
+        mem_rows = memory.as_rows()
+        anchors, invalid = e._anchors(shapes)
+        self.anchors = anchors.to(self.dev).contiguous()
+        self.invalid = invalid.to(self.dev).contiguous()
+        self.shapes_t = torch.tensor(shapes, dtype=torch.int32, device=self.dev)
+        self.starts_t = torch.tensor(starts, dtype=torch.int32, device=self.dev)
+        om_lin = self.linear(mem_rows, P[f"{hp}.enc_output.0"], name="om_lin")
+        om = self.layernorm(om_lin, f"{hp}.enc_output.1", "output_memory")
+        self._op(lib.fx_fill_rows_bf16, om.ptr, om.ld, S, self.invalid.data_ptr(), int(self.invalid.numel()), e.invalid_row.data_ptr(), B, 256)
+        enc_logits = self.linear(om, P[f"{hp}.enc_score"], name="enc_logits", out_f32=True)
+        Q, K = e.nq, e.nc
+        self.enc_scores = torch.empty(B, S, dtype=torch.float32, device=self.dev)
+        self._op(lib.fx_rowmax_f32, enc_logits.ptr, enc_logits.ld, self.enc_scores.data_ptr(), B * S, K)
+        self.enc_topk_val = torch.empty(B, Q, dtype=torch.float32, device=self.dev)
+        self.enc_topk = torch.empty(B, Q, dtype=torch.int32, device=self.dev)
+        self._op(lib.fx_topk_rows_f32, self.enc_scores.data_ptr(), S, B, S, Q, self.enc_topk_val.data_ptr(), self.enc_topk.data_ptr())
+        self.split_at = len(self.ops)
+        R = B * Q
+        tgt = self._new("target", R, 1, 1, 256)
+        self._op(lib.fx_gather_rows_bf16, om.ptr, om.ld, S, self.enc_topk.data_ptr(), Q, tgt.ptr, tgt.ld, B, 256)
+        hb = self.linear(tgt, P[f"{hp}.enc_bbox.0"], name="encbb.0", act="relu")
+        hb = self.linear(hb, P[f"{hp}.enc_bbox.1"], name="encbb.1", act="relu")
+        self.ref_unact = torch.empty(R, 4, dtype=torch.float32, device=self.dev)
+        refs = [torch.empty(R, 4, dtype=torch.float32, device=self.dev) for _ in range(e.nl + 1)]
+        wl, bl = e.bbox_last["enc"]
+        self._op(lib.fx_bbox_head, hb.ptr, hb.ld, wl.data_ptr(), bl.data_ptr(), None, self.anchors.data_ptr(), self.enc_topk.data_ptr(), Q, 1,
+                 refs[0].data_ptr(), self.ref_unact.data_ptr(), R, 256)
+        value = self.linear(mem_rows, P[f"{hp}.value_all"], name="value_all")
+        qp1 = self._new("qpos_h", R, 1, 1, 512)
+        for li in range(e.nl):
+            p = f"{hp}.decoder.layers.{li}"
+            ref = refs[li]
+            self._op(lib.fx_linear_k4_relu, ref.data_ptr(), e.qpos0[0].data_ptr(), e.qpos0[1].data_ptr(), qp1.ptr, qp1.ld, R, 512)
+            qpos = self.linear(qp1, P[f"{hp}.qpos1"], name=f"dec{li}.qpos")
+            qk_in = self.add_rows(tgt, qpos, R, f"dec{li}.qk_in")
+            qkv = self._new(f"dec{li}.qkv", R, 1, 1, 768)
+            self.linear(qk_in, P[f"{p}.qk"], out=qkv.slice(0, 512))
+            self.linear(tgt, P[f"{p}.v"], out=qkv.slice(512, 256))
+            att = self.mha(qkv, B, Q, f"dec{li}.att")
+            o = self.linear(att, P[f"{p}.out_proj"], name=f"dec{li}.o", residual=tgt)
+            t1 = self.layernorm(o, f"{p}.norm1", f"dec{li}.t1")
+            q2 = self.add_rows(t1, qpos, R, f"dec{li}.q2")
+            offaw = self.linear(q2, P[f"{p}.cross_attn.offaw"], name=f"dec{li}.offaw", out_f32=True)
+            ms = self._new(f"dec{li}.msda", R, 1, 1, 256)
+            vsl = value.slice(li * 256, 256)
+            self._op(lib.fx_msda_bf16, vsl.ptr, vsl.ld, self.shapes_t.data_ptr(), self.starts_t.data_ptr(), 3, 4, offaw.ptr, offaw.ld,
+                     offaw.ptr + 192 * 4, offaw.ld, ref.data_ptr(), 1, ms.ptr, ms.ld, B, S, Q, 8)
+            o2 = self.linear(ms, P[f"{p}.cross_attn.output_proj"], name=f"dec{li}.o2", residual=t1)
+            t2 = self.layernorm(o2, f"{p}.norm2", f"dec{li}.t2")
+            f1 = self.linear(t2, P[f"{p}.linear1"], name=f"dec{li}.f1", act="relu")
+            f2 = self.linear(f1, P[f"{p}.linear2"], name=f"dec{li}.f2", residual=t2)
+            tgt = self.layernorm(f2, f"{p}.norm3", f"dec{li}.out")
+            hb = self.linear(tgt, P[f"{hp}.dec_bbox.{li}.0"], name=f"dec{li}.bb0", act="relu")
+            hb = self.linear(hb, P[f"{hp}.dec_bbox.{li}.1"], name=f"dec{li}.bb1", act="relu")
+            wl, bl = e.bbox_last[f"dec{li}"]
+            self._op(lib.fx_bbox_head, hb.ptr, hb.ld, wl.data_ptr(), bl.data_ptr(), ref.data_ptr(), None, None, Q, 0, refs[li + 1].data_ptr(),
+                     None, R, 256)
+        self.refs = refs
+        logits = self.linear(tgt, P[f"{hp}.dec_score"], name="logits", out_f32=True)
+        self.probs = torch.empty(B, Q, K, dtype=torch.float32, device=self.dev)
+        self.boxes = torch.empty(B, Q, 4, dtype=torch.float32, device=self.dev)
+        self._op(lib.fx_detr_head_out, logits.ptr, logits.ld, refs[e.nl].data_ptr(), self.probs.data_ptr(), self.boxes.data_ptr(), R, K)
+        # ---- device side of DETRProcessor.postprocess (processor.py:146-151,183-197)
+        tk = min(e.top_k, Q * K)
+        self.top_k = tk
+        self.det_scores = torch.empty(B, tk, dtype=torch.float32, device=self.dev)
+        self.det_flat = torch.empty(B, tk, dtype=torch.int32, device=self.dev)
+        self.det_labels = torch.empty(B, tk, dtype=torch.int32, device=self.dev)
+        self.det_queries = torch.empty(B, tk, dtype=torch.int32, device=self.dev)
+        self.det_boxes = torch.empty(B, tk, 4, dtype=torch.int32, device=self.dev)
+        self.det_count = torch.empty(B, dtype=torch.int32, device=self.dev)
+        self._op(lib.fx_topk_rows_f32, self.probs.data_ptr(), Q * K, B, Q * K, tk, self.det_scores.data_ptr(), self.det_flat.data_ptr())
+        self.post_index = len(self.ops)
+        self._op(lib.fx_detr_postprocess, self.det_scores.data_ptr(), self.det_flat.data_ptr(), self.boxes.data_ptr(), self.sizes.data_ptr(), B, Q,
+                 K, tk, None, self.det_labels.data_ptr(), self.det_queries.data_ptr(), self.det_boxes.data_ptr(), self.det_count.data_ptr())
+
+    # -------------------------------------------------------------- execution
+    def _launch(self, ops, stream: int, thr: float):
+        for fn, args in ops:
+            if fn is self.lib.fx_detr_postprocess:
+                args = args[:8] + (C.c_float(thr),) + args[9:]
+            check(fn(*args, C.c_void_p(stream)), fn.__name__)
+
+    def run(self, stream: int, thr: float, forced_topk: Optional[torch.Tensor] = None, use_graph: bool = True):
+        if forced_topk is not None:
+            self._launch(self.ops[: self.split_at], stream, thr)
+            self.enc_topk.copy_(forced_topk.to(device=self.dev, dtype=torch.int32))
+            self._launch(self.ops[self.split_at:], stream, thr)
+            return
+        if not use_graph:
+            self._launch(self.ops, stream, thr)
+            return
+        if self.graph is None or self.graph_thr != thr:
+            if self.graph is not None:
+                check(self.lib.fx_graph_destroy(self.graph), "fx_graph_destroy")
+                self.graph = None
+            self._launch(self.ops, stream, thr)  # warm-up (first-use initialisation must not happen under capture)
+            torch.cuda.current_stream(self.dev).synchronize()
+            check(self.lib.fx_graph_begin(C.c_void_p(stream)), "fx_graph_begin")
+            try:
+                self._launch(self.ops, stream, thr)
+            finally:
+                g = C.c_void_p()
+                rc = self.lib.fx_graph_end(C.c_void_p(stream), C.byref(g))
+            check(rc, "fx_graph_end")
+            self.graph, self.graph_thr = g, thr
+        check(self.lib.fx_graph_launch(self.graph, C.c_void_p(stream)), "fx_graph_launch")
+
+    def time_graph(self, stream: int, iters: int) -> float:
+        ms = C.c_float(0)
+        check(self.lib.fx_graph_time(self.graph, C.c_void_p(stream), iters, C.byref(ms)), "fx_graph_time")
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.graph is not None:
+                self.lib.fx_graph_destroy(self.graph)
+        except Exception:
+            pass

@@ -1,0 +1,211 @@
+"""Host-side mirror of the reference's public surface for the RT-DETR path:
+
+  ModelManager.get()        focoos/model_manager.py:42-155
+  FocoosModel.__call__/infer focoos/models/focoos_model.py:370-416,575-621
+  FAIDetr (BaseModelNN)     focoos/models/fai_detr/modelling.py:1273-1358, focoos/models/base_model.py:17-143
+
+Same names, argument meaning and error behaviour; the compute is the HIP engine (engine.py).
+``.train()`` / ``.export()`` are not part of this round's hot path and raise NotImplementedError
+(loudly — never a silent fallback)."""
+from __future__ import annotations
+
+import os
+import warnings
+from collections import OrderedDict
+from time import perf_counter
+from typing import Callable, Dict, List, Optional, Tuple, Type, Union
+
+import numpy as np
+import torch
+
+from .engine import DetrEngine
+from .ports import DETRModelOutput, FocoosDetections, InferLatency, ModelInfo
+from .processor import DETRProcessor
+from .registry import ModelRegistry
+from .state_spec import detr_state_spec
+from .synth import synth_state_dict
+
+
+class IncompatibleKeys:
+    def __init__(self, missing_keys, unexpected_keys, incorrect_shapes):
+        self.missing_keys, self.unexpected_keys, self.incorrect_shapes = missing_keys, unexpected_keys, incorrect_shapes
+
+    def __repr__(self):
+        return f"IncompatibleKeys(missing={self.missing_keys}, unexpected={self.unexpected_keys}, incorrect_shapes={self.incorrect_shapes})"
+
+
+class FAIDetr:
+    """Engine-backed RT-DETR.  ``state_dict()`` keeps the reference's key names and fp32 values, so
+    checkpoints round-trip; the packed bf16 copies the kernels read are rebuilt on ``load_state_dict``."""
+
+    def __init__(self, config: dict, device: Union[str, torch.device] = "cuda:0", seed: int = 0):
+        self.config = dict(config)
+        self.training = False
+        self._spec = detr_state_spec(self.config)
+        self._state = synth_state_dict(self.config, seed)  # "random init" (no network -> no pretrained weights)
+        self._device = torch.device(device)
+        self.engine = DetrEngine(self.config, self._state, str(self._device))
+        self.num_classes = int(self.config["num_classes"])
+
+    # ---- BaseModelNN surface
+    @property
+    def device(self) -> torch.device:
+        return self._device
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return torch.float32  # pixel_mean.dtype in the reference (modelling.py:1340-1342)
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode: bool = True):
+        if mode:
+            raise NotImplementedError("focoos_amd round 1 covers the inference hot path; training (SURVEY §8 config 4) is the next row")
+        return self.eval()
+
+    def cuda(self, device=None):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def state_dict(self) -> "OrderedDict[str, torch.Tensor]":
+        return OrderedDict((k, v.clone()) for k, v in self._state.items())
+
+    def load_state_dict(self, checkpoint_state_dict: Dict[str, torch.Tensor], strict: bool = True) -> IncompatibleKeys:
+        """base_model.py:98-143: strips a DDP ``module.`` prefix, skips shape-mismatched tensors (reported),
+        reports missing / unexpected keys; raises only when ``strict`` and something is off."""
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in checkpoint_state_dict.items()}
+        missing, unexpected, bad = [], [], []
+        new = OrderedDict(self._state)
+        for k, (shape, _) in self._spec.items():
+            if k not in sd:
+                missing.append(k)
+                continue
+            v = sd[k].detach().cpu()
+            if tuple(v.shape) != tuple(shape):
+                bad.append((k, tuple(v.shape), tuple(shape)))
+                continue
+            new[k] = v.to(self._state[k].dtype).clone()
+        unexpected = [k for k in sd if k not in self._spec]
+        if strict and (missing or unexpected or bad):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing={missing[:5]} unexpected={unexpected[:5]} incorrect_shapes={bad[:5]}")
+        self._state = new
+        self.engine.load_state_dict(new)
+        return IncompatibleKeys(missing, unexpected, bad)
+
+    # ---- forward
+    def _to_nhwc(self, images: torch.Tensor) -> torch.Tensor:
+        if images.dim() != 4:
+            raise ValueError("images must be [B,3,H,W] float (reference contract) or [B,H,W,3] uint8/float32")
+        if images.shape[1] == 3 and images.shape[-1] != 3:  # reference contract: NCHW, 0..255, un-normalised
+            images = images.permute(0, 2, 3, 1)
+        if images.dtype != torch.uint8:
+            images = images.to(torch.float32)
+        return images.to(self._device).contiguous()
+
+    def forward(self, images: torch.Tensor, targets: list = [], forced_topk: Optional[torch.Tensor] = None,
+                use_graph: bool = True) -> DETRModelOutput:
+        if self.training or (targets is not None and len(targets) > 0):
+            raise NotImplementedError("training forward (loss) is not part of this round")
+        pl = self.engine.forward(self._to_nhwc(images), forced_topk=forced_topk, use_graph=use_graph)
+        self.last_plan = pl
+        return DETRModelOutput(logits=pl.probs.clone(), boxes=pl.boxes.clone(), loss=None)
+
+    __call__ = forward
+
+    def detect(self, images: torch.Tensor, sizes: Optional[torch.Tensor] = None, threshold: Optional[float] = None):
+        """Fused forward + device post-process.  Returns the plan; ``det_scores/det_labels/det_boxes/det_count``
+        hold the packed results."""
+        pl = self.engine.forward(self._to_nhwc(images), sizes=sizes, threshold=threshold)
+        self.last_plan = pl
+        return pl
+
+
+class FocoosModel:
+    """focoos/models/focoos_model.py:88-147 — model + processor + model_info."""
+
+    def __init__(self, model: FAIDetr, model_info: ModelInfo):
+        self.model = model
+        self.model_info = model_info
+        self.processor = DETRProcessor(model_info.config, image_size=model_info.im_size).eval()
+        self.model.eval()
+
+    @property
+    def device(self):
+        return self.model.device
+
+    def infer_batch(self, inputs: list, threshold: Optional[float] = None) -> List[FocoosDetections]:
+        """Batched inference: list of images in, list of FocoosDetections out (per-image result == the
+        reference at B=1; the reference's own __call__ drops all but image 0 — focoos_model.py:615-621)."""
+        t0 = perf_counter()
+        images, _ = self.processor.preprocess(inputs, device=self.model.device, dtype=self.model.dtype)
+        t1 = perf_counter()
+        sizes = torch.tensor(self.processor.get_image_sizes(inputs), dtype=torch.int32)
+        thr = threshold or self.processor.threshold
+        pl = self.model.detect(images, sizes=sizes, threshold=thr)
+        torch.cuda.current_stream(self.model.device).synchronize()
+        t2 = perf_counter()
+        out = self.processor.pack_detections(pl.det_scores, pl.det_labels, pl.det_boxes, pl.det_count, self.model_info.classes)
+        t3 = perf_counter()
+        for o in out:
+            o.latency = InferLatency(preprocess=round(t1 - t0, 3), inference=round(t2 - t1, 3), postprocess=round(t3 - t2, 3))
+        return out
+
+    def __call__(self, inputs, **kwargs) -> FocoosDetections:
+        lst = inputs if isinstance(inputs, list) else [inputs]
+        return self.infer_batch(lst, threshold=kwargs.get("threshold"))[0]
+
+    def infer(self, image, threshold: Optional[float] = None, annotate: bool = False) -> FocoosDetections:
+        if isinstance(image, (str, os.PathLike)):
+            from PIL import Image
+
+            image = np.array(Image.open(image).convert("RGB"))
+        if annotate:
+            raise NotImplementedError("annotation/drawing is outside the hot path")
+        return self(image, threshold=threshold)
+
+    def train(self, *a, **k):
+        raise NotImplementedError("FocoosModel.train: data-parallel fine-tuning is SURVEY §8 config 4 (next round)")
+
+    def export(self, *a, **k):
+        raise NotImplementedError("FocoosModel.export: the ONNX/TensorRT export path is out of scope (BASELINE north_star)")
+
+
+class ModelManager:
+    """focoos/model_manager.py:17-155 — lazy family registry + ``get``."""
+
+    _MODEL_MAPPING: Dict[str, Callable[[], Type]] = {"fai_detr": lambda: FAIDetr}
+
+    @classmethod
+    def register_model(cls, model_family: str, model_loader: Callable[[], Type]):
+        cls._MODEL_MAPPING[getattr(model_family, "value", model_family)] = model_loader
+
+    @classmethod
+    def get(cls, name: str, model_info: Optional[ModelInfo] = None, config: Optional[dict] = None, device: str = "cuda:0", seed: int = 0,
+            **kwargs) -> FocoosModel:
+        if model_info is None:
+            if not ModelRegistry.exists(name):
+                raise ValueError(f"⚠️ Model {name} not found")
+            d = ModelRegistry.get_model_info(name)
+            model_info = ModelInfo(**{k: d[k] for k in ("name", "model_family", "classes", "im_size", "task", "config", "weights_uri", "description")})
+        fam = getattr(model_info.model_family, "value", model_info.model_family)
+        if fam not in cls._MODEL_MAPPING:
+            raise ValueError(f"Model {fam} not supported")
+        cfg = dict(model_info.config)
+        if config:
+            cfg.update(config)
+        cfg.update(kwargs)
+        model_info.config = cfg
+        nn = cls._MODEL_MAPPING[fam]()(cfg, device=device, seed=seed)
+        fm = FocoosModel(nn, model_info)
+        if model_info.weights_uri:
+            if not os.path.exists(model_info.weights_uri):
+                raise FileNotFoundError(f"Weights file not found: {model_info.weights_uri}")
+            state = torch.load(model_info.weights_uri, map_location="cpu", weights_only=True)
+            nn.load_state_dict(state.get("model", state) if isinstance(state, dict) else state, strict=False)
+        else:
+            warnings.warn(f"⚠️ Model {model_info.name} has no pretrained weights (offline): seeded synthetic weights (seed={seed})")
+        return fm

@@ -1,0 +1,168 @@
+/* focoos_amd.h — C ABI of libfocoos_amd.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * focoos RT-DETR hot path.
+ *
+ * The reference (FocoosAI/focoos v0.25.0) is 100 % Python: it has NO native FFI for this path
+ * (SURVEY.md §0.1, §8b "B6 proposed C ABI").  Each entry point below therefore names the reference
+ * *Python* function(s) whose arithmetic it replaces (file:line relative to the reference root); the
+ * Python adapter in focoos_amd/ binds these with ctypes and re-exposes the reference's
+ * ModelManager / FAIDetr / DETRProcessor interface (INTEGRATION.md shows the binding).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (the Python host passes
+ *    torch.Tensor.data_ptr()); the library never allocates, frees or retains caller memory;
+ *  - activations are NHWC, bf16 (raw uint16 bits) unless a name says f32/u8/i32; "ld*" arguments are
+ *    the distance in ELEMENTS between consecutive pixels/rows (>= the channel count), so a tensor may
+ *    be a channel slice of a wider (concatenated) buffer;
+ *  - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); every call only
+ *    enqueues work on that stream and is capturable into a hipGraph (fx_graph_*);
+ *  - return value: FX_OK (0) or a negative FX_ERR_* code (fx_error_string()); nothing is swallowed.
+ */
+#ifndef FOCOOS_AMD_H
+#define FOCOOS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FX_ABI_VERSION 1
+
+enum { FX_OK = 0, FX_ERR_INVALID_ARGUMENT = -1, FX_ERR_LAUNCH = -2, FX_ERR_UNSUPPORTED = -3, FX_ERR_RUNTIME = -4 };
+enum { FX_ACT_NONE = 0, FX_ACT_RELU = 1, FX_ACT_SILU = 2, FX_ACT_GELU = 3 };
+
+typedef void* fx_stream_t; /* hipStream_t */
+
+int fx_abi_version(void);
+const char* fx_error_string(int code);
+/* Device sanity: returns FX_OK iff device 0..n has a gfx950 agent; writes CU count / arch name. */
+int fx_device_info(int device, int* cu_count, char* arch_name, int arch_name_len);
+
+/* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM convolution / linear layer on the MFMA matrix cores (bf16 in, fp32 accumulate):
+ *   y[b,ho,wo,n] = act( sum_{kh,kw,c} x[b, ho*stride-pad+kh, wo*stride-pad+kw, c] * w[n,kh,kw,c]
+ *                        + bias[n] + residual[b,ho,wo,n] )
+ * Replaces ConvNormLayer.forward = F.conv2d + eval BatchNorm (folded into w/bias by the host) +
+ * activation (focoos/nn/layers/conv.py:78-98, norm.py:49-57), the residual add + ReLU of
+ * BottleNeck.forward (focoos/nn/backbone/resnet.py:107-121), the avg-pool of the "d" shortcut
+ * (resnet.py:89-100; `pool2`), RepVggBlock/CSPRepLayer adds (fai_detr/modelling.py:39-45,103-107)
+ * and every nn.Linear on the path (H=W=1: x is [M,C] row-major).
+ * w is packed [Npad][KH][KW][C] bf16 with Npad = N rounded up to 128 (zero rows); C % 32 == 0.
+ */
+typedef struct fx_conv_desc {
+  const void* x;        /* bf16 [B,H,W,ldx] */
+  const void* w;        /* bf16 [Npad, KH*KW*C] */
+  const float* bias;    /* f32 [Npad] or NULL */
+  const void* residual; /* bf16 [B,Ho,Wo,ldr] or NULL (added before the activation) */
+  void* y;              /* bf16 (or f32 if out_f32) [B,Ho,Wo,ldy] */
+  int32_t B, H, W, C, ldx;
+  int32_t Ho, Wo, N, ldy, ldr;
+  int32_t KH, KW, stride, pad;
+  int32_t pool2;   /* 1: x is 2x2/2 average-pooled (ceil mode) on the fly; needs KH=KW=1, stride 1 */
+  int32_t act;     /* FX_ACT_* */
+  int32_t out_f32; /* 1: y is float32 */
+  int32_t residual_after_act; /* 0: act(conv+bias+residual) (BottleNeck); 1: act(conv+bias)+residual (CSPRepLayer x_1+x_2) */
+  int64_t y_batch_stride;     /* elements between images of y; 0 = contiguous (Ho*Wo*ldy). Lets a level write its rows of
+                                 the [B, sum(HW), C] decoder memory directly (modelling.py:1158-1165 flatten+concat for free) */
+} fx_conv_desc;
+int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream);
+
+/* Stem: pixel normalisation (x-mean)/std (fai_detr/modelling.py:1349) fused with conv1_1 3x3/s2 +
+ * folded BN + ReLU (focoos/nn/backbone/resnet.py:184-196,253).  x is HWC uint8 (in_f32=0) or HWC
+ * float32 on the 0..255 scale (in_f32=1, output of fx_resize_bilinear_u8).  w: f32 [32][3][3][3]
+ * (n,kh,kw,c) with BN folded, bias f32 [32]; y: bf16 [B,Ho,Wo,32]. */
+int fx_stem_conv3x3s2(const void* x, int in_f32, const float* w, const float* bias, const float* mean,
+                      const float* inv_std, void* y, int B, int H, int W, int Cout, fx_stream_t stream);
+
+/* Processor.get_torch_batch resize (focoos/processor/base_processor.py:285-288):
+ * F.interpolate(bilinear, align_corners=False) of one HWC uint8 image to [Ho,Wo,3] float32. */
+int fx_resize_bilinear_u8(const uint8_t* x, int H, int W, float* y, int Ho, int Wo, fx_stream_t stream);
+
+/* F.max_pool2d(k=3,s=2,p=1) (resnet.py:254) on NHWC bf16. */
+int fx_maxpool3x3s2_nhwc_bf16(const void* x, int ldx, void* y, int ldy, int B, int H, int W, int C, fx_stream_t stream);
+
+/* F.interpolate(mode="bilinear", align_corners=False) to (Ho,Wo) on NHWC bf16
+ * (fai_detr/modelling.py:334,342); writing into a channel slice (ldy) makes torch.concat free. */
+int fx_resize_bilinear_nhwc_bf16(const void* x, int ldx, void* y, int ldy, int B, int H, int W, int C, int Ho, int Wo,
+                                 fx_stream_t stream);
+
+/* out[r,:] = x[r,:] + y[(r % y_rows),:]  (with_pos_embed, modelling.py:918-919, transformer.py:580-581). */
+int fx_add_rows_bf16(const void* x, int ldx, const void* y, int ldy_, int y_rows, void* out, int ldo, int rows, int cols,
+                     fx_stream_t stream);
+
+/* out = LayerNorm(x + residual) * gamma + beta, eps 1e-5, cols == 256 (nn.LayerNorm uses:
+ * modelling.py:940,951,956,1089; transformer.py:592,600).  residual may be NULL. */
+int fx_layernorm_bf16(const void* x, int ldx, const void* residual, int ldr, const float* gamma, const float* beta, void* out,
+                      int ldo, int rows, int cols, fx_stream_t stream);
+
+/* Multi-head softmax attention, head_dim 32 (nn.MultiheadAttention core, modelling.py:938,
+ * transformer.py:589): q,k,v are [B, L, heads*32] bf16 views with row strides ldq/ldk/ldv (already
+ * projected, bias added); out[b,l,h*32+d] bf16.  scale = 1/sqrt(32). */
+int fx_mha_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B, int Lq, int Lk,
+                int heads, fx_stream_t stream);
+
+/* Multi-scale deformable attention sampling — the B4 seam: ms_deform_attn_core_pytorch
+ * (focoos/nn/layers/deformable.py:10-35; bound at fai_detr/modelling.py:806, called :880).
+ * value bf16 [B,S,M*D] (row stride ldv), D=32; spatial_shapes i32 [L][2]=(H,W), level_start i32 [L].
+ * mode 0 ("core"): loc f32 [B,Q,M,L,P,2] in [0,1], attn f32 [B,Q,M,L,P] (already softmaxed).
+ * mode 1 ("fused"): loc = raw sampling_offsets f32 [B,Q,M,L,P,2], attn = raw logits f32 [B,Q,M,L*P],
+ *   ref = f32 [B,Q,4] (cx,cy,w,h); the kernel applies modelling.py:860-874 itself
+ *   (softmax over L*P; loc = ref_xy + off/P * ref_wh * 0.5).
+ * ld_loc / ld_attn: elements between consecutive (b,q) rows of loc / attn (>= M*L*P*2 / M*L*P), so both may be
+ * column slices of one fused projection output.  out bf16 [B,Q,M*D] (row stride ldo). */
+int fx_msda_bf16(const void* value, int ldv, const int32_t* spatial_shapes, const int32_t* level_start, int L, int P,
+                 const float* loc, int ld_loc, const float* attn, int ld_attn, const float* ref, int mode, void* out, int ldo,
+                 int B, int S, int Q, int M, fx_stream_t stream);
+
+/* Row-wise max over the first `cols` columns of an f32 matrix (enc_outputs_class.max(-1), modelling.py:1210). */
+int fx_rowmax_f32(const float* x, int ldx, float* out, int rows, int cols, fx_stream_t stream);
+
+/* torch.topk(scores, k, dim=1) for f32 rows (modelling.py:1214; processor.py:147): for each of B rows
+ * of length n writes the k largest values (descending; ties -> lower index first) and their indices. */
+int fx_topk_rows_f32(const float* scores, int ld, int B, int n, int k, float* out_val, int32_t* out_idx, fx_stream_t stream);
+
+/* out[b,i,:] = src[b, idx[b,i], :] (the three gathers of modelling.py:1216-1229), bf16 rows of `cols`. */
+int fx_gather_rows_bf16(const void* src, int lds, int rows_per_batch, const int32_t* idx, int k, void* out, int ldo, int B, int cols,
+                        fx_stream_t stream);
+
+/* Overwrite rows listed in `rows_idx` (per batch) of a bf16 [B,R,cols] matrix with one constant row
+ * (valid_mask * memory of modelling.py:1202 folded through enc_output: Linear(0)+LN = const). */
+int fx_fill_rows_bf16(void* x, int ldx, int rows_per_batch, const int32_t* rows_idx, int n_idx, const void* row_bf16, int B, int cols,
+                      fx_stream_t stream);
+
+/* First layer of query_pos_head: relu(ref[r,0:4] @ W0^T + b0) -> bf16 [rows, N] (MLP(4,512,256), modelling.py:990,1084). */
+int fx_linear_k4_relu(const float* ref, const float* w, const float* b, void* out, int ldo, int rows, int N, fx_stream_t stream);
+
+/* Last layer of a bbox MLP (256->4) fused with the box update:
+ *  mode 0 (decoder, modelling.py:1003): new_ref = sigmoid(h@W^T + b + inverse_sigmoid(ref)), eps 1e-5
+ *  mode 1 (encoder, modelling.py:1207,1216,1221): unact = h@W^T + b + anchors[idx[r]]; new_ref = sigmoid(unact)
+ * h bf16 [rows,K]; w f32 [4,K]; ref/new_ref f32 [rows,4]; anchors f32 [S,4]; idx i32 [rows] (row -> token). */
+int fx_bbox_head(const void* h, int ldh, const float* w, const float* b, const float* ref, const float* anchors, const int32_t* idx,
+                 int rows_per_batch, int mode, float* new_ref, float* unact_out, int rows, int K, fx_stream_t stream);
+
+/* DETRHead.forward tail (modelling.py:392-397): probs = sigmoid(logits[:, :K]) (compact [rows,K] f32),
+ * boxes_xyxy = cxcywh_to_xyxy(ref) (utils/box.py:14-17). */
+int fx_detr_head_out(const float* logits, int ldl, const float* ref_cxcywh, float* probs, float* boxes_xyxy, int rows, int K,
+                     fx_stream_t stream);
+
+/* DETRProcessor.postprocess on device (fai_detr/processor.py:146-151,183-197) after fx_topk_rows_f32 over
+ * the flattened [Q*K] probabilities: label = idx % K, query = idx / K, box = round(box[query]*(W,H,W,H)) as
+ * int32, count[b] = #scores > threshold (a prefix, scores are sorted).  sizes i32 [B][2] = (H,W). */
+int fx_detr_postprocess(const float* topk_val, const int32_t* topk_idx, const float* boxes_xyxy, const int32_t* sizes, int B, int Q,
+                        int K, int top_k, float threshold, int32_t* labels, int32_t* queries, int32_t* boxes_i32, int32_t* count,
+                        fx_stream_t stream);
+
+/* hipGraph capture of a launch sequence issued on `stream` (HIP graphs instead of a tracing compiler). */
+int fx_graph_begin(fx_stream_t stream);
+int fx_graph_end(fx_stream_t stream, void** graph_exec_out);
+int fx_graph_launch(void* graph_exec, fx_stream_t stream);
+int fx_graph_destroy(void* graph_exec);
+
+/* Timing helper for bench.py: average duration in ms of `iters` graph replays measured with HIP events
+ * recorded on `stream` itself. */
+int fx_graph_time(void* graph_exec, fx_stream_t stream, int iters, float* ms_avg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOCOOS_AMD_H */

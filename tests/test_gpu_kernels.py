@@ -1,0 +1,409 @@
+"""Per-kernel parity of the HIP C-ABI (libfocoos_amd.so) on a real MI355X against CPU fp32 references:
+the oracle's functions where the reference has a named function for the op (ms_deform_attn_core,
+postprocess, inverse_sigmoid ...) and the plain torch op the reference calls otherwise (F.conv2d,
+F.interpolate, F.max_pool2d, F.layer_norm, torch.topk).  All calls go through ctypes -> extern "C"."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from focoos_amd import _lib  # noqa: E402
+from focoos_amd._lib import FX_ACT, FxConvDesc, check  # noqa: E402
+from oracle import detr_oracle as O  # noqa: E402
+from tests._cases import MSDA_SHAPES, msda_case_inputs  # noqa: E402
+from tests.helpers import load_golden  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return _lib.load()
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def bf(t):
+    return t.to(torch.bfloat16)
+
+
+def to_dev(t, dtype=None):
+    return t.to(device=DEV, dtype=dtype or t.dtype).contiguous()
+
+
+def pack_w(W4, bias):
+    N, Cc, KH, KW = W4.shape
+    Np = (N + 127) // 128 * 128
+    w = torch.zeros(Np, KH, KW, Cc)
+    w[:N] = W4.permute(0, 2, 3, 1)
+    b = torch.zeros(Np)
+    if bias is not None:
+        b[:N] = bias
+    return to_dev(w, torch.bfloat16), to_dev(b)
+
+
+def run_conv(lib, x_nhwc, W4, bias, stride=1, act=None, residual=None, res_after=False, pool2=False, out_f32=False, ldx=None, ldy=None,
+             ybs=0, y_buf=None, y_off=0):
+    """x_nhwc: [B,H,W,C] float (will be rounded to bf16). Returns y [B,Ho,Wo,N] float32 (cpu)."""
+    B, H, W, Cc = x_nhwc.shape
+    N, _, KH, KW = W4.shape
+    pad = (KH - 1) // 2
+    Ho, Wo = ((H + 1) // 2, (W + 1) // 2) if pool2 else ((H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1)
+    ldx = ldx or Cc
+    xb = torch.zeros(B, H, W, ldx, dtype=torch.bfloat16)
+    xb[..., :Cc] = bf(x_nhwc)
+    xd = to_dev(xb)
+    wd, bd = pack_w(W4, bias)
+    N8 = (N + 7) // 8 * 8
+    ldy = ldy or N8
+    yd = torch.full((B, Ho, Wo, ldy), float("nan"), dtype=torch.float32 if out_f32 else torch.bfloat16, device=DEV) if y_buf is None else y_buf
+    d = FxConvDesc()
+    d.x, d.w, d.bias, d.y = xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), yd.data_ptr() + y_off * yd.element_size()
+    rd = None
+    if residual is not None:
+        rd = to_dev(bf(residual))
+        d.residual, d.ldr = rd.data_ptr(), residual.shape[-1]
+    d.B, d.H, d.W, d.C, d.ldx = B, H, W, Cc, ldx
+    d.Ho, d.Wo, d.N, d.ldy = Ho, Wo, N, ldy
+    d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+    d.pool2, d.act, d.out_f32, d.residual_after_act, d.y_batch_stride = int(pool2), FX_ACT[act], int(out_f32), int(res_after), ybs
+    check(lib.fx_conv2d_nhwc_bf16(C.byref(d), stream()), "conv")
+    torch.cuda.synchronize()
+    return yd.float().cpu()
+
+
+def ref_conv(x_nhwc, W4, bias, stride=1, act=None, residual=None, res_after=False, pool2=False):
+    x = bf(x_nhwc).float().permute(0, 3, 1, 2)
+    Wq = bf(W4).float()
+    if pool2:
+        x = bf(F.avg_pool2d(x, 2, 2, 0, ceil_mode=True)).float()
+    y = F.conv2d(x, Wq, bias, stride=stride, padding=(W4.shape[-1] - 1) // 2)
+    r = bf(residual).float().permute(0, 3, 1, 2) if residual is not None else None
+    if r is not None and not res_after:
+        y = y + r
+    y = O.apply_act(y, act)
+    if r is not None and res_after:
+        y = y + r
+    return y.permute(0, 2, 3, 1)
+
+
+CONV_CASES = [
+    # B,H,W,C,N,k,stride,act,residual,res_after,pool2,out_f32
+    (2, 20, 20, 64, 256, 1, 1, "relu", True, False, False, False),
+    (1, 24, 40, 128, 128, 3, 1, "relu", False, False, False, False),
+    (2, 16, 16, 128, 128, 3, 2, "relu", False, False, False, False),
+    (1, 13, 9, 256, 512, 1, 1, None, False, False, True, False),     # odd dims: ceil-mode pooled shortcut, M tail
+    (2, 16, 16, 256, 512, 1, 1, None, False, False, True, False),
+    (1, 30, 30, 32, 32, 3, 1, "relu", False, False, False, False),    # stem conv1_2 shape class (BK=32, BN=32)
+    (1, 30, 30, 32, 64, 3, 1, "relu", False, False, False, False),    # stem conv1_3 (BK=32, BN=64)
+    (1, 10, 10, 64, 64, 3, 1, "relu", False, False, False, False),    # BN=64
+    (1, 8, 8, 64, 32, 1, 1, "silu", False, False, False, False),      # BN=32, BK=64
+    (3, 10, 10, 256, 256, 3, 1, "silu", True, True, False, False),    # RepVGG/CSP: act then add
+    (1, 1, 300, 256, 365, 1, 1, None, False, False, False, True),     # score head: N tail, fp32 out
+    (1, 1, 77, 256, 1024, 1, 1, "gelu", False, False, False, False),
+    (1, 1, 200, 1024, 256, 1, 1, None, True, False, False, False),
+    (1, 1, 50, 32, 160, 1, 1, None, False, False, False, False),      # BK=32, BN=128
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_igemm(lib, case):
+    B, H, W, Cc, N, k, stride, act, has_res, res_after, pool2, out_f32 = case
+    g = torch.Generator().manual_seed(100 + CONV_CASES.index(case))
+    x = torch.randn(B, H, W, Cc, generator=g)
+    W4 = torch.randn(N, Cc, k, k, generator=g) / math.sqrt(Cc * k * k)
+    bias = torch.randn(N, generator=g) * 0.5
+    ref0 = ref_conv(x, W4, bias, stride, None, None, False, pool2)
+    res = torch.randn(ref0.shape, generator=g) if has_res else None
+    ref = ref_conv(x, W4, bias, stride, act, res, res_after, pool2)
+    got = run_conv(lib, x, W4, bias, stride, act, res, res_after, pool2, out_f32)[..., :N]
+    tol = 2e-4 if out_f32 else 1.2e-2  # bf16 output rounding is 2^-8 relative
+    err = (got - ref).abs().max() / ref.abs().max()
+    assert err < tol, f"rel err {err}"
+    assert not torch.isnan(got).any()
+
+
+def test_conv_asymmetric_identity(lib):
+    """Transpose-detecting check (guide rule 16): identity activations, asymmetric weights."""
+    Cc, N = 64, 128
+    x = torch.eye(Cc).view(1, 1, Cc, Cc)  # pixel m has a one at channel m
+    W4 = (torch.arange(N * Cc).float().view(N, Cc, 1, 1) % 251) / 64.0
+    got = run_conv(lib, x, W4, None)[0, 0, :, :N]  # [m, n] = W[n, m]
+    assert torch.allclose(got, bf(W4).float().view(N, Cc).t(), atol=0, rtol=2e-2)
+
+
+def test_conv_slices_and_batch_stride(lib):
+    """Reading a channel slice (ldx > C), writing a channel slice of a concat buffer (ldy > N) and a
+    per-image row offset into the [B, S, C] decoder memory (y_batch_stride)."""
+    g = torch.Generator().manual_seed(3)
+    B, H, W, Cc, N = 2, 6, 5, 64, 256
+    x = torch.randn(B, H, W, Cc, generator=g)
+    W4 = torch.randn(N, Cc, 1, 1, generator=g) / 8
+    bias = torch.randn(N, generator=g)
+    ref = ref_conv(x, W4, bias)
+    got = run_conv(lib, x, W4, bias, ldx=96, ldy=512)
+    assert torch.isnan(got[..., N:]).all(), "columns outside the slice must stay untouched"
+    assert (got[..., :N] - ref).abs().max() / ref.abs().max() < 1.2e-2
+    S, start = 100, 17
+    mem = torch.full((B, S, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    run_conv(lib, x, W4, bias, ybs=S * N, y_buf=mem, y_off=start * N)
+    m = mem.float().cpu()
+    assert torch.isnan(m[:, :start]).all() and torch.isnan(m[:, start + H * W:]).all()
+    assert (m[:, start:start + H * W].reshape(B, H, W, N) - ref).abs().max() / ref.abs().max() < 1.2e-2
+
+
+def test_conv_rejects_bad_arguments(lib):
+    d = FxConvDesc()
+    assert lib.fx_conv2d_nhwc_bf16(C.byref(d), stream()) == -1
+    x = torch.zeros(1, 4, 4, 48)
+    with pytest.raises(_lib.FocoosAmdError):
+        run_conv(lib, x, torch.zeros(8, 48, 1, 1), None)  # C % 32 != 0
+
+
+@pytest.mark.parametrize("in_f32", [0, 1])
+def test_stem(lib, in_f32):
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 2, 38, 50
+    img = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    Wt = torch.randn(32, 3, 3, 3, generator=g) * 0.2
+    bias = torch.randn(32, generator=g) * 0.1
+    mean, std = torch.tensor([123.675, 116.28, 103.53]), torch.tensor([58.395, 57.12, 57.375])
+    xin = to_dev(img.float() if in_f32 else img)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.empty(B, Ho, Wo, 32, dtype=torch.bfloat16, device=DEV)
+    wd, bd, md, sd_ = to_dev(Wt.permute(0, 2, 3, 1).contiguous()), to_dev(bias), to_dev(mean), to_dev(1.0 / std)
+    check(lib.fx_stem_conv3x3s2(xin.data_ptr(), in_f32, wd.data_ptr(), bd.data_ptr(), md.data_ptr(), sd_.data_ptr(), y.data_ptr(), B, H, W, 32, stream()))
+    torch.cuda.synchronize()
+    xn = (img.float().permute(0, 3, 1, 2) - mean.view(-1, 1, 1)) / std.view(-1, 1, 1)
+    ref = F.relu(F.conv2d(xn, Wt, bias, stride=2, padding=1)).permute(0, 2, 3, 1)
+    assert (y.float().cpu() - ref).abs().max() / ref.abs().max() < 6e-3
+
+
+@pytest.mark.parametrize("hw", [(480, 600, 640, 640), (50, 37, 64, 96), (64, 64, 64, 64), (130, 70, 32, 32)])
+def test_resize_u8(lib, hw):
+    H, W, Ho, Wo = hw
+    g = torch.Generator().manual_seed(5)
+    img = torch.randint(0, 256, (H, W, 3), generator=g, dtype=torch.uint8)
+    xd = to_dev(img)
+    y = torch.empty(Ho, Wo, 3, dtype=torch.float32, device=DEV)
+    check(lib.fx_resize_bilinear_u8(xd.data_ptr(), H, W, y.data_ptr(), Ho, Wo, stream()))
+    torch.cuda.synchronize()
+    ref = O.get_torch_batch([img.numpy()], (Ho, Wo))[0].permute(1, 2, 0)
+    assert (y.cpu() - ref).abs().max() < 2e-3  # values 0..255, fp32 arithmetic in both
+
+
+@pytest.mark.parametrize("cfg", [(2, 20, 20, 256, 40, 40), (2, 40, 40, 256, 20, 20), (1, 6, 10, 64, 3, 5), (1, 5, 7, 64, 10, 14)])
+def test_resize_nhwc_and_maxpool(lib, cfg):
+    B, H, W, Cc, Ho, Wo = cfg
+    g = torch.Generator().manual_seed(2)
+    x = bf(torch.randn(B, H, W, Cc, generator=g))
+    xd = to_dev(x)
+    y = torch.full((B, Ho, Wo, Cc + 64), float("nan"), dtype=torch.bfloat16, device=DEV)
+    check(lib.fx_resize_bilinear_nhwc_bf16(xd.data_ptr(), Cc, y.data_ptr() + 64 * 2, Cc + 64, B, H, W, Cc, Ho, Wo, stream()))
+    torch.cuda.synchronize()
+    ref = F.interpolate(x.float().permute(0, 3, 1, 2), size=(Ho, Wo), mode="bilinear").permute(0, 2, 3, 1)
+    yc = y.float().cpu()
+    assert torch.isnan(yc[..., :64]).all()
+    assert (yc[..., 64:] - ref).abs().max() < 2e-2
+    Hp, Wp = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    yp = torch.empty(B, Hp, Wp, Cc, dtype=torch.bfloat16, device=DEV)
+    check(lib.fx_maxpool3x3s2_nhwc_bf16(xd.data_ptr(), Cc, yp.data_ptr(), Cc, B, H, W, Cc, stream()))
+    torch.cuda.synchronize()
+    refp = F.max_pool2d(x.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    assert torch.equal(yp.float().cpu(), refp)  # max of bf16 values is exact
+
+
+def test_layernorm_and_add(lib):
+    g = torch.Generator().manual_seed(9)
+    rows = 301
+    x, r = bf(torch.randn(rows, 256, generator=g) * 3), bf(torch.randn(rows, 256, generator=g))
+    gam, bet = torch.rand(256, generator=g) + 0.5, torch.randn(256, generator=g) * 0.1
+    xd, rd, gd, bd = to_dev(x), to_dev(r), to_dev(gam), to_dev(bet)
+    out = torch.empty(rows, 256, dtype=torch.bfloat16, device=DEV)
+    for res in (rd, None):
+        check(lib.fx_layernorm_bf16(xd.data_ptr(), 256, res.data_ptr() if res is not None else None, 256, gd.data_ptr(), bd.data_ptr(), out.data_ptr(),
+                                    256, rows, 256, stream()))
+        torch.cuda.synchronize()
+        ref = F.layer_norm(x.float() + (r.float() if res is not None else 0), (256,), gam, bet, 1e-5)
+        assert (out.float().cpu() - ref).abs().max() < 3e-2
+    pos = bf(torch.randn(43, 256, generator=g))
+    pd_ = to_dev(pos)
+    check(lib.fx_add_rows_bf16(xd.data_ptr(), 256, pd_.data_ptr(), 256, 43, out.data_ptr(), 256, rows, 256, stream()))
+    torch.cuda.synchronize()
+    ref = bf(x.float() + pos.float()[torch.arange(rows) % 43]).float()
+    assert torch.equal(out.float().cpu(), ref)
+
+
+@pytest.mark.parametrize("BL", [(2, 300), (1, 400), (3, 77)])
+def test_mha(lib, BL):
+    B, L = BL
+    g = torch.Generator().manual_seed(4)
+    qkv = bf(torch.randn(B, L, 768, generator=g) * 1.5)
+    d = to_dev(qkv)
+    out = torch.empty(B, L, 256, dtype=torch.bfloat16, device=DEV)
+    check(lib.fx_mha_bf16(d.data_ptr(), 768, d.data_ptr() + 512, 768, d.data_ptr() + 1024, 768, out.data_ptr(), 256, B, L, L, 8, stream()))
+    torch.cuda.synchronize()
+    q, k, v = (t.float().view(B, L, 8, 32).transpose(1, 2) for t in qkv.split(256, -1))
+    att = torch.softmax(q @ k.transpose(-1, -2) / math.sqrt(32), -1)
+    ref = (att @ v).transpose(1, 2).reshape(B, L, 256)
+    assert (out.float().cpu() - ref).abs().max() < 2e-2
+
+
+def test_msda_core_golden_and_fused(lib):
+    """B4 seam: kernel vs the reference's ms_deform_attn_core_pytorch output committed as a golden vector
+    (mode 0), and the fused mode (softmax + location arithmetic of modelling.py:860-874 in-kernel) vs the oracle."""
+    gold = load_golden("msda_core.npz")["out"]
+    value, loc, w = (torch.from_numpy(a) for a in msda_case_inputs())
+    N, S, M, D = value.shape
+    Lq = loc.shape[1]
+    shapes = torch.tensor(MSDA_SHAPES, dtype=torch.int32)
+    starts = torch.tensor([0] + list(np.cumsum([h * w_ for h, w_ in MSDA_SHAPES])[:-1]), dtype=torch.int32)
+    vd = to_dev(bf(value.reshape(N, S, M * D)))
+    out = torch.empty(N, Lq, 256, dtype=torch.bfloat16, device=DEV)
+    ld, wd, sd_, st = to_dev(loc), to_dev(w), to_dev(shapes), to_dev(starts)
+    check(lib.fx_msda_bf16(vd.data_ptr(), 256, sd_.data_ptr(), st.data_ptr(), 3, 4, ld.data_ptr(), 8 * 3 * 4 * 2, wd.data_ptr(), 8 * 3 * 4, None, 0,
+                           out.data_ptr(), 256, N, S, Lq, 8, stream()))
+    torch.cuda.synchronize()
+    ref_bf = O.ms_deform_attn_core(bf(value).float(), MSDA_SHAPES, loc, w)
+    got = out.float().cpu()
+    assert (got - ref_bf).abs().max() < 1.5e-2          # same bf16-rounded values, fp32 math
+    assert (got - torch.from_numpy(gold)).abs().max() < 4e-2  # vs reference golden (fp32 values)
+    # fused mode
+    g = torch.Generator().manual_seed(8)
+    off = torch.randn(N, Lq, M, 3, 4, 2, generator=g) * 2
+    logit = torch.randn(N, Lq, M, 12, generator=g)
+    ref4 = torch.rand(N, Lq, 4, generator=g) * torch.tensor([1.0, 1.0, 0.4, 0.4]) + torch.tensor([0.0, 0.0, 0.02, 0.02])
+    aw = torch.softmax(logit, -1).view(N, Lq, M, 3, 4)
+    locs = ref4[:, :, None, None, None, :2] + off / 4 * ref4[:, :, None, None, None, 2:] * 0.5
+    ref_f = O.ms_deform_attn_core(bf(value).float(), MSDA_SHAPES, locs, aw)
+    cat = to_dev(torch.cat([off.reshape(N, Lq, 192), logit.reshape(N, Lq, 96)], -1))
+    rd = to_dev(ref4)
+    check(lib.fx_msda_bf16(vd.data_ptr(), 256, sd_.data_ptr(), st.data_ptr(), 3, 4, cat.data_ptr(), 288, cat.data_ptr() + 192 * 4, 288, rd.data_ptr(), 1,
+                           out.data_ptr(), 256, N, S, Lq, 8, stream()))
+    torch.cuda.synchronize()
+    assert (out.float().cpu() - ref_f).abs().max() < 1.5e-2
+
+
+@pytest.mark.parametrize("cfg", [(4, 8400, 300), (2, 109500, 300), (3, 1000, 1), (2, 700, 700), (1, 64, 5)])
+def test_topk_exact(lib, cfg):
+    B, n, k = cfg
+    g = torch.Generator().manual_seed(n + k)
+    s = torch.randn(B, n, generator=g)
+    if n == 8400:
+        s[1] = torch.sigmoid(s[1])                       # positive, clustered exponents
+        s[2, ::3] = s[2, 0]                               # massive ties straddling the cut
+        s[3] = 0.25                                       # all equal: lowest indices win
+    sd_ = to_dev(s)
+    val = torch.empty(B, k, dtype=torch.float32, device=DEV)
+    idx = torch.empty(B, k, dtype=torch.int32, device=DEV)
+    check(lib.fx_topk_rows_f32(sd_.data_ptr(), n, B, n, k, val.data_ptr(), idx.data_ptr(), stream()))
+    torch.cuda.synchronize()
+    # reference order: value descending, index ascending among equals (stable sort == that order)
+    order = torch.sort(s, dim=1, descending=True, stable=True).indices[:, :k]
+    assert torch.equal(idx.cpu().long(), order), "indices must be bit-exact"
+    assert torch.equal(val.cpu(), s.gather(1, order))
+    tv = torch.topk(s, k, dim=1).values
+    assert torch.equal(val.cpu(), tv)  # same multiset of values as torch.topk (modelling.py:1214)
+
+
+def test_rowmax_gather_fill(lib):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1000, 368, generator=g)
+    xd = to_dev(x)
+    out = torch.empty(1000, dtype=torch.float32, device=DEV)
+    check(lib.fx_rowmax_f32(xd.data_ptr(), 368, out.data_ptr(), 1000, 365, stream()))
+    src = bf(torch.randn(2, 50, 256, generator=g))
+    idx = torch.randint(0, 50, (2, 7), generator=g, dtype=torch.int32)
+    sd_, idd = to_dev(src), to_dev(idx)
+    got = torch.empty(2, 7, 256, dtype=torch.bfloat16, device=DEV)
+    check(lib.fx_gather_rows_bf16(sd_.data_ptr(), 256, 50, idd.data_ptr(), 7, got.data_ptr(), 256, 2, 256, stream()))
+    rows = to_dev(torch.tensor([3, 49], dtype=torch.int32))
+    rowv = to_dev(bf(torch.arange(256).float()))
+    check(lib.fx_fill_rows_bf16(sd_.data_ptr(), 256, 50, rows.data_ptr(), 2, rowv.data_ptr(), 2, 256, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(out.cpu(), x[:, :365].max(-1).values)
+    assert torch.equal(got.cpu(), src.gather(1, idx.long()[..., None].expand(-1, -1, 256)))
+    filled = sd_.cpu()
+    assert torch.equal(filled[:, 3], rowv.cpu().expand(2, -1)) and torch.equal(filled[:, 49], rowv.cpu().expand(2, -1))
+    assert torch.equal(filled[:, 4], src[:, 4])
+
+
+def test_decoder_small_heads(lib):
+    g = torch.Generator().manual_seed(6)
+    rows = 601
+    ref = torch.rand(rows, 4, generator=g)
+    ref[0] = torch.tensor([0.0, 1.0, 1e-7, 0.5])  # inverse_sigmoid clamps (functional.py:4-6)
+    W0, b0 = torch.randn(512, 4, generator=g), torch.randn(512, generator=g)
+    out = torch.empty(rows, 512, dtype=torch.bfloat16, device=DEV)
+    rd, wd, bd = to_dev(ref), to_dev(W0), to_dev(b0)
+    check(lib.fx_linear_k4_relu(rd.data_ptr(), wd.data_ptr(), bd.data_ptr(), out.data_ptr(), 512, rows, 512, stream()))
+    torch.cuda.synchronize()
+    r0 = F.relu(F.linear(ref, W0, b0))
+    assert (out.float().cpu() - r0).abs().max() / r0.abs().max() < 6e-3
+    h = bf(torch.randn(rows, 256, generator=g))
+    W2, b2 = torch.randn(4, 256, generator=g) / 16, torch.randn(4, generator=g) * 0.1
+    hd, w2d, b2d = to_dev(h), to_dev(W2), to_dev(b2)
+    new = torch.empty(rows, 4, dtype=torch.float32, device=DEV)
+    check(lib.fx_bbox_head(hd.data_ptr(), 256, w2d.data_ptr(), b2d.data_ptr(), rd.data_ptr(), None, None, 300, 0, new.data_ptr(), None, rows, 256, stream()))
+    torch.cuda.synchronize()
+    r1 = torch.sigmoid(F.linear(h.float(), W2, b2) + O.inverse_sigmoid(ref))
+    assert (new.cpu() - r1).abs().max() < 2e-5
+    anchors = torch.randn(50, 4, generator=g)
+    idx = torch.randint(0, 50, (rows,), generator=g, dtype=torch.int32)
+    ad, idd = to_dev(anchors), to_dev(idx)
+    un = torch.empty(rows, 4, dtype=torch.float32, device=DEV)
+    check(lib.fx_bbox_head(hd.data_ptr(), 256, w2d.data_ptr(), b2d.data_ptr(), None, ad.data_ptr(), idd.data_ptr(), 300, 1, new.data_ptr(), un.data_ptr(), rows, 256,
+                           stream()))
+    torch.cuda.synchronize()
+    u = F.linear(h.float(), W2, b2) + anchors[idx.long()]
+    assert (un.cpu() - u).abs().max() < 2e-5 and (new.cpu() - torch.sigmoid(u)).abs().max() < 2e-5
+
+
+def test_head_out_and_postprocess_vs_oracle(lib):
+    g = torch.Generator().manual_seed(12)
+    B, Q, K = 3, 300, 365
+    logits = torch.randn(B * Q, 368, generator=g) * 2 - 4
+    refb = torch.rand(B * Q, 4, generator=g) * torch.tensor([1.0, 1.0, 0.5, 0.5])
+    ld, rd = to_dev(logits), to_dev(refb)
+    probs = torch.empty(B, Q, K, dtype=torch.float32, device=DEV)
+    boxes = torch.empty(B, Q, 4, dtype=torch.float32, device=DEV)
+    check(lib.fx_detr_head_out(ld.data_ptr(), 368, rd.data_ptr(), probs.data_ptr(), boxes.data_ptr(), B * Q, K, stream()))
+    torch.cuda.synchronize()
+    p_ref = torch.sigmoid(logits[:, :K]).view(B, Q, K)
+    b_ref = O.box_cxcywh_to_xyxy(refb).view(B, Q, 4)
+    assert (probs.cpu() - p_ref).abs().max() < 1e-6 and (boxes.cpu() - b_ref).abs().max() < 1e-6
+    # device post-process on the *oracle's* probabilities/boxes -> indices and integer boxes must be bit-exact
+    sizes = [(480, 640), (640, 640), (333, 517)]
+    thr = 0.35
+    pd_, bd_ = to_dev(p_ref), to_dev(b_ref)
+    val = torch.empty(B, 300, dtype=torch.float32, device=DEV)
+    idx = torch.empty(B, 300, dtype=torch.int32, device=DEV)
+    lab, qq = torch.empty_like(idx), torch.empty_like(idx)
+    ob = torch.empty(B, 300, 4, dtype=torch.int32, device=DEV)
+    cnt = torch.empty(B, dtype=torch.int32, device=DEV)
+    sz = to_dev(torch.tensor(sizes, dtype=torch.int32))
+    check(lib.fx_topk_rows_f32(pd_.data_ptr(), Q * K, B, Q * K, 300, val.data_ptr(), idx.data_ptr(), stream()))
+    check(lib.fx_detr_postprocess(val.data_ptr(), idx.data_ptr(), bd_.data_ptr(), sz.data_ptr(), B, Q, K, 300, thr, lab.data_ptr(), qq.data_ptr(), ob.data_ptr(),
+                                  cnt.data_ptr(), stream()))
+    torch.cuda.synchronize()
+    ref = O.postprocess(p_ref, b_ref, sizes, 300, thr)
+    for i, (s, l, q, bp) in enumerate(ref):
+        n = int(cnt[i])
+        assert n == len(s) and n > 0
+        assert torch.equal(val[i, :n].cpu(), s)
+        assert torch.equal(lab[i, :n].cpu().long(), l) and torch.equal(qq[i, :n].cpu().long(), q)
+        assert torch.equal(ob[i, :n].cpu(), bp)
+
+
+def test_library_exports_and_device(lib):
+    cu, arch = C.c_int(0), C.create_string_buffer(64)
+    check(lib.fx_device_info(0, C.byref(cu), arch, 64))
+    assert arch.value.decode().startswith("gfx950") and cu.value >= 200
