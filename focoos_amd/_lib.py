@@ -70,6 +70,7 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    import torch  # noqa: F401  -- must be imported first: it loads the HIP runtime (its bundled libamdhip64) our .so binds to
     path = lib_path()
     if not os.path.exists(path):
         raise FocoosAmdError(

@@ -13,6 +13,10 @@
 // BK divides C.  Zero padding / M tails are predicated loads.
 #include "common.h"
 
+#ifndef FX_K64_MIN_KTOT
+#define FX_K64_MIN_KTOT 1024
+#endif
+
 struct ConvArgs {
   const bf16_t* x;
   const bf16_t* w;
@@ -24,7 +28,8 @@ struct ConvArgs {
   int KH, KW, stride, pad;
   int act, out_f32, res_after;
   int M, Ktot, nNt, Nstore;
-  int64_t y_bstride;  // 0: contiguous
+  unsigned x_bytes, w_bytes, r_bytes;  // buffer sizes for the bounds-checked buffer loads (< 4 GiB)
+  int64_t y_bstride;          // 0: contiguous
 };
 
 template <int BK>
@@ -34,8 +39,15 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * (BK * 2) + ((chunk ^ ((row / R) & (CPR - 1))) << 4);
 }
 
+// 16-byte buffer load: out-of-range offsets (>= num_records) return zeros without touching memory,
+// which gives zero padding / M-tail predication for free (one v_cndmask on the offset).
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+#define FX_OOB 0xFFFFFFF0u
+
 template <int BM, int BN, int BK, int WM, int WN, bool POOL>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void conv_igemm_kernel(const ConvArgs p) {
   constexpr int CPR = BK / 8, RPP = 256 / CPR;
   constexpr int A_PASS = BM / RPP, B_PASS = (BN + RPP - 1) / RPP;
   constexpr int WTM = BM / WM, WTN = BN / WN, TM = WTM / 32, TN = WTN / 32;
@@ -51,8 +63,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
   const int mt = bid / p.nNt, nt = bid % p.nNt;
   const int m0 = mt * BM, n0 = nt * BN;
 
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
+
   const int kc = tid % CPR, r_in = tid / CPR;
-  int a_hi0[A_PASS], a_wi0[A_PASS], a_pix[A_PASS];
+  int a_hi0[A_PASS], a_wi0[A_PASS], a_off[A_PASS];  // a_off: element offset of (b, hi0, wi0, kc*8); may be "before" the row, fixed by delta
   bool a_ok[A_PASS];
   const int HoWo = p.Ho * p.Wo;
 #pragma unroll
@@ -62,65 +77,73 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
     int mm = a_ok[i] ? m : 0;
     int b = mm / HoWo, rem = mm - b * HoWo;
     int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-    a_hi0[i] = ho * p.stride - p.pad;
-    a_wi0[i] = wo * p.stride - p.pad;
-    a_pix[i] = b * p.H * p.W;
+    if constexpr (POOL) {
+      a_hi0[i] = ho * 2;
+      a_wi0[i] = wo * 2;
+    } else {
+      a_hi0[i] = ho * p.stride - p.pad;
+      a_wi0[i] = wo * p.stride - p.pad;
+    }
+    a_off[i] = ((b * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.ldx + kc * 8;
   }
-  const bf16_t* wrow[B_PASS];
+  unsigned w_off[B_PASS];
 #pragma unroll
-  for (int i = 0; i < B_PASS; ++i) wrow[i] = p.w + (int64_t)(n0 + r_in + i * RPP) * p.Ktot + kc * 8;
+  for (int i = 0; i < B_PASS; ++i) w_off[i] = (unsigned)(((n0 + r_in + i * RPP) * p.Ktot + kc * 8) * 2);
 
   uint4 ra[A_PASS], rb[B_PASS];
-  const uint4 zero4 = make_uint4(0, 0, 0, 0);
 
-  auto load_tiles = [&](int kh, int kw, int c0, int kbase) {
-#pragma unroll
-    for (int i = 0; i < A_PASS; ++i) {
-      if constexpr (!POOL) {
-        int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;
-        bool ok = a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-        const bf16_t* src = p.x + (int64_t)(a_pix[i] + hi * p.W + wi) * p.ldx + c0 + kc * 8;
-        ra[i] = ok ? *reinterpret_cast<const uint4*>(src) : zero4;
-      } else {
-        // 2x2/2 average pool (ceil mode: average over the in-bounds taps) of the source, on the fly
-        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        int cnt = 0;
-#pragma unroll
-        for (int dy = 0; dy < 2; ++dy)
-#pragma unroll
-          for (int dx = 0; dx < 2; ++dx) {
-            int hi = a_hi0[i] * 2 + dy, wi = a_wi0[i] * 2 + dx;
-            bool ok = a_ok[i] && hi < p.H && wi < p.W;
-            if (ok) {
-              const bf16_t* src = p.x + (int64_t)(a_pix[i] + hi * p.W + wi) * p.ldx + c0 + kc * 8;
-              uint4 v = *reinterpret_cast<const uint4*>(src);
-              float f[8];
-              unpack_bf16x8(v, f);
-#pragma unroll
-              for (int j = 0; j < 8; ++j) s[j] += f[j];
-              ++cnt;
-            }
-          }
-        float inv = cnt > 0 ? 1.0f / (float)cnt : 0.0f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] *= inv;
-        ra[i] = pack_bf16x8(s);
-      }
-    }
-#pragma unroll
-    for (int i = 0; i < B_PASS; ++i) {
-      if (BN % RPP == 0 || r_in + i * RPP < BN) rb[i] = *reinterpret_cast<const uint4*>(wrow[i] + kbase);
-    }
-  };
-  auto store_tiles = [&](int s) {
-    unsigned char* A = smem + s * STAGE;
-    unsigned char* Bm = A + A_BYTES;
-#pragma unroll
-    for (int i = 0; i < A_PASS; ++i) *reinterpret_cast<uint4*>(A + lds_off<BK>(r_in + i * RPP, kc)) = ra[i];
-#pragma unroll
-    for (int i = 0; i < B_PASS; ++i)
-      if (BN % RPP == 0 || r_in + i * RPP < BN) *reinterpret_cast<uint4*>(Bm + lds_off<BK>(r_in + i * RPP, kc)) = rb[i];
-  };
+#define FX_LOAD_TILES(KH_, KW_, C0_, KBASE_)                                                                         \
+  {                                                                                                                  \
+    const int delta_ = ((KH_)*p.W + (KW_)) * p.ldx + (C0_);                                                          \
+    _Pragma("unroll") for (int i = 0; i < A_PASS; ++i) {                                                             \
+      if constexpr (!POOL) {                                                                                         \
+        int hi = a_hi0[i] + (KH_), wi = a_wi0[i] + (KW_);                                                            \
+        bool ok = a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;                           \
+        ra[i] = buf_load16(xr, ok ? (unsigned)(a_off[i] + delta_) * 2u : FX_OOB);                                     \
+      } else {                                                                                                       \
+        float s_[8] = {0, 0, 0, 0, 0, 0, 0, 0};                                                                      \
+        int cnt_ = 0;                                                                                                \
+        _Pragma("unroll") for (int dy = 0; dy < 2; ++dy) _Pragma("unroll") for (int dx = 0; dx < 2; ++dx) {          \
+          bool ok = a_ok[i] && (a_hi0[i] + dy) < p.H && (a_wi0[i] + dx) < p.W;                                       \
+          uint4 v_ = buf_load16(xr, ok ? (unsigned)(a_off[i] + delta_ + (dy * p.W + dx) * p.ldx) * 2u : FX_OOB);      \
+          float f_[8];                                                                                               \
+          unpack_bf16x8(v_, f_);                                                                                     \
+          _Pragma("unroll") for (int j = 0; j < 8; ++j) s_[j] += f_[j];                                              \
+          cnt_ += ok ? 1 : 0;                                                                                        \
+        }                                                                                                            \
+        float inv_ = cnt_ > 0 ? 1.0f / (float)cnt_ : 0.0f;                                                           \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) s_[j] *= inv_;                                                 \
+        ra[i] = pack_bf16x8(s_);                                                                                     \
+      }                                                                                                              \
+    }                                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < B_PASS; ++i) {                                                             \
+      if (BN % RPP == 0 || r_in + i * RPP < BN) rb[i] = buf_load16(wr, w_off[i] + (unsigned)(KBASE_)*2u);            \
+    }                                                                                                                \
+  }
+#define FX_STORE_TILES(S_)                                                                                           \
+  {                                                                                                                  \
+    unsigned char* A_ = smem + (S_)*STAGE;                                                                           \
+    unsigned char* B_ = A_ + A_BYTES;                                                                                \
+    _Pragma("unroll") for (int i = 0; i < A_PASS; ++i) *reinterpret_cast<uint4*>(A_ + lds_off<BK>(r_in + i * RPP, kc)) = ra[i]; \
+    _Pragma("unroll") for (int i = 0; i < B_PASS; ++i) {                                                             \
+      if (BN % RPP == 0 || r_in + i * RPP < BN) *reinterpret_cast<uint4*>(B_ + lds_off<BK>(r_in + i * RPP, kc)) = rb[i]; \
+    }                                                                                                                \
+  }
+#define FX_COMPUTE(S_)                                                                                               \
+  {                                                                                                                  \
+    const unsigned char* A_ = smem + (S_)*STAGE;                                                                     \
+    const unsigned char* B_ = A_ + A_BYTES;                                                                          \
+    _Pragma("unroll") for (int kk = 0; kk < BK / 16; ++kk) {                                                         \
+      const int chunk = kk * 2 + lhalf;                                                                              \
+      bf16x8 xa[TM], wb[TN];                                                                                         \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) xa[i] =                                                         \
+          *reinterpret_cast<const bf16x8*>(A_ + lds_off<BK>(wm * WTM + i * 32 + lrow, chunk));                       \
+      _Pragma("unroll") for (int i = 0; i < TN; ++i) wb[i] =                                                         \
+          *reinterpret_cast<const bf16x8*>(B_ + lds_off<BK>(wn * WTN + i * 32 + lrow, chunk));                       \
+      _Pragma("unroll") for (int a = 0; a < TN; ++a) _Pragma("unroll") for (int b = 0; b < TM; ++b) acc[a][b] =      \
+          __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[a], xa[b], acc[a][b], 0, 0, 0);                                 \
+    }                                                                                                                \
+  }
 
   f32x16 acc[TN][TM];
 #pragma unroll
@@ -130,117 +153,124 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(const ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-  const int steps_per_tap = p.C / BK;
-  const int T = p.KH * p.KW * steps_per_tap;
-  int kh = 0, kw = 0, c0 = 0, kbase = 0;
-  load_tiles(kh, kw, c0, kbase);
-  store_tiles(0);
-  __syncthreads();
-
+  const int T = p.KH * p.KW * (p.C / BK);
   const int lrow = lane & 31, lhalf = lane >> 5;
-  for (int t = 0; t < T; ++t) {
+  int kh = 0, kw = 0, c0 = 0, kbase = 0;
+  FX_LOAD_TILES(kh, kw, c0, kbase);
+  FX_STORE_TILES(0);
+  __syncthreads();
+  for (int t = 0; t < T - 1; ++t) {
     const int cur = t & 1;
-    const bool more = (t + 1 < T);
-    if (more) {
-      c0 += BK;
-      kbase += BK;
-      if (c0 == p.C) {
-        c0 = 0;
-        if (++kw == p.KW) { kw = 0; ++kh; }
+    c0 += BK;
+    kbase += BK;
+    if (c0 == p.C) {
+      c0 = 0;
+      if (++kw == p.KW) {
+        kw = 0;
+        ++kh;
       }
-      load_tiles(kh, kw, c0, kbase);
     }
-    const unsigned char* A = smem + cur * STAGE;
-    const unsigned char* Bm = A + A_BYTES;
+    FX_LOAD_TILES(kh, kw, c0, kbase);  // next tile's global loads fly under this tile's MFMAs
+    FX_COMPUTE(cur);
+    FX_STORE_TILES(cur ^ 1);
+    __syncthreads();
+  }
+  // The residual tile is independent of the GEMM: fetch it now (into the registers the tile prefetch no longer
+  // needs) so its latency hides under the last MFMA block and the LDS staging instead of serialising the epilogue.
+  constexpr int TPR = BN / 8, RPP2 = 256 / TPR, HALF = 64, PER_HALF = HALF / RPP2, NRES = BM / RPP2;
+  const int col8 = (tid % TPR) * 8;
+  const int n = n0 + col8;
+  const bool n_ok = n < p.Nstore;
+  uint4 rres[NRES];
+  if (p.res) {
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, p.r_bytes, 0x00020000);
 #pragma unroll
-    for (int kk = 0; kk < BK / 16; ++kk) {
-      const int chunk = kk * 2 + lhalf;
-      bf16x8 xa[TM], wb[TN];
+    for (int q = 0; q < NRES; ++q) {
+      const int m = m0 + (q / PER_HALF) * HALF + tid / TPR + (q % PER_HALF) * RPP2;
+      rres[q] = buf_load16(rr, (m < p.M && n_ok) ? (unsigned)(m * p.ldr + n) * 2u : FX_OOB);
+    }
+  }
+  FX_COMPUTE((T - 1) & 1);
+  __syncthreads();
+#undef FX_LOAD_TILES
+#undef FX_STORE_TILES
+#undef FX_COMPUTE
+
+  // ---- epilogue: accumulators -> LDS (fp32, 64 rows at a time) -> coalesced 16-byte channel vectors
+  float* stg = reinterpret_cast<float*>(smem);
+  float bs[8];
+  if (p.bias && n_ok) {
+    float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
+    bs[0] = b0.x; bs[1] = b0.y; bs[2] = b0.z; bs[3] = b0.w; bs[4] = b1.x; bs[5] = b1.y; bs[6] = b1.z; bs[7] = b1.w;
+  } else {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(A + lds_off<BK>(wm * WTM + i * 32 + lrow, chunk));
+    for (int j = 0; j < 8; ++j) bs[j] = 0.0f;
+  }
 #pragma unroll
-      for (int i = 0; i < TN; ++i) wb[i] = *reinterpret_cast<const bf16x8*>(Bm + lds_off<BK>(wn * WTN + i * 32 + lrow, chunk));
+  for (int hh = 0; hh < BM / HALF; ++hh) {
+    if ((wm * WTM) / HALF == hh) {
 #pragma unroll
       for (int a = 0; a < TN; ++a)
 #pragma unroll
-        for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[a], xa[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < TM; ++b)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            int ml = wm * WTM + b * 32 + lrow - hh * HALF;
+            int nl = wn * WTN + a * 32 + 8 * g + 4 * lhalf;
+            float4 v = make_float4(acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]);
+            *reinterpret_cast<float4*>(stg + ml * EPI_LD + nl) = v;
+          }
     }
-    if (more) store_tiles(cur ^ 1);
     __syncthreads();
-  }
-
-  // ---- epilogue: accumulators -> LDS (fp32) -> coalesced 16-byte channel vectors
-  float* stg = reinterpret_cast<float*>(smem);
 #pragma unroll
-  for (int a = 0; a < TN; ++a)
+    for (int j = 0; j < PER_HALF; ++j) {
+      const int r = tid / TPR + j * RPP2;
+      const int m = m0 + hh * HALF + r;
+      if (m < p.M && n_ok) {
+        float4 v0 = *reinterpret_cast<const float4*>(stg + r * EPI_LD + col8);
+        float4 v1 = *reinterpret_cast<const float4*>(stg + r * EPI_LD + col8 + 4);
+        float v[8] = {v0.x + bs[0], v0.y + bs[1], v0.z + bs[2], v0.w + bs[3], v1.x + bs[4], v1.y + bs[5], v1.z + bs[6], v1.w + bs[7]};
+        float rf[8];
+        if (p.res) {
+          unpack_bf16x8(rres[hh * PER_HALF + j], rf);
+          if (!p.res_after) {
 #pragma unroll
-    for (int b = 0; b < TM; ++b)
+            for (int i = 0; i < 8; ++i) v[i] += rf[i];
+          }
+        }
+        if (p.act != FX_ACT_NONE) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        int ml = wm * WTM + b * 32 + lrow;
-        int nl = wn * WTN + a * 32 + 8 * g + 4 * lhalf;
-        float4 v = make_float4(acc[a][b][4 * g], acc[a][b][4 * g + 1], acc[a][b][4 * g + 2], acc[a][b][4 * g + 3]);
-        *reinterpret_cast<float4*>(stg + ml * EPI_LD + nl) = v;
-      }
-  __syncthreads();
-  constexpr int TPR = BN / 8, RPP2 = 256 / TPR;
-  const int col8 = (tid % TPR) * 8;
-  const int n = n0 + col8;
-  if (n < p.Nstore) {
-    float bs[8];
-    if (p.bias) {
-      float4 b0 = *reinterpret_cast<const float4*>(p.bias + n), b1 = *reinterpret_cast<const float4*>(p.bias + n + 4);
-      bs[0] = b0.x; bs[1] = b0.y; bs[2] = b0.z; bs[3] = b0.w; bs[4] = b1.x; bs[5] = b1.y; bs[6] = b1.z; bs[7] = b1.w;
-    } else {
+          for (int i = 0; i < 8; ++i) v[i] = fx_act(v[i], p.act);
+        }
+        if (p.res && p.res_after) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) bs[j] = 0.0f;
-    }
-    for (int r = tid / TPR; r < BM; r += RPP2) {
-      int m = m0 + r;
-      if (m >= p.M) break;
-      float4 v0 = *reinterpret_cast<const float4*>(stg + r * EPI_LD + col8);
-      float4 v1 = *reinterpret_cast<const float4*>(stg + r * EPI_LD + col8 + 4);
-      float v[8] = {v0.x + bs[0], v0.y + bs[1], v0.z + bs[2], v0.w + bs[3], v1.x + bs[4], v1.y + bs[5], v1.z + bs[6], v1.w + bs[7]};
-      float rf[8];
-      if (p.res) {
-        uint4 rv = *reinterpret_cast<const uint4*>(p.res + (int64_t)m * p.ldr + n);
-        unpack_bf16x8(rv, rf);
-        if (!p.res_after) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += rf[j];
+          for (int i = 0; i < 8; ++i) v[i] += rf[i];
+        }
+        int64_t yoff;
+        if (p.y_bstride) {
+          int bb = m / HoWo;
+          yoff = (int64_t)bb * p.y_bstride + (int64_t)(m - bb * HoWo) * p.ldy + n;
+        } else {
+          yoff = (int64_t)m * p.ldy + n;
+        }
+        if (p.out_f32) {
+          float* dst = reinterpret_cast<float*>(p.y) + yoff;
+          *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          bf16_t* dst = reinterpret_cast<bf16_t*>(p.y) + yoff;
+          *reinterpret_cast<uint4*>(dst) = pack_bf16x8(v);
         }
       }
-      if (p.act != FX_ACT_NONE) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = fx_act(v[j], p.act);
-      }
-      if (p.res && p.res_after) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += rf[j];
-      }
-      int64_t yoff;
-      if (p.y_bstride) {
-        int bb = m / HoWo;
-        yoff = (int64_t)bb * p.y_bstride + (int64_t)(m - bb * HoWo) * p.ldy + n;
-      } else {
-        yoff = (int64_t)m * p.ldy + n;
-      }
-      if (p.out_f32) {
-        float* dst = reinterpret_cast<float*>(p.y) + yoff;
-        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
-      } else {
-        bf16_t* dst = reinterpret_cast<bf16_t*>(p.y) + yoff;
-        *reinterpret_cast<uint4*>(dst) = pack_bf16x8(v);
-      }
     }
+    if (hh + 1 < BM / HALF) __syncthreads();
   }
 }
 
 template <int BM, int BN, int BK, int WM, int WN, bool POOL>
 static int launch_conv(ConvArgs& a, hipStream_t stream) {
   constexpr int STAGE = (BM + BN) * BK * 2;
-  constexpr int EPI = BM * (BN + 4) * 4;
+  constexpr int EPI = 64 * (BN + 4) * 4;  // the epilogue stages 64 rows at a time
   constexpr int SMEM = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
   static bool attr_set = false;
   auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, POOL>;
@@ -275,6 +305,12 @@ extern "C" int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream_) {
     FX_CHECK_ARG(d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1);
   }
   if ((int64_t)d->B * d->H * d->W >= (1ll << 31) || (int64_t)d->B * d->Ho * d->Wo >= (1ll << 31)) return FX_ERR_UNSUPPORTED;
+  // 32-bit byte offsets in the buffer loads: activation / weight views must stay below 4 GiB
+  const int64_t x_bytes = ((int64_t)d->B * d->H * d->W - 1) * d->ldx * 2 + (int64_t)d->C * 2;
+  const int64_t Npad = (int64_t)(d->N + 127) / 128 * 128;
+  const int64_t w_bytes = Npad * d->KH * d->KW * d->C * 2;
+  const int64_t r_bytes = d->residual ? (((int64_t)d->B * d->Ho * d->Wo - 1) * d->ldr + Nstore) * 2 : 0;
+  if (x_bytes >= 0xFFFFFFF0ll || w_bytes >= 0xFFFFFFF0ll || r_bytes >= 0xFFFFFFF0ll) return FX_ERR_UNSUPPORTED;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   ConvArgs a;
   a.x = reinterpret_cast<const bf16_t*>(d->x);
@@ -292,9 +328,14 @@ extern "C" int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream_) {
   a.Ktot = d->KH * d->KW * d->C;
   a.Nstore = Nstore;
   a.nNt = 0;
-  const bool k64 = (d->C % 64 == 0);
+  a.x_bytes = (unsigned)x_bytes;
+  a.w_bytes = (unsigned)w_bytes;
+  a.r_bytes = (unsigned)r_bytes;
+  // BK=64 (2 workgroups/CU, 64 KiB LDS) for deep-K compute-bound layers; BK=32 (4 workgroups/CU, 34 KiB LDS: more
+  // tiles and bytes in flight per CU) for the short-K layers, which are HBM/latency-bound.
+  const bool k64 = (d->C % 64 == 0) && (a.Ktot >= FX_K64_MIN_KTOT);
   if (d->pool2) {
-    if (!k64) return FX_ERR_UNSUPPORTED;
+    if (d->C % 64 != 0) return FX_ERR_UNSUPPORTED;
     return launch_conv<128, 128, 64, 2, 2, true>(a, stream);
   }
   if (k64) {

@@ -5,60 +5,53 @@
 
 // ------------------------------------------------------------------------------------------------
 // Stem: (x-mean)*inv_std  ->  3x3/s2/p1 conv (3 -> 32)  ->  +bias (BN folded)  ->  ReLU  -> bf16 NHWC.
-// One lane = one output pixel x 32 channels; the 27x32 fp32 weights live in LDS and are read as
-// broadcast float4 (all lanes same address).  Zero padding applies to the NORMALISED image
-// (reference pads after normalising), i.e. padded taps contribute nothing.
+// Four lanes per output pixel, 8 output channels each: the 27 normalised taps + 8 fp32 accumulators live in
+// registers, the [27][32] fp32 weight table sits in LDS and is read as float4 (4 distinct addresses per
+// wave instruction -> conflict-free broadcast), and the wave stores 16 pixels x 64 B = 1 KiB contiguous.
+// Zero padding applies to the NORMALISED image (the reference pads after normalising): padded taps add 0.
 template <typename TIn>
-__global__ __launch_bounds__(256) void stem_conv_kernel(const TIn* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void stem_conv_kernel(const TIn* __restrict__ x, const float* __restrict__ wt /*[27][32]*/,
                                                          const float* __restrict__ bias, const float* __restrict__ mean,
                                                          const float* __restrict__ inv_std, bf16_t* __restrict__ y, int B, int H,
                                                          int W, int Ho, int Wo) {
-  __shared__ __attribute__((aligned(16))) float ws[27 * 32];  // [tap(kh,kw,c)][n]
-  __shared__ float bs[32];
-  for (int i = threadIdx.x; i < 27 * 32; i += 256) {
-    int n = i & 31, tap = i >> 5;  // w is [n][kh][kw][c] = [n][tap]
-    ws[i] = w[n * 27 + tap];
-  }
-  if (threadIdx.x < 32) bs[threadIdx.x] = bias[threadIdx.x];
+  __shared__ __attribute__((aligned(16))) float ws[27 * 32];
+  for (int i = threadIdx.x; i < 27 * 32; i += 256) ws[i] = wt[i];
   __syncthreads();
   const int total = B * Ho * Wo;
-  float mu[3] = {mean[0], mean[1], mean[2]}, is[3] = {inv_std[0], inv_std[1], inv_std[2]};
-  for (int o = blockIdx.x * 256 + threadIdx.x; o < total; o += gridDim.x * 256) {
-    int b = o / (Ho * Wo), rem = o - b * Ho * Wo;
-    int ho = rem / Wo, wo = rem - ho * Wo;
-    float acc[32];
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  const int o = gid >> 2, cg = gid & 3;
+  if (o >= total) return;
+  const int b = o / (Ho * Wo), rem = o - b * Ho * Wo;
+  const int ho = rem / Wo, wo = rem - ho * Wo;
+  const float m0 = mean[0], m1 = mean[1], m2 = mean[2], s0 = inv_std[0], s1 = inv_std[1], s2 = inv_std[2];
+  float acc[8];
+  {
+    float4 b0 = *reinterpret_cast<const float4*>(bias + cg * 8), b1 = *reinterpret_cast<const float4*>(bias + cg * 8 + 4);
+    acc[0] = b0.x; acc[1] = b0.y; acc[2] = b0.z; acc[3] = b0.w; acc[4] = b1.x; acc[5] = b1.y; acc[6] = b1.z; acc[7] = b1.w;
+  }
+#pragma unroll 1
+  for (int kh = 0; kh < 3; ++kh) {
+    const int hi = ho * 2 - 1 + kh;
+    const int hc = min(max(hi, 0), H - 1);
 #pragma unroll
-    for (int n = 0; n < 32; ++n) acc[n] = bs[n];
+    for (int kw = 0; kw < 3; ++kw) {
+      const int wi = wo * 2 - 1 + kw;
+      const int wc = min(max(wi, 0), W - 1);
+      const bool ok = (hi == hc) && (wi == wc);
+      const TIn* px = x + ((int64_t)(b * H + hc) * W + wc) * 3;
+      float v[3] = {ok ? ((float)px[0] - m0) * s0 : 0.0f, ok ? ((float)px[1] - m1) * s1 : 0.0f, ok ? ((float)px[2] - m2) * s2 : 0.0f};
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh) {
-      int hi = ho * 2 - 1 + kh;
-      if ((unsigned)hi >= (unsigned)H) continue;
-#pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        int wi = wo * 2 - 1 + kw;
-        if ((unsigned)wi >= (unsigned)W) continue;
-        const TIn* px = x + ((int64_t)(b * H + hi) * W + wi) * 3;
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          float v = ((float)px[c] - mu[c]) * is[c];
-          const float4* wr = reinterpret_cast<const float4*>(ws + ((kh * 3 + kw) * 3 + c) * 32);
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            float4 wv = wr[q];
-            acc[4 * q + 0] += v * wv.x;
-            acc[4 * q + 1] += v * wv.y;
-            acc[4 * q + 2] += v * wv.z;
-            acc[4 * q + 3] += v * wv.w;
-          }
-        }
+      for (int c = 0; c < 3; ++c) {
+        const float* wr = ws + ((kh * 3 + kw) * 3 + c) * 32 + cg * 8;
+        float4 w0 = *reinterpret_cast<const float4*>(wr), w1 = *reinterpret_cast<const float4*>(wr + 4);
+        acc[0] = fmaf(v[c], w0.x, acc[0]); acc[1] = fmaf(v[c], w0.y, acc[1]); acc[2] = fmaf(v[c], w0.z, acc[2]); acc[3] = fmaf(v[c], w0.w, acc[3]);
+        acc[4] = fmaf(v[c], w1.x, acc[4]); acc[5] = fmaf(v[c], w1.y, acc[5]); acc[6] = fmaf(v[c], w1.z, acc[6]); acc[7] = fmaf(v[c], w1.w, acc[7]);
       }
     }
-#pragma unroll
-    for (int n = 0; n < 32; ++n) acc[n] = fmaxf(acc[n], 0.0f);
-    uint4* dst = reinterpret_cast<uint4*>(y + (int64_t)o * 32);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) dst[q] = pack_bf16x8(acc + 8 * q);
   }
+#pragma unroll
+  for (int n = 0; n < 8; ++n) acc[n] = fmaxf(acc[n], 0.0f);
+  *reinterpret_cast<uint4*>(y + (int64_t)o * 32 + cg * 8) = pack_bf16x8(acc);
 }
 
 extern "C" int fx_stem_conv3x3s2(const void* x, int in_f32, const float* w, const float* bias, const float* mean, const float* inv_std,
@@ -68,8 +61,8 @@ extern "C" int fx_stem_conv3x3s2(const void* x, int in_f32, const float* w, cons
   int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   int64_t total = (int64_t)B * Ho * Wo;
   if (total >= (1ll << 31)) return FX_ERR_UNSUPPORTED;
-  int grid = (int)((total + 255) / 256);
-  if (grid > 256 * 16) grid = 256 * 16;
+  if (total * 4 >= (1ll << 31)) return FX_ERR_UNSUPPORTED;
+  int grid = (int)((total * 4 + 255) / 256);
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (in_f32)
     hipLaunchKernelGGL(stem_conv_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, w, bias, mean, inv_std, (bf16_t*)y, B,

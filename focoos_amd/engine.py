@@ -127,9 +127,9 @@ class DetrEngine:
         def cbn(name, conv="conv", norm="norm"):
             P[name] = self._pack(*_fold_bn(sd, f"{name}.{conv}.weight", f"{name}.{norm}"))
 
-        # stem conv1_1 stays fp32 [n][kh][kw][c] (direct-conv kernel)
+        # stem conv1_1 stays fp32 [kh][kw][c][n] (direct-conv kernel, weights via the scalar cache)
         w, b = _fold_bn(sd, f"{bb}.conv1.conv1_1.conv.weight", f"{bb}.conv1.conv1_1.norm")
-        self.stem_w = self._dev(w.permute(0, 2, 3, 1).contiguous())
+        self.stem_w = self._dev(w.permute(2, 3, 1, 0).contiguous())  # [kh][kw][c][n]
         self.stem_b = self._dev(b)
         mean = torch.tensor(self.cfg.get("pixel_mean", [123.675, 116.28, 103.53]), dtype=torch.float32)
         std = torch.tensor(self.cfg.get("pixel_std", [58.395, 57.12, 57.375]), dtype=torch.float32)
@@ -343,7 +343,7 @@ class _Plan:
         # bookkeeping for bench.py: which template instance runs and the ALGORITHMIC flops of the reference layer(s)
         # this launch replaces (RepVGG 1x1 branch counted although it is re-parameterised away).
         M = x.B * Ho * Wo
-        bk = 64 if pc.C % 64 == 0 else 32
+        bk = 64 if (pc.C % 64 == 0 and (pool2 or pc.KH * pc.KW * pc.C >= 1024)) else 32  # mirrors the C dispatch (FX_K64_MIN_KTOT)
         bn = 128 if (pc.N > 64 or pool2) else (64 if pc.N > 32 else 32)
         flops = 2.0 * M * pc.N * pc.KH * pc.KW * pc.C + extra_flops_per_pixel * M
         self.meta[len(self.ops)] = {"kind": "conv", "variant": f"conv_igemm<128,{bn},{bk}{',pool' if pool2 else ''}>", "flops": flops,

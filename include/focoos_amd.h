@@ -69,8 +69,9 @@ int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream);
 
 /* Stem: pixel normalisation (x-mean)/std (fai_detr/modelling.py:1349) fused with conv1_1 3x3/s2 +
  * folded BN + ReLU (focoos/nn/backbone/resnet.py:184-196,253).  x is HWC uint8 (in_f32=0) or HWC
- * float32 on the 0..255 scale (in_f32=1, output of fx_resize_bilinear_u8).  w: f32 [32][3][3][3]
- * (n,kh,kw,c) with BN folded, bias f32 [32]; y: bf16 [B,Ho,Wo,32]. */
+ * float32 on the 0..255 scale (in_f32=1, output of fx_resize_bilinear_u8).  w: f32 [3][3][3][32]
+ * (kh,kw,c,n) with BN folded (wave-uniform table read through the scalar cache), bias f32 [32];
+ * y: bf16 [B,Ho,Wo,32]. */
 int fx_stem_conv3x3s2(const void* x, int in_f32, const float* w, const float* bias, const float* mean,
                       const float* inv_std, void* y, int B, int H, int W, int Cout, fx_stream_t stream);
 

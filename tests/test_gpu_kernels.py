@@ -179,7 +179,7 @@ def test_stem(lib, in_f32):
     xin = to_dev(img.float() if in_f32 else img)
     Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     y = torch.empty(B, Ho, Wo, 32, dtype=torch.bfloat16, device=DEV)
-    wd, bd, md, sd_ = to_dev(Wt.permute(0, 2, 3, 1).contiguous()), to_dev(bias), to_dev(mean), to_dev(1.0 / std)
+    wd, bd, md, sd_ = to_dev(Wt.permute(2, 3, 1, 0).contiguous()), to_dev(bias), to_dev(mean), to_dev(1.0 / std)
     check(lib.fx_stem_conv3x3s2(xin.data_ptr(), in_f32, wd.data_ptr(), bd.data_ptr(), md.data_ptr(), sd_.data_ptr(), y.data_ptr(), B, H, W, 32, stream()))
     torch.cuda.synchronize()
     xn = (img.float().permute(0, 3, 1, 2) - mean.view(-1, 1, 1)) / std.view(-1, 1, 1)
