@@ -1,0 +1,41 @@
+// Shared definitions of the implicit-GEMM convolution kernels (conv_igemm.hip, conv_igemm_dma.hip).
+#pragma once
+#include "common.h"
+
+#ifndef FX_K64_MIN_KTOT
+#define FX_K64_MIN_KTOT 1024
+#endif
+
+struct ConvArgs {
+  const bf16_t* x;
+  const bf16_t* w;
+  const float* bias;
+  const bf16_t* res;
+  void* y;
+  int B, H, W, C, ldx;
+  int Ho, Wo, N, ldy, ldr;
+  int KH, KW, stride, pad;
+  int act, out_f32, res_after;
+  int M, Ktot, nNt, Nstore;
+  unsigned x_bytes, w_bytes, r_bytes;  // buffer sizes for the bounds-checked buffer loads (< 4 GiB)
+  int64_t y_bstride;          // 0: contiguous
+};
+
+template <int BK>
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  constexpr int CPR = BK / 8;        // 16-byte chunks per row
+  constexpr int R = 256 / (BK * 2);  // rows per 256-byte bank row
+  return row * (BK * 2) + ((chunk ^ ((row / R) & (CPR - 1))) << 4);
+}
+
+// 16-byte buffer load: out-of-range offsets (>= num_records) return zeros without touching memory,
+// which gives zero padding / M-tail predication for free (one v_cndmask on the offset).
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+  return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+#define FX_OOB 0xFFFFFFF0u
+
+
+// conv_igemm_dma.hip: 8-wave 256-row tiles fed by buffer_load ... lds DMA (deep-K, large-M layers)
+bool fx_conv_dma_eligible(const ConvArgs& a);
+int fx_launch_conv_dma(ConvArgs& a, hipStream_t stream);

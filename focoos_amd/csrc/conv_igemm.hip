@@ -11,40 +11,7 @@
 // next tile's global loads issued before the MFMA block of the current tile (guide T14), one barrier
 // per K-step.  im2col addressing is done on the fly: a K-step never straddles a filter tap because
 // BK divides C.  Zero padding / M tails are predicated loads.
-#include "common.h"
-
-#ifndef FX_K64_MIN_KTOT
-#define FX_K64_MIN_KTOT 1024
-#endif
-
-struct ConvArgs {
-  const bf16_t* x;
-  const bf16_t* w;
-  const float* bias;
-  const bf16_t* res;
-  void* y;
-  int B, H, W, C, ldx;
-  int Ho, Wo, N, ldy, ldr;
-  int KH, KW, stride, pad;
-  int act, out_f32, res_after;
-  int M, Ktot, nNt, Nstore;
-  unsigned x_bytes, w_bytes, r_bytes;  // buffer sizes for the bounds-checked buffer loads (< 4 GiB)
-  int64_t y_bstride;          // 0: contiguous
-};
-
-template <int BK>
-__device__ __forceinline__ int lds_off(int row, int chunk) {
-  constexpr int CPR = BK / 8;        // 16-byte chunks per row
-  constexpr int R = 256 / (BK * 2);  // rows per 256-byte bank row
-  return row * (BK * 2) + ((chunk ^ ((row / R) & (CPR - 1))) << 4);
-}
-
-// 16-byte buffer load: out-of-range offsets (>= num_records) return zeros without touching memory,
-// which gives zero padding / M-tail predication for free (one v_cndmask on the offset).
-__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-  return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
-}
-#define FX_OOB 0xFFFFFFF0u
+#include "conv_common.h"
 
 template <int BM, int BN, int BK, int WM, int WN, bool POOL>
 __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void conv_igemm_kernel(const ConvArgs p) {
@@ -334,6 +301,7 @@ extern "C" int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream_) {
   // BK=64 (2 workgroups/CU, 64 KiB LDS) for deep-K compute-bound layers; BK=32 (4 workgroups/CU, 34 KiB LDS: more
   // tiles and bytes in flight per CU) for the short-K layers, which are HBM/latency-bound.
   const bool k64 = (d->C % 64 == 0) && (a.Ktot >= FX_K64_MIN_KTOT);
+  if (!d->pool2 && fx_conv_dma_eligible(a)) return fx_launch_conv_dma(a, stream);
   if (d->pool2) {
     if (d->C % 64 != 0) return FX_ERR_UNSUPPORTED;
     return launch_conv<128, 128, 64, 2, 2, true>(a, stream);

@@ -346,7 +346,11 @@ class _Plan:
         bk = 64 if (pc.C % 64 == 0 and (pool2 or pc.KH * pc.KW * pc.C >= 1024)) else 32  # mirrors the C dispatch (FX_K64_MIN_KTOT)
         bn = 128 if (pc.N > 64 or pool2) else (64 if pc.N > 32 else 32)
         flops = 2.0 * M * pc.N * pc.KH * pc.KW * pc.C + extra_flops_per_pixel * M
-        self.meta[len(self.ops)] = {"kind": "conv", "variant": f"conv_igemm<128,{bn},{bk}{',pool' if pool2 else ''}>", "flops": flops,
+        variant = f"conv_igemm<128,{bn},{bk}{',pool' if pool2 else ''}>"
+        ktot = pc.KH * pc.KW * pc.C
+        if not pool2 and pc.C % 64 == 0 and ktot >= 1024 and M >= 40000 and pc.N % 128 == 0:  # fx_conv_dma_eligible
+            variant = f"conv_igemm_dma<256,{256 if pc.N % 256 == 0 else 128}>"
+        self.meta[len(self.ops)] = {"kind": "conv", "variant": variant, "flops": flops,
                                     "name": name or "slice", "M": M, "N": pc.N, "K": pc.KH * pc.KW * pc.C}
         self._op(self.lib.fx_conv2d_nhwc_bf16, C.byref(d))
         return out

@@ -111,6 +111,11 @@ CONV_CASES = [
     (1, 1, 77, 256, 1024, 1, 1, "gelu", False, False, False, False),
     (1, 1, 200, 1024, 256, 1, 1, None, True, False, False, False),
     (1, 1, 50, 32, 160, 1, 1, None, False, False, False, False),      # BK=32, BN=128
+    # large-M deep-K shapes -> conv_igemm_dma (buffer_load..lds, 256-row tiles); M tails, padding, residual-after-act
+    (5, 91, 90, 128, 256, 3, 1, "silu", True, True, False, False),    # 256x256 tile, M = 40950 (tail), 3x3 zero padding
+    (2, 145, 142, 128, 128, 3, 1, "relu", False, False, False, False),  # 256x128 tile
+    (1, 1, 40100, 1024, 384, 1, 1, None, True, False, False, False),  # N = 3 x 128, residual before act
+    (11, 121, 123, 256, 256, 3, 2, "relu", False, False, False, False),  # stride 2, 3x3, M = 41602
 ]
 
 
