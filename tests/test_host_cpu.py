@@ -1,0 +1,125 @@
+"""CPU-only checks: the C-ABI library builds/loads and exports every symbol include/focoos_amd.h declares
+(no compute call without a GPU), host logic of the processor / registry / model manager, the product path fails
+loudly without its HIP library or a GPU, and the N>1 bench harness (one process per GPU, barrier, max over ranks)
+runs under gloo with world_size 2."""
+import ctypes
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from focoos_amd import build
+
+    return build.build(force=False, verbose=False)
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "focoos_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(fx_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    import torch  # noqa: F401  (HIP runtime first, see focoos_amd/_lib.py)
+
+    lib = ctypes.CDLL(lib_path)
+    names = header_functions()
+    assert len(names) >= 24
+    for n in names:
+        assert getattr(lib, n) is not None, n
+    from focoos_amd import _lib
+
+    assert sorted(list(_lib.SIGNATURES) + ["fx_error_string"]) == names, "ctypes binding and header drifted apart"
+    lib.fx_abi_version.restype = ctypes.c_int
+    assert lib.fx_abi_version() == 1
+    lib.fx_error_string.restype = ctypes.c_char_p
+    assert b"invalid argument" in lib.fx_error_string(-1)
+
+
+def test_conv_desc_layout_matches_header(tmp_path):
+    """The ctypes mirror of fx_conv_desc has the layout a C compiler gives the header's struct (plain C, gcc)."""
+    from focoos_amd._lib import FxConvDesc
+
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "focoos_amd.h"\nint main(void){printf("%zu %zu %zu %zu\\n", sizeof(fx_conv_desc), '
+                   'offsetof(fx_conv_desc, y_batch_stride), offsetof(fx_conv_desc, B), offsetof(fx_conv_desc, residual_after_act));return 0;}\n')
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    size, off_ybs, off_b, off_raa = map(int, subprocess.check_output([str(exe)]).split())
+    assert ctypes.sizeof(FxConvDesc) == size
+    assert FxConvDesc.y_batch_stride.offset == off_ybs and FxConvDesc.B.offset == off_b and FxConvDesc.residual_after_act.offset == off_raa
+
+
+def test_missing_library_is_loud(monkeypatch):
+    from focoos_amd import _lib
+
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setenv("FOCOOS_AMD_LIB", "/nonexistent/libfocoos_amd.so")
+    with pytest.raises(_lib.FocoosAmdError, match="no CPU/PyTorch fallback"):
+        _lib.load()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="CPU-only behaviour")
+def test_engine_refuses_to_run_without_gpu():
+    from focoos_amd import _lib
+    from focoos_amd.model import ModelManager
+
+    with pytest.raises(_lib.FocoosAmdError, match="no CPU fallback"):
+        ModelManager.get("fai-detr-l-coco")
+
+
+def test_registry_and_manager_errors():
+    from focoos_amd.model import ModelManager
+    from focoos_amd.registry import ModelRegistry
+
+    assert ModelRegistry.exists("fai-detr-l-obj365") and not ModelRegistry.exists("nope")
+    with pytest.raises(ValueError):
+        ModelRegistry.get_model_info("nope")
+    with pytest.raises(ValueError):
+        ModelManager.get("nope")
+    info = ModelRegistry.get_model_info("fai-detr-l-obj365")
+    assert info["config"]["num_classes"] == 365 and len(info["classes"]) == 365
+
+
+def test_processor_host_logic():
+    from focoos_amd.ports import FocoosDetections
+    from focoos_amd.processor import DETRProcessor
+
+    p = DETRProcessor({"top_k": 300, "threshold": 0.5}, image_size=640)
+    imgs = [np.zeros((480, 600, 3), np.uint8), torch.zeros(3, 100, 50)]
+    assert p.get_image_sizes(imgs) == [(480, 600), (100, 50)]
+    assert p.get_image_sizes(np.zeros((2, 64, 32, 3), np.uint8)) == [(64, 32)]  # reference quirk H6: one size for a 4-D array
+    with pytest.raises(ValueError):
+        p.get_image_sizes("x")
+    with pytest.raises(ValueError):
+        p.train(True).preprocess(imgs, torch.device("cpu"))
+    scores = torch.tensor([[0.9, 0.8, 0.1], [0.7, 0.2, 0.1]])
+    labels = torch.tensor([[3, 1, 0], [2, 0, 0]], dtype=torch.int32)
+    boxes = torch.arange(24, dtype=torch.int32).view(2, 3, 4)
+    count = torch.tensor([2, 1], dtype=torch.int32)
+    out = DETRProcessor.pack_detections(scores, labels, boxes, count, ["a", "b", "c", "d"])
+    assert isinstance(out[0], FocoosDetections) and len(out[0]) == 2 and len(out[1]) == 1
+    d = out[0].detections[0]
+    assert d.bbox == [0, 1, 2, 3] and d.cls_id == 3 and d.label == "d" and abs(d.conf - 0.9) < 1e-6
+
+
+def test_bench_two_process_gloo_dry_run():
+    """bench.py's N>1 plumbing (RANK/WORLD_SIZE env, barrier, max-over-ranks, single JSON line on rank 0) with gloo."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29671", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--dry-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["steps"] == 5 and j["scaling"] == "weak" and j["value"] > 0

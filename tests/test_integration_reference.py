@@ -1,0 +1,32 @@
+"""Drop-in registration against the real reference (build container only)."""
+import pytest
+
+from oracle import ref_import
+
+pytestmark = pytest.mark.skipif(not ref_import.reference_available(), reason="/root/reference not present")
+
+
+def test_register_replaces_detr_family_and_keeps_state_dict():
+    ref_import.install()
+    import torch
+    from focoos.model_manager import ConfigManager, ModelManager
+    from focoos.ports import ModelFamily
+
+    import focoos_amd.integration as fx
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.state_spec import detr_state_spec
+
+    fx.register()
+    cls = ModelManager._models_family_map[ModelFamily.DETR.value]()
+    assert cls.__name__ == "EngineFAIDetr"
+    cfgd = ModelRegistry.get_model_info("fai-detr-l-coco")["config"]
+    model = cls(ConfigManager.from_dict(ModelFamily.DETR, dict(cfgd))).eval()
+    assert list(model.state_dict()) == list(detr_state_spec(cfgd))   # checkpoint keys unchanged
+    n = fx.bind_msda_core(model)
+    assert n == 6
+    if not torch.cuda.is_available():
+        from focoos_amd._lib import FocoosAmdError
+
+        with pytest.raises(FocoosAmdError):  # loud, never a silent CPU fallback
+            with torch.no_grad():
+                model(torch.zeros(1, 3, 64, 64))
