@@ -134,6 +134,13 @@ def per_op_timing(eng, pl, args):
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
         acc = [0.0] * n
         reps = 3
+        # calibrate the cost of an event->event interval with nothing in between (subtracted from every bracket)
+        torch.cuda._sleep(int(4e7))
+        for e in evs[:65]:
+            e.record(st)
+        st.synchronize()
+        gaps = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(64))
+        empty = gaps[len(gaps) // 2]
         for _ in range(reps):
             torch.cuda._sleep(int(4e7))
             evs[0].record(st)
@@ -144,7 +151,7 @@ def per_op_timing(eng, pl, args):
                 evs[i + 1].record(st)
             st.synchronize()
             for i in range(n):
-                acc[i] += evs[i].elapsed_time(evs[i + 1])
+                acc[i] += max(evs[i].elapsed_time(evs[i + 1]) - empty, 0.0)
     return [a / reps for a in acc]
 
 
@@ -230,9 +237,25 @@ def main():
         dom = max(by.items(), key=lambda kv: kv[1]["ms"])
         name, d = dom
         achieved = d["flops"] / (d["ms"] * 1e-3) / 1e12
+        # HBM bytes per launch of that kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+        # runs, gfx950 read-side x2 correction: scripts/pmc_summary.py); None when no PMC summary covers this kernel
+        traffic, traffic_src = None, None
+        try:
+            pmc_path = os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")
+            pmc = json.load(open(pmc_path))
+            m_ = __import__("re").match(r"(conv_igemm(?:_dma)?)<(\d+),(\d+)(?:,(\d+))?(,pool)?>", name)
+            for k, v in pmc.items():
+                nums = __import__("re").findall(r"\d+", k)
+                if m_ and k.startswith(m_.group(1) + "_kernel") and nums[:2] == [m_.group(2), m_.group(3)] and \
+                        (m_.group(1) == "conv_igemm_dma" or (nums[2] == m_.group(4) and (("true" in k) == bool(m_.group(5))))):
+                    traffic = round(v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"])
+                    traffic_src = "profiles/pmc_hbm_latest.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; bytes per launch, read side x2 per gfx950 note)"
+        except Exception:
+            pass
         out["roofline"] = {
             "bound": "mfma", "kernel": name, "achieved": round(achieved, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches_per_step": d["launches"],
+            "frac": round(achieved / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": d["launches"],
+            "alg_bytes_note": "compulsory bytes differ per launch (151 shapes); see profiles/*per_op* for the per-launch table",
             "avg_launch_ms": round(d["ms"] / d["launches"], 5), "alg_gflop_per_launch": round(d["flops"] / d["launches"] / 1e9, 3),
             "share_of_step_time": round(d["ms"] / total_ms, 4),
             "all_conv_variants": {k: {"ms": round(v["ms"], 4), "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), "launches": v["launches"]}
