@@ -21,12 +21,21 @@ struct ConvArgs {
   int64_t y_bstride;          // 0: contiguous
 };
 
+// Byte offset of 16-byte chunk `chunk` of tile row `row` in an LDS tile with BK bf16 per row.  The XOR swizzle makes the
+// 16 rows a ds_read_b128 lane group touches land on 16 distinct 16-byte slots of the 256-byte bank window.
 template <int BK>
 __device__ __forceinline__ int lds_off(int row, int chunk) {
-  constexpr int CPR = BK / 8;        // 16-byte chunks per row
-  constexpr int R = 256 / (BK * 2);  // rows per 256-byte bank row
-  return row * (BK * 2) + ((chunk ^ ((row / R) & (CPR - 1))) << 4);
+  constexpr int CPR = BK / 8;  // 16-byte chunks per row
+  if constexpr (BK >= 128) {
+    return row * (BK * 2) + ((chunk ^ (row & 15)) << 4);  // rows are whole bank windows: rotate by the row index
+  } else {
+    constexpr int R = 256 / (BK * 2);  // rows per 256-byte bank window
+    return row * (BK * 2) + ((chunk ^ ((row / R) & (CPR - 1))) << 4);
+  }
 }
+
+// Tuning knobs (compile-time defaults, overridable through the environment for A/B runs).
+int fx_tune(const char* env_name, int default_value);
 
 // 16-byte buffer load: out-of-range offsets (>= num_records) return zeros without touching memory,
 // which gives zero padding / M-tail predication for free (one v_cndmask on the offset).

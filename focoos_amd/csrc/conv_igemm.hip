@@ -13,7 +13,7 @@
 // BK divides C.  Zero padding / M tails are predicated loads.
 #include "conv_common.h"
 
-template <int BM, int BN, int BK, int WM, int WN, bool POOL>
+template <int BM, int BN, int BK, int WM, int WN, bool POOL, int NSTAGE = 2>
 __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void conv_igemm_kernel(const ConvArgs p) {
   constexpr int CPR = BK / 8, RPP = 256 / CPR;
   constexpr int A_PASS = BM / RPP, B_PASS = (BN + RPP - 1) / RPP;
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void conv_igemm_kernel(con
   FX_STORE_TILES(0);
   __syncthreads();
   for (int t = 0; t < T - 1; ++t) {
-    const int cur = t & 1;
+    const int cur = (NSTAGE == 2) ? (t & 1) : 0;
     c0 += BK;
     kbase += BK;
     if (c0 == p.C) {
@@ -139,7 +139,12 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void conv_igemm_kernel(con
     }
     FX_LOAD_TILES(kh, kw, c0, kbase);  // next tile's global loads fly under this tile's MFMAs
     FX_COMPUTE(cur);
-    FX_STORE_TILES(cur ^ 1);
+    if constexpr (NSTAGE == 2) {
+      FX_STORE_TILES(cur ^ 1);
+    } else {
+      __syncthreads();  // single LDS stage (whole-K-in-one-shot tiles): everyone done reading before it is overwritten
+      FX_STORE_TILES(0);
+    }
     __syncthreads();
   }
   // The residual tile is independent of the GEMM: fetch it now (into the registers the tile prefetch no longer
@@ -157,7 +162,7 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void conv_igemm_kernel(con
       rres[q] = buf_load16(rr, (m < p.M && n_ok) ? (unsigned)(m * p.ldr + n) * 2u : FX_OOB);
     }
   }
-  FX_COMPUTE((T - 1) & 1);
+  FX_COMPUTE((NSTAGE == 2) ? ((T - 1) & 1) : 0);
   __syncthreads();
 #undef FX_LOAD_TILES
 #undef FX_STORE_TILES
@@ -234,13 +239,13 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void conv_igemm_kernel(con
   }
 }
 
-template <int BM, int BN, int BK, int WM, int WN, bool POOL>
+template <int BM, int BN, int BK, int WM, int WN, bool POOL, int NSTAGE = 2>
 static int launch_conv(ConvArgs& a, hipStream_t stream) {
   constexpr int STAGE = (BM + BN) * BK * 2;
   constexpr int EPI = 64 * (BN + 4) * 4;  // the epilogue stages 64 rows at a time
-  constexpr int SMEM = (2 * STAGE > EPI) ? 2 * STAGE : EPI;
+  constexpr int SMEM = (NSTAGE * STAGE > EPI) ? NSTAGE * STAGE : EPI;
   static bool attr_set = false;
-  auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, POOL>;
+  auto kern = conv_igemm_kernel<BM, BN, BK, WM, WN, POOL, NSTAGE>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
       return FX_ERR_RUNTIME;
@@ -300,7 +305,12 @@ extern "C" int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream_) {
   a.r_bytes = (unsigned)r_bytes;
   // BK=64 (2 workgroups/CU, 64 KiB LDS) for deep-K compute-bound layers; BK=32 (4 workgroups/CU, 34 KiB LDS: more
   // tiles and bytes in flight per CU) for the short-K layers, which are HBM/latency-bound.
-  const bool k64 = (d->C % 64 == 0) && (a.Ktot >= FX_K64_MIN_KTOT);
+  static const int k64_min = fx_tune("FX_K64_MIN_KTOT", FX_K64_MIN_KTOT);
+  static const int small_m = fx_tune("FX_SMALL_M", 16384);
+  // Small-M GEMMs (decoder / 20x20 level: a few hundred tiles, latency-bound): 64x64 tiles with a 256-deep K slab per
+  // step - for K = 256 the whole reduction is ONE load phase (all 16 loads per lane in flight at once), no K loop.
+  if (!d->pool2 && a.M <= small_m && d->C % 256 == 0 && a.Ktot <= 1024) return launch_conv<64, 64, 256, 2, 2, false, 1>(a, stream);
+  const bool k64 = (d->C % 64 == 0) && (a.Ktot >= k64_min);
   if (!d->pool2 && fx_conv_dma_eligible(a)) return fx_launch_conv_dma(a, stream);
   if (d->pool2) {
     if (d->C % 64 != 0) return FX_ERR_UNSUPPORTED;

@@ -44,20 +44,26 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void conv_igemm_dma_kernel(const Co
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, p.w_bytes, 0x00020000);
 
   const int lrow = lane >> 3, pc = lane & 7;
-  int a_off[A_PW], a_hi0[A_PW], a_wi0[A_PW];
-  bool a_ok[A_PW];
+  // Per DMA slot: byte offset of (b, hi0, wi0, swizzled chunk) and a bit mask of the filter taps that fall inside the
+  // image (bit kh*KW+kw).  The K loop then needs one add + one bit test + one select per DMA instruction instead of
+  // re-deriving the bounds checks (the main loop is issue-bound: every VALU op there competes with the MFMAs).
+  unsigned a_off2[A_PW], a_mask[A_PW];
   const int HoWo = p.Ho * p.Wo;
 #pragma unroll
   for (int i = 0; i < A_PW; ++i) {
     const int row = (wave * A_PW + i) * 8 + lrow;
     const int m = m0 + row;
-    a_ok[i] = m < p.M;
-    const int mm = a_ok[i] ? m : 0;
+    const bool ok = m < p.M;
+    const int mm = ok ? m : 0;
     const int b = mm / HoWo, rem = mm - b * HoWo;
     const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-    a_hi0[i] = ho * p.stride - p.pad;
-    a_wi0[i] = wo * p.stride - p.pad;
-    a_off[i] = ((b * p.H + a_hi0[i]) * p.W + a_wi0[i]) * p.ldx + ((pc ^ ((row >> 1) & 7)) << 3);
+    const int hi0 = ho * p.stride - p.pad, wi0 = wo * p.stride - p.pad;
+    a_off2[i] = (unsigned)((((b * p.H + hi0) * p.W + wi0) * p.ldx + ((pc ^ ((row >> 1) & 7)) << 3)) * 2);
+    unsigned mask = 0;
+    for (int th = 0; th < p.KH; ++th)
+      for (int tw = 0; tw < p.KW; ++tw)
+        if (ok && (unsigned)(hi0 + th) < (unsigned)p.H && (unsigned)(wi0 + tw) < (unsigned)p.W) mask |= 1u << (th * p.KW + tw);
+    a_mask[i] = mask;
   }
   unsigned w_off[B_PW];
 #pragma unroll
@@ -66,18 +72,13 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void conv_igemm_dma_kernel(const Co
     w_off[i] = (unsigned)(((n0 + row) * p.Ktot + ((pc ^ ((row >> 1) & 7)) << 3)) * 2);
   }
 
-#define FX_DMA(S_, KH_, KW_, C0_, KBASE_)                                                                              \
+#define FX_DMA(S_, TAP_, DELTA2_, KBASE_)                                                                             \
   {                                                                                                                    \
-    const int delta_ = ((KH_)*p.W + (KW_)) * p.ldx + (C0_);                                                            \
     unsigned char* sa_ = smem + (S_)*STAGE + wave * (A_PW * 1024);                                                     \
     unsigned char* sb_ = smem + (S_)*STAGE + A_BYTES + wave * (B_PW * 1024);                                           \
-    _Pragma("unroll") for (int i = 0; i < A_PW; ++i) {                                                                 \
-      const int hi = a_hi0[i] + (KH_), wi = a_wi0[i] + (KW_);                                                          \
-      const bool ok = a_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;                         \
-      dma16(xr, sa_ + i * 1024, ok ? (unsigned)(a_off[i] + delta_) * 2u : FX_OOB, 0);                                  \
-    }                                                                                                                  \
-    _Pragma("unroll") for (int i = 0; i < B_PW; ++i)                                                                   \
-        dma16(wr, sb_ + i * 1024, w_off[i], (KBASE_)*2);                                                               \
+    _Pragma("unroll") for (int i = 0; i < A_PW; ++i)                                                                   \
+        dma16(xr, sa_ + i * 1024, ((a_mask[i] >> (TAP_)) & 1u) ? a_off2[i] + (unsigned)(DELTA2_) : FX_OOB, 0);          \
+    _Pragma("unroll") for (int i = 0; i < B_PW; ++i) dma16(wr, sb_ + i * 1024, w_off[i], (KBASE_)*2);                  \
   }
 
   f32x16 acc[TN][TM];
@@ -90,8 +91,18 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void conv_igemm_dma_kernel(const Co
 
   const int T = p.KH * p.KW * (p.C / BK);
   const int l32 = lane & 31, lhalf = lane >> 5;
-  int kh = 0, kw = 0, c0 = 0, kbase = 0;
-  FX_DMA(0, kh, kw, c0, kbase);
+  // LDS fragment addresses, hoisted: row r of this lane's fragments has swizzle (r>>1)&7 = (l32>>1)&7 for every 32-row
+  // sub-tile (sub-tile bases are multiples of 32 rows), so one address register per k-slice serves all sub-tiles
+  // through the immediate offset of ds_read_b128.
+  unsigned a_rd[BK / 16], b_rd[BK / 16];
+#pragma unroll
+  for (int kk = 0; kk < BK / 16; ++kk) {
+    const unsigned x = (unsigned)(((kk * 2 + lhalf) ^ ((l32 >> 1) & 7)) << 4);
+    a_rd[kk] = (unsigned)((wm * WTM + l32) * 128) + x;
+    b_rd[kk] = (unsigned)(A_BYTES + (wn * WTN + l32) * 128) + x;
+  }
+  int kh = 0, kw = 0, c0 = 0, kbase = 0, tap = 0;
+  FX_DMA(0, 0, 0, 0);
   for (int t = 0; t < T; ++t) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // tile t has landed for every wave; everyone is done reading the other stage
@@ -100,27 +111,36 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void conv_igemm_dma_kernel(const Co
       kbase += BK;
       if (c0 == p.C) {
         c0 = 0;
+        ++tap;
         if (++kw == p.KW) {
           kw = 0;
           ++kh;
         }
       }
-      FX_DMA((t + 1) & 1, kh, kw, c0, kbase);
+      FX_DMA((t + 1) & 1, tap, (((kh * p.W + kw) * p.ldx + c0) * 2), kbase);
     }
-    const unsigned char* A_ = smem + (t & 1) * STAGE;
-    const unsigned char* B_ = A_ + A_BYTES;
+    const unsigned char* S_ = smem + (t & 1) * STAGE;
+    // Fragment double-buffering: the k-slice kk+1 fragments are fetched into a second register set BEFORE the MFMAs of
+    // slice kk issue, so the LDS latency hides under 8 MFMAs instead of stalling the matrix pipe once per slice.
+    bf16x8 xa[2][TM], wb[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) xa[0][i] = *reinterpret_cast<const bf16x8*>(S_ + a_rd[0] + i * (32 * 128));
+#pragma unroll
+    for (int i = 0; i < TN; ++i) wb[0][i] = *reinterpret_cast<const bf16x8*>(S_ + b_rd[0] + i * (32 * 128));
 #pragma unroll
     for (int kk = 0; kk < BK / 16; ++kk) {
-      const int chunk = kk * 2 + lhalf;
-      bf16x8 xa[TM], wb[TN];
+      if (kk + 1 < BK / 16) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) xa[i] = *reinterpret_cast<const bf16x8*>(A_ + lds_off<BK>(wm * WTM + i * 32 + l32, chunk));
+        for (int i = 0; i < TM; ++i) xa[(kk + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(S_ + a_rd[kk + 1] + i * (32 * 128));
 #pragma unroll
-      for (int i = 0; i < TN; ++i) wb[i] = *reinterpret_cast<const bf16x8*>(B_ + lds_off<BK>(wn * WTN + i * 32 + l32, chunk));
+        for (int i = 0; i < TN; ++i) wb[(kk + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(S_ + b_rd[kk + 1] + i * (32 * 128));
+      }
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ABOVE this slice's MFMAs (hipcc otherwise sinks it to save VGPRs)
 #pragma unroll
       for (int a = 0; a < TN; ++a)
 #pragma unroll
-        for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[a], xa[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < TM; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[kk & 1][a], xa[kk & 1][b], acc[a][b], 0, 0, 0);
     }
   }
   __syncthreads();
@@ -243,7 +263,8 @@ static int launch_dma(ConvArgs& a, hipStream_t stream) {
 // Deep-K layers with enough rows to fill the chip with 256-row tiles.  Weights are padded to a multiple of 128
 // rows, so BN = 256 needs N % 256 == 0 (or N <= 128 -> BN = 128).
 bool fx_conv_dma_eligible(const ConvArgs& a) {
-  if (a.C % 64 != 0 || a.Ktot < FX_DMA_MIN_KTOT || a.M < FX_DMA_MIN_M) return false;
+  static const int min_k = fx_tune("FX_DMA_MIN_KTOT", FX_DMA_MIN_KTOT), min_m = fx_tune("FX_DMA_MIN_M", FX_DMA_MIN_M);
+  if (a.C % 64 != 0 || a.Ktot < min_k || a.M < min_m) return false;
   return (a.N % 256 == 0) || (a.N % 128 == 0);
 }
 

@@ -190,3 +190,49 @@ extern "C" int fx_maxpool3x3s2_nhwc_bf16(const void* x, int ldx, void* y, int ld
                      (bf16_t*)y, ldy, B, H, W, C / 8, Ho, Wo);
   return fx_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// nn.AvgPool2d(2, 2, 0, ceil_mode=True) of the ResNet-vd "d" shortcut (resnet.py:89-100): average over the in-bounds
+// taps (ceil mode with pad 0 divides by the number of valid elements).  Done ONCE here instead of inside the 1x1
+// shortcut conv's A-load, where it was recomputed for every N tile (up to 16x).
+__global__ __launch_bounds__(256) void avgpool2_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int B, int H,
+                                                        int W, int C8, int Ho, int Wo) {
+  int64_t total = (int64_t)B * Ho * Wo * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int c8 = (int)(i % C8);
+    int64_t p = i / C8;
+    int wo = (int)(p % Wo);
+    int64_t q = p / Wo;
+    int ho = (int)(q % Ho), b = (int)(q / Ho);
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int cnt = 0;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        int hi = 2 * ho + dy, wi = 2 * wo + dx;
+        if (hi < H && wi < W) {
+          float f[8];
+          unpack_bf16x8(*reinterpret_cast<const uint4*>(x + ((int64_t)(b * H + hi) * W + wi) * ldx + c8 * 8), f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s[j] += f[j];
+          ++cnt;
+        }
+      }
+    float inv = 1.0f / (float)cnt;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[j] *= inv;
+    *reinterpret_cast<uint4*>(y + p * ldy + c8 * 8) = pack_bf16x8(s);
+  }
+}
+
+extern "C" int fx_avgpool2x2_nhwc_bf16(const void* x, int ldx, void* y, int ldy, int B, int H, int W, int C, fx_stream_t stream_) {
+  FX_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && ldx >= C && ldy >= C && ldx % 8 == 0 && ldy % 8 == 0);
+  int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  int64_t total = (int64_t)B * Ho * Wo * (C / 8);
+  int64_t grid = (total + 255) / 256;
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(avgpool2_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)x, ldx,
+                     (bf16_t*)y, ldy, B, H, W, C / 8, Ho, Wo);
+  return fx_launch_status();
+}

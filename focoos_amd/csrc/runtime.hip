@@ -2,7 +2,14 @@
 // and HIP-event timing on the caller's stream.
 #include <string.h>
 
-#include "common.h"
+#include "conv_common.h"
+
+#include <stdlib.h>
+
+int fx_tune(const char* env_name, int default_value) {
+  const char* v = getenv(env_name);
+  return (v && *v) ? atoi(v) : default_value;
+}
 
 extern "C" int fx_abi_version(void) { return FX_ABI_VERSION; }
 

@@ -348,7 +348,9 @@ class _Plan:
         flops = 2.0 * M * pc.N * pc.KH * pc.KW * pc.C + extra_flops_per_pixel * M
         variant = f"conv_igemm<128,{bn},{bk}{',pool' if pool2 else ''}>"
         ktot = pc.KH * pc.KW * pc.C
-        if not pool2 and pc.C % 64 == 0 and ktot >= 1024 and M >= 40000 and pc.N % 128 == 0:  # fx_conv_dma_eligible
+        if not pool2 and M <= 16384 and pc.C % 256 == 0 and ktot <= 1024:
+            variant = "conv_igemm<64,64,256,1stage>"
+        elif not pool2 and pc.C % 64 == 0 and ktot >= 1024 and M >= 40000 and pc.N % 128 == 0:  # fx_conv_dma_eligible
             variant = f"conv_igemm_dma<256,{256 if pc.N % 256 == 0 else 128}>"
         self.meta[len(self.ops)] = {"kind": "conv", "variant": variant, "flops": flops,
                                     "name": name or "slice", "M": M, "N": pc.N, "K": pc.KH * pc.KW * pc.C}
@@ -404,7 +406,9 @@ class _Plan:
                 bmid = self.conv(a, P[f"{p}.branch2b"], name=f"{p}.b", stride=stride, act="relu")
                 if bi == 0:
                     if stride == 2:
-                        short = self.conv(x, P[f"{p}.short.conv"], name=f"{p}.s", pool2=True)
+                        pooled = self._new(f"{p}.pool", B, (x.H + 1) // 2, (x.W + 1) // 2, x.C)
+                        self._op(lib.fx_avgpool2x2_nhwc_bf16, x.ptr, x.ld, pooled.ptr, pooled.ld, B, x.H, x.W, x.C)
+                        short = self.conv(pooled, P[f"{p}.short.conv"], name=f"{p}.s")
                     else:
                         short = self.conv(x, P[f"{p}.short"], name=f"{p}.s")
                 else:

@@ -82,6 +82,11 @@ int fx_resize_bilinear_u8(const uint8_t* x, int H, int W, float* y, int Ho, int 
 /* F.max_pool2d(k=3,s=2,p=1) (resnet.py:254) on NHWC bf16. */
 int fx_maxpool3x3s2_nhwc_bf16(const void* x, int ldx, void* y, int ldy, int B, int H, int W, int C, fx_stream_t stream);
 
+/* nn.AvgPool2d(2, 2, 0, ceil_mode=True) of the "d"-variant shortcut (resnet.py:89-100) on NHWC bf16 -> [B,ceil(H/2),ceil(W/2),C].
+ * (fx_conv2d_nhwc_bf16's pool2 flag fuses the same pooling into the conv's A-load; this standalone form pools once
+ * when the conv has many N tiles.) */
+int fx_avgpool2x2_nhwc_bf16(const void* x, int ldx, void* y, int ldy, int B, int H, int W, int C, fx_stream_t stream);
+
 /* F.interpolate(mode="bilinear", align_corners=False) to (Ho,Wo) on NHWC bf16
  * (fai_detr/modelling.py:334,342); writing into a channel slice (ldy) makes torch.concat free. */
 int fx_resize_bilinear_nhwc_bf16(const void* x, int ldx, void* y, int ldy, int B, int H, int W, int C, int Ho, int Wo,

@@ -224,6 +224,12 @@ def test_resize_nhwc_and_maxpool(lib, cfg):
     torch.cuda.synchronize()
     refp = F.max_pool2d(x.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
     assert torch.equal(yp.float().cpu(), refp)  # max of bf16 values is exact
+    Ha, Wa = (H + 1) // 2, (W + 1) // 2
+    ya = torch.empty(B, Ha, Wa, Cc, dtype=torch.bfloat16, device=DEV)
+    check(lib.fx_avgpool2x2_nhwc_bf16(xd.data_ptr(), Cc, ya.data_ptr(), Cc, B, H, W, Cc, stream()))
+    torch.cuda.synchronize()
+    refa = F.avg_pool2d(x.float().permute(0, 3, 1, 2), 2, 2, 0, ceil_mode=True).permute(0, 2, 3, 1)
+    assert (ya.float().cpu() - refa).abs().max() < 2e-2
 
 
 def test_layernorm_and_add(lib):
