@@ -52,6 +52,10 @@ SIGNATURES = {
     "fx_bbox_head": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _vp],
     "fx_detr_head_out": [_vp, _i, _vp, _vp, _vp, _i, _i, _vp],
     "fx_detr_postprocess": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
+    "fx_detr_match_cost_f32": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp],
+    "fx_lsa_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "fx_detr_set_loss_workspace_bytes": [_i, _i, _i],
+    "fx_detr_set_loss_f32": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp],
     "fx_graph_begin": [_vp],
     "fx_graph_end": [_vp, C.POINTER(C.c_void_p)],
     "fx_graph_launch": [_vp, _vp],

@@ -1,0 +1,116 @@
+"""Host mirrors of the RT-DETR training criterion for the gfx950 kernels (forward values; no autograd this round):
+
+  BoxHungarianMatcher.forward   focoos/models/fai_detr/modelling.py:693-758   -> fx_detr_match_cost_f32 + fx_lsa_f32
+  SetCriterion.forward          focoos/models/fai_detr/modelling.py:553-612   -> fx_detr_set_loss_f32 per prediction set
+
+Same argument / return structure as the reference (``outputs`` dict with pred_logits / pred_boxes / aux_outputs, targets
+with ``labels`` / ``boxes``; matcher returns a list of (index_i, index_j) int64 tensors; criterion returns the dict of
+weighted losses with ``_{i}`` suffixes for the auxiliary sets).  Unlike the reference nothing leaves the GPU: no
+cost-matrix D2H copy, no host SciPy call, no ``.item()`` sync (num_boxes is computed on the host from the target list,
+as the reference does before its all-reduce)."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check
+
+
+class _Targets:
+    """Packed targets in HBM: labels i32 [sumT], boxes f32 [sumT,4], offsets i32 [B+1]."""
+
+    def __init__(self, targets: Sequence, device):
+        sizes = [int(len(t.labels)) for t in targets]
+        self.off_host = np.zeros(len(targets) + 1, np.int32)
+        self.off_host[1:] = np.cumsum(sizes)
+        self.n = int(self.off_host[-1])
+        self.tmax = max(sizes + [0])
+        self.offsets = torch.from_numpy(self.off_host).to(device)
+        if self.n:
+            self.labels = torch.cat([t.labels.to(torch.int32) for t in targets]).to(device).contiguous()
+            self.boxes = torch.cat([t.boxes.float() for t in targets]).to(device).contiguous()
+        else:
+            self.labels = torch.zeros(1, dtype=torch.int32, device=device)
+            self.boxes = torch.zeros(1, 4, device=device)
+
+
+class BoxHungarianMatcher:
+    def __init__(self, cost_class: float = 2, cost_bbox: float = 5, cost_giou: float = 2, use_focal_loss: bool = True, alpha: float = 0.25,
+                 gamma: float = 2.0):
+        assert cost_class != 0 or cost_bbox != 0 or cost_giou != 0, "all costs cant be 0"
+        if not use_focal_loss:
+            raise NotImplementedError("only the focal-cost branch (matcher_use_focal_loss=True, all registry models) is implemented")
+        self.cost_class, self.cost_bbox, self.cost_giou, self.alpha, self.gamma = cost_class, cost_bbox, cost_giou, alpha, gamma
+
+    def match_packed(self, logits: torch.Tensor, boxes: torch.Tensor, tg: _Targets):
+        lib = _lib.load()
+        B, Q, K = logits.shape
+        dev = logits.device
+        logits, boxes = logits.float().contiguous(), boxes.float().contiguous()
+        pi = torch.empty(max(tg.n, 1), dtype=torch.int32, device=dev)
+        ti = torch.empty(max(tg.n, 1), dtype=torch.int32, device=dev)
+        if tg.n:
+            cost = torch.empty(B, Q, tg.tmax, dtype=torch.float32, device=dev)
+            st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+            check(lib.fx_detr_match_cost_f32(logits.data_ptr(), K, boxes.data_ptr(), tg.labels.data_ptr(), tg.boxes.data_ptr(), tg.offsets.data_ptr(), B, Q,
+                                             K, tg.tmax, float(self.cost_class), float(self.cost_bbox), float(self.cost_giou), float(self.alpha),
+                                             float(self.gamma), cost.data_ptr(), st), "fx_detr_match_cost_f32")
+            check(lib.fx_lsa_f32(cost.data_ptr(), B, Q, tg.tmax, tg.offsets.data_ptr(), pi.data_ptr(), ti.data_ptr(), st), "fx_lsa_f32")
+        return pi, ti
+
+    @torch.no_grad()
+    def forward(self, outputs: Dict[str, torch.Tensor], targets: Sequence) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+        tg = _Targets(targets, outputs["pred_logits"].device)
+        pi, ti = self.match_packed(outputs["pred_logits"], outputs["pred_boxes"], tg)
+        pi, ti, o = pi.cpu().long(), ti.cpu().long(), tg.off_host
+        return [(pi[o[b]:o[b + 1]], ti[o[b]:o[b + 1]]) for b in range(len(targets))]
+
+    __call__ = forward
+
+
+class SetCriterion:
+    def __init__(self, num_classes: int, matcher: BoxHungarianMatcher, weight_dict: Dict[str, float], losses=("vfl", "boxes"), focal_alpha: float = 0.75,
+                 focal_gamma: float = 2.0, deep_supervision: bool = True, world_size: int = 1):
+        if sorted(losses) != ["boxes", "vfl"]:
+            raise NotImplementedError("criterion_losses must be ['vfl', 'boxes'] (the registry configuration)")
+        self.num_classes, self.matcher, self.weight_dict = num_classes, matcher, weight_dict
+        self.focal_alpha, self.focal_gamma, self.deep_supervision, self.world_size = focal_alpha, focal_gamma, deep_supervision, world_size
+
+    def _one_set(self, out, tg: _Targets, num_boxes: float) -> torch.Tensor:
+        lib = _lib.load()
+        logits, boxes = out["pred_logits"].float().contiguous(), out["pred_boxes"].float().contiguous()
+        B, Q, K = logits.shape
+        dev = logits.device
+        pi, ti = self.matcher.match_packed(logits, boxes, tg)
+        ws = torch.empty(lib.fx_detr_set_loss_workspace_bytes(B, Q, tg.n) // 8 + 1, dtype=torch.float64, device=dev)
+        out3 = torch.empty(3, dtype=torch.float32, device=dev)
+        check(lib.fx_detr_set_loss_f32(logits.data_ptr(), K, boxes.data_ptr(), tg.labels.data_ptr(), tg.boxes.data_ptr(), tg.offsets.data_ptr(), pi.data_ptr(),
+                                       ti.data_ptr(), B, Q, K, tg.n, float(num_boxes), float(self.focal_alpha), float(self.focal_gamma),
+                                       float(self.weight_dict.get("loss_vfl", 1.0)), float(self.weight_dict.get("loss_bbox", 1.0)),
+                                       float(self.weight_dict.get("loss_giou", 1.0)), ws.data_ptr(), out3.data_ptr(),
+                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)), "fx_detr_set_loss_f32")
+        return out3
+
+    @torch.no_grad()
+    def forward(self, outputs: Dict, targets: Sequence) -> Dict[str, torch.Tensor]:
+        dev = outputs["pred_logits"].device
+        tg = _Targets(targets, dev)
+        num = torch.tensor([float(tg.n)], device=dev)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(num)  # modelling.py:568-570 (the 4-byte num_boxes all-reduce, C3)
+            num = num / torch.distributed.get_world_size()
+        num_boxes = max(float(num.item()), 1.0)
+        losses = {}
+        sets = [("", {k: v for k, v in outputs.items() if k != "aux_outputs"})]
+        if self.deep_supervision:
+            sets += [(f"_{i}", a) for i, a in enumerate(outputs.get("aux_outputs", []))]
+        for suffix, o in sets:
+            l3 = self._one_set(o, tg, num_boxes)
+            losses[f"loss_vfl{suffix}"], losses[f"loss_bbox{suffix}"], losses[f"loss_giou{suffix}"] = l3[0], l3[1], l3[2]
+        return losses
+
+    __call__ = forward

@@ -158,6 +158,29 @@ int fx_detr_postprocess(const float* topk_val, const int32_t* topk_idx, const fl
                         int K, int top_k, float threshold, int32_t* labels, int32_t* queries, int32_t* boxes_i32, int32_t* count,
                         fx_stream_t stream);
 
+/* ---- set criterion (training path, forward only this round): SURVEY §8a rows A14/A15 ------------------------------
+ * BoxHungarianMatcher cost (fai_detr/modelling.py:714-746, focal branch; box math focoos/utils/box.py:14-64), computed
+ * per image: cost[b][q][t] for t < T_b (T_b = tgt_offsets[b+1]-tgt_offsets[b]; row stride Tmax; columns >= T_b zero).
+ * logits f32 [B,Q,ldl] (raw), boxes f32 [B,Q,4] cxcywh, tgt_labels i32 [sumT], tgt_boxes f32 [sumT,4] cxcywh. */
+int fx_detr_match_cost_f32(const float* logits, int ldl, const float* boxes, const int32_t* tgt_labels, const float* tgt_boxes,
+                           const int32_t* tgt_offsets, int B, int Q, int K, int Tmax, float w_class, float w_bbox, float w_giou, float alpha,
+                           float gamma, float* cost, fx_stream_t stream);
+
+/* scipy.optimize.linear_sum_assignment on every image's [Q, T_b] block (modelling.py:749-750; SciPy is a third-party
+ * dependency of the reference, pinned scipy~=1.14.1): same shortest-augmenting-path algorithm, float64 arithmetic and
+ * tie rule, so the int indices are identical to SciPy's.  Writes, at tgt_offsets[b].., the matched query indices in
+ * ascending order (pred_idx) and their targets (tgt_idx).  Needs T_b <= Q <= 1024. */
+int fx_lsa_f32(const float* cost, int B, int Q, int Tmax, const int32_t* tgt_offsets, int32_t* pred_idx, int32_t* tgt_idx, fx_stream_t stream);
+
+/* SetCriterion.loss_labels_vfl + loss_boxes of one prediction set (modelling.py:464-497, 513-530, weights :576-579):
+ * out3 = {w_vfl * loss_vfl, w_bbox * loss_bbox, w_giou * loss_giou}.  workspace: fx_detr_set_loss_workspace_bytes() bytes,
+ * 8-byte aligned.  Deterministic (fixed-order float64 reduction). */
+int fx_detr_set_loss_workspace_bytes(int B, int Q, int sum_T);
+int fx_detr_set_loss_f32(const float* logits, int ldl, const float* boxes, const int32_t* tgt_labels, const float* tgt_boxes,
+                         const int32_t* tgt_offsets, const int32_t* pred_idx, const int32_t* tgt_idx, int B, int Q, int K, int sum_T,
+                         float num_boxes, float focal_alpha, float focal_gamma, float w_vfl, float w_bbox, float w_giou, void* workspace,
+                         float* out3, fx_stream_t stream);
+
 /* hipGraph capture of a launch sequence issued on `stream` (HIP graphs instead of a tracing compiler). */
 int fx_graph_begin(fx_stream_t stream);
 int fx_graph_end(fx_stream_t stream, void** graph_exec_out);

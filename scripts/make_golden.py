@@ -141,6 +141,44 @@ def deform_core_case():
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
+def criterion_case():
+    """Golden vectors of the REAL reference's BoxHungarianMatcher + SetCriterion (modelling.py:409-758) on seeded synthetic
+    predictions/targets (incl. an image without targets): the cost blocks handed to SciPy, the matched indices, the losses."""
+    ref_import.install()
+    import focoos.models.fai_detr.modelling as M
+    from focoos.models.fai_detr.ports import DETRTargets
+
+    from oracle.criterion_oracle import synth_predictions_and_targets
+
+    logits, boxes, labels, tboxes = synth_predictions_and_targets(0)
+    targets = [DETRTargets(labels=l, boxes=b) for l, b in zip(labels, tboxes)]
+    captured = []
+    orig = M.linear_sum_assignment
+
+    def spy(c):
+        captured.append(np.array(c, dtype=np.float32))
+        return orig(c)
+
+    M.linear_sum_assignment = spy
+    try:
+        matcher = M.BoxHungarianMatcher(cost_class=2, cost_bbox=5, cost_giou=2, use_focal_loss=True, alpha=0.25, gamma=2.0)
+        crit = M.SetCriterion(num_classes=logits.shape[-1], matcher=matcher, weight_dict={"loss_vfl": 1, "loss_bbox": 5, "loss_giou": 2},
+                              losses=["vfl", "boxes"], focal_alpha=0.75, focal_gamma=2.0)
+        losses = crit({"pred_logits": logits, "pred_boxes": boxes}, targets)
+        captured_first = list(captured)
+        ind = matcher({"pred_logits": logits, "pred_boxes": boxes}, targets)
+    finally:
+        M.linear_sum_assignment = orig
+    g = {"loss": np.array([float(losses["loss_vfl"]), float(losses["loss_bbox"]), float(losses["loss_giou"])], np.float64)}
+    for b, ((i, j), c) in enumerate(zip(ind, captured_first)):
+        g[f"pred_idx_{b}"] = i.numpy().astype(np.int32)
+        g[f"tgt_idx_{b}"] = j.numpy().astype(np.int32)
+        g[f"cost_{b}"] = c
+    path = os.path.join(GOLDEN, "detr_criterion.npz")
+    np.savez_compressed(path, **g)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB); losses {g['loss']}")
+
+
 def main():
     torch.set_num_threads(os.cpu_count() or 1)
     os.makedirs(GOLDEN, exist_ok=True)
@@ -148,6 +186,7 @@ def main():
     # non-square inputs that are resized by the processor (base_processor.py:285-288)
     run_case("fai-detr-l-coco", 1, [synth_image_structured(2, 480, 600)], "detr_l_coco_resize")
     deform_core_case()
+    criterion_case()
 
 
 if __name__ == "__main__":
