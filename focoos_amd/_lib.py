@@ -56,6 +56,10 @@ SIGNATURES = {
     "fx_lsa_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "fx_detr_set_loss_workspace_bytes": [_i, _i, _i],
     "fx_detr_set_loss_f32": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp],
+    "fx_msda_f32_fwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "fx_msda_f32_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "fx_adamw_workspace_bytes": [],
+    "fx_adamw_step_f32": [_vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp],
     "fx_graph_begin": [_vp],
     "fx_graph_end": [_vp, C.POINTER(C.c_void_p)],
     "fx_graph_launch": [_vp, _vp],

@@ -1,0 +1,210 @@
+// Training-side kernels (gfx950) that do not depend on the conv backward: the multi-scale deformable attention core
+// in fp32 with its backward (the autograd half of seam B4), and a fused multi-tensor AdamW step with global-norm gradient
+// clipping (the reference runs ~500 single-tensor param groups and clips twice).
+#include <math.h>
+
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// ms_deform_attn_core (focoos/nn/layers/deformable.py:10-35), fp32.  One wave per (batch, query); lane = (head = lane>>3,
+// 4 channels = (lane&7)*4), M*D = 256.  Forward writes out[b,q,h*32+c]; backward scatters grad_value with fp32 atomics
+// (different queries hit the same value pixels) and reduces grad_loc / grad_attn over the 8 lanes of a head.
+struct Tap4 {
+  float w[4];
+  int idx[4];  // y*W+x or -1 (out of the map: zeros padding)
+  float tx, ty;
+};
+
+__device__ __forceinline__ Tap4 make_taps(float lx, float ly, int Hl, int Wl) {
+  Tap4 t;
+  const float gx = 2.0f * lx - 1.0f, gy = 2.0f * ly - 1.0f;
+  const float ix = ((gx + 1.0f) * (float)Wl - 1.0f) * 0.5f, iy = ((gy + 1.0f) * (float)Hl - 1.0f) * 0.5f;
+  const float fx0 = floorf(ix), fy0 = floorf(iy);
+  const int x0 = (int)fx0, y0 = (int)fy0;
+  t.tx = ix - fx0;
+  t.ty = iy - fy0;
+  t.w[0] = (1.f - t.tx) * (1.f - t.ty);
+  t.w[1] = t.tx * (1.f - t.ty);
+  t.w[2] = (1.f - t.tx) * t.ty;
+  t.w[3] = t.tx * t.ty;
+  const bool xin0 = (unsigned)x0 < (unsigned)Wl, xin1 = (unsigned)(x0 + 1) < (unsigned)Wl;
+  const bool yin0 = (unsigned)y0 < (unsigned)Hl, yin1 = (unsigned)(y0 + 1) < (unsigned)Hl;
+  t.idx[0] = (yin0 && xin0) ? y0 * Wl + x0 : -1;
+  t.idx[1] = (yin0 && xin1) ? y0 * Wl + x0 + 1 : -1;
+  t.idx[2] = (yin1 && xin0) ? (y0 + 1) * Wl + x0 : -1;
+  t.idx[3] = (yin1 && xin1) ? (y0 + 1) * Wl + x0 + 1 : -1;
+  return t;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void msda_f32_kernel(const float* __restrict__ value, const int32_t* __restrict__ shapes,
+                                                        const int32_t* __restrict__ lstart, int L, int P, const float* __restrict__ loc,
+                                                        const float* __restrict__ attn, const float* __restrict__ grad_out, float* __restrict__ out,
+                                                        float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn,
+                                                        int B, int S, int Q, int M) {
+  const int lane = threadIdx.x & 63;
+  const int bq = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bq >= B * Q) return;
+  const int b = bq / Q;
+  const int h = lane >> 3, cg = lane & 7;
+  const int LP = L * P, CH = M * 32;
+  const int64_t vbase = (int64_t)b * S * CH + h * 32 + cg * 4;
+  const float* locp = loc + ((int64_t)bq * M + h) * LP * 2;
+  const float* attp = attn + ((int64_t)bq * M + h) * LP;
+  float go[4] = {0.f, 0.f, 0.f, 0.f};
+  if (BWD) {
+    const float4 g = *reinterpret_cast<const float4*>(grad_out + (int64_t)bq * CH + h * 32 + cg * 4);
+    go[0] = g.x; go[1] = g.y; go[2] = g.z; go[3] = g.w;
+  }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int l = 0; l < L; ++l) {
+    const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
+    const int64_t lbase = vbase + (int64_t)lstart[l] * CH;
+    for (int pt = 0; pt < P; ++pt) {
+      const int i = l * P + pt;
+      const float aw = attp[i];
+      const Tap4 t = make_taps(locp[2 * i], locp[2 * i + 1], Hl, Wl);
+      float v[4][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (t.idx[k] >= 0) {
+          const float4 x = *reinterpret_cast<const float4*>(value + lbase + (int64_t)t.idx[k] * CH);
+          v[k][0] = x.x; v[k][1] = x.y; v[k][2] = x.z; v[k][3] = x.w;
+        } else {
+          v[k][0] = v[k][1] = v[k][2] = v[k][3] = 0.f;
+        }
+      }
+      if (!BWD) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] += aw * (t.w[0] * v[0][c] + t.w[1] * v[1][c] + t.w[2] * v[2][c] + t.w[3] * v[3][c]);
+      } else {
+        float g_a = 0.f, g_x = 0.f, g_y = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float s = t.w[0] * v[0][c] + t.w[1] * v[1][c] + t.w[2] * v[2][c] + t.w[3] * v[3][c];
+          g_a += go[c] * s;
+          g_x += go[c] * ((v[1][c] - v[0][c]) * (1.f - t.ty) + (v[3][c] - v[2][c]) * t.ty);
+          g_y += go[c] * ((v[2][c] - v[0][c]) * (1.f - t.tx) + (v[3][c] - v[1][c]) * t.tx);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (t.idx[k] >= 0) {
+            float* gv = grad_value + lbase + (int64_t)t.idx[k] * CH;
+            const float wk = aw * t.w[k];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) atomicAdd(gv + c, wk * go[c]);
+          }
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+          g_a += __shfl_xor(g_a, o, 64);
+          g_x += __shfl_xor(g_x, o, 64);
+          g_y += __shfl_xor(g_y, o, 64);
+        }
+        if (cg == 0) {
+          grad_attn[((int64_t)bq * M + h) * LP + i] = g_a;
+          // d(ix)/d(loc_x) = W, d(iy)/d(loc_y) = H  (ix = loc_x * W - 0.5)
+          grad_loc[(((int64_t)bq * M + h) * LP + i) * 2 + 0] = aw * g_x * (float)Wl;
+          grad_loc[(((int64_t)bq * M + h) * LP + i) * 2 + 1] = aw * g_y * (float)Hl;
+        }
+      }
+    }
+  }
+  if (!BWD) *reinterpret_cast<float4*>(out + (int64_t)bq * CH + h * 32 + cg * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+}
+
+extern "C" int fx_msda_f32_fwd(const float* value, const int32_t* spatial_shapes, const int32_t* level_start, int L, int P, const float* loc,
+                               const float* attn, float* out, int B, int S, int Q, int M, fx_stream_t stream_) {
+  FX_CHECK_ARG(value && spatial_shapes && level_start && loc && attn && out && B > 0 && S > 0 && Q > 0 && L > 0 && P > 0);
+  if (M != 8) return FX_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(msda_f32_kernel<false>, dim3((B * Q + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), value, spatial_shapes,
+                     level_start, L, P, loc, attn, nullptr, out, nullptr, nullptr, nullptr, B, S, Q, M);
+  return fx_launch_status();
+}
+
+extern "C" int fx_msda_f32_bwd(const float* value, const int32_t* spatial_shapes, const int32_t* level_start, int L, int P, const float* loc,
+                               const float* attn, const float* grad_out, float* grad_value, float* grad_loc, float* grad_attn, int B, int S, int Q,
+                               int M, fx_stream_t stream_) {
+  FX_CHECK_ARG(value && spatial_shapes && level_start && loc && attn && grad_out && grad_value && grad_loc && grad_attn);
+  FX_CHECK_ARG(B > 0 && S > 0 && Q > 0 && L > 0 && P > 0);
+  if (M != 8) return FX_ERR_UNSUPPORTED;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (hipMemsetAsync(grad_value, 0, (size_t)B * S * M * 32 * sizeof(float), stream) != hipSuccess) return FX_ERR_RUNTIME;
+  hipLaunchKernelGGL(msda_f32_kernel<true>, dim3((B * Q + 3) / 4), dim3(256), 0, stream, value, spatial_shapes, level_start, L, P, loc, attn, grad_out,
+                     nullptr, grad_value, grad_loc, grad_attn, B, S, Q, M);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Fused multi-tensor AdamW with global-norm clipping over ONE flat fp32 parameter buffer.
+// The reference builds one param group per tensor (trainer/solver/build.py:39-138: backbone lr x0.1, no weight decay on
+// norms/biases) and clips the full-model gradient norm (build.py:29-36, trainer.py:758-760).  Here every tensor is a
+// segment of a flat buffer with its own (lr, weight_decay); a chunk table maps workgroups to segments.
+//   pass 1: sum of squared gradients -> per-block partials (fixed order, float64)
+//   pass 2: total norm -> clip coefficient (device side, no host sync) + AdamW update, torch.optim.AdamW arithmetic
+__global__ __launch_bounds__(256) void sqnorm_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ partial) {
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) acc += (double)g[i] * (double)g[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                     const int64_t* __restrict__ chunk_start, const int32_t* __restrict__ chunk_len,
+                                                     const float* __restrict__ chunk_lr, const float* __restrict__ chunk_wd,
+                                                     const double* __restrict__ partial, int npartial, float max_norm, float beta1, float beta2,
+                                                     float eps, float bias_c1, float bias_c2_sqrt, float* __restrict__ total_norm_out) {
+  __shared__ float s_clip;
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int i = 0; i < npartial; ++i) tot += partial[i];
+    const float norm = (float)sqrt(tot);
+    float c = 1.0f;
+    if (max_norm > 0.0f) c = fminf(max_norm / (norm + 1e-6f), 1.0f);  // torch.nn.utils.clip_grad_norm_
+    s_clip = c;
+    if (blockIdx.x == 0 && total_norm_out) *total_norm_out = norm;
+  }
+  __syncthreads();
+  const float clip = s_clip;
+  const int64_t start = chunk_start[blockIdx.x];
+  const int len = chunk_len[blockIdx.x];
+  const float lr = chunk_lr[blockIdx.x], wd = chunk_wd[blockIdx.x];
+  const float step = lr / bias_c1;
+  for (int i = threadIdx.x; i < len; i += 256) {
+    const int64_t j = start + i;
+    const float gg = g[j] * clip;
+    float pp = p[j] * (1.0f - lr * wd);
+    const float mm = beta1 * m[j] + (1.0f - beta1) * gg;
+    const float vv = beta2 * v[j] + (1.0f - beta2) * gg * gg;
+    const float denom = sqrtf(vv) / bias_c2_sqrt + eps;
+    pp -= step * (mm / denom);
+    p[j] = pp;
+    m[j] = mm;
+    v[j] = vv;
+  }
+}
+
+#define NORM_BLOCKS 1024
+
+extern "C" int fx_adamw_workspace_bytes(void) { return NORM_BLOCKS * 8; }
+
+extern "C" int fx_adamw_step_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t numel, const int64_t* chunk_start,
+                                 const int32_t* chunk_len, const float* chunk_lr, const float* chunk_wd, int nchunks, int step, float beta1, float beta2,
+                                 float eps, float max_grad_norm, void* workspace, float* total_norm_out, fx_stream_t stream_) {
+  FX_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && numel > 0 && chunk_start && chunk_len && chunk_lr && chunk_wd && nchunks > 0 && step >= 1);
+  FX_CHECK_ARG(workspace && ((uintptr_t)workspace % 8) == 0);
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  double* partial = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(NORM_BLOCKS), dim3(256), 0, stream, grads, numel, partial);
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, chunk_start, chunk_len, chunk_lr, chunk_wd,
+                     partial, NORM_BLOCKS, max_grad_norm, beta1, beta2, eps, bc1, bc2s, total_norm_out);
+  return fx_launch_status();
+}

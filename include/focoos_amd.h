@@ -181,6 +181,27 @@ int fx_detr_set_loss_f32(const float* logits, int ldl, const float* boxes, const
                          float num_boxes, float focal_alpha, float focal_gamma, float w_vfl, float w_bbox, float w_giou, void* workspace,
                          float* out3, fx_stream_t stream);
 
+/* ms_deform_attn_core in fp32 with its backward - the autograd half of seam B4 (focoos/nn/layers/deformable.py:10-35;
+ * fai_detr/modelling.py:806,880).  value f32 [B,S,M*32], loc f32 [B,Q,M,L,P,2], attn f32 [B,Q,M,L,P] (contiguous),
+ * out / grad_out f32 [B,Q,M*32].  bwd zeroes grad_value [B,S,M*32] itself, then accumulates with fp32 atomics;
+ * grad_loc / grad_attn have the shapes of loc / attn. */
+int fx_msda_f32_fwd(const float* value, const int32_t* spatial_shapes, const int32_t* level_start, int L, int P, const float* loc,
+                    const float* attn, float* out, int B, int S, int Q, int M, fx_stream_t stream);
+int fx_msda_f32_bwd(const float* value, const int32_t* spatial_shapes, const int32_t* level_start, int L, int P, const float* loc,
+                    const float* attn, const float* grad_out, float* grad_value, float* grad_loc, float* grad_attn, int B, int S, int Q, int M,
+                    fx_stream_t stream);
+
+/* Fused multi-tensor AdamW + global-norm gradient clipping over one flat fp32 buffer (replaces the
+ * ~500 single-tensor param groups of focoos/trainer/solver/build.py:39-138 and the clip of :29-36 / trainer.py:758-760).
+ * The buffer is cut into chunks (chunk_start i64, chunk_len i32 <= 65536) each carrying its tensor's lr / weight_decay;
+ * arithmetic of torch.optim.AdamW (decoupled decay, bias correction with `step` >= 1), clip coefficient
+ * min(1, max_grad_norm / (||g|| + 1e-6)) computed on the device (max_grad_norm <= 0: no clipping).
+ * workspace: fx_adamw_workspace_bytes() bytes, 8-byte aligned; total_norm_out (may be NULL) receives ||g||. */
+int fx_adamw_workspace_bytes(void);
+int fx_adamw_step_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t numel, const int64_t* chunk_start,
+                      const int32_t* chunk_len, const float* chunk_lr, const float* chunk_wd, int nchunks, int step, float beta1, float beta2,
+                      float eps, float max_grad_norm, void* workspace, float* total_norm_out, fx_stream_t stream);
+
 /* hipGraph capture of a launch sequence issued on `stream` (HIP graphs instead of a tracing compiler). */
 int fx_graph_begin(fx_stream_t stream);
 int fx_graph_end(fx_stream_t stream, void** graph_exec_out);
