@@ -299,6 +299,7 @@ class _Plan:
         self.keep: List = []              # ctypes structs kept alive
         self.meta: Dict[int, dict] = {}   # op index -> {kind, variant, flops} for bench.py
         self.bufs: Dict[str, NT] = {}
+        self._win = None
         self.graph = None
         self.graph_thr = None
         self._thr_cell = None
@@ -306,6 +307,16 @@ class _Plan:
 
     # -------------------------------------------------------------- helpers
     def _new(self, name: str, B: int, H: int, W: int, Cc: int, dtype=torch.bfloat16) -> NT:
+        if self._win is not None:
+            # batch-window mode (front of the network run chunk by chunk): the buffer is allocated once for the full batch,
+            # the op sees the contiguous NHWC slice of images [b0, b0+bs)
+            b0, bs = self._win
+            assert B == bs, (name, B, bs)
+            full = self.bufs.get(name)
+            if full is None:
+                full = NT(torch.empty(self.B * H * W * Cc, dtype=dtype, device=self.dev), self.B, H, W, Cc, Cc, 0)
+                self.bufs[name] = full
+            return NT(full.t, bs, H, W, Cc, Cc, b0 * H * W * Cc)
         t = torch.empty(B * H * W * Cc, dtype=dtype, device=self.dev)
         nt = NT(t, B, H, W, Cc, Cc, 0)
         self.bufs[name] = nt
@@ -389,31 +400,57 @@ class _Plan:
         self.input = torch.empty(B, H, W, 3, dtype=torch.float32 if self.f32_input else torch.uint8, device=self.dev)
         self.sizes = torch.empty(B, 2, dtype=torch.int32, device=self.dev)
         # ---- backbone (resnet.py:252-266)
-        c1 = self._new("conv1_1", B, H // 2, W // 2, 32)
-        self._op(lib.fx_stem_conv3x3s2, self.input.data_ptr(), int(self.f32_input), e.stem_w.data_ptr(), e.stem_b.data_ptr(),
-                 e.px_mean.data_ptr(), e.px_inv_std.data_ptr(), c1.ptr, B, H, W, 32)
-        x = self.conv(c1, P[f"{bb}.conv1.conv1_2"], name="conv1_2", act="relu")
-        x = self.conv(x, P[f"{bb}.conv1.conv1_3"], name="conv1_3", act="relu")
-        mp = self._new("maxpool", B, H // 4, W // 4, 64)
-        self._op(lib.fx_maxpool3x3s2_nhwc_bf16, x.ptr, x.ld, mp.ptr, mp.ld, B, x.H, x.W, 64)
-        x = mp
+        # Experiment knob (default off): run the HBM-heavy front of the network (stem .. res3, 100-400 MB activations at
+        # bs=32) in batch chunks so that producer->consumer tensors could stay in the 256 MB Infinity Cache between layers.
+        # Measured on MI355X at bs=32: 1/2/4/8 chunks = 2777/2732/2655/2449 img/s - smaller grids cost more than the
+        # cache residency buys, so the full batch is the default.  Chunks write contiguous batch slices of the same buffers.
+        import os
+
+        nchunk = int(os.environ.get("FX_FRONT_CHUNKS", "1"))
+        while nchunk > 1 and (B % nchunk or B // nchunk < 4):
+            nchunk //= 2
+        nchunk = max(nchunk, 1)
+        blocks = RESNET_BLOCKS[e.depth]
         feats = {}
-        for si, n in enumerate(RESNET_BLOCKS[e.depth]):
-            for bi in range(n):
-                p = f"{bb}.res_layers.{si}.blocks.{bi}"
-                stride = 2 if (bi == 0 and si != 0) else 1
-                a = self.conv(x, P[f"{p}.branch2a"], name=f"{p}.a", act="relu")
-                bmid = self.conv(a, P[f"{p}.branch2b"], name=f"{p}.b", stride=stride, act="relu")
-                if bi == 0:
-                    if stride == 2:
-                        pooled = self._new(f"{p}.pool", B, (x.H + 1) // 2, (x.W + 1) // 2, x.C)
-                        self._op(lib.fx_avgpool2x2_nhwc_bf16, x.ptr, x.ld, pooled.ptr, pooled.ld, B, x.H, x.W, x.C)
-                        short = self.conv(pooled, P[f"{p}.short.conv"], name=f"{p}.s")
-                    else:
-                        short = self.conv(x, P[f"{p}.short"], name=f"{p}.s")
+
+        def bottleneck(x, si, bi):
+            p = f"{bb}.res_layers.{si}.blocks.{bi}"
+            stride = 2 if (bi == 0 and si != 0) else 1
+            a = self.conv(x, P[f"{p}.branch2a"], name=f"{p}.a", act="relu")
+            bmid = self.conv(a, P[f"{p}.branch2b"], name=f"{p}.b", stride=stride, act="relu")
+            if bi == 0:
+                if stride == 2:
+                    pooled = self._new(f"{p}.pool", x.B, (x.H + 1) // 2, (x.W + 1) // 2, x.C)
+                    self._op(lib.fx_avgpool2x2_nhwc_bf16, x.ptr, x.ld, pooled.ptr, pooled.ld, x.B, x.H, x.W, x.C)
+                    short = self.conv(pooled, P[f"{p}.short.conv"], name=f"{p}.s")
                 else:
-                    short = x
-                x = self.conv(bmid, P[f"{p}.branch2c"], name=f"{p}.c", residual=short, act="relu")
+                    short = self.conv(x, P[f"{p}.short"], name=f"{p}.s")
+            else:
+                short = x
+            return self.conv(bmid, P[f"{p}.branch2c"], name=f"{p}.c", residual=short, act="relu")
+
+        bs = B // nchunk
+        in_img = H * W * 3 * self.input.element_size()
+        for ck in range(nchunk):
+            self._win = (ck * bs, bs) if nchunk > 1 else None
+            c1 = self._new("conv1_1", bs, H // 2, W // 2, 32)
+            self._op(lib.fx_stem_conv3x3s2, self.input.data_ptr() + ck * bs * in_img, int(self.f32_input), e.stem_w.data_ptr(), e.stem_b.data_ptr(),
+                     e.px_mean.data_ptr(), e.px_inv_std.data_ptr(), c1.ptr, bs, H, W, 32)
+            x = self.conv(c1, P[f"{bb}.conv1.conv1_2"], name="conv1_2", act="relu")
+            x = self.conv(x, P[f"{bb}.conv1.conv1_3"], name="conv1_3", act="relu")
+            mp = self._new("maxpool", bs, H // 4, W // 4, 64)
+            self._op(lib.fx_maxpool3x3s2_nhwc_bf16, x.ptr, x.ld, mp.ptr, mp.ld, bs, x.H, x.W, 64)
+            x = mp
+            for si in (0, 1):
+                for bi in range(blocks[si]):
+                    x = bottleneck(x, si, bi)
+        self._win = None
+        last3 = f"{bb}.res_layers.1.blocks.{blocks[1] - 1}.c"
+        x = self.bufs[last3] if nchunk > 1 else x
+        feats[3] = x
+        for si in (2, 3):
+            for bi in range(blocks[si]):
+                x = bottleneck(x, si, bi)
             feats[si + 2] = x
         self.bufs["res3"], self.bufs["res4"], self.bufs["res5"] = feats[3], feats[4], feats[5]
         # ---- hybrid encoder (modelling.py:297-347)
