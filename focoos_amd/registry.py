@@ -1,5 +1,5 @@
-"""Model registry of the engine: the RT-DETR entries of the reference's registry
-(focoos/model_registry/fai-detr-l-{obj365,coco}.json — config values are the spec
+"""Model registry of the engine: the RT-DETR and MaskFormer-L entries of the reference's registry
+(focoos/model_registry/fai-detr-l-{obj365,coco}.json, fai-mf-l-coco-ins.json — config values are the spec
 for every shape on the hot path).  Weights URIs are remote in the reference;
 offline the engine is constructed with seeded synthetic weights (``synth.py``)
 or a local ``model_final.pth`` given by ``weights_uri``."""
@@ -35,7 +35,35 @@ def _entry(name: str, num_classes: int, description: str) -> Dict:
     }
 
 
+_MF_L_COCO_INS_CONFIG = {
+    "num_classes": 80,
+    "backbone_config": {
+        "use_pretrained": False, "backbone_url": None, "model_type": "resnet", "in_chans": 3, "depth": 101,
+        "variant": "d", "freeze_at": -1, "num_stages": 4, "freeze_norm": False, "act": "relu", "pretrained": False,
+    },
+    "num_queries": 100, "resolution": 1024,
+    "pixel_mean": [123.675, 116.28, 103.53], "pixel_std": [58.395, 57.12, 57.375], "size_divisibility": 0,
+    "pixel_decoder_out_dim": 256, "pixel_decoder_feat_dim": 256, "pixel_decoder_transformer_layers": 6,
+    "pixel_decoder_transformer_dropout": 0.0, "pixel_decoder_transformer_nheads": 8,
+    "pixel_decoder_transformer_dim_feedforward": 1024,
+    "transformer_predictor_out_dim": 256, "transformer_predictor_hidden_dim": 256,
+    "transformer_predictor_dec_layers": 9, "transformer_predictor_dim_feedforward": 2048,
+    "head_out_dim": 256, "cls_sigmoid": False, "postprocessing_type": "instance", "mask_threshold": 0.5,
+    "predict_all_pixels": False, "use_mask_score": True, "threshold": 0.5, "top_k": 100,
+}
+
+
+def _mf_entry(name: str, cfg: Dict, description: str) -> Dict:
+    cfg = copy.deepcopy(cfg)
+    return {
+        "name": name, "model_family": "fai_mf", "task": "instseg", "im_size": int(cfg["resolution"]),
+        "classes": [f"class_{i}" for i in range(int(cfg["num_classes"]))],
+        "config": cfg, "weights_uri": None, "description": description,
+    }
+
+
 _REGISTRY = {
+    "fai-mf-l-coco-ins": _mf_entry("fai-mf-l-coco-ins", _MF_L_COCO_INS_CONFIG, "MaskFormer large (R101-vd), COCO instance segmentation"),
     "fai-detr-l-obj365": _entry("fai-detr-l-obj365", 365, "RT-DETR large (R50-vd), Objects365 head"),
     "fai-detr-l-coco": _entry("fai-detr-l-coco", 80, "RT-DETR large (R50-vd), COCO head"),
 }

@@ -1,4 +1,4 @@
-"""State-dict layout of the RT-DETR family (``fai-detr-*`` with a ResNet-vd backbone).
+"""State-dict layouts of the RT-DETR family (``fai-detr-*``) and the MaskFormer family (``fai-mf-*``), ResNet-vd backbones.
 
 The engine keeps the reference's checkpoint key names unchanged so that a
 ``model_final.pth`` written by the reference loads into it and vice versa
@@ -8,7 +8,7 @@ what ``FAIDetr(config).state_dict()`` yields in the reference
 ``tests/golden/detr_l_state_keys.json`` is a dump of the reference's own keys and
 ``tests/test_state_spec.py`` pins this generator against it.
 
-kinds: conv_w, bn_w, bn_b, bn_mean, bn_var, bn_nbt, lin_w, lin_b, ln_w, ln_b, buf
+kinds: conv_w, bn_w, bn_b, bn_mean, bn_var, bn_nbt, lin_w, lin_b, ln_w, ln_b, emb, buf
 """
 from __future__ import annotations
 
@@ -149,3 +149,75 @@ def detr_state_spec(config: Dict) -> "OrderedDict[str, Tuple[Tuple[int, ...], st
         for j, (a, b) in enumerate([(hd, hd), (hd, hd), (hd, 4)]):
             _linear(spec, f"head.predictor.dec_bbox_classifier.{li}.layers.{j}", a, b)
     return spec
+
+
+def mf_state_spec(config: Dict) -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
+    """Ordered ``name -> (shape, kind)`` of ``FAIMaskFormer(config).state_dict()``
+    (focoos/models/fai_mf/modelling.py:633-710: TransformerFPN :201-338, MultiScaleMaskedTransformerDecoder :372-499,
+    PredictionHeads :28-60); pinned against the reference's own key dump in tests/golden/mf_l_state_keys.json."""
+    bb = config["backbone_config"]
+    if bb.get("model_type", "resnet") != "resnet":
+        raise ValueError("engine state spec covers resnet backbones (fai-mf-l-*)")
+    nc = int(config["num_classes"])
+    fd = int(config.get("pixel_decoder_feat_dim", 256))
+    od = int(config.get("pixel_decoder_out_dim", 256))
+    n_enc = int(config.get("pixel_decoder_transformer_layers", 0))
+    ffe = int(config.get("pixel_decoder_transformer_dim_feedforward", 1024))
+    hd = int(config.get("transformer_predictor_hidden_dim", 256))
+    md = int(config.get("transformer_predictor_out_dim", 256))
+    ffd = int(config.get("transformer_predictor_dim_feedforward", 1024))
+    nl = int(config.get("transformer_predictor_dec_layers", 6))
+    nq = int(config.get("num_queries", 100))
+
+    spec: "OrderedDict[str, Tuple[Tuple[int, ...], str]]" = OrderedDict()
+    chans = resnet_vd_spec(spec, "pixel_decoder.backbone", int(bb.get("depth", 50)), int(bb.get("in_chans", 3)))
+    P = "pixel_decoder"
+    if n_enc > 0:
+        spec[f"{P}.input_proj.weight"] = ((fd, chans[-1], 1, 1), "conv_w")
+        spec[f"{P}.input_proj.bias"] = ((fd,), "lin_b")
+        for li in range(n_enc):
+            p = f"{P}.transformer.encoder.layers.{li}"
+            _mha(spec, f"{p}.self_attn", fd)
+            _linear(spec, f"{p}.linear1", fd, ffe)
+            _linear(spec, f"{p}.linear2", ffe, fd)
+            _ln(spec, f"{p}.norm1", fd)
+            _ln(spec, f"{p}.norm2", fd)
+        _ln(spec, f"{P}.transformer.encoder.norm", fd)
+    for idx, c in enumerate(chans):
+        if idx < len(chans) - 1:
+            spec[f"{P}.adapter_{idx + 1}.weight"] = ((fd, c, 1, 1), "conv_w")
+            _bn(spec, f"{P}.adapter_{idx + 1}.norm", fd)
+        spec[f"{P}.layer_{idx + 1}.weight"] = ((fd, fd if (idx < len(chans) - 1 or n_enc > 0) else c, 3, 3), "conv_w")
+        _bn(spec, f"{P}.layer_{idx + 1}.norm", fd)
+    spec[f"{P}.mask_features.weight"] = ((od, fd, 3, 3), "conv_w")
+    spec[f"{P}.mask_features.bias"] = ((od,), "lin_b")
+    spec["head.criterion.empty_weight"] = ((nc + 1,), "buf")
+    H = "head.predictor"
+    for li in range(nl):
+        _mha(spec, f"{H}.transformer_self_attention_layers.{li}.self_attn", hd)
+        _ln(spec, f"{H}.transformer_self_attention_layers.{li}.norm", hd)
+    for li in range(nl):
+        _mha(spec, f"{H}.transformer_cross_attention_layers.{li}.multihead_attn", hd)
+        _ln(spec, f"{H}.transformer_cross_attention_layers.{li}.norm", hd)
+    for li in range(nl):
+        _linear(spec, f"{H}.transformer_ffn_layers.{li}.linear1", hd, ffd)
+        _linear(spec, f"{H}.transformer_ffn_layers.{li}.linear2", ffd, hd)
+        _ln(spec, f"{H}.transformer_ffn_layers.{li}.norm", hd)
+    spec[f"{H}.query_feat.weight"] = ((nq, hd), "emb")
+    spec[f"{H}.query_embed.weight"] = ((nq, hd), "emb")
+    for i in range(min(3, nl)):
+        spec[f"{H}.input_proj.{i}.weight"] = ((hd, od, 1, 1), "conv_w")
+        spec[f"{H}.input_proj.{i}.bias"] = ((hd,), "lin_b")
+    _ln(spec, f"{H}.forward_prediction_heads.decoder_norm", hd)
+    _linear(spec, f"{H}.forward_prediction_heads.classifier", hd, nc + 1)
+    for j, (a, b) in enumerate([(hd, hd), (hd, hd), (hd, md)]):
+        _linear(spec, f"{H}.forward_prediction_heads.mask_classifier.layers.{j}", a, b)
+    return spec
+
+
+def state_spec(config: Dict, family: str = "fai_detr"):
+    if family == "fai_detr":
+        return detr_state_spec(config)
+    if family == "fai_mf":
+        return mf_state_spec(config)
+    raise ValueError(f"engine has no state spec for model family {family!r}")

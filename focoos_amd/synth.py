@@ -18,15 +18,15 @@ from typing import Dict
 import numpy as np
 import torch
 
-from .state_spec import detr_state_spec
+from .state_spec import state_spec
 
 
 def _rs(seed: int, name: str) -> np.random.RandomState:
     return np.random.RandomState((seed * 1000003 + zlib.crc32(name.encode())) % (2**32))
 
 
-def synth_state_dict(config: Dict, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
-    spec = detr_state_spec(config)
+def synth_state_dict(config: Dict, seed: int = 0, family: str = "fai_detr") -> "OrderedDict[str, torch.Tensor]":
+    spec = state_spec(config, family)
     out: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     for name, (shape, kind) in spec.items():
         rs = _rs(seed, name)
@@ -51,6 +51,8 @@ def synth_state_dict(config: Dict, seed: int = 0) -> "OrderedDict[str, torch.Ten
             gain = 1.0
             if "score_classifier" in name:
                 gain = 2.0
+            elif name.endswith("forward_prediction_heads.classifier.weight"):
+                gain = 4.0  # softmax over K+1 classes: make some queries confident enough to pass the 0.5 threshold
             elif "bbox_classifier" in name and name.endswith("layers.2.weight"):
                 gain = 0.5
             elif "query_pos_head.layers.0" in name:
@@ -67,6 +69,8 @@ def synth_state_dict(config: Dict, seed: int = 0) -> "OrderedDict[str, torch.Ten
             a = rs.uniform(0.8, 1.2, shape).astype(np.float32)
         elif kind == "ln_b":
             a = (0.05 * rs.standard_normal(shape)).astype(np.float32)
+        elif kind == "emb":
+            a = rs.standard_normal(shape).astype(np.float32)
         elif kind == "buf":
             a = np.ones(shape, dtype=np.float32)
             a[-1] = 0.1

@@ -167,3 +167,23 @@ def build_reference_detr(config_dict: dict, name: str = "fai-detr-l-obj365"):
     im = config_dict.get("resolution") or 640
     proc = DETRProcessor(cfg, image_size=im).eval()
     return model, proc, cfg
+
+
+def build_reference_mf(config_dict: dict):
+    """Build the reference's FAIMaskFormer + MaskFormerProcessor from a registry-style config dict
+    (same recipe as ``build_reference_detr``).  Returns ``(model, processor, config)``; eval mode, CPU."""
+    install()
+    import focoos.models.fai_mf as fam
+    from focoos.model_manager import ConfigManager
+    from focoos.models.fai_mf.modelling import FAIMaskFormer
+    from focoos.models.fai_mf.processor import MaskFormerProcessor
+    from focoos.ports import ModelFamily
+
+    for attr in dir(fam):  # family registration hooks (model_manager.py:108-126)
+        if attr.startswith("_register"):
+            getattr(fam, attr)()
+    cfg = ConfigManager.from_dict(ModelFamily.MASKFORMER, dict(config_dict))
+    model = FAIMaskFormer(cfg)
+    model.eval()
+    proc = MaskFormerProcessor(cfg).eval()
+    return model, proc, cfg

@@ -179,6 +179,88 @@ def criterion_case():
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB); losses {g['loss']}")
 
 
+def mf_case(tag: str = "mf_l_coco_ins_b2", seed: int = 3, hw=(160, 192)):
+    """Golden vectors of the REAL reference's FAIMaskFormer + MaskFormerProcessor (fai_mf/modelling.py, fai_mf/processor.py)
+    on seeded synthetic weights / images: stage samples, the boolean attention masks each decoder layer used (the discrete
+    step a bf16 engine is teacher-forced with), low-res mask logits, class probabilities and the batch-1 post-process."""
+    from focoos_amd.synth import synth_image_structured as sis
+    info = ModelRegistry.get_model_info("fai-mf-l-coco-ins")
+    cfg = info["config"]
+    model, proc, _ = ref_import.build_reference_mf(cfg)
+    import focoos.models.fai_mf.processor as fp
+    fp.binary_mask_to_base64 = lambda m: ""  # the cv2/PNG tail is absent here and outside the path (SURVEY §8a A12)
+    sd = synth_state_dict(cfg, seed=seed, family="fai_mf")
+    res = model.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    cap = {}
+    model.pixel_decoder.backbone.register_forward_hook(lambda m, i, o: cap.__setitem__("bb", o))
+    model.pixel_decoder.transformer.register_forward_hook(lambda m, i, o: cap.__setitem__("enc", o))
+    model.pixel_decoder.register_forward_hook(lambda m, i, o: cap.__setitem__("pd", o))
+    model.head.predictor.register_forward_hook(lambda m, i, o: cap.__setitem__("pred", o))
+    masks_used = []
+    for lyr in model.head.predictor.transformer_cross_attention_layers:
+        lyr.register_forward_pre_hook(lambda m, a, kw: masks_used.append(kw["memory_mask"]), with_kwargs=True)
+    dec_out = []
+    for lyr in model.head.predictor.transformer_ffn_layers:
+        lyr.register_forward_hook(lambda m, i, o: dec_out.append(o))
+    images = [sis(i, *hw) for i in range(2)]
+    x, _ = proc.preprocess(images, device=torch.device("cpu"), dtype=torch.float32)
+    with torch.no_grad():
+        out = model(x)
+    B = x.shape[0]
+    g = {"seed": np.int64(seed), "hw": np.array(hw), "pre_sample": strided_sample(x, 4096)}
+    for k in ("res2", "res3", "res4", "res5"):
+        g[f"{k}_sample"] = strided_sample(cap["bb"][k], 4096)
+    g["enc_sample"] = strided_sample(cap["enc"], 4096)
+    mf, msf = cap["pd"]
+    g["mask_features_sample"] = strided_sample(mf, 8192)
+    for i in range(3):
+        g[f"msf{i}_sample"] = strided_sample(msf[i], 4096)
+    for i, m in enumerate(masks_used):  # [B*heads, Q, Lk], identical across heads
+        mm = m.view(B, 8, m.shape[1], m.shape[2])
+        assert bool((mm == mm[:, :1]).all())
+        g[f"attn_mask{i}"] = np.packbits(mm[:, 0].numpy(), axis=-1)
+        g[f"attn_mask{i}_len"] = np.int64(m.shape[2])
+    for i, o in enumerate(dec_out):  # [Q, B, C]
+        g[f"dec{i}_sample"] = strided_sample(o.permute(1, 0, 2).contiguous(), 2048)
+    g["cls_logits"] = cap["pred"]["pred_logits"].numpy()
+    g["mask_logits_f16"] = cap["pred"]["pred_masks"].numpy().astype(np.float16)
+    g["probs"] = out.logits.numpy()
+    g["masks_sample"] = strided_sample(out.masks, 16384)
+    for i in range(B):
+        o1 = type(out)(masks=out.masks[i:i + 1], logits=out.logits[i:i + 1], loss=None)
+        d = proc.postprocess(o1, [images[i]])[0].detections
+        g[f"det{i}_conf"] = np.array([a.conf for a in d], np.float32)
+        g[f"det{i}_cls"] = np.array([a.cls_id for a in d], np.int64)
+        g[f"det{i}_bbox"] = np.array([a.bbox for a in d], np.int64).reshape(-1, 4)
+    np.savez_compressed(os.path.join(GOLDEN, tag + ".npz"), **g)
+    print(tag, {k: v.shape for k, v in g.items() if hasattr(v, "shape") and v.ndim}, [len(g[f"det{i}_conf"]) for i in range(B)])
+
+
+def masks_to_xyxy_case():
+    """The reference's own known-answer vectors for this path: tests/utils/test_vision.py:185-205 (test_masks_to_xyxy),
+    evaluated with the reference's masks_to_xyxy (utils/vision.py:344-370) on extra seeded random masks as well."""
+    ref_import.install()
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("_ref_vision_m2x", os.path.join(ref_import.REFERENCE_ROOT, "focoos/utils/vision.py"))
+    rs = np.random.RandomState(11)
+    masks = np.zeros((16, 24, 40), bool)
+    for m in masks:  # a random rectangle plus a few stray pixels
+        y0, x0 = rs.randint(0, 20), rs.randint(0, 36)
+        m[y0:y0 + rs.randint(1, 12), x0:x0 + rs.randint(1, 20)] = True
+        m[rs.randint(0, 24, 2), rs.randint(0, 40, 2)] = True
+    masks[3] = False
+    try:
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        fn = mod.masks_to_xyxy
+    except Exception:
+        from focoos.utils.vision import masks_to_xyxy as fn
+    np.savez_compressed(os.path.join(GOLDEN, "masks_to_xyxy.npz"), masks=np.packbits(masks, axis=-1), shape=np.array(masks.shape),
+                        xyxy=fn(masks).astype(np.int64))
+    print("masks_to_xyxy", fn(masks)[:4].tolist())
+
+
 def main():
     torch.set_num_threads(os.cpu_count() or 1)
     os.makedirs(GOLDEN, exist_ok=True)
@@ -187,7 +269,13 @@ def main():
     run_case("fai-detr-l-coco", 1, [synth_image_structured(2, 480, 600)], "detr_l_coco_resize")
     deform_core_case()
     criterion_case()
+    mf_case()
+    masks_to_xyxy_case()
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and len(sys.argv) > 1:
+    torch.set_num_threads(os.cpu_count() or 1)
+    for name in sys.argv[1:]:  # e.g. `python scripts/make_golden.py mf_case masks_to_xyxy_case`
+        globals()[name]()
+elif __name__ == "__main__":
     main()

@@ -50,3 +50,32 @@ def test_reference_state_keys_match_spec():
     ref = {k: tuple(v.shape) for k, v in model.state_dict().items()}
     mine = {k: tuple(v[0]) for k, v in detr_state_spec(cfg).items()}
     assert list(ref) == list(mine) and ref == mine
+
+
+def test_mf_oracle_matches_reference_live():
+    """MaskFormer (A11/A12): forward + batch-1 postprocess of the restatement vs the real reference, another seed and
+    size than the committed golden."""
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.synth import synth_image_structured, synth_state_dict
+    from oracle import mf_oracle as M
+    import focoos.models.fai_mf.processor as fp
+
+    cfg = ModelRegistry.get_model_info("fai-mf-l-coco-ins")["config"]
+    model, proc, _ = ref_import.build_reference_mf(cfg)
+    fp.binary_mask_to_base64 = lambda m: ""  # cv2/PNG tail is not installed and outside the path
+    sd = synth_state_dict(cfg, seed=7, family="fai_mf")
+    model.load_state_dict(sd, strict=True)
+    assert list(model.state_dict()) == list(sd)
+    imgs = [synth_image_structured(21, 96, 128)]
+    x, _ = proc.preprocess(imgs, device=torch.device("cpu"), dtype=torch.float32)
+    with torch.no_grad():
+        out = model(x)
+        probs, masks = M.mf_forward(sd, cfg, x)
+    np.testing.assert_allclose(probs.numpy(), out.logits.numpy(), atol=1e-4)
+    assert (masks - out.masks).abs().max().item() < 5e-3
+    dets = proc.postprocess(out, imgs)[0].detections
+    s, l, q, boxes, bm = M.postprocess(probs, masks, [(96, 128)], cfg["mask_threshold"], cfg["threshold"], cfg["use_mask_score"])[0]
+    assert len(dets) == len(s)
+    np.testing.assert_allclose([d.conf for d in dets], s.numpy(), atol=5e-4)
+    assert [d.cls_id for d in dets] == l.tolist()
+    assert [list(d.bbox) for d in dets] == boxes.tolist()
