@@ -43,6 +43,13 @@ SIGNATURES = {
     "fx_add_rows_bf16": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp],
     "fx_layernorm_bf16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "fx_mha_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "fx_mha_masked_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],
+    "fx_upsample_nearest_add_nhwc_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "fx_query_pixel_logits_bf16": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "fx_mf_class_head": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "fx_mf_upsample_probs_f32": [_vp, _i, _i, _vp, _i, _i, _i, _vp],
+    "fx_mf_postprocess_workspace_bytes": [_i, _i, _i],
+    "fx_mf_postprocess": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _i, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "fx_msda_bf16": [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "fx_rowmax_f32": [_vp, _i, _vp, _i, _i, _vp],
     "fx_topk_rows_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _vp],

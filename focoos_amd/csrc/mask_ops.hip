@@ -1,0 +1,385 @@
+// MaskFormer-specific kernels (gfx950): FPN nearest-upsample + lateral add, query x pixel mask logits on MFMA
+// (attention-mask bits / sigmoid mask probabilities), class softmax head, and the device side of
+// MaskFormerProcessor.postprocess (bilinear x4 upsample of the mask probabilities fused with threshold, mask score,
+// bounding box and bit-packed binary masks).  Reference: focoos/models/fai_mf/modelling.py, fai_mf/processor.py.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// y = lateral + nearest_upsample(top)   (TransformerFPN.forward_features, fai_mf/modelling.py:364;
+// F.interpolate(mode="nearest"): src = floor(dst * in/out)).  8 channels (16 B) per thread.
+__global__ __launch_bounds__(256) void upsample_nearest_add_kernel(const bf16_t* __restrict__ lat, int ldl, const bf16_t* __restrict__ top,
+                                                                   int ldt, bf16_t* __restrict__ out, int ldo, int B, int H, int W, int Hs,
+                                                                   int Ws, int C8) {
+  const int64_t total = (int64_t)B * H * W * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    int64_t p = i / C8;
+    const int x = (int)(p % W);
+    p /= W;
+    const int y = (int)(p % H);
+    const int b = (int)(p / H);
+    const int ys = (int)(((int64_t)y * Hs) / H), xs = (int)(((int64_t)x * Ws) / W);
+    float a[8], t[8];
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(lat + (((int64_t)b * H + y) * W + x) * ldl + c8 * 8), a);
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(top + (((int64_t)b * Hs + ys) * Ws + xs) * ldt + c8 * 8), t);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] += t[j];
+    *reinterpret_cast<uint4*>(out + (((int64_t)b * H + y) * W + x) * ldo + c8 * 8) = pack_bf16x8(a);
+  }
+}
+
+extern "C" int fx_upsample_nearest_add_nhwc_bf16(const void* lateral, int ldl, const void* top, int ldt, void* out, int ldo, int B, int H,
+                                                 int W, int Hs, int Ws, int C, fx_stream_t stream_) {
+  FX_CHECK_ARG(lateral && top && out && B > 0 && H > 0 && W > 0 && Hs > 0 && Ws > 0 && C > 0 && C % 8 == 0);
+  FX_CHECK_ARG(ldl >= C && ldt >= C && ldo >= C && ldl % 8 == 0 && ldt % 8 == 0 && ldo % 8 == 0);
+  int64_t total = (int64_t)B * H * W * (C / 8);
+  int64_t grid = (total + 255) / 256;
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(upsample_nearest_add_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
+                     (const bf16_t*)lateral, ldl, (const bf16_t*)top, ldt, (bf16_t*)out, ldo, B, H, W, Hs, Ws, C / 8);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Query x pixel logits: out[b, q, p] = sum_c embed[b, q, c] * feat[b, p, c], C = 256, Q <= 128
+// (PredictionHeads.forward: torch.einsum("bqc,bchw->bqhw", mask_embed, mask_features), fai_mf/modelling.py:88).
+// One workgroup = one image's query embeddings staged in LDS (128 x 512 B, 16-byte chunks XOR-swizzled by the row)
+// x 256 pixels (each wave two 32-pixel tiles).  Pixel rows go from global memory straight into the MFMA B operand
+// (lane = pixel lane&31, 8 channels at 16*kk + 8*(lane>>5)); A = 32 queries from LDS; the 32x32 accumulator has
+// column = pixel, row = query, so stores along a query row are 128-byte contiguous and a wave ballot of (logit < 0)
+// IS the 32-pixel word of the attention-mask bitmap.
+//   MODE 0: f32 logits        out_f32[(b*Q+q)*ldo + p]
+//   MODE 1: f32 sigmoid(logit)
+//   MODE 2: attention-mask bits (fai_mf/modelling.py:104: mask = resized logit < 0; the bilinear resize of the logits is
+//           applied to `feat` beforehand, which is the same linear map): bits[(b*Q+q)*ldw + p/32], bit p&31; pixels
+//           beyond P read as masked.
+template <int MODE>
+__global__ __launch_bounds__(256) void query_pixel_logits_kernel(const bf16_t* __restrict__ embed, int lde, const bf16_t* __restrict__ feat,
+                                                                 int ldf, float* __restrict__ out, int ldo, uint32_t* __restrict__ bits,
+                                                                 int ldw, int Q, int P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char es[];  // [128][32 chunks of 16 B]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.y;
+  const bf16_t* eb = embed + (int64_t)b * Q * lde;
+  for (int i = tid; i < 128 * 32; i += 256) {
+    const int row = i >> 5, c = i & 31;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < Q) v = *reinterpret_cast<const uint4*>(eb + (int64_t)row * lde + c * 8);
+    *reinterpret_cast<uint4*>(es + row * 512 + ((c ^ (row & 31)) << 4)) = v;
+  }
+  __syncthreads();
+  const int j = lane & 31, h = lane >> 5;
+  const bf16_t* fb = feat + (int64_t)b * P * ldf;
+  const int nqt = (Q + 31) >> 5;
+#pragma unroll 1
+  for (int tt = 0; tt < 2; ++tt) {
+    const int p0 = blockIdx.x * 256 + (wave * 2 + tt) * 32;
+    if (p0 >= P) break;
+    const int p = p0 + j;
+    bf16x8 kf[16];
+    {
+      const bf16_t* fp = fb + (int64_t)(p < P ? p : P - 1) * ldf + 8 * h;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) kf[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fp + kk * 16));
+    }
+#pragma unroll 1
+    for (int qt = 0; qt < nqt; ++qt) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+      const int row = qt * 32 + j;
+      const unsigned char* er = es + row * 512;
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        bf16x8 a = *reinterpret_cast<const bf16x8*>(er + (((kk * 2 + h) ^ (row & 31)) << 4));
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[kk], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int qq = qt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (MODE == 2) {
+          const unsigned long long bal = __ballot(acc[r] < 0.0f || p >= P);
+          // low word: query row (h = 0), high word: query row + 4 (h = 1)
+          const int ql = qt * 32 + (r & 3) + 8 * (r >> 2);
+          if (lane == 0 && ql < Q) bits[((int64_t)b * Q + ql) * ldw + (p0 >> 5)] = (uint32_t)bal;
+          if (lane == 32 && ql + 4 < Q) bits[((int64_t)b * Q + ql + 4) * ldw + (p0 >> 5)] = (uint32_t)(bal >> 32);
+        } else if (qq < Q && p < P) {
+          out[((int64_t)b * Q + qq) * ldo + p] = MODE == 1 ? 1.0f / (1.0f + __expf(-acc[r])) : acc[r];
+        }
+      }
+    }
+  }
+}
+
+extern "C" int fx_query_pixel_logits_bf16(const void* embed, int lde, const void* feat, int ldf, int mode, float* out, int ldo,
+                                          uint32_t* bits, int ld_words, int B, int Q, int P, int C, fx_stream_t stream_) {
+  FX_CHECK_ARG(embed && feat && B > 0 && Q > 0 && P > 0);
+  if (C != 256 || Q > 128) return FX_ERR_UNSUPPORTED;
+  FX_CHECK_ARG(lde >= C && ldf >= C && lde % 8 == 0 && ldf % 8 == 0);
+  FX_CHECK_ARG(mode == 2 ? (bits && ld_words >= (P + 31) / 32) : ((mode == 0 || mode == 1) && out && ldo >= P));
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  dim3 grid((P + 255) / 256, B), block(256);
+  const size_t lds = 128 * 512;
+#define FX_QPL(M)                                                                                                                  \
+  hipLaunchKernelGGL(query_pixel_logits_kernel<M>, grid, block, lds, stream, (const bf16_t*)embed, lde, (const bf16_t*)feat, ldf, out, ldo, \
+                     bits, ld_words, Q, P)
+  if (mode == 0) FX_QPL(0);
+  else if (mode == 1) FX_QPL(1);
+  else FX_QPL(2);
+#undef FX_QPL
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Class head tail (MaskFormerHead.forward, fai_mf/modelling.py:610-613): softmax over K+1 logits with the
+// no-object column dropped (or sigmoid when cls_sigmoid), plus the per-query max / argmax that
+// MaskFormerProcessor.postprocess takes first (processor.py:212).  One wave per query row, K+1 <= 256.
+__global__ __launch_bounds__(256) void mf_class_head_kernel(const float* __restrict__ logits, int ldl, float* __restrict__ probs,
+                                                            float* __restrict__ score, int32_t* __restrict__ label, int rows, int K,
+                                                            int use_sigmoid) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* lp = logits + (int64_t)row * ldl;
+  float v[4], mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    v[i] = c <= K ? lp[c] : -INFINITY;
+    mx = fmaxf(mx, v[i]);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float e[4], sum = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    e[i] = (lane + 64 * i) <= K ? __expf(v[i] - mx) : 0.0f;
+    sum += e[i];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float inv = 1.0f / sum;
+  float best = -INFINITY;
+  int bi = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    if (c < K) {
+      const float pr = use_sigmoid ? 1.0f / (1.0f + __expf(-v[i])) : e[i] * inv;
+      probs[(int64_t)row * K + c] = pr;
+      if (pr > best) best = pr, bi = c;  // ascending c per lane: keeps the lowest index among equal values
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ob = __shfl_xor(best, o, 64);
+    const int oi = __shfl_xor(bi, o, 64);
+    if (ob > best || (ob == best && oi < bi)) best = ob, bi = oi;
+  }
+  if (lane == 0) {
+    score[row] = best;
+    label[row] = bi;
+  }
+}
+
+extern "C" int fx_mf_class_head(const float* logits, int ldl, float* probs, float* score, int32_t* label, int rows, int K,
+                                int use_sigmoid, fx_stream_t stream_) {
+  FX_CHECK_ARG(logits && probs && score && label && rows > 0 && K > 0 && ldl >= K + 1);
+  if (K + 1 > 256) return FX_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(mf_class_head_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), logits, ldl, probs,
+                     score, label, rows, K, use_sigmoid);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Bilinear upsample of the mask probabilities, align_corners=False (FAIMaskFormer.forward, fai_mf/modelling.py:723):
+// src = max((dst + 0.5) * in/out - 0.5, 0), i0 = floor(src), i1 = min(i0 + 1, in - 1), lambda = src - i0.
+struct LerpAxis {
+  int i0, i1;
+  float w0, w1;
+};
+
+__device__ __forceinline__ LerpAxis lerp_axis(int dst, float scale, int in) {
+  float src = ((float)dst + 0.5f) * scale - 0.5f;
+  src = src < 0.0f ? 0.0f : src;
+  LerpAxis a;
+  a.i0 = (int)src;
+  if (a.i0 > in - 1) a.i0 = in - 1;
+  a.i1 = a.i0 + (a.i0 < in - 1 ? 1 : 0);
+  a.w1 = src - (float)a.i0;
+  a.w0 = 1.0f - a.w1;
+  return a;
+}
+
+__device__ __forceinline__ float lerp2(const float* __restrict__ p, int w, const LerpAxis& ay, const LerpAxis& ax) {
+  const float* r0 = p + (int64_t)ay.i0 * w;
+  const float* r1 = p + (int64_t)ay.i1 * w;
+  return ay.w0 * (ax.w0 * r0[ax.i0] + ax.w1 * r0[ax.i1]) + ay.w1 * (ax.w0 * r1[ax.i0] + ax.w1 * r1[ax.i1]);
+}
+
+// masks[b,q,y,x] f32 — the reference's `masks` output tensor (B x Q x H x W x 4 bytes: pure HBM write).
+__global__ __launch_bounds__(256) void mf_upsample_probs_kernel(const float* __restrict__ lo, int h, int w, float* __restrict__ out, int H,
+                                                                int W, float sy, float sx) {
+  const int bq = blockIdx.y;
+  const float* p = lo + (int64_t)bq * h * w;
+  float* o = out + (int64_t)bq * H * W;
+  const int rows_per_block = 8;
+  const int y0 = blockIdx.x * rows_per_block;
+  for (int x = threadIdx.x; x < W; x += 256) {
+    const LerpAxis ax = lerp_axis(x, sx, w);
+    for (int y = y0; y < y0 + rows_per_block && y < H; ++y) {
+      const LerpAxis ay = lerp_axis(y, sy, h);
+      o[(int64_t)y * W + x] = lerp2(p, w, ay, ax);
+    }
+  }
+}
+
+extern "C" int fx_mf_upsample_probs_f32(const float* lowres, int h, int w, float* out, int H, int W, int BQ, fx_stream_t stream_) {
+  FX_CHECK_ARG(lowres && out && h > 0 && w > 0 && H > 0 && W > 0 && BQ > 0);
+  hipLaunchKernelGGL(mf_upsample_probs_kernel, dim3((H + 7) / 8, BQ), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), lowres, h, w,
+                     out, H, W, (float)h / (float)H, (float)w / (float)W);
+  return fx_launch_status();
+}
+
+// Per (image, query, band of 32 output rows): number of pixels with upsampled probability >= mask_threshold, the sum of
+// those probabilities, and the extent of the binary mask (processor.py:229-232, 246-252; utils/vision.py:344-370).
+// Partials are written per band and reduced in a fixed order by mf_select_kernel (deterministic, no float atomics).
+#define FX_MF_BAND 32
+struct MfPartial {
+  int32_t cnt;
+  float sum;
+  int32_t x0, x1, y0, y1;
+};
+
+__global__ __launch_bounds__(256) void mf_mask_stats_kernel(const float* __restrict__ lo, int h, int w, int H, int W, float sy, float sx,
+                                                            float thr, MfPartial* __restrict__ part, int nband) {
+  const int bq = blockIdx.y, band = blockIdx.x;
+  const float* p = lo + (int64_t)bq * h * w;
+  const int ya = band * FX_MF_BAND, yb = min(H, ya + FX_MF_BAND);
+  int cnt = 0, x0 = 0x7fffffff, x1 = -1, y0 = 0x7fffffff, y1 = -1;
+  float sum = 0.0f;
+  for (int x = threadIdx.x; x < W; x += 256) {
+    const LerpAxis ax = lerp_axis(x, sx, w);
+    for (int y = ya; y < yb; ++y) {
+      const LerpAxis ay = lerp_axis(y, sy, h);
+      const float v = lerp2(p, w, ay, ax);
+      if (v >= thr) {
+        ++cnt;
+        sum += v;
+        x0 = min(x0, x); x1 = max(x1, x);
+        y0 = min(y0, y); y1 = max(y1, y);
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    cnt += __shfl_xor(cnt, o, 64);
+    sum += __shfl_xor(sum, o, 64);
+    x0 = min(x0, __shfl_xor(x0, o, 64)); x1 = max(x1, __shfl_xor(x1, o, 64));
+    y0 = min(y0, __shfl_xor(y0, o, 64)); y1 = max(y1, __shfl_xor(y1, o, 64));
+  }
+  __shared__ MfPartial red[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) red[wave] = MfPartial{cnt, sum, x0, x1, y0, y1};
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    MfPartial r = red[0];
+    for (int i = 1; i < 4; ++i) {
+      r.cnt += red[i].cnt; r.sum += red[i].sum;
+      r.x0 = min(r.x0, red[i].x0); r.x1 = max(r.x1, red[i].x1);
+      r.y0 = min(r.y0, red[i].y0); r.y1 = max(r.y1, red[i].y1);
+    }
+    part[(int64_t)bq * nband + band] = r;
+  }
+}
+
+// Selection (processor.py:229-262): keep queries whose binary mask has more than one pixel; score = class score x
+// mean probability inside the mask (with the reference's 1e-3 scaling and +1e-5 in the denominator); keep score > threshold
+// (all non-empty masks when threshold <= 0).  Survivors are compacted in query order, like nonzero().
+__global__ __launch_bounds__(128) void mf_select_kernel(const MfPartial* __restrict__ part, int nband, const float* __restrict__ score,
+                                                        const int32_t* __restrict__ label, int Q, float thr, int use_mask_score,
+                                                        int32_t* __restrict__ det_count, int32_t* __restrict__ det_query,
+                                                        float* __restrict__ det_score, int32_t* __restrict__ det_label,
+                                                        int32_t* __restrict__ det_box, int32_t* __restrict__ mask_area) {
+  const int b = blockIdx.x, q = threadIdx.x;
+  MfPartial r{0, 0.0f, 0x7fffffff, -1, 0x7fffffff, -1};
+  if (q < Q)
+    for (int i = 0; i < nband; ++i) {
+      const MfPartial t = part[((int64_t)b * Q + q) * nband + i];
+      r.cnt += t.cnt; r.sum += t.sum;
+      r.x0 = min(r.x0, t.x0); r.x1 = max(r.x1, t.x1);
+      r.y0 = min(r.y0, t.y0); r.y1 = max(r.y1, t.y1);
+    }
+  float s = q < Q ? score[b * Q + q] : 0.0f;
+  bool keep = q < Q && r.cnt > 1;
+  if (keep && use_mask_score) s *= (1e-3f * r.sum) / (1e-3f * (float)r.cnt + 1e-5f);
+  if (thr > 0.0f) keep = keep && s > thr;
+  __shared__ int wcount[2];
+  const unsigned long long bal = __ballot(keep);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) wcount[wave] = __popcll(bal);
+  __syncthreads();
+  const int pos = (wave ? wcount[0] : 0) + __popcll(bal & ((1ull << lane) - 1ull));
+  if (keep) {
+    const int o = b * Q + pos;
+    det_query[o] = q;
+    det_score[o] = s;
+    det_label[o] = label[b * Q + q];
+    det_box[o * 4 + 0] = r.x0; det_box[o * 4 + 1] = r.y0; det_box[o * 4 + 2] = r.x1; det_box[o * 4 + 3] = r.y1;
+    mask_area[o] = r.cnt;
+  }
+  if (threadIdx.x == 0) det_count[b] = wcount[0] + wcount[1];
+}
+
+// Bit-packed binary masks of the kept detections: words[((b*Q + slot)*H + y)*(W/32) + x/32], bit x&31.
+__global__ __launch_bounds__(256) void mf_pack_masks_kernel(const float* __restrict__ lo, int h, int w, int H, int W, float sy, float sx,
+                                                            float thr, const int32_t* __restrict__ det_count,
+                                                            const int32_t* __restrict__ det_query, int Q, uint32_t* __restrict__ words) {
+  const int slot = blockIdx.y, b = blockIdx.z;
+  if (slot >= det_count[b]) return;
+  const int q = det_query[b * Q + slot];
+  const float* p = lo + ((int64_t)b * Q + q) * h * w;
+  const int W32 = W >> 5;
+  uint32_t* wo = words + ((int64_t)b * Q + slot) * H * W32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ya = blockIdx.x * FX_MF_BAND, yb = min(H, ya + FX_MF_BAND);
+  for (int xb = 0; xb < W; xb += 64) {
+    const int x = xb + lane;
+    const LerpAxis ax = lerp_axis(x < W ? x : W - 1, sx, w);
+    for (int y = ya + wave; y < yb; y += 4) {
+      const LerpAxis ay = lerp_axis(y, sy, h);
+      const bool on = x < W && lerp2(p, w, ay, ax) >= thr;
+      const unsigned long long bal = __ballot(on);
+      if (lane == 0) wo[(int64_t)y * W32 + (xb >> 5)] = (uint32_t)bal;
+      if (lane == 32 && xb + 32 < W) wo[(int64_t)y * W32 + (xb >> 5) + 1] = (uint32_t)(bal >> 32);
+    }
+  }
+}
+
+extern "C" int fx_mf_postprocess_workspace_bytes(int B, int Q, int H) {
+  if (B <= 0 || Q <= 0 || H <= 0) return 0;
+  return (int)((size_t)B * Q * ((H + FX_MF_BAND - 1) / FX_MF_BAND) * sizeof(MfPartial));
+}
+
+extern "C" int fx_mf_postprocess(const float* mask_probs_lowres, int h, int w, int H, int W, const float* score, const int32_t* label, int B,
+                                 int Q, float mask_threshold, float threshold, int use_mask_score, void* workspace, size_t workspace_bytes,
+                                 int32_t* det_count, int32_t* det_query, float* det_score, int32_t* det_label, int32_t* det_box,
+                                 int32_t* det_area, uint32_t* mask_words, fx_stream_t stream_) {
+  FX_CHECK_ARG(mask_probs_lowres && score && label && workspace && det_count && det_query && det_score && det_label && det_box && det_area);
+  FX_CHECK_ARG(B > 0 && Q > 0 && h > 0 && w > 0 && H > 0 && W > 0);
+  if (Q > 128) return FX_ERR_UNSUPPORTED;
+  FX_CHECK_ARG(!mask_words || W % 32 == 0);
+  FX_CHECK_ARG(workspace_bytes >= (size_t)fx_mf_postprocess_workspace_bytes(B, Q, H));
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const int nband = (H + FX_MF_BAND - 1) / FX_MF_BAND;
+  const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+  MfPartial* part = reinterpret_cast<MfPartial*>(workspace);
+  hipLaunchKernelGGL(mf_mask_stats_kernel, dim3(nband, B * Q), dim3(256), 0, stream, mask_probs_lowres, h, w, H, W, sy, sx, mask_threshold,
+                     part, nband);
+  hipLaunchKernelGGL(mf_select_kernel, dim3(B), dim3(128), 0, stream, part, nband, score, label, Q, threshold, use_mask_score, det_count,
+                     det_query, det_score, det_label, det_box, det_area);
+  if (mask_words)
+    hipLaunchKernelGGL(mf_pack_masks_kernel, dim3(nband, Q, B), dim3(256), 0, stream, mask_probs_lowres, h, w, H, W, sy, sx, mask_threshold,
+                       det_count, det_query, Q, mask_words);
+  return fx_launch_status();
+}

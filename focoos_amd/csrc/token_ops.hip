@@ -80,44 +80,30 @@ extern "C" int fx_layernorm_bf16(const void* x, int ldx, const void* residual, i
 // ------------------------------------------------------------------------------------------------
 // Softmax attention, head_dim 32, on the MFMA matrix cores (flash-style, scores never leave registers).
 // Workgroup = 4 waves = 128 query rows of one (batch, head); the head's K ([Lk,32], XOR-swizzled rows) and
-// V^T ([tile][d][32 keys], XOR-swizzled 8-byte pieces) are staged once in LDS.  Per 32-key tile a wave does
+// V^T ([tile][d][32 keys], XOR-swizzled 8-byte pieces) are staged in LDS.  Per 32-key tile a wave does
 //   S^T[key][q] = K_tile . Q^T          2 x v_mfma_f32_32x32x16_bf16   (lane = one query column, 16 keys)
 //   online softmax in registers         (row max needs ONE cross-lane exchange: lane ^ 32)
 //   O^T[d][q]  += V_tile^T . P          2 x v_mfma_f32_32x32x16_bf16
 // The accumulator layout of S^T hands each lane exactly the P fragment the second MFMA wants as its B operand,
 // because the reduction index (key) order inside an MFMA is free as long as A (V^T) uses the same order:
 // k-slot (half h, j) <-> key (j&3) + 8*(j>>2) + 4h, i.e. V^T pieces h and h+2 of the 8-byte pieces of a row.
-template <int MAXT>
+// Keys/values are streamed through LDS in chunks of CT 32-key tiles, so Lk is unbounded (the MaskFormer decoder attends
+// over up to (H/8)*(W/8) keys).  MASKED adds the boolean attention mask of MultiScaleMaskedTransformerDecoder
+// (fai_mf/modelling.py:509-523): bit (key & 31) of word mask[(b*Lq+q)*ldm + key/32] set = key not allowed; a query whose
+// mask forbids every key attends everywhere, so both softmaxes are accumulated in the same pass and selected per query.
+template <int CT, bool MASKED>
 __global__ __launch_bounds__(256) void mha32_mfma_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                                                           const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ out, int ldo, int Lq,
-                                                          int Lk, int heads) {
-  __shared__ __attribute__((aligned(16))) unsigned char ks[MAXT * 32 * 64];
-  __shared__ __attribute__((aligned(16))) unsigned char vt[MAXT * 32 * 64];
+                                                          int Lk, int heads, const uint32_t* __restrict__ mask, int ldm) {
+  __shared__ __attribute__((aligned(16))) unsigned char ks[CT * 32 * 64];
+  __shared__ __attribute__((aligned(16))) unsigned char vt[CT * 32 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int bh = blockIdx.y, b = bh / heads, hd = bh % heads;
   const int T = (Lk + 31) >> 5;
   const bf16_t* kb = k + (int64_t)b * Lk * ldk + hd * 32;
   const bf16_t* vb = v + (int64_t)b * Lk * ldv + hd * 32;
-  for (int i = tid; i < T * 32 * 4; i += 256) {
-    const int row = i >> 2, c = i & 3;
-    uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-    if (row < Lk) {
-      kv = *reinterpret_cast<const uint4*>(kb + (int64_t)row * ldk + c * 8);
-      vv = *reinterpret_cast<const uint4*>(vb + (int64_t)row * ldv + c * 8);
-    }
-    *reinterpret_cast<uint4*>(ks + row * 64 + ((c ^ ((row >> 2) & 3)) << 4)) = kv;
-    const int tile = row >> 5, kk = row & 31;
-    const uint32_t w4[4] = {vv.x, vv.y, vv.z, vv.w};
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int d = c * 8 + e;
-      const bf16_t val = (bf16_t)((e & 1) ? (w4[e >> 1] >> 16) : (w4[e >> 1] & 0xffffu));
-      *reinterpret_cast<bf16_t*>(vt + tile * 2048 + d * 64 + ((((kk >> 2) ^ ((d >> 2) & 7))) << 3) + (kk & 3) * 2) = val;
-    }
-  }
-  __syncthreads();
   const int q0 = blockIdx.x * 128 + wave * 32;
-  if (q0 >= Lq) return;
+  const bool active = q0 < Lq;  // inactive waves still take part in the cooperative loads and barriers
   const int j = lane & 31, h = lane >> 5;
   const int qi = q0 + j;
   bf16x8 qf0, qf1;
@@ -131,57 +117,120 @@ __global__ __launch_bounds__(256) void mha32_mfma_kernel(const bf16_t* __restric
     qf0 = __builtin_bit_cast(bf16x8, a);
     qf1 = __builtin_bit_cast(bf16x8, c);
   }
+  const uint32_t* mrow = MASKED ? mask + ((int64_t)b * Lq + (qi < Lq ? qi : 0)) * ldm : nullptr;
   const float scale = 0.17677669529663687f * 1.4426950408889634f;  // 1/sqrt(32) * log2(e): softmax in the exp2 domain
-  f32x16 o;
+  f32x16 o, o2;
 #pragma unroll
-  for (int r = 0; r < 16; ++r) o[r] = 0.0f;
-  float m = -INFINITY, l = 0.0f;
+  for (int r = 0; r < 16; ++r) o[r] = 0.0f, o2[r] = 0.0f;
+  float m = -INFINITY, l = 0.0f, m2 = -INFINITY, l2 = 0.0f;
   const int vsw = (j >> 2) & 7;  // V^T swizzle of row d = j
-  for (int t = 0; t < T; ++t) {
-    const int krow = t * 32 + j;
-    const unsigned char* kr = ks + krow * 64;
-    const int ksw = (krow >> 2) & 3;
-    bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kr + ((h ^ ksw) << 4));
-    bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kr + (((2 + h) ^ ksw) << 4));
-    f32x16 s;
+  for (int c0 = 0; c0 < T; c0 += CT) {
+    const int nt = (T - c0) < CT ? (T - c0) : CT;
+    if (c0) __syncthreads();
+    for (int i = tid; i < nt * 32 * 4; i += 256) {
+      const int lrow = i >> 2, c = i & 3;
+      const int row = c0 * 32 + lrow;
+      uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+      if (row < Lk) {
+        kv = *reinterpret_cast<const uint4*>(kb + (int64_t)row * ldk + c * 8);
+        vv = *reinterpret_cast<const uint4*>(vb + (int64_t)row * ldv + c * 8);
+      }
+      *reinterpret_cast<uint4*>(ks + lrow * 64 + ((c ^ ((lrow >> 2) & 3)) << 4)) = kv;
+      const int tile = lrow >> 5, kk = lrow & 31;
+      const uint32_t w4[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s[r] = 0.0f;
-    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf0, s, 0, 0, 0);
-    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf1, s, 0, 0, 0);
-    float mx = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-      s[r] = key < Lk ? s[r] * scale : -INFINITY;
-      mx = fmaxf(mx, s[r]);
+      for (int e = 0; e < 8; ++e) {
+        const int d = c * 8 + e;
+        const bf16_t val = (bf16_t)((e & 1) ? (w4[e >> 1] >> 16) : (w4[e >> 1] & 0xffffu));
+        *reinterpret_cast<bf16_t*>(vt + tile * 2048 + d * 64 + ((((kk >> 2) ^ ((d >> 2) & 7))) << 3) + (kk & 3) * 2) = val;
+      }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float mn = fmaxf(m, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m - mn);
-    m = mn;
-    float psum = 0.0f;
-    float pf[16];
+    __syncthreads();
+    if (!active) continue;
+    for (int t = 0; t < nt; ++t) {
+      const int krow = t * 32 + j;
+      const unsigned char* kr = ks + krow * 64;
+      const int ksw = (krow >> 2) & 3;
+      bf16x8 kf0 = *reinterpret_cast<const bf16x8*>(kr + ((h ^ ksw) << 4));
+      bf16x8 kf1 = *reinterpret_cast<const bf16x8*>(kr + (((2 + h) ^ ksw) << 4));
+      f32x16 s;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      pf[r] = __builtin_amdgcn_exp2f(s[r] - mn);
-      psum += pf[r];
+      for (int r = 0; r < 16; ++r) s[r] = 0.0f;
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf0, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf1, s, 0, 0, 0);
+      uint32_t mw = 0;
+      if (MASKED) mw = mrow[c0 + t];
+      float mx = -INFINITY, mx2 = -INFINITY;
+      float s2[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kofs = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const int key = (c0 + t) * 32 + kofs;
+        s[r] = key < Lk ? s[r] * scale : -INFINITY;
+        mx = fmaxf(mx, s[r]);
+        if (MASKED) {
+          s2[r] = ((mw >> kofs) & 1u) ? -INFINITY : s[r];
+          mx2 = fmaxf(mx2, s2[r]);
+        }
+      }
+      const unsigned char* vr = vt + t * 2048 + j * 64;
+      uint2 va = *reinterpret_cast<const uint2*>(vr + (((h) ^ vsw) << 3));
+      uint2 vb2 = *reinterpret_cast<const uint2*>(vr + (((h + 2) ^ vsw) << 3));
+      uint2 vc = *reinterpret_cast<const uint2*>(vr + (((h + 4) ^ vsw) << 3));
+      uint2 vd = *reinterpret_cast<const uint2*>(vr + (((h + 6) ^ vsw) << 3));
+      bf16x8 vf0 = __builtin_bit_cast(bf16x8, make_uint4(va.x, va.y, vb2.x, vb2.y));
+      bf16x8 vf1 = __builtin_bit_cast(bf16x8, make_uint4(vc.x, vc.y, vd.x, vd.y));
+      {
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);  // finite: every tile holds at least one real key
+        const float alpha = __builtin_amdgcn_exp2f(m - mn);
+        m = mn;
+        float psum = 0.0f;
+        float pf[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          pf[r] = __builtin_amdgcn_exp2f(s[r] - mn);
+          psum += pf[r];
+        }
+        l = l * alpha + psum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[r] *= alpha;
+        uint4 p0 = pack_bf16x8(pf), p1 = pack_bf16x8(pf + 8);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, __builtin_bit_cast(bf16x8, p0), o, 0, 0, 0);
+        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, __builtin_bit_cast(bf16x8, p1), o, 0, 0, 0);
+      }
+      if (MASKED) {
+        mx2 = fmaxf(mx2, __shfl_xor(mx2, 32, 64));
+        const float mn = fmaxf(m2, mx2);
+        const float ms = mn == -INFINITY ? 0.0f : mn;  // nothing allowed so far: keep l2 = 0 without producing NaNs
+        const float alpha = __builtin_amdgcn_exp2f(m2 - ms);
+        m2 = mn;
+        float psum = 0.0f;
+        float pf[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          pf[r] = __builtin_amdgcn_exp2f(s2[r] - ms);
+          psum += pf[r];
+        }
+        l2 = l2 * alpha + psum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o2[r] *= alpha;
+        uint4 p0 = pack_bf16x8(pf), p1 = pack_bf16x8(pf + 8);
+        o2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, __builtin_bit_cast(bf16x8, p0), o2, 0, 0, 0);
+        o2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, __builtin_bit_cast(bf16x8, p1), o2, 0, 0, 0);
+      }
     }
-    l = l * alpha + psum;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] *= alpha;
-    uint4 p0 = pack_bf16x8(pf), p1 = pack_bf16x8(pf + 8);
-    const unsigned char* vr = vt + t * 2048 + j * 64;
-    uint2 va = *reinterpret_cast<const uint2*>(vr + (((h) ^ vsw) << 3));
-    uint2 vb2 = *reinterpret_cast<const uint2*>(vr + (((h + 2) ^ vsw) << 3));
-    uint2 vc = *reinterpret_cast<const uint2*>(vr + (((h + 4) ^ vsw) << 3));
-    uint2 vd = *reinterpret_cast<const uint2*>(vr + (((h + 6) ^ vsw) << 3));
-    bf16x8 vf0 = __builtin_bit_cast(bf16x8, make_uint4(va.x, va.y, vb2.x, vb2.y));
-    bf16x8 vf1 = __builtin_bit_cast(bf16x8, make_uint4(vc.x, vc.y, vd.x, vd.y));
-    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, __builtin_bit_cast(bf16x8, p0), o, 0, 0, 0);
-    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, __builtin_bit_cast(bf16x8, p1), o, 0, 0, 0);
   }
+  if (!active) return;
   l += __shfl_xor(l, 32, 64);
-  const float inv = 1.0f / l;
+  float inv = 1.0f / l;
+  if (MASKED) {
+    l2 += __shfl_xor(l2, 32, 64);
+    if (l2 > 0.0f) {  // at least one allowed key: the masked softmax is the answer
+      inv = 1.0f / l2;
+      o = o2;
+    }
+  }
   if (qi < Lq) {
     bf16_t* op = out + ((int64_t)b * Lq + qi) * ldo + hd * 32 + 4 * h;
 #pragma unroll
@@ -194,18 +243,25 @@ __global__ __launch_bounds__(256) void mha32_mfma_kernel(const bf16_t* __restric
   }
 }
 
-extern "C" int fx_mha_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B, int Lq, int Lk,
-                           int heads, fx_stream_t stream_) {
+extern "C" int fx_mha_masked_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B, int Lq,
+                                  int Lk, int heads, const uint32_t* mask_bits, int ld_mask_words, fx_stream_t stream_) {
   FX_CHECK_ARG(q && k && v && out && B > 0 && Lq > 0 && Lk > 0 && heads > 0);
   FX_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0 && ldq >= heads * 32 && ldo >= heads * 32);
+  FX_CHECK_ARG(!mask_bits || ld_mask_words >= (Lk + 31) / 32);
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   dim3 grid((Lq + 127) / 128, B * heads), block(256);
-  if (Lk <= 448)
-    hipLaunchKernelGGL(mha32_mfma_kernel<14>, grid, block, 0, stream, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv,
-                       (bf16_t*)out, ldo, Lq, Lk, heads);
+  if (mask_bits)
+    hipLaunchKernelGGL((mha32_mfma_kernel<14, true>), grid, block, 0, stream, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
+                       (const bf16_t*)v, ldv, (bf16_t*)out, ldo, Lq, Lk, heads, mask_bits, ld_mask_words);
   else
-    return FX_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((mha32_mfma_kernel<14, false>), grid, block, 0, stream, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
+                       (const bf16_t*)v, ldv, (bf16_t*)out, ldo, Lq, Lk, heads, (const uint32_t*)nullptr, 0);
   return fx_launch_status();
+}
+
+extern "C" int fx_mha_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B, int Lq, int Lk,
+                           int heads, fx_stream_t stream_) {
+  return fx_mha_masked_bf16(q, ldq, k, ldk, v, ldv, out, ldo, B, Lq, Lk, heads, nullptr, 0, stream_);
 }
 
 // ------------------------------------------------------------------------------------------------

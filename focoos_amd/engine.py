@@ -77,8 +77,10 @@ def _fold_bn(sd, conv_w_key: str, bn_prefix: str) -> Tuple[torch.Tensor, torch.T
     return (W * s.view(-1, 1, 1, 1)).float(), (bta - mu * s).float()
 
 
-class DetrEngine:
-    def __init__(self, config: Dict, state_dict: Dict[str, torch.Tensor], device: str = "cuda:0"):
+class _EngineBase:
+    """Device handle, weight-packing helpers and the ResNet-vd backbone weights shared by the model families."""
+
+    def __init__(self, config: Dict, device: str = "cuda:0"):
         if not torch.cuda.is_available():
             raise _lib.FocoosAmdError("focoos_amd needs a ROCm GPU (gfx950); no CPU fallback exists")
         self.lib = _lib.load()
@@ -87,22 +89,11 @@ class DetrEngine:
         cu, arch = C.c_int(0), C.create_string_buffer(64)
         check(self.lib.fx_device_info(self.dev.index or 0, C.byref(cu), arch, 64), "fx_device_info (gfx950 required)")
         self.cu_count, self.arch = cu.value, arch.value.decode()
-        self.nc = int(config["num_classes"])
-        self.nq = int(config.get("num_queries", 300))
-        self.hd = int(config.get("transformer_predictor_hidden_dim", 256))
-        self.nl = int(config.get("transformer_predictor_dec_layers", 6))
-        self.nhead = int(config.get("transformer_predictor_nhead", 8))
-        self.n_enc = int(config.get("pixel_decoder_num_encoder_layers", 1))
         self.depth = int(config["backbone_config"].get("depth", 50))
-        if self.hd != 256 or int(config.get("pixel_decoder_feat_dim", 256)) != 256 or self.nhead != 8:
-            raise _lib.FocoosAmdError("engine kernels are specialised for hidden_dim 256 / 8 heads (fai-detr-l)")
-        self.top_k = int(config.get("top_k", 300))
-        self.threshold = float(config.get("threshold", 0.5))
         self.stream = torch.cuda.Stream(self.dev)
-        self.plans: Dict[Tuple[int, int, int, bool], "_Plan"] = {}
-        self.load_state_dict(state_dict)
+        self.plans: Dict[Tuple, "_PlanBase"] = {}
+        self.ln: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
 
-    # ------------------------------------------------------------------ weight packing
     def _dev(self, t: torch.Tensor, dtype=None) -> torch.Tensor:
         return t.to(device=self.dev, dtype=dtype or t.dtype).contiguous()
 
@@ -119,15 +110,17 @@ class DetrEngine:
     def _pack_linear(self, W: torch.Tensor, b: Optional[torch.Tensor]) -> PackedConv:
         return self._pack(W.float().view(W.shape[0], W.shape[1], 1, 1), None if b is None else b.float())
 
-    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
-        sd = {k: v.detach().cpu() for k, v in sd.items()}
-        P: Dict[str, PackedConv] = {}
+    def _pack_ln(self, sd, name: str) -> None:
+        self.ln[name] = (self._dev(sd[f"{name}.weight"].float()), self._dev(sd[f"{name}.bias"].float()))
+
+    def _pack_backbone(self, sd, P: Dict[str, PackedConv]) -> None:
+        """ResNet-vd: eval BatchNorm folded into every conv (resnet.py:164-250)."""
         bb = "pixel_decoder.backbone"
 
-        def cbn(name, conv="conv", norm="norm"):
-            P[name] = self._pack(*_fold_bn(sd, f"{name}.{conv}.weight", f"{name}.{norm}"))
+        def cbn(name):
+            P[name] = self._pack(*_fold_bn(sd, f"{name}.conv.weight", f"{name}.norm"))
 
-        # stem conv1_1 stays fp32 [kh][kw][c][n] (direct-conv kernel, weights via the scalar cache)
+        # stem conv1_1 stays fp32 [kh][kw][c][n] (direct-conv kernel, weights via LDS)
         w, b = _fold_bn(sd, f"{bb}.conv1.conv1_1.conv.weight", f"{bb}.conv1.conv1_1.norm")
         self.stem_w = self._dev(w.permute(2, 3, 1, 0).contiguous())  # [kh][kw][c][n]
         self.stem_b = self._dev(b)
@@ -143,6 +136,32 @@ class DetrEngine:
                     cbn(f"{p}.{br}")
                 if bi == 0:
                     cbn(f"{p}.short" if si == 0 else f"{p}.short.conv")
+
+
+class DetrEngine(_EngineBase):
+    def __init__(self, config: Dict, state_dict: Dict[str, torch.Tensor], device: str = "cuda:0"):
+        super().__init__(config, device)
+        self.nc = int(config["num_classes"])
+        self.nq = int(config.get("num_queries", 300))
+        self.hd = int(config.get("transformer_predictor_hidden_dim", 256))
+        self.nl = int(config.get("transformer_predictor_dec_layers", 6))
+        self.nhead = int(config.get("transformer_predictor_nhead", 8))
+        self.n_enc = int(config.get("pixel_decoder_num_encoder_layers", 1))
+        if self.hd != 256 or int(config.get("pixel_decoder_feat_dim", 256)) != 256 or self.nhead != 8:
+            raise _lib.FocoosAmdError("engine kernels are specialised for hidden_dim 256 / 8 heads (fai-detr-l)")
+        self.top_k = int(config.get("top_k", 300))
+        self.threshold = float(config.get("threshold", 0.5))
+        self.load_state_dict(state_dict)
+
+    # ------------------------------------------------------------------ weight packing
+    def load_state_dict(self, sd: Dict[str, torch.Tensor]) -> None:
+        sd = {k: v.detach().cpu() for k, v in sd.items()}
+        P: Dict[str, PackedConv] = {}
+
+        def cbn(name, conv="conv", norm="norm"):
+            P[name] = self._pack(*_fold_bn(sd, f"{name}.{conv}.weight", f"{name}.{norm}"))
+
+        self._pack_backbone(sd, P)
         pd = "pixel_decoder"
         for i in range(3):
             P[f"{pd}.input_proj.{i}"] = self._pack(*_fold_bn(sd, f"{pd}.input_proj.{i}.0.weight", f"{pd}.input_proj.{i}.1"))
@@ -156,10 +175,10 @@ class DetrEngine:
                 P[f"{p}.{l}"] = self._pack_linear(sd[f"{p}.{l}.weight"], sd[f"{p}.{l}.bias"])
             for nrm in ("norm1", "norm2"):
                 setattr(self, f"_ln_{p}.{nrm}", None)
-        self.ln: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+        self.ln = {}
 
         def ln(name):
-            self.ln[name] = (self._dev(sd[f"{name}.weight"].float()), self._dev(sd[f"{name}.bias"].float()))
+            self._pack_ln(sd, name)
 
         for li in range(self.n_enc):
             ln(f"{pd}.encoder.0.layers.{li}.norm1")
@@ -285,10 +304,10 @@ class DetrEngine:
         return pl
 
 
-class _Plan:
-    """Buffers + the static launch sequence for one (batch, height, width)."""
+class _PlanBase:
+    """Buffers + the static launch sequence for one (batch, height, width); helpers shared by the model families."""
 
-    def __init__(self, eng: DetrEngine, B: int, H: int, W: int, f32_input: bool):
+    def __init__(self, eng: _EngineBase, B: int, H: int, W: int, f32_input: bool):
         if H % 32 or W % 32:
             raise _lib.FocoosAmdError("input height/width must be multiples of 32")
         self.eng, self.B, self.H, self.W, self.f32_input = eng, B, H, W, f32_input
@@ -392,14 +411,14 @@ class _Plan:
         self._op(self.lib.fx_mha_bf16, q.ptr, q.ld, k.ptr, k.ld, v.ptr, v.ld, out.ptr, out.ld, B, L, L, 8)
         return out
 
-    # -------------------------------------------------------------- the network
-    def _build(self):
+    # -------------------------------------------------------------- shared front: input buffers + ResNet-vd
+    def build_backbone(self) -> Dict[int, NT]:
+        """ResNet.forward (resnet.py:252-266) -> {2: res2, 3: res3, 4: res4, 5: res5} (NHWC bf16)."""
         e, P, B, lib = self.eng, self.eng.P, self.B, self.lib
         H, W = self.H, self.W
         bb = "pixel_decoder.backbone"
         self.input = torch.empty(B, H, W, 3, dtype=torch.float32 if self.f32_input else torch.uint8, device=self.dev)
         self.sizes = torch.empty(B, 2, dtype=torch.int32, device=self.dev)
-        # ---- backbone (resnet.py:252-266)
         # Experiment knob (default off): run the HBM-heavy front of the network (stem .. res3, 100-400 MB activations at
         # bs=32) in batch chunks so that producer->consumer tensors could stay in the 256 MB Infinity Cache between layers.
         # Measured on MI355X at bs=32: 1/2/4/8 chunks = 2777/2732/2655/2449 img/s - smaller grids cost more than the
@@ -444,15 +463,64 @@ class _Plan:
             for si in (0, 1):
                 for bi in range(blocks[si]):
                     x = bottleneck(x, si, bi)
+                if si == 0 and nchunk == 1:
+                    feats[2] = x
         self._win = None
-        last3 = f"{bb}.res_layers.1.blocks.{blocks[1] - 1}.c"
-        x = self.bufs[last3] if nchunk > 1 else x
+        if nchunk > 1:
+            feats[2] = self.bufs[f"{bb}.res_layers.0.blocks.{blocks[0] - 1}.c"]
+            x = self.bufs[f"{bb}.res_layers.1.blocks.{blocks[1] - 1}.c"]
         feats[3] = x
         for si in (2, 3):
             for bi in range(blocks[si]):
                 x = bottleneck(x, si, bi)
             feats[si + 2] = x
-        self.bufs["res3"], self.bufs["res4"], self.bufs["res5"] = feats[3], feats[4], feats[5]
+        for k, v in feats.items():
+            self.bufs[f"res{k}"] = v
+        return feats
+
+    # -------------------------------------------------------------- execution
+    def _launch(self, ops, stream: int, thr: float):
+        for fn, args in ops:
+            check(fn(*args, C.c_void_p(stream)), fn.__name__)
+
+    def capture_and_launch(self, stream: int, thr: float):
+        if self.graph is None or self.graph_thr != thr:
+            if self.graph is not None:
+                check(self.lib.fx_graph_destroy(self.graph), "fx_graph_destroy")
+                self.graph = None
+            self._launch(self.ops, stream, thr)  # warm-up (first-use initialisation must not happen under capture)
+            torch.cuda.current_stream(self.dev).synchronize()
+            check(self.lib.fx_graph_begin(C.c_void_p(stream)), "fx_graph_begin")
+            try:
+                self._launch(self.ops, stream, thr)
+            finally:
+                g = C.c_void_p()
+                rc = self.lib.fx_graph_end(C.c_void_p(stream), C.byref(g))
+            check(rc, "fx_graph_end")
+            self.graph, self.graph_thr = g, thr
+        check(self.lib.fx_graph_launch(self.graph, C.c_void_p(stream)), "fx_graph_launch")
+
+    def time_graph(self, stream: int, iters: int) -> float:
+        ms = C.c_float(0)
+        check(self.lib.fx_graph_time(self.graph, C.c_void_p(stream), iters, C.byref(ms)), "fx_graph_time")
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.graph is not None:
+                self.lib.fx_graph_destroy(self.graph)
+        except Exception:
+            pass
+
+
+class _Plan(_PlanBase):
+    """RT-DETR launch sequence."""
+
+    # -------------------------------------------------------------- the network
+    def _build(self):
+        e, P, B, lib = self.eng, self.eng.P, self.B, self.lib
+        H, W = self.H, self.W
+        feats = self.build_backbone()
         # ---- hybrid encoder (modelling.py:297-347)
         pd = "pixel_decoder"
         h8, w8, h16, w16, h32, w32 = H // 8, W // 8, H // 16, W // 16, H // 32, W // 32
@@ -609,30 +677,4 @@ class _Plan:
         if not use_graph:
             self._launch(self.ops, stream, thr)
             return
-        if self.graph is None or self.graph_thr != thr:
-            if self.graph is not None:
-                check(self.lib.fx_graph_destroy(self.graph), "fx_graph_destroy")
-                self.graph = None
-            self._launch(self.ops, stream, thr)  # warm-up (first-use initialisation must not happen under capture)
-            torch.cuda.current_stream(self.dev).synchronize()
-            check(self.lib.fx_graph_begin(C.c_void_p(stream)), "fx_graph_begin")
-            try:
-                self._launch(self.ops, stream, thr)
-            finally:
-                g = C.c_void_p()
-                rc = self.lib.fx_graph_end(C.c_void_p(stream), C.byref(g))
-            check(rc, "fx_graph_end")
-            self.graph, self.graph_thr = g, thr
-        check(self.lib.fx_graph_launch(self.graph, C.c_void_p(stream)), "fx_graph_launch")
-
-    def time_graph(self, stream: int, iters: int) -> float:
-        ms = C.c_float(0)
-        check(self.lib.fx_graph_time(self.graph, C.c_void_p(stream), iters, C.byref(ms)), "fx_graph_time")
-        return ms.value
-
-    def __del__(self):
-        try:
-            if self.graph is not None:
-                self.lib.fx_graph_destroy(self.graph)
-        except Exception:
-            pass
+        self.capture_and_launch(stream, thr)

@@ -36,6 +36,8 @@ def synth_state_dict(config: Dict, seed: int = 0, family: str = "fai_detr") -> "
         elif kind == "bn_w":
             if ".branch2c." in name:  # damp the residual branch so 16 blocks do not blow up
                 a = rs.uniform(0.15, 0.35, shape).astype(np.float32)
+            elif ".adapter_" in name:  # MaskFormer FPN laterals: bring the O(10) backbone features back to O(1)
+                a = rs.uniform(0.03, 0.07, shape).astype(np.float32)
             else:
                 a = rs.uniform(0.6, 1.4, shape).astype(np.float32)
         elif kind == "bn_b":
@@ -52,7 +54,7 @@ def synth_state_dict(config: Dict, seed: int = 0, family: str = "fai_detr") -> "
             if "score_classifier" in name:
                 gain = 2.0
             elif name.endswith("forward_prediction_heads.classifier.weight"):
-                gain = 4.0  # softmax over K+1 classes: make some queries confident enough to pass the 0.5 threshold
+                gain = 3.0  # softmax over K+1 classes: make some queries confident enough to pass the 0.5 threshold
             elif "bbox_classifier" in name and name.endswith("layers.2.weight"):
                 gain = 0.5
             elif "query_pos_head.layers.0" in name:

@@ -158,6 +158,48 @@ int fx_detr_postprocess(const float* topk_val, const int32_t* topk_idx, const fl
                         int K, int top_k, float threshold, int32_t* labels, int32_t* queries, int32_t* boxes_i32, int32_t* count,
                         fx_stream_t stream);
 
+/* ---- MaskFormer path (fai-mf-*) ------------------------------------------------------------
+ * Same attention core with keys/values streamed in chunks (Lk unbounded) and the boolean attention mask of
+ * MultiScaleMaskedTransformerDecoder (fai_mf/modelling.py:509-523; nn.MultiheadAttention attn_mask, shared by all heads):
+ * mask_bits u32 [B*Lq][ld_mask_words], bit (key & 31) of word key/32 set = key NOT allowed; a query whose mask forbids every
+ * key attends to all keys (modelling.py:509-512).  mask_bits NULL = plain attention (== fx_mha_bf16). */
+int fx_mha_masked_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B, int Lq, int Lk,
+                       int heads, const uint32_t* mask_bits, int ld_mask_words, fx_stream_t stream);
+
+/* TransformerFPN top-down step (fai_mf/modelling.py:364): out = lateral + F.interpolate(top, size=(H,W), mode="nearest").
+ * lateral/out bf16 NHWC [B,H,W,C], top bf16 NHWC [B,Hs,Ws,C]; C % 8 == 0. */
+int fx_upsample_nearest_add_nhwc_bf16(const void* lateral, int ldl, const void* top, int ldt, void* out, int ldo, int B, int H, int W,
+                                      int Hs, int Ws, int C, fx_stream_t stream);
+
+/* PredictionHeads mask einsum (fai_mf/modelling.py:88): logit[b,q,p] = sum_c embed[b,q,c] * feat[b,p,c]; embed bf16
+ * [B*Q, C] (row stride lde), feat bf16 [B*P, C] (row stride ldf), C == 256, Q <= 128.
+ *  mode 0: out f32 [B*Q][ldo] = logit;  mode 1: out = sigmoid(logit) (MaskFormerHead.forward :614);
+ *  mode 2: bits u32 [B*Q][ld_words]: bit (p & 31) of word p/32 = (logit < 0), the attention mask of :104 when feat is the
+ *          mask-feature map bilinearly resized to the attended level (the resize commutes with the einsum). */
+int fx_query_pixel_logits_bf16(const void* embed, int lde, const void* feat, int ldf, int mode, float* out, int ldo, uint32_t* bits,
+                               int ld_words, int B, int Q, int P, int C, fx_stream_t stream);
+
+/* MaskFormerHead.forward class tail (:610-613) + the per-query max of MaskFormerProcessor.postprocess (processor.py:212):
+ * probs f32 [rows][K] = softmax(logits[:, :K+1])[:, :K] (sigmoid(logits)[:, :K] when use_sigmoid), score = max_k, label = argmax_k. */
+int fx_mf_class_head(const float* logits, int ldl, float* probs, float* score, int32_t* label, int rows, int K, int use_sigmoid,
+                     fx_stream_t stream);
+
+/* FAIMaskFormer.forward tail (:723): masks f32 [BQ][H][W] = bilinear(lowres f32 [BQ][h][w], align_corners=False). */
+int fx_mf_upsample_probs_f32(const float* lowres, int h, int w, float* out, int H, int W, int BQ, fx_stream_t stream);
+
+/* Device side of MaskFormerProcessor.postprocess (fai_mf/processor.py:212-262 + masks_to_xyxy utils/vision.py:344-370),
+ * fused with the x4 bilinear upsample so the [B,Q,H,W] tensor is never materialised: binary mask = upsampled prob >=
+ * mask_threshold; keep masks with > 1 pixel; score = class score * (1e-3*sum_in_mask p)/(1e-3*area + 1e-5) when
+ * use_mask_score; keep score > threshold (threshold <= 0 keeps all).  Survivors compacted in query order per image:
+ * det_count i32 [B]; det_query/det_label/det_area i32 [B][Q]; det_score f32 [B][Q]; det_box i32 [B][Q][4] =
+ * (x_min, y_min, x_max, y_max) inclusive; mask_words (optional, W % 32 == 0) u32 [B][Q][H][W/32], bit x&31 — slot j holds the
+ * binary mask of detection j.  workspace: fx_mf_postprocess_workspace_bytes(B,Q,H) bytes.  Deterministic. */
+int fx_mf_postprocess_workspace_bytes(int B, int Q, int H);
+int fx_mf_postprocess(const float* mask_probs_lowres, int h, int w, int H, int W, const float* score, const int32_t* label, int B, int Q,
+                      float mask_threshold, float threshold, int use_mask_score, void* workspace, size_t workspace_bytes,
+                      int32_t* det_count, int32_t* det_query, float* det_score, int32_t* det_label, int32_t* det_box, int32_t* det_area,
+                      uint32_t* mask_words, fx_stream_t stream);
+
 /* ---- set criterion (training path, forward only this round): SURVEY §8a rows A14/A15 ------------------------------
  * BoxHungarianMatcher cost (fai_detr/modelling.py:714-746, focal branch; box math focoos/utils/box.py:14-64), computed
  * per image: cost[b][q][t] for t < T_b (T_b = tgt_offsets[b+1]-tgt_offsets[b]; row stride Tmax; columns >= T_b zero).
