@@ -146,14 +146,15 @@ class MfEngine(_EngineBase):
         return torch.cat([py, px], dim=-1).reshape(h * w, 2 * npf)
 
     # ------------------------------------------------------------------ run
-    def plan(self, B: int, H: int, W: int, f32_input: bool = False) -> "_MfPlan":
-        key = (B, H, W, f32_input)
+    def plan(self, B: int, H: int, W: int, f32_input: bool = False, full_masks: Optional[bool] = None) -> "_MfPlan":
+        full = self.full_masks if full_masks is None else bool(full_masks)
+        key = (B, H, W, f32_input, full)
         if key not in self.plans:
-            self.plans[key] = _MfPlan(self, B, H, W, f32_input)
+            self.plans[key] = _MfPlan(self, B, H, W, f32_input, full)
         return self.plans[key]
 
-    def forward(self, images: torch.Tensor, threshold: Optional[float] = None,
-                forced_attn: Optional[Sequence[torch.Tensor]] = None, use_graph: bool = True) -> "_MfPlan":
+    def forward(self, images: torch.Tensor, threshold: Optional[float] = None, forced_attn: Optional[Sequence[torch.Tensor]] = None,
+                use_graph: bool = True, full_masks: Optional[bool] = None) -> "_MfPlan":
         """images: uint8 [B,H,W,3] (fused normalise path) or float32 [B,H,W,3] (0..255 scale) on the engine device; the
         model runs at the image size (MaskFormerProcessor.preprocess does not resize, fai_mf/processor.py:96).  Returns the
         plan whose output buffers (probs, mask_probs, [masks], det_*) hold the results until the next call."""
@@ -161,7 +162,7 @@ class MfEngine(_EngineBase):
         f32 = images.dtype == torch.float32
         assert f32 or images.dtype == torch.uint8
         B, H, W, _ = images.shape
-        pl = self.plan(B, H, W, f32)
+        pl = self.plan(B, H, W, f32, full_masks)
         cur = torch.cuda.current_stream(self.dev)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
@@ -182,6 +183,10 @@ def pack_mask_bits(mask: torch.Tensor, words: int) -> torch.Tensor:
 
 class _MfPlan(_PlanBase):
     """MaskFormer launch sequence for one (batch, height, width)."""
+
+    def __init__(self, eng: "MfEngine", B: int, H: int, W: int, f32_input: bool, full_masks: bool):
+        self.full_masks = bool(full_masks)
+        super().__init__(eng, B, H, W, f32_input)
 
     def _build(self):
         e, P, B, lib = self.eng, self.eng.P, self.B, self.lib
@@ -303,7 +308,7 @@ class _MfPlan(_PlanBase):
         mf_rows = mf.as_rows()
         self._op(lib.fx_query_pixel_logits_bf16, emb.ptr, emb.ld, mf_rows.ptr, mf_rows.ld, 1, self.mask_probs.data_ptr(), P4, None, 0, B, Q, P4, 256)
         self.masks = None
-        if e.full_masks:
+        if self.full_masks:
             self.masks = torch.empty(B, Q, H, W, dtype=torch.float32, device=self.dev)
             self._op(lib.fx_mf_upsample_probs_f32, self.mask_probs.data_ptr(), h4, w4, self.masks.data_ptr(), H, W, R)
         # ---- device side of MaskFormerProcessor.postprocess (processor.py:212-262)

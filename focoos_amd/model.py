@@ -1,8 +1,9 @@
-"""Host-side mirror of the reference's public surface for the RT-DETR path:
+"""Host-side mirror of the reference's public surface for the RT-DETR and MaskFormer paths:
 
   ModelManager.get()        focoos/model_manager.py:42-155
   FocoosModel.__call__/infer focoos/models/focoos_model.py:370-416,575-621
   FAIDetr (BaseModelNN)     focoos/models/fai_detr/modelling.py:1273-1358, focoos/models/base_model.py:17-143
+  FAIMaskFormer             focoos/models/fai_mf/modelling.py:633-725
 
 Same names, argument meaning and error behaviour; the compute is the HIP engine (engine.py).
 ``.train()`` / ``.export()`` are not part of this round's hot path and raise NotImplementedError
@@ -19,10 +20,11 @@ import numpy as np
 import torch
 
 from .engine import DetrEngine
-from .ports import DETRModelOutput, FocoosDetections, InferLatency, ModelInfo
-from .processor import DETRProcessor
+from .engine_mf import MfEngine
+from .ports import DETRModelOutput, FocoosDetections, InferLatency, MaskFormerModelOutput, ModelInfo
+from .processor import DETRProcessor, MaskFormerProcessor
 from .registry import ModelRegistry
-from .state_spec import detr_state_spec
+from .state_spec import state_spec
 from .synth import synth_state_dict
 
 
@@ -34,17 +36,24 @@ class IncompatibleKeys:
         return f"IncompatibleKeys(missing={self.missing_keys}, unexpected={self.unexpected_keys}, incorrect_shapes={self.incorrect_shapes})"
 
 
-class FAIDetr:
-    """Engine-backed RT-DETR.  ``state_dict()`` keeps the reference's key names and fp32 values, so
-    checkpoints round-trip; the packed bf16 copies the kernels read are rebuilt on ``load_state_dict``."""
+class _EngineModel:
+    """BaseModelNN surface shared by the engine-backed model classes (focoos/models/base_model.py:17-143).
+    ``state_dict()`` keeps the reference's key names and fp32 values, so checkpoints round-trip; the packed bf16 copies the
+    kernels read are rebuilt on ``load_state_dict``."""
 
-    def __init__(self, config: dict, device: Union[str, torch.device] = "cuda:0", seed: int = 0):
+    family = ""
+
+    def _make_engine(self):  # pragma: no cover - overridden
+        raise NotImplementedError
+
+    def __init__(self, config: dict, device: Union[str, torch.device] = "cuda:0", seed: int = 0, **engine_kwargs):
         self.config = dict(config)
         self.training = False
-        self._spec = detr_state_spec(self.config)
-        self._state = synth_state_dict(self.config, seed)  # "random init" (no network -> no pretrained weights)
+        self._spec = state_spec(self.config, self.family)
+        self._state = synth_state_dict(self.config, seed, family=self.family)  # "random init" (no network -> no pretrained weights)
         self._device = torch.device(device)
-        self.engine = DetrEngine(self.config, self._state, str(self._device))
+        self._engine_kwargs = engine_kwargs
+        self.engine = self._make_engine()
         self.num_classes = int(self.config["num_classes"])
 
     # ---- BaseModelNN surface
@@ -106,6 +115,16 @@ class FAIDetr:
             images = images.to(torch.float32)
         return images.to(self._device).contiguous()
 
+
+
+class FAIDetr(_EngineModel):
+    """Engine-backed RT-DETR (focoos/models/fai_detr/modelling.py:1273-1358)."""
+
+    family = "fai_detr"
+
+    def _make_engine(self):
+        return DetrEngine(self.config, self._state, str(self._device))
+
     def forward(self, images: torch.Tensor, targets: list = [], forced_topk: Optional[torch.Tensor] = None,
                 use_graph: bool = True) -> DETRModelOutput:
         if self.training or (targets is not None and len(targets) > 0):
@@ -124,13 +143,41 @@ class FAIDetr:
         return pl
 
 
+class FAIMaskFormer(_EngineModel):
+    """Engine-backed MaskFormer (focoos/models/fai_mf/modelling.py:633-725).  ``forward`` returns the reference's
+    ``MaskFormerModelOutput`` (full-resolution fp32 ``masks``, a separate plan that adds the upsample kernel);
+    ``detect`` is the fused forward + device post-process that never materialises the [B,Q,H,W] tensor."""
+
+    family = "fai_mf"
+
+    def _make_engine(self):
+        return MfEngine(self.config, self._state, str(self._device), **self._engine_kwargs)
+
+    def forward(self, images: torch.Tensor, targets: list = [], forced_attn=None, use_graph: bool = True) -> MaskFormerModelOutput:
+        if self.training or (targets is not None and len(targets) > 0):
+            raise NotImplementedError("training forward (loss) is not part of this round")
+        pl = self.engine.forward(self._to_nhwc(images), forced_attn=forced_attn, use_graph=use_graph, full_masks=True)
+        self.last_plan = pl
+        return MaskFormerModelOutput(masks=pl.masks.clone(), logits=pl.probs.clone(), loss=None)
+
+    __call__ = forward
+
+    def detect(self, images: torch.Tensor, sizes: Optional[torch.Tensor] = None, threshold: Optional[float] = None):
+        pl = self.engine.forward(self._to_nhwc(images), threshold=threshold, full_masks=False)
+        self.last_plan = pl
+        return pl
+
+
 class FocoosModel:
     """focoos/models/focoos_model.py:88-147 — model + processor + model_info."""
 
-    def __init__(self, model: FAIDetr, model_info: ModelInfo):
+    def __init__(self, model: _EngineModel, model_info: ModelInfo):
         self.model = model
         self.model_info = model_info
-        self.processor = DETRProcessor(model_info.config, image_size=model_info.im_size).eval()
+        if model.family == "fai_mf":  # MaskFormerProcessor ignores image_size (fai_mf/processor.py:96: no resize)
+            self.processor = MaskFormerProcessor(model_info.config).eval()
+        else:
+            self.processor = DETRProcessor(model_info.config, image_size=model_info.im_size).eval()
         self.model.eval()
 
     @property
@@ -148,7 +195,10 @@ class FocoosModel:
         pl = self.model.detect(images, sizes=sizes, threshold=thr)
         torch.cuda.current_stream(self.model.device).synchronize()
         t2 = perf_counter()
-        out = self.processor.pack_detections(pl.det_scores, pl.det_labels, pl.det_boxes, pl.det_count, self.model_info.classes)
+        if self.model.family == "fai_mf":
+            out = self.processor.pack_detections(pl, self.model_info.classes)
+        else:
+            out = self.processor.pack_detections(pl.det_scores, pl.det_labels, pl.det_boxes, pl.det_count, self.model_info.classes)
         t3 = perf_counter()
         for o in out:
             o.latency = InferLatency(preprocess=round(t1 - t0, 3), inference=round(t2 - t1, 3), postprocess=round(t3 - t2, 3))
@@ -177,7 +227,7 @@ class FocoosModel:
 class ModelManager:
     """focoos/model_manager.py:17-155 — lazy family registry + ``get``."""
 
-    _MODEL_MAPPING: Dict[str, Callable[[], Type]] = {"fai_detr": lambda: FAIDetr}
+    _MODEL_MAPPING: Dict[str, Callable[[], Type]] = {"fai_detr": lambda: FAIDetr, "fai_mf": lambda: FAIMaskFormer}
 
     @classmethod
     def register_model(cls, model_family: str, model_loader: Callable[[], Type]):

@@ -47,6 +47,14 @@ class DETRModelOutput:
 
 
 @dataclass
+class MaskFormerModelOutput:
+    """focoos/models/fai_mf/ports.py:9-13."""
+    masks: torch.Tensor   # [N, num_queries, H, W] mask probabilities (sigmoid, bilinearly upsampled to the input size)
+    logits: torch.Tensor  # [N, num_queries, num_classes] class probabilities (softmax, no-object column dropped)
+    loss: Optional[dict] = None
+
+
+@dataclass
 class DETRTargets:
     labels: torch.Tensor
     boxes: torch.Tensor

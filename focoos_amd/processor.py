@@ -1,4 +1,4 @@
-"""DETRProcessor for the engine — same interface and semantics as
+"""DETRProcessor / MaskFormerProcessor for the engine — same interface and semantics as
 focoos/models/fai_detr/processor.py:60-217 (+ Processor.get_torch_batch / get_image_sizes,
 focoos/processor/base_processor.py:176-296), with the arithmetic on the GPU:
 
@@ -20,7 +20,7 @@ import torch
 
 from . import _lib
 from ._lib import check
-from .ports import DETRModelOutput, FocoosDet, FocoosDetections
+from .ports import DETRModelOutput, FocoosDet, FocoosDetections, MaskFormerModelOutput  # noqa: F401
 
 try:  # PIL is optional
     from PIL import Image
@@ -141,3 +141,127 @@ class DETRProcessor:
                 FocoosDet(bbox=b[i][j], conf=s[i][j], cls_id=l[i][j], label=class_names[l[i][j]] if class_names else None)
                 for j in range(ni)]))
         return res
+
+
+# ------------------------------------------------------------------------------------------------ MaskFormer
+def trim_mask(mask: np.ndarray, bbox) -> np.ndarray:
+    """focoos/utils/vision.py:264-267 (note: the inclusive box is used as an exclusive slice end, as in the reference)."""
+    x1, y1, x2, y2 = map(int, bbox)
+    y2, x2 = min(y2, mask.shape[0]), min(x2, mask.shape[1])
+    return mask[y1:y2, x1:x2]
+
+
+def binary_mask_to_base64(binary_mask: np.ndarray) -> str:
+    """focoos/utils/vision.py:270-293: 8-bit grayscale PNG (0/255) of the mask, base64-encoded.  The reference encodes with
+    cv2.imencode; this host tail writes the PNG container directly (zlib), so the bytes differ but decode to the same image."""
+    import base64
+    import struct
+    import zlib
+
+    img = (np.asarray(binary_mask) * 255).astype(np.uint8)
+    if img.ndim != 2:
+        raise ValueError("binary_mask must be 2-D")
+    h, w = img.shape
+    raw = b"".join(b"\x00" + img[y].tobytes() for y in range(h))
+
+    def chunk(tag: bytes, data: bytes) -> bytes:
+        return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b"")
+    return base64.b64encode(png).decode("utf-8")
+
+
+class MaskFormerProcessor(DETRProcessor):
+    """Mirror of focoos/models/fai_mf/processor.py:34-306 (instance branch).  ``preprocess`` does not resize
+    (processor.py:96: "we are not using image_size input"); ``postprocess`` runs the reference's mask thresholding,
+    empty-mask filter, mask score and score filter on the GPU (``fx_mf_postprocess``) and only the PNG/base64 packaging on
+    the host.  The reference's gather-based filtering only works for batch 1 (index tensors are [1, n]); here every image
+    of the batch gets the batch-1 behaviour."""
+
+    def __init__(self, config: dict, image_size=None):
+        super().__init__(config, None)
+        if config.get("postprocessing_type", "instance") != "instance":
+            raise NotImplementedError("engine MaskFormerProcessor covers postprocessing_type='instance' (fai-mf-*-coco-ins)")
+        self.num_classes = int(config["num_classes"])
+        self.mask_threshold = float(config.get("mask_threshold", 0.5))
+        self.top_k = int(config.get("top_k", 100))
+        self.threshold = float(config.get("threshold", 0.5))
+        self.use_mask_score = bool(config.get("use_mask_score", False))
+        self.predict_all_pixels = bool(config.get("predict_all_pixels", False))
+
+    def preprocess(self, inputs: ImageInput, device: torch.device, dtype: torch.dtype = torch.float32):
+        """fai_mf/processor.py:60-97 (inference branch): images are batched at their own size; mixed sizes cannot be stacked
+        (base_processor.py:294 torch.stack) and are rejected here as well."""
+        lst = inputs if isinstance(inputs, list) else [inputs]
+        sizes = set(self.get_image_sizes(lst))
+        if len(sizes) > 1:
+            raise ValueError(f"MaskFormerProcessor does not resize: all images of a batch must share one size, got {sorted(sizes)}")
+        return super().preprocess(inputs, device, dtype)
+
+    def postprocess(self, output, inputs: ImageInput, class_names: Sequence[str] = (), top_k: Optional[int] = None,
+                    threshold: Optional[float] = None, use_mask_score: Optional[bool] = None,
+                    predict_all_pixels: Optional[bool] = None) -> List[FocoosDetections]:
+        threshold = threshold or self.threshold
+        use_mask_score = use_mask_score or self.use_mask_score
+        if predict_all_pixels or self.predict_all_pixels:
+            raise NotImplementedError("predict_all_pixels=True (argmax-over-queries masks) is not on the engine path")
+        image_sizes = self.get_image_sizes(inputs)
+        masks = output.masks.contiguous()
+        probs = output.logits.contiguous()
+        B, Q, H, W = masks.shape
+        assert len(image_sizes) == B, f"Expected image sizes {len(image_sizes)} to match batch size {B}"
+        if any(tuple(sz) != (H, W) for sz in image_sizes):
+            raise NotImplementedError("mask resize to a different original size is not on the engine path (the processor never resizes)")
+        dev = masks.device
+        lib = _lib.load()
+        score, label = probs.max(-1)  # processor.py:212
+        score, label = score.contiguous(), label.to(torch.int32).contiguous()
+        res = _MfDeviceResults(B, Q, H, W, dev)
+        nb = lib.fx_mf_postprocess_workspace_bytes(B, Q, H)
+        ws = torch.empty(max(nb, 8), dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        # full-resolution probabilities: the kernel's bilinear tap degenerates to the identity (scale 1)
+        check(lib.fx_mf_postprocess(masks.data_ptr(), H, W, H, W, score.data_ptr(), label.data_ptr(), B, Q, float(self.mask_threshold),
+                                    float(threshold), int(bool(use_mask_score)), ws.data_ptr(), ws.numel(), res.det_count.data_ptr(),
+                                    res.det_query.data_ptr(), res.det_scores.data_ptr(), res.det_labels.data_ptr(), res.det_boxes.data_ptr(),
+                                    res.det_area.data_ptr(), res.mask_words.data_ptr(), stream), "fx_mf_postprocess")
+        return self.pack_detections(res, class_names)
+
+    @staticmethod
+    def unpack_masks(words: torch.Tensor, H: int, W: int) -> np.ndarray:
+        """int32 [n, H, W/32] bit-packed -> bool [n, H, W]."""
+        w = words.cpu().numpy().view(np.uint8)
+        return np.unpackbits(w, axis=-1, bitorder="little").reshape(words.shape[0], H, W).astype(bool)
+
+    def pack_detections(self, res, class_names: Sequence[str] = (), encode_masks: bool = True) -> List[FocoosDetections]:
+        """D2H of the packed device results (counts, scores, labels, boxes, bit-packed masks of the kept detections only),
+        then the host tail of processor.py:270-303: trim to the box, PNG + base64."""
+        n = res.det_count.cpu().tolist()
+        s, l, b = res.det_scores.cpu().tolist(), res.det_labels.cpu().tolist(), res.det_boxes.cpu().tolist()
+        H, W = res.mask_words.shape[2], res.mask_words.shape[3] * 32
+        out = []
+        for i, ni in enumerate(n):
+            if ni == 0:
+                out.append(FocoosDetections(detections=[]))
+                continue
+            masks = self.unpack_masks(res.mask_words[i, :ni], H, W)
+            out.append(FocoosDetections(detections=[
+                FocoosDet(bbox=b[i][j], conf=s[i][j], cls_id=l[i][j], label=class_names[l[i][j]] if class_names else None,
+                          mask=binary_mask_to_base64(trim_mask(masks[j], b[i][j])) if encode_masks else None)
+                for j in range(ni)]))
+        return out
+
+
+class _MfDeviceResults:
+    """Output buffers of fx_mf_postprocess (same attribute names as the engine plan)."""
+
+    def __init__(self, B: int, Q: int, H: int, W: int, dev):
+        if W % 32:
+            raise ValueError("mask width must be a multiple of 32 for the bit-packed mask output")
+        self.det_count = torch.zeros(B, dtype=torch.int32, device=dev)
+        self.det_query = torch.zeros(B, Q, dtype=torch.int32, device=dev)
+        self.det_scores = torch.zeros(B, Q, dtype=torch.float32, device=dev)
+        self.det_labels = torch.zeros(B, Q, dtype=torch.int32, device=dev)
+        self.det_boxes = torch.zeros(B, Q, 4, dtype=torch.int32, device=dev)
+        self.det_area = torch.zeros(B, Q, dtype=torch.int32, device=dev)
+        self.mask_words = torch.zeros(B, Q, H, W // 32, dtype=torch.int32, device=dev)

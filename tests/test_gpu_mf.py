@@ -280,3 +280,38 @@ def test_mf_loud_failures(setup):
     bad = dict(cfg, num_queries=200)
     with pytest.raises(_lib.FocoosAmdError):
         MfEngine(bad, sd, device=DEV)
+
+
+def test_mf_model_manager_and_processor_paths(setup):
+    """ModelManager.get -> FocoosModel: the fused detect path and the reference-shaped forward() + processor.postprocess()
+    path give the same detections; masks decode from base64 PNG to the bit-packed device masks."""
+    import base64
+    import io
+
+    from PIL import Image
+
+    from focoos_amd.model import ModelManager
+    from focoos_amd.processor import MaskFormerProcessor
+
+    g, cfg, sd, eng, images, *_ = setup
+    fm = ModelManager.get("fai-mf-l-coco-ins", seed=int(g["seed"]))
+    assert isinstance(fm.processor, MaskFormerProcessor)
+    dets = fm.infer_batch(images)
+    assert len(dets) == 2 and len(dets[0]) > 5
+    x, _ = fm.processor.preprocess(images, device=fm.device)
+    out = fm.model.forward(x)
+    assert tuple(out.masks.shape) == (2, 100, images[0].shape[0], images[0].shape[1]) and tuple(out.logits.shape) == (2, 100, 80)
+    dets2 = fm.processor.postprocess(out, images, class_names=fm.model_info.classes)
+    for a, b in zip(dets, dets2):
+        assert len(a) == len(b)
+        for da, db in zip(a.detections, b.detections):
+            assert da.cls_id == db.cls_id and da.bbox == db.bbox and abs(da.conf - db.conf) < 1e-5 and da.mask == db.mask
+    d0 = dets[0].detections[0]
+    png = np.array(Image.open(io.BytesIO(base64.b64decode(d0.mask))))
+    x0, y0, x1, y1 = d0.bbox
+    assert png.shape == (y1 - y0, x1 - x0) and png.dtype == np.uint8 and set(np.unique(png)) <= {0, 255}
+    # single image through __call__ equals the batch result (batch-1 semantics of the reference's post-process)
+    one = fm(images[1])
+    assert [d.cls_id for d in one.detections] == [d.cls_id for d in dets[1].detections]
+    with pytest.raises(ValueError):
+        fm.processor.preprocess([images[0], images[1][:64]], device=fm.device)
