@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""bench.py — images/sec of the focoos RT-DETR hot path on MI355X (BASELINE.json metric).
+"""bench.py — images/sec of the focoos RT-DETR hot path on MI355X (BASELINE.json metric); with
+`--model fai-mf-l-coco-ins` the MaskFormer path of BASELINE configs[2] (bs=16, 800x800).
 
 A "step" = one pass of the hot path over one batch of synthetic input already resident in HBM:
 uint8 HWC images -> fused normalise+stem -> ResNet50-vd -> hybrid encoder -> query selection ->
@@ -26,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16 peak, MI355X_MICROARCH.md (2:1-sparse marketing figure NOT used)
 ALG_GFLOP_PER_IMAGE = 139.05  # RT-DETR-L inference @640^2, algorithmic (dead mask_features conv excluded)
+ALG_GFLOP_PER_IMAGE_MF_800 = 372.7  # fai-mf-l-coco-ins @800^2 as executed by the reference (scaled by area for other sizes)
 
 
 def parse():
@@ -33,8 +35,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=32, help="images per GPU per step")
-    ap.add_argument("--size", type=int, default=640)
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32; 16 for fai-mf-*)")
+    ap.add_argument("--size", type=int, default=None, help="square input size (default 640; 800 for fai-mf-*)")
+    ap.add_argument("--mf-full-masks", action="store_true", help="fai-mf-*: also write the reference's [B,Q,H,W] fp32 `masks` tensor")
+    ap.add_argument("--mf-masks-d2h", action="store_true", help="fai-mf-*: include the D2H copy of the bit-packed mask buffer in the step")
     ap.add_argument("--model", default="fai-detr-l-obj365")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2)
@@ -42,7 +46,12 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--dry-run", action="store_true", help="CPU-only plumbing check (gloo): no GPU work, fake step")
     ap.add_argument("--per-op", default="", help="write per-op timing table to this path")
-    return ap.parse_args()
+    a = ap.parse_args()
+    mf = a.model.startswith("fai-mf")
+    a.family = "fai_mf" if mf else "fai_detr"
+    a.batch = a.batch or (16 if mf else 32)
+    a.size = a.size or (800 if mf else 640)
+    return a
 
 
 def dist_setup(args):
@@ -90,9 +99,13 @@ def cpu_baseline(args):
     from focoos_amd.registry import ModelRegistry
     from focoos_amd.synth import synth_image, synth_state_dict
     from oracle import detr_oracle as O
+    from oracle import mf_oracle as M
 
     cfg = ModelRegistry.get_model_info(args.model)["config"]
-    sd = synth_state_dict(cfg, 0)
+    sd = synth_state_dict(cfg, 0, family=args.family)
+    mf = args.family == "fai_mf"
+    if mf:
+        args.cpu_batch = 1
     # Thread count actually used (reported as `cores`): PyTorch's CPU convs stop scaling (and at 256 threads collapse:
     # 0.03 img/s measured on the 256-core GPU host) well before a big host's core count, so cap it.
     cores = min(os.cpu_count() or 1, args.cpu_threads)
@@ -103,8 +116,12 @@ def cpu_baseline(args):
         for it in range(args.cpu_iters + 1):
             t0 = time.perf_counter()
             x = O.get_torch_batch(imgs, (args.size, args.size))
-            p, b = O.detr_forward(sd, cfg, x)
-            O.postprocess(p, b, [(args.size, args.size)] * len(imgs), 300, 0.5)
+            if mf:
+                p, m = M.mf_forward(sd, cfg, x)
+                M.postprocess(p, m, [(args.size, args.size)] * len(imgs), cfg["mask_threshold"], cfg["threshold"], cfg["use_mask_score"])
+            else:
+                p, b = O.detr_forward(sd, cfg, x)
+                O.postprocess(p, b, [(args.size, args.size)] * len(imgs), 300, 0.5)
             dt = time.perf_counter() - t0
             if it > 0:
                 times.append(dt)
@@ -114,7 +131,7 @@ def cpu_baseline(args):
     times.sort()
     med = times[len(times) // 2]
     return {"value": round(args.cpu_batch / med, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/detr_oracle.py (CPU fp32 restatement of the reference path) preprocess+forward+postprocess, bs={args.cpu_batch}, "
+            "sample": f"oracle/{'mf' if mf else 'detr'}_oracle.py (CPU fp32 restatement of the reference path) preprocess+forward+postprocess, bs={args.cpu_batch}, "
                       f"{args.size}x{args.size}, median of {len(times)} pass(es) after 1 warm-up, {cores} threads of {os.cpu_count()} host cores"}
 
 
@@ -145,9 +162,7 @@ def per_op_timing(eng, pl, args):
             torch.cuda._sleep(int(4e7))
             evs[0].record(st)
             for i, (fn, a) in enumerate(pl.ops):
-                if fn is pl.lib.fx_detr_postprocess:
-                    a = a[:8] + (C.c_float(0.5),) + a[9:]
-                check(fn(*a, C.c_void_p(st.cuda_stream)), fn.__name__)
+                check(fn(*pl.patch_args(fn, a, 0.5), C.c_void_p(st.cuda_stream)), fn.__name__)
                 evs[i + 1].record(st)
             st.synchronize()
             for i in range(n):
@@ -174,7 +189,7 @@ def main():
 
     import torch
 
-    from focoos_amd.model import FAIDetr
+    from focoos_amd.model import FAIDetr, FAIMaskFormer
     from focoos_amd.registry import ModelRegistry
     from focoos_amd.synth import synth_image
 
@@ -185,13 +200,17 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
-    model = FAIDetr(cfg, device=dev, seed=0)
+    mf = args.family == "fai_mf"
+    model = (FAIMaskFormer if mf else FAIDetr)(cfg, device=dev, seed=0)
     eng = model.engine
     # image i of rank r = synth_image(r*B + i): seeded uint8 HWC, resident in HBM before the timed region
     imgs = torch.stack([torch.from_numpy(synth_image(rank * B + i, args.size, args.size)) for i in range(B)]).to(dev)
     sizes = torch.tensor([[args.size, args.size]] * B, dtype=torch.int32, device=dev)
-    pl = eng.plan(B, args.size, args.size, False)
-    host = {k: torch.empty_like(getattr(pl, k), device="cpu").pin_memory() for k in ("det_scores", "det_labels", "det_boxes", "det_count")}
+    pl = eng.plan(B, args.size, args.size, False, args.mf_full_masks) if mf else eng.plan(B, args.size, args.size, False)
+    keys = ("det_scores", "det_labels", "det_boxes", "det_count") + (("det_query", "det_area") if mf else ())
+    if mf and args.mf_masks_d2h:
+        keys += ("mask_words",)
+    host = {k: torch.empty_like(getattr(pl, k), device="cpu").pin_memory() for k in keys}
     st = eng.stream
 
     def step():
@@ -199,7 +218,7 @@ def main():
             pl.input.copy_(imgs, non_blocking=True)       # device->device: hand the batch to the engine's input buffer
             pl.sizes.copy_(sizes, non_blocking=True)
             pl.run(st.cuda_stream, 0.5, None, True)
-            for k, h in host.items():                      # D2H of the packed results (<= 300 x 6 per image)
+            for k, h in host.items():                      # D2H of the packed results (<= 300 x 6 per image; MaskFormer: <= 100 x 8)
                 h.copy_(getattr(pl, k), non_blocking=True)
 
     for _ in range(max(args.warmup, 1)):
@@ -215,14 +234,18 @@ def main():
     ms_step = 1e3 * dt / args.steps
     value = world * B * args.steps / dt
 
+    alg = ALG_GFLOP_PER_IMAGE_MF_800 * (args.size / 800.0) ** 2 if mf else ALG_GFLOP_PER_IMAGE * (args.size / 640.0) ** 2
     out = {
-        "metric": "images/sec @ 640^2 (infer bs=32)", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+        "metric": f"images/sec @ {args.size}^2 (infer bs={B})", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{args.model} inference, bf16 MFMA, bs={B}/GPU, {args.size}x{args.size}, random-init weights (seed 0), "
-                               "uint8 HWC images resident in HBM, device post-process + D2H of packed detections included",
+                               "uint8 HWC images resident in HBM, device post-process + D2H of packed detections included"
+                               + ((", bit-packed binary masks of the detections " + ("copied D2H" if args.mf_masks_d2h else "left in HBM")
+                                   + (", [B,Q,H,W] fp32 masks tensor written" if args.mf_full_masks else ", [B,Q,H,W] fp32 masks tensor not materialised")) if mf else ""),
                    "global_batch": B * world, "parallelism": f"replicas x{world} (no data-path collective)", "steps_are": "hipGraph replays"},
-        "frac_of_bf16_mfma_roofline_whole_path": round(value / world * ALG_GFLOP_PER_IMAGE * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
+        "alg_gflop_per_image": round(alg, 2),
+        "frac_of_bf16_mfma_roofline_whole_path": round(value / world * alg * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
     }
     if rank == 0:
         # ---- roofline of the dominant kernel (live, in-sequence HIP-event timing; world==1 or rank 0 only)

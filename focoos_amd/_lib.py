@@ -43,7 +43,8 @@ SIGNATURES = {
     "fx_add_rows_bf16": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp],
     "fx_layernorm_bf16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "fx_mha_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
-    "fx_mha_masked_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp],
+    "fx_mha_workspace_bytes": [_i, _i, _i, _i, _i],
+    "fx_mha_masked_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, C.c_size_t, _vp],
     "fx_upsample_nearest_add_nhwc_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "fx_query_pixel_logits_bf16": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "fx_mf_class_head": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],

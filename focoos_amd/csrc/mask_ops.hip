@@ -211,10 +211,19 @@ __device__ __forceinline__ LerpAxis lerp_axis(int dst, float scale, int in) {
   return a;
 }
 
+// Unfused multiply/add in the order of PyTorch's CPU kernel (UpSampleKernel.cpp, linear interpolate): every kernel
+// below that thresholds these values must round identically, so FMA contraction is switched off here.
+__device__ __forceinline__ float lerp_taps(float p00, float p01, float p10, float p11, float wy0, float wy1, float wx0, float wx1) {
+#pragma clang fp contract(off)
+  const float top = wx0 * p00 + wx1 * p01;
+  const float bot = wx0 * p10 + wx1 * p11;
+  return wy0 * top + wy1 * bot;
+}
+
 __device__ __forceinline__ float lerp2(const float* __restrict__ p, int w, const LerpAxis& ay, const LerpAxis& ax) {
   const float* r0 = p + (int64_t)ay.i0 * w;
   const float* r1 = p + (int64_t)ay.i1 * w;
-  return ay.w0 * (ax.w0 * r0[ax.i0] + ax.w1 * r0[ax.i1]) + ay.w1 * (ax.w0 * r1[ax.i0] + ax.w1 * r1[ax.i1]);
+  return lerp_taps(r0[ax.i0], r0[ax.i1], r1[ax.i0], r1[ax.i1], ay.w0, ay.w1, ax.w0, ax.w1);
 }
 
 // masks[b,q,y,x] f32 — the reference's `masks` output tensor (B x Q x H x W x 4 bytes: pure HBM write).
@@ -251,23 +260,84 @@ struct MfPartial {
   int32_t x0, x1, y0, y1;
 };
 
+// A query whose class score is <= threshold can never be kept (its final score is the class score times a mean
+// probability <= 1), so its masks are not evaluated at all: with trained weights most of the Q queries exit here.
+// X4: exact x4 upsample (H = 4h, W = 4w, the MaskFormer case): one thread per quarter-resolution cell produces its 4x4
+// output pixels from the 3x3 neighbourhood (9 loads per 16 pixels) with the same tap arithmetic as the generic path.
+// NOTE the summation order over pixels differs between the two paths (sum is a float reduction).
+template <bool X4>
 __global__ __launch_bounds__(256) void mf_mask_stats_kernel(const float* __restrict__ lo, int h, int w, int H, int W, float sy, float sx,
-                                                            float thr, MfPartial* __restrict__ part, int nband) {
+                                                            float thr, const float* __restrict__ score, float score_thr,
+                                                            MfPartial* __restrict__ part, int nband) {
   const int bq = blockIdx.y, band = blockIdx.x;
+  if (score_thr > 0.0f && !(score[bq] > score_thr)) {
+    if (threadIdx.x == 0) part[(int64_t)bq * nband + band] = MfPartial{0, 0.0f, 0x7fffffff, -1, 0x7fffffff, -1};
+    return;
+  }
   const float* p = lo + (int64_t)bq * h * w;
   const int ya = band * FX_MF_BAND, yb = min(H, ya + FX_MF_BAND);
   int cnt = 0, x0 = 0x7fffffff, x1 = -1, y0 = 0x7fffffff, y1 = -1;
   float sum = 0.0f;
-  for (int x = threadIdx.x; x < W; x += 256) {
-    const LerpAxis ax = lerp_axis(x, sx, w);
-    for (int y = ya; y < yb; ++y) {
-      const LerpAxis ay = lerp_axis(y, sy, h);
-      const float v = lerp2(p, w, ay, ax);
-      if (v >= thr) {
-        ++cnt;
-        sum += v;
-        x0 = min(x0, x); x1 = max(x1, x);
-        y0 = min(y0, y); y1 = max(y1, y);
+  if (X4) {
+    const int ia = ya >> 2, ib = yb >> 2;  // FX_MF_BAND % 4 == 0
+    const int ncell = (ib - ia) * w;
+    for (int c = threadIdx.x; c < ncell; c += 256) {
+      const int i = ia + c / w, j = c % w;
+      if (i >= 1 && i <= h - 2 && j >= 1 && j <= w - 2) {
+        float v[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) v[a][b] = p[(int64_t)(i - 1 + a) * w + (j - 1 + b)];
+        // output offset r in 0..3: src = cell + (r - 1.5)/4 -> taps (cell-1, cell) with lambda .625/.875 for r < 2 and
+        // (cell, cell+1) with lambda .125/.375 for r >= 2: exactly what lerp_axis yields for interior cells (all values
+        // are exact in fp32), so this path is bit-identical to the generic one.
+        const float lam[4] = {0.625f, 0.875f, 0.125f, 0.375f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int a0 = r < 2 ? 0 : 1;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int b0 = q < 2 ? 0 : 1;
+            const float val = lerp_taps(v[a0][b0], v[a0][b0 + 1], v[a0 + 1][b0], v[a0 + 1][b0 + 1], 1.0f - lam[r], lam[r], 1.0f - lam[q], lam[q]);
+            if (val >= thr) {
+              const int x = 4 * j + q, y = 4 * i + r;
+              ++cnt;
+              sum += val;
+              x0 = min(x0, x); x1 = max(x1, x);
+              y0 = min(y0, y); y1 = max(y1, y);
+            }
+          }
+        }
+      } else {  // border cells: clamped taps, generic arithmetic
+        for (int r = 0; r < 4; ++r) {
+          const int y = 4 * i + r;
+          const LerpAxis ay = lerp_axis(y, sy, h);
+          for (int q = 0; q < 4; ++q) {
+            const int x = 4 * j + q;
+            const float val = lerp2(p, w, ay, lerp_axis(x, sx, w));
+            if (val >= thr) {
+              ++cnt;
+              sum += val;
+              x0 = min(x0, x); x1 = max(x1, x);
+              y0 = min(y0, y); y1 = max(y1, y);
+            }
+          }
+        }
+      }
+    }
+  } else {
+    for (int x = threadIdx.x; x < W; x += 256) {
+      const LerpAxis ax = lerp_axis(x, sx, w);
+      for (int y = ya; y < yb; ++y) {
+        const LerpAxis ay = lerp_axis(y, sy, h);
+        const float v = lerp2(p, w, ay, ax);
+        if (v >= thr) {
+          ++cnt;
+          sum += v;
+          x0 = min(x0, x); x1 = max(x1, x);
+          y0 = min(y0, y); y1 = max(y1, y);
+        }
       }
     }
   }
@@ -374,8 +444,12 @@ extern "C" int fx_mf_postprocess(const float* mask_probs_lowres, int h, int w, i
   const int nband = (H + FX_MF_BAND - 1) / FX_MF_BAND;
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
   MfPartial* part = reinterpret_cast<MfPartial*>(workspace);
-  hipLaunchKernelGGL(mf_mask_stats_kernel, dim3(nband, B * Q), dim3(256), 0, stream, mask_probs_lowres, h, w, H, W, sy, sx, mask_threshold,
-                     part, nband);
+  if (H == 4 * h && W == 4 * w)
+    hipLaunchKernelGGL(mf_mask_stats_kernel<true>, dim3(nband, B * Q), dim3(256), 0, stream, mask_probs_lowres, h, w, H, W, sy, sx,
+                       mask_threshold, score, threshold, part, nband);
+  else
+    hipLaunchKernelGGL(mf_mask_stats_kernel<false>, dim3(nband, B * Q), dim3(256), 0, stream, mask_probs_lowres, h, w, H, W, sy, sx,
+                       mask_threshold, score, threshold, part, nband);
   hipLaunchKernelGGL(mf_select_kernel, dim3(B), dim3(128), 0, stream, part, nband, score, label, Q, threshold, use_mask_score, det_count,
                      det_query, det_score, det_label, det_box, det_area);
   if (mask_words)

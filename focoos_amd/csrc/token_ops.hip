@@ -91,10 +91,14 @@ extern "C" int fx_layernorm_bf16(const void* x, int ldx, const void* residual, i
 // over up to (H/8)*(W/8) keys).  MASKED adds the boolean attention mask of MultiScaleMaskedTransformerDecoder
 // (fai_mf/modelling.py:509-523): bit (key & 31) of word mask[(b*Lq+q)*ldm + key/32] set = key not allowed; a query whose
 // mask forbids every key attends everywhere, so both softmaxes are accumulated in the same pass and selected per query.
-template <int CT, bool MASKED>
+// SPLIT (flash-decoding): few queries x many keys leaves most CUs idle, so blockIdx.z takes a slice of `tps` key tiles and
+// writes un-normalised partials (o[32], m, l per query row; masked and unmasked variants) that mha32_combine_kernel merges.
+#define FX_MHA_PART 34  // floats per partial row: o[0..31], m, l
+template <int CT, bool MASKED, bool SPLIT>
 __global__ __launch_bounds__(256) void mha32_mfma_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
                                                           const bf16_t* __restrict__ v, int ldv, bf16_t* __restrict__ out, int ldo, int Lq,
-                                                          int Lk, int heads, const uint32_t* __restrict__ mask, int ldm) {
+                                                          int Lk, int heads, const uint32_t* __restrict__ mask, int ldm,
+                                                          float* __restrict__ part, int tps) {
   __shared__ __attribute__((aligned(16))) unsigned char ks[CT * 32 * 64];
   __shared__ __attribute__((aligned(16))) unsigned char vt[CT * 32 * 64];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -124,9 +128,11 @@ __global__ __launch_bounds__(256) void mha32_mfma_kernel(const bf16_t* __restric
   for (int r = 0; r < 16; ++r) o[r] = 0.0f, o2[r] = 0.0f;
   float m = -INFINITY, l = 0.0f, m2 = -INFINITY, l2 = 0.0f;
   const int vsw = (j >> 2) & 7;  // V^T swizzle of row d = j
-  for (int c0 = 0; c0 < T; c0 += CT) {
-    const int nt = (T - c0) < CT ? (T - c0) : CT;
-    if (c0) __syncthreads();
+  const int tb = SPLIT ? (int)blockIdx.z * tps : 0;
+  const int te = SPLIT ? (tb + tps < T ? tb + tps : T) : T;
+  for (int c0 = tb; c0 < te; c0 += CT) {
+    const int nt = (te - c0) < CT ? (te - c0) : CT;
+    if (c0 != tb) __syncthreads();
     for (int i = tid; i < nt * 32 * 4; i += 256) {
       const int lrow = i >> 2, c = i & 3;
       const int row = c0 * 32 + lrow;
@@ -223,6 +229,30 @@ __global__ __launch_bounds__(256) void mha32_mfma_kernel(const bf16_t* __restric
   }
   if (!active) return;
   l += __shfl_xor(l, 32, 64);
+  if (SPLIT) {
+    if (qi < Lq) {
+      const int nsplit = gridDim.z;
+      const int64_t vstride = (int64_t)gridDim.y * nsplit * Lq * FX_MHA_PART;
+      float* wp = part + (((int64_t)bh * nsplit + blockIdx.z) * Lq + qi) * FX_MHA_PART;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        wp[8 * g + 4 * h + 0] = o[4 * g]; wp[8 * g + 4 * h + 1] = o[4 * g + 1];
+        wp[8 * g + 4 * h + 2] = o[4 * g + 2]; wp[8 * g + 4 * h + 3] = o[4 * g + 3];
+      }
+      if (h == 0) wp[32] = m, wp[33] = l;
+      if (MASKED) {
+        l2 += __shfl_xor(l2, 32, 64);
+        wp += vstride;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          wp[8 * g + 4 * h + 0] = o2[4 * g]; wp[8 * g + 4 * h + 1] = o2[4 * g + 1];
+          wp[8 * g + 4 * h + 2] = o2[4 * g + 2]; wp[8 * g + 4 * h + 3] = o2[4 * g + 3];
+        }
+        if (h == 0) wp[32] = m2, wp[33] = l2;
+      }
+    }
+    return;
+  }
   float inv = 1.0f / l;
   if (MASKED) {
     l2 += __shfl_xor(l2, 32, 64);
@@ -243,25 +273,92 @@ __global__ __launch_bounds__(256) void mha32_mfma_kernel(const bf16_t* __restric
   }
 }
 
+// Merge the per-slice partials: thread = (query, channel d of the head).
+__global__ __launch_bounds__(256) void mha32_combine_kernel(const float* __restrict__ part, int nsplit, int masked, bf16_t* __restrict__ out,
+                                                             int ldo, int Lq, int heads) {
+  const int bh = blockIdx.y, b = bh / heads, hd = bh % heads;
+  const int qi = blockIdx.x * 8 + (threadIdx.x >> 5), d = threadIdx.x & 31;
+  if (qi >= Lq) return;
+  const int64_t vstride = (int64_t)gridDim.y * nsplit * Lq * FX_MHA_PART;
+  float res = 0.0f;
+  bool done = false;
+  for (int var = masked ? 1 : 0; var >= 0 && !done; --var) {
+    const float* base = part + var * vstride + ((int64_t)bh * nsplit * Lq + qi) * FX_MHA_PART;
+    float M = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, base[(int64_t)s * Lq * FX_MHA_PART + 32]);
+    if (M == -INFINITY) continue;  // masked variant with no allowed key anywhere: fall through to the unmasked one
+    float l = 0.0f, o = 0.0f;
+    for (int s = 0; s < nsplit; ++s) {
+      const float* r = base + (int64_t)s * Lq * FX_MHA_PART;
+      const float ms = r[32];
+      const float w = ms == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(ms - M);
+      l += w * r[33];
+      o += w * r[d];
+    }
+    if (l > 0.0f) {
+      res = o / l;
+      done = true;
+    }
+  }
+  out[((int64_t)b * Lq + qi) * ldo + hd * 32 + d] = f32_to_bf16(res);
+}
+
+// key-slice policy shared by fx_mha_workspace_bytes and the launcher (a pure function of the shapes)
+static inline void fx_mha_split(int B, int Lq, int Lk, int heads, int* nsplit, int* tps) {
+  const int T = (Lk + 31) / 32;
+  const int base = ((Lq + 127) / 128) * B * heads;
+  int ns = 1;
+  if (T >= 32) {
+    ns = (T + 15) / 16;
+    const int want = 1024 / (base > 0 ? base : 1);
+    if (ns > want) ns = want;
+    if (ns > 16) ns = 16;
+    if (ns < 1) ns = 1;
+  }
+  *tps = (T + ns - 1) / ns;
+  *nsplit = (T + *tps - 1) / *tps;
+}
+
+extern "C" int fx_mha_workspace_bytes(int B, int Lq, int Lk, int heads, int masked) {
+  if (B <= 0 || Lq <= 0 || Lk <= 0 || heads <= 0) return 0;
+  int ns, tps;
+  fx_mha_split(B, Lq, Lk, heads, &ns, &tps);
+  if (ns <= 1) return 0;
+  return (int)((size_t)(masked ? 2 : 1) * B * heads * ns * Lq * FX_MHA_PART * sizeof(float));
+}
+
 extern "C" int fx_mha_masked_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B, int Lq,
-                                  int Lk, int heads, const uint32_t* mask_bits, int ld_mask_words, fx_stream_t stream_) {
+                                  int Lk, int heads, const uint32_t* mask_bits, int ld_mask_words, void* workspace, size_t workspace_bytes,
+                                  fx_stream_t stream_) {
   FX_CHECK_ARG(q && k && v && out && B > 0 && Lq > 0 && Lk > 0 && heads > 0);
   FX_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 4 == 0 && ldq >= heads * 32 && ldo >= heads * 32);
   FX_CHECK_ARG(!mask_bits || ld_mask_words >= (Lk + 31) / 32);
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   dim3 grid((Lq + 127) / 128, B * heads), block(256);
-  if (mask_bits)
-    hipLaunchKernelGGL((mha32_mfma_kernel<14, true>), grid, block, 0, stream, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
-                       (const bf16_t*)v, ldv, (bf16_t*)out, ldo, Lq, Lk, heads, mask_bits, ld_mask_words);
-  else
-    hipLaunchKernelGGL((mha32_mfma_kernel<14, false>), grid, block, 0, stream, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
-                       (const bf16_t*)v, ldv, (bf16_t*)out, ldo, Lq, Lk, heads, (const uint32_t*)nullptr, 0);
+  int ns = 1, tps = 0;
+  const size_t need = (size_t)fx_mha_workspace_bytes(B, Lq, Lk, heads, mask_bits != nullptr);
+  if (workspace && need > 0 && workspace_bytes >= need) fx_mha_split(B, Lq, Lk, heads, &ns, &tps);
+#define FX_MHA(MASKED, SPLIT)                                                                                                           \
+  hipLaunchKernelGGL((mha32_mfma_kernel<14, MASKED, SPLIT>), grid, block, 0, stream, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,      \
+                     (const bf16_t*)v, ldv, (bf16_t*)out, ldo, Lq, Lk, heads, mask_bits, ld_mask_words, (float*)workspace, tps)
+  if (ns > 1) {
+    grid.z = ns;
+    if (mask_bits) FX_MHA(true, true);
+    else FX_MHA(false, true);
+    hipLaunchKernelGGL(mha32_combine_kernel, dim3((Lq + 7) / 8, B * heads), dim3(256), 0, stream, (const float*)workspace, ns,
+                       mask_bits ? 1 : 0, (bf16_t*)out, ldo, Lq, heads);
+  } else if (mask_bits) {
+    FX_MHA(true, false);
+  } else {
+    FX_MHA(false, false);
+  }
+#undef FX_MHA
   return fx_launch_status();
 }
 
 extern "C" int fx_mha_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B, int Lq, int Lk,
                            int heads, fx_stream_t stream_) {
-  return fx_mha_masked_bf16(q, ldq, k, ldk, v, ldv, out, ldo, B, Lq, Lk, heads, nullptr, 0, stream_);
+  return fx_mha_masked_bf16(q, ldq, k, ldk, v, ldv, out, ldo, B, Lq, Lk, heads, nullptr, 0, nullptr, 0, stream_);
 }
 
 // ------------------------------------------------------------------------------------------------

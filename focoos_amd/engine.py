@@ -479,9 +479,13 @@ class _PlanBase:
         return feats
 
     # -------------------------------------------------------------- execution
+    def patch_args(self, fn, args, thr: float):
+        """Per-call arguments that are not baked into the op list (the score threshold of the post-process op)."""
+        return args
+
     def _launch(self, ops, stream: int, thr: float):
         for fn, args in ops:
-            check(fn(*args, C.c_void_p(stream)), fn.__name__)
+            check(fn(*self.patch_args(fn, args, thr), C.c_void_p(stream)), fn.__name__)
 
     def capture_and_launch(self, stream: int, thr: float):
         if self.graph is None or self.graph_thr != thr:
@@ -662,11 +666,10 @@ class _Plan(_PlanBase):
                  K, tk, None, self.det_labels.data_ptr(), self.det_queries.data_ptr(), self.det_boxes.data_ptr(), self.det_count.data_ptr())
 
     # -------------------------------------------------------------- execution
-    def _launch(self, ops, stream: int, thr: float):
-        for fn, args in ops:
-            if fn is self.lib.fx_detr_postprocess:
-                args = args[:8] + (C.c_float(thr),) + args[9:]
-            check(fn(*args, C.c_void_p(stream)), fn.__name__)
+    def patch_args(self, fn, args, thr: float):
+        if fn is self.lib.fx_detr_postprocess:
+            return args[:8] + (C.c_float(thr),) + args[9:]
+        return args
 
     def run(self, stream: int, thr: float, forced_topk: Optional[torch.Tensor] = None, use_graph: bool = True):
         if forced_topk is not None:

@@ -272,6 +272,9 @@ class _MfPlan(_PlanBase):
 
         heads(out, 0, 0)
         dn = emb = None
+        # one workspace for the key-sliced cross attention (launches are serial on one stream)
+        mha_ws = torch.empty(max(8, max(lib.fx_mha_workspace_bytes(B, Q, L, 8, 1) for L in Ls)), dtype=torch.uint8, device=self.dev)
+        self.keep.append(mha_ws)
         for i in range(e.nl):
             lvl, j = i % nlev, i // nlev
             p = f"{hp}.transformer_cross_attention_layers.{i}"
@@ -281,7 +284,7 @@ class _MfPlan(_PlanBase):
             att = self._new(f"dec{i}.c_att", R, 1, 1, 256)
             ks, vs = k_all[lvl].slice(j * 256, 256), v_all[lvl].slice(j * 256, 256)
             self._op(lib.fx_mha_masked_bf16, qc.ptr, qc.ld, ks.ptr, ks.ld, vs.ptr, vs.ld, att.ptr, att.ld, B, Q, Ls[lvl], 8,
-                     self.attn_bits[i].data_ptr(), W32[lvl])
+                     self.attn_bits[i].data_ptr(), W32[lvl], mha_ws.data_ptr(), C.c_size_t(mha_ws.numel()))
             out = self.linear(att, P[f"{p}.out_proj"], name=f"dec{i}.c_o", residual=out)
             p = f"{hp}.transformer_self_attention_layers.{i}"
             t2 = self.layernorm(out, f"{p}.norm", f"dec{i}.s_n")
@@ -330,11 +333,10 @@ class _MfPlan(_PlanBase):
         self.W32 = W32
 
     # -------------------------------------------------------------- execution
-    def _launch(self, ops, stream: int, thr: float):
-        for fn, args in ops:
-            if fn is self.lib.fx_mf_postprocess:
-                args = args[:10] + (C.c_float(thr),) + args[11:]
-            check(fn(*args, C.c_void_p(stream)), fn.__name__)
+    def patch_args(self, fn, args, thr: float):
+        if fn is self.lib.fx_mf_postprocess:
+            return args[:10] + (C.c_float(thr),) + args[11:]
+        return args
 
     def run(self, stream: int, thr: float, forced_attn: Optional[Sequence[torch.Tensor]] = None, use_graph: bool = True):
         if forced_attn is not None:

@@ -162,9 +162,12 @@ int fx_detr_postprocess(const float* topk_val, const int32_t* topk_idx, const fl
  * Same attention core with keys/values streamed in chunks (Lk unbounded) and the boolean attention mask of
  * MultiScaleMaskedTransformerDecoder (fai_mf/modelling.py:509-523; nn.MultiheadAttention attn_mask, shared by all heads):
  * mask_bits u32 [B*Lq][ld_mask_words], bit (key & 31) of word key/32 set = key NOT allowed; a query whose mask forbids every
- * key attends to all keys (modelling.py:509-512).  mask_bits NULL = plain attention (== fx_mha_bf16). */
+ * key attends to all keys (modelling.py:509-512).  mask_bits NULL = plain attention (== fx_mha_bf16).
+ * workspace (optional): fx_mha_workspace_bytes() bytes let long key sequences be sliced across workgroups
+ * (partial softmax per slice + a merge kernel); without it one workgroup per (batch, head, 128 queries) walks all keys. */
+int fx_mha_workspace_bytes(int B, int Lq, int Lk, int heads, int masked);
 int fx_mha_masked_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, void* out, int ldo, int B, int Lq, int Lk,
-                       int heads, const uint32_t* mask_bits, int ld_mask_words, fx_stream_t stream);
+                       int heads, const uint32_t* mask_bits, int ld_mask_words, void* workspace, size_t workspace_bytes, fx_stream_t stream);
 
 /* TransformerFPN top-down step (fai_mf/modelling.py:364): out = lateral + F.interpolate(top, size=(H,W), mode="nearest").
  * lateral/out bf16 NHWC [B,H,W,C], top bf16 NHWC [B,Hs,Ws,C]; C % 8 == 0. */

@@ -44,9 +44,10 @@ def dev(t, dtype=None):
     return t.to(device=DEV, dtype=dtype or t.dtype).contiguous()
 
 
-@pytest.mark.parametrize("cfg", [(2, 100, 1000, True), (1, 100, 4096, True), (2, 625, 625, False), (1, 37, 449, True)])
+@pytest.mark.parametrize("cfg", [(2, 100, 1000, True, False), (1, 100, 4096, True, False), (2, 625, 625, False, False), (1, 37, 449, True, False),
+                                 (2, 100, 4100, True, True), (1, 100, 10000, True, True), (3, 50, 2500, False, True)])
 def test_mha_streamed_and_masked(lib, cfg):
-    B, Lq, Lk, masked = cfg
+    B, Lq, Lk, masked, split = cfg
     g = torch.Generator().manual_seed(Lk)
     q = (torch.randn(B, Lq, 256, generator=g) * 1.5).bfloat16()
     k = (torch.randn(B, Lk, 256, generator=g) * 1.5).bfloat16()
@@ -62,8 +63,11 @@ def test_mha_streamed_and_masked(lib, cfg):
     qd, kd, vd = dev(q), dev(k), dev(v)
     out = torch.empty(B, Lq, 256, dtype=torch.bfloat16, device=DEV)
     bits = dev(pack_mask_bits(mask.reshape(B * Lq, Lk), words)) if masked else None
+    nws = lib.fx_mha_workspace_bytes(B, Lq, Lk, 8, int(masked)) if split else 0
+    assert (nws > 0) == split  # the key-sliced (flash-decoding) path is taken exactly when a workspace is offered for long Lk
+    ws = torch.empty(max(nws, 8), dtype=torch.uint8, device=DEV)
     check(lib.fx_mha_masked_bf16(qd.data_ptr(), 256, kd.data_ptr(), 256, vd.data_ptr(), 256, out.data_ptr(), 256, B, Lq, Lk, 8,
-                                 bits.data_ptr() if masked else None, words, stream()))
+                                 bits.data_ptr() if masked else None, words, ws.data_ptr() if split else None, nws, stream()))
     torch.cuda.synchronize()
     qh, kh, vh = (t.float().view(B, -1, 8, 32).transpose(1, 2) for t in (q, k, v))
     s = qh @ kh.transpose(-1, -2) / math.sqrt(32)
