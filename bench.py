@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32; 16 for fai-mf-*)")
     ap.add_argument("--size", type=int, default=None, help="square input size (default 640; 800 for fai-mf-*)")
+    ap.add_argument("--streams", type=int, default=None, help="concurrent batch parts per step (default: engine default / FX_STREAMS)")
     ap.add_argument("--mf-full-masks", action="store_true", help="fai-mf-*: also write the reference's [B,Q,H,W] fp32 `masks` tensor")
     ap.add_argument("--mf-masks-d2h", action="store_true", help="fai-mf-*: include the D2H copy of the bit-packed mask buffer in the step")
     ap.add_argument("--model", default="fai-detr-l-obj365")
@@ -206,7 +207,7 @@ def main():
     # image i of rank r = synth_image(r*B + i): seeded uint8 HWC, resident in HBM before the timed region
     imgs = torch.stack([torch.from_numpy(synth_image(rank * B + i, args.size, args.size)) for i in range(B)]).to(dev)
     sizes = torch.tensor([[args.size, args.size]] * B, dtype=torch.int32, device=dev)
-    pl = eng.plan(B, args.size, args.size, False, args.mf_full_masks) if mf else eng.plan(B, args.size, args.size, False)
+    pl = eng.plan(B, args.size, args.size, False, args.mf_full_masks, args.streams) if mf else eng.plan(B, args.size, args.size, False, args.streams)
     keys = ("det_scores", "det_labels", "det_boxes", "det_count") + (("det_query", "det_area") if mf else ())
     if mf and args.mf_masks_d2h:
         keys += ("mask_words",)
@@ -243,7 +244,8 @@ def main():
                                "uint8 HWC images resident in HBM, device post-process + D2H of packed detections included"
                                + ((", bit-packed binary masks of the detections " + ("copied D2H" if args.mf_masks_d2h else "left in HBM")
                                    + (", [B,Q,H,W] fp32 masks tensor written" if args.mf_full_masks else ", [B,Q,H,W] fp32 masks tensor not materialised")) if mf else ""),
-                   "global_batch": B * world, "parallelism": f"replicas x{world} (no data-path collective)", "steps_are": "hipGraph replays"},
+                   "global_batch": B * world, "parallelism": f"replicas x{world} (no data-path collective)", "steps_are": "hipGraph replays",
+                   "concurrent_batch_parts": getattr(pl, "n", 1)},
         "alg_gflop_per_image": round(alg, 2),
         "frac_of_bf16_mfma_roofline_whole_path": round(value / world * alg * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
     }

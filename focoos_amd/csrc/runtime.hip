@@ -39,6 +39,21 @@ extern "C" int fx_graph_begin(fx_stream_t stream) {
   return hipStreamBeginCapture(reinterpret_cast<hipStream_t>(stream), hipStreamCaptureModeThreadLocal) == hipSuccess ? FX_OK : FX_ERR_RUNTIME;
 }
 
+// Fork / join of a side stream (also inside a capture: the side stream joins the capture through the event dependency, so
+// the captured graph keeps the two launch sequences as independent branches the GPU may run concurrently).
+extern "C" int fx_stream_fork(fx_stream_t main_stream, fx_stream_t side_stream) {
+  FX_CHECK_ARG(side_stream);
+  hipEvent_t ev;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return FX_ERR_RUNTIME;
+  int rc = FX_OK;
+  if (hipEventRecord(ev, reinterpret_cast<hipStream_t>(main_stream)) != hipSuccess) rc = FX_ERR_RUNTIME;
+  if (rc == FX_OK && hipStreamWaitEvent(reinterpret_cast<hipStream_t>(side_stream), ev, 0) != hipSuccess) rc = FX_ERR_RUNTIME;
+  (void)hipEventDestroy(ev);
+  return rc;
+}
+
+extern "C" int fx_stream_join(fx_stream_t main_stream, fx_stream_t side_stream) { return fx_stream_fork(side_stream, main_stream); }
+
 extern "C" int fx_graph_end(fx_stream_t stream, void** graph_exec_out) {
   FX_CHECK_ARG(graph_exec_out);
   hipGraph_t graph = nullptr;

@@ -22,6 +22,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -31,6 +32,8 @@ from ._lib import FX_ACT, FxConvDesc, check
 from .state_spec import RESNET_BLOCKS
 
 BN_EPS = 1e-5
+DEFAULT_STREAMS = 2   # concurrent batch parts per step (FX_STREAMS overrides); measured on MI355X bs=32: 1/2/4 parts = 2727/2879/2810 img/s
+MIN_PART_BATCH = 4
 
 
 class NT:
@@ -276,10 +279,16 @@ class DetrEngine(_EngineBase):
         return a, torch.nonzero(~valid).flatten().to(torch.int32)
 
     # ------------------------------------------------------------------ run
-    def plan(self, B: int, H: int, W: int, f32_input: bool = False) -> "_Plan":
-        key = (B, H, W, f32_input)
+    def plan(self, B: int, H: int, W: int, f32_input: bool = False, nsplit: Optional[int] = None):
+        """nsplit > 1: the batch is cut into nsplit parts whose launch sequences are captured as concurrent branches of
+        one hipGraph (default from FX_STREAMS, see _MultiPlan)."""
+        if nsplit is None:
+            nsplit = int(os.environ.get("FX_STREAMS", str(DEFAULT_STREAMS)))
+        while nsplit > 1 and (B % nsplit or B // nsplit < MIN_PART_BATCH):
+            nsplit -= 1
+        key = (B, H, W, f32_input, nsplit)
         if key not in self.plans:
-            self.plans[key] = _Plan(self, B, H, W, f32_input)
+            self.plans[key] = _Plan(self, B, H, W, f32_input) if nsplit <= 1 else _MultiPlan(self, _Plan, B, H, W, f32_input, nsplit)
         return self.plans[key]
 
     def forward(self, images: torch.Tensor, sizes: Optional[torch.Tensor] = None, threshold: Optional[float] = None,
@@ -290,7 +299,7 @@ class DetrEngine(_EngineBase):
         f32 = images.dtype == torch.float32
         assert f32 or images.dtype == torch.uint8
         B, H, W, _ = images.shape
-        pl = self.plan(B, H, W, f32)
+        pl = self.plan(B, H, W, f32, 1 if (forced_topk is not None or not use_graph) else None)
         cur = torch.cuda.current_stream(self.dev)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
@@ -307,10 +316,11 @@ class DetrEngine(_EngineBase):
 class _PlanBase:
     """Buffers + the static launch sequence for one (batch, height, width); helpers shared by the model families."""
 
-    def __init__(self, eng: _EngineBase, B: int, H: int, W: int, f32_input: bool):
+    def __init__(self, eng: _EngineBase, B: int, H: int, W: int, f32_input: bool, parent: Optional["_MultiPlan"] = None, index: int = 0):
         if H % 32 or W % 32:
             raise _lib.FocoosAmdError("input height/width must be multiples of 32")
         self.eng, self.B, self.H, self.W, self.f32_input = eng, B, H, W, f32_input
+        self.parent, self.index = parent, index
         self.lib = eng.lib
         self.dev = eng.dev
         self.ops: List[Tuple] = []        # (fn, args) ; stream appended at call time
@@ -343,6 +353,13 @@ class _PlanBase:
 
     def _op(self, fn, *args):
         self.ops.append((fn, args))
+
+    def _io(self, name: str, shape: Tuple[int, ...], dtype) -> torch.Tensor:
+        """Input / output tensor with a leading batch dimension.  Under a _MultiPlan it is this part's contiguous batch slice
+        of one full-batch tensor, so callers see a single result buffer whichever way the step is split."""
+        if self.parent is not None:
+            return self.parent.io_slice(name, shape, dtype, self.index)
+        return torch.empty(*shape, dtype=dtype, device=self.dev)
 
     def conv(self, x: NT, pc: PackedConv, out: Optional[NT] = None, name: Optional[str] = None, stride: int = 1, act=None,
              residual: Optional[NT] = None, res_after: bool = False, pool2: bool = False, out_f32: bool = False,
@@ -417,8 +434,8 @@ class _PlanBase:
         e, P, B, lib = self.eng, self.eng.P, self.B, self.lib
         H, W = self.H, self.W
         bb = "pixel_decoder.backbone"
-        self.input = torch.empty(B, H, W, 3, dtype=torch.float32 if self.f32_input else torch.uint8, device=self.dev)
-        self.sizes = torch.empty(B, 2, dtype=torch.int32, device=self.dev)
+        self.input = self._io("input", (B, H, W, 3), torch.float32 if self.f32_input else torch.uint8)
+        self.sizes = self._io("sizes", (B, 2), torch.int32)
         # Experiment knob (default off): run the HBM-heavy front of the network (stem .. res3, 100-400 MB activations at
         # bs=32) in batch chunks so that producer->consumer tensors could stay in the 256 MB Infinity Cache between layers.
         # Measured on MI355X at bs=32: 1/2/4/8 chunks = 2777/2732/2655/2449 img/s - smaller grids cost more than the
@@ -600,10 +617,10 @@ class _Plan(_PlanBase):
         self._op(lib.fx_fill_rows_bf16, om.ptr, om.ld, S, self.invalid.data_ptr(), int(self.invalid.numel()), e.invalid_row.data_ptr(), B, 256)
         enc_logits = self.linear(om, P[f"{hp}.enc_score"], name="enc_logits", out_f32=True)
         Q, K = e.nq, e.nc
-        self.enc_scores = torch.empty(B, S, dtype=torch.float32, device=self.dev)
+        self.enc_scores = self._io("enc_scores", (B, S), torch.float32)
         self._op(lib.fx_rowmax_f32, enc_logits.ptr, enc_logits.ld, self.enc_scores.data_ptr(), B * S, K)
-        self.enc_topk_val = torch.empty(B, Q, dtype=torch.float32, device=self.dev)
-        self.enc_topk = torch.empty(B, Q, dtype=torch.int32, device=self.dev)
+        self.enc_topk_val = self._io("enc_topk_val", (B, Q), torch.float32)
+        self.enc_topk = self._io("enc_topk", (B, Q), torch.int32)
         self._op(lib.fx_topk_rows_f32, self.enc_scores.data_ptr(), S, B, S, Q, self.enc_topk_val.data_ptr(), self.enc_topk.data_ptr())
         self.split_at = len(self.ops)
         R = B * Q
@@ -648,18 +665,18 @@ class _Plan(_PlanBase):
                      None, R, 256)
         self.refs = refs
         logits = self.linear(tgt, P[f"{hp}.dec_score"], name="logits", out_f32=True)
-        self.probs = torch.empty(B, Q, K, dtype=torch.float32, device=self.dev)
-        self.boxes = torch.empty(B, Q, 4, dtype=torch.float32, device=self.dev)
+        self.probs = self._io("probs", (B, Q, K), torch.float32)
+        self.boxes = self._io("boxes", (B, Q, 4), torch.float32)
         self._op(lib.fx_detr_head_out, logits.ptr, logits.ld, refs[e.nl].data_ptr(), self.probs.data_ptr(), self.boxes.data_ptr(), R, K)
         # ---- device side of DETRProcessor.postprocess (processor.py:146-151,183-197)
         tk = min(e.top_k, Q * K)
         self.top_k = tk
-        self.det_scores = torch.empty(B, tk, dtype=torch.float32, device=self.dev)
-        self.det_flat = torch.empty(B, tk, dtype=torch.int32, device=self.dev)
-        self.det_labels = torch.empty(B, tk, dtype=torch.int32, device=self.dev)
-        self.det_queries = torch.empty(B, tk, dtype=torch.int32, device=self.dev)
-        self.det_boxes = torch.empty(B, tk, 4, dtype=torch.int32, device=self.dev)
-        self.det_count = torch.empty(B, dtype=torch.int32, device=self.dev)
+        self.det_scores = self._io("det_scores", (B, tk), torch.float32)
+        self.det_flat = self._io("det_flat", (B, tk), torch.int32)
+        self.det_labels = self._io("det_labels", (B, tk), torch.int32)
+        self.det_queries = self._io("det_queries", (B, tk), torch.int32)
+        self.det_boxes = self._io("det_boxes", (B, tk, 4), torch.int32)
+        self.det_count = self._io("det_count", (B,), torch.int32)
         self._op(lib.fx_topk_rows_f32, self.probs.data_ptr(), Q * K, B, Q * K, tk, self.det_scores.data_ptr(), self.det_flat.data_ptr())
         self.post_index = len(self.ops)
         self._op(lib.fx_detr_postprocess, self.det_scores.data_ptr(), self.det_flat.data_ptr(), self.boxes.data_ptr(), self.sizes.data_ptr(), B, Q,
@@ -681,3 +698,90 @@ class _Plan(_PlanBase):
             self._launch(self.ops, stream, thr)
             return
         self.capture_and_launch(stream, thr)
+
+
+class _MultiPlan:
+    """One step = `n` batch parts, each a complete plan of B/n images with its own activation buffers, captured as
+    independent branches of ONE hipGraph (side streams forked from / joined to the capturing stream).  The GPU then overlaps
+    kernels of different parts: an HBM-bound layer of one part runs beside an MFMA-bound layer of another, and the tail wave of
+    one launch (tile-count quantisation) is filled by the other part's blocks.  Inputs and outputs are single full-batch
+    tensors (each part reads / writes its contiguous batch slice), so callers cannot tell the difference."""
+
+    def __init__(self, eng: _EngineBase, plan_cls, B: int, H: int, W: int, f32_input: bool, n: int, **kw):
+        self.eng, self.B, self.H, self.W, self.n = eng, B, H, W, n
+        self.lib, self.dev = eng.lib, eng.dev
+        self._io_full: Dict[str, torch.Tensor] = {}
+        self.parts = [plan_cls(eng, B // n, H, W, f32_input, parent=self, index=i, **kw) for i in range(n)]
+        self.side = [torch.cuda.Stream(self.dev) for _ in range(n - 1)]
+        self.graph = None
+        self.graph_thr = None
+        # bench.py's per-op view: the parts' launch lists back to back
+        self.ops = [op for p in self.parts for op in p.ops]
+        self.meta = {}
+        off = 0
+        for p in self.parts:
+            for i, m in p.meta.items():
+                self.meta[off + i] = m
+            off += len(p.ops)
+
+    def io_slice(self, name: str, shape, dtype, index: int) -> torch.Tensor:
+        bp = shape[0]
+        full = self._io_full.get(name)
+        if full is None:
+            full = torch.empty(bp * self.n, *shape[1:], dtype=dtype, device=self.dev)
+            self._io_full[name] = full
+        return full[index * bp:(index + 1) * bp]
+
+    def __getattr__(self, name):
+        io = self.__dict__.get("_io_full", {})
+        if name in io:
+            return io[name]
+        parts = self.__dict__.get("parts")
+        if parts and name in ("top_k", "S", "post_index", "levels", "W32", "full_masks"):
+            return getattr(parts[0], name)
+        raise AttributeError(name)
+
+    def patch_args(self, fn, args, thr: float):
+        return self.parts[0].patch_args(fn, args, thr)
+
+    def run(self, stream: int, thr: float, forced=None, use_graph: bool = True):
+        if forced is not None:
+            raise _lib.FocoosAmdError("teacher forcing runs on a single-part plan (plan(..., nsplit=1))")
+        if not use_graph:
+            for p in self.parts:
+                p._launch(p.ops, stream, thr)
+            return
+        if self.graph is None or self.graph_thr != thr:
+            if self.graph is not None:
+                check(self.lib.fx_graph_destroy(self.graph), "fx_graph_destroy")
+                self.graph = None
+            for p in self.parts:  # warm-up (first-use initialisation must not happen under capture)
+                p._launch(p.ops, stream, thr)
+            torch.cuda.current_stream(self.dev).synchronize()
+            check(self.lib.fx_graph_begin(C.c_void_p(stream)), "fx_graph_begin")
+            try:
+                for s in self.side:
+                    check(self.lib.fx_stream_fork(C.c_void_p(stream), C.c_void_p(s.cuda_stream)), "fx_stream_fork")
+                self.parts[0]._launch(self.parts[0].ops, stream, thr)
+                for p, s in zip(self.parts[1:], self.side):
+                    p._launch(p.ops, s.cuda_stream, thr)
+                for s in self.side:
+                    check(self.lib.fx_stream_join(C.c_void_p(stream), C.c_void_p(s.cuda_stream)), "fx_stream_join")
+            finally:
+                g = C.c_void_p()
+                rc = self.lib.fx_graph_end(C.c_void_p(stream), C.byref(g))
+            check(rc, "fx_graph_end")
+            self.graph, self.graph_thr = g, thr
+        check(self.lib.fx_graph_launch(self.graph, C.c_void_p(stream)), "fx_graph_launch")
+
+    def time_graph(self, stream: int, iters: int) -> float:
+        ms = C.c_float(0)
+        check(self.lib.fx_graph_time(self.graph, C.c_void_p(stream), iters, C.byref(ms)), "fx_graph_time")
+        return ms.value
+
+    def __del__(self):
+        try:
+            if self.graph is not None:
+                self.lib.fx_graph_destroy(self.graph)
+        except Exception:
+            pass

@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -31,7 +32,7 @@ import torch
 
 from . import _lib
 from ._lib import check
-from .engine import NT, PackedConv, _EngineBase, _PlanBase, _fold_bn
+from .engine import DEFAULT_STREAMS, MIN_PART_BATCH, NT, PackedConv, _EngineBase, _MultiPlan, _PlanBase, _fold_bn
 
 
 class MfEngine(_EngineBase):
@@ -146,11 +147,16 @@ class MfEngine(_EngineBase):
         return torch.cat([py, px], dim=-1).reshape(h * w, 2 * npf)
 
     # ------------------------------------------------------------------ run
-    def plan(self, B: int, H: int, W: int, f32_input: bool = False, full_masks: Optional[bool] = None) -> "_MfPlan":
+    def plan(self, B: int, H: int, W: int, f32_input: bool = False, full_masks: Optional[bool] = None, nsplit: Optional[int] = None):
         full = self.full_masks if full_masks is None else bool(full_masks)
-        key = (B, H, W, f32_input, full)
+        if nsplit is None:
+            nsplit = int(os.environ.get("FX_STREAMS", str(DEFAULT_STREAMS)))
+        while nsplit > 1 and (B % nsplit or B // nsplit < MIN_PART_BATCH):
+            nsplit -= 1
+        key = (B, H, W, f32_input, full, nsplit)
         if key not in self.plans:
-            self.plans[key] = _MfPlan(self, B, H, W, f32_input, full)
+            self.plans[key] = (_MfPlan(self, B, H, W, f32_input, full) if nsplit <= 1
+                               else _MultiPlan(self, _MfPlan, B, H, W, f32_input, nsplit, full_masks=full))
         return self.plans[key]
 
     def forward(self, images: torch.Tensor, threshold: Optional[float] = None, forced_attn: Optional[Sequence[torch.Tensor]] = None,
@@ -162,7 +168,7 @@ class MfEngine(_EngineBase):
         f32 = images.dtype == torch.float32
         assert f32 or images.dtype == torch.uint8
         B, H, W, _ = images.shape
-        pl = self.plan(B, H, W, f32, full_masks)
+        pl = self.plan(B, H, W, f32, full_masks, 1 if (forced_attn is not None or not use_graph) else None)
         cur = torch.cuda.current_stream(self.dev)
         self.stream.wait_stream(cur)
         with torch.cuda.stream(self.stream):
@@ -184,9 +190,9 @@ def pack_mask_bits(mask: torch.Tensor, words: int) -> torch.Tensor:
 class _MfPlan(_PlanBase):
     """MaskFormer launch sequence for one (batch, height, width)."""
 
-    def __init__(self, eng: "MfEngine", B: int, H: int, W: int, f32_input: bool, full_masks: bool):
+    def __init__(self, eng: "MfEngine", B: int, H: int, W: int, f32_input: bool, full_masks: bool = False, parent=None, index: int = 0):
         self.full_masks = bool(full_masks)
-        super().__init__(eng, B, H, W, f32_input)
+        super().__init__(eng, B, H, W, f32_input, parent, index)
 
     def _build(self):
         e, P, B, lib = self.eng, self.eng.P, self.B, self.lib
@@ -301,29 +307,29 @@ class _MfPlan(_PlanBase):
             dn, emb = heads(out, i + 1, (i + 1) % nlev if i < e.nl - 1 else None)
         # ---- outputs (MaskFormerHead.forward :599-617, FAIMaskFormer.forward :720-725)
         cls_logits = self.linear(dn, P[f"{ph}.classifier"], name="cls_logits", out_f32=True)
-        self.probs = torch.empty(B, Q, K, dtype=torch.float32, device=self.dev)
-        self.cls_score = torch.empty(B, Q, dtype=torch.float32, device=self.dev)
-        self.cls_label = torch.empty(B, Q, dtype=torch.int32, device=self.dev)
+        self.probs = self._io("probs", (B, Q, K), torch.float32)
+        self.cls_score = self._io("cls_score", (B, Q), torch.float32)
+        self.cls_label = self._io("cls_label", (B, Q), torch.int32)
         self._op(lib.fx_mf_class_head, cls_logits.ptr, cls_logits.ld, self.probs.data_ptr(), self.cls_score.data_ptr(), self.cls_label.data_ptr(),
                  R, K, int(e.cls_sigmoid))
         P4 = h4 * w4
-        self.mask_probs = torch.empty(B, Q, h4, w4, dtype=torch.float32, device=self.dev)  # sigmoid(mask logits) at 1/4 resolution
+        self.mask_probs = self._io("mask_probs", (B, Q, h4, w4), torch.float32)  # sigmoid(mask logits) at 1/4 resolution
         mf_rows = mf.as_rows()
         self._op(lib.fx_query_pixel_logits_bf16, emb.ptr, emb.ld, mf_rows.ptr, mf_rows.ld, 1, self.mask_probs.data_ptr(), P4, None, 0, B, Q, P4, 256)
         self.masks = None
         if self.full_masks:
-            self.masks = torch.empty(B, Q, H, W, dtype=torch.float32, device=self.dev)
+            self.masks = self._io("masks", (B, Q, H, W), torch.float32)
             self._op(lib.fx_mf_upsample_probs_f32, self.mask_probs.data_ptr(), h4, w4, self.masks.data_ptr(), H, W, R)
         # ---- device side of MaskFormerProcessor.postprocess (processor.py:212-262)
         ws_bytes = lib.fx_mf_postprocess_workspace_bytes(B, Q, H)
         self.post_ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=self.dev)
-        self.det_count = torch.zeros(B, dtype=torch.int32, device=self.dev)
-        self.det_query = torch.zeros(B, Q, dtype=torch.int32, device=self.dev)
-        self.det_scores = torch.zeros(B, Q, dtype=torch.float32, device=self.dev)
-        self.det_labels = torch.zeros(B, Q, dtype=torch.int32, device=self.dev)
-        self.det_boxes = torch.zeros(B, Q, 4, dtype=torch.int32, device=self.dev)
-        self.det_area = torch.zeros(B, Q, dtype=torch.int32, device=self.dev)
-        self.mask_words = torch.zeros(B, Q, H, W // 32, dtype=torch.int32, device=self.dev)
+        self.det_count = self._io("det_count", (B,), torch.int32).zero_()
+        self.det_query = self._io("det_query", (B, Q), torch.int32).zero_()
+        self.det_scores = self._io("det_scores", (B, Q), torch.float32).zero_()
+        self.det_labels = self._io("det_labels", (B, Q), torch.int32).zero_()
+        self.det_boxes = self._io("det_boxes", (B, Q, 4), torch.int32).zero_()
+        self.det_area = self._io("det_area", (B, Q), torch.int32).zero_()
+        self.mask_words = self._io("mask_words", (B, Q, H, W // 32), torch.int32).zero_()
         self.post_index = len(self.ops)
         self._op(lib.fx_mf_postprocess, self.mask_probs.data_ptr(), h4, w4, H, W, self.cls_score.data_ptr(), self.cls_label.data_ptr(), B, Q,
                  C.c_float(e.mask_threshold), None, int(e.use_mask_score), self.post_ws.data_ptr(), C.c_size_t(self.post_ws.numel()),

@@ -247,6 +247,12 @@ int fx_adamw_step_f32(float* params, const float* grads, float* exp_avg, float* 
                       const int32_t* chunk_len, const float* chunk_lr, const float* chunk_wd, int nchunks, int step, float beta1, float beta2,
                       float eps, float max_grad_norm, void* workspace, float* total_norm_out, fx_stream_t stream);
 
+/* Fork: `side` waits for everything queued on `main` so far; join: `main` waits for `side`.  Valid inside
+ * fx_graph_begin/fx_graph_end (the side stream joins the capture), which turns two launch sequences into independent
+ * branches of one hipGraph - used to run the two half-batches of a step concurrently. */
+int fx_stream_fork(fx_stream_t main_stream, fx_stream_t side_stream);
+int fx_stream_join(fx_stream_t main_stream, fx_stream_t side_stream);
+
 /* hipGraph capture of a launch sequence issued on `stream` (HIP graphs instead of a tracing compiler). */
 int fx_graph_begin(fx_stream_t stream);
 int fx_graph_end(fx_stream_t stream, void** graph_exec_out);

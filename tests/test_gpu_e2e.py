@@ -163,3 +163,25 @@ def test_state_dict_roundtrip_and_loud_failures(setup):
         model.load_state_dict(bad, strict=True)
     with pytest.raises(NotImplementedError):
         model.train(True)
+
+
+def test_concurrent_batch_parts_equal_single_plan(setup):
+    """_MultiPlan: the batch cut into parts captured as concurrent hipGraph branches gives bit-identical results to the
+    single-plan graph (every image is computed independently of its batch neighbours)."""
+    g, cfg, sd, model, images, x_u8, *_ = setup
+    x8 = torch.cat([x_u8] * 4, 0)  # 8 images -> 2 parts of 4
+    eng = model.engine
+    outs = []
+    for ns in (1, 2):
+        pl = eng.plan(8, 640, 640, False, ns)
+        assert getattr(pl, "n", 1) == ns
+        with torch.cuda.stream(eng.stream):
+            pl.input.copy_(x8)
+            pl.sizes.copy_(torch.tensor([[640, 640]] * 8, dtype=torch.int32))
+            pl.run(eng.stream.cuda_stream, 0.3, None, True)
+            pl.run(eng.stream.cuda_stream, 0.3, None, True)
+        eng.stream.synchronize()
+        outs.append([getattr(pl, k).clone() for k in ("probs", "boxes", "det_scores", "det_labels", "det_boxes", "det_count")])
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[0][0][:2], outs[0][0][2:4])  # the repeated images give repeated rows

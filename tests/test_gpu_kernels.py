@@ -116,6 +116,14 @@ CONV_CASES = [
     (2, 145, 142, 128, 128, 3, 1, "relu", False, False, False, False),  # 256x128 tile
     (1, 1, 40100, 1024, 384, 1, 1, None, True, False, False, False),  # N = 3 x 128, residual before act
     (11, 121, 123, 256, 256, 3, 2, "relu", False, False, False, False),  # stride 2, 3x3, M = 41602
+    # large-M short-K pointwise layers -> conv_pw_stream (register-resident W, LDS-free, permlane32_swap epilogue)
+    (2, 97, 95, 64, 256, 1, 1, "relu", True, False, False, False),     # res2 "c": M = 18430 (tail of 30 rows), residual
+    (1, 130, 131, 128, 512, 1, 1, "relu", True, False, False, False),  # res3 "c"
+    (1, 129, 130, 256, 1024, 1, 1, "silu", True, True, False, False),  # K = 256, residual after act
+    (1, 1, 16500, 256, 365, 1, 1, None, False, False, False, True),    # N tail (368 stored), fp32 out
+    (1, 1, 17000, 256, 288, 1, 1, None, False, False, False, True),    # 4.5 channel blocks
+    (3, 80, 80, 256, 64, 1, 1, "relu", False, False, False, False),    # N = one channel block
+    (1, 128, 130, 64, 72, 1, 1, "gelu", False, False, False, False),   # N = 72: second block partly stored
 ]
 
 
@@ -158,6 +166,26 @@ def test_conv_slices_and_batch_stride(lib):
     assert torch.isnan(got[..., N:]).all(), "columns outside the slice must stay untouched"
     assert (got[..., :N] - ref).abs().max() / ref.abs().max() < 1.2e-2
     S, start = 100, 17
+    mem = torch.full((B, S, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    run_conv(lib, x, W4, bias, ybs=S * N, y_buf=mem, y_off=start * N)
+    m = mem.float().cpu()
+    assert torch.isnan(m[:, :start]).all() and torch.isnan(m[:, start + H * W:]).all()
+    assert (m[:, start:start + H * W].reshape(B, H, W, N) - ref).abs().max() / ref.abs().max() < 1.2e-2
+
+
+def test_conv_pw_stream_slices_and_batch_stride(lib):
+    """Same view semantics on the large-M pointwise path (conv_pw_stream): channel-slice input (ldx > C), channel-slice output
+    of a concat buffer (ldy > N) and the per-image row offset into the decoder memory (y_batch_stride)."""
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Cc, N = 2, 100, 90, 256, 256
+    x = torch.randn(B, H, W, Cc, generator=g)
+    W4 = torch.randn(N, Cc, 1, 1, generator=g) / 16
+    bias = torch.randn(N, generator=g)
+    ref = ref_conv(x, W4, bias)
+    got = run_conv(lib, x, W4, bias, ldx=320, ldy=512)
+    assert torch.isnan(got[..., N:]).all(), "columns outside the slice must stay untouched"
+    assert (got[..., :N] - ref).abs().max() / ref.abs().max() < 1.2e-2
+    S, start = H * W + 300, 123
     mem = torch.full((B, S, N), float("nan"), dtype=torch.bfloat16, device=DEV)
     run_conv(lib, x, W4, bias, ybs=S * N, y_buf=mem, y_off=start * N)
     m = mem.float().cpu()
