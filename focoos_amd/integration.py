@@ -4,7 +4,7 @@
     model = focoos.ModelManager.get("fai-detr-l-obj365")   # unchanged user code
     model.infer(image)                                      # forward now runs on libfocoos_amd.so
 
-``register()`` re-registers ``ModelFamily.DETR`` through the reference's own
+``register()`` re-registers ``ModelFamily.DETR`` (and ``ModelFamily.MASKFORMER``) through the reference's own
 ``ModelManager.register_model`` (focoos/model_manager.py:93-105) with a subclass of the reference's ``FAIDetr`` whose
 parameters / ``state_dict()`` / training path are untouched (it still IS the reference module, so checkpoints, EMA, DDP
 wrapping, ``.export()`` keep working) and whose **eval-mode forward** is the HIP engine.  Weights are re-packed lazily
@@ -65,18 +65,58 @@ def make_engine_class():
     return EngineFAIDetr
 
 
+def make_mf_engine_class():
+    """Adapter for the MaskFormer family: reference FAIMaskFormer whose eval forward is the gfx950 engine."""
+    from focoos.models.fai_mf.modelling import FAIMaskFormer as RefFAIMaskFormer
+    from focoos.models.fai_mf.ports import MaskFormerModelOutput
+
+    from .engine_mf import MfEngine
+
+    class EngineFAIMaskFormer(RefFAIMaskFormer):
+        def __init__(self, config):
+            super().__init__(config)
+            self._fx_engine: Optional[MfEngine] = None
+            self._fx_version = None
+
+        def _fx_sync(self):
+            ver = tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+            if self._fx_engine is None:
+                self._fx_engine = MfEngine(_config_to_dict(self.config), self.state_dict(), str(self.device), full_masks=True)
+            elif ver != self._fx_version:
+                self._fx_engine.load_state_dict(self.state_dict())
+            self._fx_version = ver
+
+        def forward(self, images, targets=[]):
+            if self.training or (targets is not None and len(targets) > 0) or torch.is_grad_enabled() and images.requires_grad:
+                return super().forward(images, targets)  # training path: the reference's own graph
+            self._fx_sync()
+            x = images
+            if x.dim() == 4 and x.shape[1] == 3 and x.shape[-1] != 3:
+                x = x.permute(0, 2, 3, 1)
+            x = (x if x.dtype == torch.uint8 else x.float()).contiguous()
+            pl = self._fx_engine.forward(x, full_masks=True)
+            return MaskFormerModelOutput(masks=pl.masks.clone(), logits=pl.probs.clone(), loss=None)
+
+    return EngineFAIMaskFormer
+
+
 def register() -> None:
-    """Re-register the DETR family with the engine-backed model class (last registration wins, model_manager.py:93-105)."""
+    """Re-register the DETR and MaskFormer families with the engine-backed model classes (last registration wins,
+    model_manager.py:93-105)."""
     from focoos.model_manager import ModelManager
     from focoos.ports import ModelFamily
 
     import focoos.models.fai_detr as family
+    import focoos.models.fai_mf as family_mf
 
-    for name in dir(family):  # the family's own _register(): config + processor (+ stock model) registries
-        if name.startswith("_register") and callable(getattr(family, name)):
-            getattr(family, name)()
+    for fam in (family, family_mf):
+        for name in dir(fam):  # the family's own _register(): config + processor (+ stock model) registries
+            if name.startswith("_register") and callable(getattr(fam, name)):
+                getattr(fam, name)()
     cls = make_engine_class()
     ModelManager.register_model(ModelFamily.DETR, lambda: cls)
+    cls_mf = make_mf_engine_class()
+    ModelManager.register_model(ModelFamily.MASKFORMER, lambda: cls_mf)
 
 
 def bind_msda_core(module) -> int:

@@ -30,3 +30,20 @@ def test_register_replaces_detr_family_and_keeps_state_dict():
         with pytest.raises(FocoosAmdError):  # loud, never a silent CPU fallback
             with torch.no_grad():
                 model(torch.zeros(1, 3, 64, 64))
+
+
+def test_register_replaces_maskformer_family_and_keeps_state_dict():
+    ref_import.install()
+    from focoos.model_manager import ConfigManager, ModelManager
+    from focoos.ports import ModelFamily
+
+    import focoos_amd.integration as fx
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.state_spec import mf_state_spec
+
+    fx.register()
+    cls = ModelManager._models_family_map[ModelFamily.MASKFORMER.value]()
+    assert cls.__name__ == "EngineFAIMaskFormer"
+    cfgd = ModelRegistry.get_model_info("fai-mf-l-coco-ins")["config"]
+    model = cls(ConfigManager.from_dict(ModelFamily.MASKFORMER, dict(cfgd))).eval()
+    assert list(model.state_dict()) == list(mf_state_spec(cfgd))   # checkpoint keys unchanged
