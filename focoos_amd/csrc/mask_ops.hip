@@ -220,6 +220,16 @@ __device__ __forceinline__ float lerp_taps(float p00, float p01, float p10, floa
   return wy0 * top + wy1 * bot;
 }
 
+// the two halves of lerp_taps, for callers that reuse the x-interpolated rows across output rows
+__device__ __forceinline__ float lerp_row(const float* __restrict__ row, const LerpAxis& ax) {
+#pragma clang fp contract(off)
+  return ax.w0 * row[ax.i0] + ax.w1 * row[ax.i1];
+}
+__device__ __forceinline__ float lerp_col(float top, float bot, const LerpAxis& ay) {
+#pragma clang fp contract(off)
+  return ay.w0 * top + ay.w1 * bot;
+}
+
 __device__ __forceinline__ float lerp2(const float* __restrict__ p, int w, const LerpAxis& ay, const LerpAxis& ax) {
   const float* r0 = p + (int64_t)ay.i0 * w;
   const float* r1 = p + (int64_t)ay.i1 * w;
@@ -413,12 +423,25 @@ __global__ __launch_bounds__(256) void mf_pack_masks_kernel(const float* __restr
   uint32_t* wo = words + ((int64_t)b * Q + slot) * H * W32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ya = blockIdx.x * FX_MF_BAND, yb = min(H, ya + FX_MF_BAND);
+  // each wave owns 8 consecutive output rows: consecutive rows share their two source rows, so the x-interpolated
+  // source rows are carried in registers (about half a load per output pixel instead of four; same arithmetic)
+  const int y0w = ya + wave * (FX_MF_BAND / 4), y1w = min(yb, y0w + FX_MF_BAND / 4);
   for (int xb = 0; xb < W; xb += 64) {
     const int x = xb + lane;
     const LerpAxis ax = lerp_axis(x < W ? x : W - 1, sx, w);
-    for (int y = ya + wave; y < yb; y += 4) {
+    int c0 = -1, c1 = -1;
+    float top = 0.0f, bot = 0.0f;
+    for (int y = y0w; y < y1w; ++y) {
       const LerpAxis ay = lerp_axis(y, sy, h);
-      const bool on = x < W && lerp2(p, w, ay, ax) >= thr;
+      if (ay.i0 != c0) {
+        top = ay.i0 == c1 ? bot : lerp_row(p + (int64_t)ay.i0 * w, ax);
+        c0 = ay.i0;
+      }
+      if (ay.i1 != c1) {
+        bot = ay.i1 == c0 ? top : lerp_row(p + (int64_t)ay.i1 * w, ax);
+        c1 = ay.i1;
+      }
+      const bool on = x < W && lerp_col(top, bot, ay) >= thr;
       const unsigned long long bal = __ballot(on);
       if (lane == 0) wo[(int64_t)y * W32 + (xb >> 5)] = (uint32_t)bal;
       if (lane == 32 && xb + 32 < W) wo[(int64_t)y * W32 + (xb >> 5) + 1] = (uint32_t)(bal >> 32);
