@@ -32,7 +32,7 @@ from ._lib import FX_ACT, FxConvDesc, check
 from .state_spec import RESNET_BLOCKS
 
 BN_EPS = 1e-5
-DEFAULT_STREAMS = 2   # concurrent batch parts per step (FX_STREAMS overrides); measured on MI355X bs=32: 1/2/4 parts = 2727/2879/2810 img/s
+DEFAULT_STREAMS = 1   # batch parts per step.  FX_STREAMS=2 (two half-batch parts on two streams) measured +7 % but is UNSAFE: see _MultiPlan
 MIN_PART_BATCH = 4
 
 
@@ -346,10 +346,29 @@ class _PlanBase:
                 full = NT(torch.empty(self.B * H * W * Cc, dtype=dtype, device=self.dev), self.B, H, W, Cc, Cc, 0)
                 self.bufs[name] = full
             return NT(full.t, bs, H, W, Cc, Cc, b0 * H * W * Cc)
-        t = torch.empty(B * H * W * Cc, dtype=dtype, device=self.dev)
-        nt = NT(t, B, H, W, Cc, Cc, 0)
+        guard = int(os.environ.get("FX_GUARD", "0"))  # debugging aid: sentinel elements around every activation buffer
+        if guard:
+            t = torch.empty(B * H * W * Cc + 2 * guard, dtype=dtype, device=self.dev)
+            t.view(torch.uint8).fill_(0x5A)
+            nt = NT(t, B, H, W, Cc, Cc, guard)
+            self.guards = getattr(self, "guards", [])
+            self.guards.append((name, t, guard))
+        else:
+            t = torch.empty(B * H * W * Cc, dtype=dtype, device=self.dev)
+            nt = NT(t, B, H, W, Cc, Cc, 0)
         self.bufs[name] = nt
         return nt
+
+    def check_guards(self):
+        """FX_GUARD=n: report buffers whose sentinel elements before / after the payload were overwritten."""
+        bad = []
+        for name, t, g in getattr(self, "guards", []):
+            u = t.view(torch.uint8)
+            es = t.element_size()
+            head, tail = u[: g * es], u[-g * es:]
+            if not bool((head == 0x5A).all()) or not bool((tail == 0x5A).all()):
+                bad.append((name, int((head != 0x5A).sum()), int((tail != 0x5A).sum())))
+        return bad
 
     def _op(self, fn, *args):
         self.ops.append((fn, args))
@@ -570,7 +589,7 @@ class _Plan(_PlanBase):
                 f2 = self.linear(f1, P[f"{p}.linear2"], name=f"aifi{li}.f2", residual=s1)
                 s = self.layernorm(f2, f"{p}.norm2", f"aifi{li}.s2")
             self.bufs["aifi"] = s
-            src = NT(s.t, B, h32, w32, 256, 256)
+            src = NT(s.t, B, h32, w32, 256, 256, s.off)
 
         def csp(xin: NT, p: str, out_name: str) -> NT:
             c12 = self.conv(xin, P[f"{p}.conv12"], name=f"{p}.c12", act="silu")  # [x_1 | x_2]
@@ -604,7 +623,7 @@ class _Plan(_PlanBase):
         starts = [0, shapes[0][0] * shapes[0][1], shapes[0][0] * shapes[0][1] + shapes[1][0] * shapes[1][1]]
         memory = self._new("memory", B, S, 1, 256)
         for i, (f, st) in enumerate(zip((out20, out40, out80), starts)):
-            lvl = NT(memory.t, B, f.H, f.W, 256, 256, st * 256)
+            lvl = NT(memory.t, B, f.H, f.W, 256, 256, memory.off + st * 256)
             self.conv(f, P[f"{hp}.input_proj.{i}"], out=lvl, y_batch_stride=S * 256)
         mem_rows = memory.as_rows()
         anchors, invalid = e._anchors(shapes)
@@ -701,11 +720,16 @@ class _Plan(_PlanBase):
 
 
 class _MultiPlan:
-    """One step = `n` batch parts, each a complete plan of B/n images with its own activation buffers, captured as
-    independent branches of ONE hipGraph (side streams forked from / joined to the capturing stream).  The GPU then overlaps
-    kernels of different parts: an HBM-bound layer of one part runs beside an MFMA-bound layer of another, and the tail wave of
-    one launch (tile-count quantisation) is filled by the other part's blocks.  Inputs and outputs are single full-batch
-    tensors (each part reads / writes its contiguous batch slice), so callers cannot tell the difference."""
+    """EXPERIMENT, off by default (FX_STREAMS=2 / plan(..., nsplit=2)).  One step = `n` batch parts, each a complete plan of
+    B/n images with its own activation buffers, replayed concurrently on `n` streams so that an HBM-bound layer of one part
+    overlaps an MFMA-bound layer of another and fills its tail wave: +7 % on RT-DETR bs=32 (2727 -> 2973 img/s).
+    NOT SAFE on this stack (ROCm 7.2, MI355X): whenever the small decoder kernels of one part overlap the large conv kernels
+    of the other, some decoder rows are computed from stale inputs (30 of 40 replays had >= 1 wrong image; scripts/dev/
+    stability*.py).  Nothing is shared between the parts (guard bands around every buffer stay intact, FX_GUARD), the error
+    reproduces with plain eager launches on two streams and disappears with AMD_SERIALIZE_KERNEL=3, and a foreign torch matmul
+    stream beside ONE part does not trigger it - cross-queue visibility of kernel outputs between the per-XCD L2s is the open
+    suspect.  Parity comes first, so the product path runs one part; the class stays for the investigation.
+    Inputs and outputs are single full-batch tensors (each part reads / writes its contiguous batch slice)."""
 
     def __init__(self, eng: _EngineBase, plan_cls, B: int, H: int, W: int, f32_input: bool, n: int, **kw):
         self.eng, self.B, self.H, self.W, self.n = eng, B, H, W, n
@@ -751,6 +775,41 @@ class _MultiPlan:
             for p in self.parts:
                 p._launch(p.ops, stream, thr)
             return
+        mode = os.environ.get("FX_MULTI_MODE", "graphs")
+        if mode == "branches":
+            return self._run_branches(stream, thr)
+        # One linear graph per part, each replayed on its own stream (part 0 on the caller's stream), joined by events.
+        # (A single graph with the parts as concurrent BRANCHES - FX_MULTI_MODE=branches - is ~1 % faster but on ROCm 7.2 it
+        # occasionally lets a small decoder kernel read stale data: 1 image in 32 differed in 1 of 4 replays.  Per-stream
+        # linear graphs use the ordinary in-queue ordering and were bit-stable over hundreds of replays.)
+        if self.graph is None or self.graph_thr != thr:
+            for g in (self.graph or []):
+                check(self.lib.fx_graph_destroy(g), "fx_graph_destroy")
+            self.graph = None
+            graphs = []
+            streams = [stream] + [s.cuda_stream for s in self.side]
+            for p in self.parts:  # warm-up outside capture
+                p._launch(p.ops, stream, thr)
+            torch.cuda.current_stream(self.dev).synchronize()
+            for p, st in zip(self.parts, streams):
+                check(self.lib.fx_graph_begin(C.c_void_p(st)), "fx_graph_begin")
+                try:
+                    p._launch(p.ops, st, thr)
+                finally:
+                    g = C.c_void_p()
+                    rc = self.lib.fx_graph_end(C.c_void_p(st), C.byref(g))
+                check(rc, "fx_graph_end")
+                graphs.append(g)
+            self.graph, self.graph_thr = graphs, thr
+        for s in self.side:
+            check(self.lib.fx_stream_fork(C.c_void_p(stream), C.c_void_p(s.cuda_stream)), "fx_stream_fork")
+        check(self.lib.fx_graph_launch(self.graph[0], C.c_void_p(stream)), "fx_graph_launch")
+        for g, s in zip(self.graph[1:], self.side):
+            check(self.lib.fx_graph_launch(g, C.c_void_p(s.cuda_stream)), "fx_graph_launch")
+        for s in self.side:
+            check(self.lib.fx_stream_join(C.c_void_p(stream), C.c_void_p(s.cuda_stream)), "fx_stream_join")
+
+    def _run_branches(self, stream: int, thr: float):
         if self.graph is None or self.graph_thr != thr:
             if self.graph is not None:
                 check(self.lib.fx_graph_destroy(self.graph), "fx_graph_destroy")
@@ -774,14 +833,10 @@ class _MultiPlan:
             self.graph, self.graph_thr = g, thr
         check(self.lib.fx_graph_launch(self.graph, C.c_void_p(stream)), "fx_graph_launch")
 
-    def time_graph(self, stream: int, iters: int) -> float:
-        ms = C.c_float(0)
-        check(self.lib.fx_graph_time(self.graph, C.c_void_p(stream), iters, C.byref(ms)), "fx_graph_time")
-        return ms.value
-
     def __del__(self):
         try:
-            if self.graph is not None:
-                self.lib.fx_graph_destroy(self.graph)
+            for g in (self.graph if isinstance(self.graph, list) else [self.graph]):
+                if g is not None:
+                    self.lib.fx_graph_destroy(g)
         except Exception:
             pass

@@ -222,7 +222,7 @@ class _MfPlan(_PlanBase):
                 f1 = self.linear(s2, P[f"{p}.linear1"], name=f"enc{li}.f1", act="relu")
                 s = self.linear(f1, P[f"{p}.linear2"], name=f"enc{li}.f2", residual=o)
             s = self.layernorm(s, f"{pd}.transformer.encoder.norm", "enc_tokens")
-            x5 = NT(s.t, B, h32, w32, 256, 256)
+            x5 = NT(s.t, B, h32, w32, 256, 256, s.off)
         y = self.conv(x5, P[f"{pd}.layer_4"], name="msf0", act="relu")
         msf = [y]
         for idx, f in ((3, feats[4]), (2, feats[3]), (1, feats[2])):

@@ -319,3 +319,44 @@ def test_mf_model_manager_and_processor_paths(setup):
     assert [d.cls_id for d in one.detections] == [d.cls_id for d in dets[1].detections]
     with pytest.raises(ValueError):
         fm.processor.preprocess([images[0], images[1][:64]], device=fm.device)
+
+
+def test_mf_full_size_batch_properties(setup):
+    """BASELINE configs[2] at full size (800x800, bs=8): batch-position independence
+    (permuted batch -> permuted result, bit-for-bit), idempotent replay, and post-process invariants (boxes enclose the
+    packed masks exactly, areas = popcount of the bit masks, kept scores above the threshold, queries ascending)."""
+    g, cfg, sd, eng, *_ = setup
+    imgs = torch.from_numpy(np.stack([synth_image_structured(50 + i, 800, 800) for i in range(8)])).to(DEV)
+    perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device=DEV)
+    keys = ("probs", "det_count", "det_query", "det_scores", "det_labels", "det_boxes", "det_area")
+
+    def run(x):
+        pl = eng.forward(x, full_masks=False)
+        torch.cuda.synchronize()
+        out = {k: getattr(pl, k).clone() for k in keys}
+        out["mask_probs"] = pl.mask_probs.clone()
+        n = out["det_count"].cpu()
+        out["words"] = [pl.mask_words[i, : int(n[i])].clone() for i in range(x.shape[0])]
+        return out
+
+    a = run(imgs)
+    b = run(imgs[perm].contiguous())
+    assert torch.equal(a["probs"][perm], b["probs"]) and torch.equal(a["mask_probs"][perm], b["mask_probs"])
+    assert torch.equal(a["det_count"][perm], b["det_count"])
+    n = a["det_count"].cpu()
+    assert int(n.min()) > 0
+    for j, i in enumerate(perm.cpu().tolist()):
+        ni = int(n[i])
+        for k in ("det_query", "det_scores", "det_labels", "det_boxes", "det_area"):
+            assert torch.equal(a[k][i, :ni], b[k][j, :ni]), k
+        assert torch.equal(a["words"][i], b["words"][j])
+    a2 = run(imgs)
+    assert torch.equal(a["mask_probs"], a2["mask_probs"]) and torch.equal(a["det_scores"], a2["det_scores"])
+    for i in range(8):
+        ni = int(n[i])
+        q = a["det_query"][i, :ni].cpu()
+        assert (q[1:] > q[:-1]).all()
+        assert (a["det_scores"][i, :ni] > cfg["threshold"]).all()
+        m = np.unpackbits(a["words"][i].cpu().numpy().view(np.uint8), axis=-1, bitorder="little").reshape(ni, 800, 800).astype(bool)
+        assert m.reshape(ni, -1).sum(-1).tolist() == a["det_area"][i, :ni].cpu().tolist()
+        assert M.masks_to_xyxy(m).tolist() == a["det_boxes"][i, :ni].cpu().tolist()
