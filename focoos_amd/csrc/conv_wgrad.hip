@@ -1,0 +1,176 @@
+// Weight gradient of the NHWC bf16 convolution (training path) on the gfx950 matrix cores:
+//   dW[n][kh][kw][c] += sum over output pixels m of dZ[m][n] * X[pixel(m, kh, kw)][c]
+// i.e. the GEMM  D[n][kc] = sum_m  dZ^T[n][m] * Xcol[m][kc]  whose REDUCTION index is the pixel.  Both operands live in
+// memory pixel-major (NHWC), the opposite of what an MFMA fragment wants (8 consecutive reduction indices per lane), so:
+//   * tiles are staged in LDS exactly as they sit in memory ([32 pixels][128 channels], rows padded to 288 B), filled
+//     with coalesced 16-byte buffer loads (im2col addressing per row; out-of-image taps read zeros);
+//   * fragments are fetched with the gfx950 transpose read ds_read_b64_tr_b16: 16 lanes hand in the addresses of a
+//     [4 pixels][16 channels] block (4 contiguous bf16 each) and get it back column-major, so two reads give a lane the 8
+//     consecutive pixels of its channel.  The 32-byte row padding spreads the 4 rows of a block over distinct banks.
+//   * the pixel range is split across workgroups (grid.y) - the output tile count alone (N/128 x Ktot/128) cannot fill
+//     256 CUs - and partial sums are added into the fp32 gradient with hardware float atomics.
+#include "conv_common.h"
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+struct WgradArgs {
+  const bf16_t* x;
+  const bf16_t* dz;
+  float* dw;
+  int B, H, W, C, ldx;
+  int Ho, Wo, N, lddz;
+  int KH, KW, stride, pad;
+  int M, Ktot, nKt, mchunk;
+  unsigned x_bytes, dz_bytes;
+};
+
+#define WG_BP 32          // pixels per K-step
+#define WG_ROW 288        // LDS row stride in bytes: 128 channels * 2 B + 32 B padding
+#define WG_TILE (WG_BP * WG_ROW)
+
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base) {
+  // two transpose reads: pixels +0..3 and +4..7 of the lane's channel
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base));
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * WG_ROW));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * WG_TILE];  // [stage][dZ tile | X tile]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nt = blockIdx.x / p.nKt, kt = blockIdx.x % p.nKt;
+  const int n0 = nt * 128, kc0 = kt * 128;
+  const int m_lo = blockIdx.y * p.mchunk;
+  const int m_hi = min(p.M, m_lo + p.mchunk);
+  if (m_lo >= m_hi) return;
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, p.dz_bytes, 0x00020000);
+
+  // staging: thread -> (row r0 + 16*i, 16-byte chunk cc) of both tiles, i = 0..1
+  const int cc = tid & 15, r0 = tid >> 4;
+  const int HoWo = p.Ho * p.Wo;
+  // this thread's X columns: kc = kc0 + 8*cc .. +7 -> one filter tap and channel offset (C % 8 == 0, a chunk never straddles taps)
+  const int kc = kc0 + cc * 8;
+  const bool kc_ok = kc < p.Ktot;
+  const int tap = kc_ok ? kc / p.C : 0;
+  const int cch = kc - tap * p.C;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int nch = n0 + cc * 8;
+  const bool n_ok = nch < p.N;  // N % 8 == 0
+
+  uint4 rz[2], rx[2];
+  auto load = [&](int mbase) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mbase + r0 + 16 * i;
+      const bool ok = m < m_hi;
+      rz[i] = buf_load16(zr, (ok && n_ok) ? ((unsigned)m * (unsigned)p.lddz + nch) * 2u : FX_OOB);
+      const int mm = ok ? m : 0;
+      const int b = mm / HoWo, rem = mm - b * HoWo;
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      const int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;
+      const bool in = ok && kc_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+      rx[i] = buf_load16(xr, in ? ((unsigned)((b * p.H + hi) * p.W + wi) * (unsigned)p.ldx + cch) * 2u : FX_OOB);
+    }
+  };
+  auto store = [&](int s) {
+    unsigned char* Z = smem + s * 2 * WG_TILE;
+    unsigned char* X = Z + WG_TILE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<uint4*>(Z + (r0 + 16 * i) * WG_ROW + cc * 16) = rz[i];
+      *reinterpret_cast<uint4*>(X + (r0 + 16 * i) * WG_ROW + cc * 16) = rx[i];
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+  // fragment addressing (see header): lane l -> group g = l>>4 (channels 16*(g&1).., pixel half g>>1), t = l&15 supplies
+  // row (t>>2), 8-byte piece (t&3) of the [4][16] block
+  const int g = lane >> 4, t = lane & 15;
+  const int frag_off = ((g >> 1) * 8 + (t >> 2)) * WG_ROW + ((g & 1) * 16 + (t & 3) * 4) * 2;
+
+  const int nsteps = (m_hi - m_lo + WG_BP - 1) / WG_BP;
+  load(m_lo);
+  store(0);
+  __syncthreads();
+  for (int st = 0; st < nsteps; ++st) {
+    const int cur = st & 1;
+    if (st + 1 < nsteps) load(m_lo + (st + 1) * WG_BP);
+    const unsigned char* Z = smem + cur * 2 * WG_TILE;
+    const unsigned char* X = Z + WG_TILE;
+#pragma unroll
+    for (int ks = 0; ks < WG_BP / 16; ++ks) {
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) af[a] = tr_frag(Z + ks * 16 * WG_ROW + frag_off + (wm * 64 + a * 32) * 2);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) bfr[b] = tr_frag(X + ks * 16 * WG_ROW + frag_off + (wn * 64 + b * 32) * 2);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+    }
+    if (st + 1 < nsteps) store(cur ^ 1);
+    __syncthreads();
+  }
+  // epilogue: D rows = out channel n, cols = kc; a register index r is one n for 32 consecutive kc -> 128-byte atomics
+  const int l32 = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int kcol = kc0 + wn * 64 + b * 32 + l32;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (n < p.N && kcol < p.Ktot) unsafeAtomicAdd(p.dw + (int64_t)n * p.Ktot + kcol, acc[a][b][r]);
+      }
+    }
+}
+
+extern "C" int fx_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, float* dw, int B, int H, int W, int C, int Ho,
+                                         int Wo, int N, int KH, int KW, int stride, int pad, fx_stream_t stream_) {
+  FX_CHECK_ARG(x && dz && dw && B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && N > 0 && C > 0);
+  FX_CHECK_ARG(C % 8 == 0 && N % 8 == 0 && ldx >= C && lddz >= N && ldx % 8 == 0 && lddz % 8 == 0);
+  FX_CHECK_ARG(KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0);
+  FX_CHECK_ARG(Ho == (H + 2 * pad - KH) / stride + 1 && Wo == (W + 2 * pad - KW) / stride + 1);
+  FX_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)dz % 16) == 0 && ((uintptr_t)dw % 4) == 0);
+  const int64_t x_bytes = ((int64_t)B * H * W - 1) * ldx * 2 + (int64_t)C * 2;
+  const int64_t dz_bytes = ((int64_t)B * Ho * Wo - 1) * lddz * 2 + (int64_t)N * 2;
+  if (x_bytes >= 0xFFFFFFF0ll || dz_bytes >= 0xFFFFFFF0ll || (int64_t)B * Ho * Wo >= (1ll << 31)) return FX_ERR_UNSUPPORTED;
+  WgradArgs a;
+  a.x = reinterpret_cast<const bf16_t*>(x);
+  a.dz = reinterpret_cast<const bf16_t*>(dz);
+  a.dw = dw;
+  a.B = B; a.H = H; a.W = W; a.C = C; a.ldx = ldx;
+  a.Ho = Ho; a.Wo = Wo; a.N = N; a.lddz = lddz;
+  a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;
+  a.M = B * Ho * Wo;
+  a.Ktot = KH * KW * C;
+  a.nKt = (a.Ktot + 127) / 128;
+  const int nNt = (N + 127) / 128;
+  a.x_bytes = (unsigned)x_bytes;
+  a.dz_bytes = (unsigned)dz_bytes;
+  // pixel split: enough workgroups to fill the chip a few times over, chunks a multiple of the K-step
+  const int tiles = nNt * a.nKt;
+  int want = (256 * 4 + tiles - 1) / tiles;
+  int mchunk = (a.M + want - 1) / want;
+  if (mchunk < 512) mchunk = 512;
+  mchunk = (mchunk + WG_BP - 1) / WG_BP * WG_BP;
+  a.mchunk = mchunk;
+  const int S = (a.M + mchunk - 1) / mchunk;
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles, S), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), a);
+  return fx_launch_status();
+}

@@ -247,6 +247,15 @@ int fx_adamw_step_f32(float* params, const float* grads, float* exp_avg, float* 
                       const int32_t* chunk_len, const float* chunk_lr, const float* chunk_wd, int nchunks, int step, float beta1, float beta2,
                       float eps, float max_grad_norm, void* workspace, float* total_norm_out, fx_stream_t stream);
 
+/* ---- training path, convolution backward (autograd of F.conv2d as used by ConvNormLayer,
+ * focoos/nn/layers/conv.py:78-98) -----------------------------------------------------------------------------------
+ * Weight gradient: dw[n][kh][kw][c] (fp32, layout of the packed forward weights without row padding) +=
+ * sum_m dz[m][n] * x[pixel(m,kh,kw)][c].  x bf16 NHWC [B,H,W,C] (pixel stride ldx), dz bf16 [B,Ho,Wo,N] (pixel stride
+ * lddz) = gradient w.r.t. the convolution output (activation backward already applied).  ACCUMULATES with float atomics:
+ * the caller zeroes dw.  C % 8 == 0, N % 8 == 0. */
+int fx_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, float* dw, int B, int H, int W, int C, int Ho, int Wo, int N,
+                              int KH, int KW, int stride, int pad, fx_stream_t stream);
+
 /* Fork: `side` waits for everything queued on `main` so far; join: `main` waits for `side`.  Valid inside
  * fx_graph_begin/fx_graph_end (the side stream joins the capture), which turns two launch sequences into independent
  * branches of one hipGraph - used to run the two half-batches of a step concurrently. */
