@@ -1,0 +1,263 @@
+// Training-path support kernels around the convolution: weight (re)packing from the fp32 master
+// copy, gradient unpacking, activation / pooling backward, the zero-insertion that turns a stride-2 input gradient into a
+// stride-1 convolution.  All are HBM-bound elementwise kernels, 8 bf16 (16 B) per lane.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// Master weights (reference layout [N][C][KH][KW], fp32) -> the two bf16 images the MFMA kernels read:
+//   w_fwd [Npad][KH][KW][C]            : forward / weight layout of fx_conv2d_nhwc_bf16, optional per-out-channel scale
+//                                        (eval-mode BatchNorm folded: gamma / sqrt(var + eps))
+//   w_dgrad [Cpad][KH][KW][N]          : w_dgrad[c][kh][kw][n] = scale[n] * w[n][c][KH-1-kh][KW-1-kw]  (the input gradient
+//                                        of a stride-1 "same" conv is the conv of dZ with the flipped, transposed filter)
+// Rows beyond N (C) of the padded images are zeroed by the caller once.
+__global__ __launch_bounds__(256) void pack_conv_weights_kernel(const float* __restrict__ w, const float* __restrict__ scale,
+                                                                bf16_t* __restrict__ w_fwd, bf16_t* __restrict__ w_dgrad, int N, int C, int KH,
+                                                                int KW) {
+  const int64_t total = (int64_t)N * C * KH * KW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int kw = (int)(i % KW);
+    int64_t r = i / KW;
+    int kh = (int)(r % KH);
+    r /= KH;
+    int c = (int)(r % C);
+    int n = (int)(r / C);
+    const float v = w[i] * (scale ? scale[n] : 1.0f);
+    const bf16_t b = f32_to_bf16(v);
+    if (w_fwd) w_fwd[(((int64_t)n * KH + kh) * KW + kw) * C + c] = b;
+    if (w_dgrad) w_dgrad[(((int64_t)c * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)) * N + n] = b;
+  }
+}
+
+extern "C" int fx_pack_conv_weights_f32(const float* w, const float* scale, void* w_fwd, void* w_dgrad, int N, int C, int KH, int KW,
+                                        fx_stream_t stream_) {
+  FX_CHECK_ARG(w && (w_fwd || w_dgrad) && N > 0 && C > 0 && KH > 0 && KW > 0);
+  int64_t total = (int64_t)N * C * KH * KW;
+  int64_t grid = (total + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(pack_conv_weights_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), w, scale,
+                     (bf16_t*)w_fwd, (bf16_t*)w_dgrad, N, C, KH, KW);
+  return fx_launch_status();
+}
+
+// dw_master[n][c][kh][kw] (+)= scale[n] * dw_eff[n][kh][kw][c]   (chain rule through the folded BatchNorm scale)
+__global__ __launch_bounds__(256) void unpack_conv_wgrad_kernel(const float* __restrict__ dw_eff, const float* __restrict__ scale,
+                                                                float* __restrict__ dw, int N, int C, int KH, int KW, int Ceff, int accumulate) {
+  const int64_t total = (int64_t)N * C * KH * KW;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int kw = (int)(i % KW);
+    int64_t r = i / KW;
+    int kh = (int)(r % KH);
+    r /= KH;
+    int c = (int)(r % C);
+    int n = (int)(r / C);
+    const float v = dw_eff[(((int64_t)n * KH + kh) * KW + kw) * Ceff + c] * (scale ? scale[n] : 1.0f);
+    dw[i] = accumulate ? dw[i] + v : v;
+  }
+}
+
+extern "C" int fx_unpack_conv_wgrad_f32(const float* dw_eff, const float* scale, float* dw_master, int N, int C, int KH, int KW, int C_eff,
+                                        int accumulate, fx_stream_t stream_) {
+  FX_CHECK_ARG(dw_eff && dw_master && N > 0 && C > 0 && KH > 0 && KW > 0 && C_eff >= C);
+  int64_t total = (int64_t)N * C * KH * KW;
+  int64_t grid = (total + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), dw_eff, scale, dw_master,
+                     N, C, KH, KW, C_eff, accumulate);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the fused conv epilogue  y = act(conv + bias [+ residual]) :  dz = dy * act'(.)  (dz is both the gradient of
+// the conv output and, for a pre-activation residual, of the residual branch).  ReLU needs only the saved OUTPUT
+// (y > 0); an optional second upstream gradient dy2 (the tensor had two consumers) is added first.
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ dy2, int lddy2,
+                                                       const bf16_t* __restrict__ y, int ldy, bf16_t* __restrict__ dz, int lddz, int64_t rows,
+                                                       int C8, int use_relu) {
+  const int64_t total = rows * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t r = i / C8;
+    float g[8], o[8];
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(dy + r * lddy + c8 * 8), g);
+    if (dy2) {
+      float g2[8];
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(dy2 + r * lddy2 + c8 * 8), g2);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] += g2[j];
+    }
+    if (use_relu) {
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(y + r * ldy + c8 * 8), o);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = o[j] > 0.0f ? g[j] : 0.0f;
+    }
+    *reinterpret_cast<uint4*>(dz + r * lddz + c8 * 8) = pack_bf16x8(g);
+  }
+}
+
+extern "C" int fx_relu_bwd_bf16(const void* dy, int lddy, const void* dy2, int lddy2, const void* y, int ldy, void* dz, int lddz, int64_t rows,
+                                int cols, int use_relu, fx_stream_t stream_) {
+  FX_CHECK_ARG(dy && dz && rows > 0 && cols > 0 && cols % 8 == 0 && lddy >= cols && lddz >= cols && lddy % 8 == 0 && lddz % 8 == 0);
+  FX_CHECK_ARG(!use_relu || (y && ldy >= cols && ldy % 8 == 0));
+  FX_CHECK_ARG(!dy2 || (lddy2 >= cols && lddy2 % 8 == 0));
+  int64_t total = rows * (cols / 8);
+  int64_t grid = (total + 255) / 256;
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(relu_bwd_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)dy, lddy,
+                     (const bf16_t*)dy2, lddy2, (const bf16_t*)y, ldy, (bf16_t*)dz, lddz, rows, cols / 8, use_relu);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// u[b, 2*ho, 2*wo, :] = dz[b, ho, wo, :], zero elsewhere (u is [B, H, W, C] with H >= 2*Ho-1): the input gradient of a
+// stride-2 3x3 pad-1 conv is the stride-1 conv of u with the flipped filter.
+__global__ __launch_bounds__(256) void zero_insert2_kernel(const bf16_t* __restrict__ dz, int lddz, bf16_t* __restrict__ u, int ldu, int B,
+                                                           int Ho, int Wo, int H, int W, int C8) {
+  const int64_t total = (int64_t)B * H * W * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    int64_t p = i / C8;
+    const int x = (int)(p % W);
+    p /= W;
+    const int y = (int)(p % H);
+    const int b = (int)(p / H);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (!(y & 1) && !(x & 1) && (y >> 1) < Ho && (x >> 1) < Wo)
+      v = *reinterpret_cast<const uint4*>(dz + (((int64_t)b * Ho + (y >> 1)) * Wo + (x >> 1)) * lddz + c8 * 8);
+    *reinterpret_cast<uint4*>(u + (((int64_t)b * H + y) * W + x) * ldu + c8 * 8) = v;
+  }
+}
+
+extern "C" int fx_zero_insert2_nhwc_bf16(const void* dz, int lddz, void* u, int ldu, int B, int Ho, int Wo, int H, int W, int C,
+                                         fx_stream_t stream_) {
+  FX_CHECK_ARG(dz && u && B > 0 && Ho > 0 && Wo > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && lddz >= C && ldu >= C);
+  int64_t total = (int64_t)B * H * W * (C / 8);
+  int64_t grid = (total + 255) / 256;
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(zero_insert2_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)dz, lddz,
+                     (bf16_t*)u, ldu, B, Ho, Wo, H, W, C / 8);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// AvgPool2d(2, 2, 0, ceil_mode=True) backward: dx[2ho+dy, 2wo+dx] = dp[ho, wo] / (#in-bounds taps of that window)
+__global__ __launch_bounds__(256) void avgpool2_bwd_kernel(const bf16_t* __restrict__ dp, int lddp, bf16_t* __restrict__ dx, int lddx, int B,
+                                                           int H, int W, int C8, int Ho, int Wo) {
+  const int64_t total = (int64_t)B * H * W * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    int64_t p = i / C8;
+    const int x = (int)(p % W);
+    p /= W;
+    const int y = (int)(p % H);
+    const int b = (int)(p / H);
+    const int ho = y >> 1, wo = x >> 1;
+    const int cnt = ((2 * ho + 1 < H) ? 2 : 1) * ((2 * wo + 1 < W) ? 2 : 1);
+    float g[8];
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(dp + (((int64_t)b * Ho + ho) * Wo + wo) * lddp + c8 * 8), g);
+    const float inv = 1.0f / (float)cnt;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] *= inv;
+    *reinterpret_cast<uint4*>(dx + (((int64_t)b * H + y) * W + x) * lddx + c8 * 8) = pack_bf16x8(g);
+  }
+}
+
+extern "C" int fx_avgpool2x2_bwd_nhwc_bf16(const void* dp, int lddp, void* dx, int lddx, int B, int H, int W, int C, fx_stream_t stream_) {
+  FX_CHECK_ARG(dp && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && lddp >= C && lddx >= C && lddp % 8 == 0 && lddx % 8 == 0);
+  const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
+  int64_t total = (int64_t)B * H * W * (C / 8);
+  int64_t grid = (total + 255) / 256;
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(avgpool2_bwd_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)dp, lddp,
+                     (bf16_t*)dx, lddx, B, H, W, C / 8, Ho, Wo);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// MaxPool2d(3, 2, 1) backward, gather form (no atomics, deterministic): an input pixel receives dy of every window whose
+// arg-max it is.  PyTorch's CPU/GPU kernels keep the FIRST maximum in window scan order (kh-major) - after a ReLU ties
+// (zeros) are common, so the scan order is reproduced: a later tap wins only if strictly greater.
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dy, int lddy,
+                                                               bf16_t* __restrict__ dx, int lddx, int B, int H, int W, int C8, int Ho,
+                                                               int Wo) {
+  const int64_t total = (int64_t)B * H * W * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    int64_t p = i / C8;
+    const int xi = (int)(p % W);
+    p /= W;
+    const int yi = (int)(p % H);
+    const int b = (int)(p / H);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // windows (ho, wo) with 2*ho - 1 <= yi <= 2*ho + 1
+    const int ho_lo = max((yi - 1 + 1) / 2, 0), ho_hi = min((yi + 1) / 2, Ho - 1);
+    const int wo_lo = max((xi - 1 + 1) / 2, 0), wo_hi = min((xi + 1) / 2, Wo - 1);
+    for (int ho = ho_lo; ho <= ho_hi; ++ho)
+      for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+        float best[8];
+        int arg[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) best[j] = -INFINITY, arg[j] = -1;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int hi = ho * 2 - 1 + kh;
+          if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int wi = wo * 2 - 1 + kw;
+            if ((unsigned)wi >= (unsigned)W) continue;
+            float f[8];
+            unpack_bf16x8(*reinterpret_cast<const uint4*>(x + (((int64_t)b * H + hi) * W + wi) * ldx + c8 * 8), f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (f[j] > best[j] || arg[j] < 0) best[j] = f[j], arg[j] = hi * W + wi;
+          }
+        }
+        float g[8];
+        unpack_bf16x8(*reinterpret_cast<const uint4*>(dy + (((int64_t)b * Ho + ho) * Wo + wo) * lddy + c8 * 8), g);
+        const int me = yi * W + xi;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (arg[j] == me) acc[j] += g[j];
+      }
+    *reinterpret_cast<uint4*>(dx + (((int64_t)b * H + yi) * W + xi) * lddx + c8 * 8) = pack_bf16x8(acc);
+  }
+}
+
+extern "C" int fx_maxpool3x3s2_bwd_nhwc_bf16(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int B, int H, int W, int C,
+                                             fx_stream_t stream_) {
+  FX_CHECK_ARG(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0);
+  FX_CHECK_ARG(ldx >= C && lddy >= C && lddx >= C && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0);
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  int64_t total = (int64_t)B * H * W * (C / 8);
+  int64_t grid = (total + 255) / 256;
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)x, ldx,
+                     (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, B, H, W, C / 8, Ho, Wo);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// (x - mean) / std of the uint8 / fp32 HWC image, as bf16 NHWC with the 3 channels padded to 8 (zeros): the activation
+// tensor the stem conv's weight gradient reads (fx_conv2d_wgrad_nhwc_bf16 needs C % 8 == 0).
+__global__ __launch_bounds__(256) void normalize_pad8_kernel(const void* __restrict__ img, int is_f32, const float* __restrict__ mean,
+                                                             const float* __restrict__ inv_std, bf16_t* __restrict__ out, int64_t pixels) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pixels; i += (int64_t)gridDim.x * 256) {
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float raw = is_f32 ? reinterpret_cast<const float*>(img)[i * 3 + c] : (float)reinterpret_cast<const unsigned char*>(img)[i * 3 + c];
+      v[c] = (raw - mean[c]) * inv_std[c];
+    }
+    *reinterpret_cast<uint4*>(out + i * 8) = pack_bf16x8(v);
+  }
+}
+
+extern "C" int fx_normalize_pad8(const void* img, int is_f32, const float* mean, const float* inv_std, void* out, int64_t pixels,
+                                 fx_stream_t stream_) {
+  FX_CHECK_ARG(img && mean && inv_std && out && pixels > 0);
+  int64_t grid = (pixels + 255) / 256;
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(normalize_pad8_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), img, is_f32, mean, inv_std,
+                     (bf16_t*)out, pixels);
+  return fx_launch_status();
+}

@@ -256,6 +256,33 @@ int fx_adamw_step_f32(float* params, const float* grads, float* exp_avg, float* 
 int fx_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, float* dw, int B, int H, int W, int C, int Ho, int Wo, int N,
                               int KH, int KW, int stride, int pad, fx_stream_t stream);
 
+/* Master weights fp32 [N][C][KH][KW] (reference / checkpoint layout) -> bf16 images for the MFMA kernels, optionally
+ * multiplied by a per-out-channel scale (frozen BatchNorm folded): w_fwd [Npad][KH][KW][C] (fx_conv2d_nhwc_bf16 layout) and
+ * w_dgrad [Cpad][KH][KW][N] = flipped + transposed filter: for a stride-1 "same" conv, dX = fx_conv2d_nhwc_bf16(dZ, w_dgrad).
+ * Either output may be NULL; padding rows are not touched (zero them once). */
+int fx_pack_conv_weights_f32(const float* w, const float* scale, void* w_fwd, void* w_dgrad, int N, int C, int KH, int KW, fx_stream_t stream);
+
+/* dw_master[n][c][kh][kw] (+)= scale[n] * dw_eff[n][kh][kw][c]; dw_eff rows have C_eff >= C channels (stem: 3 of 8). */
+int fx_unpack_conv_wgrad_f32(const float* dw_eff, const float* scale, float* dw_master, int N, int C, int KH, int KW, int C_eff, int accumulate,
+                             fx_stream_t stream);
+
+/* Backward of the fused epilogue y = relu(conv + bias [+ residual]): dz = (dy [+ dy2]) * (y > 0)  (use_relu = 0: plain sum). */
+int fx_relu_bwd_bf16(const void* dy, int lddy, const void* dy2, int lddy2, const void* y, int ldy, void* dz, int lddz, int64_t rows, int cols,
+                     int use_relu, fx_stream_t stream);
+
+/* u[b,2ho,2wo,:] = dz[b,ho,wo,:], zeros elsewhere; u is [B,H,W,C]: input gradient of a stride-2 3x3 pad-1 conv =
+ * fx_conv2d_nhwc_bf16(u, w_dgrad) at stride 1. */
+int fx_zero_insert2_nhwc_bf16(const void* dz, int lddz, void* u, int ldu, int B, int Ho, int Wo, int H, int W, int C, fx_stream_t stream);
+
+/* Backward of fx_avgpool2x2_nhwc_bf16 (AvgPool2d(2,2,0,ceil_mode=True)) and fx_maxpool3x3s2_nhwc_bf16 (first maximum in
+ * window scan order receives the gradient, like PyTorch); dx is [B,H,W,C]. */
+int fx_avgpool2x2_bwd_nhwc_bf16(const void* dp, int lddp, void* dx, int lddx, int B, int H, int W, int C, fx_stream_t stream);
+int fx_maxpool3x3s2_bwd_nhwc_bf16(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int B, int H, int W, int C,
+                                  fx_stream_t stream);
+
+/* (img - mean) * inv_std as bf16 NHWC with the 3 channels padded to 8: the stem conv's input for its weight gradient. */
+int fx_normalize_pad8(const void* img, int is_f32, const float* mean, const float* inv_std, void* out, int64_t pixels, fx_stream_t stream);
+
 /* Fork: `side` waits for everything queued on `main` so far; join: `main` waits for `side`.  Valid inside
  * fx_graph_begin/fx_graph_end (the side stream joins the capture), which turns two launch sequences into independent
  * branches of one hipGraph - used to run the two half-batches of a step concurrently. */

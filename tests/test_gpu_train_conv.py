@@ -79,3 +79,109 @@ def test_conv_wgrad_asymmetric_and_strided_views(lib):
     want = torch.zeros(N, 1, 1, Cc)
     want[7, 0, 0, 5] = 6.0
     assert torch.equal(dw.cpu(), want)
+
+
+def test_pack_unpack_and_elementwise_backward(lib):
+    g = torch.Generator().manual_seed(0)
+    N, Cc, k = 40, 24, 3
+    w = torch.randn(N, Cc, k, k, generator=g)
+    s = torch.rand(N, generator=g) + 0.5
+    wf = torch.zeros(128, k, k, Cc, dtype=torch.bfloat16, device=DEV)
+    wd = torch.zeros(128, k, k, N, dtype=torch.bfloat16, device=DEV)
+    wdv, sd = w.to(DEV), s.to(DEV)
+    check(lib.fx_pack_conv_weights_f32(wdv.data_ptr(), sd.data_ptr(), wf.data_ptr(), wd.data_ptr(), N, Cc, k, k, stream()))
+    torch.cuda.synchronize()
+    ws = (w * s.view(-1, 1, 1, 1)).bfloat16()
+    assert torch.equal(wf[:N].cpu(), ws.permute(0, 2, 3, 1)) and float(wf[N:].abs().max()) == 0
+    assert torch.equal(wd[:Cc].cpu(), ws.flip(2, 3).permute(1, 2, 3, 0))
+    dwe = torch.randn(N, k, k, 32, generator=g)
+    out = torch.ones(N, Cc, k, k, device=DEV)
+    dd = dwe.to(DEV)
+    check(lib.fx_unpack_conv_wgrad_f32(dd.data_ptr(), sd.data_ptr(), out.data_ptr(), N, Cc, k, k, 32, 1, stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), (1 + dwe[..., :Cc].permute(0, 3, 1, 2) * s.view(-1, 1, 1, 1)).numpy(), rtol=1e-6)
+    # relu backward with a second upstream gradient
+    y = torch.randn(5, 7, 9, 64, generator=g).clamp_min(0).bfloat16()
+    dy, dy2 = torch.randn(5, 7, 9, 64, generator=g).bfloat16(), torch.randn(5, 7, 9, 64, generator=g).bfloat16()
+    dz = torch.empty_like(y, device=DEV)
+    a, b, c = dy.to(DEV), dy2.to(DEV), y.to(DEV)
+    check(lib.fx_relu_bwd_bf16(a.data_ptr(), 64, b.data_ptr(), 64, c.data_ptr(), 64, dz.data_ptr(), 64, 5 * 7 * 9, 64, 1, stream()))
+    torch.cuda.synchronize()
+    ref = ((dy.float() + dy2.float()) * (y.float() > 0)).bfloat16()
+    assert torch.equal(dz.cpu(), ref)
+
+
+@pytest.mark.parametrize("hw", [(12, 16), (13, 15)])
+def test_pool_backward(lib, hw):
+    H, W = hw
+    g = torch.Generator().manual_seed(H)
+    # max pool: ReLU-like input with many exact ties (zeros) -> the first-max rule matters
+    x = torch.randn(2, H, W, 16, generator=g).clamp_min(0).bfloat16()
+    xt = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    y = F.max_pool2d(xt, 3, 2, 1)
+    dy = torch.randn(y.shape, generator=g).bfloat16()
+    y.backward(dy.float())
+    ref = xt.grad.permute(0, 2, 3, 1)
+    xd, dyd = x.to(DEV), dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dx = torch.empty_like(xd)
+    check(lib.fx_maxpool3x3s2_bwd_nhwc_bf16(xd.data_ptr(), 16, dyd.data_ptr(), 16, dx.data_ptr(), 16, 2, H, W, 16, stream()))
+    torch.cuda.synchronize()
+    assert (dx.float().cpu() - ref).abs().max() <= 2e-2 * ref.abs().max()  # sums of up to 4 bf16 gradients, rounded once
+    assert ((dx.float().cpu() != 0) == (ref != 0)).all()               # identical routing (arg-max choice incl. ties)
+    # average pool (ceil mode)
+    xt = torch.zeros(2, 16, H, W, requires_grad=True)
+    y = F.avg_pool2d(xt, 2, 2, 0, ceil_mode=True)
+    dy = torch.randn(y.shape, generator=g).bfloat16()
+    y.backward(dy.float())
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dx = torch.empty(2, H, W, 16, dtype=torch.bfloat16, device=DEV)
+    check(lib.fx_avgpool2x2_bwd_nhwc_bf16(dyd.data_ptr(), 16, dx.data_ptr(), 16, 2, H, W, 16, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(dx.cpu(), xt.grad.permute(0, 2, 3, 1).bfloat16())
+
+
+def test_resnet_vd_backward_vs_torch_autograd():
+    """ResNet50-vd (frozen BN) forward + backward through the HIP autograd nodes vs torch CPU fp32 autograd of the oracle's
+    restatement of the reference backbone, same seeded weights / images / loss.  bf16 activations and gradients through
+    ~50 layers: per-parameter relative L2 error of the weight gradients <= 6e-2 (typically 1-2e-2), features <= 2e-2."""
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.synth import synth_image_structured, synth_state_dict
+    from focoos_amd.train_nn import ResNetVd
+    from oracle import detr_oracle as O
+    from tests.helpers import rel_l2
+
+    cfg = ModelRegistry.get_model_info("fai-detr-l-coco")["config"]
+    sd = synth_state_dict(cfg, 11)
+    pre = "pixel_decoder.backbone."
+    bsd = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    net = ResNetVd(50).to(DEV)
+    missing = net.load_state_dict(bsd, strict=True)
+    assert list(net.state_dict().keys()) == list(bsd.keys())
+    imgs = [synth_image_structured(40 + i, 128, 160) for i in range(2)]
+    x_u8 = torch.from_numpy(np.stack(imgs)).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    proj = {k: torch.randn(c, generator=g) for k, c in (("res2", 256), ("res3", 512), ("res4", 1024), ("res5", 2048))}
+    outs = net(x_u8)
+    loss = sum((outs[k].float() * proj[k].to(DEV)).sum() for k in proj) * 1e-2
+    loss.backward()
+    torch.cuda.synchronize()
+    # CPU fp32 reference
+    ref_sd = {k: (v.clone().requires_grad_(True) if k.endswith("conv.weight") else v) for k, v in sd.items() if k.startswith(pre)}
+    mean = torch.tensor(cfg["pixel_mean"]).view(-1, 1, 1)
+    std = torch.tensor(cfg["pixel_std"]).view(-1, 1, 1)
+    xi = (O.get_torch_batch(imgs, None) - mean) / std
+    feats = O.resnet_vd(ref_sd, pre[:-1], xi, O.RESNET_BLOCKS[50])
+    ref_loss = sum((feats[k] * proj[k].view(1, -1, 1, 1)).sum() for k in proj) * 1e-2
+    ref_loss.backward()
+    for k in proj:
+        assert rel_l2(outs[k].detach().float().cpu().permute(0, 3, 1, 2), feats[k].detach()) <= 2e-2, k
+    assert abs(float(loss) - float(ref_loss)) <= 2e-2 * abs(float(ref_loss))
+    worst = 0.0
+    for name, p in net.named_parameters():
+        if not p.requires_grad:
+            continue
+        assert p.grad is not None, name
+        e = rel_l2(p.grad.cpu(), ref_sd[pre + name].grad)
+        worst = max(worst, e)
+        assert e <= 6e-2, (name, e)
+    print("worst weight-gradient rel-L2:", worst)
