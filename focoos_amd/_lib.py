@@ -76,6 +76,15 @@ SIGNATURES = {
     "fx_avgpool2x2_bwd_nhwc_bf16": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "fx_maxpool3x3s2_bwd_nhwc_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "fx_normalize_pad8": [_vp, _i, _vp, _vp, _vp, C.c_int64, _vp],
+    "fx_act_fwd_bf16": [_vp, _i, _vp, _i, C.c_int64, _i, _i, _vp],
+    "fx_act_bwd_bf16": [_vp, _i, _vp, _i, _vp, _i, C.c_int64, _i, _i, _vp],
+    "fx_colsum_bf16": [_vp, _i, _vp, C.c_int64, _i, _vp],
+    "fx_layernorm_bwd_bf16": [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp],
+    "fx_resize_bilinear_bwd_nhwc": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "fx_cast_f32_bf16": [_vp, _vp, C.c_int64, _vp],
+    "fx_mha_bwd_workspace_bytes": [_i, _i, _i, _i],
+    "fx_mha_bwd_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, C.c_size_t, _vp],
+    "fx_scatter_rows_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
     "fx_stream_fork": [_vp, _vp],
     "fx_stream_join": [_vp, _vp],
     "fx_graph_begin": [_vp],
@@ -109,6 +118,7 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.fx_mha_bwd_workspace_bytes.restype = C.c_size_t
     lib.fx_error_string.argtypes = [C.c_int]
     lib.fx_error_string.restype = C.c_char_p
     if lib.fx_abi_version() != 1:

@@ -1,0 +1,404 @@
+// Training-path kernels of the token-space layers: activation forward/backward on a saved
+// pre-activation, bias gradient (column sum), LayerNorm backward, bilinear-resize backward, attention backward, row
+// scatter (backward of the query gather).  Correctness-first versions: fp32 math, wavefront reductions, fp32 atomics for
+// the cross-row parameter gradients; the decoder / AIFI tensors they touch are small (<= B*8400 rows of 256).
+#include "common.h"
+
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wmax(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------ activations
+__device__ __forceinline__ float act_grad(float z, int act) {
+  switch (act) {
+    case FX_ACT_RELU: return z > 0.0f ? 1.0f : 0.0f;
+    case FX_ACT_SILU: {
+      const float s = 1.0f / (1.0f + __expf(-z));
+      return s * (1.0f + z * (1.0f - s));
+    }
+    case FX_ACT_GELU: {  // exact (erf) GELU, like F.gelu
+      const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752f));
+      return cdf + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+    }
+    default: return 1.0f;
+  }
+}
+
+__global__ __launch_bounds__(256) void act_fwd_kernel(const bf16_t* __restrict__ z, int ldz, bf16_t* __restrict__ y, int ldy, int64_t rows, int C8,
+                                                      int act) {
+  const int64_t total = rows * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t r = i / C8;
+    float v[8];
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(z + r * ldz + c8 * 8), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = fx_act(v[j], act);
+    *reinterpret_cast<uint4*>(y + r * ldy + c8 * 8) = pack_bf16x8(v);
+  }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ z, int ldz,
+                                                      bf16_t* __restrict__ dz, int lddz, int64_t rows, int C8, int act) {
+  const int64_t total = rows * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t r = i / C8;
+    float g[8], v[8];
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(dy + r * lddy + c8 * 8), g);
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(z + r * ldz + c8 * 8), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) g[j] *= act_grad(v[j], act);
+    *reinterpret_cast<uint4*>(dz + r * lddz + c8 * 8) = pack_bf16x8(g);
+  }
+}
+
+static inline int ew_grid(int64_t total) {
+  int64_t grid = (total + 255) / 256;
+  return (int)(grid > 256 * 32 ? 256 * 32 : grid);
+}
+
+extern "C" int fx_act_fwd_bf16(const void* z, int ldz, void* y, int ldy, int64_t rows, int cols, int act, fx_stream_t stream_) {
+  FX_CHECK_ARG(z && y && rows > 0 && cols > 0 && cols % 8 == 0 && ldz >= cols && ldy >= cols && ldz % 8 == 0 && ldy % 8 == 0);
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(ew_grid(rows * (cols / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)z, ldz,
+                     (bf16_t*)y, ldy, rows, cols / 8, act);
+  return fx_launch_status();
+}
+
+extern "C" int fx_act_bwd_bf16(const void* dy, int lddy, const void* z, int ldz, void* dz, int lddz, int64_t rows, int cols, int act,
+                               fx_stream_t stream_) {
+  FX_CHECK_ARG(dy && z && dz && rows > 0 && cols > 0 && cols % 8 == 0 && lddy >= cols && ldz >= cols && lddz >= cols);
+  FX_CHECK_ARG(lddy % 8 == 0 && ldz % 8 == 0 && lddz % 8 == 0);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(ew_grid(rows * (cols / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)dy,
+                     lddy, (const bf16_t*)z, ldz, (bf16_t*)dz, lddz, rows, cols / 8, act);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ bias gradient
+// out[c] += sum_r x[r][c]: each block sums 256 rows per column in registers/LDS, one atomic per column per block.
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, int ldx, float* __restrict__ out, int64_t rows, int cols) {
+  __shared__ float part[4][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + lane;
+  const int64_t r0 = (int64_t)blockIdx.y * 1024;
+  float s = 0.0f;
+  if (c < cols)
+    for (int64_t r = r0 + wave; r < r0 + 1024 && r < rows; r += 4) s += bf16_to_f32(x[r * ldx + c]);
+  part[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && c < cols) unsafeAtomicAdd(out + c, part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+}
+
+extern "C" int fx_colsum_bf16(const void* x, int ldx, float* out, int64_t rows, int cols, fx_stream_t stream_) {
+  FX_CHECK_ARG(x && out && rows > 0 && cols > 0 && ldx >= cols);
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, (unsigned)((rows + 1023) / 1024)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
+                     (const bf16_t*)x, ldx, out, rows, cols);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ LayerNorm backward
+// y = (x - mu) * rstd * gamma + beta over 256 channels, one wave per row (4 channels per lane):
+//   g = dy * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat));  dgamma += dy * xhat;  dbeta += dy.
+__global__ __launch_bounds__(256) void layernorm256_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
+                                                               const float* __restrict__ gamma, bf16_t* __restrict__ dx, int lddx,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int rows) {
+  __shared__ float pg[4][256], pb[4][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float ag[4] = {0, 0, 0, 0}, ab[4] = {0, 0, 0, 0};
+  const float4 gm = *reinterpret_cast<const float4*>(gamma + lane * 4);
+  const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    uint2 xv = *reinterpret_cast<const uint2*>(x + (int64_t)row * ldx + lane * 4);
+    uint2 dv = *reinterpret_cast<const uint2*>(dy + (int64_t)row * lddy + lane * 4);
+    const float v[4] = {__uint_as_float(xv.x << 16), __uint_as_float(xv.x & 0xffff0000u), __uint_as_float(xv.y << 16),
+                        __uint_as_float(xv.y & 0xffff0000u)};
+    const float d[4] = {__uint_as_float(dv.x << 16), __uint_as_float(dv.x & 0xffff0000u), __uint_as_float(dv.y << 16),
+                        __uint_as_float(dv.y & 0xffff0000u)};
+    const float mean = wsum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+    float c[4], var = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = v[j] - mean, var += c[j] * c[j];
+    const float rstd = rsqrtf(wsum(var) * (1.0f / 256.0f) + 1e-5f);
+    float xh[4], g[4], sg = 0.0f, sgx = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xh[j] = c[j] * rstd;
+      g[j] = d[j] * gmv[j];
+      sg += g[j];
+      sgx += g[j] * xh[j];
+      ag[j] += d[j] * xh[j];
+      ab[j] += d[j];
+    }
+    sg = wsum(sg) * (1.0f / 256.0f);
+    sgx = wsum(sgx) * (1.0f / 256.0f);
+    uint2 o;
+    o.x = pack_bf16x2(rstd * (g[0] - sg - xh[0] * sgx), rstd * (g[1] - sg - xh[1] * sgx));
+    o.y = pack_bf16x2(rstd * (g[2] - sg - xh[2] * sgx), rstd * (g[3] - sg - xh[3] * sgx));
+    *reinterpret_cast<uint2*>(dx + (int64_t)row * lddx + lane * 4) = o;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) pg[wave][lane * 4 + j] = ag[j], pb[wave][lane * 4 + j] = ab[j];
+  __syncthreads();
+  const int c = threadIdx.x;
+  if (dgamma) unsafeAtomicAdd(dgamma + c, pg[0][c] + pg[1][c] + pg[2][c] + pg[3][c]);
+  if (dbeta) unsafeAtomicAdd(dbeta + c, pb[0][c] + pb[1][c] + pb[2][c] + pb[3][c]);
+}
+
+extern "C" int fx_layernorm_bwd_bf16(const void* dy, int lddy, const void* x, int ldx, const float* gamma, void* dx, int lddx, float* dgamma,
+                                     float* dbeta, int rows, int cols, fx_stream_t stream_) {
+  FX_CHECK_ARG(dy && x && gamma && dx && rows > 0);
+  if (cols != 256) return FX_ERR_UNSUPPORTED;
+  FX_CHECK_ARG(lddy >= cols && ldx >= cols && lddx >= cols && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0);
+  int grid = (rows + 3) / 4;
+  if (grid > 1024) grid = 1024;
+  hipLaunchKernelGGL(layernorm256_bwd_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)dy, lddy,
+                     (const bf16_t*)x, ldx, gamma, (bf16_t*)dx, lddx, dgamma, dbeta, rows);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ bilinear resize backward
+// Scatter form of fx_resize_bilinear_nhwc_bf16 (align_corners=False): every output pixel adds its gradient, weighted by
+// the four bilinear weights, into an fp32 accumulator [B,H,W,C] (zeroed by the caller); fx_cast_f32_bf16 converts.
+__device__ __forceinline__ void bil_src(int dst, float scale, int in, int& i0, int& i1, float& w0, float& w1) {
+  float src = ((float)dst + 0.5f) * scale - 0.5f;
+  src = src < 0.0f ? 0.0f : src;
+  i0 = (int)src;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + (i0 < in - 1 ? 1 : 0);
+  w1 = src - (float)i0;
+  w0 = 1.0f - w1;
+}
+
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, float* __restrict__ dx, int B, int H, int W, int C8,
+                                                         int Ho, int Wo, float sh, float sw) {
+  const int64_t total = (int64_t)B * Ho * Wo * C8;
+  const int Cc = C8 * 8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t p = i / C8;
+    const int wo = (int)(p % Wo);
+    const int64_t q = p / Wo;
+    const int ho = (int)(q % Ho), b = (int)(q / Ho);
+    int h0, h1, w0, w1;
+    float lh0, lh1, lw0, lw1;
+    bil_src(ho, sh, H, h0, h1, lh0, lh1);
+    bil_src(wo, sw, W, w0, w1, lw0, lw1);
+    float g[8];
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(dy + p * lddy + c8 * 8), g);
+    float* base = dx + (int64_t)b * H * W * Cc + c8 * 8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      unsafeAtomicAdd(base + ((int64_t)h0 * W + w0) * Cc + j, lh0 * lw0 * g[j]);
+      unsafeAtomicAdd(base + ((int64_t)h0 * W + w1) * Cc + j, lh0 * lw1 * g[j]);
+      unsafeAtomicAdd(base + ((int64_t)h1 * W + w0) * Cc + j, lh1 * lw0 * g[j]);
+      unsafeAtomicAdd(base + ((int64_t)h1 * W + w1) * Cc + j, lh1 * lw1 * g[j]);
+    }
+  }
+}
+
+extern "C" int fx_resize_bilinear_bwd_nhwc(const void* dy, int lddy, float* dx_f32, int B, int H, int W, int C, int Ho, int Wo, fx_stream_t stream_) {
+  FX_CHECK_ARG(dy && dx_f32 && B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 8 == 0 && lddy >= C && lddy % 8 == 0);
+  hipLaunchKernelGGL(resize_bwd_kernel, dim3(ew_grid((int64_t)B * Ho * Wo * (C / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
+                     (const bf16_t*)dy, lddy, dx_f32, B, H, W, C / 8, Ho, Wo, (float)H / (float)Ho, (float)W / (float)Wo);
+  return fx_launch_status();
+}
+
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const float4 a = *reinterpret_cast<const float4*>(x + i * 8), b = *reinterpret_cast<const float4*>(x + i * 8 + 4);
+    const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    *reinterpret_cast<uint4*>(y + i * 8) = pack_bf16x8(v);
+  }
+}
+
+extern "C" int fx_cast_f32_bf16(const float* x, void* y, int64_t n, fx_stream_t stream_) {
+  FX_CHECK_ARG(x && y && n > 0 && n % 8 == 0);
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ew_grid(n / 8)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), x, (bf16_t*)y, n / 8);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ attention backward
+// head_dim 32, Lk <= 512.  Pass 1 (one wave per query row): recompute p = softmax(q k^T / sqrt(32)) in fp32, D = dO . O,
+// dS = p * (dO V^T - D), dQ = dS K / sqrt(32); P and dS rows go to the workspace.  Pass 2 (one wave per key): dV = P^T dO,
+// dK = dS^T Q / sqrt(32).  O(L^2) workspace, no tiling: the sequences on this path are 300-400 tokens.
+#define MHA_MAXJ 8
+__global__ __launch_bounds__(256) void mha32_bwd_q_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
+                                                          const bf16_t* __restrict__ v, int ldv, const bf16_t* __restrict__ o, int ldo,
+                                                          const bf16_t* __restrict__ dout, int lddo, bf16_t* __restrict__ dq, int lddq,
+                                                          float* __restrict__ P, float* __restrict__ dS, int Lq, int Lk, int heads) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh % heads;
+  const int qi = blockIdx.x * 4 + wave;
+  if (qi >= Lq) return;
+  const float scale = 0.17677669529663687f;
+  float qr[32], dor[32], D = 0.0f;
+  {
+    const bf16_t* qp = q + ((int64_t)b * Lq + qi) * ldq + hd * 32;
+    const bf16_t* op = o + ((int64_t)b * Lq + qi) * ldo + hd * 32;
+    const bf16_t* dp = dout + ((int64_t)b * Lq + qi) * lddo + hd * 32;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float t[8], u[8], w[8];
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(qp + c * 8), t);
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(op + c * 8), u);
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(dp + c * 8), w);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qr[c * 8 + j] = t[j], dor[c * 8 + j] = w[j], D += w[j] * u[j];
+    }
+  }
+  float s[MHA_MAXJ], dpv[MHA_MAXJ];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < MHA_MAXJ; ++t) {
+    const int j = lane + 64 * t;
+    s[t] = -INFINITY;
+    dpv[t] = 0.0f;
+    if (j < Lk) {
+      const bf16_t* kp = k + ((int64_t)b * Lk + j) * ldk + hd * 32;
+      const bf16_t* vp = v + ((int64_t)b * Lk + j) * ldv + hd * 32;
+      float acc = 0.0f, accv = 0.0f;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float kk[8], vv[8];
+        unpack_bf16x8(*reinterpret_cast<const uint4*>(kp + c * 8), kk);
+        unpack_bf16x8(*reinterpret_cast<const uint4*>(vp + c * 8), vv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += qr[c * 8 + e] * kk[e], accv += dor[c * 8 + e] * vv[e];
+      }
+      s[t] = acc * scale;
+      dpv[t] = accv;
+      mx = fmaxf(mx, s[t]);
+    }
+  }
+  mx = wmax(mx);
+  float l = 0.0f;
+#pragma unroll
+  for (int t = 0; t < MHA_MAXJ; ++t) {
+    s[t] = (lane + 64 * t) < Lk ? __expf(s[t] - mx) : 0.0f;
+    l += s[t];
+  }
+  const float inv = 1.0f / wsum(l);
+  // D = sum_j p_j * dP_j from the fp32 probabilities recomputed here, not dO . O: the forward O is bf16-rounded, and
+  // with peaked softmaxes dP_j - D cancels to a few percent of its terms, which would amplify that rounding ~50x.
+  D = 0.0f;
+#pragma unroll
+  for (int t = 0; t < MHA_MAXJ; ++t) D += s[t] * inv * dpv[t];
+  D = wsum(D);
+  float dqa[32];
+#pragma unroll
+  for (int d = 0; d < 32; ++d) dqa[d] = 0.0f;
+  float* Prow = P + ((int64_t)bh * Lq + qi) * Lk;
+  float* Srow = dS + ((int64_t)bh * Lq + qi) * Lk;
+#pragma unroll
+  for (int t = 0; t < MHA_MAXJ; ++t) {
+    const int j = lane + 64 * t;
+    if (j < Lk) {
+      const float p = s[t] * inv;
+      const float ds = p * (dpv[t] - D);
+      Prow[j] = p;
+      Srow[j] = ds;
+      const bf16_t* kp = k + ((int64_t)b * Lk + j) * ldk + hd * 32;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        float kk[8];
+        unpack_bf16x8(*reinterpret_cast<const uint4*>(kp + c * 8), kk);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dqa[c * 8 + e] += ds * kk[e];
+      }
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 32; ++d) dqa[d] = wsum(dqa[d]) * scale;
+  if (lane == 0) {
+    bf16_t* dp = dq + ((int64_t)b * Lq + qi) * lddq + hd * 32;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) *reinterpret_cast<uint4*>(dp + c * 8) = pack_bf16x8(dqa + c * 8);
+  }
+}
+
+__global__ __launch_bounds__(256) void mha32_bwd_kv_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ dout, int lddo,
+                                                           const float* __restrict__ P, const float* __restrict__ dS, bf16_t* __restrict__ dk,
+                                                           int lddk, bf16_t* __restrict__ dv, int lddv, int Lq, int Lk, int heads) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int bh = blockIdx.y, b = bh / heads, hd = bh % heads;
+  const int j = blockIdx.x * 4 + wave;
+  if (j >= Lk) return;
+  const float scale = 0.17677669529663687f;
+  float dka[32], dva[32];
+#pragma unroll
+  for (int d = 0; d < 32; ++d) dka[d] = 0.0f, dva[d] = 0.0f;
+  for (int i = lane; i < Lq; i += 64) {
+    const float p = P[((int64_t)bh * Lq + i) * Lk + j], ds = dS[((int64_t)bh * Lq + i) * Lk + j];
+    const bf16_t* qp = q + ((int64_t)b * Lq + i) * ldq + hd * 32;
+    const bf16_t* dp = dout + ((int64_t)b * Lq + i) * lddo + hd * 32;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float qq[8], dd[8];
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(qp + c * 8), qq);
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(dp + c * 8), dd);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dka[c * 8 + e] += ds * qq[e], dva[c * 8 + e] += p * dd[e];
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < 32; ++d) dka[d] = wsum(dka[d]) * scale, dva[d] = wsum(dva[d]);
+  if (lane == 0) {
+    bf16_t* kp = dk + ((int64_t)b * Lk + j) * lddk + hd * 32;
+    bf16_t* vp = dv + ((int64_t)b * Lk + j) * lddv + hd * 32;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      *reinterpret_cast<uint4*>(kp + c * 8) = pack_bf16x8(dka + c * 8);
+      *reinterpret_cast<uint4*>(vp + c * 8) = pack_bf16x8(dva + c * 8);
+    }
+  }
+}
+
+extern "C" size_t fx_mha_bwd_workspace_bytes(int B, int Lq, int Lk, int heads) {
+  if (B <= 0 || Lq <= 0 || Lk <= 0 || heads <= 0) return 0;
+  return (size_t)2 * B * heads * Lq * Lk * sizeof(float);
+}
+
+extern "C" int fx_mha_bwd_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o, int ldo, const void* dout,
+                               int lddo, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int Lq, int Lk, int heads,
+                               void* workspace, size_t workspace_bytes, fx_stream_t stream_) {
+  FX_CHECK_ARG(q && k && v && o && dout && dq && dk && dv && workspace && B > 0 && Lq > 0 && Lk > 0 && heads > 0);
+  if (Lk > 64 * MHA_MAXJ) return FX_ERR_UNSUPPORTED;
+  FX_CHECK_ARG(workspace_bytes >= fx_mha_bwd_workspace_bytes(B, Lq, Lk, heads));
+  FX_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0 && lddk % 8 == 0 && lddv % 8 == 0);
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  float* P = reinterpret_cast<float*>(workspace);
+  float* dS = P + (size_t)B * heads * Lq * Lk;
+  hipLaunchKernelGGL(mha32_bwd_q_kernel, dim3((Lq + 3) / 4, B * heads), dim3(256), 0, stream, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
+                     (const bf16_t*)v, ldv, (const bf16_t*)o, ldo, (const bf16_t*)dout, lddo, (bf16_t*)dq, lddq, P, dS, Lq, Lk, heads);
+  hipLaunchKernelGGL(mha32_bwd_kv_kernel, dim3((Lk + 3) / 4, B * heads), dim3(256), 0, stream, (const bf16_t*)q, ldq, (const bf16_t*)dout, lddo, P,
+                     dS, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, Lq, Lk, heads);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------ gather backward
+// dsrc[b, idx[b,j], :] = dout[b, j, :]  (indices are a top-k result: unique per image; dsrc zeroed by the caller)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const bf16_t* __restrict__ dout, int ldo, const int32_t* __restrict__ idx, int k,
+                                                           bf16_t* __restrict__ dsrc, int lds, int rpb, int B, int C8) {
+  const int64_t total = (int64_t)B * k * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t r = i / C8;
+    const int b = (int)(r / k);
+    *reinterpret_cast<uint4*>(dsrc + ((int64_t)b * rpb + idx[r]) * lds + c8 * 8) = *reinterpret_cast<const uint4*>(dout + r * ldo + c8 * 8);
+  }
+}
+
+extern "C" int fx_scatter_rows_bf16(const void* dout, int ldo, const int32_t* idx, int k, void* dsrc, int lds, int rows_per_batch, int B, int cols,
+                                    fx_stream_t stream_) {
+  FX_CHECK_ARG(dout && idx && dsrc && k > 0 && B > 0 && cols > 0 && cols % 8 == 0 && ldo >= cols && lds >= cols && ldo % 8 == 0 && lds % 8 == 0);
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(ew_grid((int64_t)B * k * (cols / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
+                     (const bf16_t*)dout, ldo, idx, k, (bf16_t*)dsrc, lds, rows_per_batch, B, cols / 8);
+  return fx_launch_status();
+}

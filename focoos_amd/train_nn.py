@@ -59,10 +59,12 @@ class _ConvBnActFn(torch.autograd.Function):
         lib = layer.lib
         layer.sync_packed()
         N, Cc, KH, KW = weight.shape
-        y = _conv_call(lib, x, layer.w_fwd, layer.shift, N, KH, KW, layer.stride, layer.pad, layer.act, residual)
+        fused = layer.act in (None, "relu")
+        z = _conv_call(lib, x, layer.w_fwd, layer.shift, N, KH, KW, layer.stride, layer.pad, layer.act if fused else None, residual)
+        y = z if fused else _act_fwd(lib, z, layer.act)  # SiLU / GELU: the backward needs the pre-activation
         ctx.layer = layer
         ctx.has_res = residual is not None
-        ctx.save_for_backward(x, y)
+        ctx.save_for_backward(x, y if fused else z)
         return y
 
     @staticmethod
@@ -80,8 +82,8 @@ class _ConvBnActFn(torch.autograd.Function):
             check(lib.fx_relu_bwd_bf16(dy.data_ptr(), N, None, 0, y.data_ptr(), N, dz.data_ptr(), N, B * Ho * Wo, N, 1, st), "fx_relu_bwd_bf16")
         elif layer.act is None:
             dz = dy
-        else:  # pragma: no cover
-            raise NotImplementedError(f"backward of activation {layer.act}")
+        else:
+            dz = _act_bwd(lib, dy, y, layer.act)  # `y` holds the saved pre-activation here
         dx = None
         if ctx.needs_input_grad[0]:
             if layer.stride == 1:
@@ -108,32 +110,35 @@ class _Holder(nn.Module):
 class ConvNormLayer(nn.Module):
     """focoos/nn/layers/conv.py:78-98 — conv (no bias) + BatchNorm2d (frozen here) + activation."""
 
-    def __init__(self, lib, cin: int, cout: int, k: int, stride: int = 1, act: Optional[str] = None):
+    def __init__(self, lib, cin: int, cout: int, k: int, stride: int = 1, act: Optional[str] = None, names=("conv", "norm")):
         super().__init__()
         self.lib, self.cin, self.cout, self.k, self.stride, self.act = lib, cin, cout, k, stride, act
         self.pad = (k - 1) // 2
-        self.conv = _Holder()
-        self.conv.weight = nn.Parameter(torch.empty(cout, cin, k, k, dtype=torch.float32))
-        self.norm = _Holder()
-        self.norm.weight = nn.Parameter(torch.ones(cout), requires_grad=False)   # frozen BatchNorm
-        self.norm.bias = nn.Parameter(torch.zeros(cout), requires_grad=False)
-        self.norm.register_buffer("running_mean", torch.zeros(cout))
-        self.norm.register_buffer("running_var", torch.ones(cout))
-        self.norm.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        conv, norm = _Holder(), _Holder()
+        self.add_module(names[0], conv)   # "conv"/"norm" (ConvNormLayer) or "0"/"1" (nn.Sequential(conv, bn) in the encoder)
+        self.add_module(names[1], norm)
+        object.__setattr__(self, "_conv_h", conv)
+        object.__setattr__(self, "_norm_h", norm)
+        conv.weight = nn.Parameter(torch.empty(cout, cin, k, k, dtype=torch.float32))
+        norm.weight = nn.Parameter(torch.ones(cout), requires_grad=False)   # frozen BatchNorm
+        norm.bias = nn.Parameter(torch.zeros(cout), requires_grad=False)
+        norm.register_buffer("running_mean", torch.zeros(cout))
+        norm.register_buffer("running_var", torch.ones(cout))
+        norm.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
         self._packed_version = None
         self.w_fwd = self.w_dgrad = self.scale = self.shift = None
 
     def sync_packed(self):
         """(Re)build the bf16 weight images when the master weight changed (optimizer step, load_state_dict)."""
-        w = self.conv.weight
-        ver = (w._version, self.norm.weight._version, self.norm.running_var._version, w.device)
+        w = self._conv_h.weight
+        ver = (w._version, self._norm_h.weight._version, self._norm_h.running_var._version, w.device)
         if ver == self._packed_version:
             return
         dev = w.device
         N, Cc, k = self.cout, self.cin, self.k
         with torch.no_grad():
-            self.scale = (self.norm.weight.double() / torch.sqrt(self.norm.running_var.double() + BN_EPS)).float().contiguous()
-            shift = (self.norm.bias.double() - self.norm.running_mean.double() * self.scale.double()).float()
+            self.scale = (self._norm_h.weight.double() / torch.sqrt(self._norm_h.running_var.double() + BN_EPS)).float().contiguous()
+            shift = (self._norm_h.bias.double() - self._norm_h.running_mean.double() * self.scale.double()).float()
             Np, Cp = (N + 127) // 128 * 128, (Cc + 127) // 128 * 128
             self.shift = torch.zeros(Np, dtype=torch.float32, device=dev)
             self.shift[:N] = shift
@@ -145,7 +150,7 @@ class ConvNormLayer(nn.Module):
         self._packed_version = ver
 
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-        return _ConvBnActFn.apply(x, self.conv.weight, residual, self)
+        return _ConvBnActFn.apply(x, self._conv_h.weight, residual, self)
 
 
 class _StemFn(torch.autograd.Function):
@@ -197,18 +202,18 @@ class StemConv(ConvNormLayer):
         self.stem_w = self.stem_b = None
 
     def sync_packed(self):
-        w = self.conv.weight
+        w = self._conv_h.weight
         ver = (w._version, w.device)
         if ver == self._packed_version:
             return
         with torch.no_grad():
-            self.scale = (self.norm.weight.double() / torch.sqrt(self.norm.running_var.double() + BN_EPS)).float().contiguous()
-            self.stem_b = (self.norm.bias.double() - self.norm.running_mean.double() * self.scale.double()).float().contiguous()
+            self.scale = (self._norm_h.weight.double() / torch.sqrt(self._norm_h.running_var.double() + BN_EPS)).float().contiguous()
+            self.stem_b = (self._norm_h.bias.double() - self._norm_h.running_mean.double() * self.scale.double()).float().contiguous()
             self.stem_w = (w * self.scale.view(-1, 1, 1, 1)).permute(2, 3, 1, 0).contiguous()  # [kh][kw][c][n] fp32 (tiny: 864 values)
         self._packed_version = ver
 
     def forward(self, images: torch.Tensor) -> torch.Tensor:  # type: ignore[override]
-        return _StemFn.apply(images, self.conv.weight, self)
+        return _StemFn.apply(images, self._conv_h.weight, self)
 
 
 class _PoolFn(torch.autograd.Function):
@@ -317,3 +322,384 @@ class ResNetVd(nn.Module):
 
     def trainable_parameters(self) -> List[nn.Parameter]:
         return [p for p in self.parameters() if p.requires_grad]
+
+
+# ================================================================================================ token-space layers
+def _rows(t: torch.Tensor) -> int:
+    return t.numel() // t.shape[-1]
+
+
+def _act_fwd(lib, z, act):
+    y = torch.empty_like(z)
+    Cc = z.shape[-1]
+    check(lib.fx_act_fwd_bf16(z.data_ptr(), Cc, y.data_ptr(), Cc, _rows(z), Cc, FX_ACT[act], _stream(z.device)), "fx_act_fwd_bf16")
+    return y
+
+
+def _act_bwd(lib, dy, z, act):
+    dz = torch.empty_like(z)
+    Cc = z.shape[-1]
+    check(lib.fx_act_bwd_bf16(dy.data_ptr(), Cc, z.data_ptr(), Cc, dz.data_ptr(), Cc, _rows(z), Cc, FX_ACT[act], _stream(z.device)), "fx_act_bwd_bf16")
+    return dz
+
+
+def _rup(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+class _PackedLinear:
+    """bf16 images of a [N, K] fp32 weight (row range r0:r1 of a parameter): forward layout and its transpose.  The kernels
+    want K % 32 == 0 and N % 8 == 0; other shapes (bbox heads N = 4, query-pos head K = 4, score heads N = 365) are
+    zero-padded here and sliced by the caller."""
+
+    def __init__(self):
+        self.ver = None
+        self.w_fwd = self.w_t = self.bias = None
+        self.Np = self.Kp = 0
+
+    def sync(self, lib, weight, bias, r0, r1):
+        ver = (weight._version, None if bias is None else bias._version, weight.device, r0, r1)
+        if ver == self.ver:
+            return
+        dev = weight.device
+        N, K = r1 - r0, weight.shape[1]
+        Np, Kp = _rup(N, 32), _rup(K, 32)  # both serve as the reduction dim of one of the two GEMMs (C % 32 == 0)
+        self.Np, self.Kp = Np, Kp
+        with torch.no_grad():
+            w = weight[r0:r1]
+            if Np != N or Kp != K:
+                wp = torch.zeros(Np, Kp, dtype=torch.float32, device=dev)
+                wp[:N, :K] = w
+                w = wp
+            w = w.contiguous()
+            if self.w_fwd is None or self.w_fwd.device != dev:
+                self.w_fwd = torch.zeros(_rup(Np, 128), 1, 1, Kp, dtype=torch.bfloat16, device=dev)
+                self.w_t = torch.zeros(_rup(Kp, 128), 1, 1, Np, dtype=torch.bfloat16, device=dev)
+            check(lib.fx_pack_conv_weights_f32(w.data_ptr(), None, self.w_fwd.data_ptr(), self.w_t.data_ptr(), Np, Kp, 1, 1, _stream(dev)),
+                  "fx_pack_conv_weights_f32")
+            self.bias = torch.zeros(_rup(Np, 128), dtype=torch.float32, device=dev)
+            if bias is not None:
+                self.bias[:N] = bias[r0:r1]
+        self.ver = ver
+
+
+def _pad_last(t: torch.Tensor, n: int) -> torch.Tensor:
+    if t.shape[-1] == n:
+        return t.contiguous()
+    out = torch.zeros(*t.shape[:-1], n, dtype=t.dtype, device=t.device)
+    out[..., : t.shape[-1]] = t
+    return out
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = act(x @ W[r0:r1]^T + b[r0:r1] [+ residual]) on [..., K] bf16 rows; W, b fp32 master parameters."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, pack: _PackedLinear, lib, r0, r1, act):
+        pack.sync(lib, weight, bias, r0, r1)
+        N, K = r1 - r0, weight.shape[1]
+        Np, Kp = pack.Np, pack.Kp
+        x2 = _pad_last(x.reshape(1, 1, -1, K), Kp)
+        res2 = _pad_last(residual.reshape(1, 1, -1, N), Np) if residual is not None else None
+        fused = act in (None, "relu")
+        z = _conv_call(lib, x2, pack.w_fwd, pack.bias, Np, 1, 1, 1, 0, act if fused else None, res2)
+        y = z if fused else _act_fwd(lib, z, act)
+        ctx.lib, ctx.pack, ctx.rng, ctx.act, ctx.has_res, ctx.has_bias = lib, pack, (r0, r1), act, residual is not None, bias is not None
+        ctx.wshape, ctx.K = tuple(weight.shape), K
+        ctx.save_for_backward(x2, y if fused else z)
+        out = y.reshape(*x.shape[:-1], Np)
+        return out if Np == N else out[..., :N].contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib, pack, (r0, r1), act = ctx.lib, ctx.pack, ctx.rng, ctx.act
+        x2, saved = ctx.saved_tensors
+        dev = x2.device
+        N, K, Np, Kp = r1 - r0, ctx.K, pack.Np, pack.Kp
+        R = x2.shape[2]
+        st = _stream(dev)
+        dy2 = _pad_last(dy.reshape(1, 1, R, N), Np)
+        if act == "relu":
+            dz = torch.empty_like(saved)
+            check(lib.fx_relu_bwd_bf16(dy2.data_ptr(), Np, None, 0, saved.data_ptr(), Np, dz.data_ptr(), Np, R, Np, 1, st), "fx_relu_bwd_bf16")
+        elif act is None:
+            dz = dy2
+        else:
+            dz = _act_bwd(lib, dy2, saved, act)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dxp = _conv_call(lib, dz, pack.w_t, None, Kp, 1, 1, 1, 0, None, None).reshape(dy.shape[:-1] + (Kp,))
+            dx = dxp if Kp == K else dxp[..., :K].contiguous()
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros(ctx.wshape, dtype=torch.float32, device=dev)
+            direct = Np == N and Kp == K
+            tgt = dw[r0:r1] if direct else torch.zeros(Np, Kp, dtype=torch.float32, device=dev)
+            check(lib.fx_conv2d_wgrad_nhwc_bf16(x2.data_ptr(), Kp, dz.data_ptr(), Np, tgt.data_ptr(), 1, 1, R, Kp, 1, R, Np, 1, 1, 1, 0, st),
+                  "fx_conv2d_wgrad_nhwc_bf16")
+            if not direct:
+                dw[r0:r1] = tgt[:N, :K]
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.zeros(ctx.wshape[0], dtype=torch.float32, device=dev)
+            tgt = db[r0:r1] if Np == N else torch.zeros(Np, dtype=torch.float32, device=dev)
+            check(lib.fx_colsum_bf16(dz.data_ptr(), Np, tgt.data_ptr(), R, Np, st), "fx_colsum_bf16")
+            if Np != N:
+                db[r0:r1] = tgt[:N]
+        dres = None
+        if ctx.has_res:
+            dres = (dz if Np == N else dz[..., :N].contiguous()).reshape(dy.shape)
+        return dx, dw, db, dres, None, None, None, None, None
+
+
+class Linear(nn.Module):
+    """nn.Linear with the reference's parameter names; forward/backward on the MFMA conv + wgrad kernels."""
+
+    def __init__(self, lib, cin, cout, act: Optional[str] = None, bias: bool = True):
+        super().__init__()
+        self.lib, self.act = lib, act
+        self.weight = nn.Parameter(torch.empty(cout, cin))
+        self.bias = nn.Parameter(torch.zeros(cout)) if bias else None
+        self._pack = _PackedLinear()
+
+    def forward(self, x, residual=None, act="__default__"):
+        a = self.act if act == "__default__" else act
+        return _LinearFn.apply(x, self.weight, self.bias, residual, self._pack, self.lib, 0, self.weight.shape[0], a)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, lib):
+        R = _rows(x)
+        y = torch.empty_like(x)
+        check(lib.fx_layernorm_bf16(x.data_ptr(), 256, None, 0, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), 256, R, 256, _stream(x.device)),
+              "fx_layernorm_bf16")
+        ctx.lib = lib
+        ctx.save_for_backward(x, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        lib = ctx.lib
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dg = torch.zeros(256, dtype=torch.float32, device=x.device)
+        db = torch.zeros(256, dtype=torch.float32, device=x.device)
+        check(lib.fx_layernorm_bwd_bf16(dy.data_ptr(), 256, x.data_ptr(), 256, gamma.data_ptr(), dx.data_ptr(), 256, dg.data_ptr(), db.data_ptr(),
+                                        _rows(x), 256, _stream(x.device)), "fx_layernorm_bwd_bf16")
+        return dx, dg, db, None
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, lib, c=256):
+        super().__init__()
+        assert c == 256
+        self.lib = lib
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+    def forward(self, x):
+        return _LayerNormFn.apply(x.contiguous(), self.weight, self.bias, self.lib)
+
+
+class _MHACoreFn(torch.autograd.Function):
+    """softmax(q k^T / sqrt(32)) v per head on projected [B, L, 256] bf16 tensors (fx_mha_bf16 / fx_mha_bwd_bf16)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, lib):
+        B, Lq, Cc = q.shape
+        Lk = k.shape[1]
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        o = torch.empty_like(q)
+        check(lib.fx_mha_bf16(q.data_ptr(), Cc, k.data_ptr(), Cc, v.data_ptr(), Cc, o.data_ptr(), Cc, B, Lq, Lk, Cc // 32, _stream(q.device)), "fx_mha_bf16")
+        ctx.lib = lib
+        ctx.save_for_backward(q, k, v, o)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o = ctx.saved_tensors
+        lib = ctx.lib
+        B, Lq, Cc = q.shape
+        Lk, H = k.shape[1], Cc // 32
+        do = do.contiguous()
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        nb = lib.fx_mha_bwd_workspace_bytes(B, Lq, Lk, H)
+        ws = torch.empty(nb, dtype=torch.uint8, device=q.device)
+        check(lib.fx_mha_bwd_bf16(q.data_ptr(), Cc, k.data_ptr(), Cc, v.data_ptr(), Cc, o.data_ptr(), Cc, do.data_ptr(), Cc, dq.data_ptr(), Cc,
+                                  dk.data_ptr(), Cc, dv.data_ptr(), Cc, B, Lq, Lk, H, ws.data_ptr(), nb, _stream(q.device)), "fx_mha_bwd_bf16")
+        return dq, dk, dv, None
+
+
+class MultiheadAttention(nn.Module):
+    """nn.MultiheadAttention(256, 8, batch_first=True) with the reference's parameter names (in_proj_weight, in_proj_bias,
+    out_proj.weight/bias); q = k inputs share one projection GEMM."""
+
+    def __init__(self, lib, c=256):
+        super().__init__()
+        self.lib, self.c = lib, c
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * c, c))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * c))
+        self.out_proj = Linear(lib, c, c)
+        self._pq, self._pk, self._pv, self._pqk = _PackedLinear(), _PackedLinear(), _PackedLinear(), _PackedLinear()
+
+    def forward(self, q_in, k_in, v_in, residual=None):
+        c, lib, W, b = self.c, self.lib, self.in_proj_weight, self.in_proj_bias
+        if q_in is k_in:
+            qk = _LinearFn.apply(q_in, W, b, None, self._pqk, lib, 0, 2 * c, None)
+            q, k = qk[..., :c], qk[..., c:]
+        else:
+            q = _LinearFn.apply(q_in, W, b, None, self._pq, lib, 0, c, None)
+            k = _LinearFn.apply(k_in, W, b, None, self._pk, lib, c, 2 * c, None)
+        v = _LinearFn.apply(v_in, W, b, None, self._pv, lib, 2 * c, 3 * c, None)
+        o = _MHACoreFn.apply(q, k, v, lib)
+        return self.out_proj(o, residual=residual)
+
+
+class _ResizeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo, lib):
+        B, H, W_, Cc = x.shape
+        x = x.contiguous()
+        y = torch.empty(B, Ho, Wo, Cc, dtype=torch.bfloat16, device=x.device)
+        check(lib.fx_resize_bilinear_nhwc_bf16(x.data_ptr(), Cc, y.data_ptr(), Cc, B, H, W_, Cc, Ho, Wo, _stream(x.device)), "fx_resize_bilinear_nhwc_bf16")
+        ctx.lib, ctx.shape = lib, (B, H, W_, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = ctx.lib
+        B, H, W_, Cc = ctx.shape
+        dy = dy.contiguous()
+        acc = torch.zeros(B, H, W_, Cc, dtype=torch.float32, device=dy.device)
+        check(lib.fx_resize_bilinear_bwd_nhwc(dy.data_ptr(), Cc, acc.data_ptr(), B, H, W_, Cc, dy.shape[1], dy.shape[2], _stream(dy.device)),
+              "fx_resize_bilinear_bwd_nhwc")
+        dx = torch.empty(B, H, W_, Cc, dtype=torch.bfloat16, device=dy.device)
+        check(lib.fx_cast_f32_bf16(acc.data_ptr(), dx.data_ptr(), acc.numel(), _stream(dy.device)), "fx_cast_f32_bf16")
+        return dx, None, None, None
+
+
+class _AddFn(torch.autograd.Function):
+    """x + y (same shape, or y broadcast over the leading rows: positional embeddings) through fx_add_rows_bf16."""
+
+    @staticmethod
+    def forward(ctx, x, y, lib):
+        x, y = x.contiguous(), y.contiguous()
+        Cc = x.shape[-1]
+        out = torch.empty_like(x)
+        check(lib.fx_add_rows_bf16(x.data_ptr(), Cc, y.data_ptr(), Cc, _rows(y), out.data_ptr(), Cc, _rows(x), Cc, _stream(x.device)), "fx_add_rows_bf16")
+        ctx.same = y.shape == x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, (d if ctx.same else None), None
+
+
+# ================================================================================================ hybrid encoder (RT-DETR)
+def _pos_embed_sine(h: int, w: int, npf: int, temperature: float = 10000.0) -> torch.Tensor:
+    """AIFI sine position embedding [h*w, 2*npf] = [y_sin | y_cos | x_sin | x_cos] (fai_detr/modelling.py:148-179)."""
+    ys = torch.arange(h, dtype=torch.float32).view(h, 1).expand(h, w)
+    xs = torch.arange(w, dtype=torch.float32).view(1, w).expand(h, w)
+    i = torch.arange(npf, dtype=torch.float32)
+    dim_t = temperature ** (2 * torch.div(i, 2, rounding_mode="floor") / npf)
+    px, py = xs[..., None] / dim_t, ys[..., None] / dim_t
+    return torch.cat([py[..., 0::2].sin(), py[..., 1::2].cos(), px[..., 0::2].sin(), px[..., 1::2].cos()], dim=-1).reshape(h * w, 2 * npf)
+
+
+class TransformerEncoderLayer(nn.Module):
+    """Post-norm encoder layer with GELU FFN (focoos/nn/layers/transformer.py:553-601)."""
+
+    def __init__(self, lib, c=256, ffn=1024):
+        super().__init__()
+        self.lib = lib
+        self.self_attn = MultiheadAttention(lib, c)
+        self.linear1 = Linear(lib, c, ffn, act="gelu")
+        self.linear2 = Linear(lib, ffn, c)
+        self.norm1 = LayerNorm(lib, c)
+        self.norm2 = LayerNorm(lib, c)
+
+    def forward(self, src, pos):
+        qk = _AddFn.apply(src, pos, self.lib)
+        src = self.norm1(self.self_attn(qk, qk, src, residual=src))
+        return self.norm2(self.linear2(self.linear1(src), residual=src))
+
+
+class RepVggBlock(nn.Module):
+    """Unfused training form: silu(conv3x3+bn(x) + conv1x1+bn(x)) (fai_detr/modelling.py:30-45)."""
+
+    def __init__(self, lib, c):
+        super().__init__()
+        self.conv1 = ConvNormLayer(lib, c, c, 3, 1, None)
+        self.conv2 = ConvNormLayer(lib, c, c, 1, 1, "silu")  # its epilogue adds conv1's branch, then SiLU
+
+    def forward(self, x):
+        return self.conv2(x, residual=self.conv1(x))
+
+
+class CSPRepLayer(nn.Module):
+    """fai_detr/modelling.py:84-107 (expansion 1.0: conv3 = Identity)."""
+
+    def __init__(self, lib, cin, cout, n=3):
+        super().__init__()
+        self.lib = lib
+        self.conv1 = ConvNormLayer(lib, cin, cout, 1, 1, "silu")
+        self.conv2 = ConvNormLayer(lib, cin, cout, 1, 1, "silu")
+        self.bottlenecks = nn.Sequential(*[RepVggBlock(lib, cout) for _ in range(n)])
+
+    def forward(self, x):
+        return _AddFn.apply(self.bottlenecks(self.conv1(x)), self.conv2(x), self.lib)
+
+
+class HybridEncoder(nn.Module):
+    """Encoder.forward (fai_detr/modelling.py:297-347) as HIP autograd nodes; parameter names = ``pixel_decoder.*`` minus the
+    backbone.  Channel concats use torch.cat (a copy; the inference engine writes channel slices in place instead)."""
+
+    def __init__(self, lib, in_channels=(512, 1024, 2048), c=256, ffn=1024, n_enc=1):
+        super().__init__()
+        self.lib, self.c = lib, c
+        self.input_proj = nn.ModuleList([ConvNormLayer(lib, ci, c, 1, 1, None, names=("0", "1")) for ci in in_channels])
+        self.encoder = nn.ModuleList([_Layers([TransformerEncoderLayer(lib, c, ffn) for _ in range(n_enc)])])
+        self.lateral_convs = nn.ModuleList([ConvNormLayer(lib, c, c, 1, 1, "silu") for _ in range(2)])
+        self.fpn_blocks = nn.ModuleList([CSPRepLayer(lib, 2 * c, c) for _ in range(2)])
+        self.downsample_convs = nn.ModuleList([ConvNormLayer(lib, c, c, 3, 1, "silu") for _ in range(2)])
+        self.pan_blocks = nn.ModuleList([CSPRepLayer(lib, 2 * c, c) for _ in range(2)])
+        self.mask_features = _Holder()  # dead in RT-DETR's forward (fai_detr/modelling.py:347); kept for checkpoint compatibility
+        self.mask_features.weight = nn.Parameter(torch.zeros(c, c, 3, 3), requires_grad=False)
+        self.mask_features.bias = nn.Parameter(torch.zeros(c), requires_grad=False)
+        self._pos = {}
+
+    def _pos_for(self, h, w, dev):
+        key = (h, w, dev)
+        if key not in self._pos:
+            self._pos[key] = _pos_embed_sine(h, w, self.c // 2).to(device=dev, dtype=torch.bfloat16).contiguous()
+        return self._pos[key]
+
+    def forward(self, feats: List[torch.Tensor]) -> List[torch.Tensor]:
+        lib = self.lib
+        proj = [p(f) for p, f in zip(self.input_proj, feats)]
+        B, h, w, c = proj[2].shape
+        src = proj[2].reshape(B, h * w, c)
+        pos = self._pos_for(h, w, src.device)
+        for layer in self.encoder[0].layers:
+            src = layer(src, pos)
+        proj[2] = src.reshape(B, h, w, c)
+        inner = [proj[2]]
+        for idx in (2, 1):
+            high = self.lateral_convs[2 - idx](inner[0])
+            inner[0] = high
+            low = proj[idx - 1]
+            up = _ResizeFn.apply(high, low.shape[1], low.shape[2], lib)
+            inner.insert(0, self.fpn_blocks[2 - idx](torch.cat([up, low], dim=-1)))
+        outs = [inner[0]]
+        for idx in range(2):
+            nxt = inner[idx + 1]
+            down = self.downsample_convs[idx](_ResizeFn.apply(outs[-1], nxt.shape[1], nxt.shape[2], lib))
+            outs.append(self.pan_blocks[idx](torch.cat([down, nxt], dim=-1)))
+        return outs[::-1]  # [stride 32, 16, 8]
+
+
+class _Layers(nn.Module):
+    def __init__(self, layers):
+        super().__init__()
+        self.layers = nn.ModuleList(layers)

@@ -283,6 +283,34 @@ int fx_maxpool3x3s2_bwd_nhwc_bf16(const void* x, int ldx, const void* dy, int ld
 /* (img - mean) * inv_std as bf16 NHWC with the 3 channels padded to 8: the stem conv's input for its weight gradient. */
 int fx_normalize_pad8(const void* img, int is_f32, const float* mean, const float* inv_std, void* out, int64_t pixels, fx_stream_t stream);
 
+/* ---- training path, token-space layers (A17): correctness-first fp32-math kernels ----------------------------------
+ * Activation on a saved pre-activation z (FX_ACT_RELU/SILU/GELU): y = act(z); dz = dy * act'(z). */
+int fx_act_fwd_bf16(const void* z, int ldz, void* y, int ldy, int64_t rows, int cols, int act, fx_stream_t stream);
+int fx_act_bwd_bf16(const void* dy, int lddy, const void* z, int ldz, void* dz, int lddz, int64_t rows, int cols, int act, fx_stream_t stream);
+
+/* Bias gradient: out[c] += sum_r x[r][c] (fp32 atomics; caller zeroes out). */
+int fx_colsum_bf16(const void* x, int ldx, float* out, int64_t rows, int cols, fx_stream_t stream);
+
+/* Backward of fx_layernorm_bf16 (no residual): dx; dgamma/dbeta (optional) accumulate with fp32 atomics.  cols == 256. */
+int fx_layernorm_bwd_bf16(const void* dy, int lddy, const void* x, int ldx, const float* gamma, void* dx, int lddx, float* dgamma, float* dbeta,
+                          int rows, int cols, fx_stream_t stream);
+
+/* Backward of fx_resize_bilinear_nhwc_bf16: scatter-adds dy [B,Ho,Wo,C] into the fp32 accumulator dx_f32 [B,H,W,C] (zeroed by
+ * the caller); fx_cast_f32_bf16 converts n (multiple of 8) floats to bf16. */
+int fx_resize_bilinear_bwd_nhwc(const void* dy, int lddy, float* dx_f32, int B, int H, int W, int C, int Ho, int Wo, fx_stream_t stream);
+int fx_cast_f32_bf16(const float* x, void* y, int64_t n, fx_stream_t stream);
+
+/* Backward of fx_mha_bf16 (head_dim 32, Lk <= 512): dq, dk, dv from q, k, v, the forward output o and dout.
+ * workspace: fx_mha_bwd_workspace_bytes() (P and dS, fp32 [B*heads, Lq, Lk] each). */
+size_t fx_mha_bwd_workspace_bytes(int B, int Lq, int Lk, int heads);
+int fx_mha_bwd_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o, int ldo, const void* dout, int lddo,
+                    void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int Lq, int Lk, int heads, void* workspace,
+                    size_t workspace_bytes, fx_stream_t stream);
+
+/* Backward of fx_gather_rows_bf16 for unique indices (top-k): dsrc[b, idx[b,j], :] = dout[b,j,:]; dsrc zeroed by the caller. */
+int fx_scatter_rows_bf16(const void* dout, int ldo, const int32_t* idx, int k, void* dsrc, int lds, int rows_per_batch, int B, int cols,
+                         fx_stream_t stream);
+
 /* Fork: `side` waits for everything queued on `main` so far; join: `main` waits for `side`.  Valid inside
  * fx_graph_begin/fx_graph_end (the side stream joins the capture), which turns two launch sequences into independent
  * branches of one hipGraph - used to run the two half-batches of a step concurrently. */
