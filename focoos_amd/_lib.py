@@ -85,6 +85,7 @@ SIGNATURES = {
     "fx_mha_bwd_workspace_bytes": [_i, _i, _i, _i],
     "fx_mha_bwd_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, C.c_size_t, _vp],
     "fx_scatter_rows_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
+    "fx_vfl_loss_bf16": [_vp, _i, _vp, _vp, _f, _f, _f, _vp, _vp, _i, C.c_int64, _i, _vp],
     "fx_stream_fork": [_vp, _vp],
     "fx_stream_join": [_vp, _vp],
     "fx_graph_begin": [_vp],

@@ -402,3 +402,40 @@ extern "C" int fx_scatter_rows_bf16(const void* dout, int ldo, const int32_t* id
                      (const bf16_t*)dout, ldo, idx, k, (bf16_t*)dsrc, lds, rows_per_batch, B, cols / 8);
   return fx_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------ VFL loss forward + gradient
+// SetCriterion.loss_labels_vfl (fai_detr/modelling.py:464-497) fused with its gradient:
+//   t[r][c] = score[r] if c == cls[r] else 0;  w = alpha * sigmoid(x)^gamma * (1 - onehot) + t   (sigmoid detached)
+//   loss = sum_{r,c} w * BCEwithLogits(x, t) * scale,   dx = w * (sigmoid(x) - t) * scale        (scale = weight / num_boxes)
+// logits bf16 [rows][ld]; cls i32 [rows] (K = no object); loss_out fp32 scalar accumulated with an atomic per block.
+__global__ __launch_bounds__(256) void vfl_loss_kernel(const bf16_t* __restrict__ logits, int ld, const int32_t* __restrict__ cls,
+                                                       const float* __restrict__ score, float alpha, float gamma, float scale,
+                                                       float* __restrict__ loss_out, bf16_t* __restrict__ dlogits, int lddl, int64_t rows, int K) {
+  __shared__ float red[4];
+  const int64_t total = rows * K;
+  float acc = 0.0f;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % K);
+    const int64_t r = i / K;
+    const float x = bf16_to_f32(logits[r * ld + c]);
+    const bool pos = cls[r] == c;
+    const float t = pos ? score[r] : 0.0f;
+    const float p = 1.0f / (1.0f + __expf(-x));
+    const float w = pos ? t : alpha * __powf(p, gamma);
+    const float bce = fmaxf(x, 0.0f) - x * t + __logf(1.0f + __expf(-fabsf(x)));
+    acc += w * bce;
+    if (dlogits) dlogits[r * lddl + c] = f32_to_bf16(w * (p - t) * scale);
+  }
+  acc = wsum(acc);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) unsafeAtomicAdd(loss_out, (red[0] + red[1] + red[2] + red[3]) * scale);
+}
+
+extern "C" int fx_vfl_loss_bf16(const void* logits, int ld, const int32_t* cls, const float* score, float alpha, float gamma, float scale,
+                                float* loss_out, void* dlogits, int lddl, int64_t rows, int K, fx_stream_t stream_) {
+  FX_CHECK_ARG(logits && cls && score && loss_out && rows > 0 && K > 0 && ld >= K && (!dlogits || lddl >= K));
+  hipLaunchKernelGGL(vfl_loss_kernel, dim3(ew_grid(rows * K / 4 + 1)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)logits, ld,
+                     cls, score, alpha, gamma, scale, loss_out, (bf16_t*)dlogits, lddl, rows, K);
+  return fx_launch_status();
+}

@@ -1,0 +1,292 @@
+"""RT-DETR as a trainable HIP autograd graph (BASELINE config 4 minus the batch-statistics BatchNorm):
+backbone + hybrid encoder (``train_nn``) + ``TransformerPredictor`` in training mode + the set criterion, i.e. what
+``FAIDetr.forward(images, targets)`` computes under ``model.train()`` (fai_detr/modelling.py:1344-1358 with
+``TransformerPredictor.forward`` :1234-1263, ``TransformerDecoder.forward`` :969-1020, ``SetCriterion.forward`` :553-612).
+
+Kernels: every GEMM / conv / attention / normalisation / deformable sampling / VFL loss, forward and backward, is a
+libfocoos_amd.so call.  PyTorch supplies the autograd tape and a handful of *glue* ops on small tensors, listed here so that
+nothing hides: ``torch.cat`` of the three memory levels, the 0/1 valid-mask multiply, ``softmax`` over the 12 sampling
+weights, sampling-location / sigmoid / inverse-sigmoid arithmetic on [B,300,4], ``gather`` of the encoder top-k rows,
+max/top-k index selection (no gradient), and the L1 / GIoU losses on the <= sum(T) matched box pairs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import check
+from .criterion import BoxHungarianMatcher, _Targets
+from .train import ms_deform_attn_core
+from .train_nn import (ConvNormLayer, HybridEncoder, LayerNorm, Linear, MultiheadAttention, ResNetVd, _AddFn, _Layers, _stream)
+
+
+class MLP(nn.Module):
+    """focoos/nn/layers/base.py:31-61 (ReLU between layers)."""
+
+    def __init__(self, lib, cin, hidden, cout, n):
+        super().__init__()
+        dims = [cin] + [hidden] * (n - 1) + [cout]
+        self.layers = nn.ModuleList([Linear(lib, dims[i], dims[i + 1], act="relu" if i < n - 1 else None) for i in range(n)])
+
+    def forward(self, x):
+        for l in self.layers:
+            x = l(x)
+        return x
+
+
+def inverse_sigmoid(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    x = x.clip(min=0.0, max=1.0)
+    return torch.log(x.clip(min=eps) / (1 - x).clip(min=eps))
+
+
+class MSDeformableAttention(nn.Module):
+    """fai_detr/modelling.py:760-884 (4-d reference branch); the sampling core is fx_msda_f32_fwd/bwd."""
+
+    def __init__(self, lib, c=256, heads=8, levels=3, points=4):
+        super().__init__()
+        self.c, self.h, self.l, self.p = c, heads, levels, points
+        self.sampling_offsets = Linear(lib, c, heads * levels * points * 2)
+        self.attention_weights = Linear(lib, c, heads * levels * points)
+        self.value_proj = Linear(lib, c, c)
+        self.output_proj = Linear(lib, c, c)
+
+    def forward(self, query, ref_points, memory, shapes, residual):
+        B, Q, _ = query.shape
+        S = memory.shape[1]
+        value = self.value_proj(memory).view(B, S, self.h, self.c // self.h)
+        off = self.sampling_offsets(query).float().view(B, Q, self.h, self.l, self.p, 2)
+        aw = torch.softmax(self.attention_weights(query).float().view(B, Q, self.h, self.l * self.p), -1).view(B, Q, self.h, self.l, self.p)
+        loc = ref_points[:, :, None, :, None, :2] + off / self.p * ref_points[:, :, None, :, None, 2:] * 0.5
+        out = ms_deform_attn_core(value, shapes, loc, aw)
+        return self.output_proj(out.to(torch.bfloat16), residual=residual)
+
+
+class TransformerDecoderLayer(nn.Module):
+    """fai_detr/modelling.py:887-958."""
+
+    def __init__(self, lib, c=256, ffn=1024):
+        super().__init__()
+        self.lib = lib
+        self.self_attn = MultiheadAttention(lib, c)
+        self.norm1 = LayerNorm(lib, c)
+        self.cross_attn = MSDeformableAttention(lib, c)
+        self.norm2 = LayerNorm(lib, c)
+        self.linear1 = Linear(lib, c, ffn, act="relu")
+        self.linear2 = Linear(lib, ffn, c)
+        self.norm3 = LayerNorm(lib, c)
+
+    def forward(self, tgt, ref_input, memory, shapes, qpos):
+        qk = _AddFn.apply(tgt, qpos, self.lib)
+        tgt = self.norm1(self.self_attn(qk, qk, tgt, residual=tgt))
+        tgt = self.norm2(self.cross_attn(_AddFn.apply(tgt, qpos, self.lib), ref_input, memory, shapes, residual=tgt))
+        return self.norm3(self.linear2(self.linear1(tgt), residual=tgt))
+
+
+class _Seq2(nn.Module):
+    """nn.Sequential(Linear, LayerNorm) with keys ``0`` / ``1`` (enc_output)."""
+
+    def __init__(self, a, b):
+        super().__init__()
+        self.add_module("0", a)
+        self.add_module("1", b)
+        object.__setattr__(self, "_a", a)
+        object.__setattr__(self, "_b", b)
+
+    def forward(self, x):
+        return self._b(self._a(x))
+
+
+class TransformerPredictor(nn.Module):
+    """fai_detr/modelling.py:1023-1263, training branch (all decoder layers + the encoder top-k set are supervised)."""
+
+    def __init__(self, lib, nc: int, c=256, nq=300, nl=6, ffn=1024):
+        super().__init__()
+        self.lib, self.nc, self.c, self.nq, self.nl = lib, nc, c, nq, nl
+        self.input_proj = nn.ModuleList([ConvNormLayer(lib, c, c, 1, 1, None) for _ in range(3)])
+        self.decoder = _Layers([TransformerDecoderLayer(lib, c, ffn) for _ in range(nl)])
+        self.query_pos_head = MLP(lib, 4, 2 * c, c, 2)
+        self.enc_output = _Seq2(Linear(lib, c, c), LayerNorm(lib, c))
+        self.enc_score_classifier = Linear(lib, c, nc)
+        self.enc_bbox_classifier = MLP(lib, c, c, 4, 3)
+        self.dec_score_classifier = nn.ModuleList([Linear(lib, c, nc) for _ in range(nl)])
+        self.dec_bbox_classifier = nn.ModuleList([MLP(lib, c, c, 4, 3) for _ in range(nl)])
+        self._anchor_cache = {}
+
+    def _anchors(self, shapes, dev, grid_size=0.05, eps=1e-2):
+        key = (tuple(shapes), dev)
+        if key not in self._anchor_cache:
+            out = []
+            for lvl, (h, w) in enumerate(shapes):
+                gy, gx = torch.meshgrid(torch.arange(h, dtype=torch.float32), torch.arange(w, dtype=torch.float32), indexing="ij")
+                xy = (torch.stack([gx, gy], -1) + 0.5) / torch.tensor([w, h], dtype=torch.float32)
+                wh = torch.ones_like(xy) * grid_size * (2.0 ** (2 - lvl))
+                out.append(torch.cat([xy, wh], -1).reshape(h * w, 4))
+            a = torch.cat(out, 0)
+            valid = ((a > eps) & (a < 1 - eps)).all(-1, keepdim=True)
+            a = torch.where(valid, torch.log(a / (1 - a)), torch.zeros_like(a))
+            self._anchor_cache[key] = (a.to(dev), valid.to(dev))
+        return self._anchor_cache[key]
+
+    def forward(self, feats: List[torch.Tensor], forced_topk: Optional[torch.Tensor] = None):
+        B = feats[0].shape[0]
+        proj = [p(f) for p, f in zip(self.input_proj, feats)]
+        shapes = [(t.shape[1], t.shape[2]) for t in proj]
+        memory = torch.cat([t.reshape(B, -1, self.c) for t in proj], 1)  # [B, S, 256]
+        anchors, valid = self._anchors(shapes, memory.device)
+        mem_v = memory * valid.to(memory.dtype)
+        output_memory = self.enc_output(mem_v)
+        enc_class = self.enc_score_classifier(output_memory)                    # [B, S, nc] bf16
+        enc_coord_unact = self.enc_bbox_classifier(output_memory).float() + anchors
+        with torch.no_grad():
+            topk_ind = torch.topk(enc_class.float().max(-1).values, self.nq, dim=1).indices if forced_topk is None else forced_topk
+        ref_unact = enc_coord_unact.gather(1, topk_ind.unsqueeze(-1).expand(-1, -1, 4))
+        enc_topk_bboxes = torch.sigmoid(ref_unact)
+        enc_topk_logits = enc_class.gather(1, topk_ind.unsqueeze(-1).expand(-1, -1, self.nc))
+        target = output_memory.gather(1, topk_ind.unsqueeze(-1).expand(-1, -1, self.c)).detach()
+        out = target
+        ref_detach = torch.sigmoid(ref_unact.detach())
+        ref = ref_detach
+        logits, boxes = [], []
+        for i, layer in enumerate(self.decoder.layers):
+            qpos = self.query_pos_head(ref_detach.to(torch.bfloat16))
+            out = layer(out, ref_detach.unsqueeze(2), memory, shapes, qpos)
+            delta = self.dec_bbox_classifier[i](out).float()
+            inter = torch.sigmoid(delta + inverse_sigmoid(ref_detach))
+            logits.append(self.dec_score_classifier[i](out))
+            boxes.append(inter if i == 0 else torch.sigmoid(delta + inverse_sigmoid(ref)))
+            ref, ref_detach = inter, inter.detach()
+        return {"pred_logits": logits[-1], "pred_boxes": boxes[-1],
+                "aux_outputs": [{"pred_logits": a, "pred_boxes": b} for a, b in zip(logits[:-1], boxes[:-1])]
+                + [{"pred_logits": enc_topk_logits, "pred_boxes": enc_topk_bboxes}], "topk_ind": topk_ind}
+
+
+# ------------------------------------------------------------------------------------------------ differentiable criterion
+class _VFLFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, cls, score, alpha, gamma, scale):
+        lib = _lib.load()
+        B, Q, K = logits.shape
+        lg = logits.contiguous()
+        loss = torch.zeros(1, dtype=torch.float32, device=lg.device)
+        dl = torch.empty_like(lg)
+        check(lib.fx_vfl_loss_bf16(lg.data_ptr(), K, cls.data_ptr(), score.data_ptr(), float(alpha), float(gamma), float(scale), loss.data_ptr(),
+                                   dl.data_ptr(), K, B * Q, K, _stream(lg.device)), "fx_vfl_loss_bf16")
+        ctx.save_for_backward(dl)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g.to(dl.dtype), None, None, None, None, None
+
+
+def _box_xyxy(b):
+    cx, cy, w, h = b.unbind(-1)
+    return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], -1)
+
+
+def _pair_iou_giou(a, b):
+    """IoU and GIoU of matched pairs (focoos/utils/box.py:27-64 restricted to the diagonal), xyxy."""
+    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
+    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    lt, rb = torch.max(a[:, :2], b[:, :2]), torch.min(a[:, 2:], b[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[:, 0] * wh[:, 1]
+    union = area_a + area_b - inter
+    iou = inter / union
+    lt2, rb2 = torch.min(a[:, :2], b[:, :2]), torch.max(a[:, 2:], b[:, 2:])
+    wh2 = (rb2 - lt2).clamp(min=0)
+    area = wh2[:, 0] * wh2[:, 1]
+    return iou, iou - (area - union) / (area + 1e-5)
+
+
+class SetCriterionTrain(nn.Module):
+    """SetCriterion.forward (fai_detr/modelling.py:553-612) with gradients: Hungarian matching per prediction set on the GPU
+    (fx_detr_match_cost_f32 + fx_lsa_f32), VFL through fx_vfl_loss_bf16, box losses on the matched pairs."""
+
+    def __init__(self, nc, weight_dict=None, alpha=0.75, gamma=2.0):
+        super().__init__()
+        self.nc = nc
+        self.matcher = BoxHungarianMatcher()
+        self.w = weight_dict or {"loss_vfl": 1.0, "loss_bbox": 5.0, "loss_giou": 2.0}
+        self.alpha, self.gamma = alpha, gamma
+        self.register_buffer("empty_weight", torch.ones(nc + 1))  # checkpoint key head.criterion.empty_weight
+
+    def _one_set(self, out, tg: _Targets, slot_b, num_boxes, fixed=None):
+        logits, boxes = out["pred_logits"], out["pred_boxes"].float()
+        B, Q, K = logits.shape
+        dev = logits.device
+        if fixed is None:
+            pi, ti = self.matcher.match_packed(logits.detach(), boxes.detach(), tg)
+        else:
+            pi, ti = fixed
+        losses = {}
+        cls = torch.full((B * Q,), K, dtype=torch.int32, device=dev)
+        score = torch.zeros(B * Q, dtype=torch.float32, device=dev)
+        if tg.n:
+            q = pi[: tg.n].long()
+            t = tg.offsets[:-1].long()[slot_b] + ti[: tg.n].long()
+            src = boxes[slot_b, q]
+            tb = tg.boxes[t]
+            iou, giou = _pair_iou_giou(_box_xyxy(src), _box_xyxy(tb))
+            flat = slot_b * Q + q
+            cls[flat] = tg.labels[t]
+            score[flat] = iou.detach()
+            losses["loss_bbox"] = self.w["loss_bbox"] * (src - tb).abs().sum() / num_boxes
+            losses["loss_giou"] = self.w["loss_giou"] * (1 - giou).sum() / num_boxes
+        else:
+            z = boxes.sum() * 0
+            losses["loss_bbox"], losses["loss_giou"] = z, z
+        losses["loss_vfl"] = _VFLFn.apply(logits, cls, score, self.alpha, self.gamma, self.w["loss_vfl"] / num_boxes)
+        return losses, (pi, ti)
+
+    def forward(self, outputs, targets: Sequence, fixed_matches=None):
+        dev = outputs["pred_logits"].device
+        tg = _Targets(targets, dev)
+        num = torch.tensor([float(tg.n)], device=dev)
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            torch.distributed.all_reduce(num)
+            num = num / torch.distributed.get_world_size()
+        num_boxes = max(float(num.item()), 1.0)
+        slot_b = torch.from_numpy(np.repeat(np.arange(len(targets)), np.diff(tg.off_host))).to(dev)
+        sets = [("", outputs)] + [(f"_{i}", a) for i, a in enumerate(outputs.get("aux_outputs", []))]
+        losses, matches = {}, []
+        for j, (suffix, o) in enumerate(sets):
+            l, m = self._one_set(o, tg, slot_b, num_boxes, None if fixed_matches is None else fixed_matches[j])
+            matches.append(m)
+            for k, v in l.items():
+                losses[k + suffix] = v
+        self.last_matches = matches
+        return losses
+
+
+class FAIDetrTrainable(nn.Module):
+    """Reference-compatible parameter tree (``pixel_decoder.backbone.*``, ``pixel_decoder.*``, ``head.predictor.*``,
+    ``head.criterion.empty_weight``) whose forward(images, targets) returns the dict of weighted losses."""
+
+    def __init__(self, config: Dict):
+        super().__init__()
+        if not torch.cuda.is_available():
+            raise _lib.FocoosAmdError("focoos_amd needs a ROCm GPU (gfx950); no CPU fallback exists")
+        lib = _lib.load()
+        nc = int(config["num_classes"])
+        self.pixel_decoder = HybridEncoder(lib, ffn=int(config.get("pixel_decoder_dim_feedforward", 1024)),
+                                           n_enc=int(config.get("pixel_decoder_num_encoder_layers", 1)))
+        self.pixel_decoder.backbone = ResNetVd(int(config["backbone_config"].get("depth", 50)), config.get("pixel_mean", (123.675, 116.28, 103.53)),
+                                               config.get("pixel_std", (58.395, 57.12, 57.375)))
+        self.head = nn.Module()
+        self.head.criterion = SetCriterionTrain(nc)
+        self.head.predictor = TransformerPredictor(lib, nc, nq=int(config.get("num_queries", 300)), nl=int(config.get("transformer_predictor_dec_layers", 6)),
+                                                   ffn=int(config.get("transformer_predictor_dim_feedforward", 1024)))
+
+    def forward(self, images: torch.Tensor, targets: Sequence, forced_topk=None, fixed_matches=None):
+        f = self.pixel_decoder.backbone(images)
+        enc = self.pixel_decoder([f["res3"], f["res4"], f["res5"]])
+        out = self.head.predictor(enc, forced_topk)
+        self.last_outputs = out
+        return self.head.criterion(out, targets, fixed_matches)

@@ -311,6 +311,12 @@ int fx_mha_bwd_bf16(const void* q, int ldq, const void* k, int ldk, const void* 
 int fx_scatter_rows_bf16(const void* dout, int ldo, const int32_t* idx, int k, void* dsrc, int lds, int rows_per_batch, int B, int cols,
                          fx_stream_t stream);
 
+/* SetCriterion.loss_labels_vfl (fai_detr/modelling.py:464-497) and its gradient in one pass: logits bf16 [rows][ld],
+ * cls i32 [rows] (matched class, K = none), score f32 [rows] (IoU of the matched pair); *loss_out += scale * sum w*BCE,
+ * dlogits (optional, bf16 [rows][lddl]) = scale * w * (sigmoid(x) - t); scale = loss weight / num_boxes. */
+int fx_vfl_loss_bf16(const void* logits, int ld, const int32_t* cls, const float* score, float alpha, float gamma, float scale, float* loss_out,
+                     void* dlogits, int lddl, int64_t rows, int K, fx_stream_t stream);
+
 /* Fork: `side` waits for everything queued on `main` so far; join: `main` waits for `side`.  Valid inside
  * fx_graph_begin/fx_graph_end (the side stream joins the capture), which turns two launch sequences into independent
  * branches of one hipGraph - used to run the two half-batches of a step concurrently. */

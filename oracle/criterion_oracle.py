@@ -149,7 +149,7 @@ def set_criterion_losses(logits: torch.Tensor, boxes: torch.Tensor, tgt_labels, 
     sidx = torch.cat([torch.as_tensor(i, dtype=torch.int64) for i, _ in indices])
     src_boxes = boxes[bidx, sidx]
     tb = torch.cat([tgt_boxes[b][torch.as_tensor(j, dtype=torch.int64)] for b, (_, j) in enumerate(indices)], 0)
-    ious = torch.diag(box_iou(box_cxcywh_to_xyxy(src_boxes), box_cxcywh_to_xyxy(tb))[0]) if len(sidx) else torch.zeros(0)
+    ious = torch.diag(box_iou(box_cxcywh_to_xyxy(src_boxes), box_cxcywh_to_xyxy(tb))[0]).detach() if len(sidx) else torch.zeros(0)  # :471 detached
     tco = torch.cat([tgt_labels[b][torch.as_tensor(j, dtype=torch.int64)].long() for b, (_, j) in enumerate(indices)])
     target_classes = torch.full((B, Q), K, dtype=torch.int64)
     target_classes[bidx, sidx] = tco
@@ -157,7 +157,7 @@ def set_criterion_losses(logits: torch.Tensor, boxes: torch.Tensor, tgt_labels, 
     tso = torch.zeros(B, Q)
     tso[bidx, sidx] = ious
     target_score = tso.unsqueeze(-1) * target
-    pred = torch.sigmoid(logits)
+    pred = torch.sigmoid(logits).detach()  # :487 detached
     weight = focal_alpha * pred.pow(focal_gamma) * (1 - target) + target_score
     loss = F.binary_cross_entropy_with_logits(logits, target_score, weight=weight, reduction="none")
     l_vfl = loss.mean(1).sum() * Q / num_boxes
