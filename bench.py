@@ -37,6 +37,9 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32; 16 for fai-mf-*)")
     ap.add_argument("--size", type=int, default=None, help="square input size (default 640; 800 for fai-mf-*)")
+    ap.add_argument("--train", action="store_true",
+                    help="training step instead of inference: fai-detr-l-obj365 forward + 7-set criterion + backward + DP gradient "
+                         "all-reduce + fused AdamW, bs=16/GPU (BASELINE config 4 with BatchNorm frozen)")
     ap.add_argument("--streams", type=int, default=None, help="concurrent batch parts per step (default: engine default / FX_STREAMS)")
     ap.add_argument("--mf-full-masks", action="store_true", help="fai-mf-*: also write the reference's [B,Q,H,W] fp32 `masks` tensor")
     ap.add_argument("--mf-masks-d2h", action="store_true", help="fai-mf-*: include the D2H copy of the bit-packed mask buffer in the step")
@@ -50,7 +53,7 @@ def parse():
     a = ap.parse_args()
     mf = a.model.startswith("fai-mf")
     a.family = "fai_mf" if mf else "fai_detr"
-    a.batch = a.batch or (16 if mf else 32)
+    a.batch = a.batch or (16 if (mf or a.train) else 32)
     a.size = a.size or (800 if mf else 640)
     return a
 
@@ -171,6 +174,63 @@ def per_op_timing(eng, pl, args):
     return [a / reps for a in acc]
 
 
+def train_main(args, world, rank, local):
+    """BASELINE config 4 per GPU: 16 synthetic 640^2 images + COCO-shaped targets (T_i ~ U{1..20}, seed = rank*1000 + iter),
+    one optimisation step = forward (training mode, frozen BN) + criterion + backward + gradient all-reduce + AdamW."""
+    import numpy as np
+    import torch
+
+    from focoos_amd.ports import DETRTargets
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.synth import synth_image, synth_state_dict
+    from focoos_amd.train_detr import FAIDetrTrainable, TrainStep
+
+    dev = f"cuda:{local}"
+    torch.cuda.set_device(local)
+    cfg = ModelRegistry.get_model_info(args.model)["config"]
+    K, B, S = int(cfg["num_classes"]), args.batch, args.size
+    model = FAIDetrTrainable(cfg).to(dev)
+    model.load_state_dict(synth_state_dict(cfg, 0), strict=True)
+    stepper = TrainStep(model)
+    imgs = torch.stack([torch.from_numpy(synth_image(rank * B + i, S, S)) for i in range(B)]).to(dev)
+
+    def targets(it):
+        rs = np.random.RandomState(rank * 1000 + it)
+        out = []
+        for _ in range(B):
+            t = rs.randint(1, 21)
+            bx = np.concatenate([rs.uniform(0.2, 0.8, (t, 2)), rs.uniform(0.05, 0.35, (t, 2))], -1).astype(np.float32)
+            out.append(DETRTargets(labels=torch.from_numpy(rs.randint(0, K, (t,))).to(dev), boxes=torch.from_numpy(bx).to(dev)))
+        return out
+
+    for it in range(max(args.warmup, 1)):
+        losses = stepper.step(imgs, targets(it))
+    barrier(world, False)
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        losses = stepper.step(imgs, targets(args.warmup + it))
+    barrier(world, False)
+    dt = max_over_ranks(time.perf_counter() - t0, world, False)
+    total = float(sum(v.detach().float() for v in losses.values()))
+    value = world * B * args.steps / dt
+    alg = 3 * ALG_GFLOP_PER_IMAGE * (S / 640.0) ** 2  # SURVEY §8d: training ~ 3 x forward (fwd + dgrad + wgrad)
+    if rank == 0:
+        print(json.dumps({
+            "metric": f"images/sec @ {S}^2 (train bs={B}/GPU)", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"{args.model} training step: forward (train mode, BatchNorm frozen) + Hungarian set criterion over 7 prediction "
+                                   f"sets + backward + gradient all-reduce + fused AdamW/clip, bs={B}/GPU, {S}x{S}, bf16 activations and gradients, "
+                                   "fp32 master weights; HIP autograd nodes (eager launches, no graph)",
+                       "global_batch": B * world, "parallelism": f"dp{world} (RCCL all-reduce of one flat fp32 gradient buffer, 64 MiB buckets)"},
+            "alg_gflop_per_image": round(alg, 1), "frac_of_bf16_mfma_roofline_whole_path": round(value / world * alg * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
+            "final_total_loss": round(total, 4)}))
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
     world, rank, local = dist_setup(args)
@@ -187,6 +247,9 @@ def main():
                               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none", "config": {"workload": "dry-run"}}))
         return
+
+    if args.train:
+        return train_main(args, world, rank, local)
 
     import torch
 

@@ -80,7 +80,7 @@ SIGNATURES = {
     "fx_act_bwd_bf16": [_vp, _i, _vp, _i, _vp, _i, C.c_int64, _i, _i, _vp],
     "fx_colsum_bf16": [_vp, _i, _vp, C.c_int64, _i, _vp],
     "fx_layernorm_bwd_bf16": [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp],
-    "fx_resize_bilinear_bwd_nhwc": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "fx_resize_bilinear_bwd_nhwc_bf16": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "fx_cast_f32_bf16": [_vp, _vp, C.c_int64, _vp],
     "fx_mha_bwd_workspace_bytes": [_i, _i, _i, _i],
     "fx_mha_bwd_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, C.c_size_t, _vp],

@@ -82,24 +82,40 @@ extern "C" int fx_act_bwd_bf16(const void* dy, int lddy, const void* z, int ldz,
 }
 
 // ------------------------------------------------------------------------------------------------ bias gradient
-// out[c] += sum_r x[r][c]: each block sums 256 rows per column in registers/LDS, one atomic per column per block.
+// out[c] += sum_r x[r][c].  Thread = 8 consecutive columns (one 16-byte load) x a strided set of rows; a workgroup covers
+// 32 column groups (256 columns) x 8 row lanes and walks COLSUM_ROWS rows, then reduces the row lanes through LDS and
+// issues one atomic per column.
+#define COLSUM_ROWS 2048
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, int ldx, float* __restrict__ out, int64_t rows, int cols) {
-  __shared__ float part[4][64];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + lane;
-  const int64_t r0 = (int64_t)blockIdx.y * 1024;
-  float s = 0.0f;
-  if (c < cols)
-    for (int64_t r = r0 + wave; r < r0 + 1024 && r < rows; r += 4) s += bf16_to_f32(x[r * ldx + c]);
-  part[wave][lane] = s;
+  __shared__ float part[8][256];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 256 + cg * 8;
+  const int64_t r0 = (int64_t)blockIdx.y * COLSUM_ROWS;
+  const int64_t r1 = r0 + COLSUM_ROWS < rows ? r0 + COLSUM_ROWS : rows;
+  float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c0 < cols)
+    for (int64_t r = r0 + rl; r < r1; r += 8) {
+      float v[8];
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(x + r * ldx + c0), v);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += v[j];
+    }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[rl][cg * 8 + j] = s[j];
   __syncthreads();
-  if (wave == 0 && c < cols) unsafeAtomicAdd(out + c, part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane]);
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < cols) {
+    float t = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t += part[i][threadIdx.x];
+    unsafeAtomicAdd(out + c, t);
+  }
 }
 
 extern "C" int fx_colsum_bf16(const void* x, int ldx, float* out, int64_t rows, int cols, fx_stream_t stream_) {
-  FX_CHECK_ARG(x && out && rows > 0 && cols > 0 && ldx >= cols);
-  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, (unsigned)((rows + 1023) / 1024)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
-                     (const bf16_t*)x, ldx, out, rows, cols);
+  FX_CHECK_ARG(x && out && rows > 0 && cols > 0 && cols % 8 == 0 && ldx >= cols && ldx % 8 == 0);
+  hipLaunchKernelGGL(colsum_kernel, dim3((cols + 255) / 256, (unsigned)((rows + COLSUM_ROWS - 1) / COLSUM_ROWS)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)x, ldx, out, rows, cols);
   return fx_launch_status();
 }
 
@@ -164,8 +180,8 @@ extern "C" int fx_layernorm_bwd_bf16(const void* dy, int lddy, const void* x, in
 }
 
 // ------------------------------------------------------------------------------------------------ bilinear resize backward
-// Scatter form of fx_resize_bilinear_nhwc_bf16 (align_corners=False): every output pixel adds its gradient, weighted by
-// the four bilinear weights, into an fp32 accumulator [B,H,W,C] (zeroed by the caller); fx_cast_f32_bf16 converts.
+// Gather form of the adjoint of fx_resize_bilinear_nhwc_bf16 (align_corners=False): an input pixel sums, over the output
+// pixels whose two taps per axis include it, dy times the tap weight.  Deterministic, no atomics, writes bf16 directly.
 __device__ __forceinline__ void bil_src(int dst, float scale, int in, int& i0, int& i1, float& w0, float& w1) {
   float src = ((float)dst + 0.5f) * scale - 0.5f;
   src = src < 0.0f ? 0.0f : src;
@@ -176,37 +192,57 @@ __device__ __forceinline__ void bil_src(int dst, float scale, int in, int& i0, i
   w0 = 1.0f - w1;
 }
 
-__global__ __launch_bounds__(256) void resize_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, float* __restrict__ dx, int B, int H, int W, int C8,
-                                                         int Ho, int Wo, float sh, float sw) {
-  const int64_t total = (int64_t)B * Ho * Wo * C8;
-  const int Cc = C8 * 8;
+// candidate output range whose source coordinate can fall in [i - 1, i + 1]
+__device__ __forceinline__ void bil_range(int i, float scale, int out, int& lo, int& hi) {
+  const float inv = 1.0f / scale;
+  lo = (int)floorf(((float)i - 1.0f + 0.5f) * inv - 0.5f) - 1;
+  hi = (int)ceilf(((float)i + 1.0f + 0.5f) * inv - 0.5f) + 1;
+  lo = lo < 0 ? 0 : lo;
+  hi = hi > out - 1 ? out - 1 : hi;
+}
+
+__global__ __launch_bounds__(256) void resize_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, bf16_t* __restrict__ dx, int lddx, int B, int H,
+                                                         int W, int C8, int Ho, int Wo, float sh, float sw) {
+  const int64_t total = (int64_t)B * H * W * C8;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int c8 = (int)(i % C8);
-    const int64_t p = i / C8;
-    const int wo = (int)(p % Wo);
-    const int64_t q = p / Wo;
-    const int ho = (int)(q % Ho), b = (int)(q / Ho);
-    int h0, h1, w0, w1;
-    float lh0, lh1, lw0, lw1;
-    bil_src(ho, sh, H, h0, h1, lh0, lh1);
-    bil_src(wo, sw, W, w0, w1, lw0, lw1);
-    float g[8];
-    unpack_bf16x8(*reinterpret_cast<const uint4*>(dy + p * lddy + c8 * 8), g);
-    float* base = dx + (int64_t)b * H * W * Cc + c8 * 8;
+    int64_t p = i / C8;
+    const int w = (int)(p % W);
+    p /= W;
+    const int h = (int)(p % H);
+    const int b = (int)(p / H);
+    int holo, hohi, wolo, wohi;
+    bil_range(h, sh, Ho, holo, hohi);
+    bil_range(w, sw, Wo, wolo, wohi);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int ho = holo; ho <= hohi; ++ho) {
+      int h0, h1;
+      float lh0, lh1;
+      bil_src(ho, sh, H, h0, h1, lh0, lh1);
+      const float wh = (h0 == h ? lh0 : 0.0f) + (h1 == h ? lh1 : 0.0f);
+      if (wh == 0.0f) continue;
+      for (int wo = wolo; wo <= wohi; ++wo) {
+        int w0, w1;
+        float lw0, lw1;
+        bil_src(wo, sw, W, w0, w1, lw0, lw1);
+        const float ww = (w0 == w ? lw0 : 0.0f) + (w1 == w ? lw1 : 0.0f);
+        if (ww == 0.0f) continue;
+        float g[8];
+        unpack_bf16x8(*reinterpret_cast<const uint4*>(dy + (((int64_t)b * Ho + ho) * Wo + wo) * lddy + c8 * 8), g);
+        const float k = wh * ww;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      unsafeAtomicAdd(base + ((int64_t)h0 * W + w0) * Cc + j, lh0 * lw0 * g[j]);
-      unsafeAtomicAdd(base + ((int64_t)h0 * W + w1) * Cc + j, lh0 * lw1 * g[j]);
-      unsafeAtomicAdd(base + ((int64_t)h1 * W + w0) * Cc + j, lh1 * lw0 * g[j]);
-      unsafeAtomicAdd(base + ((int64_t)h1 * W + w1) * Cc + j, lh1 * lw1 * g[j]);
+        for (int j = 0; j < 8; ++j) acc[j] += k * g[j];
+      }
     }
+    *reinterpret_cast<uint4*>(dx + (((int64_t)b * H + h) * W + w) * lddx + c8 * 8) = pack_bf16x8(acc);
   }
 }
 
-extern "C" int fx_resize_bilinear_bwd_nhwc(const void* dy, int lddy, float* dx_f32, int B, int H, int W, int C, int Ho, int Wo, fx_stream_t stream_) {
-  FX_CHECK_ARG(dy && dx_f32 && B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 8 == 0 && lddy >= C && lddy % 8 == 0);
-  hipLaunchKernelGGL(resize_bwd_kernel, dim3(ew_grid((int64_t)B * Ho * Wo * (C / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
-                     (const bf16_t*)dy, lddy, dx_f32, B, H, W, C / 8, Ho, Wo, (float)H / (float)Ho, (float)W / (float)Wo);
+extern "C" int fx_resize_bilinear_bwd_nhwc_bf16(const void* dy, int lddy, void* dx, int lddx, int B, int H, int W, int C, int Ho, int Wo,
+                                                fx_stream_t stream_) {
+  FX_CHECK_ARG(dy && dx && B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 8 == 0 && lddy >= C && lddy % 8 == 0 && lddx >= C && lddx % 8 == 0);
+  hipLaunchKernelGGL(resize_bwd_kernel, dim3(ew_grid((int64_t)B * H * W * (C / 8))), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
+                     (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, B, H, W, C / 8, Ho, Wo, (float)H / (float)Ho, (float)W / (float)Wo);
   return fx_launch_status();
 }
 

@@ -62,9 +62,14 @@ def ms_deform_attn_core(value: torch.Tensor, value_spatial_shapes, sampling_loca
     for h, w in shapes:
         starts.append(acc)
         acc += h * w
-    st = torch.tensor(shapes, dtype=torch.int32, device=dev)
-    ss = torch.tensor(starts, dtype=torch.int32, device=dev)
+    key = (tuple(shapes), str(dev))
+    if key not in _SHAPE_CACHE:  # cached: no host->device copy per call
+        _SHAPE_CACHE[key] = (torch.tensor(shapes, dtype=torch.int32, device=dev), torch.tensor(starts, dtype=torch.int32, device=dev))
+    st, ss = _SHAPE_CACHE[key]
     return _MSDAFunction.apply(value, st, ss, sampling_locations, attention_weights)
+
+
+_SHAPE_CACHE: Dict = {}
 
 
 class FlatAdamW:

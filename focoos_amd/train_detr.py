@@ -290,3 +290,53 @@ class FAIDetrTrainable(nn.Module):
         out = self.head.predictor(enc, forced_topk)
         self.last_outputs = out
         return self.head.criterion(out, targets, fixed_matches)
+
+
+class TrainStep:
+    """One optimisation step of TrainerLoop.run_step (focoos/trainer/trainer.py:723-773) for the engine: forward + losses +
+    backward on the HIP autograd graph, data-parallel gradient averaging (RCCL all-reduce of one flat fp32 buffer in 64 MiB
+    buckets), global-norm clipping + AdamW in one fused kernel.  Parameters and their gradients live in the optimizer's flat
+    buffers (the gradient kernels accumulate straight into the flat gradient views); per-parameter lr / weight decay follow
+    build_optimizer (solver/build.py:104-138: backbone lr x0.1, no decay on norms / biases).
+    The step is launched eagerly (~5 800 launches, host-bound at ~75 ms): capturing forward+backward in a hipGraph through
+    torch.cuda.make_graphed_callables was tried and dead-locked inside the capture on this stack, so it is not used."""
+
+    def __init__(self, model: FAIDetrTrainable, lr: float = 1e-4, backbone_multiplier: float = 0.1, weight_decay: float = 1e-4,
+                 max_grad_norm: float = 0.1):
+        from . import train_nn
+        from .train import BucketedGradAllReduce, FlatAdamW
+
+        self.model, self._nn = model, train_nn
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        dev = named[0][1].device
+        spec = []
+        for n, p in named:
+            no_decay = p.dim() == 1
+            spec.append((n, tuple(p.shape), lr * (backbone_multiplier if ".backbone." in n else 1.0), 0.0 if no_decay else weight_decay))
+        self.opt = FlatAdamW(spec, dev, max_grad_norm=max_grad_norm)
+        with torch.no_grad():
+            for n, p in named:
+                self.opt.params[n].copy_(p.data)
+                p.data = self.opt.params[n]
+                p.grad = self.opt.grads[n]
+        self.named = named
+        self.reducer = BucketedGradAllReduce(self.opt.flat_g)
+
+    def step(self, images: torch.Tensor, targets: Sequence) -> Dict[str, torch.Tensor]:
+        nn_ = self._nn
+        self.opt.zero_grad()
+        for n, p in self.named:  # gradient kernels / autograd accumulate in place into these views
+            p.grad = self.opt.grads[n]
+        nn_.ARENA.arm(self.opt.numel + (8 << 20), self.opt.dev)   # staging for the 3x3 weight gradients + padded heads
+        nn_.DIRECT_GRAD[0] = True
+        try:
+            losses = self.model(images, targets)
+            total = sum(losses.values())
+            total.backward()
+        finally:
+            nn_.DIRECT_GRAD[0] = False
+        self.reducer.launch()
+        self.reducer.wait()
+        self.opt.step()
+        nn_.WEIGHTS_EPOCH[0] += 1
+        return losses

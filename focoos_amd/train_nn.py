@@ -27,6 +27,44 @@ from ._lib import FX_ACT, FxConvDesc, check
 from .state_spec import RESNET_BLOCKS
 
 BN_EPS = 1e-5
+# Bumped by the training loop after every optimizer step: the fused AdamW kernel updates the fp32 masters through raw
+# pointers (tensor._version does not move), and the bf16 weight images must be rebuilt from them.
+WEIGHTS_EPOCH = [0]
+# Set by train_detr.TrainStep: parameter gradients are accumulated by the kernels straight into the (pre-zeroed) flat
+# gradient views held in ``param.grad`` and the backward returns None for them - no per-parameter zero-fill / add launches.
+DIRECT_GRAD = [False]
+
+
+class ZeroArena:
+    """One big pre-zeroed fp32 buffer per step for the accumulate-into temporaries (weight-gradient staging, bias sums):
+    a single memset instead of hundreds of small fill launches.  Falls back to torch.zeros when not armed (tests)."""
+
+    def __init__(self):
+        self.buf = None
+        self.used = 0
+
+    def arm(self, numel: int, device):
+        if self.buf is None or self.buf.numel() < numel or self.buf.device != torch.device(device):
+            self.buf = torch.empty(numel, dtype=torch.float32, device=device)
+        self.buf.zero_()
+        self.used = 0
+
+    def disarm(self):
+        self.buf = None
+
+    def zeros(self, shape, device) -> torch.Tensor:
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n_al = (n + 63) // 64 * 64
+        if self.buf is None or self.buf.device != torch.device(device) or self.used + n_al > self.buf.numel():
+            return torch.zeros(*shape, dtype=torch.float32, device=device)
+        out = self.buf[self.used:self.used + n].view(*shape)
+        self.used += n_al
+        return out
+
+
+ARENA = ZeroArena()
 
 
 def _stream(dev) -> C.c_void_p:
@@ -94,12 +132,16 @@ class _ConvBnActFn(torch.autograd.Function):
             dx = _conv_call(lib, src, layer.w_dgrad, None, Cc, layer.k, layer.k, 1, layer.pad, None, None)
         dw = None
         if ctx.needs_input_grad[1]:
-            dw_eff = torch.zeros(N, layer.k, layer.k, Cc, dtype=torch.float32, device=dev)
+            dw_eff = ARENA.zeros((N, layer.k, layer.k, Cc), dev)
             check(lib.fx_conv2d_wgrad_nhwc_bf16(x.data_ptr(), Cc, dz.data_ptr(), N, dw_eff.data_ptr(), B, H, W_, Cc, Ho, Wo, N, layer.k, layer.k,
                                                 layer.stride, layer.pad, st), "fx_conv2d_wgrad_nhwc_bf16")
-            dw = torch.empty(N, Cc, layer.k, layer.k, dtype=torch.float32, device=dev)
-            check(lib.fx_unpack_conv_wgrad_f32(dw_eff.data_ptr(), layer.scale.data_ptr(), dw.data_ptr(), N, Cc, layer.k, layer.k, Cc, 0, st),
+            wparam = layer._conv_h.weight
+            direct = DIRECT_GRAD[0] and wparam.grad is not None
+            dw = wparam.grad if direct else torch.empty(N, Cc, layer.k, layer.k, dtype=torch.float32, device=dev)
+            check(lib.fx_unpack_conv_wgrad_f32(dw_eff.data_ptr(), layer.scale.data_ptr(), dw.data_ptr(), N, Cc, layer.k, layer.k, Cc, int(direct), st),
                   "fx_unpack_conv_wgrad_f32")
+            if direct:
+                dw = None
         return dx, dw, (dz if ctx.has_res else None), None
 
 
@@ -131,7 +173,7 @@ class ConvNormLayer(nn.Module):
     def sync_packed(self):
         """(Re)build the bf16 weight images when the master weight changed (optimizer step, load_state_dict)."""
         w = self._conv_h.weight
-        ver = (w._version, self._norm_h.weight._version, self._norm_h.running_var._version, w.device)
+        ver = (w._version, self._norm_h.weight._version, self._norm_h.running_var._version, w.device, WEIGHTS_EPOCH[0])
         if ver == self._packed_version:
             return
         dev = w.device
@@ -186,7 +228,7 @@ class _StemFn(torch.autograd.Function):
         xn = torch.empty(B, H, W_, 8, dtype=torch.bfloat16, device=dev)
         check(lib.fx_normalize_pad8(images.data_ptr(), int(images.dtype == torch.float32), layer.px_mean.data_ptr(), layer.px_inv_std.data_ptr(),
                                     xn.data_ptr(), B * H * W_, st), "fx_normalize_pad8")
-        dw_eff = torch.zeros(32, 3, 3, 8, dtype=torch.float32, device=dev)
+        dw_eff = ARENA.zeros((32, 3, 3, 8), dev)
         check(lib.fx_conv2d_wgrad_nhwc_bf16(xn.data_ptr(), 8, dz.data_ptr(), 32, dw_eff.data_ptr(), B, H, W_, 8, Ho, Wo, 32, 3, 3, 2, 1, st),
               "fx_conv2d_wgrad_nhwc_bf16")
         dw = torch.empty(32, 3, 3, 3, dtype=torch.float32, device=dev)
@@ -203,7 +245,7 @@ class StemConv(ConvNormLayer):
 
     def sync_packed(self):
         w = self._conv_h.weight
-        ver = (w._version, w.device)
+        ver = (w._version, w.device, WEIGHTS_EPOCH[0])
         if ver == self._packed_version:
             return
         with torch.no_grad():
@@ -358,7 +400,7 @@ class _PackedLinear:
         self.Np = self.Kp = 0
 
     def sync(self, lib, weight, bias, r0, r1):
-        ver = (weight._version, None if bias is None else bias._version, weight.device, r0, r1)
+        ver = (weight._version, None if bias is None else bias._version, weight.device, r0, r1, WEIGHTS_EPOCH[0])
         if ver == self.ver:
             return
         dev = weight.device
@@ -406,6 +448,7 @@ class _LinearFn(torch.autograd.Function):
         y = z if fused else _act_fwd(lib, z, act)
         ctx.lib, ctx.pack, ctx.rng, ctx.act, ctx.has_res, ctx.has_bias = lib, pack, (r0, r1), act, residual is not None, bias is not None
         ctx.wshape, ctx.K = tuple(weight.shape), K
+        ctx.wparam, ctx.bparam = weight, bias
         ctx.save_for_backward(x2, y if fused else z)
         out = y.reshape(*x.shape[:-1], Np)
         return out if Np == N else out[..., :N].contiguous()
@@ -432,19 +475,33 @@ class _LinearFn(torch.autograd.Function):
             dx = dxp if Kp == K else dxp[..., :K].contiguous()
         dw = db = None
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros(ctx.wshape, dtype=torch.float32, device=dev)
-            direct = Np == N and Kp == K
-            tgt = dw[r0:r1] if direct else torch.zeros(Np, Kp, dtype=torch.float32, device=dev)
+            same = Np == N and Kp == K
+            into_grad = DIRECT_GRAD[0] and ctx.wparam.grad is not None  # kernels accumulate into the pre-zeroed flat gradient
+            if into_grad and same:
+                tgt = ctx.wparam.grad[r0:r1]
+            else:
+                dw = None if into_grad else ARENA.zeros(ctx.wshape, dev)
+                tgt = dw[r0:r1] if (same and not into_grad) else ARENA.zeros((Np, Kp), dev)
             check(lib.fx_conv2d_wgrad_nhwc_bf16(x2.data_ptr(), Kp, dz.data_ptr(), Np, tgt.data_ptr(), 1, 1, R, Kp, 1, R, Np, 1, 1, 1, 0, st),
                   "fx_conv2d_wgrad_nhwc_bf16")
-            if not direct:
-                dw[r0:r1] = tgt[:N, :K]
+            if not same:
+                if into_grad:
+                    ctx.wparam.grad[r0:r1] += tgt[:N, :K]
+                else:
+                    dw[r0:r1] = tgt[:N, :K]
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            db = torch.zeros(ctx.wshape[0], dtype=torch.float32, device=dev)
-            tgt = db[r0:r1] if Np == N else torch.zeros(Np, dtype=torch.float32, device=dev)
+            into_grad = DIRECT_GRAD[0] and ctx.bparam.grad is not None
+            if into_grad and Np == N:
+                tgt = ctx.bparam.grad[r0:r1]
+            else:
+                db = None if into_grad else ARENA.zeros((ctx.wshape[0],), dev)
+                tgt = db[r0:r1] if (Np == N and not into_grad) else ARENA.zeros((Np,), dev)
             check(lib.fx_colsum_bf16(dz.data_ptr(), Np, tgt.data_ptr(), R, Np, st), "fx_colsum_bf16")
             if Np != N:
-                db[r0:r1] = tgt[:N]
+                if into_grad:
+                    ctx.bparam.grad[r0:r1] += tgt[:N]
+                else:
+                    db[r0:r1] = tgt[:N]
         dres = None
         if ctx.has_res:
             dres = (dz if Np == N else dz[..., :N].contiguous()).reshape(dy.shape)
@@ -474,6 +531,7 @@ class _LayerNormFn(torch.autograd.Function):
         check(lib.fx_layernorm_bf16(x.data_ptr(), 256, None, 0, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), 256, R, 256, _stream(x.device)),
               "fx_layernorm_bf16")
         ctx.lib = lib
+        ctx.gparam, ctx.bparam = gamma, beta
         ctx.save_for_backward(x, gamma)
         return y
 
@@ -483,11 +541,12 @@ class _LayerNormFn(torch.autograd.Function):
         lib = ctx.lib
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dg = torch.zeros(256, dtype=torch.float32, device=x.device)
-        db = torch.zeros(256, dtype=torch.float32, device=x.device)
+        direct = DIRECT_GRAD[0] and ctx.gparam.grad is not None and ctx.bparam.grad is not None
+        dg = ctx.gparam.grad if direct else ARENA.zeros((256,), x.device)
+        db = ctx.bparam.grad if direct else ARENA.zeros((256,), x.device)
         check(lib.fx_layernorm_bwd_bf16(dy.data_ptr(), 256, x.data_ptr(), 256, gamma.data_ptr(), dx.data_ptr(), 256, dg.data_ptr(), db.data_ptr(),
                                         _rows(x), 256, _stream(x.device)), "fx_layernorm_bwd_bf16")
-        return dx, dg, db, None
+        return dx, (None if direct else dg), (None if direct else db), None
 
 
 class LayerNorm(nn.Module):
@@ -571,11 +630,9 @@ class _ResizeFn(torch.autograd.Function):
         lib = ctx.lib
         B, H, W_, Cc = ctx.shape
         dy = dy.contiguous()
-        acc = torch.zeros(B, H, W_, Cc, dtype=torch.float32, device=dy.device)
-        check(lib.fx_resize_bilinear_bwd_nhwc(dy.data_ptr(), Cc, acc.data_ptr(), B, H, W_, Cc, dy.shape[1], dy.shape[2], _stream(dy.device)),
-              "fx_resize_bilinear_bwd_nhwc")
         dx = torch.empty(B, H, W_, Cc, dtype=torch.bfloat16, device=dy.device)
-        check(lib.fx_cast_f32_bf16(acc.data_ptr(), dx.data_ptr(), acc.numel(), _stream(dy.device)), "fx_cast_f32_bf16")
+        check(lib.fx_resize_bilinear_bwd_nhwc_bf16(dy.data_ptr(), Cc, dx.data_ptr(), Cc, B, H, W_, Cc, dy.shape[1], dy.shape[2], _stream(dy.device)),
+              "fx_resize_bilinear_bwd_nhwc_bf16")
         return dx, None, None, None
 
 

@@ -295,9 +295,9 @@ int fx_colsum_bf16(const void* x, int ldx, float* out, int64_t rows, int cols, f
 int fx_layernorm_bwd_bf16(const void* dy, int lddy, const void* x, int ldx, const float* gamma, void* dx, int lddx, float* dgamma, float* dbeta,
                           int rows, int cols, fx_stream_t stream);
 
-/* Backward of fx_resize_bilinear_nhwc_bf16: scatter-adds dy [B,Ho,Wo,C] into the fp32 accumulator dx_f32 [B,H,W,C] (zeroed by
- * the caller); fx_cast_f32_bf16 converts n (multiple of 8) floats to bf16. */
-int fx_resize_bilinear_bwd_nhwc(const void* dy, int lddy, float* dx_f32, int B, int H, int W, int C, int Ho, int Wo, fx_stream_t stream);
+/* Backward (adjoint) of fx_resize_bilinear_nhwc_bf16 in gather form: dx bf16 [B,H,W,C] from dy bf16 [B,Ho,Wo,C]; deterministic.
+ * fx_cast_f32_bf16 converts n (multiple of 8) floats to bf16. */
+int fx_resize_bilinear_bwd_nhwc_bf16(const void* dy, int lddy, void* dx, int lddx, int B, int H, int W, int C, int Ho, int Wo, fx_stream_t stream);
 int fx_cast_f32_bf16(const float* x, void* y, int64_t n, fx_stream_t stream);
 
 /* Backward of fx_mha_bf16 (head_dim 32, Lk <= 512): dq, dk, dv from q, k, v, the forward output o and dout.
