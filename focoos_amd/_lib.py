@@ -69,6 +69,7 @@ SIGNATURES = {
     "fx_adamw_workspace_bytes": [],
     "fx_adamw_step_f32": [_vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp],
     "fx_conv2d_wgrad_nhwc_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "fx_conv2d_wgrad_bias_nhwc_bf16": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "fx_pack_conv_weights_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "fx_unpack_conv_wgrad_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "fx_relu_bwd_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, C.c_int64, _i, _i, _vp],

@@ -18,6 +18,7 @@ struct WgradArgs {
   const bf16_t* x;
   const bf16_t* dz;
   float* dw;
+  float* dbias;  // optional: dbias[n] += sum_m dz[m][n] (the bias gradient), taken from the dZ tiles already staged here
   int B, H, W, C, ldx;
   int Ho, Wo, N, lddz;
   int KH, KW, stride, pad;
@@ -64,6 +65,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   const bool n_ok = nch < p.N;  // N % 8 == 0
 
   uint4 rz[2], rx[2];
+  float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const bool want_bias = p.dbias != nullptr && kt == 0;
   auto load = [&](int mbase) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -81,6 +84,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   auto store = [&](int s) {
     unsigned char* Z = smem + s * 2 * WG_TILE;
     unsigned char* X = Z + WG_TILE;
+    if (want_bias) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float f[8];
+        unpack_bf16x8(rz[i], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum[j] += f[j];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       *reinterpret_cast<uint4*>(Z + (r0 + 16 * i) * WG_ROW + cc * 16) = rz[i];
@@ -125,6 +137,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     if (st + 1 < nsteps) store(cur ^ 1);
     __syncthreads();
   }
+  if (want_bias) {  // reduce the 16 row-threads of each channel chunk through LDS (the tiles are no longer needed)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[r0 * 128 + cc * 8 + j] = bsum[j];
+    __syncthreads();
+    if (tid < 128 && n0 + tid < p.N) {
+      float t = 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) t += red[r * 128 + tid];
+      unsafeAtomicAdd(p.dbias + n0 + tid, t);
+    }
+  }
   // epilogue: D rows = out channel n, cols = kc; a register index r is one n for 32 consecutive kc -> 128-byte atomics
   const int l32 = lane & 31, lh = lane >> 5;
 #pragma unroll
@@ -140,8 +165,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     }
 }
 
+extern "C" int fx_conv2d_wgrad_bias_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, float* dw, float* dbias, int B, int H, int W,
+                                              int C, int Ho, int Wo, int N, int KH, int KW, int stride, int pad, fx_stream_t stream_);
+
 extern "C" int fx_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, float* dw, int B, int H, int W, int C, int Ho,
                                          int Wo, int N, int KH, int KW, int stride, int pad, fx_stream_t stream_) {
+  return fx_conv2d_wgrad_bias_nhwc_bf16(x, ldx, dz, lddz, dw, nullptr, B, H, W, C, Ho, Wo, N, KH, KW, stride, pad, stream_);
+}
+
+extern "C" int fx_conv2d_wgrad_bias_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, float* dw, float* dbias, int B, int H, int W,
+                                              int C, int Ho, int Wo, int N, int KH, int KW, int stride, int pad, fx_stream_t stream_) {
   FX_CHECK_ARG(x && dz && dw && B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && N > 0 && C > 0);
   FX_CHECK_ARG(C % 8 == 0 && N % 8 == 0 && ldx >= C && lddz >= N && ldx % 8 == 0 && lddz % 8 == 0);
   FX_CHECK_ARG(KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0);
@@ -154,6 +187,7 @@ extern "C" int fx_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz,
   a.x = reinterpret_cast<const bf16_t*>(x);
   a.dz = reinterpret_cast<const bf16_t*>(dz);
   a.dw = dw;
+  a.dbias = dbias;
   a.B = B; a.H = H; a.W = W; a.C = C; a.ldx = ldx;
   a.Ho = Ho; a.Wo = Wo; a.N = N; a.lddz = lddz;
   a.KH = KH; a.KW = KW; a.stride = stride; a.pad = pad;

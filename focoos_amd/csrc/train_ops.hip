@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void msda_f32_kernel(const float* __restrict__
             float* gv = grad_value + lbase + (int64_t)t.idx[k] * CH;
             const float wk = aw * t.w[k];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) atomicAdd(gv + c, wk * go[c]);
+            for (int c = 0; c < 4; ++c) unsafeAtomicAdd(gv + c, wk * go[c]);  // hardware fp32 atomic (plain atomicAdd lowers to a CAS loop)
           }
         }
 #pragma unroll

@@ -85,7 +85,7 @@ extern "C" int fx_act_bwd_bf16(const void* dy, int lddy, const void* z, int ldz,
 // out[c] += sum_r x[r][c].  Thread = 8 consecutive columns (one 16-byte load) x a strided set of rows; a workgroup covers
 // 32 column groups (256 columns) x 8 row lanes and walks COLSUM_ROWS rows, then reduces the row lanes through LDS and
 // issues one atomic per column.
-#define COLSUM_ROWS 2048
+#define COLSUM_ROWS 256
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, int ldx, float* __restrict__ out, int64_t rows, int cols) {
   __shared__ float part[8][256];
   const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;

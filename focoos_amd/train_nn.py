@@ -474,34 +474,38 @@ class _LinearFn(torch.autograd.Function):
             dxp = _conv_call(lib, dz, pack.w_t, None, Kp, 1, 1, 1, 0, None, None).reshape(dy.shape[:-1] + (Kp,))
             dx = dxp if Kp == K else dxp[..., :K].contiguous()
         dw = db = None
-        if ctx.needs_input_grad[1]:
+        want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        if want_w or want_b:
             same = Np == N and Kp == K
-            into_grad = DIRECT_GRAD[0] and ctx.wparam.grad is not None  # kernels accumulate into the pre-zeroed flat gradient
-            if into_grad and same:
-                tgt = ctx.wparam.grad[r0:r1]
+            direct = DIRECT_GRAD[0] and ctx.wparam.grad is not None  # kernels accumulate into the pre-zeroed flat gradients
+            if direct and same:
+                wt = ctx.wparam.grad[r0:r1]
             else:
-                dw = None if into_grad else ARENA.zeros(ctx.wshape, dev)
-                tgt = dw[r0:r1] if (same and not into_grad) else ARENA.zeros((Np, Kp), dev)
-            check(lib.fx_conv2d_wgrad_nhwc_bf16(x2.data_ptr(), Kp, dz.data_ptr(), Np, tgt.data_ptr(), 1, 1, R, Kp, 1, R, Np, 1, 1, 1, 0, st),
-                  "fx_conv2d_wgrad_nhwc_bf16")
+                dw = None if direct else ARENA.zeros(ctx.wshape, dev)
+                wt = dw[r0:r1] if (same and not direct) else ARENA.zeros((Np, Kp), dev)
+            bt = None
+            if want_b:
+                bdirect = DIRECT_GRAD[0] and ctx.bparam.grad is not None
+                if bdirect and Np == N:
+                    bt = ctx.bparam.grad[r0:r1]
+                else:
+                    db = None if bdirect else ARENA.zeros((ctx.wshape[0],), dev)
+                    bt = db[r0:r1] if (Np == N and not bdirect) else ARENA.zeros((Np,), dev)
+            # one launch: weight gradient + bias gradient (column sums of the dZ tiles it stages anyway)
+            check(lib.fx_conv2d_wgrad_bias_nhwc_bf16(x2.data_ptr(), Kp, dz.data_ptr(), Np, wt.data_ptr(), bt.data_ptr() if bt is not None else None,
+                                                     1, 1, R, Kp, 1, R, Np, 1, 1, 1, 0, st), "fx_conv2d_wgrad_bias_nhwc_bf16")
             if not same:
-                if into_grad:
-                    ctx.wparam.grad[r0:r1] += tgt[:N, :K]
+                if direct:
+                    ctx.wparam.grad[r0:r1] += wt[:N, :K]
                 else:
-                    dw[r0:r1] = tgt[:N, :K]
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            into_grad = DIRECT_GRAD[0] and ctx.bparam.grad is not None
-            if into_grad and Np == N:
-                tgt = ctx.bparam.grad[r0:r1]
-            else:
-                db = None if into_grad else ARENA.zeros((ctx.wshape[0],), dev)
-                tgt = db[r0:r1] if (Np == N and not into_grad) else ARENA.zeros((Np,), dev)
-            check(lib.fx_colsum_bf16(dz.data_ptr(), Np, tgt.data_ptr(), R, Np, st), "fx_colsum_bf16")
-            if Np != N:
-                if into_grad:
-                    ctx.bparam.grad[r0:r1] += tgt[:N]
+                    dw[r0:r1] = wt[:N, :K]
+            if want_b and Np != N:
+                if DIRECT_GRAD[0] and ctx.bparam.grad is not None:
+                    ctx.bparam.grad[r0:r1] += bt[:N]
                 else:
-                    db[r0:r1] = tgt[:N]
+                    db[r0:r1] = bt[:N]
+            if not want_w:
+                dw = None
         dres = None
         if ctx.has_res:
             dres = (dz if Np == N else dz[..., :N].contiguous()).reshape(dy.shape)

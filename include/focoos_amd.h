@@ -255,6 +255,9 @@ int fx_adamw_step_f32(float* params, const float* grads, float* exp_avg, float* 
  * the caller zeroes dw.  C % 8 == 0, N % 8 == 0. */
 int fx_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, float* dw, int B, int H, int W, int C, int Ho, int Wo, int N,
                               int KH, int KW, int stride, int pad, fx_stream_t stream);
+/* Same, and dbias[n] += sum_m dz[m][n] (bias gradient of a Linear / biased conv) from the tiles the kernel stages anyway. */
+int fx_conv2d_wgrad_bias_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, float* dw, float* dbias, int B, int H, int W, int C, int Ho,
+                                   int Wo, int N, int KH, int KW, int stride, int pad, fx_stream_t stream);
 
 /* Master weights fp32 [N][C][KH][KW] (reference / checkpoint layout) -> bf16 images for the MFMA kernels, optionally
  * multiplied by a per-out-channel scale (frozen BatchNorm folded): w_fwd [Npad][KH][KW][C] (fx_conv2d_nhwc_bf16 layout) and
