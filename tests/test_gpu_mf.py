@@ -351,7 +351,9 @@ def test_mf_full_size_batch_properties(setup):
             assert torch.equal(a[k][i, :ni], b[k][j, :ni]), k
         assert torch.equal(a["words"][i], b["words"][j])
     a2 = run(imgs)
-    assert torch.equal(a["mask_probs"], a2["mask_probs"]) and torch.equal(a["det_scores"], a2["det_scores"])
+    assert torch.equal(a["mask_probs"], a2["mask_probs"]) and torch.equal(a["det_count"], a2["det_count"])
+    for i in range(8):  # slots beyond det_count are not written: compare the valid prefixes
+        assert torch.equal(a["det_scores"][i, : int(n[i])], a2["det_scores"][i, : int(n[i])])
     for i in range(8):
         ni = int(n[i])
         q = a["det_query"][i, :ni].cpu()
