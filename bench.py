@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--train", action="store_true",
                     help="training step instead of inference: fai-detr-l-obj365 forward + 7-set criterion + backward + DP gradient "
                          "all-reduce + fused AdamW, bs=16/GPU (BASELINE config 4 with BatchNorm frozen)")
+    ap.add_argument("--norm", default="FrozenBN", choices=["FrozenBN", "BN", "SyncBN"],
+                    help="--train: BatchNorm mode (FrozenBN = reference freeze_bn; BN / SyncBN = batch statistics, SyncBN all-reduces them)")
     ap.add_argument("--streams", type=int, default=None, help="concurrent batch parts per step (default: engine default / FX_STREAMS)")
     ap.add_argument("--mf-full-masks", action="store_true", help="fai-mf-*: also write the reference's [B,Q,H,W] fp32 `masks` tensor")
     ap.add_argument("--mf-masks-d2h", action="store_true", help="fai-mf-*: include the D2H copy of the bit-packed mask buffer in the step")
@@ -189,7 +191,7 @@ def train_main(args, world, rank, local):
     torch.cuda.set_device(local)
     cfg = ModelRegistry.get_model_info(args.model)["config"]
     K, B, S = int(cfg["num_classes"]), args.batch, args.size
-    model = FAIDetrTrainable(cfg).to(dev)
+    model = FAIDetrTrainable(cfg, norm=args.norm).to(dev)
     model.load_state_dict(synth_state_dict(cfg, 0), strict=True)
     stepper = TrainStep(model)
     imgs = torch.stack([torch.from_numpy(synth_image(rank * B + i, S, S)) for i in range(B)]).to(dev)
@@ -219,7 +221,7 @@ def train_main(args, world, rank, local):
             "metric": f"images/sec @ {S}^2 (train bs={B}/GPU)", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.model} training step: forward (train mode, BatchNorm frozen) + Hungarian set criterion over 7 prediction "
+            "config": {"workload": f"{args.model} training step: forward (train mode, norm={args.norm}) + Hungarian set criterion over 7 prediction "
                                    f"sets + backward + gradient all-reduce + fused AdamW/clip, bs={B}/GPU, {S}x{S}, bf16 activations and gradients, "
                                    "fp32 master weights; HIP autograd nodes (eager launches, no graph)",
                        "global_batch": B * world, "parallelism": f"dp{world} (RCCL all-reduce of one flat fp32 gradient buffer, 64 MiB buckets)"},

@@ -77,6 +77,12 @@ SIGNATURES = {
     "fx_avgpool2x2_bwd_nhwc_bf16": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "fx_maxpool3x3s2_bwd_nhwc_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "fx_normalize_pad8": [_vp, _i, _vp, _vp, _vp, C.c_int64, _vp],
+    "fx_stem_conv3x3s2_linear": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "fx_bn_stats_bf16": [_vp, _i, _vp, C.c_int64, _i, _vp],
+    "fx_bn_finalize_f32": [_vp, C.c_float, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "fx_bn_apply_bf16": [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, C.c_int64, _i, _vp],
+    "fx_bn_bwd_stats_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, C.c_int64, _i, _vp],
+    "fx_bn_bwd_apply_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, C.c_float, _vp, _i, _vp, _i, C.c_int64, _i, _vp],
     "fx_act_fwd_bf16": [_vp, _i, _vp, _i, C.c_int64, _i, _i, _vp],
     "fx_act_bwd_bf16": [_vp, _i, _vp, _i, _vp, _i, C.c_int64, _i, _i, _vp],
     "fx_colsum_bf16": [_vp, _i, _vp, C.c_int64, _i, _vp],

@@ -9,7 +9,7 @@
 // registers, the [27][32] fp32 weight table sits in LDS and is read as float4 (4 distinct addresses per
 // wave instruction -> conflict-free broadcast), and the wave stores 16 pixels x 64 B = 1 KiB contiguous.
 // Zero padding applies to the NORMALISED image (the reference pads after normalising): padded taps add 0.
-template <typename TIn>
+template <typename TIn, bool RELU>
 __global__ __launch_bounds__(256) void stem_conv_kernel(const TIn* __restrict__ x, const float* __restrict__ wt /*[27][32]*/,
                                                          const float* __restrict__ bias, const float* __restrict__ mean,
                                                          const float* __restrict__ inv_std, bf16_t* __restrict__ y, int B, int H,
@@ -49,28 +49,42 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const TIn* __restrict__ 
       }
     }
   }
+  if (RELU) {
 #pragma unroll
-  for (int n = 0; n < 8; ++n) acc[n] = fmaxf(acc[n], 0.0f);
+    for (int n = 0; n < 8; ++n) acc[n] = fmaxf(acc[n], 0.0f);
+  }
   *reinterpret_cast<uint4*>(y + (int64_t)o * 32 + cg * 8) = pack_bf16x8(acc);
 }
 
-extern "C" int fx_stem_conv3x3s2(const void* x, int in_f32, const float* w, const float* bias, const float* mean, const float* inv_std,
-                                 void* y, int B, int H, int W, int Cout, fx_stream_t stream_) {
+static int stem_launch(const void* x, int in_f32, const float* w, const float* bias, const float* mean, const float* inv_std, void* y, int B,
+                       int H, int W, int Cout, int relu, fx_stream_t stream_) {
   FX_CHECK_ARG(x && w && bias && mean && inv_std && y && B > 0 && H > 0 && W > 0);
   if (Cout != 32) return FX_ERR_UNSUPPORTED;
   int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   int64_t total = (int64_t)B * Ho * Wo;
-  if (total >= (1ll << 31)) return FX_ERR_UNSUPPORTED;
   if (total * 4 >= (1ll << 31)) return FX_ERR_UNSUPPORTED;
   int grid = (int)((total * 4 + 255) / 256);
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (in_f32)
-    hipLaunchKernelGGL(stem_conv_kernel<float>, dim3(grid), dim3(256), 0, stream, (const float*)x, w, bias, mean, inv_std, (bf16_t*)y, B,
-                       H, W, Ho, Wo);
-  else
-    hipLaunchKernelGGL(stem_conv_kernel<uint8_t>, dim3(grid), dim3(256), 0, stream, (const uint8_t*)x, w, bias, mean, inv_std,
-                       (bf16_t*)y, B, H, W, Ho, Wo);
+#define STEM_GO(T, R) \
+  hipLaunchKernelGGL((stem_conv_kernel<T, R>), dim3(grid), dim3(256), 0, stream, (const T*)x, w, bias, mean, inv_std, (bf16_t*)y, B, H, W, Ho, Wo)
+  if (in_f32) {
+    if (relu) STEM_GO(float, true); else STEM_GO(float, false);
+  } else {
+    if (relu) STEM_GO(uint8_t, true); else STEM_GO(uint8_t, false);
+  }
+#undef STEM_GO
   return fx_launch_status();
+}
+
+extern "C" int fx_stem_conv3x3s2(const void* x, int in_f32, const float* w, const float* bias, const float* mean, const float* inv_std,
+                                 void* y, int B, int H, int W, int Cout, fx_stream_t stream_) {
+  return stem_launch(x, in_f32, w, bias, mean, inv_std, y, B, H, W, Cout, 1, stream_);
+}
+
+// The same convolution without the ReLU: the pre-BatchNorm tensor of the training path with batch statistics.
+extern "C" int fx_stem_conv3x3s2_linear(const void* x, int in_f32, const float* w, const float* bias, const float* mean, const float* inv_std,
+                                        void* y, int B, int H, int W, int Cout, fx_stream_t stream_) {
+  return stem_launch(x, in_f32, w, bias, mean, inv_std, y, B, H, W, Cout, 0, stream_);
 }
 
 // ------------------------------------------------------------------------------------------------

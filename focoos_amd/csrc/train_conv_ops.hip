@@ -261,3 +261,211 @@ extern "C" int fx_normalize_pad8(const void* img, int is_f32, const float* mean,
                      (bf16_t*)out, pixels);
   return fx_launch_status();
 }
+
+// ------------------------------------------------------------------------------------------------
+// Train-mode BatchNorm2d around the convolution (ConvNormLayer under model.train(), focoos/nn/layers/conv.py:78-98 with
+// nn.BatchNorm2d / SyncBatchNorm: batch statistics over (B, H, W) per channel).  NHWC bf16 activations [rows][C], fp32
+// statistics.  Four HBM-bound passes, each thread 8 channels x a strided set of rows:
+//   forward : fx_bn_stats_bf16  -> sums[c] = sum z, sums[C + c] = sum z^2           (host: all-reduce for SyncBN, mean / var)
+//             fx_bn_apply_bf16  -> y = act(z * scale[c] + shift[c] [+ residual])     scale = gamma * rstd, shift = beta - mean * scale
+//   backward: da = dy * act'(a), a = z * scale + shift (recomputed, nothing but z is kept from the forward)
+//             fx_bn_bwd_stats_bf16 -> sums[c] = sum da (= dbeta), sums[C + c] = sum da * xhat (= dgamma), xhat = (z - mean) * rstd
+//             fx_bn_bwd_apply_bf16 -> dz = scale * (da - sums[c] / n - xhat * sums[C + c] / n)   [and da itself for a residual branch]
+#define BN_ROWS 256
+__device__ __forceinline__ float bn_act_grad(float a, int act) {
+  switch (act) {
+    case FX_ACT_RELU: return a > 0.0f ? 1.0f : 0.0f;
+    case FX_ACT_SILU: {
+      const float s = 1.0f / (1.0f + __expf(-a));
+      return s * (1.0f + a * (1.0f - s));
+    }
+    case FX_ACT_GELU: return 0.5f * (1.0f + erff(a * 0.70710678118654752f)) + a * 0.3989422804014327f * __expf(-0.5f * a * a);
+    default: return 1.0f;
+  }
+}
+
+// shared column-reduction skeleton: 32 column groups x 8 row lanes per workgroup, BN_ROWS rows, two sums per channel
+template <int MODE>  // 0: (z, z^2)   1: (da, da * xhat)
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const bf16_t* __restrict__ z, int ldz, const bf16_t* __restrict__ dy, int lddy,
+                                                        const bf16_t* __restrict__ res, int ldr, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        const float* __restrict__ mean, const float* __restrict__ rstd, int act,
+                                                        float* __restrict__ sums, int64_t rows, int C) {
+  __shared__ float part[2][8][256];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c0 = blockIdx.x * 256 + cg * 8;
+  const int64_t r0 = (int64_t)blockIdx.y * BN_ROWS;
+  const int64_t r1 = r0 + BN_ROWS < rows ? r0 + BN_ROWS : rows;
+  float s0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c0 < C) {
+    float sc[8], sh[8], mu[8], rs[8];
+    if (MODE == 1) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sc[j] = scale[c0 + j], sh[j] = shift[c0 + j], mu[j] = mean[c0 + j], rs[j] = rstd[c0 + j];
+    }
+    for (int64_t r = r0 + rl; r < r1; r += 8) {
+      float v[8];
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(z + r * ldz + c0), v);
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s0[j] += v[j], s1[j] += v[j] * v[j];
+      } else {
+        float g[8], rr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unpack_bf16x8(*reinterpret_cast<const uint4*>(dy + r * lddy + c0), g);
+        if (res) unpack_bf16x8(*reinterpret_cast<const uint4*>(res + r * ldr + c0), rr);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float da = g[j] * bn_act_grad(v[j] * sc[j] + sh[j] + rr[j], act);
+          s0[j] += da;
+          s1[j] += da * (v[j] - mu[j]) * rs[j];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[0][rl][cg * 8 + j] = s0[j], part[1][rl][cg * 8 + j] = s1[j];
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < C) {
+    float a = 0.0f, b = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a += part[0][i][threadIdx.x], b += part[1][i][threadIdx.x];
+    unsafeAtomicAdd(sums + c, a);
+    unsafeAtomicAdd(sums + C + c, b);
+  }
+}
+
+extern "C" int fx_bn_stats_bf16(const void* z, int ldz, float* sums, int64_t rows, int C, fx_stream_t stream_) {
+  FX_CHECK_ARG(z && sums && rows > 0 && C > 0 && C % 8 == 0 && ldz >= C && ldz % 8 == 0);
+  hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3((C + 255) / 256, (unsigned)((rows + BN_ROWS - 1) / BN_ROWS)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)z, ldz, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, sums, rows, C);
+  return fx_launch_status();
+}
+
+extern "C" int fx_bn_bwd_stats_bf16(const void* dy, int lddy, const void* z, int ldz, const void* residual, int ldr, const float* scale,
+                                    const float* shift, const float* mean, const float* rstd, int act, float* sums, int64_t rows, int C,
+                                    fx_stream_t stream_) {
+  FX_CHECK_ARG(!residual || (ldr >= C && ldr % 8 == 0));
+  FX_CHECK_ARG(dy && z && scale && shift && mean && rstd && sums && rows > 0 && C > 0 && C % 8 == 0);
+  FX_CHECK_ARG(ldz >= C && lddy >= C && ldz % 8 == 0 && lddy % 8 == 0);
+  hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((C + 255) / 256, (unsigned)((rows + BN_ROWS - 1) / BN_ROWS)), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)z, ldz, (const bf16_t*)dy, lddy, (const bf16_t*)residual, ldr, scale, shift, mean, rstd, act, sums, rows, C);
+  return fx_launch_status();
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ z, int ldz, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, const bf16_t* __restrict__ res, int ldr, int act,
+                                                       bf16_t* __restrict__ y, int ldy, int64_t rows, int C8) {
+  const int64_t total = rows * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t r = i / C8;
+    float v[8];
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(z + r * ldz + c8 * 8), v);
+    const float4 s0 = *reinterpret_cast<const float4*>(scale + c8 * 8), s1 = *reinterpret_cast<const float4*>(scale + c8 * 8 + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(shift + c8 * 8), h1 = *reinterpret_cast<const float4*>(shift + c8 * 8 + 4);
+    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = v[j] * sc[j] + sh[j];
+    if (res) {
+      float rr[8];
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(res + r * ldr + c8 * 8), rr);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += rr[j];
+    }
+    if (act != FX_ACT_NONE) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = fx_act(v[j], act);
+    }
+    *reinterpret_cast<uint4*>(y + r * ldy + c8 * 8) = pack_bf16x8(v);
+  }
+}
+
+extern "C" int fx_bn_apply_bf16(const void* z, int ldz, const float* scale, const float* shift, const void* residual, int ldr, int act, void* y,
+                                int ldy, int64_t rows, int C, fx_stream_t stream_) {
+  FX_CHECK_ARG(z && scale && shift && y && rows > 0 && C > 0 && C % 8 == 0 && ldz >= C && ldy >= C && ldz % 8 == 0 && ldy % 8 == 0);
+  FX_CHECK_ARG(!residual || (ldr >= C && ldr % 8 == 0));
+  int64_t total = rows * (C / 8);
+  int64_t grid = (total + 255) / 256;
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)z, ldz, scale, shift,
+                     (const bf16_t*)residual, ldr, act, (bf16_t*)y, ldy, rows, C / 8);
+  return fx_launch_status();
+}
+
+// With a residual the activation input is a = z * scale + shift + residual; the residual is re-read rather than keeping a.
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ z, int ldz,
+                                                           const bf16_t* __restrict__ res, int ldr, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ mean, const float* __restrict__ rstd, int act,
+                                                           const float* __restrict__ sums, float inv_n, bf16_t* __restrict__ da_out, int ldda,
+                                                           bf16_t* __restrict__ dz, int lddz, int64_t rows, int C) {
+  const int C8 = C / 8;
+  const int64_t total = rows * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    const int64_t r = i / C8;
+    float v[8], g[8], o[8], d[8], rr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(z + r * ldz + c8 * 8), v);
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(dy + r * lddy + c8 * 8), g);
+    if (res) unpack_bf16x8(*reinterpret_cast<const uint4*>(res + r * ldr + c8 * 8), rr);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c8 * 8 + j;
+      const float sc = scale[c];
+      const float da = g[j] * bn_act_grad(v[j] * sc + shift[c] + rr[j], act);
+      const float xh = (v[j] - mean[c]) * rstd[c];
+      d[j] = da;
+      o[j] = sc * (da - sums[c] * inv_n - xh * sums[C + c] * inv_n);
+    }
+    if (da_out) *reinterpret_cast<uint4*>(da_out + r * ldda + c8 * 8) = pack_bf16x8(d);
+    *reinterpret_cast<uint4*>(dz + r * lddz + c8 * 8) = pack_bf16x8(o);
+  }
+}
+
+extern "C" int fx_bn_bwd_apply_bf16(const void* dy, int lddy, const void* z, int ldz, const void* residual, int ldr, const float* scale,
+                                    const float* shift, const float* mean, const float* rstd, int act, const float* sums, float inv_n,
+                                    void* da_out, int ldda, void* dz, int lddz, int64_t rows, int C, fx_stream_t stream_) {
+  FX_CHECK_ARG(!residual || (ldr >= C && ldr % 8 == 0));
+  FX_CHECK_ARG(dy && z && scale && shift && mean && rstd && sums && dz && rows > 0 && C > 0 && C % 8 == 0);
+  FX_CHECK_ARG(ldz >= C && lddy >= C && lddz >= C && ldz % 8 == 0 && lddy % 8 == 0 && lddz % 8 == 0 && (!da_out || (ldda >= C && ldda % 8 == 0)));
+  int64_t total = rows * (C / 8);
+  int64_t grid = (total + 255) / 256;
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)dy, lddy,
+                     (const bf16_t*)z, ldz, (const bf16_t*)residual, ldr, scale, shift, mean, rstd, act, sums, inv_n, (bf16_t*)da_out, ldda, (bf16_t*)dz, lddz,
+                     rows, C);
+  return fx_launch_status();
+}
+
+// Per-channel epilogue of the forward statistics (one launch instead of a dozen tiny tensor ops): batch mean / biased
+// variance from the (all-reduced) sums, the affine that fx_bn_apply_bf16 uses, and the running-statistics update of
+// nn.BatchNorm2d (momentum, unbiased variance; num_batches_tracked += 1).
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ sums, float n, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, float momentum,
+                                                          float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                          int64_t* __restrict__ num_batches_tracked, float* __restrict__ mean,
+                                                          float* __restrict__ rstd, float* __restrict__ scale, float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  if (c >= C) return;
+  const float m = sums[c] / n;
+  const float var = fmaxf(sums[C + c] / n - m * m, 0.0f);
+  const float r = rsqrtf(var + eps);
+  const float sc = gamma[c] * r;
+  mean[c] = m;
+  rstd[c] = r;
+  scale[c] = sc;
+  shift[c] = beta[c] - m * sc;
+  if (running_mean) {
+    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * m;
+    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * var * (n > 1.0f ? n / (n - 1.0f) : 1.0f);
+  }
+}
+
+extern "C" int fx_bn_finalize_f32(const float* sums, float n, const float* gamma, const float* beta, float eps, float momentum,
+                                  float* running_mean, float* running_var, int64_t* num_batches_tracked, float* mean, float* rstd, float* scale,
+                                  float* shift, int C, fx_stream_t stream_) {
+  FX_CHECK_ARG(sums && gamma && beta && mean && rstd && scale && shift && C > 0 && n > 0.0f && (!running_mean == !running_var));
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), sums, n, gamma, beta, eps,
+                     momentum, running_mean, running_var, num_batches_tracked, mean, rstd, scale, shift, C);
+  return fx_launch_status();
+}

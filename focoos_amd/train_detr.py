@@ -269,7 +269,10 @@ class FAIDetrTrainable(nn.Module):
     """Reference-compatible parameter tree (``pixel_decoder.backbone.*``, ``pixel_decoder.*``, ``head.predictor.*``,
     ``head.criterion.empty_weight``) whose forward(images, targets) returns the dict of weighted losses."""
 
-    def __init__(self, config: Dict):
+    def __init__(self, config: Dict, norm: str = "FrozenBN"):
+        """``norm``: "FrozenBN" (the reference's freeze_bn: running statistics, fixed affine), "BN" (batch statistics under
+        .train(), trainable affine, running-statistics updates) or "SyncBN" (BN with the statistics all-reduced over the
+        data-parallel group - what the reference converts to for multi-GPU training)."""
         super().__init__()
         if not torch.cuda.is_available():
             raise _lib.FocoosAmdError("focoos_amd needs a ROCm GPU (gfx950); no CPU fallback exists")
@@ -283,6 +286,8 @@ class FAIDetrTrainable(nn.Module):
         self.head.criterion = SetCriterionTrain(nc)
         self.head.predictor = TransformerPredictor(lib, nc, nq=int(config.get("num_queries", 300)), nl=int(config.get("transformer_predictor_dec_layers", 6)),
                                                    ffn=int(config.get("transformer_predictor_dim_feedforward", 1024)))
+        from .train_nn import set_norm_mode
+        set_norm_mode(self, norm)
 
     def forward(self, images: torch.Tensor, targets: Sequence, forced_topk=None, fixed_matches=None):
         f = self.pixel_decoder.backbone(images)

@@ -122,27 +122,132 @@ class _ConvBnActFn(torch.autograd.Function):
             dz = dy
         else:
             dz = _act_bwd(lib, dy, y, layer.act)  # `y` holds the saved pre-activation here
-        dx = None
-        if ctx.needs_input_grad[0]:
-            if layer.stride == 1:
-                src = dz
-            else:  # stride 2: zero-insert, then the stride-1 transposed filter
-                src = torch.empty(B, H, W_, N, dtype=torch.bfloat16, device=dev)
-                check(lib.fx_zero_insert2_nhwc_bf16(dz.data_ptr(), N, src.data_ptr(), N, B, Ho, Wo, H, W_, N, st), "fx_zero_insert2_nhwc_bf16")
-            dx = _conv_call(lib, src, layer.w_dgrad, None, Cc, layer.k, layer.k, 1, layer.pad, None, None)
-        dw = None
-        if ctx.needs_input_grad[1]:
-            dw_eff = ARENA.zeros((N, layer.k, layer.k, Cc), dev)
-            check(lib.fx_conv2d_wgrad_nhwc_bf16(x.data_ptr(), Cc, dz.data_ptr(), N, dw_eff.data_ptr(), B, H, W_, Cc, Ho, Wo, N, layer.k, layer.k,
-                                                layer.stride, layer.pad, st), "fx_conv2d_wgrad_nhwc_bf16")
-            wparam = layer._conv_h.weight
-            direct = DIRECT_GRAD[0] and wparam.grad is not None
-            dw = wparam.grad if direct else torch.empty(N, Cc, layer.k, layer.k, dtype=torch.float32, device=dev)
-            check(lib.fx_unpack_conv_wgrad_f32(dw_eff.data_ptr(), layer.scale.data_ptr(), dw.data_ptr(), N, Cc, layer.k, layer.k, Cc, int(direct), st),
-                  "fx_unpack_conv_wgrad_f32")
-            if direct:
-                dw = None
+        dx = _conv_input_grad(layer, dz, x.shape) if ctx.needs_input_grad[0] else None
+        dw = _conv_param_grads(layer, x, dz, layer.scale) if ctx.needs_input_grad[1] else None
         return dx, dw, (dz if ctx.has_res else None), None
+
+
+BN_MOMENTUM = 0.1
+
+
+def _bn_sync_group(layer):
+    """SyncBatchNorm semantics (norm "SyncBN"): statistics are summed over the data-parallel group (RCCL all-reduce of one
+    [2][C] fp32 vector per layer and direction).  Per-rank row counts are equal by construction (fixed-shape batches)."""
+    if layer.norm_mode != "SyncBN":
+        return 1
+    import torch.distributed as dist
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _bn_forward(layer, z: torch.Tensor, residual: Optional[torch.Tensor]):
+    """Batch-statistics BatchNorm + activation on the conv output z [B,Ho,Wo,N]: returns (y, stats[4][N] = mean/rstd/scale/shift, n)."""
+    lib, dev = layer.lib, z.device
+    N = z.shape[-1]
+    rows = z.numel() // N
+    st = _stream(dev)
+    sums = ARENA.zeros((2, N), dev)
+    check(lib.fx_bn_stats_bf16(z.data_ptr(), N, sums.data_ptr(), rows, N, st), "fx_bn_stats_bf16")
+    world = _bn_sync_group(layer)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(sums)
+    n = float(rows * world)
+    norm = layer._norm_h
+    stats = torch.empty(4, N, dtype=torch.float32, device=dev)
+    check(lib.fx_bn_finalize_f32(sums.data_ptr(), n, norm.weight.data_ptr(), norm.bias.data_ptr(), BN_EPS, BN_MOMENTUM,
+                                 norm.running_mean.data_ptr(), norm.running_var.data_ptr(), norm.num_batches_tracked.data_ptr(),
+                                 stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), N, st), "fx_bn_finalize_f32")
+    y = torch.empty_like(z)
+    check(lib.fx_bn_apply_bf16(z.data_ptr(), N, stats[2].data_ptr(), stats[3].data_ptr(), residual.data_ptr() if residual is not None else None, N,
+                               FX_ACT[layer.act], y.data_ptr(), N, rows, N, st), "fx_bn_apply_bf16")
+    return y, stats, n
+
+
+def _bn_backward(layer, dy: torch.Tensor, z: torch.Tensor, residual: Optional[torch.Tensor], stats: torch.Tensor, n: float, want_affine: bool):
+    """Returns (dz, da or None): dz = gradient of the conv output, da = gradient of the residual branch.  The affine
+    gradients (dgamma = sum da * xhat, dbeta = sum da; LOCAL sums, data parallelism averages them later) are added to
+    ``norm.weight.grad`` / ``norm.bias.grad`` in place when those exist, else returned through ``layer._affine_grads``."""
+    lib, dev = layer.lib, z.device
+    N = z.shape[-1]
+    rows = z.numel() // N
+    st = _stream(dev)
+    rp = residual.data_ptr() if residual is not None else None
+    sums = ARENA.zeros((2, N), dev)
+    check(lib.fx_bn_bwd_stats_bf16(dy.data_ptr(), N, z.data_ptr(), N, rp, N, stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(),
+                                   stats[1].data_ptr(), FX_ACT[layer.act], sums.data_ptr(), rows, N, st), "fx_bn_bwd_stats_bf16")
+    local = sums
+    if _bn_sync_group(layer) > 1:
+        import torch.distributed as dist
+        local = sums.clone()
+        dist.all_reduce(sums)
+    dz = torch.empty_like(z)
+    da = torch.empty_like(z) if residual is not None else None
+    check(lib.fx_bn_bwd_apply_bf16(dy.data_ptr(), N, z.data_ptr(), N, rp, N, stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(),
+                                   stats[1].data_ptr(), FX_ACT[layer.act], sums.data_ptr(), 1.0 / n, da.data_ptr() if da is not None else None, N,
+                                   dz.data_ptr(), N, rows, N, st), "fx_bn_bwd_apply_bf16")
+    dgamma = dbeta = None
+    if want_affine:
+        norm = layer._norm_h
+        if DIRECT_GRAD[0] and norm.weight.grad is not None and norm.bias.grad is not None:
+            norm.weight.grad.add_(local[1])
+            norm.bias.grad.add_(local[0])
+        else:
+            dgamma, dbeta = local[1].clone(), local[0].clone()
+    return dz, da, dgamma, dbeta
+
+
+def _conv_param_grads(layer, x: torch.Tensor, dz: torch.Tensor, scale: Optional[torch.Tensor]):
+    """Weight gradient of the layer's conv: MFMA wgrad into the [N][k][k][C] staging image, then (scaled) unpack into the
+    master layout - straight into ``weight.grad`` when the optimizer's flat views are installed."""
+    lib, dev = layer.lib, x.device
+    B, H, W_, Cc = x.shape
+    _, Ho, Wo, N = dz.shape
+    st = _stream(dev)
+    dw_eff = ARENA.zeros((N, layer.k, layer.k, Cc), dev)
+    check(lib.fx_conv2d_wgrad_nhwc_bf16(x.data_ptr(), Cc, dz.data_ptr(), N, dw_eff.data_ptr(), B, H, W_, Cc, Ho, Wo, N, layer.k, layer.k,
+                                        layer.stride, layer.pad, st), "fx_conv2d_wgrad_nhwc_bf16")
+    wparam = layer._conv_h.weight
+    direct = DIRECT_GRAD[0] and wparam.grad is not None
+    dw = wparam.grad if direct else torch.empty(N, Cc, layer.k, layer.k, dtype=torch.float32, device=dev)
+    check(lib.fx_unpack_conv_wgrad_f32(dw_eff.data_ptr(), scale.data_ptr() if scale is not None else None, dw.data_ptr(), N, Cc, layer.k, layer.k, Cc,
+                                       int(direct), st), "fx_unpack_conv_wgrad_f32")
+    return None if direct else dw
+
+
+def _conv_input_grad(layer, dz: torch.Tensor, x_shape) -> torch.Tensor:
+    lib, dev = layer.lib, dz.device
+    B, H, W_, Cc = x_shape
+    _, Ho, Wo, N = dz.shape
+    if layer.stride == 1:
+        src = dz
+    else:  # stride 2: zero-insert, then the stride-1 transposed filter
+        src = torch.empty(B, H, W_, N, dtype=torch.bfloat16, device=dev)
+        check(lib.fx_zero_insert2_nhwc_bf16(dz.data_ptr(), N, src.data_ptr(), N, B, Ho, Wo, H, W_, N, _stream(dev)), "fx_zero_insert2_nhwc_bf16")
+    return _conv_call(lib, src, layer.w_dgrad, None, Cc, layer.k, layer.k, 1, layer.pad, None, None)
+
+
+class _ConvBnTrainFn(torch.autograd.Function):
+    """ConvNormLayer under model.train() with a live BatchNorm (norm "BN" / "SyncBN"): z = conv(x, W);
+    y = act(gamma * (z - mean_batch) * rstd_batch + beta [+ residual]); running statistics updated in place."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, layer: "ConvNormLayer"):
+        layer.sync_packed()
+        N, Cc, KH, KW = weight.shape
+        z = _conv_call(layer.lib, x, layer.w_fwd, None, N, KH, KW, layer.stride, layer.pad, None, None)
+        y, stats, n = _bn_forward(layer, z, residual)
+        ctx.layer, ctx.n = layer, n
+        ctx.save_for_backward(x, z, residual, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        layer: ConvNormLayer = ctx.layer
+        x, z, residual, stats = ctx.saved_tensors
+        dz, da, dgamma, dbeta = _bn_backward(layer, dy.contiguous(), z, residual, stats, ctx.n, ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        dx = _conv_input_grad(layer, dz, x.shape) if ctx.needs_input_grad[0] else None
+        dw = _conv_param_grads(layer, x, dz, None) if ctx.needs_input_grad[1] else None
+        return dx, dw, dgamma, dbeta, da, None
 
 
 class _Holder(nn.Module):
@@ -150,7 +255,12 @@ class _Holder(nn.Module):
 
 
 class ConvNormLayer(nn.Module):
-    """focoos/nn/layers/conv.py:78-98 — conv (no bias) + BatchNorm2d (frozen here) + activation."""
+    """focoos/nn/layers/conv.py:78-98 — conv (no bias) + BatchNorm2d + activation.  ``norm_mode`` (set for the whole model by
+    ``set_norm_mode``): "FrozenBN" = running statistics folded into the conv, affine fixed (the reference's freeze_bn /
+    FrozenBatchNorm2d); "BN" / "SyncBN" = batch statistics under ``.train()`` with trainable affine and running-statistics
+    updates (SyncBN: statistics all-reduced over the data-parallel group), running statistics under ``.eval()``."""
+
+    norm_mode = "FrozenBN"
 
     def __init__(self, lib, cin: int, cout: int, k: int, stride: int = 1, act: Optional[str] = None, names=("conv", "norm")):
         super().__init__()
@@ -170,29 +280,62 @@ class ConvNormLayer(nn.Module):
         self._packed_version = None
         self.w_fwd = self.w_dgrad = self.scale = self.shift = None
 
+    @property
+    def batch_stats(self) -> bool:
+        return self.training and self.norm_mode != "FrozenBN"
+
+    def _fold_norm(self):
+        """scale = gamma / sqrt(running_var + eps), shift = beta - running_mean * scale; recomputed only when the norm tensors
+        can have changed (they are constants for FrozenBN, so the per-step weight repack skips these small launches)."""
+        norm = self._norm_h
+        ver = (norm.weight._version, norm.bias._version, norm.running_var._version, norm.running_mean._version, norm.weight.device,
+               WEIGHTS_EPOCH[0] if self.norm_mode != "FrozenBN" else -1)
+        if ver == getattr(self, "_norm_version", None):
+            return
+        self.scale = (norm.weight.double() / torch.sqrt(norm.running_var.double() + BN_EPS)).float().contiguous()
+        self._shift_n = (norm.bias.double() - norm.running_mean.double() * self.scale.double()).float().contiguous()
+        self._norm_version = ver
+
     def sync_packed(self):
-        """(Re)build the bf16 weight images when the master weight changed (optimizer step, load_state_dict)."""
+        """(Re)build the bf16 weight images when the master weight changed (optimizer step, load_state_dict).  With batch
+        statistics the images hold the plain weights (the normalisation is a separate pass); otherwise BN is folded in."""
         w = self._conv_h.weight
-        ver = (w._version, self._norm_h.weight._version, self._norm_h.running_var._version, w.device, WEIGHTS_EPOCH[0])
+        live = self.batch_stats
+        ver = (w._version, self._norm_h.weight._version, self._norm_h.running_var._version, w.device, WEIGHTS_EPOCH[0], live)
         if ver == self._packed_version:
             return
         dev = w.device
         N, Cc, k = self.cout, self.cin, self.k
         with torch.no_grad():
-            self.scale = (self._norm_h.weight.double() / torch.sqrt(self._norm_h.running_var.double() + BN_EPS)).float().contiguous()
-            shift = (self._norm_h.bias.double() - self._norm_h.running_mean.double() * self.scale.double()).float()
+            self._fold_norm()
+            shift = self._shift_n
             Np, Cp = (N + 127) // 128 * 128, (Cc + 127) // 128 * 128
             self.shift = torch.zeros(Np, dtype=torch.float32, device=dev)
             self.shift[:N] = shift
             if self.w_fwd is None or self.w_fwd.device != dev:
                 self.w_fwd = torch.zeros(Np, k, k, Cc, dtype=torch.bfloat16, device=dev)
                 self.w_dgrad = torch.zeros(Cp, k, k, N, dtype=torch.bfloat16, device=dev)
-            check(self.lib.fx_pack_conv_weights_f32(w.data_ptr(), self.scale.data_ptr(), self.w_fwd.data_ptr(), self.w_dgrad.data_ptr(), N, Cc, k, k,
-                                                    _stream(dev)), "fx_pack_conv_weights_f32")
+            check(self.lib.fx_pack_conv_weights_f32(w.data_ptr(), None if live else self.scale.data_ptr(), self.w_fwd.data_ptr(),
+                                                    self.w_dgrad.data_ptr(), N, Cc, k, k, _stream(dev)), "fx_pack_conv_weights_f32")
         self._packed_version = ver
 
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        if self.batch_stats:
+            return _ConvBnTrainFn.apply(x, self._conv_h.weight, self._norm_h.weight, self._norm_h.bias, residual, self)
         return _ConvBnActFn.apply(x, self._conv_h.weight, residual, self)
+
+
+def set_norm_mode(module: nn.Module, mode: str) -> nn.Module:
+    """Model-wide BatchNorm behaviour: "FrozenBN" (freeze_bn), "BN", or "SyncBN" (the reference converts BN -> SyncBN for
+    multi-GPU runs, focoos/trainer/trainer.py:175-178).  The affine parameters train only with live statistics."""
+    if mode not in ("FrozenBN", "BN", "SyncBN"):
+        raise ValueError(f"unknown norm mode {mode!r}")
+    for m in module.modules():
+        if isinstance(m, ConvNormLayer):
+            m.norm_mode = mode
+            m._norm_h.weight.requires_grad_(mode != "FrozenBN")
+            m._norm_h.bias.requires_grad_(mode != "FrozenBN")
+    return module
 
 
 class _StemFn(torch.autograd.Function):
@@ -225,15 +368,48 @@ class _StemFn(torch.autograd.Function):
         dy = dy.contiguous()
         dz = torch.empty_like(y)
         check(lib.fx_relu_bwd_bf16(dy.data_ptr(), 32, None, 0, y.data_ptr(), 32, dz.data_ptr(), 32, B * Ho * Wo, 32, 1, st), "fx_relu_bwd_bf16")
-        xn = torch.empty(B, H, W_, 8, dtype=torch.bfloat16, device=dev)
-        check(lib.fx_normalize_pad8(images.data_ptr(), int(images.dtype == torch.float32), layer.px_mean.data_ptr(), layer.px_inv_std.data_ptr(),
-                                    xn.data_ptr(), B * H * W_, st), "fx_normalize_pad8")
-        dw_eff = ARENA.zeros((32, 3, 3, 8), dev)
-        check(lib.fx_conv2d_wgrad_nhwc_bf16(xn.data_ptr(), 8, dz.data_ptr(), 32, dw_eff.data_ptr(), B, H, W_, 8, Ho, Wo, 32, 3, 3, 2, 1, st),
-              "fx_conv2d_wgrad_nhwc_bf16")
-        dw = torch.empty(32, 3, 3, 3, dtype=torch.float32, device=dev)
-        check(lib.fx_unpack_conv_wgrad_f32(dw_eff.data_ptr(), layer.scale.data_ptr(), dw.data_ptr(), 32, 3, 3, 3, 8, 0, st), "fx_unpack_conv_wgrad_f32")
-        return None, dw, None
+        return None, _stem_wgrad(layer, images, dz, layer.scale), None
+
+
+class _StemTrainFn(torch.autograd.Function):
+    """conv1_1 with batch statistics: the un-normalised conv through fx_stem_conv3x3s2_linear, then the BatchNorm passes."""
+
+    @staticmethod
+    def forward(ctx, images, weight, gamma, beta, layer: "StemConv"):
+        lib = layer.lib
+        layer.sync_packed()
+        B, H, W_, _ = images.shape
+        z = torch.empty(B, H // 2, W_ // 2, 32, dtype=torch.bfloat16, device=images.device)
+        check(lib.fx_stem_conv3x3s2_linear(images.data_ptr(), int(images.dtype == torch.float32), layer.stem_w.data_ptr(), layer.stem_b.data_ptr(),
+                                           layer.px_mean.data_ptr(), layer.px_inv_std.data_ptr(), z.data_ptr(), B, H, W_, 32,
+                                           _stream(images.device)), "fx_stem_conv3x3s2_linear")
+        y, stats, n = _bn_forward(layer, z, None)
+        ctx.layer, ctx.n = layer, n
+        ctx.save_for_backward(images, z, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        layer: StemConv = ctx.layer
+        images, z, stats = ctx.saved_tensors
+        dz, _, dgamma, dbeta = _bn_backward(layer, dy.contiguous(), z, None, stats, ctx.n, ctx.needs_input_grad[2] or ctx.needs_input_grad[3])
+        return None, _stem_wgrad(layer, images, dz, None), dgamma, dbeta, None
+
+
+def _stem_wgrad(layer, images, dz, scale):
+    lib, dev = layer.lib, images.device
+    B, H, W_, _ = images.shape
+    st = _stream(dev)
+    xn = torch.empty(B, H, W_, 8, dtype=torch.bfloat16, device=dev)
+    check(lib.fx_normalize_pad8(images.data_ptr(), int(images.dtype == torch.float32), layer.px_mean.data_ptr(), layer.px_inv_std.data_ptr(),
+                                xn.data_ptr(), B * H * W_, st), "fx_normalize_pad8")
+    dw_eff = ARENA.zeros((32, 3, 3, 8), dev)
+    check(lib.fx_conv2d_wgrad_nhwc_bf16(xn.data_ptr(), 8, dz.data_ptr(), 32, dw_eff.data_ptr(), B, H, W_, 8, H // 2, W_ // 2, 32, 3, 3, 2, 1, st),
+          "fx_conv2d_wgrad_nhwc_bf16")
+    dw = torch.empty(32, 3, 3, 3, dtype=torch.float32, device=dev)
+    check(lib.fx_unpack_conv_wgrad_f32(dw_eff.data_ptr(), scale.data_ptr() if scale is not None else None, dw.data_ptr(), 32, 3, 3, 3, 8, 0, st),
+          "fx_unpack_conv_wgrad_f32")
+    return dw
 
 
 class StemConv(ConvNormLayer):
@@ -245,16 +421,23 @@ class StemConv(ConvNormLayer):
 
     def sync_packed(self):
         w = self._conv_h.weight
-        ver = (w._version, w.device, WEIGHTS_EPOCH[0])
+        live = self.batch_stats
+        ver = (w._version, self._norm_h.weight._version, self._norm_h.running_var._version, w.device, WEIGHTS_EPOCH[0], live)
         if ver == self._packed_version:
             return
         with torch.no_grad():
-            self.scale = (self._norm_h.weight.double() / torch.sqrt(self._norm_h.running_var.double() + BN_EPS)).float().contiguous()
-            self.stem_b = (self._norm_h.bias.double() - self._norm_h.running_mean.double() * self.scale.double()).float().contiguous()
-            self.stem_w = (w * self.scale.view(-1, 1, 1, 1)).permute(2, 3, 1, 0).contiguous()  # [kh][kw][c][n] fp32 (tiny: 864 values)
+            self._fold_norm()
+            if live:
+                self.stem_b = torch.zeros(32, dtype=torch.float32, device=w.device)
+                self.stem_w = w.permute(2, 3, 1, 0).contiguous()
+            else:
+                self.stem_b = self._shift_n
+                self.stem_w = (w * self.scale.view(-1, 1, 1, 1)).permute(2, 3, 1, 0).contiguous()  # [kh][kw][c][n] fp32 (tiny: 864 values)
         self._packed_version = ver
 
     def forward(self, images: torch.Tensor) -> torch.Tensor:  # type: ignore[override]
+        if self.batch_stats:
+            return _StemTrainFn.apply(images, self._conv_h.weight, self._norm_h.weight, self._norm_h.bias, self)
         return _StemFn.apply(images, self._conv_h.weight, self)
 
 

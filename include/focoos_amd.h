@@ -286,6 +286,33 @@ int fx_maxpool3x3s2_bwd_nhwc_bf16(const void* x, int ldx, const void* dy, int ld
 /* (img - mean) * inv_std as bf16 NHWC with the 3 channels padded to 8: the stem conv's input for its weight gradient. */
 int fx_normalize_pad8(const void* img, int is_f32, const float* mean, const float* inv_std, void* out, int64_t pixels, fx_stream_t stream);
 
+/* The stem convolution without its ReLU (pre-BatchNorm tensor of the batch-statistics training path). */
+int fx_stem_conv3x3s2_linear(const void* x, int in_f32, const float* w, const float* bias, const float* mean, const float* inv_std, void* y,
+                             int B, int H, int W, int Cout, fx_stream_t stream);
+
+/* ---- train-mode BatchNorm2d (batch statistics; nn.BatchNorm2d / SyncBatchNorm of ConvNormLayer under model.train(),
+ * focoos/nn/layers/conv.py:78-98, focoos/nn/layers/norm.py get_norm) on NHWC bf16 [rows][C] with fp32 statistics.
+ *   forward : fx_bn_stats_bf16 ACCUMULATES sums[c] += sum_r z, sums[C + c] += sum_r z^2 (zero `sums` first; all-reduce it
+ *             across ranks for SyncBN) -> fx_bn_finalize_f32(sums, n) writes mean, rstd, scale = gamma * rstd,
+ *             shift = beta - mean * scale and updates running_mean / running_var (unbiased) / num_batches_tracked (any of
+ *             the three may be NULL) -> fx_bn_apply_bf16: y = act(z * scale + shift [+ residual]).
+ *   backward: da = dy * act'(z * scale + shift [+ residual]);  fx_bn_bwd_stats_bf16 ACCUMULATES sums[c] += sum da (= dbeta),
+ *             sums[C + c] += sum da * xhat (= dgamma), xhat = (z - mean) * rstd; (all-reduce for SyncBN);
+ *             fx_bn_bwd_apply_bf16: dz = scale * (da - sums[c] * inv_n - xhat * sums[C + c] * inv_n); da_out (optional) = da,
+ *             the gradient of the residual branch. */
+int fx_bn_stats_bf16(const void* z, int ldz, float* sums, int64_t rows, int C, fx_stream_t stream);
+int fx_bn_finalize_f32(const float* sums, float n, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                       float* running_var, int64_t* num_batches_tracked, float* mean, float* rstd, float* scale, float* shift, int C,
+                       fx_stream_t stream);
+int fx_bn_apply_bf16(const void* z, int ldz, const float* scale, const float* shift, const void* residual, int ldr, int act, void* y, int ldy,
+                     int64_t rows, int C, fx_stream_t stream);
+int fx_bn_bwd_stats_bf16(const void* dy, int lddy, const void* z, int ldz, const void* residual, int ldr, const float* scale,
+                         const float* shift, const float* mean, const float* rstd, int act, float* sums, int64_t rows, int C,
+                         fx_stream_t stream);
+int fx_bn_bwd_apply_bf16(const void* dy, int lddy, const void* z, int ldz, const void* residual, int ldr, const float* scale,
+                         const float* shift, const float* mean, const float* rstd, int act, const float* sums, float inv_n, void* da_out,
+                         int ldda, void* dz, int lddz, int64_t rows, int C, fx_stream_t stream);
+
 /* ---- training path, token-space layers (A17): correctness-first fp32-math kernels ----------------------------------
  * Activation on a saved pre-activation z (FX_ACT_RELU/SILU/GELU): y = act(z); dz = dy * act'(z). */
 int fx_act_fwd_bf16(const void* z, int ldz, void* y, int ldy, int64_t rows, int cols, int act, fx_stream_t stream);

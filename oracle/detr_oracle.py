@@ -32,6 +32,16 @@ RESNET_BLOCKS = {50: [3, 4, 6, 3], 101: [3, 4, 23, 3]}  # focoos/nn/backbone/res
 
 
 # ----------------------------------------------------------------------------- building blocks
+# nn.BatchNorm2d's mode: False = running statistics (eval / freeze_bn), True = batch statistics with the in-place
+# running-statistics update (model.train(); used by the training oracle only - see oracle/train_oracle.py).
+BN_TRAINING = [False]
+
+
+def batch_norm(sd: SD, prefix: str, y: torch.Tensor) -> torch.Tensor:
+    return F.batch_norm(y, sd[f"{prefix}.running_mean"], sd[f"{prefix}.running_var"], sd[f"{prefix}.weight"], sd[f"{prefix}.bias"],
+                        training=BN_TRAINING[0], momentum=0.1, eps=1e-5)
+
+
 def conv_bn(sd: SD, prefix: str, x: torch.Tensor, stride: int = 1, act: Optional[str] = None,
             conv: str = "conv", norm: str = "norm", padding: Optional[int] = None) -> torch.Tensor:
     """ConvNormLayer.forward — focoos/nn/layers/conv.py:78-98 (conv, BN eval, act)."""
@@ -39,8 +49,7 @@ def conv_bn(sd: SD, prefix: str, x: torch.Tensor, stride: int = 1, act: Optional
     k = w.shape[-1]
     pad = (k - 1) // 2 if padding is None else padding
     y = F.conv2d(x, w, None, stride=stride, padding=pad)
-    y = F.batch_norm(y, sd[f"{prefix}.{norm}.running_mean"], sd[f"{prefix}.{norm}.running_var"],
-                     sd[f"{prefix}.{norm}.weight"], sd[f"{prefix}.{norm}.bias"], training=False, eps=1e-5)
+    y = batch_norm(sd, f"{prefix}.{norm}", y)
     return apply_act(y, act)
 
 
@@ -176,8 +185,7 @@ def hybrid_encoder(sd: SD, feats: List[torch.Tensor], cfg: Dict, collect: Option
     proj = []
     for i, f in enumerate(feats):
         y = F.conv2d(f, sd[f"{P}.input_proj.{i}.0.weight"])
-        y = F.batch_norm(y, sd[f"{P}.input_proj.{i}.1.running_mean"], sd[f"{P}.input_proj.{i}.1.running_var"],
-                         sd[f"{P}.input_proj.{i}.1.weight"], sd[f"{P}.input_proj.{i}.1.bias"], False, 0.0, 1e-5)
+        y = batch_norm(sd, f"{P}.input_proj.{i}.1", y)
         proj.append(y)
     n_enc = int(cfg.get("pixel_decoder_num_encoder_layers", 1))
     if n_enc > 0:

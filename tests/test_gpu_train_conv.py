@@ -322,3 +322,119 @@ def test_backbone_plus_hybrid_encoder_backward_vs_torch_autograd():
     bad = [(round(e, 4), nm) for e, nm in errs if e > 8e-2]
     print(f"{n} parameter tensors, worst gradient rel-L2 {worst:.4f}")
     assert not bad, bad
+
+
+@pytest.mark.parametrize("act,with_res,C,rows_shape", [("relu", True, 64, (3, 9, 11)), ("silu", True, 256, (2, 5, 7)), (None, False, 24, (4, 33, 17)),
+                                                        ("gelu", False, 520, (1, 6, 5))])
+def test_batchnorm_train_kernels(lib, act, with_res, C, rows_shape):
+    """fx_bn_stats / finalize / apply and fx_bn_bwd_stats / apply vs torch fp32 autograd of
+    act(F.batch_norm(z, training=True) [+ residual]) on the same bf16-rounded inputs."""
+    from focoos_amd._lib import FX_ACT
+
+    g = torch.Generator().manual_seed(C)
+    Bn, H, W_ = rows_shape
+    rows = Bn * H * W_
+    z = (torch.randn(Bn, H, W_, C, generator=g) * (torch.rand(C, generator=g) * 3 + 0.2) + torch.randn(C, generator=g)).bfloat16()
+    res = torch.randn(Bn, H, W_, C, generator=g).bfloat16() if with_res else None
+    dy = torch.randn(Bn, H, W_, C, generator=g).bfloat16()
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    rm, rv = torch.randn(C, generator=g), torch.rand(C, generator=g) + 0.5
+    # reference
+    zt = z.float().permute(0, 3, 1, 2).requires_grad_(True)
+    gt, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    a = F.batch_norm(zt, rm_ref, rv_ref, gt, bt, training=True, momentum=0.1, eps=1e-5)
+    rt = None
+    if with_res:
+        rt = res.float().permute(0, 3, 1, 2).requires_grad_(True)
+        a = a + rt
+    yt = {"relu": F.relu, "silu": F.silu, "gelu": F.gelu, None: lambda t: t}[act](a)
+    yt.backward(dy.float().permute(0, 3, 1, 2))
+    # kernels
+    st = stream()
+    zd, dyd = z.to(DEV), dy.to(DEV)
+    rd = res.to(DEV) if with_res else None
+    sums = torch.zeros(2, C, device=DEV)
+    check(lib.fx_bn_stats_bf16(zd.data_ptr(), C, sums.data_ptr(), rows, C, st))
+    stats = torch.empty(4, C, device=DEV)
+    gd, bd, rmd, rvd = gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV)
+    nbt = torch.zeros((), dtype=torch.long, device=DEV)
+    check(lib.fx_bn_finalize_f32(sums.data_ptr(), float(rows), gd.data_ptr(), bd.data_ptr(), 1e-5, 0.1, rmd.data_ptr(), rvd.data_ptr(), nbt.data_ptr(),
+                                 stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), C, st))
+    y = torch.empty_like(zd)
+    rp = rd.data_ptr() if with_res else None
+    check(lib.fx_bn_apply_bf16(zd.data_ptr(), C, stats[2].data_ptr(), stats[3].data_ptr(), rp, C, FX_ACT[act], y.data_ptr(), C, rows, C, st))
+    bs = torch.zeros(2, C, device=DEV)
+    check(lib.fx_bn_bwd_stats_bf16(dyd.data_ptr(), C, zd.data_ptr(), C, rp, C, stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(),
+                                   stats[1].data_ptr(), FX_ACT[act], bs.data_ptr(), rows, C, st))
+    dz = torch.empty_like(zd)
+    da = torch.empty_like(zd) if with_res else None
+    check(lib.fx_bn_bwd_apply_bf16(dyd.data_ptr(), C, zd.data_ptr(), C, rp, C, stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(),
+                                   stats[1].data_ptr(), FX_ACT[act], bs.data_ptr(), 1.0 / rows, da.data_ptr() if with_res else None, C, dz.data_ptr(), C,
+                                   rows, C, st))
+    torch.cuda.synchronize()
+    assert int(nbt) == 1
+    np.testing.assert_allclose(rmd.cpu().numpy(), rm_ref.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(rvd.cpu().numpy(), rv_ref.numpy(), rtol=1e-4, atol=1e-5)
+    nhwc = lambda t: t.detach().permute(0, 2, 3, 1)
+    assert (y.float().cpu() - nhwc(yt)).abs().max() <= 2e-2 * nhwc(yt).abs().max()      # one bf16 rounding of the output
+    np.testing.assert_allclose(bs[0].cpu().numpy(), bt.grad.numpy(), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(bs[1].cpu().numpy(), gt.grad.numpy(), rtol=2e-3, atol=2e-3 * float(gt.grad.abs().max()))
+    assert (dz.float().cpu() - nhwc(zt.grad)).abs().max() <= 1e-2 * nhwc(zt.grad).abs().max() + 1e-6
+    if with_res:
+        assert (da.float().cpu() - nhwc(rt.grad)).abs().max() <= 1e-2 * nhwc(rt.grad).abs().max()
+
+
+def test_resnet_vd_batch_stat_batchnorm_backward_vs_torch_autograd():
+    """ResNet50-vd with LIVE BatchNorm (batch statistics, trainable affine, running-statistics update) through the HIP
+    autograd nodes vs torch CPU fp32 autograd of the oracle in BN-training mode (itself pinned to the reference in .train())."""
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.synth import synth_image_structured, synth_state_dict
+    from focoos_amd.train_nn import ResNetVd, set_norm_mode
+    from oracle import detr_oracle as O
+    from tests.helpers import rel_l2
+
+    cfg = ModelRegistry.get_model_info("fai-detr-l-coco")["config"]
+    sd = synth_state_dict(cfg, 12)
+    pre = "pixel_decoder.backbone."
+    bsd = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    net = set_norm_mode(ResNetVd(50), "BN").to(DEV)
+    net.load_state_dict(bsd, strict=True)
+    imgs = [synth_image_structured(50 + i, 160, 192) for i in range(4)]
+    x_u8 = torch.from_numpy(np.stack(imgs)).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    proj = {k: torch.randn(c, generator=g) for k, c in (("res2", 256), ("res3", 512), ("res4", 1024), ("res5", 2048))}
+    outs = net(x_u8)
+    loss = sum((outs[k].float() * proj[k].to(DEV)).sum() for k in proj) * 1e-2
+    loss.backward()
+    torch.cuda.synchronize()
+    ref_sd = {k: (v.clone().requires_grad_(True) if k.endswith(("conv.weight", "norm.weight", "norm.bias")) else v.clone())
+              for k, v in sd.items() if k.startswith(pre)}
+    mean = torch.tensor(cfg["pixel_mean"]).view(-1, 1, 1)
+    std = torch.tensor(cfg["pixel_std"]).view(-1, 1, 1)
+    xi = (O.get_torch_batch(imgs, None) - mean) / std
+    O.BN_TRAINING[0] = True
+    try:
+        feats = O.resnet_vd(ref_sd, pre[:-1], xi, O.RESNET_BLOCKS[50])
+    finally:
+        O.BN_TRAINING[0] = False
+    ref_loss = sum((feats[k] * proj[k].view(1, -1, 1, 1)).sum() for k in proj) * 1e-2
+    ref_loss.backward()
+    for k in proj:
+        assert rel_l2(outs[k].detach().float().cpu().permute(0, 3, 1, 2), feats[k].detach()) <= 3e-2, k
+    errs = []
+    for name, p in net.named_parameters():
+        assert p.requires_grad and p.grad is not None, name
+        errs.append((rel_l2(p.grad.cpu(), ref_sd[pre + name].grad), name))
+    errs.sort(reverse=True)
+    print("worst gradient rel-L2:", errs[:4], "median", errs[len(errs) // 2][0])
+    assert len(errs) == 3 * 53 and errs[0][0] <= 0.12 and errs[len(errs) // 2][0] <= 0.04, errs[:6]
+    msd = net.state_dict()
+    for k in ("conv1.conv1_1.norm.running_mean", "res_layers.0.blocks.0.short.norm.running_var", "res_layers.3.blocks.2.branch2c.norm.running_mean"):
+        assert rel_l2(msd[k].cpu(), ref_sd[pre + k]) <= 1e-2, k
+    # .eval() folds the UPDATED running statistics into the conv images
+    net.eval()
+    with torch.no_grad():
+        ev = net(x_u8)
+    feats_e = O.resnet_vd({k: v.detach() for k, v in ref_sd.items()}, pre[:-1], xi, O.RESNET_BLOCKS[50])
+    assert rel_l2(ev["res5"].float().cpu().permute(0, 3, 1, 2), feats_e["res5"]) <= 3e-2

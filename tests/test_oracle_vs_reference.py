@@ -122,3 +122,51 @@ def test_train_oracle_matches_reference_losses_and_gradients():
         g_ref, g_mine = named[k].grad, sdg[k].grad
         assert g_ref is not None and g_mine is not None, k
         assert (g_mine - g_ref).abs().max() <= 2e-3 * g_ref.abs().max() + 1e-7, k
+
+
+def test_train_oracle_batch_stat_batchnorm_matches_reference():
+    """Same check with the reference fully in .train() (BatchNorm on batch statistics, the reference's default when
+    freeze_bn is off): losses, gradients including the BN affine parameters, and the running-statistics update."""
+    ref_import.install()
+    from focoos.models.fai_detr.ports import DETRTargets
+
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.synth import synth_image_structured, synth_state_dict
+    from oracle import detr_oracle as O
+    from oracle import train_oracle as T
+
+    cfg = ModelRegistry.get_model_info("fai-detr-l-coco")["config"]
+    model, proc, _ = ref_import.build_reference_detr(cfg)
+    sd = synth_state_dict(cfg, seed=6)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    imgs = [synth_image_structured(30 + i, 128, 160) for i in range(2)]
+    x = O.get_torch_batch(imgs, None)
+    labels, boxes = T.synth_targets(1, 2, 80, counts=(3, 5))
+    out = model(x, [DETRTargets(labels=l, boxes=b) for l, b in zip(labels, boxes)])
+    ref_losses = out.loss
+    sum(ref_losses.values()).backward()
+    sdg = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and v.dim() > 0 and "running" not in k and "empty_weight" not in k
+               else v.clone()) for k, v in sd.items()}
+    O.BN_TRAINING[0] = True
+    try:
+        outs = T.detr_train_outputs(sdg, cfg, x)
+    finally:
+        O.BN_TRAINING[0] = False
+    losses, _ = T.criterion(outs, labels, boxes)
+    for k in ref_losses:
+        np.testing.assert_allclose(float(losses[k]), float(ref_losses[k]), rtol=5e-4, atol=1e-5, err_msg=k)
+    sum(losses.values()).backward()
+    named = dict(model.named_parameters())
+    for k in ("pixel_decoder.backbone.res_layers.1.blocks.0.branch2b.conv.weight", "pixel_decoder.backbone.res_layers.2.blocks.1.branch2c.norm.weight",
+              "pixel_decoder.backbone.conv1.conv1_1.norm.bias", "pixel_decoder.input_proj.1.1.weight",
+              "pixel_decoder.fpn_blocks.1.bottlenecks.2.conv1.conv.weight", "pixel_decoder.fpn_blocks.0.bottlenecks.0.conv2.norm.weight",
+              "head.predictor.input_proj.0.norm.bias", "head.predictor.enc_score_classifier.weight"):
+        g_ref, g_mine = named[k].grad, sdg[k].grad
+        assert g_ref is not None and g_mine is not None, k
+        assert (g_mine - g_ref).abs().max() <= 5e-3 * g_ref.abs().max() + 1e-7, k
+    ref_sd = model.state_dict()
+    for k in ("pixel_decoder.backbone.conv1.conv1_2.norm.running_mean", "pixel_decoder.backbone.res_layers.3.blocks.2.branch2b.norm.running_var",
+              "pixel_decoder.pan_blocks.0.conv2.norm.running_var", "head.predictor.input_proj.2.norm.running_mean"):
+        np.testing.assert_allclose(sdg[k].numpy(), ref_sd[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+        assert not torch.equal(sdg[k], sd[k]), k
