@@ -157,6 +157,7 @@ def _bn_forward(layer, z: torch.Tensor, residual: Optional[torch.Tensor]):
     check(lib.fx_bn_finalize_f32(sums.data_ptr(), n, norm.weight.data_ptr(), norm.bias.data_ptr(), BN_EPS, BN_MOMENTUM,
                                  norm.running_mean.data_ptr(), norm.running_var.data_ptr(), norm.num_batches_tracked.data_ptr(),
                                  stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), N, st), "fx_bn_finalize_f32")
+    layer._stats_epoch = getattr(layer, "_stats_epoch", 0) + 1   # the kernel moved the running statistics behind autograd's back
     y = torch.empty_like(z)
     check(lib.fx_bn_apply_bf16(z.data_ptr(), N, stats[2].data_ptr(), stats[3].data_ptr(), residual.data_ptr() if residual is not None else None, N,
                                FX_ACT[layer.act], y.data_ptr(), N, rows, N, st), "fx_bn_apply_bf16")
@@ -289,7 +290,7 @@ class ConvNormLayer(nn.Module):
         can have changed (they are constants for FrozenBN, so the per-step weight repack skips these small launches)."""
         norm = self._norm_h
         ver = (norm.weight._version, norm.bias._version, norm.running_var._version, norm.running_mean._version, norm.weight.device,
-               WEIGHTS_EPOCH[0] if self.norm_mode != "FrozenBN" else -1)
+               WEIGHTS_EPOCH[0] if self.norm_mode != "FrozenBN" else -1, getattr(self, "_stats_epoch", 0))
         if ver == getattr(self, "_norm_version", None):
             return
         self.scale = (norm.weight.double() / torch.sqrt(norm.running_var.double() + BN_EPS)).float().contiguous()
@@ -301,17 +302,20 @@ class ConvNormLayer(nn.Module):
         statistics the images hold the plain weights (the normalisation is a separate pass); otherwise BN is folded in."""
         w = self._conv_h.weight
         live = self.batch_stats
-        ver = (w._version, self._norm_h.weight._version, self._norm_h.running_var._version, w.device, WEIGHTS_EPOCH[0], live)
+        ver = (w._version, self._norm_h.weight._version, self._norm_h.running_var._version, w.device, WEIGHTS_EPOCH[0], live,
+               0 if live else getattr(self, "_stats_epoch", 0))
         if ver == self._packed_version:
             return
         dev = w.device
         N, Cc, k = self.cout, self.cin, self.k
         with torch.no_grad():
-            self._fold_norm()
-            shift = self._shift_n
             Np, Cp = (N + 127) // 128 * 128, (Cc + 127) // 128 * 128
-            self.shift = torch.zeros(Np, dtype=torch.float32, device=dev)
-            self.shift[:N] = shift
+            if not live:   # fold the (running-statistics) BatchNorm into the conv: scaled weights + per-channel shift
+                nver = getattr(self, "_norm_version", None)
+                self._fold_norm()
+                if self.shift is None or self.shift.device != dev or nver != self._norm_version:
+                    self.shift = torch.zeros(Np, dtype=torch.float32, device=dev)
+                    self.shift[:N] = self._shift_n
             if self.w_fwd is None or self.w_fwd.device != dev:
                 self.w_fwd = torch.zeros(Np, k, k, Cc, dtype=torch.bfloat16, device=dev)
                 self.w_dgrad = torch.zeros(Cp, k, k, N, dtype=torch.bfloat16, device=dev)
@@ -422,15 +426,16 @@ class StemConv(ConvNormLayer):
     def sync_packed(self):
         w = self._conv_h.weight
         live = self.batch_stats
-        ver = (w._version, self._norm_h.weight._version, self._norm_h.running_var._version, w.device, WEIGHTS_EPOCH[0], live)
+        ver = (w._version, self._norm_h.weight._version, self._norm_h.running_var._version, w.device, WEIGHTS_EPOCH[0], live,
+               0 if live else getattr(self, "_stats_epoch", 0))
         if ver == self._packed_version:
             return
         with torch.no_grad():
-            self._fold_norm()
             if live:
                 self.stem_b = torch.zeros(32, dtype=torch.float32, device=w.device)
                 self.stem_w = w.permute(2, 3, 1, 0).contiguous()
             else:
+                self._fold_norm()
                 self.stem_b = self._shift_n
                 self.stem_w = (w * self.scale.view(-1, 1, 1, 1)).permute(2, 3, 1, 0).contiguous()  # [kh][kw][c][n] fp32 (tiny: 864 values)
         self._packed_version = ver

