@@ -437,11 +437,11 @@ def test_conv_norm_layer_batch_stat(lib, case):
 
 
 def test_bottleneck_pair_batch_stat(lib):
-    """Two ResNet-vd bottlenecks (projection shortcut, then identity shortcut) with live BatchNorm vs torch fp32 autograd of
-    the same composition written with the oracle's conv_bn: the residual / two-consumer gradient wiring at a depth where
-    bf16 noise is still small."""
+    """Two ResNet-vd bottlenecks (projection shortcut, then identity shortcut; 7 live BatchNorm layers) vs torch autograd of
+    the same composition, twice: with straight-through bf16 rounding where the engine stores tensors (tight: proves the
+    residual / two-consumer gradient wiring and the BN backward in composition) and in pure fp32 (loose: documents how far
+    bf16 storage of the pre-normalisation conv output moves gradients through ReLU sign flips)."""
     from focoos_amd.train_nn import BottleNeck, _Blocks, set_norm_mode
-    from oracle import detr_oracle as O
     from tests.helpers import rel_l2
 
     g = torch.Generator().manual_seed(5)
@@ -463,26 +463,43 @@ def test_bottleneck_pair_batch_stat(lib):
     y = net(xd)
     y.backward(cot.to(DEV))
     torch.cuda.synchronize()
-    ref = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.clone()) for k, v in sd.items()}
-    xt = x.float().permute(0, 3, 1, 2).requires_grad_(True)
-    O.BN_TRAINING[0] = True
-    try:
+    nchw = lambda t: t.detach().float().cpu().permute(0, 3, 1, 2)
+
+    def reference(rb):
+        """The same composition in torch fp32; ``rb`` = identity (the reference's arithmetic) or straight-through bf16 rounding
+        at the points where the engine STORES a tensor (weight image, conv output z, layer output)."""
+        ref = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.clone()) for k, v in sd.items()}
+        xt = x.float().permute(0, 3, 1, 2).requires_grad_(True)
+
+        def cbn(p, h, act, res=None):
+            z = rb(F.conv2d(h, rb(ref[f"{p}.conv.weight"]), None, 1, (ref[f"{p}.conv.weight"].shape[-1] - 1) // 2))
+            a = F.batch_norm(z, ref[f"{p}.norm.running_mean"], ref[f"{p}.norm.running_var"], ref[f"{p}.norm.weight"], ref[f"{p}.norm.bias"], True, 0.1, 1e-5)
+            if res is not None:
+                a = a + res
+            return rb(F.relu(a) if act else a)
+
         h = xt
         for bi in range(2):
             p = f"blocks.{bi}"
-            out = O.conv_bn(ref, f"{p}.branch2c", O.conv_bn(ref, f"{p}.branch2b", O.conv_bn(ref, f"{p}.branch2a", h, 1, "relu"), 1, "relu"), 1, None)
-            short = O.conv_bn(ref, f"{p}.short", h, 1, None) if bi == 0 else h
-            h = F.relu(out + short)
-    finally:
-        O.BN_TRAINING[0] = False
-    h.backward(cot.float().permute(0, 3, 1, 2))
-    # six ReLU layers deep: each contributes 2-4% (sign flips of near-zero ReLU inputs caused by the bf16 storage of the conv
-    # output - see _bn_layer_case), adding up incoherently to ~11% at the input
-    assert rel_l2(y.detach().float().cpu().permute(0, 3, 1, 2), h.detach()) <= 8e-3
-    assert rel_l2(xd.grad.float().cpu().permute(0, 3, 1, 2), xt.grad) <= 0.16
-    errs = sorted(((rel_l2(p.grad.cpu(), ref[n].grad), n) for n, p in net.named_parameters()), reverse=True)
-    print("bottleneck pair, worst:", errs[:3])
-    assert len(errs) == 21 and errs[0][0] <= 0.16, errs[:5]
+            short = cbn(f"{p}.short", h, False) if bi == 0 else h
+            h = cbn(f"{p}.branch2c", cbn(f"{p}.branch2b", cbn(f"{p}.branch2a", h, True), True), True, short)
+        h.backward(cot.float().permute(0, 3, 1, 2))
+        return ref, xt, h
+
+    def compare(ref, xt, h):
+        e_y, e_x = rel_l2(nchw(y), h.detach()), rel_l2(nchw(xd.grad), xt.grad)
+        errs = sorted(((rel_l2(p.grad.cpu(), ref[n].grad), n) for n, p in net.named_parameters()), reverse=True)
+        assert len(errs) == 21
+        return e_y, e_x, errs
+
+    # (1) against the engine's own storage precision: the ReLU sign pattern is reproduced, what is left is bf16 gradient storage
+    e_y, e_x, errs = compare(*reference(lambda t: t + (t.bfloat16().float() - t).detach()))
+    print(f"bottleneck pair vs bf16-storage emulation: y {e_y:.4f} dx {e_x:.4f} worst {errs[:2]}")
+    assert e_y <= 4e-3 and e_x <= 2.5e-2 and errs[0][0] <= 2.5e-2, (e_y, e_x, errs[:4])
+    # (2) against pure fp32 (the reference's arithmetic): six ReLU layers of sign flips near zero, ~2-4% each (see _bn_layer_case)
+    e_y, e_x, errs = compare(*reference(lambda t: t))
+    print(f"bottleneck pair vs fp32: y {e_y:.4f} dx {e_x:.4f} worst {errs[:2]}")
+    assert e_y <= 8e-3 and e_x <= 0.25 and errs[0][0] <= 0.25, (e_y, e_x, errs[:4])
 
 
 def test_resnet_vd_batch_stat_batchnorm_backward_vs_torch_autograd():
