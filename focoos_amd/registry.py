@@ -53,6 +53,35 @@ _MF_L_COCO_INS_CONFIG = {
 }
 
 
+# focoos/model_registry/bisenetformer-l-ade.json (config block; the loss / matcher weights of the training criterion included)
+_BF_L_ADE_CONFIG = {
+    "num_classes": 150,
+    "backbone_config": {
+        "use_pretrained": False, "backbone_url": None, "model_type": "stdc", "in_chans": 3, "base": 64, "layers": [4, 5, 3],
+        "out_features": ["res2", "res3", "res4", "res5"], "block_num": 4, "block_type": "cat", "use_conv_last": False,
+    },
+    "num_queries": 100, "resolution": 640,
+    "pixel_mean": [123.675, 116.28, 103.53], "pixel_std": [58.395, 57.12, 57.375], "size_divisibility": 0,
+    "pixel_decoder_out_dim": 128, "pixel_decoder_feat_dim": 128,
+    "transformer_predictor_out_dim": 128, "transformer_predictor_hidden_dim": 256,
+    "transformer_predictor_dec_layers": 6, "transformer_predictor_dim_feedforward": 1024,
+    "head_out_dim": 128, "cls_sigmoid": False, "postprocessing_type": "semantic", "top_k": 100, "mask_threshold": 0.5,
+    "predict_all_pixels": True, "use_mask_score": False, "threshold": 0.5,
+    "criterion_deep_supervision": True, "criterion_eos_coef": 0.1, "criterion_num_points": 12544,
+    "weight_dict_loss_dice": 5, "weight_dict_loss_mask": 5, "weight_dict_loss_ce": 2,
+    "matcher_cost_class": 2, "matcher_cost_mask": 5, "matcher_cost_dice": 5,
+}
+
+
+def _bf_entry(name: str, cfg: Dict, description: str) -> Dict:
+    cfg = copy.deepcopy(cfg)
+    return {
+        "name": name, "model_family": "bisenetformer", "task": "semseg", "im_size": int(cfg["resolution"]),
+        "classes": [f"class_{i}" for i in range(int(cfg["num_classes"]))],
+        "config": cfg, "weights_uri": None, "description": description,
+    }
+
+
 def _mf_entry(name: str, cfg: Dict, description: str) -> Dict:
     cfg = copy.deepcopy(cfg)
     return {
@@ -63,6 +92,7 @@ def _mf_entry(name: str, cfg: Dict, description: str) -> Dict:
 
 
 _REGISTRY = {
+    "bisenetformer-l-ade": _bf_entry("bisenetformer-l-ade", _BF_L_ADE_CONFIG, "BiSeNetFormer large (STDC-2), ADE20K semantic segmentation"),
     "fai-mf-l-coco-ins": _mf_entry("fai-mf-l-coco-ins", _MF_L_COCO_INS_CONFIG, "MaskFormer large (R101-vd), COCO instance segmentation"),
     "fai-detr-l-obj365": _entry("fai-detr-l-obj365", 365, "RT-DETR large (R50-vd), Objects365 head"),
     "fai-detr-l-coco": _entry("fai-detr-l-coco", 80, "RT-DETR large (R50-vd), COCO head"),

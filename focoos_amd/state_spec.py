@@ -1,4 +1,5 @@
-"""State-dict layouts of the RT-DETR family (``fai-detr-*``) and the MaskFormer family (``fai-mf-*``), ResNet-vd backbones.
+"""State-dict layouts of the RT-DETR family (``fai-detr-*``), the MaskFormer family (``fai-mf-*``; ResNet-vd backbones) and the
+BiSeNetFormer family (``bisenetformer-*``; STDC backbone).
 
 The engine keeps the reference's checkpoint key names unchanged so that a
 ``model_final.pth`` written by the reference loads into it and vice versa
@@ -215,9 +216,97 @@ def mf_state_spec(config: Dict) -> "OrderedDict[str, Tuple[Tuple[int, ...], str]
     return spec
 
 
+def stdc_spec(spec, prefix: str, base: int = 64, layers=(4, 5, 3), block_num: int = 4, in_chans: int = 3):
+    """STDC backbone with CatBottleneck blocks (focoos/nn/backbone/stdc.py:108-166, 282-311); returns the res2..res5 channels."""
+    if block_num != 4:
+        raise ValueError("engine state spec covers STDC block_num=4 (stdc small / large)")
+    _conv_bn(spec, f"{prefix}.features.0", in_chans, base // 2, 3, "conv", "bn")
+    _conv_bn(spec, f"{prefix}.features.1", base // 2, base, 3, "conv", "bn")
+    idx, cin = 2, base
+    for i, n in enumerate(layers):
+        cout = base * 2 ** (i + 2)
+        for j in range(n):
+            p = f"{prefix}.features.{idx}"
+            _conv_bn(spec, f"{p}.conv_list.0", cin, cout // 2, 1, "conv", "bn")
+            _conv_bn(spec, f"{p}.conv_list.1", cout // 2, cout // 4, 3, "conv", "bn")
+            _conv_bn(spec, f"{p}.conv_list.2", cout // 4, cout // 8, 3, "conv", "bn")
+            _conv_bn(spec, f"{p}.conv_list.3", cout // 8, cout // 8, 3, "conv", "bn")
+            if j == 0:  # stride-2 block: depthwise 3x3 stride-2 conv + BN on the first branch
+                spec[f"{p}.avd_layer.0.weight"] = ((cout // 2, 1, 3, 3), "conv_w")
+                _bn(spec, f"{p}.avd_layer.1", cout // 2)
+            cin = cout
+            idx += 1
+    return [base, base * 4, base * 8, base * 16]
+
+
+def bf_state_spec(config: Dict) -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
+    """Ordered ``name -> (shape, kind)`` of ``BisenetFormer(config).state_dict()``
+    (focoos/models/bisenetformer/modelling.py:523-592: BiseNet :235-279 with ContextPath :170-212 / FeatureFusionModule
+    :215-237, TransformerDecoder :282-461, PredictionHeads :26-60); pinned against the reference's own key dump in
+    tests/golden/bf_l_state_keys.json."""
+    bb = config["backbone_config"]
+    if bb.get("model_type") != "stdc" or bb.get("block_type", "cat") != "cat":
+        raise ValueError("engine state spec covers STDC (cat) backbones (bisenetformer-*)")
+    nc = int(config["num_classes"])
+    fd = int(config.get("pixel_decoder_feat_dim", 128))
+    od = int(config.get("pixel_decoder_out_dim", 128))
+    hd = int(config.get("transformer_predictor_hidden_dim", 256))
+    md = int(config.get("transformer_predictor_out_dim", 128))
+    ffd = int(config.get("transformer_predictor_dim_feedforward", 1024))
+    nl = int(config.get("transformer_predictor_dec_layers", 6))
+    nq = int(config.get("num_queries", 100))
+    spec: "OrderedDict[str, Tuple[Tuple[int, ...], str]]" = OrderedDict()
+    chans = stdc_spec(spec, "pixel_decoder.backbone", int(bb.get("base", 64)), tuple(bb.get("layers", (4, 5, 3))), int(bb.get("block_num", 4)),
+                      int(bb.get("in_chans", 3)))
+    P = "pixel_decoder"
+
+    def arm(prefix, cin):
+        spec[f"{prefix}.proj.weight"] = ((fd, cin, 1, 1), "conv_w")
+        _conv_bn(spec, f"{prefix}.conv", fd, fd, 3, "conv", "bn")
+        spec[f"{prefix}.conv_atten.weight"] = ((fd, fd, 1, 1), "conv_w")
+        _bn(spec, f"{prefix}.bn_atten", fd)
+
+    arm(f"{P}.cp.arm32", chans[3])
+    _conv_bn(spec, f"{P}.cp.conv_avg", chans[3], fd, 1, "conv", "bn")
+    _conv_bn(spec, f"{P}.cp.conv_head32", fd, fd, 3, "conv", "bn")
+    arm(f"{P}.cp.arm16", chans[2])
+    _conv_bn(spec, f"{P}.cp.conv_head16", fd, fd, 3, "conv", "bn")
+    for name, cin in (("proj1", chans[1]), ("proj2", fd)):
+        spec[f"{P}.ffm.{name}.weight"] = ((fd, cin, 1, 1), "conv_w")
+        spec[f"{P}.ffm.{name}.bias"] = ((fd,), "lin_b")
+    _conv_bn(spec, f"{P}.ffm.convblk", fd, fd, 1, "conv", "bn")
+    spec[f"{P}.ffm.conv1.weight"] = ((fd // 4, fd, 1, 1), "conv_w")
+    spec[f"{P}.ffm.conv2.weight"] = ((fd, fd // 4, 1, 1), "conv_w")
+    _conv_bn(spec, f"{P}.conv_out", fd, od, 3, "conv", "bn")
+    spec["head.criterion.empty_weight"] = ((nc + 1,), "buf")
+    H = "head.predictor"
+    for li in range(nl):
+        _mha(spec, f"{H}.transformer_self_attention_layers.{li}.self_attn", hd)
+        _ln(spec, f"{H}.transformer_self_attention_layers.{li}.norm", hd)
+    for li in range(nl):
+        _mha(spec, f"{H}.transformer_cross_attention_layers.{li}.multihead_attn", hd)
+        _ln(spec, f"{H}.transformer_cross_attention_layers.{li}.norm", hd)
+    for li in range(nl):
+        _linear(spec, f"{H}.transformer_ffn_layers.{li}.linear1", hd, ffd)
+        _linear(spec, f"{H}.transformer_ffn_layers.{li}.linear2", ffd, hd)
+        _ln(spec, f"{H}.transformer_ffn_layers.{li}.norm", hd)
+    spec[f"{H}.query_feat.weight"] = ((nq, hd), "emb")
+    spec[f"{H}.query_embed.weight"] = ((nq, hd), "emb")
+    for i in range(min(2, nl)):
+        spec[f"{H}.input_proj.{i}.weight"] = ((hd, od, 1, 1), "conv_w")
+        spec[f"{H}.input_proj.{i}.bias"] = ((hd,), "lin_b")
+    _ln(spec, f"{H}.forward_prediction_heads.decoder_norm", hd)
+    _linear(spec, f"{H}.forward_prediction_heads.classifier", hd, nc + 1)
+    for j, (a, b) in enumerate([(hd, hd), (hd, hd), (hd, md)]):
+        _linear(spec, f"{H}.forward_prediction_heads.mask_classifier.layers.{j}", a, b)
+    return spec
+
+
 def state_spec(config: Dict, family: str = "fai_detr"):
     if family == "fai_detr":
         return detr_state_spec(config)
     if family == "fai_mf":
         return mf_state_spec(config)
+    if family == "bisenetformer":
+        return bf_state_spec(config)
     raise ValueError(f"engine has no state spec for model family {family!r}")

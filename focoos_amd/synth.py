@@ -38,6 +38,8 @@ def synth_state_dict(config: Dict, seed: int = 0, family: str = "fai_detr") -> "
                 a = rs.uniform(0.15, 0.35, shape).astype(np.float32)
             elif ".adapter_" in name:  # MaskFormer FPN laterals: bring the O(10) backbone features back to O(1)
                 a = rs.uniform(0.03, 0.07, shape).astype(np.float32)
+            elif ".cp." in name or ".ffm." in name:  # BiSeNet context path / fusion: keep the decoder memory O(1)
+                a = rs.uniform(0.15, 0.35, shape).astype(np.float32)
             else:
                 a = rs.uniform(0.6, 1.4, shape).astype(np.float32)
         elif kind == "bn_b":

@@ -123,16 +123,18 @@ def prediction_heads(sd: SD, x: torch.Tensor, mask_features: torch.Tensor, size:
 
 
 def masked_decoder(sd: SD, msf: List[torch.Tensor], mask_features: torch.Tensor, cfg: Dict,
-                   forced_attn: Optional[Sequence[torch.Tensor]] = None, collect: Optional[dict] = None):
+                   forced_attn: Optional[Sequence[torch.Tensor]] = None, collect: Optional[dict] = None, max_levels: int = 3):
     """MultiScaleMaskedTransformerDecoder.forward — fai_mf/modelling.py:453-549 (pre_norm=True, enforce_input_project=True,
     use_attn_masks=True; cross-attn first, then self-attn, then FFN; layers cycle over the 3 levels).
     ``forced_attn``: optional list (one per decoder layer) of boolean masks [B,Q,Lk] to teacher-force the masked attention
-    (the discrete step whose flips near logit 0 are the H1-style hazard of this model)."""
+    (the discrete step whose flips near logit 0 are the H1-style hazard of this model).
+    ``max_levels`` = 2 gives BiSeNetFormer's TransformerDecoder.forward (bisenetformer/modelling.py:375-447), the same
+    layer sequence cycling over two levels."""
     H = "head.predictor"
     nl = int(cfg.get("transformer_predictor_dec_layers", 6))
     hd = int(cfg.get("transformer_predictor_hidden_dim", 256))
     nhead = 8  # fai_mf/modelling.py:689
-    nlev = min(3, nl)
+    nlev = min(max_levels, nl)
     src, pos, sizes = [], [], []
     for i in range(nlev):
         f = msf[i]
@@ -208,16 +210,20 @@ def masks_to_xyxy(masks: np.ndarray) -> np.ndarray:
 
 
 def postprocess(probs: torch.Tensor, mask_pred: torch.Tensor, image_sizes: Sequence[Tuple[int, int]],
-                mask_threshold: float = 0.5, threshold: float = 0.5, use_mask_score: bool = True):
-    """MaskFormerProcessor.postprocess — fai_mf/processor.py:168-306 (predict_all_pixels=False branch), stopping before the
-    cv2 PNG/base64 encoding (:296).  The reference's gather indexing (:237-262) only works for batch 1 (index tensors are
+                mask_threshold: float = 0.5, threshold: float = 0.5, use_mask_score: bool = True, predict_all_pixels: bool = False):
+    """MaskFormerProcessor.postprocess — fai_mf/processor.py:168-306 (and the line-for-line identical
+    BisenetFormerProcessor.postprocess, bisenetformer/processor.py:176-300), stopping before the cv2 PNG/base64 encoding (:296).  The reference's gather indexing (:237-262) only works for batch 1 (index tensors are
     [1, n]); this restates the batch-1 behaviour and applies it to each image independently.
     Per image returns (scores f32 [n], labels i64 [n], query index i64 [n], boxes int [n,4], masks bool [n,H_img,W_img])."""
     res = []
     for i in range(probs.shape[0]):
         scores, labels = probs[i].max(-1)
         mp = mask_pred[i]
-        binm = mp >= mask_threshold
+        if predict_all_pixels:   # :215-229 / bisenetformer/processor.py:215-229: every pixel goes to the query maximising score x probability
+            winner = (scores.view(-1, 1, 1) * mp).argmax(dim=0)
+            binm = winner.unsqueeze(0) == torch.arange(mp.shape[0]).view(-1, 1, 1)
+        else:
+            binm = mp >= mask_threshold
         keep = (binm.sum(dim=(-2, -1)) > 1).nonzero(as_tuple=True)[0]          # :232 (strictly more than one pixel)
         scores, labels, binm, mp, q = scores[keep], labels[keep], binm[keep], mp[keep], keep
         if use_mask_score:

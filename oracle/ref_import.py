@@ -187,3 +187,23 @@ def build_reference_mf(config_dict: dict):
     model.eval()
     proc = MaskFormerProcessor(cfg).eval()
     return model, proc, cfg
+
+
+def build_reference_bf(config_dict: dict):
+    """Build the reference's BisenetFormer + BisenetFormerProcessor from a registry-style config dict
+    (same recipe as ``build_reference_detr``).  Returns ``(model, processor, config)``; eval mode, CPU."""
+    install()
+    import focoos.models.bisenetformer as fam
+    from focoos.model_manager import ConfigManager
+    from focoos.models.bisenetformer.modelling import BisenetFormer
+    from focoos.models.bisenetformer.processor import BisenetFormerProcessor
+    from focoos.ports import ModelFamily
+
+    for attr in dir(fam):  # family registration hooks (model_manager.py:108-126)
+        if attr.startswith("_register"):
+            getattr(fam, attr)()
+    cfg = ConfigManager.from_dict(ModelFamily.BISENETFORMER, dict(config_dict))
+    model = BisenetFormer(cfg)
+    model.eval()
+    proc = BisenetFormerProcessor(cfg).eval()
+    return model, proc, cfg

@@ -237,6 +237,71 @@ def mf_case(tag: str = "mf_l_coco_ins_b2", seed: int = 3, hw=(160, 192)):
     print(tag, {k: v.shape for k, v in g.items() if hasattr(v, "shape") and v.ndim}, [len(g[f"det{i}_conf"]) for i in range(B)])
 
 
+def bf_case(tag: str = "bf_l_ade_b2", seed: int = 4, hw=(160, 192)):
+    """Golden vectors of the REAL reference's BisenetFormer + BisenetFormerProcessor (bisenetformer/modelling.py, processor.py)
+    on seeded synthetic weights / images: stage samples (STDC features, context path, fusion, mask features), the boolean
+    attention masks each decoder layer used, low-res mask logits, class probabilities and the batch-1 post-process
+    (predict_all_pixels=True: per-pixel argmax over queries), including each detection's mask area."""
+    from focoos_amd.synth import synth_image_structured as sis
+    info = ModelRegistry.get_model_info("bisenetformer-l-ade")
+    cfg = info["config"]
+    rc = {k: v for k, v in cfg.items() if k != "resolution"}
+    model, proc, _ = ref_import.build_reference_bf(rc)
+    import focoos.models.bisenetformer.processor as bp
+    bp.binary_mask_to_base64 = lambda m: ""  # the cv2/PNG tail is absent here and outside the path
+    areas = []
+    orig_trim = bp.trim_mask
+    bp.trim_mask = lambda m, b: (areas.append(int(np.asarray(m).sum())), orig_trim(m, b))[1]
+    sd = synth_state_dict(cfg, seed=seed, family="bisenetformer")
+    res = model.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    cap = {}
+    model.pixel_decoder.backbone.register_forward_hook(lambda m, i, o: cap.__setitem__("bb", o))
+    model.pixel_decoder.cp.register_forward_hook(lambda m, i, o: cap.__setitem__("cp", o))
+    model.pixel_decoder.ffm.register_forward_hook(lambda m, i, o: cap.__setitem__("ffm", o))
+    model.pixel_decoder.register_forward_hook(lambda m, i, o: cap.__setitem__("pd", o))
+    model.head.predictor.register_forward_hook(lambda m, i, o: cap.__setitem__("pred", o))
+    masks_used = []
+    for lyr in model.head.predictor.transformer_cross_attention_layers:
+        lyr.register_forward_pre_hook(lambda m, a, kw: masks_used.append(kw["memory_mask"]), with_kwargs=True)
+    dec_out = []
+    for lyr in model.head.predictor.transformer_ffn_layers:
+        lyr.register_forward_hook(lambda m, i, o: dec_out.append(o))
+    images = [sis(i, *hw) for i in range(2)]
+    x, _ = proc.preprocess(images, device=torch.device("cpu"), dtype=torch.float32)
+    with torch.no_grad():
+        out = model(x)
+    B = x.shape[0]
+    g = {"seed": np.int64(seed), "hw": np.array(hw), "pre_sample": strided_sample(x, 4096)}
+    for k in ("res2", "res3", "res4", "res5"):
+        g[f"{k}_sample"] = strided_sample(cap["bb"][k], 4096)
+    _, cp8, cp16, cp32 = cap["cp"]
+    for k, v in (("cp8", cp8), ("cp16", cp16), ("cp32", cp32), ("ffm", cap["ffm"])):
+        g[f"{k}_sample"] = strided_sample(v, 4096)
+    g["mask_features_sample"] = strided_sample(cap["pd"][0], 8192)
+    for i, m in enumerate(masks_used):  # [B*heads, Q, Lk], identical across heads
+        mm = m.view(B, 8, m.shape[1], m.shape[2])
+        assert bool((mm == mm[:, :1]).all())
+        g[f"attn_mask{i}"] = np.packbits(mm[:, 0].numpy(), axis=-1)
+        g[f"attn_mask{i}_len"] = np.int64(m.shape[2])
+    for i, o in enumerate(dec_out):  # [Q, B, C]
+        g[f"dec{i}_sample"] = strided_sample(o.permute(1, 0, 2).contiguous(), 2048)
+    g["cls_logits"] = cap["pred"]["pred_logits"].numpy()
+    g["mask_logits_f16"] = cap["pred"]["pred_masks"].numpy().astype(np.float16)
+    g["probs"] = out.logits.numpy()
+    g["masks_sample"] = strided_sample(out.masks, 16384)
+    for i in range(B):
+        o1 = type(out)(masks=out.masks[i:i + 1], logits=out.logits[i:i + 1], loss=None)
+        del areas[:]
+        d = proc.postprocess(o1, [images[i]])[0].detections
+        g[f"det{i}_conf"] = np.array([a.conf for a in d], np.float32)
+        g[f"det{i}_cls"] = np.array([a.cls_id for a in d], np.int64)
+        g[f"det{i}_bbox"] = np.array([a.bbox for a in d], np.int64).reshape(-1, 4)
+        g[f"det{i}_area"] = np.array(areas, np.int64)
+    np.savez_compressed(os.path.join(GOLDEN, tag + ".npz"), **g)
+    print(tag, {k: v.shape for k, v in g.items() if hasattr(v, "shape") and v.ndim}, [len(g[f"det{i}_conf"]) for i in range(B)])
+
+
 def masks_to_xyxy_case():
     """The reference's own known-answer vectors for this path: tests/utils/test_vision.py:185-205 (test_masks_to_xyxy),
     evaluated with the reference's masks_to_xyxy (utils/vision.py:344-370) on extra seeded random masks as well."""
@@ -270,6 +335,7 @@ def main():
     deform_core_case()
     criterion_case()
     mf_case()
+    bf_case()
     masks_to_xyxy_case()
 
 
