@@ -53,19 +53,22 @@ extern "C" int fx_upsample_nearest_add_nhwc_bf16(const void* lateral, int ldl, c
 //   MODE 2: attention-mask bits (fai_mf/modelling.py:104: mask = resized logit < 0; the bilinear resize of the logits is
 //           applied to `feat` beforehand, which is the same linear map): bits[(b*Q+q)*ldw + p/32], bit p&31; pixels
 //           beyond P read as masked.
-template <int MODE>
+template <int MODE, int CH>   // CH = channels of the mask embedding (256: fai-mf, 128: bisenetformer)
 __global__ __launch_bounds__(256) void query_pixel_logits_kernel(const bf16_t* __restrict__ embed, int lde, const bf16_t* __restrict__ feat,
                                                                  int ldf, float* __restrict__ out, int ldo, uint32_t* __restrict__ bits,
                                                                  int ldw, int Q, int P) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char es[];  // [128][32 chunks of 16 B]
+  constexpr int NCH = CH / 8;      // 16-byte chunks per embedding row
+  constexpr int KS = CH / 16;      // MFMA k-steps
+  constexpr int ROWB = CH * 2;     // bytes per LDS row
+  extern __shared__ __attribute__((aligned(16))) unsigned char es[];  // [128][NCH chunks of 16 B], chunk index XOR-swizzled by the row
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b = blockIdx.y;
   const bf16_t* eb = embed + (int64_t)b * Q * lde;
-  for (int i = tid; i < 128 * 32; i += 256) {
-    const int row = i >> 5, c = i & 31;
+  for (int i = tid; i < 128 * NCH; i += 256) {
+    const int row = i / NCH, c = i % NCH;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (row < Q) v = *reinterpret_cast<const uint4*>(eb + (int64_t)row * lde + c * 8);
-    *reinterpret_cast<uint4*>(es + row * 512 + ((c ^ (row & 31)) << 4)) = v;
+    *reinterpret_cast<uint4*>(es + row * ROWB + ((c ^ (row & (NCH - 1))) << 4)) = v;
   }
   __syncthreads();
   const int j = lane & 31, h = lane >> 5;
@@ -76,11 +79,11 @@ __global__ __launch_bounds__(256) void query_pixel_logits_kernel(const bf16_t* _
     const int p0 = blockIdx.x * 256 + (wave * 2 + tt) * 32;
     if (p0 >= P) break;
     const int p = p0 + j;
-    bf16x8 kf[16];
+    bf16x8 kf[KS];
     {
       const bf16_t* fp = fb + (int64_t)(p < P ? p : P - 1) * ldf + 8 * h;
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) kf[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fp + kk * 16));
+      for (int kk = 0; kk < KS; ++kk) kf[kk] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(fp + kk * 16));
     }
 #pragma unroll 1
     for (int qt = 0; qt < nqt; ++qt) {
@@ -88,10 +91,10 @@ __global__ __launch_bounds__(256) void query_pixel_logits_kernel(const bf16_t* _
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
       const int row = qt * 32 + j;
-      const unsigned char* er = es + row * 512;
+      const unsigned char* er = es + row * ROWB;
 #pragma unroll
-      for (int kk = 0; kk < 16; ++kk) {
-        bf16x8 a = *reinterpret_cast<const bf16x8*>(er + (((kk * 2 + h) ^ (row & 31)) << 4));
+      for (int kk = 0; kk < KS; ++kk) {
+        bf16x8 a = *reinterpret_cast<const bf16x8*>(er + (((kk * 2 + h) ^ (row & (NCH - 1))) << 4));
         acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[kk], acc, 0, 0, 0);
       }
 #pragma unroll
@@ -114,18 +117,24 @@ __global__ __launch_bounds__(256) void query_pixel_logits_kernel(const bf16_t* _
 extern "C" int fx_query_pixel_logits_bf16(const void* embed, int lde, const void* feat, int ldf, int mode, float* out, int ldo,
                                           uint32_t* bits, int ld_words, int B, int Q, int P, int C, fx_stream_t stream_) {
   FX_CHECK_ARG(embed && feat && B > 0 && Q > 0 && P > 0);
-  if (C != 256 || Q > 128) return FX_ERR_UNSUPPORTED;
+  if ((C != 256 && C != 128) || Q > 128) return FX_ERR_UNSUPPORTED;
   FX_CHECK_ARG(lde >= C && ldf >= C && lde % 8 == 0 && ldf % 8 == 0);
   FX_CHECK_ARG(mode == 2 ? (bits && ld_words >= (P + 31) / 32) : ((mode == 0 || mode == 1) && out && ldo >= P));
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   dim3 grid((P + 255) / 256, B), block(256);
-  const size_t lds = 128 * 512;
-#define FX_QPL(M)                                                                                                                  \
-  hipLaunchKernelGGL(query_pixel_logits_kernel<M>, grid, block, lds, stream, (const bf16_t*)embed, lde, (const bf16_t*)feat, ldf, out, ldo, \
-                     bits, ld_words, Q, P)
-  if (mode == 0) FX_QPL(0);
-  else if (mode == 1) FX_QPL(1);
-  else FX_QPL(2);
+  const size_t lds = (size_t)128 * C * 2;
+#define FX_QPL(M, CH)                                                                                                                  \
+  hipLaunchKernelGGL((query_pixel_logits_kernel<M, CH>), grid, block, lds, stream, (const bf16_t*)embed, lde, (const bf16_t*)feat, ldf, out, \
+                     ldo, bits, ld_words, Q, P)
+  if (C == 256) {
+    if (mode == 0) FX_QPL(0, 256);
+    else if (mode == 1) FX_QPL(1, 256);
+    else FX_QPL(2, 256);
+  } else {
+    if (mode == 0) FX_QPL(0, 128);
+    else if (mode == 1) FX_QPL(1, 128);
+    else FX_QPL(2, 128);
+  }
 #undef FX_QPL
   return fx_launch_status();
 }

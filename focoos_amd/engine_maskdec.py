@@ -1,0 +1,243 @@
+"""The masked-attention query decoder shared by the MaskFormer (fai-mf-*) and BiSeNetFormer (bisenetformer-*) engines:
+weight packing and the launch sequence of
+
+  MultiScaleMaskedTransformerDecoder.forward     focoos/models/fai_mf/modelling.py:453-549          (3 memory levels)
+  TransformerDecoder.forward                     focoos/models/bisenetformer/modelling.py:375-447   (2 memory levels)
+  PredictionHeads.forward                        fai_mf/modelling.py:71-113 == bisenetformer/modelling.py:68-113
+  MaskFormerHead.forward tail                    fai_mf/modelling.py:599-617 == bisenetformer/modelling.py:497-510
+  {MaskFormer,BisenetFormer}Processor.postprocess (device part)  fai_mf/processor.py:212-262 == bisenetformer/processor.py:212-262
+
+(the two reference files are the same code up to the number of levels and the channel count of the mask embedding).
+Layer order: cross-attention (masked), self-attention, FFN, all pre-norm; layers cycle over the levels; K/V projections of the
+layers that attend the same level are one GEMM; the boolean attention mask `interpolate(mask_embed x mask_features) < 0` is
+computed as `mask_embed x interpolate(mask_features)` straight into a bitmap."""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .engine import NT, PackedConv
+
+HP = "head.predictor"
+PH = f"{HP}.forward_prediction_heads"
+
+
+def pack_mask_bits(mask: torch.Tensor, words: int) -> torch.Tensor:
+    """bool [R, L] (True = key not allowed) -> int32 [R, words], bit (key & 31) of word key/32; padding keys masked."""
+    R, L = mask.shape
+    m = np.ones((R, words * 32), dtype=np.uint8)
+    m[:, :L] = mask.cpu().numpy().astype(np.uint8)
+    packed = np.packbits(m, axis=-1, bitorder="little")  # [R, words*4] bytes, little-endian words
+    return torch.from_numpy(np.ascontiguousarray(packed).view("<u4").view(np.int32).reshape(R, words).copy())
+
+
+def pos_embed_sine_normalized(h: int, w: int, npf: int, temperature: float = 10000.0, scale: float = 2 * math.pi, eps: float = 1e-6) -> torch.Tensor:
+    """PositionEmbeddingSine(normalize=True) (nn/layers/position_encoding.py:52-81), token-major [h*w, 2*npf]:
+    embed = (index+1)/(size+eps)*2pi, sin/cos interleaved per channel pair, [y half | x half]."""
+    ys = (torch.arange(1, h + 1, dtype=torch.float32) / (h + eps) * scale).view(h, 1).expand(h, w)
+    xs = (torch.arange(1, w + 1, dtype=torch.float32) / (w + eps) * scale).view(1, w).expand(h, w)
+    i = torch.arange(npf, dtype=torch.float32)
+    dim_t = temperature ** (2 * torch.div(i, 2, rounding_mode="floor") / npf)
+    px, py = xs[..., None] / dim_t, ys[..., None] / dim_t
+    px = torch.stack((px[..., 0::2].sin(), px[..., 1::2].cos()), dim=-1).flatten(-2)
+    py = torch.stack((py[..., 0::2].sin(), py[..., 1::2].cos()), dim=-1).flatten(-2)
+    return torch.cat([py, px], dim=-1).reshape(h * w, 2 * npf)
+
+
+def pack_masked_decoder(eng, sd: Dict[str, torch.Tensor], P: Dict[str, PackedConv], nlev: int) -> None:
+    """Decoder + prediction-head weights of ``eng`` (attributes nl, hd=256) into P / eng.ln / eng.query_*."""
+
+    def lin(key, wkey):
+        P[key] = eng._pack_linear(sd[f"{wkey}.weight"], sd[f"{wkey}.bias"])
+
+    kw: List[List[torch.Tensor]] = [[] for _ in range(nlev)]
+    kb: List[List[torch.Tensor]] = [[] for _ in range(nlev)]
+    vw: List[List[torch.Tensor]] = [[] for _ in range(nlev)]
+    vb: List[List[torch.Tensor]] = [[] for _ in range(nlev)]
+    for li in range(eng.nl):
+        p = f"{HP}.transformer_cross_attention_layers.{li}"
+        Wi, bi = sd[f"{p}.multihead_attn.in_proj_weight"], sd[f"{p}.multihead_attn.in_proj_bias"]
+        P[f"{p}.q"] = eng._pack_linear(Wi[:256], bi[:256])
+        lin(f"{p}.out_proj", f"{p}.multihead_attn.out_proj")
+        lvl = li % nlev
+        kw[lvl].append(Wi[256:512]); kb[lvl].append(bi[256:512])
+        vw[lvl].append(Wi[512:]); vb[lvl].append(bi[512:])
+        eng._pack_ln(sd, f"{p}.norm")
+        p = f"{HP}.transformer_self_attention_layers.{li}"
+        Wi, bi = sd[f"{p}.self_attn.in_proj_weight"], sd[f"{p}.self_attn.in_proj_bias"]
+        P[f"{p}.qk"] = eng._pack_linear(Wi[:512], bi[:512])
+        P[f"{p}.v"] = eng._pack_linear(Wi[512:], bi[512:])
+        lin(f"{p}.out_proj", f"{p}.self_attn.out_proj")
+        eng._pack_ln(sd, f"{p}.norm")
+        p = f"{HP}.transformer_ffn_layers.{li}"
+        lin(f"{p}.linear1", f"{p}.linear1")
+        lin(f"{p}.linear2", f"{p}.linear2")
+        eng._pack_ln(sd, f"{p}.norm")
+    for lvl in range(nlev):
+        # the layers attending level lvl share their memory: all their key (value) projections as ONE GEMM
+        P[f"{HP}.k_all.{lvl}"] = eng._pack_linear(torch.cat(kw[lvl], 0), torch.cat(kb[lvl], 0))
+        P[f"{HP}.v_all.{lvl}"] = eng._pack_linear(torch.cat(vw[lvl], 0), torch.cat(vb[lvl], 0))
+        P[f"{HP}.input_proj.{lvl}"] = eng._pack(sd[f"{HP}.input_proj.{lvl}.weight"].float(), sd[f"{HP}.input_proj.{lvl}.bias"].float())
+    eng.query_feat = eng._dev(sd[f"{HP}.query_feat.weight"].float(), torch.bfloat16)
+    eng.query_embed = eng._dev(sd[f"{HP}.query_embed.weight"].float(), torch.bfloat16)
+    eng._pack_ln(sd, f"{PH}.decoder_norm")
+    lin(f"{PH}.classifier", f"{PH}.classifier")
+    for j in range(3):
+        lin(f"{PH}.mask_classifier.{j}", f"{PH}.mask_classifier.layers.{j}")
+
+
+class MaskDecoderPlanMixin:
+    """Launch-sequence builders for plans (subclasses of engine._PlanBase) whose engine has nq, nc, nl, nlev, P, ln, query_*."""
+
+    def build_masked_decoder(self, msf: Sequence[NT], mf: NT, md: int):
+        """``msf``: the nlev memory levels (coarsest first), ``mf``: mask features [B,h,w,md].  Returns (decoder_norm output of
+        the last layer [B*Q,256], its mask embedding [B*Q,md])."""
+        e, P, B, lib = self.eng, self.eng.P, self.B, self.lib
+        Q = e.nq
+        nlev = e.nlev
+        Ls, k_all, v_all, mfp, W32 = [], [], [], [], []
+        for l in range(nlev):
+            f = msf[l]
+            L = f.H * f.W
+            Ls.append(L)
+            W32.append((L + 31) // 32)
+            src_l = self.conv(f, P[f"{HP}.input_proj.{l}"], name=f"dec.src{l}").as_rows()
+            pos = pos_embed_sine_normalized(f.H, f.W, 128).to(device=self.dev, dtype=torch.bfloat16).contiguous()
+            pos_nt = NT(pos, L, 1, 1, 256, 256)
+            self.keep.append(pos)
+            srcpos = self.add_rows(src_l, pos_nt, L, f"dec.srcpos{l}")
+            k_all.append(self.linear(srcpos, P[f"{HP}.k_all.{l}"], name=f"dec.k_all{l}"))
+            v_all.append(self.linear(src_l, P[f"{HP}.v_all.{l}"], name=f"dec.v_all{l}"))
+            # attention-mask source: the mask features bilinearly resized to this level (commutes with the mask einsum)
+            m = self._new(f"dec.mfp{l}", B, f.H, f.W, md)
+            self.resize(mf, m)
+            mfp.append(m)
+        R = B * Q
+        qe = NT(e.query_embed, Q, 1, 1, 256, 256)
+        out0 = e.query_feat.repeat(B, 1).contiguous()
+        self.keep.append(out0)
+        out = NT(out0, R, 1, 1, 256, 256)
+        self.attn_bits: List[torch.Tensor] = []
+        self.force_points: List[int] = []
+
+        def heads(x: NT, idx: int, level: Optional[int]):
+            dn = self.layernorm(x, f"{PH}.decoder_norm", f"ph{idx}.dn")
+            m1 = self.linear(dn, P[f"{PH}.mask_classifier.0"], name=f"ph{idx}.m1", act="relu")
+            m2 = self.linear(m1, P[f"{PH}.mask_classifier.1"], name=f"ph{idx}.m2", act="relu")
+            emb = self.linear(m2, P[f"{PH}.mask_classifier.2"], name=f"ph{idx}.emb")
+            if level is not None:
+                bits = torch.zeros(R, W32[level], dtype=torch.int32, device=self.dev)
+                self._op(lib.fx_query_pixel_logits_bf16, emb.ptr, emb.ld, mfp[level].ptr, mfp[level].ld, 2, None, 0, bits.data_ptr(),
+                         W32[level], B, Q, Ls[level], md)
+                self.attn_bits.append(bits)
+                self.force_points.append(len(self.ops))
+            return dn, emb
+
+        heads(out, 0, 0)
+        dn = emb = None
+        # one workspace for the key-sliced cross attention (launches are serial on one stream)
+        mha_ws = torch.empty(max(8, max(lib.fx_mha_workspace_bytes(B, Q, L, 8, 1) for L in Ls)), dtype=torch.uint8, device=self.dev)
+        self.keep.append(mha_ws)
+        for i in range(e.nl):
+            lvl, j = i % nlev, i // nlev
+            p = f"{HP}.transformer_cross_attention_layers.{i}"
+            t2 = self.layernorm(out, f"{p}.norm", f"dec{i}.c_n")
+            qin = self.add_rows(t2, qe, Q, f"dec{i}.c_qin")
+            qc = self.linear(qin, P[f"{p}.q"], name=f"dec{i}.c_q")
+            att = self._new(f"dec{i}.c_att", R, 1, 1, 256)
+            ks, vs = k_all[lvl].slice(j * 256, 256), v_all[lvl].slice(j * 256, 256)
+            self._op(lib.fx_mha_masked_bf16, qc.ptr, qc.ld, ks.ptr, ks.ld, vs.ptr, vs.ld, att.ptr, att.ld, B, Q, Ls[lvl], 8,
+                     self.attn_bits[i].data_ptr(), W32[lvl], mha_ws.data_ptr(), C.c_size_t(mha_ws.numel()))
+            out = self.linear(att, P[f"{p}.out_proj"], name=f"dec{i}.c_o", residual=out)
+            p = f"{HP}.transformer_self_attention_layers.{i}"
+            t2 = self.layernorm(out, f"{p}.norm", f"dec{i}.s_n")
+            qk_in = self.add_rows(t2, qe, Q, f"dec{i}.s_qk_in")
+            qkv = self._new(f"dec{i}.s_qkv", R, 1, 1, 768)
+            self.linear(qk_in, P[f"{p}.qk"], out=qkv.slice(0, 512))
+            self.linear(t2, P[f"{p}.v"], out=qkv.slice(512, 256))
+            att = self.mha(qkv, B, Q, f"dec{i}.s_att")
+            out = self.linear(att, P[f"{p}.out_proj"], name=f"dec{i}.s_o", residual=out)
+            p = f"{HP}.transformer_ffn_layers.{i}"
+            t2 = self.layernorm(out, f"{p}.norm", f"dec{i}.f_n")
+            f1 = self.linear(t2, P[f"{p}.linear1"], name=f"dec{i}.f1", act="relu")
+            out = self.linear(f1, P[f"{p}.linear2"], name=f"dec{i}.out", residual=out)
+            dn, emb = heads(out, i + 1, (i + 1) % nlev if i < e.nl - 1 else None)
+        self.levels = Ls
+        self.W32 = W32
+        return dn, emb
+
+    def build_mask_outputs(self, dn: NT, emb: NT, mf: NT, md: int, full_masks: bool, predict_all_pixels: bool):
+        """Class probabilities, low-resolution mask probabilities, optional full-resolution ``masks`` and the device side of the
+        processor's postprocess (threshold branch: fx_mf_postprocess; predict_all_pixels branch: fx_seg_postprocess)."""
+        e, P, B, lib = self.eng, self.eng.P, self.B, self.lib
+        H, W = self.H, self.W
+        Q, K = e.nq, e.nc
+        R = B * Q
+        hl, wl = mf.H, mf.W
+        cls_logits = self.linear(dn, P[f"{PH}.classifier"], name="cls_logits", out_f32=True)
+        self.probs = self._io("probs", (B, Q, K), torch.float32)
+        self.cls_score = self._io("cls_score", (B, Q), torch.float32)
+        self.cls_label = self._io("cls_label", (B, Q), torch.int32)
+        self._op(lib.fx_mf_class_head, cls_logits.ptr, cls_logits.ld, self.probs.data_ptr(), self.cls_score.data_ptr(), self.cls_label.data_ptr(),
+                 R, K, int(e.cls_sigmoid))
+        PL = hl * wl
+        self.mask_probs = self._io("mask_probs", (B, Q, hl, wl), torch.float32)  # sigmoid(mask logits) at the mask-feature resolution
+        mf_rows = mf.as_rows()
+        self._op(lib.fx_query_pixel_logits_bf16, emb.ptr, emb.ld, mf_rows.ptr, mf_rows.ld, 1, self.mask_probs.data_ptr(), PL, None, 0, B, Q, PL, md)
+        self.masks = None
+        if full_masks:
+            self.masks = self._io("masks", (B, Q, H, W), torch.float32)
+            self._op(lib.fx_mf_upsample_probs_f32, self.mask_probs.data_ptr(), hl, wl, self.masks.data_ptr(), H, W, R)
+        self.det_count = self._io("det_count", (B,), torch.int32).zero_()
+        self.det_query = self._io("det_query", (B, Q), torch.int32).zero_()
+        self.det_scores = self._io("det_scores", (B, Q), torch.float32).zero_()
+        self.det_labels = self._io("det_labels", (B, Q), torch.int32).zero_()
+        self.det_boxes = self._io("det_boxes", (B, Q, 4), torch.int32).zero_()
+        self.det_area = self._io("det_area", (B, Q), torch.int32).zero_()
+        self.mask_words = self._io("mask_words", (B, Q, H, W // 32), torch.int32).zero_()
+        self.winner = None
+        self.post_index = len(self.ops)
+        if predict_all_pixels:
+            ws_bytes = lib.fx_seg_postprocess_workspace_bytes(B, Q, hl, wl, H, W)
+            self.post_ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=self.dev)
+            self.winner = self._io("winner", (B, H, W), torch.uint8)   # per-pixel query index (semantic map = cls_label[winner])
+            self._op(lib.fx_seg_postprocess, self.mask_probs.data_ptr(), hl, wl, H, W, self.cls_score.data_ptr(), self.cls_label.data_ptr(), B, Q,
+                     None, int(e.use_mask_score), self.post_ws.data_ptr(), C.c_size_t(self.post_ws.numel()), self.det_count.data_ptr(),
+                     self.det_query.data_ptr(), self.det_scores.data_ptr(), self.det_labels.data_ptr(), self.det_boxes.data_ptr(),
+                     self.det_area.data_ptr(), self.mask_words.data_ptr(), self.winner.data_ptr())
+        else:
+            ws_bytes = lib.fx_mf_postprocess_workspace_bytes(B, Q, H)
+            self.post_ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=self.dev)
+            self._op(lib.fx_mf_postprocess, self.mask_probs.data_ptr(), hl, wl, H, W, self.cls_score.data_ptr(), self.cls_label.data_ptr(), B, Q,
+                     C.c_float(e.mask_threshold), None, int(e.use_mask_score), self.post_ws.data_ptr(), C.c_size_t(self.post_ws.numel()),
+                     self.det_count.data_ptr(), self.det_query.data_ptr(), self.det_scores.data_ptr(), self.det_labels.data_ptr(),
+                     self.det_boxes.data_ptr(), self.det_area.data_ptr(), self.mask_words.data_ptr())
+
+    # -------------------------------------------------------------- execution
+    def patch_args(self, fn, args, thr: float):
+        if fn is self.lib.fx_mf_postprocess:
+            return args[:10] + (C.c_float(thr),) + args[11:]
+        if fn is self.lib.fx_seg_postprocess:
+            return args[:9] + (C.c_float(thr),) + args[10:]
+        return args
+
+    def run(self, stream: int, thr: float, forced_attn: Optional[Sequence[torch.Tensor]] = None, use_graph: bool = True):
+        if forced_attn is not None:
+            # teacher-forced attention masks (parity tests): overwrite each layer's bitmap right after it is produced
+            assert len(forced_attn) == len(self.force_points)
+            prev = 0
+            for i, (pt, m) in enumerate(zip(self.force_points, forced_attn)):
+                self._launch(self.ops[prev:pt], stream, thr)
+                bits = pack_mask_bits(m.reshape(self.B * self.eng.nq, -1), self.attn_bits[i].shape[1])
+                self.attn_bits[i].copy_(bits.to(self.dev))
+                prev = pt
+            self._launch(self.ops[prev:], stream, thr)
+            return
+        if not use_graph:
+            self._launch(self.ops, stream, thr)
+            return
+        self.capture_and_launch(stream, thr)

@@ -100,16 +100,52 @@ def make_mf_engine_class():
     return EngineFAIMaskFormer
 
 
+def make_bf_engine_class():
+    """Adapter for the BiSeNetFormer family: reference BisenetFormer whose eval forward is the gfx950 engine."""
+    from focoos.models.bisenetformer.modelling import BisenetFormer as RefBisenetFormer
+    from focoos.models.bisenetformer.ports import BisenetFormerOutput
+
+    from .engine_bf import BfEngine
+
+    class EngineBisenetFormer(RefBisenetFormer):
+        def __init__(self, config):
+            super().__init__(config)
+            self._fx_engine: Optional[BfEngine] = None
+            self._fx_version = None
+
+        def _fx_sync(self):
+            ver = tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
+            if self._fx_engine is None:
+                self._fx_engine = BfEngine(_config_to_dict(self.config), self.state_dict(), str(self.device), full_masks=True)
+            elif ver != self._fx_version:
+                self._fx_engine.load_state_dict(self.state_dict())
+            self._fx_version = ver
+
+        def forward(self, images, targets=[]):
+            if self.training or (targets is not None and len(targets) > 0) or torch.is_grad_enabled() and images.requires_grad:
+                return super().forward(images, targets)  # training path: the reference's own graph
+            self._fx_sync()
+            x = images
+            if x.dim() == 4 and x.shape[1] == 3 and x.shape[-1] != 3:
+                x = x.permute(0, 2, 3, 1)
+            x = (x if x.dtype == torch.uint8 else x.float()).contiguous()
+            pl = self._fx_engine.forward(x, full_masks=True)
+            return BisenetFormerOutput(masks=pl.masks.clone(), logits=pl.probs.clone(), loss=None)
+
+    return EngineBisenetFormer
+
+
 def register() -> None:
-    """Re-register the DETR and MaskFormer families with the engine-backed model classes (last registration wins,
+    """Re-register the DETR, MaskFormer and BiSeNetFormer families with the engine-backed model classes (last registration wins,
     model_manager.py:93-105)."""
     from focoos.model_manager import ModelManager
     from focoos.ports import ModelFamily
 
+    import focoos.models.bisenetformer as family_bf
     import focoos.models.fai_detr as family
     import focoos.models.fai_mf as family_mf
 
-    for fam in (family, family_mf):
+    for fam in (family, family_mf, family_bf):
         for name in dir(fam):  # the family's own _register(): config + processor (+ stock model) registries
             if name.startswith("_register") and callable(getattr(fam, name)):
                 getattr(fam, name)()
@@ -117,6 +153,8 @@ def register() -> None:
     ModelManager.register_model(ModelFamily.DETR, lambda: cls)
     cls_mf = make_mf_engine_class()
     ModelManager.register_model(ModelFamily.MASKFORMER, lambda: cls_mf)
+    cls_bf = make_bf_engine_class()
+    ModelManager.register_model(ModelFamily.BISENETFORMER, lambda: cls_bf)
 
 
 def bind_msda_core(module) -> int:

@@ -20,9 +20,10 @@ import numpy as np
 import torch
 
 from .engine import DetrEngine
+from .engine_bf import BfEngine
 from .engine_mf import MfEngine
-from .ports import DETRModelOutput, FocoosDetections, InferLatency, MaskFormerModelOutput, ModelInfo
-from .processor import DETRProcessor, MaskFormerProcessor
+from .ports import BisenetFormerOutput, DETRModelOutput, FocoosDetections, InferLatency, MaskFormerModelOutput, ModelInfo
+from .processor import BisenetFormerProcessor, DETRProcessor, MaskFormerProcessor
 from .registry import ModelRegistry
 from .state_spec import state_spec
 from .synth import synth_state_dict
@@ -168,6 +169,23 @@ class FAIMaskFormer(_EngineModel):
         return pl
 
 
+class BisenetFormer(FAIMaskFormer):
+    """Engine-backed BiSeNetFormer (focoos/models/bisenetformer/modelling.py:523-609): same contract as FAIMaskFormer
+    (``forward`` -> BisenetFormerOutput with the full-resolution fp32 ``masks``; ``detect`` -> fused forward + device post-process,
+    whose plan also holds ``winner`` [B,H,W] uint8, the per-pixel query index of the predict_all_pixels branch)."""
+
+    family = "bisenetformer"
+
+    def _make_engine(self):
+        return BfEngine(self.config, self._state, str(self._device), **self._engine_kwargs)
+
+    def forward(self, images: torch.Tensor, targets: list = [], forced_attn=None, use_graph: bool = True) -> BisenetFormerOutput:
+        out = super().forward(images, targets, forced_attn, use_graph)
+        return BisenetFormerOutput(masks=out.masks, logits=out.logits, loss=None)
+
+    __call__ = forward
+
+
 class FocoosModel:
     """focoos/models/focoos_model.py:88-147 — model + processor + model_info."""
 
@@ -176,6 +194,8 @@ class FocoosModel:
         self.model_info = model_info
         if model.family == "fai_mf":  # MaskFormerProcessor ignores image_size (fai_mf/processor.py:96: no resize)
             self.processor = MaskFormerProcessor(model_info.config).eval()
+        elif model.family == "bisenetformer":
+            self.processor = BisenetFormerProcessor(model_info.config).eval()
         else:
             self.processor = DETRProcessor(model_info.config, image_size=model_info.im_size).eval()
         self.model.eval()
@@ -195,7 +215,7 @@ class FocoosModel:
         pl = self.model.detect(images, sizes=sizes, threshold=thr)
         torch.cuda.current_stream(self.model.device).synchronize()
         t2 = perf_counter()
-        if self.model.family == "fai_mf":
+        if self.model.family in ("fai_mf", "bisenetformer"):
             out = self.processor.pack_detections(pl, self.model_info.classes)
         else:
             out = self.processor.pack_detections(pl.det_scores, pl.det_labels, pl.det_boxes, pl.det_count, self.model_info.classes)
@@ -227,7 +247,8 @@ class FocoosModel:
 class ModelManager:
     """focoos/model_manager.py:17-155 — lazy family registry + ``get``."""
 
-    _MODEL_MAPPING: Dict[str, Callable[[], Type]] = {"fai_detr": lambda: FAIDetr, "fai_mf": lambda: FAIMaskFormer}
+    _MODEL_MAPPING: Dict[str, Callable[[], Type]] = {"fai_detr": lambda: FAIDetr, "fai_mf": lambda: FAIMaskFormer,
+                                                              "bisenetformer": lambda: BisenetFormer}
 
     @classmethod
     def register_model(cls, model_family: str, model_loader: Callable[[], Type]):

@@ -55,6 +55,14 @@ class MaskFormerModelOutput:
 
 
 @dataclass
+class BisenetFormerOutput:
+    """focoos/models/bisenetformer/ports.py (same fields as MaskFormerModelOutput)."""
+    masks: torch.Tensor   # [N, num_queries, H, W] mask probabilities (sigmoid at 1/8 resolution, bilinearly upsampled to the input size)
+    logits: torch.Tensor  # [N, num_queries, num_classes] class probabilities (softmax, no-object column dropped)
+    loss: Optional[dict] = None
+
+
+@dataclass
 class DETRTargets:
     labels: torch.Tensor
     boxes: torch.Tensor

@@ -178,10 +178,12 @@ class MaskFormerProcessor(DETRProcessor):
     the host.  The reference's gather-based filtering only works for batch 1 (index tensors are [1, n]); here every image
     of the batch gets the batch-1 behaviour."""
 
+    _postprocessing_types = ("instance",)
+
     def __init__(self, config: dict, image_size=None):
         super().__init__(config, None)
-        if config.get("postprocessing_type", "instance") != "instance":
-            raise NotImplementedError("engine MaskFormerProcessor covers postprocessing_type='instance' (fai-mf-*-coco-ins)")
+        if config.get("postprocessing_type", "instance") not in self._postprocessing_types:
+            raise NotImplementedError(f"engine {type(self).__name__} covers postprocessing_type in {self._postprocessing_types}")
         self.num_classes = int(config["num_classes"])
         self.mask_threshold = float(config.get("mask_threshold", 0.5))
         self.top_k = int(config.get("top_k", 100))
@@ -203,8 +205,7 @@ class MaskFormerProcessor(DETRProcessor):
                     predict_all_pixels: Optional[bool] = None) -> List[FocoosDetections]:
         threshold = threshold or self.threshold
         use_mask_score = use_mask_score or self.use_mask_score
-        if predict_all_pixels or self.predict_all_pixels:
-            raise NotImplementedError("predict_all_pixels=True (argmax-over-queries masks) is not on the engine path")
+        predict_all_pixels = predict_all_pixels or self.predict_all_pixels
         image_sizes = self.get_image_sizes(inputs)
         masks = output.masks.contiguous()
         probs = output.logits.contiguous()
@@ -217,9 +218,17 @@ class MaskFormerProcessor(DETRProcessor):
         score, label = probs.max(-1)  # processor.py:212
         score, label = score.contiguous(), label.to(torch.int32).contiguous()
         res = _MfDeviceResults(B, Q, H, W, dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        if predict_all_pixels:  # every pixel goes to the query maximising score x probability (processor.py:215-229)
+            nb = lib.fx_seg_postprocess_workspace_bytes(B, Q, H, W, H, W)
+            ws = torch.empty(max(nb, 16), dtype=torch.uint8, device=dev)
+            check(lib.fx_seg_postprocess(masks.data_ptr(), H, W, H, W, score.data_ptr(), label.data_ptr(), B, Q, float(threshold),
+                                         int(bool(use_mask_score)), ws.data_ptr(), ws.numel(), res.det_count.data_ptr(), res.det_query.data_ptr(),
+                                         res.det_scores.data_ptr(), res.det_labels.data_ptr(), res.det_boxes.data_ptr(), res.det_area.data_ptr(),
+                                         res.mask_words.data_ptr(), None, stream), "fx_seg_postprocess")
+            return self.pack_detections(res, class_names)
         nb = lib.fx_mf_postprocess_workspace_bytes(B, Q, H)
         ws = torch.empty(max(nb, 8), dtype=torch.uint8, device=dev)
-        stream = torch.cuda.current_stream(dev).cuda_stream
         # full-resolution probabilities: the kernel's bilinear tap degenerates to the identity (scale 1)
         check(lib.fx_mf_postprocess(masks.data_ptr(), H, W, H, W, score.data_ptr(), label.data_ptr(), B, Q, float(self.mask_threshold),
                                     float(threshold), int(bool(use_mask_score)), ws.data_ptr(), ws.numel(), res.det_count.data_ptr(),
@@ -250,6 +259,15 @@ class MaskFormerProcessor(DETRProcessor):
                           mask=binary_mask_to_base64(trim_mask(masks[j], b[i][j])) if encode_masks else None)
                 for j in range(ni)]))
         return out
+
+
+class BisenetFormerProcessor(MaskFormerProcessor):
+    """Mirror of focoos/models/bisenetformer/processor.py:25-300 - the same processor as MaskFormerProcessor (the reference files
+    are line-for-line copies) for the "semantic" / "instance" configurations; ``postprocess`` covers both the threshold branch and
+    the predict_all_pixels branch (per-pixel argmax over queries, ``fx_seg_postprocess``).  The trainer-side
+    ``eval_postprocess`` (semantic_inference einsum, :95-101, 134-157) belongs to the evaluator and is not mirrored."""
+
+    _postprocessing_types = ("semantic", "instance")
 
 
 class _MfDeviceResults:

@@ -175,7 +175,7 @@ int fx_upsample_nearest_add_nhwc_bf16(const void* lateral, int ldl, const void* 
                                       int Hs, int Ws, int C, fx_stream_t stream);
 
 /* PredictionHeads mask einsum (fai_mf/modelling.py:88): logit[b,q,p] = sum_c embed[b,q,c] * feat[b,p,c]; embed bf16
- * [B*Q, C] (row stride lde), feat bf16 [B*P, C] (row stride ldf), C == 256, Q <= 128.
+ * [B*Q, C] (row stride lde), feat bf16 [B*P, C] (row stride ldf), C == 256 (fai-mf) or 128 (bisenetformer), Q <= 128.
  *  mode 0: out f32 [B*Q][ldo] = logit;  mode 1: out = sigmoid(logit) (MaskFormerHead.forward :614);
  *  mode 2: bits u32 [B*Q][ld_words]: bit (p & 31) of word p/32 = (logit < 0), the attention mask of :104 when feat is the
  *          mask-feature map bilinearly resized to the attended level (the resize commutes with the einsum). */
@@ -202,6 +202,38 @@ int fx_mf_postprocess(const float* mask_probs_lowres, int h, int w, int H, int W
                       float mask_threshold, float threshold, int use_mask_score, void* workspace, size_t workspace_bytes,
                       int32_t* det_count, int32_t* det_query, float* det_score, int32_t* det_label, int32_t* det_box, int32_t* det_area,
                       uint32_t* mask_words, fx_stream_t stream);
+
+/* ---- BiSeNetFormer path (focoos/models/bisenetformer/modelling.py, focoos/nn/backbone/stdc.py) -------
+ * Depthwise 3x3 stride-2 pad-1 convolution on NHWC bf16: y[b,ho,wo,c] = bias[c] + sum_k w[k][c] * x[...] (w f32 [9][C] with the
+ * eval BatchNorm scale folded in, bias f32 [C] = BN shift or NULL).  STDC CatBottleneck `avd_layer` (stdc.py:114-127); with
+ * w = 1/9 and no bias it is the block's AvgPool2d(3, 2, 1) skip (:128, count_include_pad=True).  C % 8 == 0. */
+int fx_dwconv3x3s2_nhwc_bf16(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int B, int H, int W, int C,
+                             fx_stream_t stream);
+
+/* mean over the P pixels of each image: out f32 [B][ldo] (feat.mean(dim=(2,3)), modelling.py:161,187; adaptive_avg_pool2d :230). */
+int fx_global_mean_nhwc_bf16(const void* x, int ldx, float* out, int ldo, int B, int P, int C, fx_stream_t stream);
+
+/* 1x1 convolutions on pooled [B,C,1,1] tensors: out[b][n] = act(bias[n] + sum_c W[n][c] * in[b][c]), all f32; act = FX_ACT_NONE,
+ * FX_ACT_RELU or 4 (sigmoid).  conv_avg (:188), conv_atten + bn_atten + sigmoid (:162-164), FFM conv1/relu/conv2/sigmoid (:231-234). */
+int fx_pooled_linear_f32(const float* in, int ldi, const float* W, const float* bias, int act, float* out, int ldo, int B, int C, int N,
+                         fx_stream_t stream);
+
+/* y[b,p,c] = x[b,p,c] * gate[b][c] (+ x if self_add) (+ add_vec[b][c]) (+ add_map[b,p,c]); x / add_map / y bf16 NHWC, gate /
+ * add_vec f32 [B][ld].  ARM output (:165) fused with ContextPath's sums (:191,196); FFM `feat * atten + feat` (:235-236). */
+int fx_channel_gate_nhwc_bf16(const void* x, int ldx, const float* gate, int ldg, int self_add, const float* add_vec, int ldv,
+                              const void* add_map, int ldm, void* y, int ldy, int B, int P, int C, fx_stream_t stream);
+
+/* Device side of BisenetFormerProcessor.postprocess with predict_all_pixels (bisenetformer/processor.py:212-262 + masks_to_xyxy):
+ * winner[b,y,x] = argmax_q score[b,q] * up(mask_probs_lowres[b,q])[y,x] (first maximum; `up` = the bilinear x(H/h) upsample of
+ * BisenetFormer.forward :607, fused); query q's binary mask = (winner == q); keep masks with > 1 pixel; score = class score
+ * [* (1e-3 * sum winning prob) / (1e-3 * area + 1e-5) if use_mask_score]; keep score > threshold (<= 0 keeps all).  Outputs as
+ * fx_mf_postprocess (survivors compacted in query order); winner_out (optional) u8 [B][H][W], 16-byte aligned: the per-pixel
+ * query index (the semantic map is label[winner]).  Q <= 128; workspace: fx_seg_postprocess_workspace_bytes(...), 16-byte aligned. */
+size_t fx_seg_postprocess_workspace_bytes(int B, int Q, int h, int w, int H, int W);
+int fx_seg_postprocess(const float* mask_probs_lowres, int h, int w, int H, int W, const float* score, const int32_t* label, int B, int Q,
+                       float threshold, int use_mask_score, void* workspace, size_t workspace_bytes, int32_t* det_count, int32_t* det_query,
+                       float* det_score, int32_t* det_label, int32_t* det_box, int32_t* det_area, uint32_t* mask_words, uint8_t* winner_out,
+                       fx_stream_t stream);
 
 /* ---- set criterion (training path, forward only this round): SURVEY §8a rows A14/A15 ------------------------------
  * BoxHungarianMatcher cost (fai_detr/modelling.py:714-746, focal branch; box math focoos/utils/box.py:14-64), computed

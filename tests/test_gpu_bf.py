@@ -1,0 +1,353 @@
+"""BiSeNetFormer path on a real MI355X: per-kernel parity of the new C-ABI entry points against plain torch
+fp32 / the oracle, and end-to-end parity of the engine against oracle/bf_oracle.py (pinned to the real reference by
+tests/golden/bf_l_ade_b2.npz).
+
+Tolerances (bf16 activations/weights, fp32 accumulate; class logits, mask probabilities and scores fp32):
+  * depthwise conv / pooling / gate kernels on bf16-representable inputs: one bf16 rounding of the output (rel 4e-3);
+  * feature maps: relative L2 <= 2.5e-2 vs the fp32 oracle;
+  * with the boolean attention masks teacher-forced to the reference's: |dprob| <= 3e-2, low-resolution mask probabilities
+    mean |d| <= 1e-2 and >= 99 % binary agreement at 0.5;
+  * predict_all_pixels post-process (fed identical fp32 inputs): winner map, counts, labels, int boxes, areas and bit masks
+    bit-exact vs the oracle's restatement of the reference, scores 1e-5.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from focoos_amd import _lib  # noqa: E402
+from focoos_amd._lib import check  # noqa: E402
+from focoos_amd.engine_bf import BfEngine  # noqa: E402
+from focoos_amd.engine_maskdec import pack_mask_bits  # noqa: E402
+from focoos_amd.registry import ModelRegistry  # noqa: E402
+from focoos_amd.synth import synth_image_structured, synth_state_dict  # noqa: E402
+from oracle import bf_oracle as BF  # noqa: E402
+from oracle import mf_oracle as M  # noqa: E402
+from oracle.detr_oracle import get_torch_batch  # noqa: E402
+from tests.helpers import load_golden, rel_l2  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def lib():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return _lib.load()
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev(t, dtype=None):
+    return t.to(device=DEV, dtype=dtype or t.dtype).contiguous()
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 16, 128), (1, 13, 15, 64), (3, 7, 9, 520)])
+def test_dwconv3x3s2_and_avgpool(lib, shape):
+    B, H, W, Cc = shape
+    g = torch.Generator().manual_seed(Cc)
+    x = torch.randn(B, H, W, Cc, generator=g).bfloat16()
+    w = torch.randn(Cc, 1, 3, 3, generator=g) * 0.4
+    bias = torch.randn(Cc, generator=g) * 0.2
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    xd, wd, bd = dev(x), dev(w[:, 0].permute(1, 2, 0).reshape(9, Cc).contiguous()), dev(bias)
+    y = torch.empty(B, Ho, Wo, Cc + 8, dtype=torch.bfloat16, device=DEV).fill_(7.0)   # strided output (channel slice of a wider buffer)
+    check(lib.fx_dwconv3x3s2_nhwc_bf16(xd.data_ptr(), Cc, wd.data_ptr(), bd.data_ptr(), y.data_ptr(), Cc + 8, B, H, W, Cc, stream()))
+    torch.cuda.synchronize()
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w, bias, stride=2, padding=1, groups=Cc).permute(0, 2, 3, 1)
+    assert (y[..., :Cc].float().cpu() - ref).abs().max() <= 4e-3 * ref.abs().max() + 1e-6
+    assert bool((y[..., Cc:] == 7.0).all())
+    pw = torch.full((9, Cc), 1.0 / 9.0, device=DEV)
+    check(lib.fx_dwconv3x3s2_nhwc_bf16(xd.data_ptr(), Cc, pw.data_ptr(), None, y.data_ptr(), Cc + 8, B, H, W, Cc, stream()))
+    torch.cuda.synchronize()
+    ref = F.avg_pool2d(x.float().permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)      # count_include_pad=True, like nn.AvgPool2d(3, 2, 1)
+    assert (y[..., :Cc].float().cpu() - ref).abs().max() <= 4e-3 * ref.abs().max() + 1e-6
+
+
+def test_pooled_ops_and_gate(lib):
+    g = torch.Generator().manual_seed(1)
+    B, P, Cc, N = 3, 77, 128, 32
+    x = torch.randn(B, P, Cc, generator=g).bfloat16()
+    xd = dev(x)
+    mean = torch.empty(B, Cc, dtype=torch.float32, device=DEV)
+    check(lib.fx_global_mean_nhwc_bf16(xd.data_ptr(), Cc, mean.data_ptr(), Cc, B, P, Cc, stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(mean.cpu().numpy(), x.float().mean(1).numpy(), rtol=1e-5, atol=1e-6)
+    Wm, bv = torch.randn(N, Cc, generator=g) * 0.2, torch.randn(N, generator=g)
+    wd, bd = dev(Wm), dev(bv)
+    out = torch.empty(B, N, dtype=torch.float32, device=DEV)
+    for act, fn in ((0, lambda t: t), (1, F.relu), (4, torch.sigmoid)):
+        check(lib.fx_pooled_linear_f32(mean.data_ptr(), Cc, wd.data_ptr(), bd.data_ptr(), act, out.data_ptr(), N, B, Cc, N, stream()))
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(out.cpu().numpy(), fn(mean.cpu() @ Wm.t() + bv).numpy(), rtol=2e-5, atol=2e-6)
+    check(lib.fx_pooled_linear_f32(mean.data_ptr(), Cc, wd.data_ptr(), None, 0, out.data_ptr(), N, B, Cc, N, stream()))
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(out.cpu().numpy(), (mean.cpu() @ Wm.t()).numpy(), rtol=2e-5, atol=2e-6)
+    gate = torch.rand(B, Cc, generator=g)
+    addv = torch.randn(B, Cc, generator=g)
+    addm = torch.randn(B, P, Cc, generator=g).bfloat16()
+    gd, avd, amd = dev(gate), dev(addv), dev(addm)
+    y = torch.empty(B, P, Cc, dtype=torch.bfloat16, device=DEV)
+    for self_add, use_v, use_m in ((0, 1, 0), (0, 0, 1), (1, 0, 0), (1, 1, 1)):
+        check(lib.fx_channel_gate_nhwc_bf16(xd.data_ptr(), Cc, gd.data_ptr(), Cc, self_add, avd.data_ptr() if use_v else None, Cc,
+                                            amd.data_ptr() if use_m else None, Cc, y.data_ptr(), Cc, B, P, Cc, stream()))
+        torch.cuda.synchronize()
+        ref = x.float() * gate[:, None] + (x.float() if self_add else 0) + (addv[:, None] if use_v else 0) + (addm.float() if use_m else 0)
+        assert (y.float().cpu() - ref).abs().max() <= 4e-3 * ref.abs().max()
+
+
+@pytest.mark.parametrize("P", [500, 4096])
+def test_query_pixel_logits_128_channels(lib, P):
+    B, Q, Cc = 2, 100, 128
+    g = torch.Generator().manual_seed(P)
+    e = torch.randn(B, Q, Cc, generator=g).bfloat16()
+    f = torch.randn(B, P, Cc, generator=g).bfloat16()
+    ref = torch.einsum("bqc,bpc->bqp", e.float(), f.float())
+    ed, fd = dev(e), dev(f)
+    out = torch.full((B, Q, P), float("nan"), dtype=torch.float32, device=DEV)
+    check(lib.fx_query_pixel_logits_bf16(ed.data_ptr(), Cc, fd.data_ptr(), Cc, 0, out.data_ptr(), P, None, 0, B, Q, P, Cc, stream()))
+    torch.cuda.synchronize()
+    assert (out.cpu() - ref).abs().max() < 2e-3 * ref.abs().max()
+    check(lib.fx_query_pixel_logits_bf16(ed.data_ptr(), Cc, fd.data_ptr(), Cc, 1, out.data_ptr(), P, None, 0, B, Q, P, Cc, stream()))
+    torch.cuda.synchronize()
+    assert (out.cpu() - torch.sigmoid(ref)).abs().max() < 1e-3
+    words = (P + 31) // 32
+    bits = torch.zeros(B * Q, words, dtype=torch.int32, device=DEV)
+    check(lib.fx_query_pixel_logits_bf16(ed.data_ptr(), Cc, fd.data_ptr(), Cc, 2, None, 0, bits.data_ptr(), words, B, Q, P, Cc, stream()))
+    torch.cuda.synchronize()
+    got = bits.cpu().numpy().view(np.uint32)
+    want = pack_mask_bits((ref < 0).reshape(B * Q, P), words).numpy().view(np.uint32)
+    diff = np.unpackbits((got ^ want).view(np.uint8)).reshape(B * Q, -1)
+    near = (ref.abs() < 1e-3 * ref.abs().max()).reshape(B * Q, P).numpy()
+    assert diff.sum() <= near.sum()
+
+
+def _blob_probs(B, Q, h, w, seed):
+    rs = np.random.RandomState(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    lo = np.zeros((B, Q, h, w), np.float32)
+    for b in range(B):
+        for q in range(Q):
+            cy, cx, r = rs.uniform(0, h), rs.uniform(0, w), rs.uniform(1, h / 2)
+            lo[b, q] = 1 / (1 + np.exp(((yy - cy) ** 2 + (xx - cx) ** 2 - r * r) / (r * 2 + 1))) * rs.uniform(0.3, 1.0)
+    lo[:, 2] = 0.01
+    probs = torch.softmax(torch.from_numpy(rs.standard_normal((B, Q, 151)).astype(np.float32)) * 4, -1)[..., :-1].contiguous()
+    return torch.from_numpy(lo), probs
+
+
+@pytest.mark.parametrize("cfg", [(2, 100, 20, 24, 8), (1, 37, 9, 12, 8), (2, 50, 16, 16, 4), (1, 100, 20, 24, 1), (1, 30, 11, 13, 0)])
+@pytest.mark.parametrize("use_mask_score", [False, True])
+def test_seg_postprocess_vs_oracle(lib, cfg, use_mask_score):
+    """fx_seg_postprocess (x8 / x4 cell kernels, scale 1 and a non-integer scale through the generic kernel) vs the oracle's
+    restatement of BisenetFormerProcessor.postprocess (predict_all_pixels=True) on the kernel-independent F.interpolate output."""
+    B, Q, h, w, S = cfg
+    H, W = (S * h, S * w) if S else (96, 128)
+    lo, probs = _blob_probs(B, Q, h, w, 7 + S)
+    score, label = probs.max(-1)
+    full = F.interpolate(lo, size=(H, W), mode="bilinear", align_corners=False)
+    lod, sd, ld_ = dev(lo), dev(score), dev(label.int())
+    nb = lib.fx_seg_postprocess_workspace_bytes(B, Q, h, w, H, W)
+    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    cnt = torch.zeros(B, dtype=torch.int32, device=DEV)
+    dq, dl, da = (torch.zeros(B, Q, dtype=torch.int32, device=DEV) for _ in range(3))
+    ds = torch.zeros(B, Q, dtype=torch.float32, device=DEV)
+    db = torch.zeros(B, Q, 4, dtype=torch.int32, device=DEV)
+    words = torch.zeros(B, Q, H, W // 32, dtype=torch.int32, device=DEV)
+    winner = torch.zeros(B, H, W, dtype=torch.uint8, device=DEV)
+    want_win = (score.view(B, Q, 1, 1) * full).argmax(dim=1)
+    for thr in (0.5, 0.05):
+        check(lib.fx_seg_postprocess(lod.data_ptr(), h, w, H, W, sd.data_ptr(), ld_.data_ptr(), B, Q, thr, int(use_mask_score), ws.data_ptr(), nb,
+                                     cnt.data_ptr(), dq.data_ptr(), ds.data_ptr(), dl.data_ptr(), db.data_ptr(), da.data_ptr(), words.data_ptr(),
+                                     winner.data_ptr(), stream()))
+        torch.cuda.synchronize()
+        assert torch.equal(winner.cpu().long(), want_win)
+        for b in range(B):
+            s, l, q, boxes, bm = M.postprocess(probs[b:b + 1], full[b:b + 1], [(H, W)], 0.5, thr, use_mask_score, predict_all_pixels=True)[0]
+            n = int(cnt[b])
+            assert n == len(s) and n > 0
+            assert dq[b, :n].cpu().tolist() == q.tolist()
+            assert dl[b, :n].cpu().tolist() == l.tolist()
+            np.testing.assert_allclose(ds[b, :n].cpu().numpy(), s.numpy(), rtol=2e-5, atol=1e-6)
+            assert db[b, :n].cpu().tolist() == boxes.tolist()
+            assert da[b, :n].cpu().tolist() == bm.reshape(n, -1).sum(-1).tolist()
+            got = np.unpackbits(words[b, :n].cpu().numpy().view(np.uint8), axis=-1, bitorder="little").reshape(n, H, W).astype(bool)
+            assert (got == bm).all()
+
+
+# ------------------------------------------------------------------------------------------------- end to end
+@pytest.fixture(scope="module")
+def setup():
+    assert torch.cuda.is_available()
+    g = load_golden("bf_l_ade_b2.npz")
+    cfg = ModelRegistry.get_model_info("bisenetformer-l-ade")["config"]
+    sd = synth_state_dict(cfg, int(g["seed"]), family="bisenetformer")
+    eng = BfEngine(cfg, sd, device=DEV, full_masks=True)
+    h, w = (int(v) for v in g["hw"])
+    images = [synth_image_structured(i, h, w) for i in range(2)]
+    forced = [torch.from_numpy(np.unpackbits(g[f"attn_mask{i}"], axis=-1)[..., : int(g[f"attn_mask{i}_len"])].astype(bool)) for i in range(6)]
+    col = {}
+    with torch.no_grad():
+        x = get_torch_batch(images, None)
+        probs_o, masks_o = BF.bf_forward(sd, cfg, x, forced_attn=forced, collect=col)
+    x_u8 = torch.from_numpy(np.stack(images)).to(DEV)
+    return g, cfg, sd, eng, images, x_u8, forced, probs_o, masks_o, col
+
+
+def nchw(nt):
+    return nt.torch_view().float().cpu().permute(0, 3, 1, 2)
+
+
+def test_bf_stage_parity_teacher_forced(setup):
+    g, cfg, sd, eng, images, x_u8, forced, probs_o, masks_o, col = setup
+    pl = eng.forward(x_u8, forced_attn=forced)
+    torch.cuda.synchronize()
+    for name, key in (("res2", "res2"), ("res3", "res3"), ("res4", "res4"), ("res5", "res5"), ("cp32", "cp32"), ("cp16", "cp16"), ("cp8", "cp8"),
+                      ("ffm", "ffm"), ("mask_features", "mask_features")):
+        assert rel_l2(nchw(pl.bufs[name]), col[key]) <= 2.5e-2, name
+    B = 2
+    for i in range(6):
+        got = pl.bufs[f"dec{i}.out"].torch_view().float().cpu().reshape(B, -1, 256)
+        assert rel_l2(got, col[f"dec{i}_out"]) <= 3e-2, i
+    assert (pl.probs.cpu() - probs_o).abs().max() <= 3e-2
+    lo_o = torch.sigmoid(col["mask_logits"])
+    d = (pl.mask_probs.cpu() - lo_o).abs()
+    assert d.mean() <= 1e-2
+    assert ((pl.mask_probs.cpu() >= 0.5) == (lo_o >= 0.5)).float().mean() >= 0.99
+    assert (pl.masks.cpu() - masks_o).abs().mean() <= 1e-2           # the full-resolution `masks` of BisenetFormer.forward
+    assert np.abs(pl.probs.cpu().numpy() - g["probs"]).max() <= 3e-2   # golden (real reference) class probabilities
+
+
+def test_bf_detections_vs_reference_golden(setup):
+    """predict_all_pixels detections of the engine (teacher-forced attention masks) vs the REAL reference's post-process output:
+    reference detections with a clear margin are found with the same class, score within 5e-2, box within 2 px and a mask
+    area within 10 % (+20 px); the winner map agrees with the oracle's argmax on >= 97 % of the pixels."""
+    g, cfg, sd, eng, images, x_u8, forced, probs_o, masks_o, col = setup
+    pl = eng.forward(x_u8, forced_attn=forced)
+    torch.cuda.synchronize()
+    score_o = probs_o.max(-1).values
+    win_o = (score_o.view(2, -1, 1, 1) * masks_o).argmax(dim=1)
+    assert (pl.winner.cpu().long() == win_o).float().mean() >= 0.97
+    for b in range(2):
+        n = int(pl.det_count[b])
+        mine = [(float(s), int(l), bx.tolist(), int(a)) for s, l, bx, a in
+                zip(pl.det_scores[b, :n].cpu(), pl.det_labels[b, :n].cpu(), pl.det_boxes[b, :n].cpu(), pl.det_area[b, :n].cpu())]
+        conf, cls, bbox, area = g[f"det{b}_conf"], g[f"det{b}_cls"], g[f"det{b}_bbox"], g[f"det{b}_area"]
+        strong = (conf > cfg["threshold"] + 0.05) & (area >= 30)
+        assert strong.sum() >= 4
+        found = 0
+        for c, k, bx, a in zip(conf[strong], cls[strong], bbox[strong], area[strong]):
+            hit = [v for v in mine if v[1] == int(k) and abs(v[0] - float(c)) <= 5e-2 and max(abs(np.array(v[2]) - bx)) <= 2
+                   and abs(v[3] - a) <= 0.1 * a + 20]
+            found += bool(hit)
+        assert found >= 0.85 * strong.sum(), (found, strong.sum())
+        assert abs(n - len(conf)) <= max(3, len(conf) // 4)
+        # post-process invariants: masks partition the kept pixels, areas = popcount, boxes enclose the masks
+        H, W = images[b].shape[:2]
+        masks = np.unpackbits(pl.mask_words[b, :n].cpu().numpy().view(np.uint8), axis=-1, bitorder="little").reshape(n, H, W).astype(bool)
+        assert masks.sum(0).max() <= 1
+        assert masks.reshape(n, -1).sum(-1).tolist() == [m[3] for m in mine]
+        assert M.masks_to_xyxy(masks).tolist() == [m[2] for m in mine]
+        win = pl.winner[b].cpu().numpy()
+        for j, qi in enumerate(pl.det_query[b, :n].cpu().tolist()):
+            assert (masks[j] == (win == qi)).all()
+
+
+def test_bf_free_running_graph_and_threshold_branch(setup):
+    g, cfg, sd, eng, images, x_u8, forced, probs_o, *_ = setup
+    pl = eng.forward(x_u8, use_graph=False)
+    torch.cuda.synchronize()
+    p_eager, m_eager, cnt, win = pl.probs.clone(), pl.mask_probs.clone(), pl.det_count.clone(), pl.winner.clone()
+    agree = []
+    for i, f in enumerate(forced):
+        words = pl.attn_bits[i].cpu().numpy().view(np.uint8)
+        got = np.unpackbits(words, axis=-1, bitorder="little")[:, : f.shape[-1]].astype(bool).reshape(f.shape)
+        eff = got & (got.sum(-1, keepdims=True) != got.shape[-1])
+        agree.append(float((torch.from_numpy(eff) == f).float().mean()))
+    assert agree[0] >= 0.995, agree
+    assert min(agree) >= 0.90, agree
+    pl = eng.forward(x_u8)
+    pl = eng.forward(x_u8)
+    torch.cuda.synchronize()
+    assert torch.equal(pl.probs, p_eager) and torch.equal(pl.mask_probs, m_eager) and torch.equal(pl.det_count, cnt) and torch.equal(pl.winner, win)
+    assert int(cnt.min()) > 0
+    # the threshold branch (predict_all_pixels=False, "instance" post-processing) on the same weights: x8 upsample through the
+    # generic path of fx_mf_postprocess, checked against the oracle on the engine's own low-resolution probabilities
+    cfg2 = dict(cfg, predict_all_pixels=False, postprocessing_type="instance", use_mask_score=True)
+    eng2 = BfEngine(cfg2, sd, device=DEV)
+    pl2 = eng2.forward(x_u8, forced_attn=forced)
+    torch.cuda.synchronize()
+    H, W = images[0].shape[:2]
+    full = F.interpolate(pl2.mask_probs.cpu(), size=(H, W), mode="bilinear", align_corners=False)
+    for b in range(2):
+        s, l, q, boxes, bm = M.postprocess(pl2.probs[b:b + 1].cpu(), full[b:b + 1], [(H, W)], 0.5, cfg2["threshold"], True)[0]
+        n = int(pl2.det_count[b])
+        assert abs(n - len(s)) <= 1 and n > 0      # a pixel exactly at the 0.5 threshold may differ between the two upsamplers
+        if n == len(s):
+            assert pl2.det_labels[b, :n].cpu().tolist() == l.tolist()
+            np.testing.assert_allclose(pl2.det_scores[b, :n].cpu().numpy(), s.numpy(), atol=2e-4)
+
+
+def test_bf_loud_failures(setup):
+    g, cfg, sd, eng, *_ = setup
+    with pytest.raises(_lib.FocoosAmdError):
+        eng.plan(1, 100, 128)  # not a multiple of 32
+    with pytest.raises(_lib.FocoosAmdError):
+        BfEngine(dict(cfg, num_queries=200), sd, device=DEV)
+    bad = dict(cfg, backbone_config=dict(cfg["backbone_config"], block_type="add"))
+    with pytest.raises(_lib.FocoosAmdError):
+        BfEngine(bad, sd, device=DEV)
+
+
+def test_bf_model_manager_and_processor_paths(setup):
+    """ModelManager.get -> FocoosModel: the fused detect path and the reference-shaped forward() + processor.postprocess() path
+    give the same detections (the second runs fx_seg_postprocess on the full-resolution `masks` tensor at scale 1)."""
+    from focoos_amd.model import ModelManager
+    from focoos_amd.processor import BisenetFormerProcessor
+
+    g, cfg, sd, eng, images, *_ = setup
+    fm = ModelManager.get("bisenetformer-l-ade", seed=int(g["seed"]))
+    assert isinstance(fm.processor, BisenetFormerProcessor)
+    dets = fm.infer_batch(images)
+    assert len(dets) == 2 and len(dets[0]) > 3
+    x, _ = fm.processor.preprocess(images, device=fm.device)
+    out = fm.model.forward(x)
+    assert tuple(out.masks.shape) == (2, 100, images[0].shape[0], images[0].shape[1]) and tuple(out.logits.shape) == (2, 100, 150)
+    dets2 = fm.processor.postprocess(out, images, class_names=fm.model_info.classes)
+    for a, b in zip(dets, dets2):
+        assert len(a) == len(b)
+        for da, db in zip(a.detections, b.detections):
+            assert da.cls_id == db.cls_id and da.bbox == db.bbox and abs(da.conf - db.conf) < 1e-5 and da.mask == db.mask
+    sd2 = fm.model.state_dict()
+    assert list(sd2.keys()) == list(sd.keys())
+
+
+def test_bf_full_size_batch_properties(setup):
+    """Registry size (640x640, bs=8): batch-position independence (permuted batch -> permuted result, bit-for-bit), idempotent
+    replay, and post-process invariants at full size."""
+    g, cfg, sd, eng, *_ = setup
+    imgs = torch.from_numpy(np.stack([synth_image_structured(50 + i, 640, 640) for i in range(8)])).to(DEV)
+    perm = torch.tensor([3, 0, 7, 1, 6, 2, 5, 4], device=DEV)
+    pl = eng.forward(imgs, full_masks=False)
+    torch.cuda.synchronize()
+    probs, mp, cnt, win = pl.probs.clone(), pl.mask_probs.clone(), pl.det_count.clone(), pl.winner.clone()
+    boxes, area, words, dq = pl.det_boxes.clone(), pl.det_area.clone(), pl.mask_words.clone(), pl.det_query.clone()
+    pl = eng.forward(imgs[perm].contiguous(), full_masks=False)
+    torch.cuda.synchronize()
+    assert torch.equal(pl.probs, probs[perm]) and torch.equal(pl.mask_probs, mp[perm]) and torch.equal(pl.det_count, cnt[perm])
+    assert torch.equal(pl.winner, win[perm])
+    pl = eng.forward(imgs, full_masks=False)
+    torch.cuda.synchronize()
+    assert torch.equal(pl.winner, win) and torch.equal(pl.det_boxes, boxes)
+    for b in range(8):
+        n = int(cnt[b])
+        assert n >= 1
+        m = np.unpackbits(words[b, :n].cpu().numpy().view(np.uint8), axis=-1, bitorder="little").reshape(n, 640, 640).astype(bool)
+        assert m.reshape(n, -1).sum(-1).tolist() == area[b, :n].cpu().tolist()
+        assert M.masks_to_xyxy(m).tolist() == boxes[b, :n].cpu().tolist()
+        assert m.sum(0).max() <= 1
+        assert sorted(dq[b, :n].cpu().tolist()) == dq[b, :n].cpu().tolist()
