@@ -54,7 +54,7 @@ def parse():
     ap.add_argument("--per-op", default="", help="write per-op timing table to this path")
     a = ap.parse_args()
     mf = a.model.startswith("fai-mf")
-    a.family = "fai_mf" if mf else "fai_detr"
+    a.family = "fai_mf" if mf else ("bisenetformer" if a.model.startswith("bisenetformer") else "fai_detr")
     a.batch = a.batch or (16 if (mf or a.train) else 32)
     a.size = a.size or (800 if mf else 640)
     return a
@@ -104,12 +104,14 @@ def cpu_baseline(args):
 
     from focoos_amd.registry import ModelRegistry
     from focoos_amd.synth import synth_image, synth_state_dict
+    from oracle import bf_oracle as BFO
     from oracle import detr_oracle as O
     from oracle import mf_oracle as M
 
     cfg = ModelRegistry.get_model_info(args.model)["config"]
     sd = synth_state_dict(cfg, 0, family=args.family)
     mf = args.family == "fai_mf"
+    bf = args.family == "bisenetformer"
     if mf:
         args.cpu_batch = 1
     # Thread count actually used (reported as `cores`): PyTorch's CPU convs stop scaling (and at 256 threads collapse:
@@ -125,6 +127,10 @@ def cpu_baseline(args):
             if mf:
                 p, m = M.mf_forward(sd, cfg, x)
                 M.postprocess(p, m, [(args.size, args.size)] * len(imgs), cfg["mask_threshold"], cfg["threshold"], cfg["use_mask_score"])
+            elif bf:
+                p, m = BFO.bf_forward(sd, cfg, x)
+                for i in range(len(imgs)):   # the reference post-process is batch-1 (see oracle/mf_oracle.postprocess)
+                    BFO.postprocess(p[i:i + 1], m[i:i + 1], [(args.size, args.size)], cfg)
             else:
                 p, b = O.detr_forward(sd, cfg, x)
                 O.postprocess(p, b, [(args.size, args.size)] * len(imgs), 300, 0.5)
@@ -137,7 +143,7 @@ def cpu_baseline(args):
     times.sort()
     med = times[len(times) // 2]
     return {"value": round(args.cpu_batch / med, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"oracle/{'mf' if mf else 'detr'}_oracle.py (CPU fp32 restatement of the reference path) preprocess+forward+postprocess, bs={args.cpu_batch}, "
+            "sample": f"oracle/{'mf' if mf else ('bf' if bf else 'detr')}_oracle.py (CPU fp32 restatement of the reference path) preprocess+forward+postprocess, bs={args.cpu_batch}, "
                       f"{args.size}x{args.size}, median of {len(times)} pass(es) after 1 warm-up, {cores} threads of {os.cpu_count()} host cores"}
 
 
@@ -255,7 +261,7 @@ def main():
 
     import torch
 
-    from focoos_amd.model import FAIDetr, FAIMaskFormer
+    from focoos_amd.model import BisenetFormer, FAIDetr, FAIMaskFormer
     from focoos_amd.registry import ModelRegistry
     from focoos_amd.synth import synth_image
 
@@ -266,8 +272,9 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
-    mf = args.family == "fai_mf"
-    model = (FAIMaskFormer if mf else FAIDetr)(cfg, device=dev, seed=0)
+    bf = args.family == "bisenetformer"
+    mf = args.family == "fai_mf" or bf     # the two mask families share the engine interface (engine_maskdec.py)
+    model = (BisenetFormer if bf else (FAIMaskFormer if mf else FAIDetr))(cfg, device=dev, seed=0)
     eng = model.engine
     # image i of rank r = synth_image(r*B + i): seeded uint8 HWC, resident in HBM before the timed region
     imgs = torch.stack([torch.from_numpy(synth_image(rank * B + i, args.size, args.size)) for i in range(B)]).to(dev)
@@ -301,6 +308,9 @@ def main():
     value = world * B * args.steps / dt
 
     alg = ALG_GFLOP_PER_IMAGE_MF_800 * (args.size / 800.0) ** 2 if mf else ALG_GFLOP_PER_IMAGE * (args.size / 640.0) ** 2
+    if bf:  # conv / linear layers of the reference as listed by the plan (the pooling / gate / attention-core flops are not counted)
+        parts = getattr(pl, "parts", [pl])
+        alg = sum(m["flops"] for part in parts for m in part.meta.values()) / B / 1e9
     out = {
         "metric": f"images/sec @ {args.size}^2 (infer bs={B})", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

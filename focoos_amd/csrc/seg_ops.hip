@@ -104,7 +104,8 @@ __global__ __launch_bounds__(256) void pooled_linear_kernel(const float* __restr
                                                             int N) {
   const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const float* ib = in + (int64_t)b * ldi;
-  for (int n = wave; n < N; n += 4) {
+  const int n_end = min(N, (int)(blockIdx.y + 1) * 16);   // 16 output rows per workgroup, 4 per wave
+  for (int n = blockIdx.y * 16 + wave; n < n_end; n += 4) {
     const float* wr = W + (int64_t)n * C;
     float s = 0.0f;
     for (int c = lane; c < C; c += 64) s = fmaf(wr[c], ib[c], s);
@@ -123,7 +124,7 @@ extern "C" int fx_pooled_linear_f32(const float* in, int ldi, const float* W, co
                                     int N, fx_stream_t stream_) {
   FX_CHECK_ARG(in && W && out && B > 0 && C > 0 && N > 0 && ldi >= C && ldo >= N);
   FX_CHECK_ARG(act == FX_ACT_NONE || act == FX_ACT_RELU || act == FX_ACT_SIGMOID_LOCAL);
-  hipLaunchKernelGGL(pooled_linear_kernel, dim3(B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), in, ldi, W, bias, act, out, ldo, C, N);
+  hipLaunchKernelGGL(pooled_linear_kernel, dim3(B, (N + 15) / 16), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), in, ldi, W, bias, act, out, ldo, C, N);
   return fx_launch_status();
 }
 
