@@ -47,3 +47,21 @@ def test_register_replaces_maskformer_family_and_keeps_state_dict():
     cfgd = ModelRegistry.get_model_info("fai-mf-l-coco-ins")["config"]
     model = cls(ConfigManager.from_dict(ModelFamily.MASKFORMER, dict(cfgd))).eval()
     assert list(model.state_dict()) == list(mf_state_spec(cfgd))   # checkpoint keys unchanged
+
+
+def test_register_replaces_bisenetformer_family_and_keeps_state_dict():
+    ref_import.install()
+    from focoos.model_manager import ConfigManager, ModelManager
+    from focoos.ports import ModelFamily
+
+    import focoos_amd.integration as fx
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.state_spec import bf_state_spec
+
+    fx.register()
+    cls = ModelManager._models_family_map[ModelFamily.BISENETFORMER.value]()
+    assert cls.__name__ == "EngineBisenetFormer"
+    cfgd = ModelRegistry.get_model_info("bisenetformer-l-ade")["config"]
+    cfg_ref = {k: v for k, v in cfgd.items() if k != "resolution"}
+    model = cls(ConfigManager.from_dict(ModelFamily.BISENETFORMER, cfg_ref)).eval()
+    assert list(model.state_dict()) == list(bf_state_spec(cfgd))   # checkpoint keys unchanged
