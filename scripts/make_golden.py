@@ -302,6 +302,56 @@ def bf_case(tag: str = "bf_l_ade_b2", seed: int = 4, hw=(160, 192)):
     print(tag, {k: v.shape for k, v in g.items() if hasattr(v, "shape") and v.ndim}, [len(g[f"det{i}_conf"]) for i in range(B)])
 
 
+def mask_criterion_case():
+    """Golden vectors of the REAL reference's MaskHungarianMatcher + mask SetCriterion (fai_mf/loss.py:345-723; bisenetformer/loss.py
+    is identical) on seeded synthetic predictions / targets with deep supervision (main + 2 aux sets), num_points = 256: the
+    reference's torch.rand draws (recorded in order - they are inputs of the restatement and of the kernels), the cost blocks
+    handed to SciPy, the matched indices and the 9 weighted losses."""
+    ref_import.install()
+    import focoos.models.fai_mf.loss as L
+    from focoos.models.fai_mf.ports import MaskFormerTargets
+
+    from oracle.mask_criterion_oracle import synth_mask_predictions_and_targets
+
+    out, labels, masks = synth_mask_predictions_and_targets(0)
+    P = 256
+    matcher = L.MaskHungarianMatcher(cost_class=2, cost_mask=5, cost_dice=5, num_points=P)
+    crit = L.SetCriterion(num_classes=80, matcher=matcher, weight_dict={"loss_ce": 2, "loss_mask": 5, "loss_dice": 5}, losses=["labels", "masks"],
+                          eos_coef=0.1, num_points=P, oversample_ratio=3.0, importance_sample_ratio=0.75)
+    targets = [MaskFormerTargets(labels=l, masks=m) for l, m in zip(labels, masks)]
+    rec, costs, idxs = [], [], []
+    orig_rand, orig_lsa = torch.rand, L.linear_sum_assignment
+
+    def spy_rand(*a, **k):
+        t = orig_rand(*a, **k)
+        rec.append(t.clone())
+        return t
+
+    def spy_lsa(c):
+        costs.append(np.array(c, dtype=np.float32))
+        r = orig_lsa(c)
+        idxs.append((np.asarray(r[0]).copy(), np.asarray(r[1]).copy()))
+        return r
+
+    torch.manual_seed(5)
+    torch.rand, L.linear_sum_assignment = spy_rand, spy_lsa
+    try:
+        ref = crit(out, targets)
+    finally:
+        torch.rand, L.linear_sum_assignment = orig_rand, orig_lsa
+    g = {"num_points": np.int64(P), "n_rand": np.int64(len(rec)), "loss_names": np.array(sorted(ref)),
+         "losses": np.array([float(ref[k]) for k in sorted(ref)], np.float64)}
+    for i, t in enumerate(rec):
+        g[f"rand_{i}"] = t.numpy()
+    for i, (c, (a, b)) in enumerate(zip(costs, idxs)):   # order: set 0 image 0, set 0 image 1, set 1 image 0, ...
+        g[f"cost_{i}"] = c
+        g[f"pred_idx_{i}"] = a.astype(np.int32)
+        g[f"tgt_idx_{i}"] = b.astype(np.int32)
+    path = os.path.join(GOLDEN, "mask_criterion.npz")
+    np.savez_compressed(path, **g)
+    print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB); losses {dict(zip(g['loss_names'], np.round(g['losses'], 4)))}")
+
+
 def masks_to_xyxy_case():
     """The reference's own known-answer vectors for this path: tests/utils/test_vision.py:185-205 (test_masks_to_xyxy),
     evaluated with the reference's masks_to_xyxy (utils/vision.py:344-370) on extra seeded random masks as well."""
@@ -336,6 +386,7 @@ def main():
     criterion_case()
     mf_case()
     bf_case()
+    mask_criterion_case()
     masks_to_xyxy_case()
 
 
