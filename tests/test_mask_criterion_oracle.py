@@ -48,7 +48,7 @@ def test_point_sample_is_grid_sample_on_unit_square():
     # pixel centres map to themselves: (col + 0.5) / W, (row + 0.5) / H
     c = torch.tensor([[[(2 + 0.5) / 4, (1 + 0.5) / 3], [0.5 / 4, 0.5 / 3], [1.0, 1.0]]])
     v = MC.point_sample(x, c)[0, 0]
-    assert v[0].item() == 6.0 and v[1].item() == 0.0
+    assert abs(v[0].item() - 6.0) < 1e-5 and abs(v[1].item()) < 1e-5   # 2*c - 1 is not exact in fp32
     assert abs(v[2].item() - 11.0 * 0.25) < 1e-6      # the corner: three of four taps fall outside (zero padding)
 
 
