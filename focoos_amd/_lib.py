@@ -70,6 +70,11 @@ SIGNATURES = {
     "fx_adamw_step_f32": [_vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp],
     "fx_conv2d_wgrad_nhwc_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "fx_conv2d_wgrad_bias_nhwc_bf16": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "fx_point_sample_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "fx_mask_match_cost_f32": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, C.c_float, C.c_float, _i, _vp, _vp],
+    "fx_mask_set_loss_workspace_bytes": [_i, _i, _i],
+    "fx_mask_set_loss_f32": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, C.c_float, C.c_float,
+                             C.c_float, C.c_float, C.c_float, _vp, C.c_size_t, _vp, _vp],
     "fx_dwconv3x3s2_nhwc_bf16": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "fx_global_mean_nhwc_bf16": [_vp, _i, _vp, _i, _i, _i, _i, _vp],
     "fx_pooled_linear_f32": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp],
@@ -134,6 +139,7 @@ def load() -> C.CDLL:
         fn.restype = C.c_int
     lib.fx_mha_bwd_workspace_bytes.restype = C.c_size_t
     lib.fx_seg_postprocess_workspace_bytes.restype = C.c_size_t
+    lib.fx_mask_set_loss_workspace_bytes.restype = C.c_size_t
     lib.fx_error_string.argtypes = [C.c_int]
     lib.fx_error_string.restype = C.c_char_p
     if lib.fx_abi_version() != 1:

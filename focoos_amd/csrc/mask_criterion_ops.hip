@@ -1,0 +1,330 @@
+// Mask-classification training criterion of the MaskFormer / BiSeNetFormer families, forward values:
+//   point_sample                                   focoos/nn/layers/point_rend.py:29-52 (F.grid_sample bilinear / zeros / align_corners=False)
+//   MaskHungarianMatcher.memory_efficient_forward  focoos/models/fai_mf/loss.py:661-723 (cost blocks; the assignment itself is fx_lsa_f32)
+//   SetCriterion.loss_labels (ce_loss) / loss_masks :411-431, :463-523 with get_uncertain_point_coords_with_randomness point_rend.py:73-128
+// The reference draws its sample points with torch.rand inside these functions; here the uniform draws are INPUTS (the host
+// wrapper generates them on the device), so results are a pure function of the arguments.  fp32 arithmetic like the reference
+// (autocast is disabled there, loss.py:702), float64 for the final reductions, fixed summation order -> deterministic.
+#include "common.h"
+
+// ATen's grid_sampler_compute_source_index (align_corners=False) applied to the wrapper's `2 * c - 1`: ((g + 1) * size - 1) / 2.
+__device__ __forceinline__ float ps_unnormalize(float c, int size) {
+#pragma clang fp contract(off)
+  const float g = 2.0f * c - 1.0f;
+  return ((g + 1.0f) * (float)size - 1.0f) / 2.0f;
+}
+
+template <typename T>
+__device__ __forceinline__ float ps_load(const T* p, int H, int W, int y, int x) {
+  return (y >= 0 && y < H && x >= 0 && x < W) ? (float)p[(int64_t)y * W + x] : 0.0f;
+}
+
+// bilinear sample with zero padding; weights as in ATen's CPU kernel: w = ix - floor(ix), e = 1 - w, n = iy - floor(iy), s = 1 - n;
+// out = nw_val * (e*s) + ne_val * (w*s) + sw_val * (e*n) + se_val * (w*n)
+template <typename T>
+__device__ __forceinline__ float ps_sample(const T* p, int H, int W, float cx, float cy) {
+#pragma clang fp contract(off)
+  const float ix = ps_unnormalize(cx, W), iy = ps_unnormalize(cy, H);
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float w = ix - fx, e = 1.0f - w, n = iy - fy, s = 1.0f - n;
+  float acc = ps_load(p, H, W, y0, x0) * (e * s);
+  acc += ps_load(p, H, W, y0, x0 + 1) * (w * s);
+  acc += ps_load(p, H, W, y0 + 1, x0) * (e * n);
+  acc += ps_load(p, H, W, y0 + 1, x0 + 1) * (w * n);
+  return acc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void point_sample_kernel(const T* __restrict__ src, int H, int W, const int32_t* __restrict__ src_index,
+                                                           const float* __restrict__ coords, const int32_t* __restrict__ coord_index,
+                                                           float* __restrict__ out, int P) {
+  const int r = blockIdx.y;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const T* m = src + (int64_t)(src_index ? src_index[r] : r) * H * W;
+  const float* c = coords + ((int64_t)(coord_index ? coord_index[r] : r) * P + p) * 2;
+  out[(int64_t)r * P + p] = ps_sample(m, H, W, c[0], c[1]);
+}
+
+extern "C" int fx_point_sample_f32(const void* src, int src_is_u8, int H, int W, const int32_t* src_index, const float* coords,
+                                   const int32_t* coord_index, float* out, int R, int P, fx_stream_t stream_) {
+  FX_CHECK_ARG(src && coords && out && H > 0 && W > 0 && R > 0 && P > 0);
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  dim3 grid((P + 255) / 256, R);
+  if (src_is_u8)
+    hipLaunchKernelGGL(point_sample_kernel<uint8_t>, grid, dim3(256), 0, stream, (const uint8_t*)src, H, W, src_index, coords, coord_index, out, P);
+  else
+    hipLaunchKernelGGL(point_sample_kernel<float>, grid, dim3(256), 0, stream, (const float*)src, H, W, src_index, coords, coord_index, out, P);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Matching cost of one prediction set.  One workgroup per (image, query): the query's P sampled logits sit in LDS; wave w
+// reduces targets t = w, w+4, ... over the points.  With pos = softplus(-x), neg = softplus(x) (binary_cross_entropy_with_logits
+// against ones / zeros):  sum_p pos*tgt + neg*(1-tgt) = sum_p neg - sum_p x*tgt.
+__device__ __forceinline__ float softplus_f(float x) { return fmaxf(x, 0.0f) + log1pf(__expf(-fabsf(x))); }
+
+__global__ __launch_bounds__(256) void mask_match_cost_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ pred_pts,
+                                                              const float* __restrict__ tgt_pts, const int32_t* __restrict__ tgt_labels,
+                                                              const int32_t* __restrict__ tgt_offsets, int Q, int K, int P, int Tmax,
+                                                              float w_class, float w_mask, float w_dice, int cls_sigmoid,
+                                                              float* __restrict__ cost) {
+  extern __shared__ float xs[];   // [P]
+  __shared__ float red[2][4];
+  __shared__ float s_norm[2];     // max logit, 1 / sum exp
+  const int b = blockIdx.y, q = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int t0 = tgt_offsets[b], T = tgt_offsets[b + 1] - t0;
+  float* crow = cost + ((int64_t)b * Q + q) * Tmax;
+  for (int t = T + threadIdx.x; t < Tmax; t += 256) crow[t] = 0.0f;
+  if (T == 0) return;
+  const float* xp = pred_pts + ((int64_t)b * Q + q) * P;
+  float sp = 0.0f, sg = 0.0f;
+  for (int p = threadIdx.x; p < P; p += 256) {
+    const float x = xp[p];
+    xs[p] = x;
+    sp += softplus_f(x);
+    sg += fx_sigmoid(x);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sp += __shfl_xor(sp, o, 64), sg += __shfl_xor(sg, o, 64);
+  if (lane == 0) red[0][wave] = sp, red[1][wave] = sg;
+  // class probabilities: softmax over the K+1 logits of this query (sigmoid when cls_sigmoid)
+  const float* lp = logits + ((int64_t)b * Q + q) * ldl;
+  if (wave == 0 && !cls_sigmoid) {
+    float mx = -INFINITY;
+    for (int c = lane; c <= K; c += 64) mx = fmaxf(mx, lp[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float se = 0.0f;
+    for (int c = lane; c <= K; c += 64) se += __expf(lp[c] - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+    if (lane == 0) s_norm[0] = mx, s_norm[1] = 1.0f / se;
+  }
+  __syncthreads();
+  const float SP = red[0][0] + red[0][1] + red[0][2] + red[0][3], SG = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  for (int t = wave; t < T; t += 4) {
+    const float* tp = tgt_pts + (int64_t)(t0 + t) * P;
+    float a = 0.0f, bs = 0.0f, st = 0.0f;
+    for (int p = lane; p < P; p += 64) {
+      const float tv = tp[p], x = xs[p];
+      a = fmaf(x, tv, a);
+      bs = fmaf(fx_sigmoid(x), tv, bs);
+      st += tv;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64), bs += __shfl_xor(bs, o, 64), st += __shfl_xor(st, o, 64);
+    if (lane == 0) {
+      const int lab = tgt_labels[t0 + t];
+      const float prob = cls_sigmoid ? fx_sigmoid(lp[lab]) : __expf(lp[lab] - s_norm[0]) * s_norm[1];
+      const float c_mask = (SP - a) / (float)P;
+      const float c_dice = 1.0f - (2.0f * bs + 1.0f) / (SG + st + 1.0f);
+      crow[t] = w_mask * c_mask + w_class * (-prob) + w_dice * c_dice;
+    }
+  }
+}
+
+extern "C" int fx_mask_match_cost_f32(const float* logits, int ldl, const float* pred_pts, const float* tgt_pts, const int32_t* tgt_labels,
+                                      const int32_t* tgt_offsets, int B, int Q, int K, int P, int Tmax, float w_class, float w_mask, float w_dice,
+                                      int cls_sigmoid, float* cost, fx_stream_t stream_) {
+  FX_CHECK_ARG(logits && pred_pts && tgt_pts && tgt_labels && tgt_offsets && cost && B > 0 && Q > 0 && K > 0 && P > 0 && Tmax > 0 && ldl >= K + 1);
+  if ((size_t)P * sizeof(float) > 150 * 1024) return FX_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(mask_match_cost_kernel, dim3(Q, B), dim3(256), (size_t)P * sizeof(float), reinterpret_cast<hipStream_t>(stream_), logits, ldl,
+                     pred_pts, tgt_pts, tgt_labels, tgt_offsets, Q, K, P, Tmax, w_class, w_mask, w_dice, cls_sigmoid, cost);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Losses of one prediction set.
+// (1) labels: target class of (b, q) = label of its matched target, else K ("no object"); loss_ce = sum w[y] * nll / sum w[y]
+//     (F.cross_entropy with class weights, weight eos_coef on K).  One wave per query row, partial sums in float64.
+__global__ __launch_bounds__(256) void mask_label_ce_kernel(const float* __restrict__ logits, int ldl, const int32_t* __restrict__ tgt_labels,
+                                                            const int32_t* __restrict__ tgt_offsets, const int32_t* __restrict__ pred_idx,
+                                                            const int32_t* __restrict__ tgt_idx, int n_rows, int Q, int K, float eos_coef,
+                                                            double* __restrict__ partial /*[B*Q][2]*/) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const int b = row / Q, q = row - b * Q;
+  const int t0 = tgt_offsets[b], T = tgt_offsets[b + 1] - t0;
+  int y = K;
+  for (int i = lane; i < T; i += 64)
+    if (pred_idx[t0 + i] == q) y = tgt_labels[t0 + tgt_idx[t0 + i]];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) y = min(y, __shfl_xor(y, o, 64));   // at most one lane found a match; K is the maximum
+  const float* lp = logits + (int64_t)row * ldl;
+  float mx = -INFINITY;
+  for (int c = lane; c <= K; c += 64) mx = fmaxf(mx, lp[c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float se = 0.0f;
+  for (int c = lane; c <= K; c += 64) se += expf(lp[c] - mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+  if (lane == 0) {
+    const float nll = (mx + logf(se)) - lp[y];
+    const float w = y == K ? eos_coef : 1.0f;
+    partial[(int64_t)row * 2 + 0] = (double)(w * nll);
+    partial[(int64_t)row * 2 + 1] = (double)w;
+  }
+}
+
+// (2) masks: one workgroup per matched (prediction, target) pair.  Importance sampling: of the n_over uniformly drawn points keep
+// the k = num_points - n_extra with the smallest |logit| (torch.topk of -|logit|; ties -> lowest index), found by a 4-pass
+// radix select on the bit pattern of |x| with the samples recomputed per pass (4 taps each) instead of stored; then the
+// BCE / dice sums over those points plus the n_extra uniformly drawn ones, target values sampled bilinearly at the same points.
+#define MPL_THREADS 1024
+template <typename TT>
+__global__ __launch_bounds__(MPL_THREADS) void mask_point_loss_kernel(const float* __restrict__ pred_masks, int h, int w, const TT* __restrict__ tgt_masks,
+                                                                      int H, int W, const int32_t* __restrict__ tgt_offsets, int B, int Q,
+                                                                      const int32_t* __restrict__ pred_idx, const int32_t* __restrict__ tgt_idx,
+                                                                      const float* __restrict__ rand_over, int n_over,
+                                                                      const float* __restrict__ rand_extra, int n_extra, int k_imp,
+                                                                      double* __restrict__ rows /*[N][4]: bce sum, sum s*t, sum s, sum t*/) {
+  __shared__ unsigned hist[256];
+  __shared__ unsigned s_prefix, s_need;
+  __shared__ unsigned s_scan[MPL_THREADS];
+  __shared__ double red[4][MPL_THREADS / 64];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  int b = 0;
+  while (b + 1 < B && tgt_offsets[b + 1] <= n) ++b;
+  const float* pm = pred_masks + ((int64_t)b * Q + pred_idx[n]) * h * w;
+  const TT* tm = tgt_masks + (int64_t)(tgt_offsets[b] + tgt_idx[n]) * H * W;
+  const float* ro = rand_over + (int64_t)n * n_over * 2;
+  // ---- radix select: key of the k_imp-th smallest |x| (prefix), and how many keys equal to it are needed
+  unsigned prefix = 0, need = (unsigned)k_imp;
+  if (k_imp > 0) {
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      for (int i = tid; i < 256; i += MPL_THREADS) hist[i] = 0;
+      __syncthreads();
+      const unsigned hi_mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
+      for (int i = tid; i < n_over; i += MPL_THREADS) {
+        const unsigned key = __float_as_uint(fabsf(ps_sample(pm, h, w, ro[2 * i], ro[2 * i + 1])));
+        if ((key & hi_mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        unsigned acc = 0, d = 0;
+        for (; d < 256; ++d) {
+          if (acc + hist[d] >= need) break;
+          acc += hist[d];
+        }
+        s_prefix = prefix | (d << shift);
+        s_need = need - acc;
+      }
+      __syncthreads();
+      prefix = s_prefix;
+      need = s_need;
+      __syncthreads();
+    }
+  }
+  // ---- selected points: key < prefix, plus the first `need` (index order) with key == prefix
+  double bce = 0.0, st = 0.0, ss = 0.0, tt = 0.0;
+  const int chunk = (n_over + MPL_THREADS - 1) / MPL_THREADS;   // contiguous index ranges so tie ranks follow the index order
+  const int i0 = tid * chunk, i1 = min(n_over, i0 + chunk);
+  unsigned ties = 0;
+  if (k_imp > 0)
+    for (int i = i0; i < i1; ++i)
+      ties += __float_as_uint(fabsf(ps_sample(pm, h, w, ro[2 * i], ro[2 * i + 1]))) == prefix;
+  s_scan[tid] = ties;
+  __syncthreads();
+  for (int o = 1; o < MPL_THREADS; o <<= 1) {   // inclusive Hillis-Steele scan
+    const unsigned v = tid >= o ? s_scan[tid - o] : 0u;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  unsigned tie_rank = s_scan[tid] - ties;   // ties before this thread's range
+  auto add_point = [&](float x, float t) {
+    bce += (double)(fmaxf(x, 0.0f) - x * t + log1pf(expf(-fabsf(x))));
+    const float s = 1.0f / (1.0f + expf(-x));
+    st += (double)(s * t);
+    ss += (double)s;
+    tt += (double)t;
+  };
+  if (k_imp > 0)
+    for (int i = i0; i < i1; ++i) {
+      const float cx = ro[2 * i], cy = ro[2 * i + 1];
+      const float x = ps_sample(pm, h, w, cx, cy);
+      const unsigned key = __float_as_uint(fabsf(x));
+      bool take = key < prefix;
+      if (key == prefix) take = tie_rank++ < need;
+      if (take) add_point(x, ps_sample(tm, H, W, cx, cy));
+    }
+  const float* re = rand_extra + (int64_t)n * n_extra * 2;
+  for (int i = tid; i < n_extra; i += MPL_THREADS) {
+    const float cx = re[2 * i], cy = re[2 * i + 1];
+    add_point(ps_sample(pm, h, w, cx, cy), ps_sample(tm, H, W, cx, cy));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    bce += __shfl_xor(bce, o, 64); st += __shfl_xor(st, o, 64); ss += __shfl_xor(ss, o, 64); tt += __shfl_xor(tt, o, 64);
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+  if (lane == 0) red[0][wave] = bce, red[1][wave] = st, red[2][wave] = ss, red[3][wave] = tt;
+  __syncthreads();
+  if (tid < 4) {
+    double a = 0.0;
+    for (int i = 0; i < MPL_THREADS / 64; ++i) a += red[tid][i];
+    rows[(int64_t)n * 4 + tid] = a;
+  }
+}
+
+__global__ __launch_bounds__(256) void mask_loss_final_kernel(const double* __restrict__ ce_partial, int n_rows, const double* __restrict__ rows, int N,
+                                                              int num_points, float num_masks, float w_ce, float w_mask, float w_dice,
+                                                              float* __restrict__ out3) {
+  __shared__ double red[4][256];
+  double a = 0.0, wsum = 0.0, lm = 0.0, ld = 0.0;
+  for (int i = threadIdx.x; i < n_rows; i += 256) a += ce_partial[2 * i], wsum += ce_partial[2 * i + 1];
+  for (int i = threadIdx.x; i < N; i += 256) {
+    lm += rows[4 * i] / (double)num_points;
+    ld += 1.0 - (2.0 * rows[4 * i + 1] + 1.0) / (rows[4 * i + 2] + rows[4 * i + 3] + 1.0);
+  }
+  red[0][threadIdx.x] = a; red[1][threadIdx.x] = wsum; red[2][threadIdx.x] = lm; red[3][threadIdx.x] = ld;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o)
+      for (int k = 0; k < 4; ++k) red[k][threadIdx.x] += red[k][threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out3[0] = w_ce * (float)(red[0][0] / red[1][0]);
+    out3[1] = w_mask * (float)(red[2][0] / (double)num_masks);
+    out3[2] = w_dice * (float)(red[3][0] / (double)num_masks);
+  }
+}
+
+extern "C" size_t fx_mask_set_loss_workspace_bytes(int B, int Q, int sum_T) {
+  if (B <= 0 || Q <= 0 || sum_T < 0) return 0;
+  return ((size_t)B * Q * 2 + (size_t)sum_T * 4) * sizeof(double);
+}
+
+extern "C" int fx_mask_set_loss_f32(const float* logits, int ldl, const float* pred_masks, int h, int w, const void* tgt_masks, int tgt_is_u8, int H,
+                                    int W, const int32_t* tgt_labels, const int32_t* tgt_offsets, int sum_T, const int32_t* pred_idx,
+                                    const int32_t* tgt_idx, const float* rand_over, int n_over, const float* rand_extra, int n_extra, int num_points,
+                                    int B, int Q, int K, float eos_coef, float num_masks, float w_ce, float w_mask, float w_dice, void* workspace,
+                                    size_t workspace_bytes, float* out3, fx_stream_t stream_) {
+  FX_CHECK_ARG(logits && pred_masks && tgt_offsets && workspace && out3 && B > 0 && Q > 0 && K > 0 && ldl >= K + 1 && h > 0 && w > 0 && H > 0 && W > 0);
+  FX_CHECK_ARG(sum_T >= 0 && num_points > 0 && n_extra >= 0 && n_extra <= num_points && n_over >= num_points - n_extra && num_masks > 0.0f);
+  FX_CHECK_ARG(sum_T == 0 || (tgt_masks && tgt_labels && pred_idx && tgt_idx && (n_extra == 0 || rand_extra) && (num_points == n_extra || rand_over)));
+  FX_CHECK_ARG(workspace_bytes >= fx_mask_set_loss_workspace_bytes(B, Q, sum_T) && ((uintptr_t)workspace % 8) == 0);
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  double* ce_partial = reinterpret_cast<double*>(workspace);
+  double* rows = ce_partial + (size_t)B * Q * 2;
+  hipLaunchKernelGGL(mask_label_ce_kernel, dim3((B * Q + 3) / 4), dim3(256), 0, stream, logits, ldl, tgt_labels, tgt_offsets, pred_idx, tgt_idx, B * Q, Q, K, eos_coef,
+                     ce_partial);
+  if (sum_T > 0) {
+    if (tgt_is_u8)
+      hipLaunchKernelGGL(mask_point_loss_kernel<uint8_t>, dim3(sum_T), dim3(MPL_THREADS), 0, stream, pred_masks, h, w, (const uint8_t*)tgt_masks, H, W,
+                         tgt_offsets, B, Q, pred_idx, tgt_idx, rand_over, n_over, rand_extra, n_extra, num_points - n_extra, rows);
+    else
+      hipLaunchKernelGGL(mask_point_loss_kernel<float>, dim3(sum_T), dim3(MPL_THREADS), 0, stream, pred_masks, h, w, (const float*)tgt_masks, H, W,
+                         tgt_offsets, B, Q, pred_idx, tgt_idx, rand_over, n_over, rand_extra, n_extra, num_points - n_extra, rows);
+  }
+  hipLaunchKernelGGL(mask_loss_final_kernel, dim3(1), dim3(256), 0, stream, ce_partial, B * Q, rows, sum_T, num_points, num_masks, w_ce, w_mask, w_dice,
+                     out3);
+  return fx_launch_status();
+}

@@ -63,6 +63,16 @@ class BisenetFormerOutput:
 
 
 @dataclass
+class MaskFormerTargets:
+    """focoos/models/fai_mf/ports.py:16-19 (BisenetFormerTargets has the same fields)."""
+    labels: torch.Tensor  # [T] class ids
+    masks: torch.Tensor   # [T, H, W] binary masks (bool / uint8 / float)
+
+
+BisenetFormerTargets = MaskFormerTargets
+
+
+@dataclass
 class DETRTargets:
     labels: torch.Tensor
     boxes: torch.Tensor

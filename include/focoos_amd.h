@@ -203,6 +203,34 @@ int fx_mf_postprocess(const float* mask_probs_lowres, int h, int w, int H, int W
                       int32_t* det_count, int32_t* det_query, float* det_score, int32_t* det_label, int32_t* det_box, int32_t* det_area,
                       uint32_t* mask_words, fx_stream_t stream);
 
+/* ---- mask-classification criterion (training path, forward values): SURVEY §8a row A16 ---------------------------------------
+ * point_sample (focoos/nn/layers/point_rend.py:29-52): out f32 [R][P] = bilinear sample (F.grid_sample, zero padding,
+ * align_corners=False) of map src[src_index ? src_index[r] : r] (f32 or u8 [.,H,W]) at coords[coord_index ? coord_index[r] : r][p] =
+ * (x, y) in [0,1]^2 (coords f32 [.][P][2]). */
+int fx_point_sample_f32(const void* src, int src_is_u8, int H, int W, const int32_t* src_index, const float* coords, const int32_t* coord_index,
+                        float* out, int R, int P, fx_stream_t stream);
+
+/* MaskHungarianMatcher cost blocks (fai_mf/loss.py:672-712 == bisenetformer/loss.py): cost[b][q][t] = w_mask * BCE-cost + w_class *
+ * (-prob[q, label_t]) + w_dice * dice-cost over the image's P shared sample points; pred_pts f32 [B*Q][P] / tgt_pts f32 [sumT][P] =
+ * fx_point_sample_f32 of the mask logits / target masks at those points; logits f32 [B,Q,ldl] (K+1 classes, softmax; sigmoid if
+ * cls_sigmoid).  Layout of cost / offsets as fx_detr_match_cost_f32 (feeds fx_lsa_f32).  P <= 38400. */
+int fx_mask_match_cost_f32(const float* logits, int ldl, const float* pred_pts, const float* tgt_pts, const int32_t* tgt_labels,
+                           const int32_t* tgt_offsets, int B, int Q, int K, int P, int Tmax, float w_class, float w_mask, float w_dice,
+                           int cls_sigmoid, float* cost, fx_stream_t stream);
+
+/* SetCriterion.loss_labels (ce_loss branch, :411-431) + loss_masks (:463-523) of one prediction set: out3 = {w_ce * loss_ce,
+ * w_mask * loss_mask, w_dice * loss_dice}.  pred_masks f32 [B,Q,h,w] (logits), tgt_masks f32 or u8 [sumT,H,W], matches as written
+ * by fx_lsa_f32.  Point selection of get_uncertain_point_coords_with_randomness (point_rend.py:73-128) with the uniform draws as
+ * inputs: rand_over f32 [sumT][n_over][2] (the oversampled candidates; the num_points - n_extra with the smallest |logit| are kept),
+ * rand_extra f32 [sumT][n_extra][2].  num_masks = the clamped, world-averaged target count of :557-561.  workspace:
+ * fx_mask_set_loss_workspace_bytes(), 8-byte aligned.  Deterministic (fixed-order float64 reductions). */
+size_t fx_mask_set_loss_workspace_bytes(int B, int Q, int sum_T);
+int fx_mask_set_loss_f32(const float* logits, int ldl, const float* pred_masks, int h, int w, const void* tgt_masks, int tgt_is_u8, int H, int W,
+                         const int32_t* tgt_labels, const int32_t* tgt_offsets, int sum_T, const int32_t* pred_idx, const int32_t* tgt_idx,
+                         const float* rand_over, int n_over, const float* rand_extra, int n_extra, int num_points, int B, int Q, int K,
+                         float eos_coef, float num_masks, float w_ce, float w_mask, float w_dice, void* workspace, size_t workspace_bytes,
+                         float* out3, fx_stream_t stream);
+
 /* ---- BiSeNetFormer path (focoos/models/bisenetformer/modelling.py, focoos/nn/backbone/stdc.py) -------
  * Depthwise 3x3 stride-2 pad-1 convolution on NHWC bf16: y[b,ho,wo,c] = bias[c] + sum_k w[k][c] * x[...] (w f32 [9][C] with the
  * eval BatchNorm scale folded in, bias f32 [C] = BN shift or NULL).  STDC CatBottleneck `avd_layer` (stdc.py:114-127); with
