@@ -2,7 +2,7 @@
 //   dW[n][kh][kw][c] += sum over output pixels m of dZ[m][n] * X[pixel(m, kh, kw)][c]
 // i.e. the GEMM  D[n][kc] = sum_m  dZ^T[n][m] * Xcol[m][kc]  whose REDUCTION index is the pixel.  Both operands live in
 // memory pixel-major (NHWC), the opposite of what an MFMA fragment wants (8 consecutive reduction indices per lane), so:
-//   * tiles are staged in LDS exactly as they sit in memory ([32 pixels][128 channels], rows padded to 288 B), filled
+//   * tiles are staged in LDS exactly as they sit in memory ([64 pixels][128 channels], rows padded to 288 B), filled
 //     with coalesced 16-byte buffer loads (im2col addressing per row; out-of-image taps read zeros);
 //   * fragments are fetched with the gfx950 transpose read ds_read_b64_tr_b16: 16 lanes hand in the addresses of a
 //     [4 pixels][16 channels] block (4 contiguous bf16 each) and get it back column-major, so two reads give a lane the 8
@@ -26,7 +26,8 @@ struct WgradArgs {
   unsigned x_bytes, dz_bytes;
 };
 
-#define WG_BP 32          // pixels per K-step
+#define WG_BP 64          // pixels per K-step (32 measured slower: half the MFMA work between barriers)
+#define WG_LD (WG_BP / 16) // staging loads per thread and tile
 #define WG_ROW 288        // LDS row stride in bytes: 128 channels * 2 B + 32 B padding
 #define WG_TILE (WG_BP * WG_ROW)
 
@@ -52,7 +53,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc((void*)p.dz, 0, p.dz_bytes, 0x00020000);
 
-  // staging: thread -> (row r0 + 16*i, 16-byte chunk cc) of both tiles, i = 0..1
+  // staging: thread -> (row r0 + 16*i, 16-byte chunk cc) of both tiles, i = 0..WG_LD-1
   const int cc = tid & 15, r0 = tid >> 4;
   const int HoWo = p.Ho * p.Wo;
   // this thread's X columns: kc = kc0 + 8*cc .. +7 -> one filter tap and channel offset (C % 8 == 0, a chunk never straddles taps)
@@ -64,12 +65,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   const int nch = n0 + cc * 8;
   const bool n_ok = nch < p.N;  // N % 8 == 0
 
-  uint4 rz[2], rx[2];
+  uint4 rz[WG_LD], rx[WG_LD];
   float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const bool want_bias = p.dbias != nullptr && kt == 0;
   auto load = [&](int mbase) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < WG_LD; ++i) {
       const int m = mbase + r0 + 16 * i;
       const bool ok = m < m_hi;
       rz[i] = buf_load16(zr, (ok && n_ok) ? ((unsigned)m * (unsigned)p.lddz + nch) * 2u : FX_OOB);
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
     unsigned char* X = Z + WG_TILE;
     if (want_bias) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      for (int i = 0; i < WG_LD; ++i) {
         float f[8];
         unpack_bf16x8(rz[i], f);
 #pragma unroll
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
       }
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < WG_LD; ++i) {
       *reinterpret_cast<uint4*>(Z + (r0 + 16 * i) * WG_ROW + cc * 16) = rz[i];
       *reinterpret_cast<uint4*>(X + (r0 + 16 * i) * WG_ROW + cc * 16) = rx[i];
     }

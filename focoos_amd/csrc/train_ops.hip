@@ -113,6 +113,63 @@ __global__ __launch_bounds__(256) void msda_f32_kernel(const float* __restrict__
   if (!BWD) *reinterpret_cast<float4*>(out + (int64_t)bq * CH + h * 32 + cg * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
 }
 
+// Backward: one wave per (batch, query); lane = (head parity, channel): every atomic instruction covers the 32 consecutive
+// channels (one 128-byte line) of two heads, so a tap costs 8 line-wide L2 atomic requests instead of the 32 quarter-filled
+// ones of the forward's lane layout (4 channels per lane) - the L2 atomic units, not the gathers, bound this kernel.
+// (A wave per sampling point - 12x the waves - was measured slower: 1.25 vs 1.06 ms per layer; the request count is what matters.)
+__global__ __launch_bounds__(256) void msda_f32_bwd_kernel(const float* __restrict__ value, const int32_t* __restrict__ shapes,
+                                                            const int32_t* __restrict__ lstart, int L, int P, const float* __restrict__ loc,
+                                                            const float* __restrict__ attn, const float* __restrict__ grad_out,
+                                                            float* __restrict__ grad_value, float* __restrict__ grad_loc,
+                                                            float* __restrict__ grad_attn, int B, int S, int Q, int M) {
+  const int lane = threadIdx.x & 63;
+  const int bq = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bq >= B * Q) return;
+  const int b = bq / Q;
+  const int hh = lane >> 5, c = lane & 31;
+  const int LP = L * P, CH = M * 32;
+  float go[4];
+#pragma unroll
+  for (int hp = 0; hp < 4; ++hp) go[hp] = grad_out[(int64_t)bq * CH + (hp * 2 + hh) * 32 + c];
+  for (int l = 0; l < L; ++l) {
+    const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
+    const int64_t lbase0 = (int64_t)b * S * CH + (int64_t)lstart[l] * CH + c;
+    for (int pt = 0; pt < P; ++pt) {
+      const int i = l * P + pt;
+#pragma unroll
+      for (int hp = 0; hp < 4; ++hp) {
+        const int h = hp * 2 + hh;
+        const int64_t pidx = ((int64_t)bq * M + h) * LP + i;
+        const float aw = attn[pidx];
+        const Tap4 t = make_taps(loc[2 * pidx], loc[2 * pidx + 1], Hl, Wl);
+        const int64_t lbase = lbase0 + h * 32;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = t.idx[k] >= 0 ? value[lbase + (int64_t)t.idx[k] * CH] : 0.f;
+        const float g = go[hp];
+        float g_a = g * (t.w[0] * v[0] + t.w[1] * v[1] + t.w[2] * v[2] + t.w[3] * v[3]);
+        float g_x = g * ((v[1] - v[0]) * (1.f - t.ty) + (v[3] - v[2]) * t.ty);
+        float g_y = g * ((v[2] - v[0]) * (1.f - t.tx) + (v[3] - v[1]) * t.tx);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (t.idx[k] >= 0) unsafeAtomicAdd(grad_value + lbase + (int64_t)t.idx[k] * CH, aw * t.w[k] * g);
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) {
+          g_a += __shfl_xor(g_a, o, 64);
+          g_x += __shfl_xor(g_x, o, 64);
+          g_y += __shfl_xor(g_y, o, 64);
+        }
+        if (c == 0) {
+          grad_attn[pidx] = g_a;
+          // d(ix)/d(loc_x) = W, d(iy)/d(loc_y) = H  (ix = loc_x * W - 0.5)
+          grad_loc[pidx * 2 + 0] = aw * g_x * (float)Wl;
+          grad_loc[pidx * 2 + 1] = aw * g_y * (float)Hl;
+        }
+      }
+    }
+  }
+}
+
 extern "C" int fx_msda_f32_fwd(const float* value, const int32_t* spatial_shapes, const int32_t* level_start, int L, int P, const float* loc,
                                const float* attn, float* out, int B, int S, int Q, int M, fx_stream_t stream_) {
   FX_CHECK_ARG(value && spatial_shapes && level_start && loc && attn && out && B > 0 && S > 0 && Q > 0 && L > 0 && P > 0);
@@ -130,8 +187,8 @@ extern "C" int fx_msda_f32_bwd(const float* value, const int32_t* spatial_shapes
   if (M != 8) return FX_ERR_UNSUPPORTED;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (hipMemsetAsync(grad_value, 0, (size_t)B * S * M * 32 * sizeof(float), stream) != hipSuccess) return FX_ERR_RUNTIME;
-  hipLaunchKernelGGL(msda_f32_kernel<true>, dim3((B * Q + 3) / 4), dim3(256), 0, stream, value, spatial_shapes, level_start, L, P, loc, attn, grad_out,
-                     nullptr, grad_value, grad_loc, grad_attn, B, S, Q, M);
+  hipLaunchKernelGGL(msda_f32_bwd_kernel, dim3((B * Q + 3) / 4), dim3(256), 0, stream, value, spatial_shapes, level_start, L, P, loc, attn, grad_out,
+                     grad_value, grad_loc, grad_attn, B, S, Q, M);
   return fx_launch_status();
 }
 

@@ -334,12 +334,14 @@ class TrainStep:
             p.grad = self.opt.grads[n]
         nn_.ARENA.arm(self.opt.numel + (8 << 20), self.opt.dev)   # staging for the 3x3 weight gradients + padded heads
         nn_.DIRECT_GRAD[0] = True
+        nn_.pin_stream(self.opt.dev, True)   # one stream-handle lookup per step instead of one per launch (backward runs on this stream too)
         try:
             losses = self.model(images, targets)
             total = sum(losses.values())
             total.backward()
         finally:
             nn_.DIRECT_GRAD[0] = False
+            nn_.pin_stream(self.opt.dev, False)
         self.reducer.launch()
         self.reducer.wait()
         self.opt.step()

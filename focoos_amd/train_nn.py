@@ -67,25 +67,52 @@ class ZeroArena:
 ARENA = ZeroArena()
 
 
+# Host-side launch cost matters here: a training step issues ~5 000 eager launches and is host-bound once the kernels are
+# fast.  Two things are therefore cached: the stream handle (TrainStep pins it for the duration of a step) and the ctypes conv
+# descriptors (a fresh 24-field Structure per call costs ~8 us; shapes are static, only the three pointers change).
+_STREAM_PIN: Dict[torch.device, C.c_void_p] = {}
+
+
+def pin_stream(dev, on: bool) -> None:
+    dev = torch.device(dev)
+    if on:
+        _STREAM_PIN[dev] = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    else:
+        _STREAM_PIN.pop(dev, None)
+
+
 def _stream(dev) -> C.c_void_p:
-    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    h = _STREAM_PIN.get(dev)
+    return h if h is not None else C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+_DESC_CACHE: Dict[tuple, tuple] = {}
 
 
 def _conv_call(lib, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], N: int, KH: int, KW: int, stride: int, pad: int,
                act: Optional[str], residual: Optional[torch.Tensor]) -> torch.Tensor:
     """fx_conv2d_nhwc_bf16 on NHWC bf16 tensors; ``w`` is a packed [Npad][KH][KW][C] bf16 image."""
     B, H, W_, Cc = x.shape
-    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W_ + 2 * pad - KW) // stride + 1
-    y = torch.empty(B, Ho, Wo, N, dtype=torch.bfloat16, device=x.device)
-    d = FxConvDesc()
-    d.x, d.w, d.y = x.data_ptr(), w.data_ptr(), y.data_ptr()
-    d.bias = bias.data_ptr() if bias is not None else None
+    key = (w.data_ptr(), bias.data_ptr() if bias is not None else 0, B, H, W_, Cc, N, KH, KW, stride, pad, act, residual is not None)
+    ent = _DESC_CACHE.get(key)
+    if ent is None:
+        Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W_ + 2 * pad - KW) // stride + 1
+        d = FxConvDesc()
+        d.w = w.data_ptr()
+        d.bias = bias.data_ptr() if bias is not None else None
+        d.B, d.H, d.W, d.C, d.ldx = B, H, W_, Cc, Cc
+        d.Ho, d.Wo, d.N, d.ldy, d.ldr = Ho, Wo, N, N, N if residual is not None else 0
+        d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
+        d.pool2, d.act, d.out_f32, d.residual_after_act, d.y_batch_stride = 0, FX_ACT[act], 0, 0, 0
+        ent = (d, C.byref(d), (B, Ho, Wo, N))
+        if len(_DESC_CACHE) > 4096:
+            _DESC_CACHE.clear()
+        _DESC_CACHE[key] = ent
+    d, ref, oshape = ent
+    y = torch.empty(oshape, dtype=torch.bfloat16, device=x.device)
+    d.x, d.y = x.data_ptr(), y.data_ptr()
     d.residual = residual.data_ptr() if residual is not None else None
-    d.B, d.H, d.W, d.C, d.ldx = B, H, W_, Cc, Cc
-    d.Ho, d.Wo, d.N, d.ldy, d.ldr = Ho, Wo, N, N, N if residual is not None else 0
-    d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
-    d.pool2, d.act, d.out_f32, d.residual_after_act, d.y_batch_stride = 0, FX_ACT[act], 0, 0, 0
-    check(lib.fx_conv2d_nhwc_bf16(C.byref(d), _stream(x.device)), "fx_conv2d_nhwc_bf16")
+    check(lib.fx_conv2d_nhwc_bf16(ref, _stream(x.device)), "fx_conv2d_nhwc_bf16")
     return y
 
 
@@ -607,7 +634,8 @@ class _PackedLinear:
                 self.w_t = torch.zeros(_rup(Kp, 128), 1, 1, Np, dtype=torch.bfloat16, device=dev)
             check(lib.fx_pack_conv_weights_f32(w.data_ptr(), None, self.w_fwd.data_ptr(), self.w_t.data_ptr(), Np, Kp, 1, 1, _stream(dev)),
                   "fx_pack_conv_weights_f32")
-            self.bias = torch.zeros(_rup(Np, 128), dtype=torch.float32, device=dev)
+            if self.bias is None or self.bias.device != dev or self.bias.numel() != _rup(Np, 128):
+                self.bias = torch.zeros(_rup(Np, 128), dtype=torch.float32, device=dev)   # allocated (and its padding zeroed) once
             if bias is not None:
                 self.bias[:N] = bias[r0:r1]
         self.ver = ver
