@@ -211,12 +211,16 @@ def train_main(args, world, rank, local):
             out.append(DETRTargets(labels=torch.from_numpy(rs.randint(0, K, (t,))).to(dev), boxes=torch.from_numpy(bx).to(dev)))
         return out
 
+    # targets of every step are created (and moved to HBM) BEFORE the timed region, like the images: a data loader hands them over
+    # asynchronously, and a pageable host->device copy inside the loop would stall the launch queue once per copy
+    all_targets = [targets(it) for it in range(max(args.warmup, 1) + args.steps)]
+    torch.cuda.synchronize()
     for it in range(max(args.warmup, 1)):
-        losses = stepper.step(imgs, targets(it))
+        losses = stepper.step(imgs, all_targets[it])
     barrier(world, False)
     t0 = time.perf_counter()
     for it in range(args.steps):
-        losses = stepper.step(imgs, targets(args.warmup + it))
+        losses = stepper.step(imgs, all_targets[max(args.warmup, 1) + it])
     barrier(world, False)
     dt = max_over_ranks(time.perf_counter() - t0, world, False)
     total = float(sum(v.detach().float() for v in losses.values()))

@@ -20,6 +20,35 @@ from . import _lib
 from ._lib import check
 
 
+class _PinnedRing:
+    """Small host->device transfers without stalling the launch queue: a pageable-memory H2D copy blocks the host until every
+    kernel queued before it has run (measured: ~11 ms per training step), a copy from pinned memory does not.  A ring of
+    pinned staging buffers keeps the source alive until the asynchronous copy has certainly been consumed."""
+
+    def __init__(self, slots: int = 64, capacity: int = 8192):
+        self.bufs = [torch.empty(capacity, dtype=torch.int32).pin_memory() for _ in range(slots)] if torch.cuda.is_available() else []
+        self.i = 0
+
+    def to_device(self, arr: np.ndarray, device) -> torch.Tensor:
+        arr = np.ascontiguousarray(arr, dtype=np.int32)
+        if not self.bufs or arr.size > self.bufs[0].numel():
+            return torch.from_numpy(arr).to(device)
+        b = self.bufs[self.i]
+        self.i = (self.i + 1) % len(self.bufs)
+        b[: arr.size].numpy()[...] = arr.reshape(-1)
+        return b[: arr.size].to(device, non_blocking=True).view(arr.shape)
+
+
+_RING = None
+
+
+def h2d_i32(arr: np.ndarray, device) -> torch.Tensor:
+    global _RING
+    if _RING is None:
+        _RING = _PinnedRing()
+    return _RING.to_device(arr, device)
+
+
 class _Targets:
     """Packed targets in HBM: labels i32 [sumT], boxes f32 [sumT,4], offsets i32 [B+1]."""
 
@@ -29,7 +58,7 @@ class _Targets:
         self.off_host[1:] = np.cumsum(sizes)
         self.n = int(self.off_host[-1])
         self.tmax = max(sizes + [0])
-        self.offsets = torch.from_numpy(self.off_host).to(device)
+        self.offsets = h2d_i32(self.off_host, device)
         if self.n:
             self.labels = torch.cat([t.labels.to(torch.int32) for t in targets]).to(device).contiguous()
             self.boxes = torch.cat([t.boxes.float() for t in targets]).to(device).contiguous()

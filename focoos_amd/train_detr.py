@@ -20,7 +20,7 @@ from torch import nn
 
 from . import _lib
 from ._lib import check
-from .criterion import BoxHungarianMatcher, _Targets
+from .criterion import h2d_i32, BoxHungarianMatcher, _Targets
 from .train import ms_deform_attn_core
 from .train_nn import (ConvNormLayer, HybridEncoder, LayerNorm, Linear, MultiheadAttention, ResNetVd, _AddFn, _Layers, _stream)
 
@@ -248,12 +248,13 @@ class SetCriterionTrain(nn.Module):
     def forward(self, outputs, targets: Sequence, fixed_matches=None):
         dev = outputs["pred_logits"].device
         tg = _Targets(targets, dev)
-        num = torch.tensor([float(tg.n)], device=dev)
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            torch.distributed.all_reduce(num)
-            num = num / torch.distributed.get_world_size()
-        num_boxes = max(float(num.item()), 1.0)
-        slot_b = torch.from_numpy(np.repeat(np.arange(len(targets)), np.diff(tg.off_host))).to(dev)
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            num = torch.tensor([float(tg.n)], device=dev)
+            torch.distributed.all_reduce(num)    # modelling.py:568-570 (4-byte all-reduce; its .item() is the reference's sync too)
+            num_boxes = max(float(num.item()) / torch.distributed.get_world_size(), 1.0)
+        else:
+            num_boxes = max(float(tg.n), 1.0)     # single process: a host integer - no device round trip, the launch queue keeps running ahead
+        slot_b = h2d_i32(np.repeat(np.arange(len(targets)), np.diff(tg.off_host)), dev).long()
         sets = [("", outputs)] + [(f"_{i}", a) for i, a in enumerate(outputs.get("aux_outputs", []))]
         losses, matches = {}, []
         for j, (suffix, o) in enumerate(sets):
