@@ -271,7 +271,7 @@ extern "C" int fx_normalize_pad8(const void* img, int is_f32, const float* mean,
 //   backward: da = dy * act'(a), a = z * scale + shift (recomputed, nothing but z is kept from the forward)
 //             fx_bn_bwd_stats_bf16 -> sums[c] = sum da (= dbeta), sums[C + c] = sum da * xhat (= dgamma), xhat = (z - mean) * rstd
 //             fx_bn_bwd_apply_bf16 -> dz = scale * (da - sums[c] / n - xhat * sums[C + c] / n)   [and da itself for a residual branch]
-#define BN_ROWS 256
+#define BN_ROWS(C) ((C) >= 256 ? 256 : 1024)   // rows per workgroup: narrow tensors have many more rows and 4-8x the row lanes
 __device__ __forceinline__ float bn_act_grad(float a, int act) {
   switch (act) {
     case FX_ACT_RELU: return a > 0.0f ? 1.0f : 0.0f;
@@ -289,12 +289,17 @@ template <int MODE>  // 0: (z, z^2)   1: (da, da * xhat)
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const bf16_t* __restrict__ z, int ldz, const bf16_t* __restrict__ dy, int lddy,
                                                         const bf16_t* __restrict__ res, int ldr, const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd, int act,
-                                                        float* __restrict__ sums, int64_t rows, int C) {
-  __shared__ float part[2][8][256];
-  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+                                                        float* __restrict__ sums, int64_t rows, int C, int rpb) {
+  __shared__ float part[2][2048];
+  // column groups x row lanes: 32 x 8 for wide tensors; narrow ones (C = 32 / 64 / 128 - most of the early backbone) get
+  // 4 x 64 / 8 x 32 / 16 x 16 so that every thread has work
+  const int cb = C - blockIdx.x * 256;
+  const int ncg = cb == 32 ? 4 : (cb == 64 ? 8 : (cb == 128 ? 16 : 32));
+  const int nrl = 256 / ncg;
+  const int cg = threadIdx.x % ncg, rl = threadIdx.x / ncg;
   const int c0 = blockIdx.x * 256 + cg * 8;
-  const int64_t r0 = (int64_t)blockIdx.y * BN_ROWS;
-  const int64_t r1 = r0 + BN_ROWS < rows ? r0 + BN_ROWS : rows;
+  const int64_t r0 = (int64_t)blockIdx.y * rpb;
+  const int64_t r1 = r0 + rpb < rows ? r0 + rpb : rows;
   float s0[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s1[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (c0 < C) {
     float sc[8], sh[8], mu[8], rs[8];
@@ -302,7 +307,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const bf16_t* __restrict
 #pragma unroll
       for (int j = 0; j < 8; ++j) sc[j] = scale[c0 + j], sh[j] = shift[c0 + j], mu[j] = mean[c0 + j], rs[j] = rstd[c0 + j];
     }
-    for (int64_t r = r0 + rl; r < r1; r += 8) {
+    for (int64_t r = r0 + rl; r < r1; r += nrl) {
       float v[8];
       unpack_bf16x8(*reinterpret_cast<const uint4*>(z + r * ldz + c0), v);
       if (MODE == 0) {
@@ -321,14 +326,14 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const bf16_t* __restrict
       }
     }
   }
+  const int cols = ncg * 8;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) part[0][rl][cg * 8 + j] = s0[j], part[1][rl][cg * 8 + j] = s1[j];
+  for (int j = 0; j < 8; ++j) part[0][rl * cols + cg * 8 + j] = s0[j], part[1][rl * cols + cg * 8 + j] = s1[j];
   __syncthreads();
   const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c < C) {
+  if ((int)threadIdx.x < cols && c < C) {
     float a = 0.0f, b = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) a += part[0][i][threadIdx.x], b += part[1][i][threadIdx.x];
+    for (int i = 0; i < nrl; ++i) a += part[0][i * cols + threadIdx.x], b += part[1][i * cols + threadIdx.x];
     unsafeAtomicAdd(sums + c, a);
     unsafeAtomicAdd(sums + C + c, b);
   }
@@ -336,8 +341,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const bf16_t* __restrict
 
 extern "C" int fx_bn_stats_bf16(const void* z, int ldz, float* sums, int64_t rows, int C, fx_stream_t stream_) {
   FX_CHECK_ARG(z && sums && rows > 0 && C > 0 && C % 8 == 0 && ldz >= C && ldz % 8 == 0);
-  hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3((C + 255) / 256, (unsigned)((rows + BN_ROWS - 1) / BN_ROWS)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)z, ldz, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, sums, rows, C);
+  hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3((C + 255) / 256, (unsigned)((rows + BN_ROWS(C) - 1) / BN_ROWS(C))), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)z, ldz, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, sums, rows, C, BN_ROWS(C));
   return fx_launch_status();
 }
 
@@ -347,8 +352,8 @@ extern "C" int fx_bn_bwd_stats_bf16(const void* dy, int lddy, const void* z, int
   FX_CHECK_ARG(!residual || (ldr >= C && ldr % 8 == 0));
   FX_CHECK_ARG(dy && z && scale && shift && mean && rstd && sums && rows > 0 && C > 0 && C % 8 == 0);
   FX_CHECK_ARG(ldz >= C && lddy >= C && ldz % 8 == 0 && lddy % 8 == 0);
-  hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((C + 255) / 256, (unsigned)((rows + BN_ROWS - 1) / BN_ROWS)), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)z, ldz, (const bf16_t*)dy, lddy, (const bf16_t*)residual, ldr, scale, shift, mean, rstd, act, sums, rows, C);
+  hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((C + 255) / 256, (unsigned)((rows + BN_ROWS(C) - 1) / BN_ROWS(C))), dim3(256), 0,
+                     reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)z, ldz, (const bf16_t*)dy, lddy, (const bf16_t*)residual, ldr, scale, shift, mean, rstd, act, sums, rows, C, BN_ROWS(C));
   return fx_launch_status();
 }
 
@@ -393,6 +398,11 @@ extern "C" int fx_bn_apply_bf16(const void* z, int ldz, const float* scale, cons
 }
 
 // With a residual the activation input is a = z * scale + shift + residual; the residual is re-read rather than keeping a.
+__device__ __forceinline__ void ld8(const float* __restrict__ p, float* f) {   // 8 consecutive per-channel values (32-byte aligned)
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ z, int ldz,
                                                            const bf16_t* __restrict__ res, int ldr, const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd, int act,
@@ -407,14 +417,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
     unpack_bf16x8(*reinterpret_cast<const uint4*>(z + r * ldz + c8 * 8), v);
     unpack_bf16x8(*reinterpret_cast<const uint4*>(dy + r * lddy + c8 * 8), g);
     if (res) unpack_bf16x8(*reinterpret_cast<const uint4*>(res + r * ldr + c8 * 8), rr);
+    float sc[8], sh[8], mu[8], rs[8], s0[8], s1[8];
+    ld8(scale + c8 * 8, sc); ld8(shift + c8 * 8, sh); ld8(mean + c8 * 8, mu); ld8(rstd + c8 * 8, rs);
+    ld8(sums + c8 * 8, s0); ld8(sums + C + c8 * 8, s1);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      const int c = c8 * 8 + j;
-      const float sc = scale[c];
-      const float da = g[j] * bn_act_grad(v[j] * sc + shift[c] + rr[j], act);
-      const float xh = (v[j] - mean[c]) * rstd[c];
+      const float da = g[j] * bn_act_grad(v[j] * sc[j] + sh[j] + rr[j], act);
+      const float xh = (v[j] - mu[j]) * rs[j];
       d[j] = da;
-      o[j] = sc * (da - sums[c] * inv_n - xh * sums[C + c] * inv_n);
+      o[j] = sc[j] * (da - s0[j] * inv_n - xh * s1[j] * inv_n);
     }
     if (da_out) *reinterpret_cast<uint4*>(da_out + r * ldda + c8 * 8) = pack_bf16x8(d);
     *reinterpret_cast<uint4*>(dz + r * lddz + c8 * 8) = pack_bf16x8(o);
