@@ -9,6 +9,8 @@
 //     consecutive pixels of its channel.  The 32-byte row padding spreads the 4 rows of a block over distinct banks.
 //   * the pixel range is split across workgroups (grid.y) - the output tile count alone (N/128 x Ktot/128) cannot fill
 //     256 CUs - and partial sums are added into the fp32 gradient with hardware float atomics.
+#include <stdlib.h>
+
 #include "conv_common.h"
 
 typedef __attribute__((ext_vector_type(4))) short s16x4;
@@ -22,7 +24,8 @@ struct WgradArgs {
   int B, H, W, C, ldx;
   int Ho, Wo, N, lddz;
   int KH, KW, stride, pad;
-  int M, Ktot, nKt, mchunk;
+  int M, Ktot, nKt, mchunk, tiles;
+  long long split_stride;  // 0: fp32 atomics into one dW; else pixel range `by` stores its partial tile sums at dw + by * split_stride
   unsigned x_bytes, dz_bytes;
 };
 
@@ -40,13 +43,18 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * WG_TILE];  // [stage][dZ tile | X tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int nt = blockIdx.x / p.nKt, kt = blockIdx.x % p.nKt;
+  // XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2); remapped so that one XCD runs
+  // ALL output tiles of a pixel range back to back - they share the same X / dZ rows, which then come from that XCD's L2 once
+  // instead of from every XCD's (measured ceiling before: ~320 TFLOP/s = the tile's 128 flop/byte x ~2.5 TB/s of L2 misses)
+  const int bid = fx_xcd_remap(blockIdx.x, gridDim.x);
+  const int bx = bid % p.tiles, by = bid / p.tiles;
+  const int nt = bx / p.nKt, kt = bx % p.nKt;
   const int n0 = nt * 128, kc0 = kt * 128;
-  const int m_lo = blockIdx.y * p.mchunk;
+  const int m_lo = by * p.mchunk;
   const int m_hi = min(p.M, m_lo + p.mchunk);
   if (m_lo >= m_hi) return;
 
@@ -65,24 +73,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   const int nch = n0 + cc * 8;
   const bool n_ok = nch < p.N;  // N % 8 == 0
 
-  uint4 rz[WG_LD], rx[WG_LD];
+  // Pipeline: two register stages + two LDS stages.  The reduction index (pixel) advances every step, so every step needs fresh
+  // global loads; with a single register stage each step waited a full memory round trip (the kernel sat at a ~45 us floor for
+  // layers whose MFMA time is 5 us).  Now the loads of tile st+2 are issued before the MFMAs of tile st.
+  uint4 rzA[WG_LD], rxA[WG_LD], rzB[WG_LD], rxB[WG_LD];
   float bsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   const bool want_bias = p.dbias != nullptr && kt == 0;
-  auto load = [&](int mbase) {
+  const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
+  auto fdiv = [](int m, int d, float inv) {   // m / d for 0 <= m < 2^24-ish: float estimate + exact correction (no integer divide)
+    int q = (int)((float)m * inv);
+    q -= (q * d > m);
+    q += ((q + 1) * d <= m);
+    return q;
+  };
+  auto load = [&](uint4* rz, uint4* rx, int mbase) {
 #pragma unroll
     for (int i = 0; i < WG_LD; ++i) {
       const int m = mbase + r0 + 16 * i;
       const bool ok = m < m_hi;
       rz[i] = buf_load16(zr, (ok && n_ok) ? ((unsigned)m * (unsigned)p.lddz + nch) * 2u : FX_OOB);
       const int mm = ok ? m : 0;
-      const int b = mm / HoWo, rem = mm - b * HoWo;
-      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      const int b = fdiv(mm, HoWo, inv_howo), rem = mm - b * HoWo;
+      const int ho = fdiv(rem, p.Wo, inv_wo), wo = rem - ho * p.Wo;
       const int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;
       const bool in = ok && kc_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
       rx[i] = buf_load16(xr, in ? ((unsigned)((b * p.H + hi) * p.W + wi) * (unsigned)p.ldx + cch) * 2u : FX_OOB);
     }
   };
-  auto store = [&](int s) {
+  auto store = [&](const uint4* rz, const uint4* rx, int s) {
     unsigned char* Z = smem + s * 2 * WG_TILE;
     unsigned char* X = Z + WG_TILE;
     if (want_bias) {
@@ -113,14 +131,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
   // row (t>>2), 8-byte piece (t&3) of the [4][16] block
   const int g = lane >> 4, t = lane & 15;
   const int frag_off = ((g >> 1) * 8 + (t >> 2)) * WG_ROW + ((g & 1) * 16 + (t & 3) * 4) * 2;
-
-  const int nsteps = (m_hi - m_lo + WG_BP - 1) / WG_BP;
-  load(m_lo);
-  store(0);
-  __syncthreads();
-  for (int st = 0; st < nsteps; ++st) {
-    const int cur = st & 1;
-    if (st + 1 < nsteps) load(m_lo + (st + 1) * WG_BP);
+  auto compute = [&](int cur) {
     const unsigned char* Z = smem + cur * 2 * WG_TILE;
     const unsigned char* X = Z + WG_TILE;
 #pragma unroll
@@ -135,7 +146,24 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
     }
-    if (st + 1 < nsteps) store(cur ^ 1);
+  };
+
+  const int nsteps = (m_hi - m_lo + WG_BP - 1) / WG_BP;
+  load(rzA, rxA, m_lo);
+  if (nsteps > 1) load(rzB, rxB, m_lo + WG_BP);
+  store(rzA, rxA, 0);
+  __syncthreads();
+  for (int st = 0; st < nsteps; st += 2) {
+    // even step: LDS[0] = tile st, registers B = tile st+1, registers A free
+    if (st + 2 < nsteps) load(rzA, rxA, m_lo + (st + 2) * WG_BP);
+    compute(0);
+    if (st + 1 < nsteps) store(rzB, rxB, 1);
+    __syncthreads();
+    if (st + 1 >= nsteps) break;
+    // odd step: LDS[1] = tile st+1, registers A = tile st+2, registers B free
+    if (st + 3 < nsteps) load(rzB, rxB, m_lo + (st + 3) * WG_BP);
+    compute(1);
+    if (st + 2 < nsteps) store(rzA, rxA, 0);
     __syncthreads();
   }
   if (want_bias) {  // reduce the 16 row-threads of each channel chunk through LDS (the tiles are no longer needed)
@@ -161,7 +189,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (n < p.N && kcol < p.Ktot) unsafeAtomicAdd(p.dw + (int64_t)n * p.Ktot + kcol, acc[a][b][r]);
+        if (n < p.N && kcol < p.Ktot) {
+          if (p.split_stride) p.dw[(int64_t)by * p.split_stride + (int64_t)n * p.Ktot + kcol] = acc[a][b][r];
+          else unsafeAtomicAdd(p.dw + (int64_t)n * p.Ktot + kcol, acc[a][b][r]);
+        }
       }
     }
 }
@@ -174,8 +205,18 @@ extern "C" int fx_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz,
   return fx_conv2d_wgrad_bias_nhwc_bf16(x, ldx, dz, lddz, dw, nullptr, B, H, W, C, Ho, Wo, N, KH, KW, stride, pad, stream_);
 }
 
-extern "C" int fx_conv2d_wgrad_bias_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, float* dw, float* dbias, int B, int H, int W,
-                                              int C, int Ho, int Wo, int N, int KH, int KW, int stride, int pad, fx_stream_t stream_) {
+// pixel split of one launch: enough workgroups to fill the chip `occ` times over, chunks a multiple of the K-step
+static void wgrad_split(int M, int tiles, int occ, int* mchunk_out, int* splits_out) {
+  int want = (256 * occ + tiles - 1) / tiles;
+  int mchunk = (M + want - 1) / want;
+  if (mchunk < 512) mchunk = 512;
+  mchunk = (mchunk + WG_BP - 1) / WG_BP * WG_BP;
+  *mchunk_out = mchunk;
+  *splits_out = (M + mchunk - 1) / mchunk;
+}
+
+static int wgrad_launch(const void* x, int ldx, const void* dz, int lddz, float* dw, long long split_stride, int expect_splits, float* dbias, int B, int H,
+                        int W, int C, int Ho, int Wo, int N, int KH, int KW, int stride, int pad, fx_stream_t stream_) {
   FX_CHECK_ARG(x && dz && dw && B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && N > 0 && C > 0);
   FX_CHECK_ARG(C % 8 == 0 && N % 8 == 0 && ldx >= C && lddz >= N && ldx % 8 == 0 && lddz % 8 == 0);
   FX_CHECK_ARG(KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0);
@@ -198,14 +239,33 @@ extern "C" int fx_conv2d_wgrad_bias_nhwc_bf16(const void* x, int ldx, const void
   const int nNt = (N + 127) / 128;
   a.x_bytes = (unsigned)x_bytes;
   a.dz_bytes = (unsigned)dz_bytes;
-  // pixel split: enough workgroups to fill the chip a few times over, chunks a multiple of the K-step
   const int tiles = nNt * a.nKt;
-  int want = (256 * 4 + tiles - 1) / tiles;
-  int mchunk = (a.M + want - 1) / want;
-  if (mchunk < 512) mchunk = 512;
-  mchunk = (mchunk + WG_BP - 1) / WG_BP * WG_BP;
-  a.mchunk = mchunk;
-  const int S = (a.M + mchunk - 1) / mchunk;
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles, S), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), a);
+  // atomics: every split adds one full pass of fp32 atomics over dW, and the L2 atomic units sustain only ~0.6 TB/s - few splits.
+  // partial stores: plain coalesced stores (summed later by fx_unpack_conv_wgrad_sum_f32) - more splits, more parallelism.
+  int S;
+  wgrad_split(a.M, tiles, split_stride ? 4 : 2, &a.mchunk, &S);
+  FX_CHECK_ARG(!split_stride || (S == expect_splits && split_stride >= (long long)N * a.Ktot));
+  a.split_stride = split_stride;
+  a.tiles = tiles;
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles * S), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), a);
   return fx_launch_status();
+}
+
+extern "C" int fx_conv2d_wgrad_bias_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, float* dw, float* dbias, int B, int H, int W,
+                                              int C, int Ho, int Wo, int N, int KH, int KW, int stride, int pad, fx_stream_t stream_) {
+  return wgrad_launch(x, ldx, dz, lddz, dw, 0, 0, dbias, B, H, W, C, Ho, Wo, N, KH, KW, stride, pad, stream_);
+}
+
+extern "C" int fx_conv2d_wgrad_splits(int B, int Ho, int Wo, int C, int N, int KH, int KW) {
+  if (B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || N <= 0 || KH <= 0 || KW <= 0) return 0;
+  int mchunk, S;
+  wgrad_split(B * Ho * Wo, ((N + 127) / 128) * ((KH * KW * C + 127) / 128), 4, &mchunk, &S);
+  return S;
+}
+
+extern "C" int fx_conv2d_wgrad_partial_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, float* partials, int64_t split_stride, int splits,
+                                                 int B, int H, int W, int C, int Ho, int Wo, int N, int KH, int KW, int stride, int pad,
+                                                 fx_stream_t stream_) {
+  FX_CHECK_ARG(split_stride > 0 && splits > 0);
+  return wgrad_launch(x, ldx, dz, lddz, partials, split_stride, splits, nullptr, B, H, W, C, Ho, Wo, N, KH, KW, stride, pad, stream_);
 }

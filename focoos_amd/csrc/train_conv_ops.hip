@@ -39,9 +39,11 @@ extern "C" int fx_pack_conv_weights_f32(const float* w, const float* scale, void
   return fx_launch_status();
 }
 
-// dw_master[n][c][kh][kw] (+)= scale[n] * dw_eff[n][kh][kw][c]   (chain rule through the folded BatchNorm scale)
-__global__ __launch_bounds__(256) void unpack_conv_wgrad_kernel(const float* __restrict__ dw_eff, const float* __restrict__ scale,
-                                                                float* __restrict__ dw, int N, int C, int KH, int KW, int Ceff, int accumulate) {
+// dw_master[n][c][kh][kw] (+)= scale[n] * sum_s dw_eff[s][n][kh][kw][c]   (chain rule through the folded BatchNorm scale; the sum runs
+// over the pixel-range partials of fx_conv2d_wgrad_partial_nhwc_bf16 - one slab when the gradient was accumulated with atomics)
+__global__ __launch_bounds__(256) void unpack_conv_wgrad_kernel(const float* __restrict__ dw_eff, int64_t split_stride, int splits,
+                                                                const float* __restrict__ scale, float* __restrict__ dw, int N, int C, int KH,
+                                                                int KW, int Ceff, int accumulate) {
   const int64_t total = (int64_t)N * C * KH * KW;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     int kw = (int)(i % KW);
@@ -50,20 +52,64 @@ __global__ __launch_bounds__(256) void unpack_conv_wgrad_kernel(const float* __r
     r /= KH;
     int c = (int)(r % C);
     int n = (int)(r / C);
-    const float v = dw_eff[(((int64_t)n * KH + kh) * KW + kw) * Ceff + c] * (scale ? scale[n] : 1.0f);
+    const int64_t src = (((int64_t)n * KH + kh) * KW + kw) * Ceff + c;
+    float v = 0.0f;
+    for (int s = 0; s < splits; ++s) v += dw_eff[(int64_t)s * split_stride + src];
+    v *= scale ? scale[n] : 1.0f;
     dw[i] = accumulate ? dw[i] + v : v;
   }
 }
 
-extern "C" int fx_unpack_conv_wgrad_f32(const float* dw_eff, const float* scale, float* dw_master, int N, int C, int KH, int KW, int C_eff,
-                                        int accumulate, fx_stream_t stream_) {
-  FX_CHECK_ARG(dw_eff && dw_master && N > 0 && C > 0 && KH > 0 && KW > 0 && C_eff >= C);
+// slab 0 += slabs 1..S-1 (coalesced float4 streams; the slabs are read at the HBM rate, which is what makes per-pixel-range
+// partial stores cheaper than fp32 atomics)
+__global__ __launch_bounds__(256) void slab_sum_kernel(float* __restrict__ part, int64_t split_stride, int splits, int64_t n4) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 a = reinterpret_cast<const float4*>(part)[i];
+    int s = 1;
+    for (; s + 3 < splits; s += 4) {
+      const float4 b0 = reinterpret_cast<const float4*>(part + (int64_t)s * split_stride)[i];
+      const float4 b1 = reinterpret_cast<const float4*>(part + (int64_t)(s + 1) * split_stride)[i];
+      const float4 b2 = reinterpret_cast<const float4*>(part + (int64_t)(s + 2) * split_stride)[i];
+      const float4 b3 = reinterpret_cast<const float4*>(part + (int64_t)(s + 3) * split_stride)[i];
+      a.x += (b0.x + b1.x) + (b2.x + b3.x); a.y += (b0.y + b1.y) + (b2.y + b3.y);
+      a.z += (b0.z + b1.z) + (b2.z + b3.z); a.w += (b0.w + b1.w) + (b2.w + b3.w);
+    }
+    for (; s < splits; ++s) {
+      const float4 b = reinterpret_cast<const float4*>(part + (int64_t)s * split_stride)[i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    reinterpret_cast<float4*>(part)[i] = a;
+  }
+}
+
+static int unpack_launch(const float* dw_eff, int64_t split_stride, int splits, const float* scale, float* dw_master, int N, int C, int KH, int KW,
+                         int C_eff, int accumulate, fx_stream_t stream_) {
+  FX_CHECK_ARG(dw_eff && dw_master && N > 0 && C > 0 && KH > 0 && KW > 0 && C_eff >= C && splits >= 1);
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const int64_t slab = (int64_t)N * KH * KW * C_eff;
+  if (splits > 1 && slab % 4 == 0 && split_stride % 4 == 0 && ((uintptr_t)dw_eff % 16) == 0) {
+    int64_t grid = (slab / 4 + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(slab_sum_kernel, dim3((int)grid), dim3(256), 0, stream, const_cast<float*>(dw_eff), split_stride, splits, slab / 4);
+    splits = 1;
+  }
   int64_t total = (int64_t)N * C * KH * KW;
   int64_t grid = (total + 255) / 256;
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), dw_eff, scale, dw_master,
-                     N, C, KH, KW, C_eff, accumulate);
+  hipLaunchKernelGGL(unpack_conv_wgrad_kernel, dim3((int)grid), dim3(256), 0, stream, dw_eff, split_stride, splits, scale, dw_master, N, C, KH, KW,
+                     C_eff, accumulate);
   return fx_launch_status();
+}
+
+extern "C" int fx_unpack_conv_wgrad_f32(const float* dw_eff, const float* scale, float* dw_master, int N, int C, int KH, int KW, int C_eff,
+                                        int accumulate, fx_stream_t stream_) {
+  return unpack_launch(dw_eff, 0, 1, scale, dw_master, N, C, KH, KW, C_eff, accumulate, stream_);
+}
+
+extern "C" int fx_unpack_conv_wgrad_sum_f32(const float* partials, int64_t split_stride, int splits, const float* scale, float* dw_master, int N,
+                                            int C, int KH, int KW, int C_eff, int accumulate, fx_stream_t stream_) {
+  FX_CHECK_ARG(split_stride >= (int64_t)N * KH * KW * C_eff);
+  return unpack_launch(partials, split_stride, splits, scale, dw_master, N, C, KH, KW, C_eff, accumulate, stream_);
 }
 
 // ------------------------------------------------------------------------------------------------

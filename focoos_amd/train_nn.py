@@ -224,21 +224,44 @@ def _bn_backward(layer, dy: torch.Tensor, z: torch.Tensor, residual: Optional[to
     return dz, da, dgamma, dbeta
 
 
+_WGRAD_WS: Dict[torch.device, torch.Tensor] = {}
+
+
+def _wgrad_workspace(numel: int, dev) -> torch.Tensor:
+    """One reusable fp32 staging buffer for the per-pixel-range partial weight gradients (launches are serial on one stream and
+    each unpack consumes the partials before the next layer overwrites them)."""
+    ws = _WGRAD_WS.get(dev)
+    if ws is None or ws.numel() < numel:
+        ws = torch.empty(max(numel, 16 << 20), dtype=torch.float32, device=dev)
+        _WGRAD_WS[dev] = ws
+    return ws
+
+
 def _conv_param_grads(layer, x: torch.Tensor, dz: torch.Tensor, scale: Optional[torch.Tensor]):
-    """Weight gradient of the layer's conv: MFMA wgrad into the [N][k][k][C] staging image, then (scaled) unpack into the
-    master layout - straight into ``weight.grad`` when the optimizer's flat views are installed."""
+    """Weight gradient of the layer's conv: MFMA wgrad of every pixel range into its own [N][k][k][C] partial slab (plain stores),
+    then one pass that sums the slabs, applies the folded-BN scale and re-lays the result out for the master weight - straight
+    into ``weight.grad`` when the optimizer's flat views are installed."""
     lib, dev = layer.lib, x.device
     B, H, W_, Cc = x.shape
     _, Ho, Wo, N = dz.shape
     st = _stream(dev)
-    dw_eff = ARENA.zeros((N, layer.k, layer.k, Cc), dev)
-    check(lib.fx_conv2d_wgrad_nhwc_bf16(x.data_ptr(), Cc, dz.data_ptr(), N, dw_eff.data_ptr(), B, H, W_, Cc, Ho, Wo, N, layer.k, layer.k,
-                                        layer.stride, layer.pad, st), "fx_conv2d_wgrad_nhwc_bf16")
+    k = layer.k
+    key = (B, Ho, Wo, Cc, N, k)
+    S = layer._wgrad_splits.get(key) if hasattr(layer, "_wgrad_splits") else None
+    if S is None:
+        S = int(lib.fx_conv2d_wgrad_splits(B, Ho, Wo, Cc, N, k, k))
+        if not hasattr(layer, "_wgrad_splits"):
+            object.__setattr__(layer, "_wgrad_splits", {})
+        layer._wgrad_splits[key] = S
+    slab = N * k * k * Cc
+    ws = _wgrad_workspace(S * slab, dev)
+    check(lib.fx_conv2d_wgrad_partial_nhwc_bf16(x.data_ptr(), Cc, dz.data_ptr(), N, ws.data_ptr(), slab, S, B, H, W_, Cc, Ho, Wo, N, k, k,
+                                                layer.stride, layer.pad, st), "fx_conv2d_wgrad_partial_nhwc_bf16")
     wparam = layer._conv_h.weight
     direct = DIRECT_GRAD[0] and wparam.grad is not None
-    dw = wparam.grad if direct else torch.empty(N, Cc, layer.k, layer.k, dtype=torch.float32, device=dev)
-    check(lib.fx_unpack_conv_wgrad_f32(dw_eff.data_ptr(), scale.data_ptr() if scale is not None else None, dw.data_ptr(), N, Cc, layer.k, layer.k, Cc,
-                                       int(direct), st), "fx_unpack_conv_wgrad_f32")
+    dw = wparam.grad if direct else torch.empty(N, Cc, k, k, dtype=torch.float32, device=dev)
+    check(lib.fx_unpack_conv_wgrad_sum_f32(ws.data_ptr(), slab, S, scale.data_ptr() if scale is not None else None, dw.data_ptr(), N, Cc, k, k, Cc,
+                                           int(direct), st), "fx_unpack_conv_wgrad_sum_f32")
     return None if direct else dw
 
 

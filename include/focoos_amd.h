@@ -329,6 +329,16 @@ int fx_pack_conv_weights_f32(const float* w, const float* scale, void* w_fwd, vo
 int fx_unpack_conv_wgrad_f32(const float* dw_eff, const float* scale, float* dw_master, int N, int C, int KH, int KW, int C_eff, int accumulate,
                              fx_stream_t stream);
 
+/* The same weight gradient without atomics: pixel range s (0 <= s < splits = fx_conv2d_wgrad_splits(...)) STORES its partial sums at
+ * partials + s * split_stride (f32 [N][KH][KW][C] each; split_stride >= N*KH*KW*C; nothing needs zeroing), and
+ * fx_unpack_conv_wgrad_sum_f32 adds the slabs while it re-lays the gradient out for the master weight.  The L2 atomic units sustain
+ * ~0.6 TB/s of fp32 adds, plain stores the HBM rate, so this is the path for the 3x3 / wide layers whose dW is megabytes. */
+int fx_conv2d_wgrad_splits(int B, int Ho, int Wo, int C, int N, int KH, int KW);
+int fx_conv2d_wgrad_partial_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, float* partials, int64_t split_stride, int splits, int B,
+                                      int H, int W, int C, int Ho, int Wo, int N, int KH, int KW, int stride, int pad, fx_stream_t stream);
+int fx_unpack_conv_wgrad_sum_f32(const float* partials, int64_t split_stride, int splits, const float* scale, float* dw_master, int N, int C, int KH,
+                                 int KW, int C_eff, int accumulate, fx_stream_t stream);
+
 /* Backward of the fused epilogue y = relu(conv + bias [+ residual]): dz = (dy [+ dy2]) * (y > 0)  (use_relu = 0: plain sum). */
 int fx_relu_bwd_bf16(const void* dy, int lddy, const void* dy2, int lddy2, const void* y, int ldy, void* dz, int lddz, int64_t rows, int cols,
                      int use_relu, fx_stream_t stream);

@@ -62,6 +62,22 @@ def test_conv_wgrad(lib, case):
     check(lib.fx_conv2d_wgrad_nhwc_bf16(xd.data_ptr(), Cc, dzd.data_ptr(), N, dw.data_ptr(), B, H, W, Cc, Ho, Wo, N, k, k, stride, pad, stream()))
     torch.cuda.synchronize()
     assert (dw.cpu() - 2 * ref).abs().max() / ref.abs().max() < 4e-3
+    # partial-slab path (plain stores per pixel range, no zeroing needed) + the summing / scaling / re-layout pass
+    S = lib.fx_conv2d_wgrad_splits(B, Ho, Wo, Cc, N, k, k)
+    assert S >= 1
+    slab = N * k * k * Cc + 64
+    ws = torch.full((S * slab,), float("nan"), dtype=torch.float32, device=DEV)
+    check(lib.fx_conv2d_wgrad_partial_nhwc_bf16(xd.data_ptr(), Cc, dzd.data_ptr(), N, ws.data_ptr(), slab, S, B, H, W, Cc, Ho, Wo, N, k, k, stride, pad,
+                                                stream()))
+    scale = (torch.rand(N, generator=g) + 0.5).to(DEV)
+    out = torch.ones(N, Cc, k, k, dtype=torch.float32, device=DEV)
+    check(lib.fx_unpack_conv_wgrad_sum_f32(ws.data_ptr(), slab, S, scale.data_ptr(), out.data_ptr(), N, Cc, k, k, Cc, 1, stream()))
+    torch.cuda.synchronize()
+    want = 1 + w.grad * scale.cpu().view(-1, 1, 1, 1)
+    assert (out.cpu() - want).abs().max() / ref.abs().max() < 3e-3
+    with pytest.raises(_lib.FocoosAmdError):   # a split count other than the planned one is rejected
+        check(lib.fx_conv2d_wgrad_partial_nhwc_bf16(xd.data_ptr(), Cc, dzd.data_ptr(), N, ws.data_ptr(), slab, S + 1, B, H, W, Cc, Ho, Wo, N, k, k, stride,
+                                                    pad, stream()))
 
 
 def test_conv_wgrad_asymmetric_and_strided_views(lib):
