@@ -12,8 +12,10 @@ export TMPDIR=/tmp
 cd $ROOT
 python bench.py --per-op $OUT/${TAG}_per_op_hipevent.txt > $OUT/${TAG}_bench.json 2> $OUT/${TAG}_bench.err
 python bench.py --model fai-mf-l-coco-ins --cpu-iters 1 --per-op $OUT/${TAG}_mf_per_op_hipevent.txt > $OUT/${TAG}_mf_bench.json 2> $OUT/${TAG}_mf_bench.err
+if [ -z "$FX_PROFILE_QUICK" ]; then
 python bench.py --model fai-mf-l-coco-ins --no-cpu-baseline --steps 10 --warmup 3 --mf-full-masks > $OUT/${TAG}_mf_bench_fullmasks.json 2>/dev/null
 python bench.py --model fai-mf-l-coco-ins --no-cpu-baseline --steps 10 --warmup 3 --mf-masks-d2h > $OUT/${TAG}_mf_bench_masks_d2h.json 2>/dev/null
+fi
 timeout 300 python bench.py --train --steps 10 --warmup 3 > $OUT/${TAG}_train_bench.json 2> $OUT/${TAG}_train_bench.err
 timeout 300 python bench.py --train --norm BN --steps 10 --warmup 3 > $OUT/${TAG}_train_bn_bench.json 2> $OUT/${TAG}_train_bn_bench.err
 python bench.py --model bisenetformer-l-ade --cpu-iters 1 --per-op $OUT/${TAG}_bf_per_op_hipevent.txt > $OUT/${TAG}_bf_bench.json 2> $OUT/${TAG}_bf_bench.err
