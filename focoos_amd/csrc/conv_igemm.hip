@@ -214,9 +214,12 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void conv_igemm_kernel(con
 #pragma unroll
           for (int i = 0; i < 8; ++i) v[i] = fx_act(v[i], p.act);
         }
-        if (p.res && p.res_after) {
+        if (p.res && p.res_after == 1) {
 #pragma unroll
           for (int i = 0; i < 8; ++i) v[i] += rf[i];
+        } else if (p.res && p.res_after == 2) {  // ReLU mask of a saved activation (training: relu backward fused into the dgrad conv)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = rf[i] > 0.0f ? v[i] : 0.0f;
         }
         int64_t yoff;
         if (p.y_bstride) {

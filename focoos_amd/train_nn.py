@@ -33,6 +33,9 @@ WEIGHTS_EPOCH = [0]
 # Set by train_detr.TrainStep: parameter gradients are accumulated by the kernels straight into the (pre-zeroed) flat
 # gradient views held in ``param.grad`` and the backward returns None for them - no per-parameter zero-fill / add launches.
 DIRECT_GRAD = [False]
+# ResNet bottlenecks as single autograd nodes with fused backward epilogues (off: one node per layer - the form the live-BatchNorm
+# path always uses); kept switchable so that tests can compare the two.
+FUSED_BLOCKS = [True]
 
 
 class ZeroArena:
@@ -90,10 +93,11 @@ _DESC_CACHE: Dict[tuple, tuple] = {}
 
 
 def _conv_call(lib, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], N: int, KH: int, KW: int, stride: int, pad: int,
-               act: Optional[str], residual: Optional[torch.Tensor]) -> torch.Tensor:
-    """fx_conv2d_nhwc_bf16 on NHWC bf16 tensors; ``w`` is a packed [Npad][KH][KW][C] bf16 image."""
+               act: Optional[str], residual: Optional[torch.Tensor], res_mode: int = 0) -> torch.Tensor:
+    """fx_conv2d_nhwc_bf16 on NHWC bf16 tensors; ``w`` is a packed [Npad][KH][KW][C] bf16 image.  ``res_mode``: 0 = add ``residual``
+    before the activation, 2 = multiply by (residual > 0) - the ReLU backward of the layer that produced ``residual``."""
     B, H, W_, Cc = x.shape
-    key = (w.data_ptr(), bias.data_ptr() if bias is not None else 0, B, H, W_, Cc, N, KH, KW, stride, pad, act, residual is not None)
+    key = (w.data_ptr(), bias.data_ptr() if bias is not None else 0, B, H, W_, Cc, N, KH, KW, stride, pad, act, residual is not None, res_mode)
     ent = _DESC_CACHE.get(key)
     if ent is None:
         Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W_ + 2 * pad - KW) // stride + 1
@@ -103,7 +107,7 @@ def _conv_call(lib, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tenso
         d.B, d.H, d.W, d.C, d.ldx = B, H, W_, Cc, Cc
         d.Ho, d.Wo, d.N, d.ldy, d.ldr = Ho, Wo, N, N, N if residual is not None else 0
         d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
-        d.pool2, d.act, d.out_f32, d.residual_after_act, d.y_batch_stride = 0, FX_ACT[act], 0, 0, 0
+        d.pool2, d.act, d.out_f32, d.residual_after_act, d.y_batch_stride = 0, FX_ACT[act], 0, res_mode, 0
         ent = (d, C.byref(d), (B, Ho, Wo, N))
         if len(_DESC_CACHE) > 4096:
             _DESC_CACHE.clear()
@@ -535,6 +539,84 @@ class _Short(nn.Module):
         return self.conv(_PoolFn.apply(x, self.lib, "avg"))
 
 
+class _BottleneckFn(torch.autograd.Function):
+    """A whole ResNet-vd bottleneck (frozen BatchNorm) as ONE autograd node.  Forward = the four fused conv launches of the
+    per-layer path.  Backward, relative to chaining the per-layer nodes through autograd:
+      * the ReLU backward of branch2a / branch2b is the epilogue of the dgrad convolution that produces their output gradient
+        (conv epilogue mode 2: multiply by (saved activation > 0)) - two elementwise passes per block disappear;
+      * the two gradients of the block input (main branch + shortcut) are summed in the epilogue of branch2a's dgrad convolution
+        (its `residual` operand) instead of by an autograd add kernel over the largest tensors of the network;
+      * one Python node instead of four to six."""
+
+    @staticmethod
+    def forward(ctx, x, wa, wb, wc, ws, blk: "BottleNeck"):
+        a_l, b_l, c_l = blk.branch2a, blk.branch2b, blk.branch2c
+        lib = a_l.lib
+        for l in (a_l, b_l, c_l):
+            l.sync_packed()
+        a = _conv_call(lib, x, a_l.w_fwd, a_l.shift, a_l.cout, 1, 1, 1, 0, "relu", None)
+        b = _conv_call(lib, a, b_l.w_fwd, b_l.shift, b_l.cout, 3, 3, b_l.stride, 1, "relu", None)
+        pooled = None
+        if blk.has_short:
+            s_l = blk.short.conv if isinstance(blk.short, _Short) else blk.short
+            s_l.sync_packed()
+            sx = x
+            if isinstance(blk.short, _Short):
+                B, H, W_, Cc = x.shape
+                pooled = torch.empty(B, (H + 1) // 2, (W_ + 1) // 2, Cc, dtype=torch.bfloat16, device=x.device)
+                check(lib.fx_avgpool2x2_nhwc_bf16(x.data_ptr(), Cc, pooled.data_ptr(), Cc, B, H, W_, Cc, _stream(x.device)), "fx_avgpool2x2_nhwc_bf16")
+                sx = pooled
+            short = _conv_call(lib, sx, s_l.w_fwd, s_l.shift, s_l.cout, 1, 1, 1, 0, None, None)
+        else:
+            short = x
+        y = _conv_call(lib, b, c_l.w_fwd, c_l.shift, c_l.cout, 1, 1, 1, 0, "relu", short)
+        ctx.blk = blk
+        ctx.save_for_backward(x, a, b, y, pooled)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        blk: BottleNeck = ctx.blk
+        x, a, b, y, pooled = ctx.saved_tensors
+        a_l, b_l, c_l = blk.branch2a, blk.branch2b, blk.branch2c
+        lib, dev = a_l.lib, x.device
+        st = _stream(dev)
+        dy = dy.contiguous()
+        B, Ho, Wo, N = y.shape
+        dz_c = torch.empty_like(y)   # gradient of conv_c's output AND of the shortcut branch (pre-activation residual add)
+        check(lib.fx_relu_bwd_bf16(dy.data_ptr(), N, None, 0, y.data_ptr(), N, dz_c.data_ptr(), N, B * Ho * Wo, N, 1, st), "fx_relu_bwd_bf16")
+        need = ctx.needs_input_grad
+        dwc = _conv_param_grads(c_l, b, dz_c, c_l.scale) if need[3] else None
+        dz_b = _conv_call(lib, dz_c, c_l.w_dgrad, None, c_l.cin, 1, 1, 1, 0, None, b, res_mode=2)       # dgrad_c * relu'(b)
+        dwb = _conv_param_grads(b_l, a, dz_b, b_l.scale) if need[2] else None
+        if b_l.stride == 1:
+            src = dz_b
+        else:
+            Ba, Ha, Wa, Ca = a.shape
+            src = torch.empty(Ba, Ha, Wa, b_l.cout, dtype=torch.bfloat16, device=dev)
+            check(lib.fx_zero_insert2_nhwc_bf16(dz_b.data_ptr(), b_l.cout, src.data_ptr(), b_l.cout, Ba, dz_b.shape[1], dz_b.shape[2], Ha, Wa, b_l.cout, st),
+                  "fx_zero_insert2_nhwc_bf16")
+        dz_a = _conv_call(lib, src, b_l.w_dgrad, None, b_l.cin, 3, 3, 1, 1, None, a, res_mode=2)       # dgrad_b * relu'(a)
+        dwa = _conv_param_grads(a_l, x, dz_a, a_l.scale) if need[1] else None
+        dws = None
+        if blk.has_short:
+            s_l = blk.short.conv if isinstance(blk.short, _Short) else blk.short
+            sx = pooled if pooled is not None else x
+            dws = _conv_param_grads(s_l, sx, dz_c, s_l.scale) if need[4] else None
+            dshort = None
+            if need[0]:
+                dshort = _conv_call(lib, dz_c, s_l.w_dgrad, None, s_l.cin, 1, 1, 1, 0, None, None)
+                if pooled is not None:
+                    dxs = torch.empty_like(x)
+                    check(lib.fx_avgpool2x2_bwd_nhwc_bf16(dshort.data_ptr(), s_l.cin, dxs.data_ptr(), s_l.cin, x.shape[0], x.shape[1], x.shape[2], s_l.cin, st),
+                          "fx_avgpool2x2_bwd_nhwc_bf16")
+                    dshort = dxs
+        else:
+            dshort = dz_c
+        dx = _conv_call(lib, dz_a, a_l.w_dgrad, None, a_l.cin, 1, 1, 1, 0, None, dshort) if need[0] else None   # + shortcut gradient in the epilogue
+        return dx, dwa, dwb, dwc, dws, None
+
+
 class BottleNeck(nn.Module):
     """focoos/nn/backbone/resnet.py:72-121 (variant d: stride on the 3x3)."""
 
@@ -548,6 +630,10 @@ class BottleNeck(nn.Module):
             self.short = ConvNormLayer(lib, ch_in, width * 4, 1, 1, None) if (first_stage or stride == 1) else _Short(lib, ch_in, width * 4)
 
     def forward(self, x):
+        if not self.branch2a.batch_stats and FUSED_BLOCKS[0]:   # frozen / eval BatchNorm: the whole block is one autograd node
+            s_l = (self.short.conv if isinstance(self.short, _Short) else self.short) if self.has_short else None
+            return _BottleneckFn.apply(x, self.branch2a._conv_h.weight, self.branch2b._conv_h.weight, self.branch2c._conv_h.weight,
+                                       s_l._conv_h.weight if s_l is not None else None, self)
         out = self.branch2b(self.branch2a(x))
         short = self.short(x) if self.has_short else x
         return self.branch2c(out, residual=short)  # relu(conv + bn + short)

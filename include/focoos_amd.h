@@ -61,7 +61,9 @@ typedef struct fx_conv_desc {
   int32_t pool2;   /* 1: x is 2x2/2 average-pooled (ceil mode) on the fly; needs KH=KW=1, stride 1 */
   int32_t act;     /* FX_ACT_* */
   int32_t out_f32; /* 1: y is float32 */
-  int32_t residual_after_act; /* 0: act(conv+bias+residual) (BottleNeck); 1: act(conv+bias)+residual (CSPRepLayer x_1+x_2) */
+  int32_t residual_after_act; /* 0: act(conv+bias+residual) (BottleNeck); 1: act(conv+bias)+residual (CSPRepLayer x_1+x_2);
+                               * 2: act(conv+bias) * (residual > 0): `residual` is a saved ReLU output - the ReLU backward of the
+                               *    producing layer fused into this (input-gradient) convolution of the training path */
   int64_t y_batch_stride;     /* elements between images of y; 0 = contiguous (Ho*Wo*ldy). Lets a level write its rows of
                                  the [B, sum(HW), C] decoder memory directly (modelling.py:1158-1165 flatten+concat for free) */
 } fx_conv_desc;

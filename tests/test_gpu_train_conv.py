@@ -579,3 +579,40 @@ def test_resnet_vd_batch_stat_batchnorm_backward_vs_torch_autograd():
         ev = net(x_u8)
     feats_e = O.resnet_vd({k: v.detach() for k, v in ref_sd.items()}, pre[:-1], xi, O.RESNET_BLOCKS[50])
     assert rel_l2(ev["res5"].float().cpu().permute(0, 3, 1, 2), feats_e["res5"]) <= 3e-2
+
+
+def test_fused_bottleneck_node_matches_per_layer_nodes():
+    """ResNet50-vd backward with every bottleneck as ONE autograd node (ReLU backward and the shortcut-gradient add fused into the
+    dgrad convolutions' epilogues) vs the per-layer nodes: same gradients up to the bf16 rounding that the fusion removes."""
+    from focoos_amd import train_nn
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.synth import synth_image_structured, synth_state_dict
+    from focoos_amd.train_nn import ResNetVd
+    from tests.helpers import rel_l2
+
+    cfg = ModelRegistry.get_model_info("fai-detr-l-coco")["config"]
+    sd = synth_state_dict(cfg, 11)
+    pre = "pixel_decoder.backbone."
+    bsd = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    x_u8 = torch.from_numpy(np.stack([synth_image_structured(40 + i, 128, 160) for i in range(2)])).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    proj = {k: torch.randn(c, generator=g).to(DEV) for k, c in (("res2", 256), ("res3", 512), ("res4", 1024), ("res5", 2048))}
+    grads = {}
+    for fused in (True, False):
+        train_nn.FUSED_BLOCKS[0] = fused
+        try:
+            net = ResNetVd(50).to(DEV)
+            net.load_state_dict(bsd, strict=True)
+            outs = net(x_u8)
+            (sum((outs[k].float() * proj[k]).sum() for k in proj) * 1e-2).backward()
+            torch.cuda.synchronize()
+            grads[fused] = {n: p.grad.clone() for n, p in net.named_parameters() if p.requires_grad}
+            feats = {k: v.detach().clone() for k, v in outs.items()}
+        finally:
+            train_nn.FUSED_BLOCKS[0] = True
+        if fused:
+            feats_fused = feats
+    assert all(torch.equal(feats[k], feats_fused[k]) for k in feats)          # identical forward launches
+    worst = max(rel_l2(grads[True][n], grads[False][n]) for n in grads[True])
+    print("fused vs per-layer weight gradients, worst rel-L2:", worst)
+    assert worst <= 2e-2
