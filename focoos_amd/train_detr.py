@@ -308,7 +308,7 @@ class TrainStep:
     torch.cuda.make_graphed_callables was tried and dead-locked inside the capture on this stack, so it is not used."""
 
     def __init__(self, model: FAIDetrTrainable, lr: float = 1e-4, backbone_multiplier: float = 0.1, weight_decay: float = 1e-4,
-                 max_grad_norm: float = 0.1):
+                 max_grad_norm: float = 0.1, ema_decay: Optional[float] = None, ema_warmups: int = 2000):
         from . import train_nn
         from .train import BucketedGradAllReduce, FlatAdamW
 
@@ -327,6 +327,12 @@ class TrainStep:
                 p.grad = self.opt.grads[n]
         self.named = named
         self.reducer = BucketedGradAllReduce(self.opt.flat_g)
+        self.ema = None
+        if ema_decay is not None:   # the trainer's EMA hook (trainer/solver/ema.py): one pass over the flat parameter buffer per step
+            from .train_data import FlatEMA
+
+            bufs = {n: b for n, b in model.named_buffers() if "running_" in n or "num_batches_tracked" in n}
+            self.ema = FlatEMA(self.opt.flat_p, {n: self.opt.params[n] for n, _ in named}, bufs, decay=ema_decay, warmups=ema_warmups)
 
     def step(self, images: torch.Tensor, targets: Sequence) -> Dict[str, torch.Tensor]:
         nn_ = self._nn
@@ -347,4 +353,6 @@ class TrainStep:
         self.reducer.wait()
         self.opt.step()
         nn_.WEIGHTS_EPOCH[0] += 1
+        if self.ema is not None:
+            self.ema.update()
         return losses
