@@ -260,14 +260,28 @@ __global__ __launch_bounds__(256) void seg_winner_cell_kernel(const float* __res
 #pragma unroll
     for (int k = 0; k < S * S; ++k) best[k] = -INFINITY, bidx[k] = 0;
     const float* pb = lo + (int64_t)b * Q * h * w;
+    // window rows (im, i, ip) x columns (jm, j, jp), clamped at the borders; the next query's window is fetched while the current
+    // one is evaluated (one wave per SIMD at this register count: nothing else hides the L2 latency)
+    const int o00 = im * w + jm, o01 = im * w + j, o02 = im * w + jp, o10 = i * w + jm, o11 = i * w + j, o12 = i * w + jp,
+              o20 = ip * w + jm, o21 = ip * w + j, o22 = ip * w + jp;
+    float nx[3][3];
+    nx[0][0] = pb[o00]; nx[0][1] = pb[o01]; nx[0][2] = pb[o02];
+    nx[1][0] = pb[o10]; nx[1][1] = pb[o11]; nx[1][2] = pb[o12];
+    nx[2][0] = pb[o20]; nx[2][1] = pb[o21]; nx[2][2] = pb[o22];
 #pragma unroll 1
     for (int q = 0; q < Q; ++q) {
-      const float* p = pb + (int64_t)q * h * w;
       const float sc = s_score[q];
-      float v[3][3];   // window rows (im, i, ip) x columns (jm, j, jp), clamped at the borders
-      v[0][0] = p[im * w + jm]; v[0][1] = p[im * w + j]; v[0][2] = p[im * w + jp];
-      v[1][0] = p[i * w + jm];  v[1][1] = p[i * w + j];  v[1][2] = p[i * w + jp];
-      v[2][0] = p[ip * w + jm]; v[2][1] = p[ip * w + j]; v[2][2] = p[ip * w + jp];
+      float v[3][3];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[a][c] = nx[a][c];
+      if (q + 1 < Q) {
+        const float* p = pb + (int64_t)(q + 1) * h * w;
+        nx[0][0] = p[o00]; nx[0][1] = p[o01]; nx[0][2] = p[o02];
+        nx[1][0] = p[o10]; nx[1][1] = p[o11]; nx[1][2] = p[o12];
+        nx[2][0] = p[o20]; nx[2][1] = p[o21]; nx[2][2] = p[o22];
+      }
       float rowi[3][S];   // x-interpolated window rows (ATen interpolates along x first; same operation order as lerp_taps)
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
