@@ -201,10 +201,13 @@ def test_conv_rejects_bad_arguments(lib):
         run_conv(lib, x, torch.zeros(8, 48, 1, 1), None)  # C % 32 != 0
 
 
+@pytest.mark.parametrize("hw", [(38, 50), (37, 49), (32, 1024)])
 @pytest.mark.parametrize("in_f32", [0, 1])
-def test_stem(lib, in_f32):
+def test_stem(lib, in_f32, hw):
+    """uint8 images run the MFMA kernel (bf16 inputs / weights: one rounding each), fp32 images the VALU kernel; odd sizes exercise
+    the bottom / right zero padding, the first pixel the clamped run start."""
     g = torch.Generator().manual_seed(11)
-    B, H, W = 2, 38, 50
+    B, (H, W) = 2, hw
     img = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
     Wt = torch.randn(32, 3, 3, 3, generator=g) * 0.2
     bias = torch.randn(32, generator=g) * 0.1
