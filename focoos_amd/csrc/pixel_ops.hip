@@ -195,14 +195,17 @@ static int stem_launch(const void* x, int in_f32, const float* w, const float* b
   const int64_t x_bytes = (int64_t)B * H * W * 3;
   static const int use_mfma = fx_env_int("FX_STEM_MFMA", 1);
   if (!in_f32 && use_mfma && x_bytes < 0xFFFFFFF0ll) {
+    // dword loads are range-checked as a whole: round the record count up so that the last (partial) dword of an image whose byte
+    // count is not a multiple of 4 is still returned (the bytes past the end belong to masked taps; allocations are 512-byte padded)
+    const unsigned x_records = (unsigned)((x_bytes + 3) & ~3ll);
     const int tiles = (int)((total + 31) / 32);
     const int tpw = 8;                                  // 256 pixels per wave: amortises the A-fragment build
     const int blocks = (tiles + 4 * tpw - 1) / (4 * tpw);
     if (relu)
-      hipLaunchKernelGGL(stem_mfma_kernel<true>, dim3(blocks), dim3(256), 0, stream, (const uint8_t*)x, (unsigned)x_bytes, w, bias, mean, inv_std,
+      hipLaunchKernelGGL(stem_mfma_kernel<true>, dim3(blocks), dim3(256), 0, stream, (const uint8_t*)x, x_records, w, bias, mean, inv_std,
                          (bf16_t*)y, B, H, W, Ho, Wo, tpw);
     else
-      hipLaunchKernelGGL(stem_mfma_kernel<false>, dim3(blocks), dim3(256), 0, stream, (const uint8_t*)x, (unsigned)x_bytes, w, bias, mean, inv_std,
+      hipLaunchKernelGGL(stem_mfma_kernel<false>, dim3(blocks), dim3(256), 0, stream, (const uint8_t*)x, x_records, w, bias, mean, inv_std,
                          (bf16_t*)y, B, H, W, Ho, Wo, tpw);
     return fx_launch_status();
   }
