@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void stem_conv_kernel(const TIn* __restrict__ 
 //     past the end, and whatever is read left of the image or above it is masked after normalisation (zero padding applies to the
 //     NORMALISED image).
 //   * with weights as A, a lane's accumulators are 4 consecutive channels of one pixel -> bias, ReLU, 8-byte bf16 stores.
-// Inputs and weights are rounded to bf16 (like every later layer); the fp32 image variant keeps the VALU kernel.
+// Inputs and weights are rounded to bf16 (like every later layer).  The VALU kernel above remains as the FX_STEM_MFMA=0 fallback.
 __device__ __forceinline__ void stem_run8(__amdgpu_buffer_rsrc_t r, int a, unsigned& lo, unsigned& hi, unsigned& b8) {
   const unsigned a4 = (unsigned)a & ~3u;
   const unsigned sh = (unsigned)a & 3u;
@@ -88,8 +88,17 @@ __device__ __forceinline__ void stem_run8(__amdgpu_buffer_rsrc_t r, int a, unsig
   b8 = (sh == 0 ? d2 : __builtin_amdgcn_alignbyte(0u, d2, sh)) & 0xffu;   // byte a+8 (sh <= 3: it lies in d2)
 }
 
-template <bool RELU>
-__global__ __launch_bounds__(256) void stem_mfma_kernel(const uint8_t* __restrict__ x, unsigned x_bytes, const float* __restrict__ wt /*[27][32]*/,
+// fp32 images (the reference's float NCHW contract, values on the 0..255 scale): the same 9 taps as floats; identical arithmetic
+// after the load, so a float image holding integer values gives bit-identical results to its uint8 form
+__device__ __forceinline__ void stem_run9_f32(__amdgpu_buffer_rsrc_t r, int elem, float* f, float& f8) {
+  const unsigned off = (unsigned)elem * 4u;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off + 4u * j, 0, 0));
+  f8 = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off + 32u, 0, 0));
+}
+
+template <typename TIn, bool RELU>
+__global__ __launch_bounds__(256) void stem_mfma_kernel(const TIn* __restrict__ x, unsigned x_bytes, const float* __restrict__ wt /*[27][32]*/,
                                                          const float* __restrict__ bias, const float* __restrict__ mean,
                                                          const float* __restrict__ inv_std, bf16_t* __restrict__ y, int B, int H, int W, int Ho,
                                                          int Wo, int tiles_per_wave) {
@@ -133,24 +142,36 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const uint8_t* __restric
     auto run = [&](int rr, float* f, float& f8) {
       const int hi_ = 2 * ho - 1 + rr;
       const bool rv = act && hi_ >= 0 && hi_ < H;
-      unsigned lo, hi, b8;
-      // leftmost pixels: the run would start 3 bytes before the row (before the buffer for the very first pixel, where a wrapped
-      // offset is not reliably range-checked) - fetch from the row start and shift the bytes up instead; bytes 0-2 are masked anyway
+      // leftmost pixels: the run would start 3 elements before the row (before the buffer for the very first pixel, where a wrapped
+      // offset is not reliably range-checked) - fetch from the row start and shift the taps up instead; taps 0-2 are masked anyway
       const bool neg = wi0 < 0;
-      stem_run8(xr, rv ? ((b * H + hi_) * W + (neg ? 0 : wi0)) * 3 : 0, lo, hi, b8);
-      if (neg) {
-        b8 = (hi >> 8) & 0xffu;
-        hi = __builtin_amdgcn_alignbyte(hi, lo, 1);
-        lo = __builtin_amdgcn_alignbyte(lo, 0u, 1);
+      const int elem = rv ? ((b * H + hi_) * W + (neg ? 0 : wi0)) * 3 : 0;
+      float raw[8], raw8;
+      if (sizeof(TIn) == 1) {
+        unsigned lo, hi, b8;
+        stem_run8(xr, elem, lo, hi, b8);
+        if (neg) {
+          b8 = (hi >> 8) & 0xffu;
+          hi = __builtin_amdgcn_alignbyte(hi, lo, 1);
+          lo = __builtin_amdgcn_alignbyte(lo, 0u, 1);
+        }
+        const unsigned w[2] = {lo, hi};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) raw[j] = (float)((w[j >> 2] >> (8 * (j & 3))) & 0xffu);
+        raw8 = (float)b8;
+      } else {
+        float t[8], t8;
+        stem_run9_f32(xr, elem, t, t8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) raw[j] = neg ? (j >= 3 ? t[j - 3] : 0.0f) : t[j];
+        raw8 = neg ? t[5] : t8;
       }
-      const unsigned w[2] = {lo, hi};
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        const float v = (float)((w[j >> 2] >> (8 * (j & 3))) & 0xffu);
         const bool ok = rv && (j < 3 ? c0 : (j < 6 ? true : c2));
-        f[j] = ok ? (v - mj[j]) * sj[j] : 0.0f;
+        f[j] = ok ? (raw[j] - mj[j]) * sj[j] : 0.0f;
       }
-      f8 = (rv && c2) ? ((float)b8 - m2) * s2 : 0.0f;
+      f8 = (rv && c2) ? (raw8 - m2) * s2 : 0.0f;
     };
     // both lane halves run the same code: rows (0 | 2) and 1; the upper half gets byte 8 of row 0 from its partner lane
     float f1[8], fb[8], ta, tb;
@@ -192,21 +213,24 @@ static int stem_launch(const void* x, int in_f32, const float* w, const float* b
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
 #define STEM_GO(T, R) \
   hipLaunchKernelGGL((stem_conv_kernel<T, R>), dim3(grid), dim3(256), 0, stream, (const T*)x, w, bias, mean, inv_std, (bf16_t*)y, B, H, W, Ho, Wo)
-  const int64_t x_bytes = (int64_t)B * H * W * 3;
+  const int64_t x_bytes = (int64_t)B * H * W * 3 * (in_f32 ? 4 : 1);
   static const int use_mfma = fx_env_int("FX_STEM_MFMA", 1);
-  if (!in_f32 && use_mfma && x_bytes < 0xFFFFFFF0ll) {
-    // dword loads are range-checked as a whole: round the record count up so that the last (partial) dword of an image whose byte
-    // count is not a multiple of 4 is still returned (the bytes past the end belong to masked taps; allocations are 512-byte padded)
+  if (use_mfma && x_bytes < 0xFFFFFFF0ll) {
+    // dword loads are range-checked as a whole: round the record count up so that the last (partial) dword of a uint8 image whose
+    // byte count is not a multiple of 4 is still returned (the bytes past the end belong to masked taps; allocations are 512-byte padded)
     const unsigned x_records = (unsigned)((x_bytes + 3) & ~3ll);
     const int tiles = (int)((total + 31) / 32);
     const int tpw = 8;                                  // 256 pixels per wave: amortises the A-fragment build
     const int blocks = (tiles + 4 * tpw - 1) / (4 * tpw);
-    if (relu)
-      hipLaunchKernelGGL(stem_mfma_kernel<true>, dim3(blocks), dim3(256), 0, stream, (const uint8_t*)x, x_records, w, bias, mean, inv_std,
-                         (bf16_t*)y, B, H, W, Ho, Wo, tpw);
-    else
-      hipLaunchKernelGGL(stem_mfma_kernel<false>, dim3(blocks), dim3(256), 0, stream, (const uint8_t*)x, x_records, w, bias, mean, inv_std,
-                         (bf16_t*)y, B, H, W, Ho, Wo, tpw);
+#define STEM_MFMA(T, R)                                                                                                                       \
+  hipLaunchKernelGGL((stem_mfma_kernel<T, R>), dim3(blocks), dim3(256), 0, stream, (const T*)x, x_records, w, bias, mean, inv_std, (bf16_t*)y, B, H, \
+                     W, Ho, Wo, tpw)
+    if (in_f32) {
+      if (relu) STEM_MFMA(float, true); else STEM_MFMA(float, false);
+    } else {
+      if (relu) STEM_MFMA(uint8_t, true); else STEM_MFMA(uint8_t, false);
+    }
+#undef STEM_MFMA
     return fx_launch_status();
   }
   if (in_f32) {
