@@ -6,6 +6,7 @@ run on N GPUs sees the same sample order and the same EMA trajectory as the refe
   per_rank_batch_size                   focoos/data/loaders.py:61-65            (TrainerArgs.batch_size is the TOTAL batch)
   rank_seed                             focoos/trainer/trainer.py:101           (seed + rank)
   FlatEMA                               focoos/trainer/solver/ema.py:83-137     (EMAUpdater: decay * (1 - exp(-updates / warmups)))
+  lr_factor                             focoos/trainer/solver/lr_scheduler.py:19-171 (FIXED / POLY / COSINE / MULTISTEP with warm-up)
 """
 from __future__ import annotations
 
@@ -124,3 +125,46 @@ class FlatEMA:
         out = {n: v.clone() for n, v in self.views.items()}
         out.update({n: v.clone() for n, v in self.buf_state.items()})
         return out
+
+
+# ------------------------------------------------------------------------------------------------ learning-rate schedules
+def _warmup_factor(method: str, it: int, warmup_iters: int, warmup_factor: float) -> float:
+    """focoos/trainer/solver/lr_scheduler.py:142-171."""
+    if it >= warmup_iters:
+        return 1.0
+    if method == "constant":
+        return warmup_factor
+    if method == "linear":
+        alpha = it / warmup_iters
+        return warmup_factor * (1 - alpha) + alpha
+    if method == "quadratic":
+        alpha = (it / warmup_iters) ** 2
+        return warmup_factor * (1 - alpha) + alpha
+    raise ValueError("Unknown warmup method: {}".format(method))
+
+
+def lr_factor(name: str, it: int, max_iters: int, *, milestones=(), gamma: float = 0.1, warmup_factor: float = 1.0, warmup_iters: int = 0,
+              warmup_method: str = "linear", power: float = 0.9, constant_ending: float = 0.0) -> float:
+    """Multiplier of every parameter group's base learning rate at iteration ``it`` - WarmupPolyLR / WarmupMultiStepLR /
+    WarmupCosineLR / the constant base scheduler of focoos/trainer/solver/lr_scheduler.py:19-139 (selected by name like
+    build_lr_scheduler, solver/build.py:141-159).  The engine applies it with one device-side multiply of the optimizer's
+    per-chunk learning-rate table (FlatAdamW.set_lr_scale) instead of a scheduler object stepping ~500 param groups."""
+    from bisect import bisect_right
+
+    key = name.upper()
+    w = _warmup_factor(warmup_method, it, warmup_iters, warmup_factor)
+    if key == "POLY":
+        decay = math.pow((1.0 - it / max_iters), power)
+        if constant_ending > 0 and w == 1.0 and decay < constant_ending:
+            return constant_ending
+        return w * decay
+    if key == "MULTISTEP":
+        if list(milestones) != sorted(milestones):
+            raise ValueError("Milestones should be a list of increasing integers. Got {}", milestones)
+        ms = [int(m * max_iters) for m in milestones]
+        return w * gamma ** bisect_right(ms, it)
+    if key == "COSINE":
+        return w * 0.5 * (1.0 + math.cos(math.pi * it / max_iters))
+    if key == "FIXED":
+        return 1.0
+    raise NotImplementedError(f"Scheduler {name} is not supported.")

@@ -308,7 +308,8 @@ class TrainStep:
     torch.cuda.make_graphed_callables was tried and dead-locked inside the capture on this stack, so it is not used."""
 
     def __init__(self, model: FAIDetrTrainable, lr: float = 1e-4, backbone_multiplier: float = 0.1, weight_decay: float = 1e-4,
-                 max_grad_norm: float = 0.1, ema_decay: Optional[float] = None, ema_warmups: int = 2000):
+                 max_grad_norm: float = 0.1, ema_decay: Optional[float] = None, ema_warmups: int = 2000, scheduler: Optional[str] = None,
+                 max_iters: int = 0, scheduler_extra: Optional[Dict] = None):
         from . import train_nn
         from .train import BucketedGradAllReduce, FlatAdamW
 
@@ -327,6 +328,10 @@ class TrainStep:
                 p.grad = self.opt.grads[n]
         self.named = named
         self.reducer = BucketedGradAllReduce(self.opt.flat_g)
+        # learning-rate schedule (trainer/solver/lr_scheduler.py): one device-side multiply of the per-chunk lr table per change
+        self.scheduler, self.max_iters, self.scheduler_extra = scheduler, max_iters, dict(scheduler_extra or {})
+        self.iteration, self._lr_factor = 0, 1.0
+        self._base_lrs = self.opt.chunk_lr.clone()
         self.ema = None
         if ema_decay is not None:   # the trainer's EMA hook (trainer/solver/ema.py): one pass over the flat parameter buffer per step
             from .train_data import FlatEMA
@@ -336,6 +341,14 @@ class TrainStep:
 
     def step(self, images: torch.Tensor, targets: Sequence) -> Dict[str, torch.Tensor]:
         nn_ = self._nn
+        if self.scheduler is not None:
+            from .train_data import lr_factor
+
+            f = lr_factor(self.scheduler, self.iteration, self.max_iters, **self.scheduler_extra)
+            if f != self._lr_factor:
+                self.opt.set_lr_scale(f, self._base_lrs)
+                self._lr_factor = f
+        self.iteration += 1
         self.opt.zero_grad()
         for n, p in self.named:  # gradient kernels / autograd accumulate in place into these views
             p.grad = self.opt.grads[n]

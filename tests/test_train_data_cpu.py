@@ -6,7 +6,7 @@ import math
 import pytest
 import torch
 
-from focoos_amd.train_data import FlatEMA, InferenceSampler, TrainingSampler, per_rank_batch_size, rank_seed
+from focoos_amd.train_data import FlatEMA, InferenceSampler, TrainingSampler, lr_factor, per_rank_batch_size, rank_seed
 
 
 def take(it, n):
@@ -128,3 +128,41 @@ def test_flat_ema_matches_reference_updater():
         sd2 = mine.state_dict()
         for n in names + list(bufs2):
             torch.testing.assert_close(sd2[n].float(), up.state.state[n].float(), rtol=1e-5, atol=1e-6)
+
+
+def test_lr_factor_matches_reference_schedulers():
+    """lr_factor vs the reference's LRScheduler classes stepped like the trainer does (one scheduler.step() per iteration)."""
+    cases = [("POLY", dict(warmup_factor=0.001, warmup_iters=20, warmup_method="linear", power=0.9, constant_ending=0.0)),
+             ("POLY", dict(warmup_factor=1.0, warmup_iters=0, power=2.0, constant_ending=0.05)),
+             ("COSINE", dict(warmup_factor=0.01, warmup_iters=15, warmup_method="quadratic")),
+             ("MULTISTEP", dict(milestones=[0.5, 0.8], gamma=0.1, warmup_factor=0.1, warmup_iters=10, warmup_method="constant")),
+             ("FIXED", dict())]
+    # defining properties, available everywhere
+    assert lr_factor("POLY", 0, 100, warmup_factor=0.001, warmup_iters=20) == pytest.approx(0.001)
+    assert lr_factor("COSINE", 100, 100) == pytest.approx(0.0, abs=1e-12) and lr_factor("FIXED", 7, 10) == 1.0
+    assert lr_factor("MULTISTEP", 80, 100, milestones=[0.5, 0.8]) == pytest.approx(0.01)
+    with pytest.raises(NotImplementedError):
+        lr_factor("STEP", 0, 10)
+    from oracle import ref_import
+
+    if not ref_import.reference_available():
+        pytest.skip("reference tree not mounted")
+    ref_import.install()
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("_ref_lrs", os.path.join(ref_import.REFERENCE_ROOT, "focoos/trainer/solver/lr_scheduler.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    classes = {"POLY": mod.WarmupPolyLR, "COSINE": mod.WarmupCosineLR, "MULTISTEP": mod.WarmupMultiStepLR, "FIXED": mod.BaseLRScheduler}
+    max_iters = 120
+    for name, extra in cases:
+        p1, p2 = torch.nn.Parameter(torch.zeros(1)), torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([{"params": [p1], "lr": 1e-4}, {"params": [p2], "lr": 1e-5}], lr=1e-4)
+        sch = classes[name](optimizer=opt, max_iters=max_iters, **extra)
+        for it in range(max_iters):
+            f = lr_factor(name, it, max_iters, **extra)
+            got = [g["lr"] for g in opt.param_groups]
+            assert got[0] == pytest.approx(1e-4 * f, rel=1e-12, abs=1e-18) and got[1] == pytest.approx(1e-5 * f, rel=1e-12, abs=1e-18), (name, it)
+            opt.step()
+            sch.step()
