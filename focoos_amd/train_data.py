@@ -168,3 +168,37 @@ def lr_factor(name: str, it: int, max_iters: int, *, milestones=(), gamma: float
     if key == "FIXED":
         return 1.0
     raise NotImplementedError(f"Scheduler {name} is not supported.")
+
+
+# ------------------------------------------------------------------------------------------------ optimizer hyper-parameters
+_NORM_KINDS = ("bn_w", "bn_b", "ln_w", "ln_b")
+
+
+def optimizer_hyperparams(name: str, kind: str, base_lr: float, weight_decay: float, weight_decay_norm: float = 0.0,
+                          weight_decay_embed: float = 0.0, backbone_multiplier: float = 0.1, decoder_multiplier: float = 1.0,
+                          head_multiplier: float = 1.0):
+    """(lr, weight_decay) of one parameter exactly as get_optimizer_params assigns them (focoos/trainer/solver/build.py:39-101):
+    lr x backbone_multiplier for modules under "backbone", x decoder_multiplier under "pixel_decoder" (the backbone lives INSIDE
+    pixel_decoder, so it gets both), x head_multiplier under "head" unless the module name contains "classifier"; weight decay
+    = weight_decay_norm for parameters of normalisation MODULES (BatchNorm / LayerNorm - not for every 1-D tensor: Linear and conv
+    biases keep the full decay), weight_decay_embed for nn.Embedding weights.  ``kind`` is the parameter's kind in
+    focoos_amd.state_spec (bn_w, ln_b, emb, lin_b, ...), which encodes the owning module's type."""
+    module_name = name.rsplit(".", 1)[0] if "." in name else ""
+    lr, wd = base_lr, weight_decay
+    if "backbone" in module_name:
+        lr *= backbone_multiplier
+        if backbone_multiplier == 0:
+            wd = 0.0
+    if "pixel_decoder" in module_name:
+        lr *= decoder_multiplier
+        if backbone_multiplier == 0:   # (sic) the reference tests backbone_multiplier here as well
+            wd = 0.0
+    if "head" in module_name and "classifier" not in module_name:
+        lr *= head_multiplier
+        if head_multiplier == 0:
+            wd = 0.0
+    if kind in _NORM_KINDS:
+        wd = weight_decay_norm
+    if kind == "emb" or "pos_embed" in name.rsplit(".", 1)[-1]:
+        wd = weight_decay_embed
+    return lr, wd

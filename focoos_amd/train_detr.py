@@ -278,6 +278,7 @@ class FAIDetrTrainable(nn.Module):
         if not torch.cuda.is_available():
             raise _lib.FocoosAmdError("focoos_amd needs a ROCm GPU (gfx950); no CPU fallback exists")
         lib = _lib.load()
+        self.config = dict(config)
         nc = int(config["num_classes"])
         self.pixel_decoder = HybridEncoder(lib, ffn=int(config.get("pixel_decoder_dim_feedforward", 1024)),
                                            n_enc=int(config.get("pixel_decoder_num_encoder_layers", 1)))
@@ -303,12 +304,12 @@ class TrainStep:
     backward on the HIP autograd graph, data-parallel gradient averaging (RCCL all-reduce of one flat fp32 buffer in 64 MiB
     buckets), global-norm clipping + AdamW in one fused kernel.  Parameters and their gradients live in the optimizer's flat
     buffers (the gradient kernels accumulate straight into the flat gradient views); per-parameter lr / weight decay follow
-    build_optimizer (solver/build.py:104-138: backbone lr x0.1, no decay on norms / biases).
+    build_optimizer (solver/build.py:39-138: backbone lr x0.1, weight_decay_norm on the parameters of normalisation modules).
     The step is launched eagerly (~5 800 launches, host-bound at ~75 ms): capturing forward+backward in a hipGraph through
     torch.cuda.make_graphed_callables was tried and dead-locked inside the capture on this stack, so it is not used."""
 
     def __init__(self, model: FAIDetrTrainable, lr: float = 1e-4, backbone_multiplier: float = 0.1, weight_decay: float = 1e-4,
-                 max_grad_norm: float = 0.1, ema_decay: Optional[float] = None, ema_warmups: int = 2000, scheduler: Optional[str] = None,
+                 weight_decay_norm: float = 0.0, weight_decay_embed: float = 0.0, max_grad_norm: float = 0.1, ema_decay: Optional[float] = None, ema_warmups: int = 2000, scheduler: Optional[str] = None,
                  max_iters: int = 0, scheduler_extra: Optional[Dict] = None):
         from . import train_nn
         from .train import BucketedGradAllReduce, FlatAdamW
@@ -316,10 +317,15 @@ class TrainStep:
         self.model, self._nn = model, train_nn
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         dev = named[0][1].device
+        from .state_spec import state_spec
+        from .train_data import optimizer_hyperparams
+
+        kinds = state_spec(model.config, "fai_detr")
         spec = []
-        for n, p in named:
-            no_decay = p.dim() == 1
-            spec.append((n, tuple(p.shape), lr * (backbone_multiplier if ".backbone." in n else 1.0), 0.0 if no_decay else weight_decay))
+        for n, p in named:   # per-parameter lr / weight decay exactly as get_optimizer_params (solver/build.py:39-101; pinned in tests/test_train_data_cpu.py)
+            plr, pwd = optimizer_hyperparams(n, kinds[n][1], lr, weight_decay, weight_decay_norm, weight_decay_embed, backbone_multiplier)
+            spec.append((n, tuple(p.shape), plr, pwd))
+        self.spec = spec
         self.opt = FlatAdamW(spec, dev, max_grad_norm=max_grad_norm)
         with torch.no_grad():
             for n, p in named:

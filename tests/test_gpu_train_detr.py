@@ -128,3 +128,41 @@ def test_syncbn_two_ranks_match_global_batch():
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     assert "SYNCBN features" in r.stdout
+
+
+def test_train_step_optimizer_schedule_and_ema():
+    """TrainStep end to end on a small batch: parameters move, the per-parameter (lr, weight decay) table follows the reference's
+    get_optimizer_params rule (biases keep their decay, norm parameters do not), the learning-rate schedule rescales the device
+    table, the EMA tracks the flat parameter buffer with the reference's warm-up decay."""
+    from focoos_amd.train_data import lr_factor
+    from focoos_amd.train_detr import FAIDetrTrainable, TrainStep
+
+    cfg = ModelRegistry.get_model_info("fai-detr-l-coco")["config"]
+    model = FAIDetrTrainable(cfg, norm="BN").to(DEV)
+    model.load_state_dict(synth_state_dict(cfg, 5), strict=True)
+    extra = dict(warmup_factor=0.1, warmup_iters=4, warmup_method="linear", power=0.9)
+    ts = TrainStep(model, lr=1e-3, weight_decay=0.01, ema_decay=0.99, ema_warmups=3, scheduler="POLY", max_iters=10, scheduler_extra=extra)
+    names = [n for n, _, _, _ in ts.opt.spec] if hasattr(ts.opt, "spec") else None
+    imgs = torch.from_numpy(np.stack([synth_image_structured(90 + i, 128, 160) for i in range(2)])).to(DEV)
+    labels, boxes = T.synth_targets(3, 2, 80, counts=(3, 5))
+    targets = [DETRTargets(labels=l.to(DEV), boxes=b.to(DEV)) for l, b in zip(labels, boxes)]
+    p0 = ts.opt.flat_p.clone()
+    base = ts._base_lrs.clone()
+    losses = []
+    for it in range(3):
+        out = ts.step(imgs, targets)
+        torch.cuda.synchronize()
+        losses.append(float(sum(v.detach().float() for v in out.values())))
+        f = lr_factor("POLY", it, 10, **extra)
+        assert torch.allclose(ts.opt.chunk_lr, base * f, rtol=1e-6)
+    assert all(np.isfinite(losses)) and not torch.equal(ts.opt.flat_p, p0)
+    # hyper-parameter table: a Linear bias decays, a LayerNorm / BatchNorm parameter does not, the backbone runs at lr x 0.1
+    hyper = {n: (lr_, wd_) for (n, _, lr_, wd_) in ts.spec}
+    assert hyper["head.predictor.enc_output.0.bias"] == (1e-3, 0.01)
+    assert hyper["head.predictor.enc_output.1.weight"] == (1e-3, 0.0)
+    assert hyper["pixel_decoder.backbone.res_layers.0.blocks.0.branch2a.norm.weight"] == (pytest.approx(1e-4), 0.0)
+    assert hyper["pixel_decoder.backbone.res_layers.0.blocks.0.branch2a.conv.weight"] == (pytest.approx(1e-4), 0.01)
+    # EMA after 3 updates with warm-up decay d_t = 0.99 * (1 - exp(-t / 3)) lies between the start and the current parameters
+    assert ts.ema.updates == 3
+    d_ema, d_now = (ts.ema.flat - p0).norm(), (ts.opt.flat_p - p0).norm()
+    assert 0 < float(d_ema) < float(d_now)

@@ -166,3 +166,51 @@ def test_lr_factor_matches_reference_schedulers():
             assert got[0] == pytest.approx(1e-4 * f, rel=1e-12, abs=1e-18) and got[1] == pytest.approx(1e-5 * f, rel=1e-12, abs=1e-18), (name, it)
             opt.step()
             sch.step()
+
+
+@pytest.mark.parametrize("model_name,family", [("fai-detr-l-coco", "fai_detr"), ("fai-mf-l-coco-ins", "fai_mf"), ("bisenetformer-l-ade", "bisenetformer")])
+def test_optimizer_hyperparams_match_reference_param_groups(model_name, family):
+    """Per-parameter (lr, weight_decay) vs the reference's get_optimizer_params on the reference model itself - in particular
+    that only parameters of normalisation MODULES lose their weight decay (biases of Linear / conv layers keep it)."""
+    from oracle import ref_import
+
+    if not ref_import.reference_available():
+        pytest.skip("reference tree not mounted")
+    ref_import.install()
+    import importlib.util
+    import os
+    import sys
+    import types
+
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.state_spec import state_spec
+    from focoos_amd.train_data import optimizer_hyperparams
+
+    cfg = ModelRegistry.get_model_info(model_name)["config"]
+    build = {"fai_detr": ref_import.build_reference_detr, "fai_mf": ref_import.build_reference_mf, "bisenetformer": ref_import.build_reference_bf}[family]
+    rc = {k: v for k, v in cfg.items() if k != "resolution"} if family == "bisenetformer" else cfg
+    model = build(rc)[0]
+    # solver/build.py imports lr_scheduler (fine) and the ConvNext layer norm; load it standalone
+    src = open(os.path.join(ref_import.REFERENCE_ROOT, "focoos/trainer/solver/build.py")).read()
+    mod = types.ModuleType("_ref_solver_build")
+    mod.__package__ = "focoos.trainer.solver"
+    sys.modules.setdefault("focoos.trainer", types.ModuleType("focoos.trainer")).__path__ = []
+    pkg = sys.modules.setdefault("focoos.trainer.solver", types.ModuleType("focoos.trainer.solver"))
+    pkg.__path__ = [os.path.join(ref_import.REFERENCE_ROOT, "focoos/trainer/solver")]
+    try:
+        exec(compile(src, "build.py", "exec"), mod.__dict__)
+    finally:
+        for k in ("focoos.trainer", "focoos.trainer.solver", "focoos.trainer.solver.lr_scheduler"):
+            sys.modules.pop(k, None)
+    groups = mod.get_optimizer_params(model, base_lr=1e-4, weight_decay=0.02, weight_decay_norm=0.0, weight_decay_embed=0.005,
+                                      backbone_multiplier=0.1, decoder_multiplier=0.5, head_multiplier=2.0)
+    by_id = {id(g["params"][0]): (g["lr"], g["weight_decay"]) for g in groups}
+    spec = state_spec(cfg, family)
+    checked = 0
+    for name, p in model.named_parameters():
+        if id(p) not in by_id:
+            continue
+        lr, wd = optimizer_hyperparams(name, spec[name][1], 1e-4, 0.02, 0.0, 0.005, 0.1, 0.5, 2.0)
+        assert (lr, wd) == pytest.approx(by_id[id(p)], rel=1e-12), (name, spec[name][1], (lr, wd), by_id[id(p)])
+        checked += 1
+    assert checked == len(groups) and checked > 300
