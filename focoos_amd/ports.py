@@ -73,6 +73,14 @@ BisenetFormerTargets = MaskFormerTargets
 
 
 @dataclass
+class DynamicAxes:
+    """focoos/ports.py:1357-1363 - dynamic axes for model export."""
+    input_names: List[str]
+    output_names: List[str]
+    dynamic_axes: dict
+
+
+@dataclass
 class DETRTargets:
     labels: torch.Tensor
     boxes: torch.Tensor

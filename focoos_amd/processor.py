@@ -20,7 +20,7 @@ import torch
 
 from . import _lib
 from ._lib import check
-from .ports import DETRModelOutput, FocoosDet, FocoosDetections, MaskFormerModelOutput  # noqa: F401
+from .ports import DETRModelOutput, DynamicAxes, FocoosDet, FocoosDetections, MaskFormerModelOutput  # noqa: F401
 
 try:  # PIL is optional
     from PIL import Image
@@ -130,6 +130,28 @@ class DETRProcessor:
                                       labels.data_ptr(), queries.data_ptr(), obox.data_ptr(), count.data_ptr(), stream), "fx_detr_postprocess")
         return self.pack_detections(val, labels, obox, count, class_names)
 
+    def _device(self) -> torch.device:
+        if not torch.cuda.is_available():
+            raise _lib.FocoosAmdError("focoos_amd needs a ROCm GPU (gfx950); no CPU fallback exists")
+        return torch.device("cuda", torch.cuda.current_device())
+
+    def export_postprocess(self, output, inputs: ImageInput, class_names: Sequence[str] = (), top_k: Optional[int] = None,
+                           threshold: float = 0.5) -> List[FocoosDetections]:
+        """fai_detr/processor.py:219-240: raw runtime outputs ``[boxes, logits]`` (tensors or ndarrays, any device) -> detections."""
+        boxes, logits = output[0], output[1]
+        if isinstance(boxes, np.ndarray):
+            boxes = torch.from_numpy(boxes)
+        if isinstance(logits, np.ndarray):
+            logits = torch.from_numpy(logits)
+        dev = self._device()
+        model_output = DETRModelOutput(boxes=boxes.to(dev, torch.float32), logits=logits.to(dev, torch.float32), loss=None)
+        return self.postprocess(model_output, inputs, class_names, 300 if top_k is None else top_k, threshold)
+
+    def get_dynamic_axes(self) -> DynamicAxes:
+        """fai_detr/processor.py:242-251."""
+        return DynamicAxes(input_names=["images"], output_names=["boxes", "logits"],
+                           dynamic_axes={"images": {0: "batch", 2: "height", 3: "width"}, "boxes": {0: "batch"}, "logits": {0: "batch"}})
+
     @staticmethod
     def pack_detections(scores, labels, boxes, count, class_names: Sequence[str] = ()) -> List[FocoosDetections]:
         """One D2H copy of the packed device results, then Python object creation (processor.py:199-217)."""
@@ -179,6 +201,7 @@ class MaskFormerProcessor(DETRProcessor):
     of the batch gets the batch-1 behaviour."""
 
     _postprocessing_types = ("instance",)
+    _export_output_names = ("masks", "logits")
 
     def __init__(self, config: dict, image_size=None):
         super().__init__(config, None)
@@ -236,6 +259,22 @@ class MaskFormerProcessor(DETRProcessor):
                                     res.det_area.data_ptr(), res.mask_words.data_ptr(), stream), "fx_mf_postprocess")
         return self.pack_detections(res, class_names)
 
+    def export_postprocess(self, output, inputs: ImageInput, class_names: Sequence[str] = (), threshold: Optional[float] = None,
+                           **kwargs) -> List[FocoosDetections]:
+        """fai_mf/processor.py:308-336 (== bisenetformer/processor.py:312-339): raw runtime outputs ``[masks, logits]`` -> detections."""
+        masks, logits = output[0], output[1]
+        if isinstance(logits, np.ndarray):
+            logits = torch.from_numpy(logits)
+        if isinstance(masks, np.ndarray):
+            masks = torch.from_numpy(masks)
+        dev = self._device()
+        model_output = MaskFormerModelOutput(logits=logits.to(dev, torch.float32), masks=masks.to(dev, torch.float32), loss=None)
+        return self.postprocess(model_output, inputs, class_names, threshold=threshold, **kwargs)
+
+    def get_dynamic_axes(self) -> DynamicAxes:
+        """fai_mf/processor.py:338-345; the BiSeNetFormer processor lists its outputs as ["logits", "masks"] (bisenetformer/processor.py:302-310)."""
+        return DynamicAxes(input_names=["images"], output_names=list(self._export_output_names), dynamic_axes={"images": {0: "batch", 2: "height", 3: "width"}})
+
     @staticmethod
     def unpack_masks(words: torch.Tensor, H: int, W: int) -> np.ndarray:
         """int32 [n, H, W/32] bit-packed -> bool [n, H, W]."""
@@ -268,6 +307,7 @@ class BisenetFormerProcessor(MaskFormerProcessor):
     ``eval_postprocess`` (semantic_inference einsum, :95-101, 134-157) belongs to the evaluator and is not mirrored."""
 
     _postprocessing_types = ("semantic", "instance")
+    _export_output_names = ("logits", "masks")
 
 
 class _MfDeviceResults:

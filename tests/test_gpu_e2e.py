@@ -129,6 +129,20 @@ def test_reference_input_contract_nchw_float(setup):
     assert torch.equal(a.logits, b.logits)
 
 
+def test_processor_postprocess_and_export_postprocess_agree(setup):
+    """Processor.postprocess on the model output and Processor.export_postprocess on the raw [boxes, logits] arrays an exported
+    runtime would return (numpy, host memory; fai_detr/processor.py:219-240) give the same detections."""
+    g, cfg, sd, model, images, x_u8, *_ = setup
+    fm = ModelManager.get("fai-detr-l-obj365", device=DEV, seed=int(g["seed"]))
+    out = fm.model.forward(x_u8, use_graph=False)
+    torch.cuda.synchronize()
+    a = fm.processor.postprocess(out, list(images), threshold=0.3)
+    b = fm.processor.export_postprocess([out.boxes.cpu().numpy(), out.logits.cpu().numpy()], list(images), threshold=0.3)
+    assert len(a) == len(b) == len(images) and sum(len(d) for d in a) > 0
+    for da, db in zip(a, b):
+        assert [(d.cls_id, d.bbox, d.conf) for d in da.detections] == [(d.cls_id, d.bbox, d.conf) for d in db.detections]
+
+
 def test_resize_case_against_reference_golden():
     g = load_golden("detr_l_coco_resize.npz")
     fm = ModelManager.get("fai-detr-l-coco", device=DEV, seed=int(g["seed"]))

@@ -310,6 +310,8 @@ def test_mf_model_manager_and_processor_paths(setup):
         assert len(a) == len(b)
         for da, db in zip(a.detections, b.detections):
             assert da.cls_id == db.cls_id and da.bbox == db.bbox and abs(da.conf - db.conf) < 1e-5 and da.mask == db.mask
+    dets3 = fm.processor.export_postprocess([out.masks.cpu().numpy(), out.logits.cpu().numpy()], images, class_names=fm.model_info.classes)
+    assert [[(d.cls_id, d.bbox, d.mask) for d in x.detections] for x in dets3] == [[(d.cls_id, d.bbox, d.mask) for d in x.detections] for x in dets2]
     d0 = dets[0].detections[0]
     png = np.array(Image.open(io.BytesIO(base64.b64decode(d0.mask))))
     x0, y0, x1, y1 = d0.bbox

@@ -123,3 +123,27 @@ def test_bench_two_process_gloo_dry_run():
     assert len(lines) == 1, r.stdout
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 5 and j["scaling"] == "weak" and j["value"] > 0
+
+
+def test_processor_dynamic_axes_match_reference():
+    """Processor.get_dynamic_axes of the three mirrors vs the reference processors (fai_detr/processor.py:242-251,
+    fai_mf/processor.py:338-345, bisenetformer/processor.py:302-310)."""
+    from focoos_amd.processor import BisenetFormerProcessor, DETRProcessor, MaskFormerProcessor
+    from focoos_amd.registry import ModelRegistry
+
+    mine = {"fai-detr-l-coco": DETRProcessor(ModelRegistry.get_model_info("fai-detr-l-coco")["config"], 640),
+            "fai-mf-l-coco-ins": MaskFormerProcessor(ModelRegistry.get_model_info("fai-mf-l-coco-ins")["config"]),
+            "bisenetformer-l-ade": BisenetFormerProcessor(ModelRegistry.get_model_info("bisenetformer-l-ade")["config"])}
+    assert mine["fai-detr-l-coco"].get_dynamic_axes().output_names == ["boxes", "logits"]
+    assert mine["fai-mf-l-coco-ins"].get_dynamic_axes().dynamic_axes == {"images": {0: "batch", 2: "height", 3: "width"}}
+    from oracle import ref_import
+
+    if not ref_import.reference_available():
+        return
+    builders = {"fai-detr-l-coco": ref_import.build_reference_detr, "fai-mf-l-coco-ins": ref_import.build_reference_mf, "bisenetformer-l-ade": ref_import.build_reference_bf}
+    for name, proc in mine.items():
+        cfg = ModelRegistry.get_model_info(name)["config"]
+        rc = {k: v for k, v in cfg.items() if k != "resolution"} if name.startswith("bisenet") else cfg
+        ref = builders[name](rc)[1].get_dynamic_axes()
+        got = proc.get_dynamic_axes()
+        assert (got.input_names, got.output_names, got.dynamic_axes) == (ref.input_names, ref.output_names, ref.dynamic_axes), name
