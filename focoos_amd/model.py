@@ -186,18 +186,32 @@ class BisenetFormer(FAIMaskFormer):
     __call__ = forward
 
 
+class ProcessorManager:
+    """focoos/processor/processor_manager.py:8-46 — family -> processor class registry (seam B1) with lazy loaders."""
+
+    _PROCESSOR_MAPPING: Dict[str, Callable[[], Type]] = {
+        "fai_detr": lambda: DETRProcessor, "fai_mf": lambda: MaskFormerProcessor, "bisenetformer": lambda: BisenetFormerProcessor}
+
+    @classmethod
+    def register_processor(cls, model_family, processor_loader: Callable[[], Type]):
+        cls._PROCESSOR_MAPPING[getattr(model_family, "value", model_family)] = processor_loader
+
+    @classmethod
+    def get_processor(cls, model_family, model_config: dict, image_size=None):
+        fam = getattr(model_family, "value", model_family)
+        if fam not in cls._PROCESSOR_MAPPING:
+            raise ValueError(f"Processor for {model_family} not supported")
+        return cls._PROCESSOR_MAPPING[fam]()(config=model_config, image_size=image_size)
+
+
 class FocoosModel:
     """focoos/models/focoos_model.py:88-147 — model + processor + model_info."""
 
     def __init__(self, model: _EngineModel, model_info: ModelInfo):
         self.model = model
         self.model_info = model_info
-        if model.family == "fai_mf":  # MaskFormerProcessor ignores image_size (fai_mf/processor.py:96: no resize)
-            self.processor = MaskFormerProcessor(model_info.config).eval()
-        elif model.family == "bisenetformer":
-            self.processor = BisenetFormerProcessor(model_info.config).eval()
-        else:
-            self.processor = DETRProcessor(model_info.config, image_size=model_info.im_size).eval()
+        # the mask families' processors ignore image_size (fai_mf/processor.py:96: no resize)
+        self.processor = ProcessorManager.get_processor(model.family, model_info.config, image_size=model_info.im_size).eval()
         self.model.eval()
 
     @property

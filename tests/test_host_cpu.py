@@ -147,3 +147,28 @@ def test_processor_dynamic_axes_match_reference():
         ref = builders[name](rc)[1].get_dynamic_axes()
         got = proc.get_dynamic_axes()
         assert (got.input_names, got.output_names, got.dynamic_axes) == (ref.input_names, ref.output_names, ref.dynamic_axes), name
+
+
+def test_processor_manager_registry():
+    """ProcessorManager (seam B1, processor/processor_manager.py:8-46): lazy family -> processor-class loaders, re-registration wins."""
+    from focoos_amd.model import ProcessorManager
+    from focoos_amd.processor import BisenetFormerProcessor, DETRProcessor, MaskFormerProcessor
+    from focoos_amd.registry import ModelRegistry
+
+    for name, fam, cls in (("fai-detr-l-coco", "fai_detr", DETRProcessor), ("fai-mf-l-coco-ins", "fai_mf", MaskFormerProcessor),
+                           ("bisenetformer-l-ade", "bisenetformer", BisenetFormerProcessor)):
+        info = ModelRegistry.get_model_info(name)
+        p = ProcessorManager.get_processor(fam, info["config"], image_size=info["im_size"])
+        assert type(p) is cls
+    with pytest.raises(ValueError):
+        ProcessorManager.get_processor("unknown_family", {})
+
+    class Custom(DETRProcessor):
+        pass
+
+    saved = ProcessorManager._PROCESSOR_MAPPING["fai_detr"]
+    try:
+        ProcessorManager.register_processor("fai_detr", lambda: Custom)
+        assert type(ProcessorManager.get_processor("fai_detr", ModelRegistry.get_model_info("fai-detr-l-coco")["config"], 640)) is Custom
+    finally:
+        ProcessorManager._PROCESSOR_MAPPING["fai_detr"] = saved
