@@ -67,13 +67,18 @@ def dist_setup(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    # the scale contract: `--gpus N` IS the number of ranks, whichever launcher started them (torchrun or our own spawn)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: WORLD_SIZE={world} but --gpus {args.gpus} (one rank per GPU; pass the same N to both)")
+    if world > 1 and not dist.is_initialized():   # torchrun path; focoos_amd.launch initialises the group itself
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         backend = "gloo" if args.dry_run else "nccl"
         if not args.dry_run:
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    if world > 1:
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
     return world, rank, local
 
 
@@ -243,8 +248,26 @@ def train_main(args, world, rank, local):
         dist.destroy_process_group()
 
 
+def _spawned_rank(argv):
+    """Entry of a rank started by focoos_amd.launch (process group already initialised, RANK/LOCAL_RANK/WORLD_SIZE exported)."""
+    sys.argv = [os.path.join(ROOT, "bench.py")] + list(argv)
+    run(parse())
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: spawn the N ranks here, one process per GPU, like the reference's launch()
+        # (focoos/utils/distributed/dist.py:38-95) does for FocoosModel.train(num_gpus=N).  Under torchrun WORLD_SIZE is set
+        # and each rank comes straight through run().
+        from focoos_amd.launch import launch
+
+        launch(_spawned_rank, args.gpus, dist_url="auto", args=(sys.argv[1:],), backend="gloo" if args.dry_run else "nccl")
+        return
+    run(args)
+
+
+def run(args):
     world, rank, local = dist_setup(args)
     if args.dry_run:
         # plumbing only: same sharding / barrier / max-over-ranks / JSON code path with a fake 1 ms step
@@ -269,7 +292,6 @@ def main():
     from focoos_amd.registry import ModelRegistry
     from focoos_amd.synth import synth_image
 
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     dev = f"cuda:{local}"
     cfg = ModelRegistry.get_model_info(args.model)["config"]
     B = args.batch

@@ -125,6 +125,45 @@ def test_bench_two_process_gloo_dry_run():
     assert j["n_gpus"] == 2 and j["steps"] == 5 and j["scaling"] == "weak" and j["value"] > 0
 
 
+def test_bench_spawns_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT torchrun starts the two ranks itself (focoos_amd.launch, the mirror of the reference's
+    launch(), utils/distributed/dist.py:38-95) and reports n_gpus 2; a mismatch between WORLD_SIZE and --gpus is refused."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    for extra in ([], ["--train"]):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1", "--dry-run"] + extra,
+                           capture_output=True, text=True, timeout=240, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, r.stdout
+        j = json.loads(lines[0])
+        assert j["n_gpus"] == 2 and j["steps"] == 4 and j["value"] > 0
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-run"], capture_output=True, text=True, timeout=120,
+                         cwd=ROOT, env=dict(env, WORLD_SIZE="2", RANK="0"))
+    assert bad.returncode != 0 and "WORLD_SIZE=2 but --gpus 1" in (bad.stderr + bad.stdout)
+
+
+def _launch_probe(path):
+    import torch.distributed as dist
+
+    t = torch.tensor([float(dist.get_rank() + 1)])
+    dist.all_reduce(t)
+    with open(f"{path}.{dist.get_rank()}", "w") as f:
+        f.write(f"{os.environ['RANK']} {os.environ['LOCAL_RANK']} {os.environ['WORLD_SIZE']} {dist.get_world_size()} {t.item()}")
+
+
+def test_launch_mirror(tmp_path):
+    """focoos_amd.launch.launch: world 1 runs in-process; world 2 = two spawned ranks with an initialised group and the torchrun env."""
+    from focoos_amd.launch import launch
+
+    seen = []
+    assert launch(lambda a: seen.append(a) or 7, 1, args=(3,)) == 7 and seen == [3]
+    launch(_launch_probe, 2, dist_url="auto", args=(str(tmp_path / "p"),), backend="gloo")
+    got = sorted(open(f"{tmp_path}/p.{r}").read() for r in range(2))
+    assert got == ["0 0 2 2 3.0", "1 1 2 2 3.0"]
+    with pytest.raises(ValueError):
+        launch(_launch_probe, 2, num_machines=2, dist_url="auto")
+
+
 def test_processor_dynamic_axes_match_reference():
     """Processor.get_dynamic_axes of the three mirrors vs the reference processors (fai_detr/processor.py:242-251,
     fai_mf/processor.py:338-345, bisenetformer/processor.py:302-310)."""
