@@ -28,6 +28,16 @@ class FxConvDesc(C.Structure):
     ]
 
 
+class FxPwChainDesc(C.Structure):
+    _fields_ = [
+        ("x1", C.c_void_p), ("x2", C.c_void_p), ("residual", C.c_void_p), ("w1", C.c_void_p), ("bias1", C.c_void_p), ("y1", C.c_void_p),
+        ("w2", C.c_void_p), ("bias2", C.c_void_p), ("y2", C.c_void_p),
+        ("M", C.c_int32), ("K1a", C.c_int32), ("K1b", C.c_int32), ("N1", C.c_int32), ("N2", C.c_int32),
+        ("ldx1", C.c_int32), ("ldx2", C.c_int32), ("ldr", C.c_int32), ("ldy1", C.c_int32), ("ldy2", C.c_int32),
+        ("act1", C.c_int32), ("act2", C.c_int32),
+    ]
+
+
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 
 # name -> argtypes (every function returns int unless noted); mirrors include/focoos_amd.h
@@ -35,6 +45,8 @@ SIGNATURES = {
     "fx_abi_version": [],
     "fx_device_info": [_i, C.POINTER(C.c_int), C.c_char_p, _i],
     "fx_conv2d_nhwc_bf16": [C.POINTER(FxConvDesc), _vp],
+    "fx_pw_chain_supported": [_i, _i, _i, _i],
+    "fx_pw_chain_bf16": [C.POINTER(FxPwChainDesc), _vp],
     "fx_stem_conv3x3s2": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "fx_resize_bilinear_u8": [_vp, _i, _i, _vp, _i, _i, _vp],
     "fx_maxpool3x3s2_nhwc_bf16": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],

@@ -28,7 +28,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import FX_ACT, FxConvDesc, check
+from ._lib import FX_ACT, FxConvDesc, FxPwChainDesc, check
 from .state_spec import RESNET_BLOCKS
 
 BN_EPS = 1e-5
@@ -110,6 +110,14 @@ class _EngineBase:
             b[:N] = bias
         return PackedConv(self._dev(w, torch.bfloat16), self._dev(b), N, Cc, KH, KW)
 
+    def _pack_frag(self, W2: torch.Tensor) -> torch.Tensor:
+        """[N, K] weights in MFMA fragment order [N/32][K/16][lane][8] (include/focoos_amd.h, fx_pw_chain_desc): lane l of
+        fragment (nb, ks) holds W[nb*32 + l%32][ks*16 + (l//32)*8 : +8] - one contiguous 1 KiB read per wave and fragment."""
+        N, K = W2.shape
+        assert N % 32 == 0 and K % 16 == 0, (N, K)
+        w = W2.float().reshape(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()  # [nb][ks][half][row][8]
+        return self._dev(w.reshape(N // 32, K // 16, 64, 8), torch.bfloat16)
+
     def _pack_linear(self, W: torch.Tensor, b: Optional[torch.Tensor]) -> PackedConv:
         return self._pack(W.float().view(W.shape[0], W.shape[1], 1, 1), None if b is None else b.float())
 
@@ -132,13 +140,27 @@ class _EngineBase:
         self.px_mean, self.px_inv_std = self._dev(mean), self._dev(1.0 / std)
         cbn(f"{bb}.conv1.conv1_2")
         cbn(f"{bb}.conv1.conv1_3")
+        # fragment-ordered copies of the 1x1 layers around the residual add for fx_pw_chain_bf16 (branch2c [+ shortcut conv as a
+        # second K segment] -> next block's branch2a in one launch): chain_c[(si,bi)] = (W1, bias1, K1a, K1b, N1), chain_a = (W2, bias2, N2)
+        self.chain_c: Dict[Tuple[int, int], Tuple] = {}
+        self.chain_a: Dict[Tuple[int, int], Tuple] = {}
         for si, n in enumerate(RESNET_BLOCKS[self.depth]):
             for bi in range(n):
                 p = f"{bb}.res_layers.{si}.blocks.{bi}"
                 for br in ("branch2a", "branch2b", "branch2c"):
                     cbn(f"{p}.{br}")
+                wa, ba = _fold_bn(sd, f"{p}.branch2a.conv.weight", f"{p}.branch2a.norm")
+                wc, bc = _fold_bn(sd, f"{p}.branch2c.conv.weight", f"{p}.branch2c.norm")
+                w1, b1, k1b = wc[:, :, 0, 0], bc, 0
                 if bi == 0:
-                    cbn(f"{p}.short" if si == 0 else f"{p}.short.conv")
+                    sk = f"{p}.short" if si == 0 else f"{p}.short.conv"
+                    cbn(sk)
+                    ws, bs = _fold_bn(sd, f"{sk}.conv.weight", f"{sk}.norm")
+                    w1, b1, k1b = torch.cat([w1, ws[:, :, 0, 0]], 1), bc + bs, ws.shape[1]
+                if w1.shape[0] % 256 == 0 and wc.shape[1] % 64 == 0 and k1b % 64 == 0:
+                    self.chain_c[(si, bi)] = (self._pack_frag(w1), self._dev(b1), wc.shape[1], k1b, w1.shape[0])
+                if wa.shape[0] % 64 == 0 and wa.shape[1] % 256 == 0:
+                    self.chain_a[(si, bi)] = (self._pack_frag(wa[:, :, 0, 0]), self._dev(ba), wa.shape[0])
 
 
 class DetrEngine(_EngineBase):
@@ -423,6 +445,32 @@ class _PlanBase:
         self._op(self.lib.fx_conv2d_nhwc_bf16, C.byref(d))
         return out
 
+    def pw_chain(self, x1: NT, x2: Optional[NT], residual: Optional[NT], cc: Tuple, ca: Optional[Tuple], name1: str, name2: Optional[str]):
+        """y1 = relu([x1 | x2] W1^T + b1 (+ residual)), y2 = relu(y1 W2^T + b2) in one launch (include/focoos_amd.h, fx_pw_chain_desc):
+        BottleNeck branch2c (+ shortcut conv) + add + ReLU and the next block's branch2a + ReLU (resnet.py:107-121)."""
+        w1, b1, k1a, k1b, n1 = cc
+        assert x1.C == k1a and (x2 is None) == (k1b == 0) and (x2 is None or x2.C == k1b), (name1, x1.C, k1a, k1b)
+        M = x1.rows
+        y1 = self._new(name1, x1.B, x1.H, x1.W, n1)
+        d = FxPwChainDesc()
+        d.x1, d.ldx1, d.K1a = x1.ptr, x1.ld, k1a
+        d.x2, d.ldx2, d.K1b = (x2.ptr, x2.ld, k1b) if x2 is not None else (None, 0, 0)
+        d.residual, d.ldr = (residual.ptr, residual.ld) if residual is not None else (None, 0)
+        d.w1, d.bias1, d.y1, d.ldy1, d.N1, d.M = w1.data_ptr(), b1.data_ptr(), y1.ptr, y1.ld, n1, M
+        d.act1 = d.act2 = FX_ACT["relu"]
+        y2, n2 = None, 0
+        if ca is not None:
+            w2, b2, n2 = ca
+            y2 = self._new(name2, x1.B, x1.H, x1.W, n2)
+            d.w2, d.bias2, d.y2, d.ldy2 = w2.data_ptr(), b2.data_ptr(), y2.ptr, y2.ld
+        d.N2 = n2
+        self.keep.append(d)
+        self.meta[len(self.ops)] = {"kind": "conv", "variant": f"pw_chain<{k1a},{k1b},{n2}>", "flops": 2.0 * M * n1 * (k1a + k1b + n2),
+                                    "name": name1 + ("+" + name2.rsplit("res_layers.", 1)[-1] if name2 else ""), "M": M, "N": n1, "K": k1a + k1b,
+                                    "bytes": 2.0 * M * (k1a + k1b + (n1 if residual is not None else 0) + n1 + n2)}
+        self._op(self.lib.fx_pw_chain_bf16, C.byref(d))
+        return y1, y2
+
     def linear(self, x: NT, pc: PackedConv, **kw) -> NT:
         return self.conv(x.as_rows() if (x.H != 1 or x.W != 1) else x, pc, **kw)
 
@@ -455,61 +503,53 @@ class _PlanBase:
         bb = "pixel_decoder.backbone"
         self.input = self._io("input", (B, H, W, 3), torch.float32 if self.f32_input else torch.uint8)
         self.sizes = self._io("sizes", (B, 2), torch.int32)
-        # Experiment knob (default off): run the HBM-heavy front of the network (stem .. res3, 100-400 MB activations at
-        # bs=32) in batch chunks so that producer->consumer tensors could stay in the 256 MB Infinity Cache between layers.
-        # Measured on MI355X at bs=32: 1/2/4/8 chunks = 2777/2732/2655/2449 img/s - smaller grids cost more than the
-        # cache residency buys, so the full batch is the default.  Chunks write contiguous batch slices of the same buffers.
-        import os
-
-        nchunk = int(os.environ.get("FX_FRONT_CHUNKS", "1"))
-        while nchunk > 1 and (B % nchunk or B // nchunk < 4):
-            nchunk //= 2
-        nchunk = max(nchunk, 1)
+        # (A batch-chunked front of the network - stem .. res3 run chunk by chunk for Infinity-Cache residency - was measured
+        # negative on MI355X at bs=32: 1/2/4/8 chunks = 2777/2732/2655/2449 img/s, and is gone.)
         blocks = RESNET_BLOCKS[e.depth]
         feats = {}
-
-        def bottleneck(x, si, bi):
+        # branch2c (+ shortcut conv) -> next block's branch2a as ONE launch (fx_pw_chain_bf16): the block output is written once
+        # and consumed from LDS; FX_PW_CHAIN=0 restores one launch per layer, FX_PW_CHAIN_MAX_STAGE limits the stages covered.
+        use_chain = int(os.environ.get("FX_PW_CHAIN", "1")) != 0
+        max_stage = int(os.environ.get("FX_PW_CHAIN_MAX_STAGE", "2"))
+        c1 = self._new("conv1_1", B, H // 2, W // 2, 32)
+        self._op(lib.fx_stem_conv3x3s2, self.input.data_ptr(), int(self.f32_input), e.stem_w.data_ptr(), e.stem_b.data_ptr(),
+                 e.px_mean.data_ptr(), e.px_inv_std.data_ptr(), c1.ptr, B, H, W, 32)
+        x = self.conv(c1, P[f"{bb}.conv1.conv1_2"], name="conv1_2", act="relu")
+        x = self.conv(x, P[f"{bb}.conv1.conv1_3"], name="conv1_3", act="relu")
+        mp = self._new("maxpool", B, H // 4, W // 4, 64)
+        self._op(lib.fx_maxpool3x3s2_nhwc_bf16, x.ptr, x.ld, mp.ptr, mp.ld, B, x.H, x.W, 64)
+        x = mp
+        seq = [(si, bi) for si in range(4) for bi in range(blocks[si])]
+        a_next: Optional[NT] = None
+        for idx, (si, bi) in enumerate(seq):
             p = f"{bb}.res_layers.{si}.blocks.{bi}"
             stride = 2 if (bi == 0 and si != 0) else 1
-            a = self.conv(x, P[f"{p}.branch2a"], name=f"{p}.a", act="relu")
+            a = a_next if a_next is not None else self.conv(x, P[f"{p}.branch2a"], name=f"{p}.a", act="relu")
+            a_next = None
             bmid = self.conv(a, P[f"{p}.branch2b"], name=f"{p}.b", stride=stride, act="relu")
+            short_in = None
             if bi == 0:
+                short_in = x
                 if stride == 2:
-                    pooled = self._new(f"{p}.pool", x.B, (x.H + 1) // 2, (x.W + 1) // 2, x.C)
-                    self._op(lib.fx_avgpool2x2_nhwc_bf16, x.ptr, x.ld, pooled.ptr, pooled.ld, x.B, x.H, x.W, x.C)
-                    short = self.conv(pooled, P[f"{p}.short.conv"], name=f"{p}.s")
-                else:
-                    short = self.conv(x, P[f"{p}.short"], name=f"{p}.s")
+                    short_in = self._new(f"{p}.pool", x.B, (x.H + 1) // 2, (x.W + 1) // 2, x.C)
+                    self._op(lib.fx_avgpool2x2_nhwc_bf16, x.ptr, x.ld, short_in.ptr, short_in.ld, x.B, x.H, x.W, x.C)
+            nxt = seq[idx + 1] if idx + 1 < len(seq) else None
+            cc = e.chain_c.get((si, bi)) if (use_chain and si <= max_stage) else None
+            n2 = 0
+            if cc is not None:
+                ca = e.chain_a.get(nxt) if nxt is not None else None
+                if ca is not None and lib.fx_pw_chain_supported(cc[2], cc[3], cc[4], ca[2]) == 1:
+                    n2 = ca[2]
+                elif lib.fx_pw_chain_supported(cc[2], cc[3], cc[4], 0) != 1:
+                    cc = None
+            if cc is not None:
+                nxt_name = f"{bb}.res_layers.{nxt[0]}.blocks.{nxt[1]}.a" if n2 else None
+                x, a_next = self.pw_chain(bmid, short_in, None if bi == 0 else x, cc, e.chain_a[nxt] if n2 else None, f"{p}.c", nxt_name)
             else:
-                short = x
-            return self.conv(bmid, P[f"{p}.branch2c"], name=f"{p}.c", residual=short, act="relu")
-
-        bs = B // nchunk
-        in_img = H * W * 3 * self.input.element_size()
-        for ck in range(nchunk):
-            self._win = (ck * bs, bs) if nchunk > 1 else None
-            c1 = self._new("conv1_1", bs, H // 2, W // 2, 32)
-            self._op(lib.fx_stem_conv3x3s2, self.input.data_ptr() + ck * bs * in_img, int(self.f32_input), e.stem_w.data_ptr(), e.stem_b.data_ptr(),
-                     e.px_mean.data_ptr(), e.px_inv_std.data_ptr(), c1.ptr, bs, H, W, 32)
-            x = self.conv(c1, P[f"{bb}.conv1.conv1_2"], name="conv1_2", act="relu")
-            x = self.conv(x, P[f"{bb}.conv1.conv1_3"], name="conv1_3", act="relu")
-            mp = self._new("maxpool", bs, H // 4, W // 4, 64)
-            self._op(lib.fx_maxpool3x3s2_nhwc_bf16, x.ptr, x.ld, mp.ptr, mp.ld, bs, x.H, x.W, 64)
-            x = mp
-            for si in (0, 1):
-                for bi in range(blocks[si]):
-                    x = bottleneck(x, si, bi)
-                if si == 0 and nchunk == 1:
-                    feats[2] = x
-        self._win = None
-        if nchunk > 1:
-            feats[2] = self.bufs[f"{bb}.res_layers.0.blocks.{blocks[0] - 1}.c"]
-            x = self.bufs[f"{bb}.res_layers.1.blocks.{blocks[1] - 1}.c"]
-        feats[3] = x
-        for si in (2, 3):
-            for bi in range(blocks[si]):
-                x = bottleneck(x, si, bi)
-            feats[si + 2] = x
+                short = x if bi != 0 else self.conv(short_in, P[f"{p}.short" if si == 0 else f"{p}.short.conv"], name=f"{p}.s")
+                x = self.conv(bmid, P[f"{p}.branch2c"], name=f"{p}.c", residual=short, act="relu")
+            if bi == blocks[si] - 1:
+                feats[si + 2] = x
         for k, v in feats.items():
             self.bufs[f"res{k}"] = v
         return feats

@@ -69,6 +69,34 @@ typedef struct fx_conv_desc {
 } fx_conv_desc;
 int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Back-to-back pointwise convolutions around the residual add of the ResNet-vd bottleneck, one launch, the block output
+ * consumed from LDS by the next layer (cross-layer fusion of the HBM-bound 1x1 layers):
+ *   y1[m, :N1] = act1( [x1[m,:K1a] | x2[m,:K1b]] . W1^T + bias1 (+ residual[m,:N1]) )
+ *   y2[m, :N2] = act2( y1[m,:N1] . W2^T + bias2 )                         (N2 = 0: first layer only)
+ * Replaces BottleNeck.forward's  branch2c + short + add + ReLU  (focoos/nn/backbone/resnet.py:107-121; variant-d
+ * shortcut conv :89-100 as the second K segment x2 with W1 = [W_2c | W_short], bias1 = b_2c + b_short, no residual)
+ * followed by the NEXT block's branch2a (+ReLU) (resnet.py:108) - eval BatchNorm folded into W/bias by the host.
+ * m indexes pixels (rows of NHWC tensors, row strides ld* in elements).  W1 / W2 are bf16 in MFMA FRAGMENT order:
+ * Wp[n/32][k/16][lane][8] with Wp[nb][ks][l][i] = W[nb*32 + l%32][ks*16 + (l/32)*8 + i]  (k runs over K1a then K1b);
+ * bias f32 [N1] / [N2].  N1 % 256 == 0; supported (K1a, K1b, N2) combinations: fx_pw_chain_supported(). */
+typedef struct fx_pw_chain_desc {
+  const void* x1;       /* bf16 [M, ldx1] */
+  const void* x2;       /* bf16 [M, ldx2] or NULL (K1b = 0) */
+  const void* residual; /* bf16 [M, ldr] or NULL */
+  const void* w1;       /* bf16 fragment-packed [N1/32][(K1a+K1b)/16][64][8] */
+  const float* bias1;   /* f32 [N1] */
+  void* y1;             /* bf16 [M, ldy1] */
+  const void* w2;       /* bf16 fragment-packed [N2/32][N1/16][64][8] or NULL */
+  const float* bias2;   /* f32 [N2] or NULL */
+  void* y2;             /* bf16 [M, ldy2] or NULL */
+  int32_t M, K1a, K1b, N1, N2;
+  int32_t ldx1, ldx2, ldr, ldy1, ldy2;
+  int32_t act1, act2;   /* FX_ACT_* */
+} fx_pw_chain_desc;
+int fx_pw_chain_supported(int K1a, int K1b, int N1, int N2); /* 1 / 0 (not an error code) */
+int fx_pw_chain_bf16(const fx_pw_chain_desc* d, fx_stream_t stream);
+
 /* Stem: pixel normalisation (x-mean)/std (fai_detr/modelling.py:1349) fused with conv1_1 3x3/s2 +
  * folded BN + ReLU (focoos/nn/backbone/resnet.py:184-196,253).  x is HWC uint8 (in_f32=0) or HWC
  * float32 on the 0..255 scale (in_f32=1, output of fx_resize_bilinear_u8).  w: f32 [3][3][3][32]

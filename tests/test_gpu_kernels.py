@@ -449,3 +449,101 @@ def test_library_exports_and_device(lib):
     cu, arch = C.c_int(0), C.create_string_buffer(64)
     check(lib.fx_device_info(0, C.byref(cu), arch, 64))
     assert arch.value.decode().startswith("gfx950") and cu.value >= 200
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# fx_pw_chain_bf16: branch2c (+ shortcut conv as second K segment) + residual + ReLU -> next branch2a + ReLU in one launch
+def frag_pack(W2):
+    """[N,K] -> MFMA fragment order [N/32][K/16][64][8] (include/focoos_amd.h, fx_pw_chain_desc)."""
+    N, K = W2.shape
+    w = W2.float().reshape(N // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).contiguous()
+    return to_dev(w.reshape(N // 32, K // 16, 64, 8), torch.bfloat16)
+
+
+PW_CHAIN_CASES = [
+    # M, K1a, K1b, N1, N2, residual, act1, pad (extra row stride)
+    (64 * 7, 64, 0, 256, 64, True, "relu", 0),       # res2 mid block
+    (64 * 5 + 37, 64, 0, 256, 64, True, "relu", 8),  # M tail, strided rows
+    (333, 64, 64, 256, 64, False, "relu", 0),        # res2 block 0: shortcut conv as second source
+    (200, 64, 0, 256, 128, True, "relu", 0),         # res2 -> res3 seam
+    (130, 64, 0, 256, 0, True, None, 0),             # first GEMM only, no activation
+    (256, 128, 0, 512, 128, True, "relu", 0),        # res3 mid (two 256-channel groups)
+    (190, 128, 256, 512, 128, False, "relu", 16),    # res3 block 0 (pooled shortcut source)
+    (129, 128, 0, 512, 256, True, "relu", 0),        # res3 -> res4 seam
+    (100, 256, 0, 1024, 256, True, "relu", 0),       # res4 mid (four groups)
+    (70, 256, 512, 1024, 256, False, "relu", 0),     # res4 block 0
+    (64, 256, 0, 1024, 0, True, "relu", 0),
+]
+
+
+@pytest.mark.parametrize("case", PW_CHAIN_CASES)
+def test_pw_chain_matches_two_convs(lib, case):
+    from focoos_amd._lib import FxPwChainDesc
+
+    M, K1a, K1b, N1, N2, has_res, act1, pad = case
+    assert lib.fx_pw_chain_supported(K1a, K1b, N1, N2) == 1
+    g = torch.Generator().manual_seed(M * 7 + K1a + N2)
+    K1 = K1a + K1b
+    # asymmetric, non-separable data: a transposed / row-swapped write shows up as an O(1) error
+    x1 = torch.randn(M, K1a, generator=g) + torch.linspace(-1, 1, M)[:, None]
+    x2 = torch.randn(M, K1b, generator=g) * 0.5 if K1b else None
+    res = torch.randn(M, N1, generator=g) if has_res else None
+    W1 = torch.randn(N1, K1, generator=g) / math.sqrt(K1) + torch.linspace(-0.05, 0.05, N1)[:, None]
+    b1 = torch.randn(N1, generator=g) * 0.3
+    W2 = torch.randn(max(N2, 1), N1, generator=g) / math.sqrt(N1)
+    b2 = torch.randn(max(N2, 1), generator=g) * 0.3
+
+    def strided(t, ld):
+        buf = torch.full((t.shape[0], ld), 7.0, dtype=torch.bfloat16)
+        buf[:, : t.shape[1]] = bf(t)
+        return to_dev(buf)
+
+    x1d = strided(x1, K1a + pad)
+    x2d = strided(x2, K1b + pad) if K1b else None
+    rd = strided(res, N1 + pad) if has_res else None
+    y1d = torch.full((M + 3, N1 + pad), float("nan"), dtype=torch.bfloat16, device=DEV)   # +3 guard rows: nothing may be written past M
+    y2d = torch.full((M + 3, N2 + pad), float("nan"), dtype=torch.bfloat16, device=DEV) if N2 else None
+    w1d, b1d = frag_pack(W1), to_dev(b1)
+    w2d, b2d = (frag_pack(W2), to_dev(b2)) if N2 else (None, None)
+    d = FxPwChainDesc()
+    d.x1, d.ldx1, d.K1a = x1d.data_ptr(), K1a + pad, K1a
+    if K1b:
+        d.x2, d.ldx2, d.K1b = x2d.data_ptr(), K1b + pad, K1b
+    if has_res:
+        d.residual, d.ldr = rd.data_ptr(), N1 + pad
+    d.w1, d.bias1, d.y1, d.ldy1, d.N1, d.M = w1d.data_ptr(), b1d.data_ptr(), y1d.data_ptr(), N1 + pad, N1, M
+    d.act1, d.act2 = FX_ACT[act1], FX_ACT["relu"]
+    if N2:
+        d.w2, d.bias2, d.y2, d.ldy2, d.N2 = w2d.data_ptr(), b2d.data_ptr(), y2d.data_ptr(), N2 + pad, N2
+    check(lib.fx_pw_chain_bf16(C.byref(d), stream()), "pw_chain")
+    torch.cuda.synchronize()
+    # reference: bf16 operands, fp32 accumulation, y1 rounded to bf16 before it feeds the second GEMM
+    X = torch.cat([bf(x1).float()] + ([bf(x2).float()] if K1b else []), 1)
+    r1 = X @ bf(W1).float().T + b1
+    if has_res:
+        r1 = r1 + bf(res).float()
+    if act1 == "relu":
+        r1 = r1.relu()
+    y1 = y1d.float().cpu()
+    assert torch.isnan(y1[M:]).all() and (pad == 0 or torch.isnan(y1[:, N1:]).all()), "wrote outside [M, N1]"
+    got1 = y1[:M, :N1]
+    assert not torch.isnan(got1).any()
+    tol1 = 1e-2 * r1.abs().max().item()
+    assert (got1 - r1).abs().max().item() <= tol1, ((got1 - r1).abs().max().item(), tol1)
+    if N2:
+        r2 = (got1 @ bf(W2).float().T + b2).relu()   # from the kernel's own (bf16) y1: isolates the second GEMM
+        y2 = y2d.float().cpu()
+        assert torch.isnan(y2[M:]).all() and (pad == 0 or torch.isnan(y2[:, N2:]).all())
+        got2 = y2[:M, :N2]
+        assert not torch.isnan(got2).any()
+        tol2 = 1e-2 * r2.abs().max().item()
+        assert (got2 - r2).abs().max().item() <= tol2, ((got2 - r2).abs().max().item(), tol2)
+
+
+def test_pw_chain_rejects_bad_arguments(lib):
+    from focoos_amd._lib import FxPwChainDesc
+
+    assert lib.fx_pw_chain_supported(64, 0, 256, 64) == 1 and lib.fx_pw_chain_supported(64, 0, 200, 64) == 0
+    assert lib.fx_pw_chain_supported(96, 0, 256, 64) == 0 and lib.fx_pw_chain_supported(64, 0, 256, 512) == 0
+    d = FxPwChainDesc()
+    assert lib.fx_pw_chain_bf16(C.byref(d), stream()) == -1   # FX_ERR_INVALID_ARGUMENT, nothing launched
