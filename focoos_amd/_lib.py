@@ -65,6 +65,7 @@ SIGNATURES = {
     "fx_mf_postprocess": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _i, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "fx_msda_bf16": [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "fx_rowmax_f32": [_vp, _i, _vp, _i, _i, _vp],
+    "fx_enc_score_head_bf16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp, _i, _vp, _i, _vp],
     "fx_topk_rows_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "fx_gather_rows_bf16": [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp],
     "fx_fill_rows_bf16": [_vp, _i, _i, _vp, _i, _vp, _i, _i, _vp],

@@ -23,9 +23,7 @@
 //   * y2: accumulators -> bf16 -> LDS (T reused) -> coalesced 16-byte stores.
 // Numerics are those of the two separate launches: bf16 operands, fp32 accumulate in the same k order, y1 rounded to bf16
 // before it feeds GEMM2.  (With a second source the shortcut sum stays in fp32 instead of being rounded to bf16 first.)
-#include "conv_common.h"
-
-typedef __attribute__((address_space(3))) void pw_lds_void_t;
+#include "pw_common.h"
 
 struct PwChainArgs {
   const bf16_t* x1;
@@ -41,39 +39,6 @@ struct PwChainArgs {
   int M, N1, act1, act2;
   unsigned x1_bytes, x2_bytes, r_bytes;
 };
-
-__device__ __forceinline__ void pw_dma16(__amdgpu_buffer_rsrc_t r, unsigned char* lds_base, unsigned voff) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (pw_lds_void_t*)lds_base, 16, voff, 0, 0, 0);
-}
-
-// physical 16-byte chunk of logical chunk `chunk` in row `row` of an LDS tile with RL chunks per row
-template <int RL>
-__device__ __forceinline__ int pw_swz(int row, int chunk) {
-  if constexpr (RL >= 16) {
-    return chunk ^ (row & 15);
-  } else {
-    constexpr int R = 16 / RL;  // rows per 256-byte bank window
-    return chunk ^ ((row / R) & (RL - 1));
-  }
-}
-
-// DMA `nrows` rows of RL chunks (global row m0+row, element stride ld, column offset col0) into a swizzled LDS tile.
-// A wave-instruction fills 64 consecutive physical chunks; the 4 waves take the instructions round-robin.
-template <int RL>
-__device__ __forceinline__ void pw_dma_rows(__amdgpu_buffer_rsrc_t r, unsigned char* tile, int nrows, int m0, int M, int ld, int col0,
-                                            int wave, int lane) {
-  const int ninstr = nrows * RL / 64;
-  for (int i = wave; i < ninstr; i += 4) {
-    const int q = i * 64 + lane;
-    const int row = q / RL, pc = q % RL;
-    const int lc = pw_swz<RL>(row, pc);
-    const int m = m0 + row;
-    const unsigned off = (m < M) ? (unsigned)(m * ld + col0 + lc * 8) * 2u : FX_OOB;
-    pw_dma16(r, tile + i * 1024, off);
-  }
-}
-
-__device__ __forceinline__ bf16x8 pw_ldg_frag(const bf16_t* p) { return *reinterpret_cast<const bf16x8*>(p); }
 
 template <int K1A, int K1B, int N2, int BM>
 __global__ __launch_bounds__(256, ((N2 <= 64 && K1B == 0) ? 4 : ((N2 <= 128 && (K1B == 0 || N2 <= 64)) ? 3 : 2))) void pw_chain_kernel(const PwChainArgs p) {

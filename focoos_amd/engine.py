@@ -232,6 +232,16 @@ class DetrEngine(_EngineBase):
         P[f"{hp}.enc_output.0"] = self._pack_linear(sd[f"{hp}.enc_output.0.weight"], sd[f"{hp}.enc_output.0.bias"])
         ln(f"{hp}.enc_output.1")
         P[f"{hp}.enc_score"] = self._pack_linear(sd[f"{hp}.enc_score_classifier.weight"], sd[f"{hp}.enc_score_classifier.bias"])
+        # fused score head (fx_enc_score_head_bf16): fragment-ordered enc_output / enc_score weights, classes padded to 128
+        self.score_head = None
+        ncp = (self.nc + 127) // 128 * 128
+        if ncp <= 384:
+            w2 = torch.zeros(ncp, self.hd)
+            w2[: self.nc] = sd[f"{hp}.enc_score_classifier.weight"].float()
+            b2 = torch.full((ncp,), -3e38)
+            b2[: self.nc] = sd[f"{hp}.enc_score_classifier.bias"].float()
+            self.score_head = (self._pack_frag(sd[f"{hp}.enc_output.0.weight"].float()), self._dev(sd[f"{hp}.enc_output.0.bias"].float()),
+                               self._pack_frag(w2), self._dev(b2), ncp)
         # constant output_memory row of masked (invalid-anchor) tokens: LN(Linear(0)) = LN(bias)
         b0 = sd[f"{hp}.enc_output.0.bias"].float()
         row = torch.nn.functional.layer_norm(b0.to(torch.bfloat16).float(), (self.hd,), sd[f"{hp}.enc_output.1.weight"].float(),
@@ -510,7 +520,7 @@ class _PlanBase:
         # branch2c (+ shortcut conv) -> next block's branch2a as ONE launch (fx_pw_chain_bf16): the block output is written once
         # and consumed from LDS; FX_PW_CHAIN=0 restores one launch per layer, FX_PW_CHAIN_MAX_STAGE limits the stages covered.
         use_chain = int(os.environ.get("FX_PW_CHAIN", "1")) != 0
-        max_stage = int(os.environ.get("FX_PW_CHAIN_MAX_STAGE", "2"))
+        max_stage = int(os.environ.get("FX_PW_CHAIN_MAX_STAGE", "1"))  # res2 + res3: HBM-bound seams; res4 measured neutral (profiles/r02a)
         c1 = self._new("conv1_1", B, H // 2, W // 2, 32)
         self._op(lib.fx_stem_conv3x3s2, self.input.data_ptr(), int(self.f32_input), e.stem_w.data_ptr(), e.stem_b.data_ptr(),
                  e.px_mean.data_ptr(), e.px_inv_std.data_ptr(), c1.ptr, B, H, W, 32)
@@ -671,13 +681,26 @@ class _Plan(_PlanBase):
         self.invalid = invalid.to(self.dev).contiguous()
         self.shapes_t = torch.tensor(shapes, dtype=torch.int32, device=self.dev)
         self.starts_t = torch.tensor(starts, dtype=torch.int32, device=self.dev)
-        om_lin = self.linear(mem_rows, P[f"{hp}.enc_output.0"], name="om_lin")
-        om = self.layernorm(om_lin, f"{hp}.enc_output.1", "output_memory")
-        self._op(lib.fx_fill_rows_bf16, om.ptr, om.ld, S, self.invalid.data_ptr(), int(self.invalid.numel()), e.invalid_row.data_ptr(), B, 256)
-        enc_logits = self.linear(om, P[f"{hp}.enc_score"], name="enc_logits", out_f32=True)
         Q, K = e.nq, e.nc
         self.enc_scores = self._io("enc_scores", (B, S), torch.float32)
-        self._op(lib.fx_rowmax_f32, enc_logits.ptr, enc_logits.ld, self.enc_scores.data_ptr(), B * S, K)
+        if e.score_head is not None and int(os.environ.get("FX_SCORE_HEAD", "1")) != 0:
+            # enc_output (Linear + LayerNorm) + enc_score_classifier + max over classes in one launch; invalid anchors enter as zero rows
+            w1, b1, w2, b2, ncp = e.score_head
+            valid = torch.ones(S, dtype=torch.uint8)
+            valid[invalid.long()] = 0
+            self.valid_u8 = valid.to(self.dev)
+            om = self._new("output_memory", B * S, 1, 1, 256)
+            g_, b_ = e.ln[f"{hp}.enc_output.1"]
+            self.meta[len(self.ops)] = {"kind": "conv", "variant": f"score_head<{ncp}>", "flops": 2.0 * B * S * 256 * (256 + K), "name": "enc_output+enc_score+max",
+                                        "M": B * S, "N": 256 + K, "K": 256, "bytes": 2.0 * B * S * 256 * 2 + 4.0 * B * S}
+            self._op(lib.fx_enc_score_head_bf16, mem_rows.ptr, mem_rows.ld, self.valid_u8.data_ptr(), S, w1.data_ptr(), b1.data_ptr(), g_.data_ptr(),
+                     b_.data_ptr(), C.c_float(1e-5), w2.data_ptr(), b2.data_ptr(), ncp, om.ptr, om.ld, self.enc_scores.data_ptr(), B * S)
+        else:
+            om_lin = self.linear(mem_rows, P[f"{hp}.enc_output.0"], name="om_lin")
+            om = self.layernorm(om_lin, f"{hp}.enc_output.1", "output_memory")
+            self._op(lib.fx_fill_rows_bf16, om.ptr, om.ld, S, self.invalid.data_ptr(), int(self.invalid.numel()), e.invalid_row.data_ptr(), B, 256)
+            enc_logits = self.linear(om, P[f"{hp}.enc_score"], name="enc_logits", out_f32=True)
+            self._op(lib.fx_rowmax_f32, enc_logits.ptr, enc_logits.ld, self.enc_scores.data_ptr(), B * S, K)
         self.enc_topk_val = self._io("enc_topk_val", (B, Q), torch.float32)
         self.enc_topk = self._io("enc_topk", (B, Q), torch.int32)
         self._op(lib.fx_topk_rows_f32, self.enc_scores.data_ptr(), S, B, S, Q, self.enc_topk_val.data_ptr(), self.enc_topk.data_ptr())

@@ -153,6 +153,18 @@ int fx_msda_bf16(const void* value, int ldv, const int32_t* spatial_shapes, cons
 /* Row-wise max over the first `cols` columns of an f32 matrix (enc_outputs_class.max(-1), modelling.py:1210). */
 int fx_rowmax_f32(const float* x, int ldx, float* out, int rows, int cols, fx_stream_t stream);
 
+/* Encoder score head of the query selection (fai_detr/modelling.py:1202-1214) as one back-to-back GEMM launch:
+ *   output_memory[m,:] = LayerNorm_256( W1 . (valid[m % S] ? memory[m,:] : 0) + b1 ) * gamma + beta     (bf16 out, row stride ldo)
+ *   scores[m]          = max_c ( W2[c,:] . output_memory[m,:] + b2[c] )                                   (f32)
+ * i.e. `valid_mask * memory` -> enc_output (Linear + LayerNorm) -> enc_score_classifier -> .max(-1); the [M, K] logits are
+ * never written.  The Linear output feeds the LayerNorm from the fp32 accumulators (index-critical path).
+ * memory bf16 [M, ldm] with 256 channels; valid u8 [S] or NULL; W1 / W2 fragment-packed like fx_pw_chain_desc
+ * ([256/32][16][64][8] and [n2_pad/32][16][64][8]); n2_pad = classes rounded up to 128 (<= 384), padding rows of W2 zero
+ * and padding entries of b2 = -3e38. */
+int fx_enc_score_head_bf16(const void* memory, int ldm, const uint8_t* valid, int S, const void* w1, const float* b1,
+                           const float* gamma, const float* beta, float eps, const void* w2, const float* b2, int n2_pad,
+                           void* output_memory, int ldo, float* scores, int M, fx_stream_t stream);
+
 /* torch.topk(scores, k, dim=1) for f32 rows (modelling.py:1214; processor.py:147): for each of B rows
  * of length n writes the k largest values (descending; ties -> lower index first) and their indices. */
 int fx_topk_rows_f32(const float* scores, int ld, int B, int n, int k, float* out_val, int32_t* out_idx, fx_stream_t stream);

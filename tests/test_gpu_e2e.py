@@ -3,10 +3,12 @@ fixtures produced by the real reference, on a real MI355X.
 
 Tolerances (bf16 activations/weights, fp32 accumulate, fp32 scores/boxes; stated per north_star):
   * intermediate feature maps: relative L2 error <= 2e-2 vs the fp32 oracle;
-  * with the encoder top-k query set teacher-forced to the reference's: |dprob| <= 2.5e-2,
-    |dbox| <= 1e-2 (normalised units), per-query argmax class identical wherever the top-2 margin > 5e-2;
-  * free-running: encoder top-300 query set overlaps the reference's by >= 85 % (index parity under bf16
-    is ill-conditioned: the reference itself under bf16 autocast changes the set — SURVEY §0.8);
+  * with the encoder top-k query set teacher-forced to the reference's: |dprob| <= 3e-2,
+    |dbox| <= 8e-3 (normalised units), per-query argmax class identical wherever the top-2 margin > 6e-2;
+  * free-running: encoder class scores within 1e-1; the top-300 token set and the post-process (query, class) pairs are
+    EXACTLY the reference's for every candidate further than 2 x tolerance from the selection boundary, and the set
+    overlaps the real reference's by >= 90 % (the boundary tokens themselves are ill-conditioned under any rounding
+    change: the reference under bf16 autocast changes the set too — SURVEY §0.8);
   * integer outputs (class ids, query ids, int32 pixel boxes): bit-exact given equal float inputs
     (tests/test_gpu_kernels.py::test_head_out_and_postprocess_vs_oracle), and equal to the reference's for every
     detection whose score margin to its neighbours and to the threshold exceeds the stated prob tolerance.
@@ -70,44 +72,108 @@ def test_stage_parity_teacher_forced(setup):
         assert (pl.refs[i + 1].cpu().view(2, 300, 4) - col[f"dec{i}_ref"]).abs().max() < 1e-2, i
     dp = (out.logits.cpu() - probs_o).abs().max().item()
     db = (out.boxes.cpu() - boxes_o).abs().max().item()
-    assert dp < 2.5e-2 and db < 1e-2, (dp, db)
+    assert dp <= TOL_PROB and db <= TOL_BOX, (dp, db)
     # vs the reference's golden outputs
-    assert np.abs(out.boxes.cpu().numpy() - g["boxes"]).max() < 1e-2
-    assert np.abs(out.logits.cpu().max(-1).values.numpy() - g["probs_max"]).max() < 2.5e-2
+    assert np.abs(out.boxes.cpu().numpy() - g["boxes"]).max() <= TOL_BOX
+    assert np.abs(out.logits.cpu().max(-1).values.numpy() - g["probs_max"]).max() <= TOL_PROB
     top2 = probs_o.topk(2, -1).values
-    safe = (top2[..., 0] - top2[..., 1]) > 5e-2
+    safe = (top2[..., 0] - top2[..., 1]) > 2 * TOL_PROB
     assert (out.logits.cpu().argmax(-1)[safe].numpy() == g["probs_argmax"][safe.numpy()]).all()
 
 
-def test_free_running_queries_and_detections(setup):
+# Stated tolerances of the free-running (no teacher forcing) comparison, bf16 engine vs fp32 oracle:
+# Measured on MI355X (scripts/dev/parity_probe.py, profiles/r02_parity_probe.txt): stage rel-L2 0.6 % (backbone) -> 0.85 % (encoder) -> 1.0 %
+# (decoder); encoder scores max |d| 0.067-0.069 (mean 0.013, score std 0.53); final logits max |d| 0.09-0.11 at std 1.9, i.e.
+# probabilities max |d| 0.016-0.024 (mean 2e-4) and boxes max |d| 0.0046-0.0055 - the maxima over 219 000 values move by +-30 % between
+# equivalent kernel selections (fused / unfused layers), so the gates are the measured maxima x 1.25-1.45, not x 1.0.
+TOL_SCORE = 1e-1   # encoder class-score logits feeding the top-300 selection
+TOL_PROB = 3e-2    # final class probabilities
+TOL_BOX = 8e-3     # final boxes, normalised units (= 5 px at 640)
+
+
+def test_free_running_index_parity_outside_margins(setup):
+    """north_star: "bit-exact class/box indices".  Both top-k selections are discontinuous, so the claim is made where it can hold:
+    every candidate whose fp32 score is further than 2 x tolerance from the selection boundary must be selected (or rejected) exactly as
+    the reference does - for the encoder's top-300 of 8400 tokens and for the post-process' (class, query) pairs above the threshold."""
     g, cfg, sd, model, images, x_u8, forced, probs_o, boxes_o, col = setup
     thr = float(g["threshold"])
     pl = model.detect(x_u8, threshold=thr)
     torch.cuda.synchronize()
+    sc_e, sc_o = pl.enc_scores.cpu(), col["enc_scores"]
+    ds = (sc_e - sc_o).abs().max().item()
+    assert ds <= TOL_SCORE, f"encoder score error {ds:.4f}"
+    mine_all = pl.enc_topk.cpu().long()
+    overlap = []
     for i in range(2):
-        mine = set(pl.enc_topk[i].cpu().tolist())
-        ref = set(g["enc_topk"][i].tolist())
-        assert len(mine) == 300 and len(mine & ref) >= 255, len(mine & ref)
-    # detections: every reference detection with a comfortable score margin must be found with the same class and
-    # (within 2 px) box; the engine must not invent confident detections either.
-    tol = 2.5e-2
+        mine = set(mine_all[i].tolist())
+        assert len(mine) == 300
+        cutoff = sc_o[i].topk(300).values[-1].item()
+        must_in = set(torch.nonzero(sc_o[i] > cutoff + 2 * TOL_SCORE).flatten().tolist())
+        must_out = set(torch.nonzero(sc_o[i] < cutoff - 2 * TOL_SCORE).flatten().tolist())
+        assert len(must_in) >= 60 and len(must_out) >= 6000, (len(must_in), len(must_out))   # the margin test is not vacuous
+        assert must_in <= mine, sorted(must_in - mine)[:8]
+        assert not (mine & must_out), sorted(mine & must_out)[:8]
+        ref = set(g["enc_topk"][i].tolist())      # the REAL reference's set (golden): same statement, plus the overlap as a number
+        assert (must_in <= ref) and not (ref & must_out)
+        overlap.append(len(mine & ref))
+        assert overlap[-1] >= 270, overlap
+        # within the set the engine's ORDER follows its own scores exactly (descending, ties to the lower index)
+        v = sc_e[i][mine_all[i]]
+        assert (v[:-1] >= v[1:]).all()
+    # ---- post-process indices: oracle on the engine's own query set (the selection itself was checked above)
+    with torch.no_grad():
+        p_o, b_o = O.detr_forward(sd, cfg, O.get_torch_batch(images, (640, 640)), forced_topk=mine_all)
+    dp = (pl.probs.cpu() - p_o).abs().max().item()
+    db = (pl.boxes.cpu() - b_o).abs().max().item()
+    assert dp <= TOL_PROB and db <= TOL_BOX, (dp, db)
+    K = p_o.shape[-1]
+    for i in range(2):
+        n = int(pl.det_count[i])
+        s = pl.det_scores[i, :n].cpu()
+        assert (s[:-1] >= s[1:]).all() and (s > thr).all()
+        pairs = {(int(q), int(c)): j for j, (q, c) in enumerate(zip(pl.det_queries[i, :n].cpu().tolist(), pl.det_labels[i, :n].cpu().tolist()))}
+        assert len(pairs) == n
+        flat = p_o[i].flatten()
+        sure = torch.nonzero(flat > thr + 2 * TOL_PROB).flatten().tolist()
+        never = set(torch.nonzero(flat < thr - 2 * TOL_PROB).flatten().tolist())
+        assert len(sure) >= 10
+        for f in sure:                                    # every confident reference detection: same (query, class), score and box within tolerance
+            q, c = divmod(f, K)
+            assert (q, c) in pairs, (i, q, c, float(flat[f]))
+            j = pairs[(q, c)]
+            assert abs(float(s[j]) - float(flat[f])) <= TOL_PROB
+            ref_box = torch.round(b_o[i, q] * 640.0)
+            assert (pl.det_boxes[i, j].cpu().float() - ref_box).abs().max().item() <= 640 * TOL_BOX + 1
+        assert not any((q * K + c) in never for (q, c) in pairs)   # and nothing the reference puts clearly below the threshold
+        # top_k = 300 truncation (processor.py:147): applies only if > 300 pairs pass - not the case for these inputs
+        assert n < 300
+
+
+def test_free_running_detections_vs_reference_golden(setup):
+    """Against the REAL reference's detections (golden, its own free-running query set): every confident reference detection is found with
+    the same class, score within tolerance and box within a few pixels; counts agree within the band the score tolerance allows."""
+    g, cfg, sd, model, images, x_u8, forced, probs_o, boxes_o, col = setup
+    thr = float(g["threshold"])
+    pl = model.detect(x_u8, threshold=thr)
+    torch.cuda.synchronize()
+    tol = 2 * TOL_PROB
     for i in range(2):
         n_ref = int(g["det_count"][i])
         n = int(pl.det_count[i])
         s = pl.det_scores[i, :n].cpu().numpy()
         lab = pl.det_labels[i, :n].cpu().numpy()
         box = pl.det_boxes[i, :n].cpu().numpy()
-        assert (np.diff(s) <= 0).all()
         rs, rl, rb = g["det_scores"][i, :n_ref], g["det_labels"][i, :n_ref], g["det_boxes"][i, :n_ref]
         confident = np.where(rs > thr + 2 * tol)[0]
         assert len(confident) > 10
         hit = 0
         for j in confident:
             cand = np.where((lab == rl[j]) & (np.abs(s - rs[j]) < tol))[0]
-            if any(np.abs(box[c] - rb[j]).max() <= 4 for c in cand):
+            if any(np.abs(box[c] - rb[j]).max() <= 640 * TOL_BOX + 1 for c in cand):
                 hit += 1
-        assert hit >= 0.95 * len(confident), (hit, len(confident))
-        assert abs(n - n_ref) <= 0.25 * n_ref + 5
+        # a reference detection can only be missed when its QUERY is one of the boundary tokens the two top-300 sets disagree on
+        assert hit >= len(confident) - 4, (hit, len(confident))
+        assert abs(n - n_ref) <= 0.15 * n_ref + 5
 
 
 def test_graph_replay_equals_eager_and_is_deterministic(setup):
@@ -154,8 +220,8 @@ def test_resize_case_against_reference_golden():
     forced = torch.from_numpy(g["enc_topk"]).long()
     out = fm.model.forward(x, forced_topk=forced, use_graph=False)
     torch.cuda.synchronize()
-    assert np.abs(out.boxes.cpu().numpy() - g["boxes"]).max() < 1e-2
-    assert np.abs(out.logits.cpu().max(-1).values.numpy() - g["probs_max"]).max() < 2.5e-2
+    assert np.abs(out.boxes.cpu().numpy() - g["boxes"]).max() <= TOL_BOX
+    assert np.abs(out.logits.cpu().max(-1).values.numpy() - g["probs_max"]).max() <= TOL_PROB
     dets = fm.infer_batch([img], threshold=float(g["threshold"]))[0]
     n_ref = int(g["det_count"][0])
     assert abs(len(dets) - n_ref) <= 4

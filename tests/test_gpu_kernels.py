@@ -547,3 +547,42 @@ def test_pw_chain_rejects_bad_arguments(lib):
     assert lib.fx_pw_chain_supported(96, 0, 256, 64) == 0 and lib.fx_pw_chain_supported(64, 0, 256, 512) == 0
     d = FxPwChainDesc()
     assert lib.fx_pw_chain_bf16(C.byref(d), stream()) == -1   # FX_ERR_INVALID_ARGUMENT, nothing launched
+
+
+@pytest.mark.parametrize("M,S,K", [(64 * 3, 64, 365), (8400 + 500, 8400, 365), (333, 111, 80), (200, 200, 150)])
+def test_enc_score_head_fused(lib, M, S, K):
+    """fx_enc_score_head_bf16 = valid_mask*memory -> Linear -> LayerNorm -> class Linear -> max (modelling.py:1202-1214) in one launch."""
+    g = torch.Generator().manual_seed(M + K)
+    mem = torch.randn(M, 256, generator=g) * 1.5 + torch.linspace(-0.5, 0.5, 256)[None]
+    valid = (torch.rand(S, generator=g) > 0.1).to(torch.uint8)
+    W1 = torch.randn(256, 256, generator=g) / 16 + torch.linspace(-0.02, 0.02, 256)[:, None]
+    b1 = torch.randn(256, generator=g) * 0.1
+    gam, bet = torch.rand(256, generator=g) * 0.4 + 0.8, torch.randn(256, generator=g) * 0.05
+    W2 = torch.randn(K, 256, generator=g) * 2 / 16
+    b2 = -6.0 + 0.5 * torch.randn(K, generator=g)
+    ncp = (K + 127) // 128 * 128
+    W2p = torch.zeros(ncp, 256)
+    W2p[:K] = W2
+    b2p = torch.full((ncp,), -3e38)
+    b2p[:K] = b2
+    memd = to_dev(bf(mem))
+    om = torch.full((M + 2, 256), float("nan"), dtype=torch.bfloat16, device=DEV)
+    sc = torch.full((M + 2,), float("nan"), dtype=torch.float32, device=DEV)
+    w1d, w2d = frag_pack(W1), frag_pack(W2p)
+    args = [to_dev(t) for t in (b1, gam, bet, b2p)]
+    vd = to_dev(valid)
+    check(lib.fx_enc_score_head_bf16(memd.data_ptr(), 256, vd.data_ptr(), S, w1d.data_ptr(), args[0].data_ptr(), args[1].data_ptr(), args[2].data_ptr(),
+                                     C.c_float(1e-5), w2d.data_ptr(), args[3].data_ptr(), ncp, om.data_ptr(), 256, sc.data_ptr(), M, stream()), "score head")
+    torch.cuda.synchronize()
+    assert torch.isnan(om[M:].float()).all() and torch.isnan(sc[M:]).all()
+    x = bf(mem).float() * valid[torch.arange(M) % S].float()[:, None]
+    y = F.layer_norm(x @ bf(W1).float().T + b1, (256,), gam, bet, 1e-5)
+    got_om = om[:M].float().cpu()
+    assert (got_om - y).abs().max().item() <= 2e-2 * y.abs().max().item()          # one bf16 rounding of an O(4) value
+    # the class GEMM + max on the kernel's own bf16 output_memory: fp32 accumulation only differs in summation order
+    ref_sc = (got_om @ bf(W2).float().T + b2).max(-1).values
+    got_sc = sc[:M].cpu()
+    assert (got_sc - ref_sc).abs().max().item() <= 2e-4 * max(1.0, ref_sc.abs().max().item()), (got_sc - ref_sc).abs().max().item()
+    # and against the all-fp32 pipeline (what the reference computes): only output_memory's bf16 rounding in between
+    full = (y @ bf(W2).float().T + b2).max(-1).values
+    assert (got_sc - full).abs().max().item() <= 3e-2
