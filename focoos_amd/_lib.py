@@ -24,7 +24,7 @@ class FxConvDesc(C.Structure):
         ("Ho", C.c_int32), ("Wo", C.c_int32), ("N", C.c_int32), ("ldy", C.c_int32), ("ldr", C.c_int32),
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("pool2", C.c_int32), ("act", C.c_int32), ("out_f32", C.c_int32), ("residual_after_act", C.c_int32),
-        ("y_batch_stride", C.c_int64),
+        ("y_batch_stride", C.c_int64), ("w_frag", C.c_void_p),
     ]
 
 
@@ -46,6 +46,7 @@ SIGNATURES = {
     "fx_device_info": [_i, C.POINTER(C.c_int), C.c_char_p, _i],
     "fx_conv2d_nhwc_bf16": [C.POINTER(FxConvDesc), _vp],
     "fx_pw_chain_supported": [_i, _i, _i, _i],
+    "fx_conv3x3_flat_supported": [_i, _i, _i],
     "fx_pw_chain_bf16": [C.POINTER(FxPwChainDesc), _vp],
     "fx_stem_conv3x3s2": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "fx_resize_bilinear_u8": [_vp, _i, _i, _vp, _i, _i, _vp],

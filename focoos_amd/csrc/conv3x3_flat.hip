@@ -1,0 +1,280 @@
+// 3x3 / stride 1 / pad 1 convolution WITHOUT im2col re-fetching (gfx950).
+//
+// The implicit-GEMM kernels (conv_igemm*.hip) fetch the pixel tile once per filter tap: nine L2 -> LDS passes over the same
+// pixels and a barrier every 32..64 channels.  Here the workgroup owns BM consecutive pixels of the flattened NHWC tensor
+// (m = (b*H + y)*W + x); a tap (dy,dx) of pixel m is pixel m + dy*W + dx of the same flat sequence, so ONE contiguous halo
+// range [m0 - W - 1, m0 + BM + W + 1) of CC channels serves all nine taps:
+//   * a dedicated LOADER wave streams the halo of the next channel chunk into LDS with buffer_load...lds while the consumer
+//     waves run 9 x CC/16 MFMA k-steps on the current chunk - 36 k-steps between barriers instead of 1..4; its DMA count
+//     lives in its own vmcnt, so the consumers' weight loads are never serialised behind it;
+//   * the pixels are the MFMA B operand, read from the halo at row p + (W+1) + dy*W + dx: consecutive lanes = consecutive
+//     rows, conflict-free under the row-pair XOR swizzle for ANY row offset; image borders (and neighbouring images - the
+//     halo is loaded blindly) are masked in registers with a per-pixel 9-bit tap mask;
+//   * the weights are the A operand and never touch LDS: fragment-ordered ([n/32][k/16][lane][8], k = tap*C + c) 1 KiB reads
+//     from L2 into a register ring;
+//   * epilogue: bias (accumulator init) + activation (+ residual, either side of the activation) in the accumulator layout
+//     on an LDS tile, then 16-byte coalesced stores.
+#include "pw_common.h"
+
+struct C3Args {
+  const bf16_t* x;
+  const bf16_t* wp;
+  const float* bias;
+  const bf16_t* res;
+  bf16_t* y;
+  int H, W, C, N, ldx, ldy, ldr, M;
+  int act, res_after;
+  int HLp;  // halo rows per chunk buffer (BM + 2W + 2 rounded up to whole DMA instructions)
+  unsigned x_bytes, r_bytes;
+};
+
+template <int CC, int TN, int TM, int WN, int WM, int ACT, int RESMODE>
+__global__ __launch_bounds__((WN* WM + 1) * 64, 1) void conv3x3_flat_kernel(const C3Args p) {
+  constexpr int NW = WN * WM, NT = (NW + 1) * 64;
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int RL = CC / 8, ROWB = CC * 2, KJ = CC / 16, STEPS = 9 * KJ;
+  constexpr int PF = KJ;  // weight-fragment ring: one slot per k-step of a tap, refilled for the next tap
+  constexpr int RLT = BN / 8;
+  static_assert(KJ % 2 == 0, "the B double buffer returns to slot 0 at every tap");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_loader = wave == NW;
+  const int l32 = lane & 31, half = lane >> 5;
+  const int wn = wave % WN, wm = wave / WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int lo = m0 - p.W - 1;
+  const int NCH = p.C / CC;
+  const int buf_bytes = p.HLp * ROWB;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  unsigned char* T = smem;  // output tile [BM][BN] bf16 (aliases the halo buffers after the K loop), rows of BN*2 bytes, pw_swz<RLT>
+
+  auto dma_chunk = [&](int cc, unsigned char* buf) {
+    const int ninstr = p.HLp * RL / 64;
+    for (int i = 0; i < ninstr; ++i) {
+      const int q = i * 64 + lane;
+      const int r = q / RL, pc = q % RL;
+      const int lc = pw_swz<RL>(r, pc);
+      const int f = lo + r;
+      const bool ok = f >= 0 && f < p.M;
+      pw_dma16(xr, buf + i * 1024, ok ? (unsigned)(f * p.ldx + cc * CC + lc * 8) * 2u : FX_OOB);
+    }
+  };
+
+  // ---- consumer state
+  f32x16 acc[TN][TM];
+  bf16x8 ar[PF][TN];
+  unsigned mask9[TM];
+  int rbase[TM];
+  const int Cs = p.C >> 4;          // k16 steps per tap over all channels
+  const bf16_t* wbase = p.wp + (size_t)((n0 >> 5) + wn * TN) * (size_t)(9 * Cs) * 512 + lane * 8;
+  // fragment of n-block a, chunk cc, in-chunk step s (tap = s / KJ, j = s % KJ)
+  auto a_ptr = [&](int a, int cc, int s) -> const bf16_t* {
+    const int ks = (s / KJ) * Cs + cc * KJ + (s % KJ);
+    return wbase + ((size_t)a * (size_t)(9 * Cs) + ks) * 512;
+  };
+  // The two roles are separate code regions with the SAME barrier sequence (one __syncthreads per chunk, then E1 / [E2] / E3
+  // below): keeping them in one loop makes the register allocator carry the 128 accumulator registers through the loader's
+  // branch and spill them at every chunk boundary.
+  if (is_loader) {
+    dma_chunk(0, smem);
+    for (int cc = 0; cc < NCH; ++cc) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // chunk cc has landed; every consumer is done with chunk cc-1 (the other buffer)
+      if (cc + 1 < NCH) dma_chunk(cc + 1, smem + ((cc + 1) & 1) * buf_bytes);
+    }
+    __syncthreads();  // E1: the halo buffers are dead; the output tile T (aliases them) may be written
+    if constexpr (RESMODE != 0) {
+    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, p.r_bytes, 0x00020000);
+    for (int i = 0; i < BM * RLT / 64; ++i) {
+      const int q = i * 64 + lane;
+      const int r = q / RLT, pc = q % RLT;
+      const int lc = pw_swz<RLT>(r, pc);
+      const int m = m0 + r;
+      pw_dma16(rr, T + i * 1024, m < p.M ? (unsigned)(m * p.ldr + n0 + lc * 8) * 2u : FX_OOB);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // E2: residual tile in T
+    }
+    __syncthreads();  // E3: output tile complete
+  } else {
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n0 + (wn * TN + a) * 32 + 8 * gq + 4 * half);
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+          acc[a][b][4 * gq] = bb.x; acc[a][b][4 * gq + 1] = bb.y; acc[a][b][4 * gq + 2] = bb.z; acc[a][b][4 * gq + 3] = bb.w;
+        }
+      }
+    const int HW = p.H * p.W;
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+      const int pl = (wm * TM + b) * 32 + l32;
+      const int m = m0 + pl;
+      rbase[b] = pl + p.W + 1;
+      const bool ok = m < p.M;
+      const int mm = ok ? m : 0;
+      const int rem = mm % HW;
+      const int yy = rem / p.W, xx = rem - yy * p.W;
+      unsigned msk = 0;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+        if (ok && (unsigned)(yy + dy) < (unsigned)p.H && (unsigned)(xx + dx) < (unsigned)p.W) msk |= 1u << t;
+      }
+      mask9[b] = msk;
+    }
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+#pragma unroll
+      for (int a = 0; a < TN; ++a) ar[i][a] = pw_ldg_frag(a_ptr(a, 0, i));
+    for (int cc = 0; cc < NCH; ++cc) {
+      __syncthreads();  // chunk cc has landed; every consumer is done with chunk cc-1 (the other buffer)
+      const unsigned char* buf = smem + (cc & 1) * buf_bytes;
+      const int ccn = cc + 1 < NCH ? cc + 1 : cc;
+      // B fragment of block b: tap t (flat offset toff), k16 step j of the chunk; image borders masked in registers
+      auto load_b = [&](int b, int t, int toff, int j) -> bf16x8 {
+        const int r = rbase[b] + toff;
+        const int sw = (RL >= 8 ? ((r >> 1) & 7) : ((r >> 2) & 3));
+        bf16x8 v = *reinterpret_cast<const bf16x8*>(buf + r * ROWB + (((j * 2 + half) ^ sw) << 4));
+        const bool ok = (mask9[b] >> t) & 1u;
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+        return ok ? v : z;
+      };
+      bf16x8 xb[2][TM];
+#pragma unroll
+      for (int b = 0; b < TM; ++b) xb[0][b] = load_b(b, 0, -p.W - 1, 0);
+      // The tap loop is a real loop (one ring cycle of KJ k-steps per tap): fully unrolled, hipcc hoists 36 steps' worth of
+      // addresses and loads and spills hundreds of registers.
+#pragma unroll 1
+      for (int t = 0; t < 9; ++t) {
+        const int toff = (t / 3 - 1) * p.W + (t % 3 - 1);
+        const int tn = t + 1;
+        const int toff_n = (tn / 3 - 1) * p.W + (tn % 3 - 1);
+        const bool last_tap = t == 8;
+#pragma unroll
+        for (int j = 0; j < KJ; ++j) {
+          if (j + 1 < KJ) {
+#pragma unroll
+            for (int b = 0; b < TM; ++b) xb[(j + 1) & 1][b] = load_b(b, t, toff, j + 1);
+          } else if (!last_tap) {
+#pragma unroll
+            for (int b = 0; b < TM; ++b) xb[0][b] = load_b(b, tn, toff_n, 0);
+          }
+#pragma unroll
+          for (int a = 0; a < TN; ++a)
+#pragma unroll
+            for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j][a], xb[j & 1][b], acc[a][b], 0, 0, 0);
+          // this ring slot is next used by the same k-step of the next tap (or of tap 0 of the next chunk; last chunk: a harmless re-read)
+          const int s_next = last_tap ? j : tn * KJ + j;
+          const int c_next = last_tap ? ccn : cc;
+#pragma unroll
+          for (int a = 0; a < TN; ++a) ar[j][a] = pw_ldg_frag(a_ptr(a, c_next, s_next));
+        }
+      }
+    }
+    __syncthreads();  // E1
+    if constexpr (RESMODE != 0) __syncthreads();  // E2
+  #pragma unroll
+      for (int a = 0; a < TN; ++a)
+  #pragma unroll
+        for (int b = 0; b < TM; ++b)
+  #pragma unroll
+          for (int gq = 0; gq < 4; ++gq) {
+            const int row = (wm * TM + b) * 32 + l32;
+            const int chunk = (wn * TN + a) * 4 + gq;
+            unsigned char* tp = T + row * (BN * 2) + (pw_swz<RLT>(row, chunk) << 4) + half * 8;
+            float v0 = acc[a][b][4 * gq], v1 = acc[a][b][4 * gq + 1], v2 = acc[a][b][4 * gq + 2], v3 = acc[a][b][4 * gq + 3];
+            float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, r3 = 0.0f;
+            if constexpr (RESMODE != 0) {
+              const uint2 rv = *reinterpret_cast<const uint2*>(tp);
+              r0 = __uint_as_float(rv.x << 16); r1 = __uint_as_float(rv.x & 0xffff0000u);
+              r2 = __uint_as_float(rv.y << 16); r3 = __uint_as_float(rv.y & 0xffff0000u);
+            }
+            if constexpr (RESMODE == 1) { v0 += r0; v1 += r1; v2 += r2; v3 += r3; }       // act(conv + residual)
+            if constexpr (ACT == FX_ACT_RELU) {
+              v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f);
+            } else if constexpr (ACT == FX_ACT_SILU) {
+              v0 = v0 / (1.0f + __expf(-v0)); v1 = v1 / (1.0f + __expf(-v1)); v2 = v2 / (1.0f + __expf(-v2)); v3 = v3 / (1.0f + __expf(-v3));
+            }
+            if constexpr (RESMODE == 2) { v0 += r0; v1 += r1; v2 += r2; v3 += r3; }       // act(conv) + residual
+            uint2 o;
+            o.x = pack_bf16x2(v0, v1);
+            o.y = pack_bf16x2(v2, v3);
+            *reinterpret_cast<uint2*>(tp) = o;
+          }
+
+    __syncthreads();  // E3
+  }
+  for (int q = tid; q < BM * RLT; q += NT) {
+    const int row = q / RLT, lc = q % RLT;
+    const int m = m0 + row;
+    if (m < p.M) {
+      const uint4 v = *reinterpret_cast<const uint4*>(T + row * (BN * 2) + (pw_swz<RLT>(row, lc) << 4));
+      *reinterpret_cast<uint4*>(p.y + (size_t)m * p.ldy + n0 + lc * 8) = v;
+    }
+  }
+}
+
+template <int CC, int TN, int TM, int WN, int WM, int ACT, int RESMODE>
+static int launch_c3(C3Args& a, hipStream_t stream) {
+  constexpr int NW = WN * WM, BM = WM * TM * 32, BN = WN * TN * 32, RL = CC / 8;
+  constexpr int RPI = 64 / RL;  // halo rows per DMA instruction
+  const int HL = BM + 2 * a.W + 2;
+  a.HLp = (HL + RPI - 1) / RPI * RPI;
+  const int nbuf = a.C / CC > 1 ? 2 : 1;
+  const int halo = nbuf * a.HLp * CC * 2, tile = BM * BN * 2;
+  const int smem = halo > tile ? halo : tile;
+  if (smem > 160 * 1024) return FX_ERR_UNSUPPORTED;
+  auto kern = conv3x3_flat_kernel<CC, TN, TM, WN, WM, ACT, RESMODE>;
+  static int attr_smem = 0;
+  if (smem > attr_smem) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return FX_ERR_RUNTIME;
+    attr_smem = smem;
+  }
+  hipLaunchKernelGGL(kern, dim3((a.M + BM - 1) / BM, a.N / BN), dim3((NW + 1) * 64), smem, stream, a);
+  return fx_launch_status();
+}
+
+// Epilogue variants instantiated: ReLU, SiLU, SiLU + residual after the activation (CSPRepLayer), none.  -1: not covered.
+int fx_c3_epilogue_mode(int act, bool has_res, int res_after) {
+  if (!has_res) return act == FX_ACT_RELU ? 0 : (act == FX_ACT_SILU ? 1 : (act == FX_ACT_NONE ? 3 : -1));
+  return (act == FX_ACT_SILU && res_after == 1) ? 2 : -1;
+}
+
+// LDS needed by the flat kernel for this shape (0 = shape not covered): the dispatcher in conv_igemm.hip asks before routing a layer here.
+extern "C" int fx_conv3x3_flat_supported(int C, int N, int W) {
+  if (C % 64 != 0 || !(N == 64 || N == 128 || N == 256)) return 0;
+  const int BM = N == 256 ? 128 : 256;
+  const int HLp = (BM + 2 * W + 2 + 7) / 8 * 8;
+  const int halo = (C / 64 > 1 ? 2 : 1) * HLp * 128, tile = BM * N * 2;
+  return (halo > tile ? halo : tile) <= 160 * 1024 ? 1 : 0;
+}
+
+int fx_launch_conv3x3_flat(const ConvArgs& c, const bf16_t* w_frag, hipStream_t stream) {
+  C3Args a;
+  a.x = c.x; a.wp = w_frag; a.bias = c.bias; a.res = c.res; a.y = reinterpret_cast<bf16_t*>(c.y);
+  a.H = c.H; a.W = c.W; a.C = c.C; a.N = c.N; a.ldx = c.ldx; a.ldy = c.ldy; a.ldr = c.ldr; a.M = c.M;
+  a.act = c.act; a.res_after = c.res_after; a.HLp = 0;
+  a.x_bytes = c.x_bytes; a.r_bytes = c.r_bytes;
+  // 4 consumer waves + the loader, one workgroup per CU; 2 x 4 accumulator blocks per wave where N allows (operand economy:
+  // 2 weight + 4 pixel fragments per 8 MFMAs).  N = 64: 256 pixels x 64 channels; 128: 256 x 128; 256: 128 pixels x 256 channels.
+  const int mode = fx_c3_epilogue_mode(c.act, c.res != nullptr, c.res_after);
+#define FX_C3_TILE(ACT_, RM_)                                                   \
+  {                                                                             \
+    if (c.N == 64) return launch_c3<64, 1, 4, 2, 2, ACT_, RM_>(a, stream);      \
+    if (c.N == 128) return launch_c3<64, 2, 4, 2, 2, ACT_, RM_>(a, stream);     \
+    return launch_c3<64, 2, 4, 4, 1, ACT_, RM_>(a, stream);                     \
+  }
+  switch (mode) {
+    case 0: FX_C3_TILE(FX_ACT_RELU, 0)
+    case 1: FX_C3_TILE(FX_ACT_SILU, 0)
+    case 2: FX_C3_TILE(FX_ACT_SILU, 2)
+    case 3: FX_C3_TILE(FX_ACT_NONE, 0)
+    default: return FX_ERR_UNSUPPORTED;
+  }
+#undef FX_C3_TILE
+}

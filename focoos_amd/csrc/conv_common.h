@@ -48,3 +48,8 @@ __device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, unsigned b
 // conv_igemm_dma.hip: 8-wave 256-row tiles fed by buffer_load ... lds DMA (deep-K, large-M layers)
 bool fx_conv_dma_eligible(const ConvArgs& a);
 int fx_launch_conv_dma(ConvArgs& a, hipStream_t stream);
+
+// conv3x3_flat.hip: 3x3 / stride 1 / pad 1 without im2col re-fetching (flat halo tile, loader wave, fragment-ordered weights)
+extern "C" int fx_conv3x3_flat_supported(int C, int N, int W);
+int fx_launch_conv3x3_flat(const ConvArgs& c, const bf16_t* w_frag, hipStream_t stream);
+int fx_c3_epilogue_mode(int act, bool has_res, int res_after);  // >= 0: epilogue variant the halo kernel has

@@ -272,6 +272,7 @@ bool fx_conv_dma_eligible(const ConvArgs& a) {
 }
 
 int fx_launch_conv_dma(ConvArgs& a, hipStream_t stream) {
-  if (a.N % 256 == 0) return launch_dma<256, 256, 2, 4>(a, stream);
+  static const int force_bn = fx_tune("FX_DMA_FORCE_BN", 0);
+  if (a.N % 256 == 0 && force_bn != 128) return launch_dma<256, 256, 2, 4>(a, stream);
   return launch_dma<256, 128, 4, 2>(a, stream);
 }

@@ -65,10 +65,10 @@ class NT:
 
 
 class PackedConv:
-    __slots__ = ("w", "b", "N", "C", "KH", "KW")
+    __slots__ = ("w", "b", "N", "C", "KH", "KW", "wf")
 
-    def __init__(self, w, b, N, Cc, KH, KW):
-        self.w, self.b, self.N, self.C, self.KH, self.KW = w, b, N, Cc, KH, KW
+    def __init__(self, w, b, N, Cc, KH, KW, wf=None):
+        self.w, self.b, self.N, self.C, self.KH, self.KW, self.wf = w, b, N, Cc, KH, KW, wf
 
 
 def _fold_bn(sd, conv_w_key: str, bn_prefix: str) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -108,7 +108,11 @@ class _EngineBase:
         b = torch.zeros(Np, dtype=torch.float32)
         if bias is not None:
             b[:N] = bias
-        return PackedConv(self._dev(w, torch.bfloat16), self._dev(b), N, Cc, KH, KW)
+        wf = None
+        if KH == 3 and KW == 3 and N in (64, 128, 256) and Cc % 64 == 0:
+            # second copy in MFMA fragment order for the halo kernel (fx_conv_desc.w_frag): k = (kh*3 + kw)*C + c
+            wf = self._pack_frag(W4.permute(0, 2, 3, 1).reshape(N, 9 * Cc))
+        return PackedConv(self._dev(w, torch.bfloat16), self._dev(b), N, Cc, KH, KW, wf)
 
     def _pack_frag(self, W2: torch.Tensor) -> torch.Tensor:
         """[N, K] weights in MFMA fragment order [N/32][K/16][lane][8] (include/focoos_amd.h, fx_pw_chain_desc): lane l of
@@ -437,6 +441,7 @@ class _PlanBase:
         d.pool2, d.act, d.out_f32 = int(pool2), FX_ACT[act], int(out_f32)
         d.residual_after_act = int(res_after)
         d.y_batch_stride = y_batch_stride
+        d.w_frag = pc.wf.data_ptr() if pc.wf is not None else None
         self.keep.append(d)
         # bookkeeping for bench.py: which template instance runs and the ALGORITHMIC flops of the reference layer(s)
         # this launch replaces (RepVGG 1x1 branch counted although it is re-parameterised away).
@@ -450,6 +455,9 @@ class _PlanBase:
             variant = "conv_igemm<64,64,256,1stage>"
         elif not pool2 and pc.C % 64 == 0 and ktot >= 1024 and M >= 40000 and pc.N % 128 == 0:  # fx_conv_dma_eligible
             variant = f"conv_igemm_dma<256,{256 if pc.N % 256 == 0 else 128}>"
+        if (pc.wf is not None and pc.KH == 3 and stride == 1 and not pool2 and not out_f32 and not y_batch_stride and M >= 40000
+                and int(os.environ.get("FX_CONV3_FLAT", "0")) and self.lib.fx_conv3x3_flat_supported(pc.C, pc.N, x.W) == 1):
+            variant = f"conv3x3_flat<{pc.N}>"
         self.meta[len(self.ops)] = {"kind": "conv", "variant": variant, "flops": flops,
                                     "name": name or "slice", "M": M, "N": pc.N, "K": pc.KH * pc.KW * pc.C}
         self._op(self.lib.fx_conv2d_nhwc_bf16, C.byref(d))

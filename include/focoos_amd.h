@@ -66,8 +66,15 @@ typedef struct fx_conv_desc {
                                *    producing layer fused into this (input-gradient) convolution of the training path */
   int64_t y_batch_stride;     /* elements between images of y; 0 = contiguous (Ho*Wo*ldy). Lets a level write its rows of
                                  the [B, sum(HW), C] decoder memory directly (modelling.py:1158-1165 flatten+concat for free) */
+  const void* w_frag;         /* optional second copy of w in MFMA fragment order, bf16 [N/32][KH*KW*C/16][64][8] with
+                                 Wp[nb][ks][l][i] = w[nb*32 + l%32][ks*16 + (l/32)*8 + i] (k = (kh*KW + kw)*C + c).  When present,
+                                 3x3 / stride-1 / pad-1 layers with N in {64,128,256}, C % 64 == 0 run on the halo kernel
+                                 (conv3x3_flat.hip: the pixels are fetched once for all nine taps).  NULL: implicit GEMM. */
 } fx_conv_desc;
 int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream);
+/* 1 iff fx_conv2d_nhwc_bf16 would run a 3x3/s1/p1 layer of C input / N output channels and image width W on the halo kernel
+ * (given w_frag): N in {64,128,256}, C % 64 == 0 and the halo tile fits the 160 KiB LDS. */
+int fx_conv3x3_flat_supported(int C, int N, int W);
 
 /* ------------------------------------------------------------------------------------------------
  * Back-to-back pointwise convolutions around the residual add of the ResNet-vd bottleneck, one launch, the block output

@@ -51,7 +51,7 @@ def pack_w(W4, bias):
 
 
 def run_conv(lib, x_nhwc, W4, bias, stride=1, act=None, residual=None, res_after=False, pool2=False, out_f32=False, ldx=None, ldy=None,
-             ybs=0, y_buf=None, y_off=0):
+             ybs=0, y_buf=None, y_off=0, frag=False):
     """x_nhwc: [B,H,W,C] float (will be rounded to bf16). Returns y [B,Ho,Wo,N] float32 (cpu)."""
     B, H, W, Cc = x_nhwc.shape
     N, _, KH, KW = W4.shape
@@ -75,6 +75,10 @@ def run_conv(lib, x_nhwc, W4, bias, stride=1, act=None, residual=None, res_after
     d.Ho, d.Wo, d.N, d.ldy = Ho, Wo, N, ldy
     d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
     d.pool2, d.act, d.out_f32, d.residual_after_act, d.y_batch_stride = int(pool2), FX_ACT[act], int(out_f32), int(res_after), ybs
+    wf = None
+    if frag:  # second weight copy in MFMA fragment order -> 3x3/s1 layers run on the halo kernel (conv3x3_flat.hip)
+        wf = frag_pack(W4.permute(0, 2, 3, 1).reshape(N, KH * KW * Cc))
+        d.w_frag = wf.data_ptr()
     check(lib.fx_conv2d_nhwc_bf16(C.byref(d), stream()), "conv")
     torch.cuda.synchronize()
     return yd.float().cpu()
@@ -586,3 +590,36 @@ def test_enc_score_head_fused(lib, M, S, K):
     # and against the all-fp32 pipeline (what the reference computes): only output_memory's bf16 rounding in between
     full = (y @ bf(W2).float().T + b2).max(-1).values
     assert (got_sc - full).abs().max().item() <= 3e-2
+
+
+# 3x3 / stride 1 layers on the halo kernel (conv3x3_flat.hip): B,H,W,C,N,act,residual-after-act,ldx pad
+FLAT_CASES = [
+    (2, 24, 20, 64, 64, "relu", False, 0),      # res2 branch2b class: one channel chunk, M = 960 (partial last tile)
+    (1, 17, 13, 64, 64, "relu", False, 8),      # odd sizes, M = 221 < one tile, strided input rows
+    (3, 16, 16, 128, 128, "relu", False, 0),    # two chunks (double-buffered halo), 256 x 128 tile
+    (2, 9, 33, 128, 64, None, False, 0),        # N = 64 with two chunks, no activation
+    (1, 12, 80, 256, 128, "silu", False, 0),    # W = 80 (the 80x80 level), four chunks
+    (2, 20, 20, 256, 256, "silu", True, 0),     # RepVGG / CSP: SiLU then + residual, 128 x 256 tile, image boundary inside a tile
+    (1, 40, 40, 256, 256, "silu", False, 0),
+    (5, 6, 7, 64, 256, "relu", False, 0),       # several tiny images per tile: every tap crosses image borders
+]
+
+
+@pytest.mark.parametrize("case", FLAT_CASES)
+def test_conv3x3_flat_halo_kernel(lib, case, monkeypatch):
+    B, H, W, Cc, N, act, res_after, pad = case
+    assert lib.fx_conv3x3_flat_supported(Cc, N, W) == 1
+    g = torch.Generator().manual_seed(300 + FLAT_CASES.index(case))
+    # position-dependent input: a wrong tap offset / border mask is an O(1) error, not noise
+    x = torch.randn(B, H, W, Cc, generator=g) + torch.linspace(-1, 1, W)[None, None, :, None] + torch.linspace(-0.5, 0.5, H)[None, :, None, None]
+    W4 = torch.randn(N, Cc, 3, 3, generator=g) / math.sqrt(Cc * 9) + torch.linspace(-0.03, 0.03, 9).view(1, 1, 3, 3)
+    bias = torch.randn(N, generator=g) * 0.5
+    res = torch.randn(B, H, W, N, generator=g) if res_after else None
+    ref = ref_conv(x, W4, bias, 1, act, res, res_after, False)
+    got = run_conv(lib, x, W4, bias, 1, act, res, res_after, ldx=Cc + pad, frag=True)[..., :N]
+    assert not torch.isnan(got).any()
+    err = (got - ref).abs().max() / ref.abs().max()
+    assert err < 1.2e-2, f"rel err {err}"
+    # same layer through the implicit-GEMM kernel: the two agree to bf16 rounding of the output
+    igemm = run_conv(lib, x, W4, bias, 1, act, res, res_after, ldx=Cc + pad, frag=False)[..., :N]
+    assert (got - igemm).abs().max() / ref.abs().max() < 1.2e-2
