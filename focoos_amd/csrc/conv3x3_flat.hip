@@ -14,6 +14,8 @@
 //     from L2 into a register ring;
 //   * epilogue: bias (accumulator init) + activation (+ residual, either side of the activation) in the accumulator layout
 //     on an LDS tile, then 16-byte coalesced stores.
+#include <type_traits>
+
 #include "pw_common.h"
 
 struct C3Args {
@@ -28,6 +30,31 @@ struct C3Args {
   unsigned x_bytes, r_bytes;
 };
 
+// Weight-fragment loads hidden from hipcc's waitcnt bookkeeping (guide 5.7 form ii): hipcc opens every iteration of a loop that
+// carries register loads with s_waitcnt vmcnt(0), which would expose one L2 round trip per filter tap.  The load is an asm
+// statement on a read-write operand (the ring slot keeps ONE register across the loop: no compiler copy of a value that has
+// not landed), and c3_wait<N> names the fragments an MFMA is about to read, after a counted wait: loads return in order, and
+// between a slot's refill and its use exactly (KJ-1)*TN younger refills are issued.
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void c3_static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    c3_static_for<N, I + 1>(f);
+  }
+}
+template <int OFF = 0>
+__device__ __forceinline__ void c3_ldg_async(bf16x8& dst, const bf16_t* ptr) {
+  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "+v"(dst) : "v"(ptr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void c3_wait(bf16x8& f0) {
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(f0) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void c3_wait(bf16x8& f0, bf16x8& f1) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(f0), "+v"(f1) : "n"(N));
+}
+
 template <int CC, int TN, int TM, int WN, int WM, int ACT, int RESMODE>
 __global__ __launch_bounds__((WN* WM + 1) * 64, 1) void conv3x3_flat_kernel(const C3Args p) {
   constexpr int NW = WN * WM, NT = (NW + 1) * 64;
@@ -35,7 +62,7 @@ __global__ __launch_bounds__((WN* WM + 1) * 64, 1) void conv3x3_flat_kernel(cons
   constexpr int RL = CC / 8, ROWB = CC * 2, KJ = CC / 16, STEPS = 9 * KJ;
   constexpr int PF = KJ;  // weight-fragment ring: one slot per k-step of a tap, refilled for the next tap
   constexpr int RLT = BN / 8;
-  static_assert(KJ % 2 == 0, "the B double buffer returns to slot 0 at every tap");
+  static_assert(TN <= 2 && KJ % 2 == 0, "the B double buffer returns to slot 0 at every tap");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -78,6 +105,7 @@ __global__ __launch_bounds__((WN* WM + 1) * 64, 1) void conv3x3_flat_kernel(cons
   // below): keeping them in one loop makes the register allocator carry the 128 accumulator registers through the loader's
   // branch and spill them at every chunk boundary.
   if (is_loader) {
+    if (lane < 8) *reinterpret_cast<uint4*>(smem + (NCH > 1 ? 2 : 1) * buf_bytes + lane * 16) = make_uint4(0, 0, 0, 0);  // the zero row (published by the first barrier)
     dma_chunk(0, smem);
     for (int cc = 0; cc < NCH; ++cc) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -130,51 +158,83 @@ __global__ __launch_bounds__((WN* WM + 1) * 64, 1) void conv3x3_flat_kernel(cons
 #pragma unroll
     for (int i = 0; i < PF; ++i)
 #pragma unroll
-      for (int a = 0; a < TN; ++a) ar[i][a] = pw_ldg_frag(a_ptr(a, 0, i));
+      for (int a = 0; a < TN; ++a) {
+        ar[i][a] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        c3_ldg_async(ar[i][a], a_ptr(a, 0, i));
+      }
+    const int zrow = (NCH > 1 ? 2 : 1) * buf_bytes;  // 128 zero bytes behind the halo buffers: where a masked (pixel, tap) reads its operand from
+    // per-lane constants of the k16 steps: byte offset of the lane's 16-byte chunk before the row swizzle
+    int hc[KJ];
+#pragma unroll
+    for (int j = 0; j < KJ; ++j) hc[j] = (j * 2 + half) << 4;
+    constexpr int SWM = (RL >= 8 ? 0x70 : 0x30);   // row swizzle as a byte mask: ((r>>1)&7)<<4 = (r<<3)&0x70, ((r>>2)&3)<<4 = (r<<2)&0x30
+    constexpr int SWS = (RL >= 8 ? 3 : 2);
+    // Per (tap, block): row byte address `ra` and swizzle `sw`; an invalid (pixel, tap) - image border, or the neighbouring image
+    // the blindly loaded halo contains - is redirected to the 128-byte zero row (ra = zrow, sw = 0): two selects per tap and
+    // block, nothing to do per k-step or once the data is back.  A fragment address is then ONE v_xad (xor + add).
+    auto tap_setup = [&](int t, int toff, int bufo, int (&ra)[TM], int (&sw)[TM]) {
+#pragma unroll
+      for (int b = 0; b < TM; ++b) {
+        const int r = rbase[b] + toff;
+        const bool ok = (mask9[b] >> t) & 1u;
+        ra[b] = ok ? bufo + r * ROWB : zrow;
+        sw[b] = ok ? ((r << SWS) & SWM) : 0;
+      }
+    };
     for (int cc = 0; cc < NCH; ++cc) {
       __syncthreads();  // chunk cc has landed; every consumer is done with chunk cc-1 (the other buffer)
-      const unsigned char* buf = smem + (cc & 1) * buf_bytes;
+      const int bufo = (cc & 1) * buf_bytes;
       const int ccn = cc + 1 < NCH ? cc + 1 : cc;
-      // B fragment of block b: tap t (flat offset toff), k16 step j of the chunk; image borders masked in registers
-      auto load_b = [&](int b, int t, int toff, int j) -> bf16x8 {
-        const int r = rbase[b] + toff;
-        const int sw = (RL >= 8 ? ((r >> 1) & 7) : ((r >> 2) & 3));
-        bf16x8 v = *reinterpret_cast<const bf16x8*>(buf + r * ROWB + (((j * 2 + half) ^ sw) << 4));
-        const bool ok = (mask9[b] >> t) & 1u;
-        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-        return ok ? v : z;
-      };
+      int ra[TM], sw[TM];
+      tap_setup(0, -p.W - 1, bufo, ra, sw);
       bf16x8 xb[2][TM];
 #pragma unroll
-      for (int b = 0; b < TM; ++b) xb[0][b] = load_b(b, 0, -p.W - 1, 0);
+      for (int b = 0; b < TM; ++b) xb[0][b] = *reinterpret_cast<const bf16x8*>(smem + ((hc[0] ^ sw[b]) + ra[b]));
       // The tap loop is a real loop (one ring cycle of KJ k-steps per tap): fully unrolled, hipcc hoists 36 steps' worth of
       // addresses and loads and spills hundreds of registers.
 #pragma unroll 1
       for (int t = 0; t < 9; ++t) {
-        const int toff = (t / 3 - 1) * p.W + (t % 3 - 1);
         const int tn = t + 1;
-        const int toff_n = (tn / 3 - 1) * p.W + (tn % 3 - 1);
         const bool last_tap = t == 8;
+        // weight fragments to request during this tap: the same k-steps of the next tap (tap 0 of the next chunk after the last
+        // tap; last chunk: a harmless re-read) - one base pointer per n-block, the k-step is an immediate offset
+        const bf16_t* wnext[TN];
 #pragma unroll
-        for (int j = 0; j < KJ; ++j) {
+        for (int a = 0; a < TN; ++a) wnext[a] = a_ptr(a, last_tap ? ccn : cc, last_tap ? 0 : tn * KJ);
+        int ran[TM], swn[TM];
+        tap_setup(last_tap ? 0 : tn, last_tap ? 0 : (tn / 3 - 1) * p.W + (tn % 3 - 1), bufo, ran, swn);
+        auto kstep = [&](auto jc) {   // j must be a compile-time constant: it is the immediate offset of the asm weight loads
+          constexpr int j = decltype(jc)::value;
+          // next k-step's pixel fragments: requested BEFORE this step's MFMAs (their LDS latency hides under them)
           if (j + 1 < KJ) {
 #pragma unroll
-            for (int b = 0; b < TM; ++b) xb[(j + 1) & 1][b] = load_b(b, t, toff, j + 1);
+            for (int b = 0; b < TM; ++b) xb[(j + 1) & 1][b] = *reinterpret_cast<const bf16x8*>(smem + ((hc[j + 1] ^ sw[b]) + ra[b]));
           } else if (!last_tap) {
 #pragma unroll
-            for (int b = 0; b < TM; ++b) xb[0][b] = load_b(b, tn, toff_n, 0);
+            for (int b = 0; b < TM; ++b) xb[0][b] = *reinterpret_cast<const bf16x8*>(smem + ((hc[0] ^ swn[b]) + ran[b]));
           }
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (TN == 1) c3_wait<(KJ - 1) * TN>(ar[j][0]); else c3_wait<(KJ - 1) * TN>(ar[j][0], ar[j][1]);
 #pragma unroll
           for (int a = 0; a < TN; ++a)
 #pragma unroll
             for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j][a], xb[j & 1][b], acc[a][b], 0, 0, 0);
-          // this ring slot is next used by the same k-step of the next tap (or of tap 0 of the next chunk; last chunk: a harmless re-read)
-          const int s_next = last_tap ? j : tn * KJ + j;
-          const int c_next = last_tap ? ccn : cc;
 #pragma unroll
-          for (int a = 0; a < TN; ++a) ar[j][a] = pw_ldg_frag(a_ptr(a, c_next, s_next));
+          for (int a = 0; a < TN; ++a) c3_ldg_async<j * 1024>(ar[j][a], wnext[a]);
+          __builtin_amdgcn_sched_barrier(0);
+        };
+        c3_static_for<KJ>(kstep);
+#pragma unroll
+        for (int b = 0; b < TM; ++b) {
+          ra[b] = ran[b];
+          sw[b] = swn[b];
         }
       }
+    }
+    // drain the hidden loads before their registers are reused by the epilogue
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      if constexpr (TN == 1) c3_wait<0>(ar[i][0]); else c3_wait<0>(ar[i][0], ar[i][1]);
     }
     __syncthreads();  // E1
     if constexpr (RESMODE != 0) __syncthreads();  // E2
@@ -225,8 +285,7 @@ static int launch_c3(C3Args& a, hipStream_t stream) {
   constexpr int RPI = 64 / RL;  // halo rows per DMA instruction
   const int HL = BM + 2 * a.W + 2;
   a.HLp = (HL + RPI - 1) / RPI * RPI;
-  const int nbuf = a.C / CC > 1 ? 2 : 1;
-  const int halo = nbuf * a.HLp * CC * 2, tile = BM * BN * 2;
+  const int halo = (a.C / CC > 1 ? 2 : 1) * a.HLp * CC * 2 + 128, tile = BM * BN * 2;  // chunk buffer(s) + the zero row
   const int smem = halo > tile ? halo : tile;
   if (smem > 160 * 1024) return FX_ERR_UNSUPPORTED;
   auto kern = conv3x3_flat_kernel<CC, TN, TM, WN, WM, ACT, RESMODE>;
@@ -250,7 +309,7 @@ extern "C" int fx_conv3x3_flat_supported(int C, int N, int W) {
   if (C % 64 != 0 || !(N == 64 || N == 128 || N == 256)) return 0;
   const int BM = N == 256 ? 128 : 256;
   const int HLp = (BM + 2 * W + 2 + 7) / 8 * 8;
-  const int halo = (C / 64 > 1 ? 2 : 1) * HLp * 128, tile = BM * N * 2;
+  const int halo = (C / 64 > 1 ? 2 : 1) * HLp * 128 + 128, tile = BM * N * 2;
   return (halo > tile ? halo : tile) <= 160 * 1024 ? 1 : 0;
 }
 

@@ -307,7 +307,7 @@ extern "C" int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream_) {
   a.w_bytes = (unsigned)w_bytes;
   a.r_bytes = (unsigned)r_bytes;
   // 3x3 / stride 1 layers with a fragment-ordered weight copy: halo kernel (pixels fetched once for all nine taps)
-  static const int c3_on = fx_tune("FX_CONV3_FLAT", 0), c3_min_m = fx_tune("FX_CONV3_MIN_M", 40000);
+  static const int c3_on = fx_tune("FX_CONV3_FLAT", 1), c3_min_m = fx_tune("FX_CONV3_MIN_M", 40000);
   if (c3_on && d->w_frag && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && !d->pool2 && !d->out_f32 && !d->y_batch_stride &&
       fx_c3_epilogue_mode(d->act, d->residual != nullptr, d->residual_after_act) >= 0 && a.M >= c3_min_m && ((uintptr_t)d->w_frag % 16) == 0 && fx_conv3x3_flat_supported(d->C, d->N, d->W))
     return fx_launch_conv3x3_flat(a, reinterpret_cast<const bf16_t*>(d->w_frag), stream);

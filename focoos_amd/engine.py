@@ -456,7 +456,7 @@ class _PlanBase:
         elif not pool2 and pc.C % 64 == 0 and ktot >= 1024 and M >= 40000 and pc.N % 128 == 0:  # fx_conv_dma_eligible
             variant = f"conv_igemm_dma<256,{256 if pc.N % 256 == 0 else 128}>"
         if (pc.wf is not None and pc.KH == 3 and stride == 1 and not pool2 and not out_f32 and not y_batch_stride and M >= 40000
-                and int(os.environ.get("FX_CONV3_FLAT", "0")) and self.lib.fx_conv3x3_flat_supported(pc.C, pc.N, x.W) == 1):
+                and int(os.environ.get("FX_CONV3_FLAT", "1")) and self.lib.fx_conv3x3_flat_supported(pc.C, pc.N, x.W) == 1):
             variant = f"conv3x3_flat<{pc.N}>"
         self.meta[len(self.ops)] = {"kind": "conv", "variant": variant, "flops": flops,
                                     "name": name or "slice", "M": M, "N": pc.N, "K": pc.KH * pc.KW * pc.C}
