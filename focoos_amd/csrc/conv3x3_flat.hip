@@ -205,23 +205,29 @@ __global__ __launch_bounds__((WN* WM + 1) * 64, 1) void conv3x3_flat_kernel(cons
         tap_setup(last_tap ? 0 : tn, last_tap ? 0 : (tn / 3 - 1) * p.W + (tn % 3 - 1), bufo, ran, swn);
         auto kstep = [&](auto jc) {   // j must be a compile-time constant: it is the immediate offset of the asm weight loads
           constexpr int j = decltype(jc)::value;
-          // next k-step's pixel fragments: requested BEFORE this step's MFMAs (their LDS latency hides under them)
-          if (j + 1 < KJ) {
-#pragma unroll
-            for (int b = 0; b < TM; ++b) xb[(j + 1) & 1][b] = *reinterpret_cast<const bf16x8*>(smem + ((hc[j + 1] ^ sw[b]) + ra[b]));
-          } else if (!last_tap) {
-#pragma unroll
-            for (int b = 0; b < TM; ++b) xb[0][b] = *reinterpret_cast<const bf16x8*>(smem + ((hc[0] ^ swn[b]) + ran[b]));
-          }
-          __builtin_amdgcn_sched_barrier(0);
+          constexpr bool tap_end = j + 1 == KJ;
           if constexpr (TN == 1) c3_wait<(KJ - 1) * TN>(ar[j][0]); else c3_wait<(KJ - 1) * TN>(ar[j][0], ar[j][1]);
+          // One wave per SIMD issues in order: an MFMA occupies the matrix pipe for 32 cycles but only 4 issue cycles, so the
+          // other work of the step is INTERLEAVED between the MFMAs (pinned with sched_barrier: left alone, hipcc groups the 8
+          // MFMAs back to back and the wave's address / LDS / load instructions wait behind them):
+          //   after MFMA (a=0, b): the next k-step's pixel fragment b (address = one xor + add, then ds_read_b128) - it has
+          //   the remaining MFMAs of this step to land; after the last MFMA of n-block a: the refill of its weight-ring slot.
 #pragma unroll
-          for (int a = 0; a < TN; ++a)
+          for (int a = 0; a < TN; ++a) {
 #pragma unroll
-            for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j][a], xb[j & 1][b], acc[a][b], 0, 0, 0);
-#pragma unroll
-          for (int a = 0; a < TN; ++a) c3_ldg_async<j * 1024>(ar[j][a], wnext[a]);
-          __builtin_amdgcn_sched_barrier(0);
+            for (int b = 0; b < TM; ++b) {
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j][a], xb[j & 1][b], acc[a][b], 0, 0, 0);
+              if (a == 0) {
+                if constexpr (!tap_end) {
+                  xb[(j + 1) & 1][b] = *reinterpret_cast<const bf16x8*>(smem + ((hc[tap_end ? 0 : j + 1] ^ sw[b]) + ra[b]));
+                } else {
+                  if (!last_tap) xb[0][b] = *reinterpret_cast<const bf16x8*>(smem + ((hc[0] ^ swn[b]) + ran[b]));
+                }
+              }
+              if (b == TM - 1) c3_ldg_async<j * 1024>(ar[j][a], wnext[a]);
+              __builtin_amdgcn_sched_barrier(0);
+            }
+          }
         };
         c3_static_for<KJ>(kstep);
 #pragma unroll
