@@ -306,11 +306,19 @@ extern "C" int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream_) {
   a.x_bytes = (unsigned)x_bytes;
   a.w_bytes = (unsigned)w_bytes;
   a.r_bytes = (unsigned)r_bytes;
-  // 3x3 / stride 1 layers with a fragment-ordered weight copy: halo kernel (pixels fetched once for all nine taps)
+  // Layers with a fragment-ordered weight copy: 3x3 / stride 1 -> halo kernel (pixels fetched once for all nine taps);
+  // 1x1 with C, N multiples of 256 -> the same machinery with 256-channel LDS rows (conv3x3_flat.hip)
   static const int c3_on = fx_tune("FX_CONV3_FLAT", 1), c3_min_m = fx_tune("FX_CONV3_MIN_M", 40000);
-  if (c3_on && d->w_frag && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && !d->pool2 && !d->out_f32 && !d->y_batch_stride &&
-      fx_c3_epilogue_mode(d->act, d->residual != nullptr, d->residual_after_act) >= 0 && a.M >= c3_min_m && ((uintptr_t)d->w_frag % 16) == 0 && fx_conv3x3_flat_supported(d->C, d->N, d->W))
-    return fx_launch_conv3x3_flat(a, reinterpret_cast<const bf16_t*>(d->w_frag), stream);
+  static const int pw_on = fx_tune("FX_PW_FLAT", 1), pw_min_m = fx_tune("FX_PW_MIN_M", 40000);
+  if (d->w_frag && ((uintptr_t)d->w_frag % 16) == 0 && d->stride == 1 && !d->pool2 && !d->out_f32) {
+    const int mode = fx_c3_epilogue_mode(d->act, d->residual != nullptr, d->residual_after_act);
+    if (c3_on && d->KH == 3 && d->KW == 3 && d->pad == 1 && !d->y_batch_stride && mode >= 0 && mode <= 3 && a.M >= c3_min_m &&
+        fx_conv3x3_flat_supported(d->C, d->N, d->W))
+      return fx_launch_conv3x3_flat(a, reinterpret_cast<const bf16_t*>(d->w_frag), stream);
+    if (pw_on && d->KH == 1 && d->KW == 1 && d->pad == 0 && d->C % 256 == 0 && d->N % 256 == 0 && a.M >= pw_min_m &&
+        (mode == 0 || mode == 1 || mode == 3 || mode == 4))
+      return fx_launch_pw_flat(a, reinterpret_cast<const bf16_t*>(d->w_frag), stream);
+  }
   // BK=64 (2 workgroups/CU, 64 KiB LDS) for deep-K compute-bound layers; BK=32 (4 workgroups/CU, 34 KiB LDS: more
   // tiles and bytes in flight per CU) for the short-K layers, which are HBM/latency-bound.
   static const int k64_min = fx_tune("FX_K64_MIN_KTOT", FX_K64_MIN_KTOT);

@@ -109,9 +109,10 @@ class _EngineBase:
         if bias is not None:
             b[:N] = bias
         wf = None
-        if KH == 3 and KW == 3 and N in (64, 128, 256) and Cc % 64 == 0:
-            # second copy in MFMA fragment order for the halo kernel (fx_conv_desc.w_frag): k = (kh*3 + kw)*C + c
-            wf = self._pack_frag(W4.permute(0, 2, 3, 1).reshape(N, 9 * Cc))
+        if (KH == 3 and KW == 3 and N in (64, 128, 256) and Cc % 64 == 0) or (KH == 1 and KW == 1 and N % 256 == 0 and Cc % 256 == 0):
+            # second copy in MFMA fragment order (fx_conv_desc.w_frag) for the halo / pointwise kernels of conv3x3_flat.hip:
+            # k = (kh*KW + kw)*C + c
+            wf = self._pack_frag(W4.permute(0, 2, 3, 1).reshape(N, KH * KW * Cc))
         return PackedConv(self._dev(w, torch.bfloat16), self._dev(b), N, Cc, KH, KW, wf)
 
     def _pack_frag(self, W2: torch.Tensor) -> torch.Tensor:
@@ -458,6 +459,9 @@ class _PlanBase:
         if (pc.wf is not None and pc.KH == 3 and stride == 1 and not pool2 and not out_f32 and not y_batch_stride and M >= 40000
                 and int(os.environ.get("FX_CONV3_FLAT", "1")) and self.lib.fx_conv3x3_flat_supported(pc.C, pc.N, x.W) == 1):
             variant = f"conv3x3_flat<{pc.N}>"
+        elif (pc.wf is not None and pc.KH == 1 and stride == 1 and not pool2 and not out_f32 and M >= 40000 and pc.C % 256 == 0 and pc.N % 256 == 0
+                and int(os.environ.get("FX_PW_FLAT", "1")) and not (residual is not None and res_after) and act != "gelu"):
+            variant = f"pw_flat<K{pc.C}>"
         self.meta[len(self.ops)] = {"kind": "conv", "variant": variant, "flops": flops,
                                     "name": name or "slice", "M": M, "N": pc.N, "K": pc.KH * pc.KW * pc.C}
         self._op(self.lib.fx_conv2d_nhwc_bf16, C.byref(d))

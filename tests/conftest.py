@@ -11,6 +11,7 @@ if ROOT not in sys.path:
 # The halo 3x3 kernel is routed to from M >= 40000 pixels in production (smaller layers do not fill the chip); the parity
 # tests run small shapes through it too.  Read once by the library at its first convolution call.
 os.environ.setdefault("FX_CONV3_MIN_M", "0")
+os.environ.setdefault("FX_PW_MIN_M", "0")
 
 
 def pytest_configure(config):

@@ -623,3 +623,45 @@ def test_conv3x3_flat_halo_kernel(lib, case, monkeypatch):
     # same layer through the implicit-GEMM kernel: the two agree to bf16 rounding of the output
     igemm = run_conv(lib, x, W4, bias, 1, act, res, res_after, ldx=Cc + pad, frag=False)[..., :N]
     assert (got - igemm).abs().max() / ref.abs().max() < 1.2e-2
+
+
+# 1x1 layers with C, N multiples of 256 on the pointwise variant of the same kernel: B,H,W,C,N,act,residual(before act)
+PW_FLAT_CASES = [
+    (1, 1, 300, 256, 256, None, False),
+    (2, 20, 20, 256, 1024, "relu", True),      # res4 branch2c: ReLU(conv + residual), four 256-channel output tiles
+    (1, 1, 1000, 512, 512, "silu", False),     # CSP conv1|conv2: two K chunks (double-buffered), M tail
+    (1, 37, 11, 1024, 256, "relu", False),     # res4 branch2a: four K chunks
+    (1, 1, 777, 256, 1536, None, False),       # the six value_proj's as one GEMM
+]
+
+
+@pytest.mark.parametrize("case", PW_FLAT_CASES)
+def test_pointwise_flat_kernel(lib, case):
+    B, H, W, Cc, N, act, has_res = case
+    g = torch.Generator().manual_seed(400 + PW_FLAT_CASES.index(case))
+    x = torch.randn(B, H, W, Cc, generator=g) + torch.linspace(-1, 1, Cc)[None, None, None, :]
+    W4 = torch.randn(N, Cc, 1, 1, generator=g) / math.sqrt(Cc) + torch.linspace(-0.02, 0.02, N).view(N, 1, 1, 1)
+    bias = torch.randn(N, generator=g) * 0.5
+    res = torch.randn(B, H, W, N, generator=g) if has_res else None
+    ref = ref_conv(x, W4, bias, 1, act, res, False, False)
+    got = run_conv(lib, x, W4, bias, 1, act, res, False, frag=True)[..., :N]
+    assert not torch.isnan(got).any()
+    err = (got - ref).abs().max() / ref.abs().max()
+    assert err < 1.2e-2, f"rel err {err}"
+    igemm = run_conv(lib, x, W4, bias, 1, act, res, False, frag=False)[..., :N]
+    assert (got - igemm).abs().max() / ref.abs().max() < 1.2e-2
+
+
+def test_pointwise_flat_batch_stride(lib):
+    """y_batch_stride (a level writing its rows of the [B, sum(HW), C] decoder memory) through the pointwise kernel."""
+    B, H, W, Cc, N, S = 3, 5, 8, 256, 256, 100
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, H, W, Cc, generator=g)
+    W4 = torch.randn(N, Cc, 1, 1, generator=g) / 16
+    bias = torch.randn(N, generator=g)
+    buf = torch.full((B, S, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    run_conv(lib, x, W4, bias, ybs=S * N, y_buf=buf, y_off=20 * N, frag=True)
+    got = buf.float().cpu()
+    ref = ref_conv(x, W4, bias).reshape(B, H * W, N)
+    assert torch.isnan(got[:, :20]).all() and torch.isnan(got[:, 20 + H * W:]).all()
+    assert (got[:, 20:20 + H * W] - ref).abs().max() / ref.abs().max() < 1.2e-2
