@@ -38,6 +38,15 @@ class FxPwChainDesc(C.Structure):
     ]
 
 
+class FxRcStage(C.Structure):
+    _fields_ = [
+        ("type", C.c_int32), ("K", C.c_int32), ("N", C.c_int32), ("act", C.c_int32),
+        ("src", C.c_int32), ("dst", C.c_int32), ("aux", C.c_int32),
+        ("ld", C.c_int32), ("ld2", C.c_int32), ("flags", C.c_int32),
+        ("w", C.c_void_p), ("bias", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p), ("g0", C.c_void_p), ("g1", C.c_void_p),
+    ]
+
+
 _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 
 # name -> argtypes (every function returns int unless noted); mirrors include/focoos_amd.h
@@ -67,6 +76,7 @@ SIGNATURES = {
     "fx_msda_bf16": [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "fx_rowmax_f32": [_vp, _i, _vp, _i, _i, _vp],
     "fx_enc_score_head_bf16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp, _i, _vp, _i, _vp],
+    "fx_row_chain": [_vp, _i, _i, _i, _vp],
     "fx_topk_rows_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "fx_gather_rows_bf16": [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp],
     "fx_fill_rows_bf16": [_vp, _i, _i, _vp, _i, _vp, _i, _i, _vp],

@@ -32,31 +32,6 @@ struct C3Args {
   unsigned x_bytes, r_bytes;
 };
 
-// Weight-fragment loads hidden from hipcc's waitcnt bookkeeping (guide 5.7 form ii): hipcc opens every iteration of a loop that
-// carries register loads with s_waitcnt vmcnt(0), which would expose one L2 round trip per filter tap.  The load is an asm
-// statement on a read-write operand (the ring slot keeps ONE register across the loop: no compiler copy of a value that has
-// not landed), and c3_wait<N> names the fragments an MFMA is about to read, after a counted wait: loads return in order, and
-// between a slot's refill and its use exactly (KJ-1)*TN younger refills are issued.
-template <int N, int I = 0, typename F>
-__device__ __forceinline__ void c3_static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    c3_static_for<N, I + 1>(f);
-  }
-}
-template <int OFF = 0>
-__device__ __forceinline__ void c3_ldg_async(bf16x8& dst, const bf16_t* ptr) {
-  asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "+v"(dst) : "v"(ptr), "n"(OFF) : "memory");
-}
-template <int N>
-__device__ __forceinline__ void c3_wait(bf16x8& f0) {
-  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(f0) : "n"(N));
-}
-template <int N>
-__device__ __forceinline__ void c3_wait(bf16x8& f0, bf16x8& f1) {
-  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(f0), "+v"(f1) : "n"(N));
-}
-
 // KT = 9: 3x3 / stride 1 / pad 1, LDS rows of CC = 64 channels, nine taps = nine flat row offsets.
 // KT = 1: pointwise (1x1) layer on the same machinery: LDS rows of CC = 256 channels, the "taps" are the CC/64 channel
 //         quarters of a row (column offsets instead of row offsets), no halo, no border masks.

@@ -28,7 +28,7 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import FX_ACT, FxConvDesc, FxPwChainDesc, check
+from ._lib import FX_ACT, FxConvDesc, FxPwChainDesc, FxRcStage, check
 from .state_spec import RESNET_BLOCKS
 
 BN_EPS = 1e-5
@@ -285,6 +285,35 @@ class DetrEngine(_EngineBase):
         P[f"{hp}.value_all"] = self._pack_linear(torch.cat(vw, 0), torch.cat(vb, 0))
         last = self.nl - 1
         P[f"{hp}.dec_score"] = self._pack_linear(sd[f"{hp}.dec_score_classifier.{last}.weight"], sd[f"{hp}.dec_score_classifier.{last}.bias"])
+        # fragment-ordered copies of the decoder's row-local linears for fx_row_chain (one launch per chain of layers)
+        RC: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+        def rc(key, W, b, pad_to=None):
+            W, b = W.float(), b.float()
+            if pad_to is not None and W.shape[0] < pad_to:
+                W = torch.cat([W, torch.zeros(pad_to - W.shape[0], W.shape[1])], 0)
+                b = torch.cat([b, torch.zeros(pad_to - b.shape[0])], 0)
+            RC[key] = (self._pack_frag(W), self._dev(b))
+
+        rc("qpos1", sd[f"{hp}.query_pos_head.layers.1.weight"], sd[f"{hp}.query_pos_head.layers.1.bias"])
+        for li in range(self.nl):
+            p = f"{hp}.decoder.layers.{li}"
+            Wi, bi_ = sd[f"{p}.self_attn.in_proj_weight"], sd[f"{p}.self_attn.in_proj_bias"]
+            rc(f"{li}.qk", Wi[:512], bi_[:512])
+            rc(f"{li}.v", Wi[512:], bi_[512:])
+            rc(f"{li}.o", sd[f"{p}.self_attn.out_proj.weight"], sd[f"{p}.self_attn.out_proj.bias"])
+            ca = f"{p}.cross_attn"
+            rc(f"{li}.offaw", torch.cat([sd[f"{ca}.sampling_offsets.weight"], sd[f"{ca}.attention_weights.weight"]], 0),
+               torch.cat([sd[f"{ca}.sampling_offsets.bias"], sd[f"{ca}.attention_weights.bias"]], 0))
+            rc(f"{li}.o2", sd[f"{ca}.output_proj.weight"], sd[f"{ca}.output_proj.bias"])
+            rc(f"{li}.f1", sd[f"{p}.linear1.weight"], sd[f"{p}.linear1.bias"])
+            rc(f"{li}.f2", sd[f"{p}.linear2.weight"], sd[f"{p}.linear2.bias"])
+            bb = f"{hp}.dec_bbox_classifier.{li}"
+            rc(f"{li}.bb0", sd[f"{bb}.layers.0.weight"], sd[f"{bb}.layers.0.bias"])
+            rc(f"{li}.bb1", sd[f"{bb}.layers.1.weight"], sd[f"{bb}.layers.1.bias"])
+        self.nc_pad32 = (self.nc + 31) // 32 * 32
+        rc("score", sd[f"{hp}.dec_score_classifier.{last}.weight"], sd[f"{hp}.dec_score_classifier.{last}.bias"], pad_to=self.nc_pad32)
+        self.RC = RC
         self.P = P
         self.plans.clear()
 
@@ -728,6 +757,32 @@ class _Plan(_PlanBase):
         self._op(lib.fx_bbox_head, hb.ptr, hb.ld, wl.data_ptr(), bl.data_ptr(), None, self.anchors.data_ptr(), self.enc_topk.data_ptr(), Q, 1,
                  refs[0].data_ptr(), self.ref_unact.data_ptr(), R, 256)
         value = self.linear(mem_rows, P[f"{hp}.value_all"], name="value_all")
+        if int(os.environ.get("FX_ROW_CHAIN", "1")) != 0 and e.hd == 256:
+            logits = self._build_decoder_row_chain(tgt, refs, value, R, B, Q, S)
+        else:
+            logits = self._build_decoder_per_op(tgt, refs, value, R, B, Q, S)
+        self.refs = refs
+        self.probs = self._io("probs", (B, Q, K), torch.float32)
+        self.boxes = self._io("boxes", (B, Q, 4), torch.float32)
+        self._op(lib.fx_detr_head_out, logits.ptr, logits.ld, refs[e.nl].data_ptr(), self.probs.data_ptr(), self.boxes.data_ptr(), R, K)
+        # ---- device side of DETRProcessor.postprocess (processor.py:146-151,183-197)
+        tk = min(e.top_k, Q * K)
+        self.top_k = tk
+        self.det_scores = self._io("det_scores", (B, tk), torch.float32)
+        self.det_flat = self._io("det_flat", (B, tk), torch.int32)
+        self.det_labels = self._io("det_labels", (B, tk), torch.int32)
+        self.det_queries = self._io("det_queries", (B, tk), torch.int32)
+        self.det_boxes = self._io("det_boxes", (B, tk, 4), torch.int32)
+        self.det_count = self._io("det_count", (B,), torch.int32)
+        self._op(lib.fx_topk_rows_f32, self.probs.data_ptr(), Q * K, B, Q * K, tk, self.det_scores.data_ptr(), self.det_flat.data_ptr())
+        self.post_index = len(self.ops)
+        self._op(lib.fx_detr_postprocess, self.det_scores.data_ptr(), self.det_flat.data_ptr(), self.boxes.data_ptr(), self.sizes.data_ptr(), B, Q,
+                 K, tk, None, self.det_labels.data_ptr(), self.det_queries.data_ptr(), self.det_boxes.data_ptr(), self.det_count.data_ptr())
+
+    def _build_decoder_per_op(self, tgt: NT, refs, value: NT, R: int, B: int, Q: int, S: int) -> NT:
+        """TransformerDecoder.forward (modelling.py:969-1020) with one launch per operation (FX_ROW_CHAIN=0)."""
+        e, P, lib = self.eng, self.eng.P, self.lib
+        hp = "head.predictor"
         qp1 = self._new("qpos_h", R, 1, 1, 512)
         for li in range(e.nl):
             p = f"{hp}.decoder.layers.{li}"
@@ -757,24 +812,93 @@ class _Plan(_PlanBase):
             wl, bl = e.bbox_last[f"dec{li}"]
             self._op(lib.fx_bbox_head, hb.ptr, hb.ld, wl.data_ptr(), bl.data_ptr(), ref.data_ptr(), None, None, Q, 0, refs[li + 1].data_ptr(),
                      None, R, 256)
-        self.refs = refs
         logits = self.linear(tgt, P[f"{hp}.dec_score"], name="logits", out_f32=True)
-        self.probs = self._io("probs", (B, Q, K), torch.float32)
-        self.boxes = self._io("boxes", (B, Q, 4), torch.float32)
-        self._op(lib.fx_detr_head_out, logits.ptr, logits.ld, refs[e.nl].data_ptr(), self.probs.data_ptr(), self.boxes.data_ptr(), R, K)
-        # ---- device side of DETRProcessor.postprocess (processor.py:146-151,183-197)
-        tk = min(e.top_k, Q * K)
-        self.top_k = tk
-        self.det_scores = self._io("det_scores", (B, tk), torch.float32)
-        self.det_flat = self._io("det_flat", (B, tk), torch.int32)
-        self.det_labels = self._io("det_labels", (B, tk), torch.int32)
-        self.det_queries = self._io("det_queries", (B, tk), torch.int32)
-        self.det_boxes = self._io("det_boxes", (B, tk, 4), torch.int32)
-        self.det_count = self._io("det_count", (B,), torch.int32)
-        self._op(lib.fx_topk_rows_f32, self.probs.data_ptr(), Q * K, B, Q * K, tk, self.det_scores.data_ptr(), self.det_flat.data_ptr())
-        self.post_index = len(self.ops)
-        self._op(lib.fx_detr_postprocess, self.det_scores.data_ptr(), self.det_flat.data_ptr(), self.boxes.data_ptr(), self.sizes.data_ptr(), B, Q,
-                 K, tk, None, self.det_labels.data_ptr(), self.det_queries.data_ptr(), self.det_boxes.data_ptr(), self.det_count.data_ptr())
+        return logits
+
+    # LDS map of the decoder's row chains (bytes): four [32][256] slots, one [32][1024] slot, the refined-box hand-over, LN scratch
+    RC_S0, RC_S1, RC_S2, RC_S3, RC_BIG, RC_REF, RC_RED, RC_LDS = 0, 16384, 32768, 49152, 65536, 131072, 131584, 132608
+
+    def _rc_program(self, stages: List[FxRcStage], rows: int, label: str, flops: float):
+        """Upload a stage list and append the fx_row_chain launch."""
+        arr = (FxRcStage * len(stages))(*stages)
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        dev = host.to(self.dev)
+        self.keep.append(dev)
+        self.meta[len(self.ops)] = {"kind": "conv", "variant": "row_chain", "flops": flops, "name": label, "M": rows, "N": 0, "K": 0}
+        self._op(self.lib.fx_row_chain, dev.data_ptr(), len(stages), rows, self.RC_LDS)
+
+    def _build_decoder_row_chain(self, tgt: NT, refs, value: NT, R: int, B: int, Q: int, S: int) -> NT:
+        """TransformerDecoder.forward (modelling.py:969-1020) as row chains: per layer  [self-attention core]  [out_proj + LN1 + offsets]
+        [deformable sampling]  [output_proj + LN2 + FFN + LN3 + bbox refinement + the NEXT layer's query_pos / q,k,v projections]."""
+        e, lib = self.eng, self.lib
+        RC = e.RC
+        S0, S1, S2, S3, BIG, REF, RED = self.RC_S0, self.RC_S1, self.RC_S2, self.RC_S3, self.RC_BIG, self.RC_REF, self.RC_RED
+        relu = FX_ACT["relu"]
+
+        def st(type_, K=0, N=0, act=0, src=-1, dst=-1, aux=-1, ld=0, ld2=0, flags=0, w=None, bias=None, gamma=None, beta=None, g0=None, g1=None):
+            s_ = FxRcStage()
+            s_.type, s_.K, s_.N, s_.act, s_.src, s_.dst, s_.aux, s_.ld, s_.ld2, s_.flags = type_, K, N, act, src, dst, aux, ld, ld2, flags
+            s_.w, s_.bias, s_.gamma, s_.beta, s_.g0, s_.g1 = w, bias, gamma, beta, g0, g1
+            return s_
+
+        def load(nt: NT, dst):
+            return st(0, K=nt.C, dst=dst, g0=nt.ptr, ld=nt.ld)
+
+        def gemm(key, src, K, N, dst=-1, act=0, out: Optional[NT] = None, f32=False):
+            w, b = RC[key]
+            return st(1, K=K, N=N, act=act, src=src, dst=dst, w=w.data_ptr(), bias=b.data_ptr(), g0=out.ptr if out is not None else None,
+                      ld=out.ld if out is not None else 0, flags=int(f32))
+
+        def gemm_ln(key, src, K, aux, ln_name, dst, out: Optional[NT] = None):
+            w, b = RC[key]
+            g_, b_ = e.ln[ln_name]
+            return st(2, K=K, N=256, src=src, dst=dst, aux=aux, w=w.data_ptr(), bias=b.data_ptr(), gamma=g_.data_ptr(), beta=b_.data_ptr(),
+                      g0=out.ptr if out is not None else None, ld=out.ld if out is not None else 0, ld2=RED)
+
+        hp = "head.predictor"
+        qkv = self._new("dec.qkv", R, 1, 1, 768)
+        qpos = self._new("dec.qpos", R, 1, 1, 256)
+        t1 = self._new("dec.t1", R, 1, 1, 256)
+        offaw = self._new("dec.offaw", R, 1, 1, 288, torch.float32)
+        ncp = e.nc_pad32
+        logits = self._new("logits", R, 1, 1, ncp, torch.float32)
+        logits.C = e.nc
+
+        def pre_attention(li, tgt_slot, ref_global=None):
+            """query_pos_head(ref) -> qpos; q = k = (tgt + qpos) W_qk, v = tgt W_v  (modelling.py:996, transformer MHA in_proj)."""
+            k4 = st(4, N=512, dst=BIG, aux=(-1 if ref_global is not None else REF), w=e.qpos0[0].data_ptr(), bias=e.qpos0[1].data_ptr(), g0=ref_global)
+            return [k4, gemm("qpos1", BIG, 512, 256, dst=S1, out=qpos), st(3, K=256, src=tgt_slot, aux=S1, dst=S2),
+                    gemm(f"{li}.qk", S2, 256, 512, out=qkv.slice(0, 512)), gemm(f"{li}.v", tgt_slot, 256, 256, out=qkv.slice(512, 256))]
+
+        fl_pre = 2.0 * R * (512 * 256 + 256 * 768)
+        self._rc_program([load(tgt, S0)] + pre_attention(0, S0, refs[0].data_ptr()), R, "dec0.pre", fl_pre)
+        for li in range(e.nl):
+            p = f"{hp}.decoder.layers.{li}"
+            att = self.mha(qkv, B, Q, f"dec{li}.att")
+            prog = [load(att, S0), load(tgt, S1), load(qpos, S2), gemm_ln(f"{li}.o", S0, 256, S1, f"{p}.norm1", S3, out=t1),
+                    st(3, K=256, src=S3, aux=S2, dst=S0), gemm(f"{li}.offaw", S0, 256, 288, out=offaw, f32=True)]
+            self._rc_program(prog, R, f"dec{li}.post_attn", 2.0 * R * 256 * (256 + 288))
+            ms = self._new(f"dec{li}.msda", R, 1, 1, 256)
+            vsl = value.slice(li * 256, 256)
+            self._op(lib.fx_msda_bf16, vsl.ptr, vsl.ld, self.shapes_t.data_ptr(), self.starts_t.data_ptr(), 3, 4, offaw.ptr, offaw.ld,
+                     offaw.ptr + 192 * 4, offaw.ld, refs[li].data_ptr(), 1, ms.ptr, ms.ld, B, S, Q, 8)
+            out = self._new(f"dec{li}.out", R, 1, 1, 256)
+            wl, bl = e.bbox_last[f"dec{li}"]
+            last = li == e.nl - 1
+            prog = [load(ms, S0), load(t1, S1), gemm_ln(f"{li}.o2", S0, 256, S1, f"{p}.norm2", S2),
+                    gemm(f"{li}.f1", S2, 256, 1024, dst=BIG, act=relu), gemm_ln(f"{li}.f2", BIG, 1024, S2, f"{p}.norm3", S3, out=out),
+                    gemm(f"{li}.bb0", S3, 256, 256, dst=S0, act=relu), gemm(f"{li}.bb1", S0, 256, 256, dst=S1, act=relu),
+                    st(5, K=256, src=S1, aux=(-1 if last else REF), w=wl.data_ptr(), bias=bl.data_ptr(), g0=refs[li].data_ptr(), g1=refs[li + 1].data_ptr())]
+            fl = 2.0 * R * (256 * 256 * 3 + 2 * 256 * 1024)
+            if last:
+                prog.append(gemm("score", S3, 256, ncp, out=logits, f32=True))
+                fl += 2.0 * R * 256 * e.nc
+            else:
+                prog += pre_attention(li + 1, S3)
+                fl += fl_pre
+            self._rc_program(prog, R, f"dec{li}.post_msda", fl)
+            tgt = out
+        return logits
 
     # -------------------------------------------------------------- execution
     def patch_args(self, fn, args, thr: float):

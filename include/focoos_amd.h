@@ -172,6 +172,38 @@ int fx_enc_score_head_bf16(const void* memory, int ldm, const uint8_t* valid, in
                            const float* gamma, const float* beta, float eps, const void* w2, const float* b2, int n2_pad,
                            void* output_memory, int ldo, float* scores, int M, fx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Row-local layer chains in one launch (csrc/row_chain.hip): a workgroup owns 32 rows of a [rows, C] activation and
+ * interprets a host-written program of stages with the activations in LDS.  Used for the transformer decoder layer
+ * (fai_detr/modelling.py:924-958 TransformerDecoderLayer.forward, :990-1003 query_pos_head / bbox refinement of
+ * TransformerDecoder.forward): everything except the self-attention core (fx_mha_bf16) and the deformable sampling
+ * (fx_msda_bf16) becomes 3 launches per layer instead of ~17.
+ * LDS buffers are [32][K] bf16 at byte offsets src / dst / aux (-1 = none) of the workgroup's LDS.  Weights `w` of the GEMM
+ * stages are bf16 in MFMA fragment order (see fx_pw_chain_desc).  Stage types:
+ *   0 LOAD     dst <- g0[row, 0:K] (bf16 global, row stride ld)
+ *   1 GEMM     act(src[32,K] . w^T + bias) -> dst (LDS, if >= 0; N in {256,512,1024}) and / or g0[row, 0:N] (row stride ld;
+ *              f32 if flags&1 else bf16); N % 32 == 0, K % 64 == 0
+ *   2 GEMM_LN  LayerNorm_256(src . w^T + bias + aux) * gamma + beta -> dst and optionally g0 (bf16); eps 1e-5; ld2 = LDS byte
+ *              offset of a 512-byte reduction scratch
+ *   3 ADD      dst <- src + aux  (K columns)
+ *   4 K4       dst[32,N] <- relu(ref[row,0:4] . w^T + bias), w f32 [N][4]; ref = f32 at LDS offset aux (16 B per row) if aux >= 0,
+ *              else g0 (f32 [rows][4])
+ *   5 BBOX     ref' = sigmoid(src[32,256] . w^T + bias + inverse_sigmoid(g0[row,0:4])), w f32 [4][256]; ref' -> g1 (f32 [rows][4])
+ *              and, if aux >= 0, to LDS offset aux (for a following K4 stage) */
+typedef struct fx_rc_stage {
+  int32_t type, K, N, act;
+  int32_t src, dst, aux;
+  int32_t ld, ld2, flags;
+  const void* w;
+  const float* bias;
+  const float* gamma;
+  const float* beta;
+  void* g0;
+  void* g1;
+} fx_rc_stage;
+/* program_device: n_stages (<= 64) stages in DEVICE memory; rows: rows of the activation; lds_bytes: LDS the program needs. */
+int fx_row_chain(const fx_rc_stage* program_device, int n_stages, int rows, int lds_bytes, fx_stream_t stream);
+
 /* torch.topk(scores, k, dim=1) for f32 rows (modelling.py:1214; processor.py:147): for each of B rows
  * of length n writes the k largest values (descending; ties -> lower index first) and their indices. */
 int fx_topk_rows_f32(const float* scores, int ld, int B, int n, int k, float* out_val, int32_t* out_idx, fx_stream_t stream);

@@ -665,3 +665,64 @@ def test_pointwise_flat_batch_stride(lib):
     ref = ref_conv(x, W4, bias).reshape(B, H * W, N)
     assert torch.isnan(got[:, :20]).all() and torch.isnan(got[:, 20 + H * W:]).all()
     assert (got[:, 20:20 + H * W] - ref).abs().max() / ref.abs().max() < 1.2e-2
+
+
+def test_row_chain_interpreter(lib):
+    """fx_row_chain: every stage type of the decoder's row chains against torch (bf16 operands, fp32 accumulation, bf16 hand-over
+    between stages exactly where the kernel stores bf16)."""
+    from focoos_amd._lib import FxRcStage
+
+    M = 32 * 5 + 7
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(M, 256, generator=g)
+    ref = torch.rand(M, 4, generator=g) * 0.8 + 0.1
+    W1, b1 = torch.randn(1024, 256, generator=g) / 16, torch.randn(1024, generator=g) * 0.1
+    W2, b2 = torch.randn(256, 1024, generator=g) / 32, torch.randn(256, generator=g) * 0.1
+    gam, bet = torch.rand(256, generator=g) * 0.4 + 0.8, torch.randn(256, generator=g) * 0.05
+    Wk, bk = torch.randn(512, 4, generator=g), torch.randn(512, generator=g) * 0.1
+    W3, b3 = torch.randn(288, 512, generator=g) / 22, torch.randn(288, generator=g) * 0.1
+    Wb, bb = torch.randn(4, 256, generator=g) / 16, torch.randn(4, generator=g) * 0.1
+    S0, S1, S2, BIG, REF, RED, LDS = 0, 16384, 32768, 65536, 131072, 131584, 132608
+    xd, refd = to_dev(bf(x)), to_dev(ref)
+    y1 = torch.full((M + 1, 1024), float("nan"), dtype=torch.bfloat16, device=DEV)
+    y2 = torch.full((M + 1, 256), float("nan"), dtype=torch.bfloat16, device=DEV)
+    y3 = torch.full((M + 1, 288), float("nan"), dtype=torch.float32, device=DEV)
+    nref = torch.full((M + 1, 4), float("nan"), dtype=torch.float32, device=DEV)
+    keep = [frag_pack(W1), to_dev(b1), frag_pack(W2), to_dev(b2), to_dev(gam), to_dev(bet), to_dev(Wk), to_dev(bk), frag_pack(W3), to_dev(b3), to_dev(Wb), to_dev(bb)]
+    w1d, b1d, w2d, b2d, gd, bd, wkd, bkd, w3d, b3d, wbd, bbd = keep
+
+    def st(**kw):
+        s = FxRcStage()
+        s.src, s.dst, s.aux = -1, -1, -1
+        for k, v in kw.items():
+            setattr(s, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+        return s
+
+    prog = [
+        st(type=0, K=256, dst=S0, g0=xd, ld=256),                                                          # x -> S0
+        st(type=1, K=256, N=1024, act=1, src=S0, dst=BIG, w=w1d, bias=b1d, g0=y1, ld=1024),                  # relu(x W1^T + b1) -> BIG, y1
+        st(type=2, K=1024, N=256, src=BIG, dst=S1, aux=S0, w=w2d, bias=b2d, gamma=gd, beta=bd, g0=y2, ld=256, ld2=RED),   # LN(h W2^T + b2 + x) -> S1, y2
+        st(type=5, K=256, src=S1, aux=REF, w=wbd, bias=bbd, g0=refd, g1=nref),                               # refined boxes -> nref, REF
+        st(type=4, N=512, dst=BIG, aux=REF, w=wkd, bias=bkd),                                                # relu(ref' Wk^T + bk) -> BIG
+        st(type=3, K=256, src=S0, aux=S1, dst=S2),                                                           # x + y2 -> S2 (not stored; feeds nothing here)
+        st(type=1, K=512, N=288, src=BIG, w=w3d, bias=b3d, g0=y3, ld=288, flags=1),                          # fp32 output, N = 9 blocks of 32
+    ]
+    arr = (FxRcStage * len(prog))(*prog)
+    pd = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+    check(lib.fx_row_chain(pd.data_ptr(), len(prog), M, LDS, stream()), "row_chain")
+    torch.cuda.synchronize()
+    xb = bf(x).float()
+    h = (xb @ bf(W1).float().T + b1).relu()
+    got1 = y1[:M].float().cpu()
+    assert torch.isnan(y1[M:].float()).all() and (got1 - h).abs().max() <= 1e-2 * h.abs().max()
+    r2 = F.layer_norm(got1 @ bf(W2).float().T + b2 + xb, (256,), gam, bet, 1e-5)      # from the kernel's own bf16 h
+    got2 = y2[:M].float().cpu()
+    assert (got2 - r2).abs().max() <= 2e-2 * r2.abs().max(), (got2 - r2).abs().max()
+    u = got2 @ Wb.T + bb + torch.log(ref.clamp(1e-5) / (1 - ref).clamp(1e-5))
+    rn = torch.sigmoid(u)
+    gotn = nref[:M].cpu()
+    assert torch.isnan(nref[M:]).all() and (gotn - rn).abs().max() <= 2e-5
+    k4 = bf((gotn @ Wk.T + bk).relu()).float()
+    r3 = k4 @ bf(W3).float().T + b3
+    got3 = y3[:M].cpu()
+    assert (got3 - r3).abs().max() <= 1e-2 * r3.abs().max(), (got3 - r3).abs().max()
