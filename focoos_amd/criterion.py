@@ -80,8 +80,11 @@ class BoxHungarianMatcher:
         B, Q, K = logits.shape
         dev = logits.device
         logits, boxes = logits.float().contiguous(), boxes.float().contiguous()
-        pi = torch.empty(max(tg.n, 1), dtype=torch.int32, device=dev)
-        ti = torch.empty(max(tg.n, 1), dtype=torch.int32, device=dev)
+        # Identity-like defaults instead of uninitialised memory: if the assignment is infeasible (NaN / inf costs after a diverged
+        # step) fx_lsa_f32 leaves an image's slots untouched, and the criterion would otherwise index boxes[slot, garbage].  The
+        # reference raises from SciPy in that case; here the step produces a (meaningless but in-bounds) loss and the NaNs surface in it.
+        pi = torch.zeros(max(tg.n, 1), dtype=torch.int32, device=dev)
+        ti = torch.zeros(max(tg.n, 1), dtype=torch.int32, device=dev)
         if tg.n:
             cost = torch.empty(B, Q, tg.tmax, dtype=torch.float32, device=dev)
             st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)

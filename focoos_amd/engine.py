@@ -491,7 +491,10 @@ class _PlanBase:
         elif (pc.wf is not None and pc.KH == 1 and stride == 1 and not pool2 and not out_f32 and M >= 40000 and pc.C % 256 == 0 and pc.N % 256 == 0
                 and int(os.environ.get("FX_PW_FLAT", "1")) and not (residual is not None and res_after) and act != "gelu"):
             variant = f"pw_flat<K{pc.C}>"
-        self.meta[len(self.ops)] = {"kind": "conv", "variant": variant, "flops": flops,
+        # algorithmic (compulsory) HBM bytes of this launch: input read once, output written once, residual, weights
+        alg_bytes = 2.0 * x.B * x.H * x.W * pc.C + (4.0 if out_f32 else 2.0) * M * pc.N + (2.0 * M * pc.N if residual is not None else 0.0) \
+            + 2.0 * pc.N * pc.KH * pc.KW * pc.C
+        self.meta[len(self.ops)] = {"kind": "conv", "variant": variant, "flops": flops, "bytes": alg_bytes,
                                     "name": name or "slice", "M": M, "N": pc.N, "K": pc.KH * pc.KW * pc.C}
         self._op(self.lib.fx_conv2d_nhwc_bf16, C.byref(d))
         return out

@@ -28,6 +28,53 @@ def _config_to_dict(cfg) -> dict:
     return d
 
 
+def _fx_version_key(module) -> tuple:
+    """Changes whenever a parameter / buffer was written in place, replaced, or the module moved to another device."""
+    return (str(module.device),) + tuple(p._version for p in module.parameters()) + tuple(b._version for b in module.buffers()) + \
+        tuple(p.data_ptr() for p in module.parameters())
+
+
+def _engine_can_run(images) -> bool:
+    """The engine's plans need H and W to be multiples of 32 (five stride-2 stages + the 2x2 ceil-mode shortcut pools).  Other sizes -
+    which stock focoos accepts for the mask families, whose processors never resize - run the reference's own (GPU) graph with a
+    warning, so user code that works with stock focoos keeps working.  A CPU tensor is NOT a reason to fall back: the engine
+    raises FocoosAmdError for it (no silent CPU path)."""
+    if images.dim() != 4:
+        return True    # let the engine raise on the malformed input
+    h, w = (images.shape[2], images.shape[3]) if (images.shape[1] == 3 and images.shape[-1] != 3) else (images.shape[1], images.shape[2])
+    ok = h % 32 == 0 and w % 32 == 0
+    if not ok and images.device.type == "cuda":
+        import warnings
+
+        warnings.warn(f"focoos_amd: input {h}x{w} is not a multiple of 32 - this call runs the reference's stock PyTorch graph, not the HIP engine")
+        return False
+    return True
+
+
+def share_parameters(engine_graph, reference_module) -> int:
+    """Make every parameter and buffer of ``engine_graph`` (train_detr.FAIDetrTrainable: the reference's key names) BE the tensor
+    object of the same name in ``reference_module``: gradients of the engine's backward accumulate in the reference module's
+    ``.grad`` fields, so the reference's optimizer, EMA hook, checkpointer and DDP wrapper keep working on the module they know.
+    Returns the number of tensors shared; raises on a name or shape mismatch."""
+    ref_p, ref_b = dict(reference_module.named_parameters()), dict(reference_module.named_buffers())
+    n = 0
+    for name, p in list(engine_graph.named_parameters()):
+        if name not in ref_p or tuple(ref_p[name].shape) != tuple(p.shape):
+            raise KeyError(f"engine parameter {name} {tuple(p.shape)} has no counterpart of that shape in the reference module")
+        mod = engine_graph.get_submodule(name.rsplit(".", 1)[0]) if "." in name else engine_graph
+        mod._parameters[name.rsplit(".", 1)[-1]] = ref_p[name]
+        n += 1
+    for name, b in list(engine_graph.named_buffers()):
+        if name not in ref_b:
+            continue   # engine-only scratch buffers
+        if tuple(ref_b[name].shape) != tuple(b.shape):
+            raise KeyError(f"engine buffer {name} {tuple(b.shape)} != reference {tuple(ref_b[name].shape)}")
+        mod = engine_graph.get_submodule(name.rsplit(".", 1)[0]) if "." in name else engine_graph
+        mod._buffers[name.rsplit(".", 1)[-1]] = ref_b[name]
+        n += 1
+    return n
+
+
 def make_engine_class():
     """Build the adapter class against the installed reference (import deferred: focoos is optional)."""
     from focoos.models.fai_detr.modelling import FAIDetr as RefFAIDetr
@@ -44,21 +91,49 @@ def make_engine_class():
             self._fx_version = None
 
         def _fx_sync(self):
-            ver = tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
-            if self._fx_engine is None:
+            ver = _fx_version_key(self)
+            if self._fx_engine is None or str(self._fx_engine.dev) != str(self.device):
                 self._fx_engine = DetrEngine(_config_to_dict(self.config), self.state_dict(), str(self.device))
             elif ver != self._fx_version:
                 self._fx_engine.load_state_dict(self.state_dict())
             self._fx_version = ver
 
+        def _fx_train_graph(self):
+            """The HIP autograd graph (train_detr.FAIDetrTrainable) over THIS module's parameters: built once, re-built when the
+            module moved; BatchNorm mode follows the module (all norms frozen -> FrozenBN, SyncBatchNorm present -> SyncBN, else BN)."""
+            g = self.__dict__.get("_fx_train")
+            if g is None or g[1] != str(self.device):
+                from .train_detr import FAIDetrTrainable
+
+                mods = list(self.modules())
+                sync = any(isinstance(m, torch.nn.SyncBatchNorm) for m in mods)
+                live = any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.weight is not None and m.weight.requires_grad for m in mods)
+                net = FAIDetrTrainable(_config_to_dict(self.config), norm="SyncBN" if sync else ("BN" if live else "FrozenBN")).to(self.device)
+                share_parameters(net, self)
+                g = (net, str(self.device))
+                self.__dict__["_fx_train"] = g     # not a registered submodule: state_dict() / parameters() stay the reference's
+            g[0].train(self.training)
+            return g[0]
+
         def forward(self, images, targets=[]):
-            if self.training or (targets is not None and len(targets) > 0) or torch.is_grad_enabled() and images.requires_grad:
-                return super().forward(images, targets)  # training path: the reference's own graph (out of scope here)
-            self._fx_sync()
+            if not _engine_can_run(images):
+                return super().forward(images, targets)   # shapes / devices the engine has no plan for: the reference's own graph
             x = images
             if x.dim() == 4 and x.shape[1] == 3 and x.shape[-1] != 3:
                 x = x.permute(0, 2, 3, 1)
             x = (x if x.dtype == torch.uint8 else x.float()).contiguous()
+            if self.training:
+                # FAIDetr.forward in train mode (modelling.py:1344-1358): empty boxes / logits + the dict of weighted losses, computed by
+                # the HIP training graph on this module's own parameters (TrainerLoop.run_step sums the dict and calls backward)
+                from . import train_nn
+
+                train_nn.WEIGHTS_EPOCH[0] += 1     # an external optimizer may have stepped the parameters since the last forward
+                losses = self._fx_train_graph()(x, targets)
+                z = torch.zeros(0, 0, 0, device=images.device)
+                return DETRModelOutput(boxes=z, logits=z, loss=losses)
+            if targets is not None and len(targets) > 0:
+                return super().forward(images, targets)
+            self._fx_sync()
             pl = self._fx_engine.forward(x)
             return DETRModelOutput(logits=pl.probs.clone(), boxes=pl.boxes.clone(), loss=None)
 
@@ -79,16 +154,17 @@ def make_mf_engine_class():
             self._fx_version = None
 
         def _fx_sync(self):
-            ver = tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
-            if self._fx_engine is None:
+            ver = _fx_version_key(self)
+            if self._fx_engine is None or str(self._fx_engine.dev) != str(self.device):
                 self._fx_engine = MfEngine(_config_to_dict(self.config), self.state_dict(), str(self.device), full_masks=True)
             elif ver != self._fx_version:
                 self._fx_engine.load_state_dict(self.state_dict())
             self._fx_version = ver
 
         def forward(self, images, targets=[]):
-            if self.training or (targets is not None and len(targets) > 0) or torch.is_grad_enabled() and images.requires_grad:
-                return super().forward(images, targets)  # training path: the reference's own graph
+            if self.training or (targets is not None and len(targets) > 0) or (torch.is_grad_enabled() and images.requires_grad) \
+                    or not _engine_can_run(images):
+                return super().forward(images, targets)  # training path (A16 backward not built) / unsupported shapes: the reference's own graph
             self._fx_sync()
             x = images
             if x.dim() == 4 and x.shape[1] == 3 and x.shape[-1] != 3:
@@ -114,16 +190,17 @@ def make_bf_engine_class():
             self._fx_version = None
 
         def _fx_sync(self):
-            ver = tuple(p._version for p in self.parameters()) + tuple(b._version for b in self.buffers())
-            if self._fx_engine is None:
+            ver = _fx_version_key(self)
+            if self._fx_engine is None or str(self._fx_engine.dev) != str(self.device):
                 self._fx_engine = BfEngine(_config_to_dict(self.config), self.state_dict(), str(self.device), full_masks=True)
             elif ver != self._fx_version:
                 self._fx_engine.load_state_dict(self.state_dict())
             self._fx_version = ver
 
         def forward(self, images, targets=[]):
-            if self.training or (targets is not None and len(targets) > 0) or torch.is_grad_enabled() and images.requires_grad:
-                return super().forward(images, targets)  # training path: the reference's own graph
+            if self.training or (targets is not None and len(targets) > 0) or (torch.is_grad_enabled() and images.requires_grad) \
+                    or not _engine_can_run(images):
+                return super().forward(images, targets)  # training path (A16 backward not built) / unsupported shapes: the reference's own graph
             self._fx_sync()
             x = images
             if x.dim() == 4 and x.shape[1] == 3 and x.shape[-1] != 3:
@@ -133,6 +210,49 @@ def make_bf_engine_class():
             return BisenetFormerOutput(masks=pl.masks.clone(), logits=pl.probs.clone(), loss=None)
 
     return EngineBisenetFormer
+
+
+def make_processor_classes():
+    """Engine-backed processors for the reference's ProcessorManager (processor/processor_manager.py:13-18, seam B1/B3): subclasses of
+    the reference processors (pre-process, training targets, export paths untouched) whose ``postprocess`` on GPU tensors runs the
+    device kernels (fx_topk_rows_f32 + fx_detr_postprocess; fx_mf_postprocess / fx_seg_postprocess) and builds the reference's own
+    ``FocoosDetections`` objects from ONE packed device->host copy."""
+    from focoos.models.bisenetformer.processor import BisenetFormerProcessor as RefBF
+    from focoos.models.fai_detr.processor import DETRProcessor as RefDETR
+    from focoos.models.fai_mf.processor import MaskFormerProcessor as RefMF
+    from focoos.ports import FocoosDet, FocoosDetections
+
+    from . import processor as fxp
+
+    def convert(dets):
+        return [FocoosDetections(detections=[FocoosDet(bbox=d.bbox, conf=d.conf, cls_id=d.cls_id, label=d.label, mask=d.mask) for d in fd.detections])
+                for fd in dets]
+
+    def cfg_dict(self):
+        return _config_to_dict(self.config)
+
+    class EngineDETRProcessor(RefDETR):
+        def postprocess(self, output, inputs, class_names=[], top_k=None, threshold=None):
+            if output.logits.device.type != "cuda":
+                return super().postprocess(output, inputs, class_names, top_k, threshold)
+            mirror = fxp.DETRProcessor({"top_k": self.top_k, "threshold": self.threshold}, self.image_size)
+            return convert(mirror.postprocess(output, inputs, class_names, top_k, threshold))
+
+    class EngineMaskFormerProcessor(RefMF):
+        def postprocess(self, output, inputs, class_names=[], threshold=None, **kw):
+            if output.logits.device.type != "cuda" or kw:
+                return super().postprocess(output, inputs, class_names, threshold=threshold, **kw)
+            mirror = fxp.MaskFormerProcessor(cfg_dict(self), self.image_size)
+            return convert(mirror.postprocess(output, inputs, class_names, threshold=threshold))
+
+    class EngineBisenetFormerProcessor(RefBF):
+        def postprocess(self, output, inputs, class_names=[], threshold=None, **kw):
+            if output.logits.device.type != "cuda" or kw:
+                return super().postprocess(output, inputs, class_names, threshold=threshold, **kw)
+            mirror = fxp.BisenetFormerProcessor(cfg_dict(self), self.image_size)
+            return convert(mirror.postprocess(output, inputs, class_names, threshold=threshold))
+
+    return EngineDETRProcessor, EngineMaskFormerProcessor, EngineBisenetFormerProcessor
 
 
 def register() -> None:
@@ -155,19 +275,29 @@ def register() -> None:
     ModelManager.register_model(ModelFamily.MASKFORMER, lambda: cls_mf)
     cls_bf = make_bf_engine_class()
     ModelManager.register_model(ModelFamily.BISENETFORMER, lambda: cls_bf)
+    # processors: ``model.infer()`` of a dropped-in model then post-processes on the device too
+    from focoos.processor.processor_manager import ProcessorManager
+
+    p_detr, p_mf, p_bf = make_processor_classes()
+    ProcessorManager.register_processor(ModelFamily.DETR, lambda: p_detr)
+    ProcessorManager.register_processor(ModelFamily.MASKFORMER, lambda: p_mf)
+    ProcessorManager.register_processor(ModelFamily.BISENETFORMER, lambda: p_bf)
 
 
 def bind_msda_core(module) -> int:
     """Bind every ``MSDeformableAttention.ms_deformable_attn_core`` slot under ``module`` to the HIP kernel (mode 0 =
-    the seam's exact signature: value [B,S,M,D], shapes, sampling_locations [B,Q,M,L,P,2], weights [B,Q,M,L,P]).
-    Inference only (no autograd).  Returns the number of slots bound."""
+    the seam's exact signature: value [B,S,M,D], shapes, sampling_locations [B,Q,M,L,P,2], weights [B,Q,M,L,P]): fx_msda_bf16
+    without autograd, the differentiable fx_msda_f32_fwd/bwd pair when a gradient is required.  Returns the number of slots bound."""
     from . import _lib
 
     lib = _lib.load()
 
     def core(value, value_spatial_shapes, sampling_locations, attention_weights):
-        if torch.is_grad_enabled() and (value.requires_grad or sampling_locations.requires_grad):
-            raise _lib.FocoosAmdError("fx_msda_bf16 is forward-only; use the reference core under autograd")
+        if torch.is_grad_enabled() and (value.requires_grad or sampling_locations.requires_grad or attention_weights.requires_grad):
+            # training: the differentiable fp32 pair fx_msda_f32_fwd / fx_msda_f32_bwd behind a torch.autograd.Function (train.py)
+            from .train import ms_deform_attn_core
+
+            return ms_deform_attn_core(value.float(), value_spatial_shapes, sampling_locations.float(), attention_weights.float()).to(value.dtype)
         B, S, M, D = value.shape
         Q, L, P = sampling_locations.shape[1], sampling_locations.shape[3], sampling_locations.shape[4]
         dev = value.device

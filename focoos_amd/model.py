@@ -6,8 +6,8 @@
   FAIMaskFormer             focoos/models/fai_mf/modelling.py:633-725
 
 Same names, argument meaning and error behaviour; the compute is the HIP engine (engine.py).
-``.train()`` / ``.export()`` are not part of this round's hot path and raise NotImplementedError
-(loudly — never a silent fallback)."""
+``FocoosModel.train`` drives the HIP training step (trainer.py, RT-DETR family); ``.export()`` is out of scope and raises
+NotImplementedError (loudly — never a silent fallback)."""
 from __future__ import annotations
 
 import os
@@ -71,9 +71,10 @@ class _EngineModel:
         return self
 
     def train(self, mode: bool = True):
-        if mode:
-            raise NotImplementedError("focoos_amd round 1 covers the inference hot path; training (SURVEY §8 config 4) is the next row")
-        return self.eval()
+        """nn.Module.train: the engine-backed module itself is the inference graph; the trainable graph (train_detr.FAIDetrTrainable)
+        is built from its state_dict by FocoosModel.train / trainer.run_train.  Calling forward in training mode raises."""
+        self.training = bool(mode)
+        return self
 
     def cuda(self, device=None):
         return self
@@ -251,8 +252,12 @@ class FocoosModel:
             raise NotImplementedError("annotation/drawing is outside the hot path")
         return self(image, threshold=threshold)
 
-    def train(self, *a, **k):
-        raise NotImplementedError("FocoosModel.train: data-parallel fine-tuning is SURVEY §8 config 4 (next round)")
+    def train(self, args, data_train, data_val=None, hub=None):
+        """focoos_model.py:221-274: fine-tune on ``data_train`` (indexable, entries = ports.DatasetEntry) with ``args`` (ports.TrainerArgs):
+        one process per GPU, TrainStep on every rank, artifacts in ``args.output_dir/args.run_name``, weights reloaded into the engine."""
+        from .trainer import train as _train
+
+        return _train(self, args, data_train, data_val, hub)
 
     def export(self, *a, **k):
         raise NotImplementedError("FocoosModel.export: the ONNX/TensorRT export path is out of scope (BASELINE north_star)")

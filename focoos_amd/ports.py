@@ -96,3 +96,137 @@ class ModelInfo:
     config: dict
     weights_uri: Optional[str] = None
     description: Optional[str] = None
+
+
+# ---- evaluation-side structures (focoos/structures.py: Boxes :18-170, Instances :430-560), the subset eval_postprocess needs
+class Boxes:
+    """[N,4] xyxy boxes with the in-place scale / clip / nonempty helpers detector_postprocess uses (structures.py:57-100,156-161)."""
+
+    def __init__(self, tensor):
+        import torch
+
+        if not isinstance(tensor, torch.Tensor):
+            tensor = torch.as_tensor(tensor, dtype=torch.float32)
+        if tensor.numel() == 0:
+            tensor = tensor.reshape((-1, 4)).to(dtype=torch.float32)
+        assert tensor.dim() == 2 and tensor.size(-1) == 4, tensor.size()
+        self.tensor = tensor
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+    def scale(self, scale_x: float, scale_y: float) -> None:
+        self.tensor[:, 0::2] *= scale_x
+        self.tensor[:, 1::2] *= scale_y
+
+    def clip(self, box_size) -> None:
+        import torch
+
+        assert torch.isfinite(self.tensor).all(), "Box tensor contains infinite or NaN!"
+        h, w = box_size
+        self.tensor = torch.stack((self.tensor[:, 0].clamp(min=0, max=w), self.tensor[:, 1].clamp(min=0, max=h),
+                                   self.tensor[:, 2].clamp(min=0, max=w), self.tensor[:, 3].clamp(min=0, max=h)), dim=-1)
+
+    def nonempty(self, threshold: float = 0.0):
+        b = self.tensor
+        return ((b[:, 2] - b[:, 0]) > threshold) & ((b[:, 3] - b[:, 1]) > threshold)
+
+    def __getitem__(self, item) -> "Boxes":
+        if isinstance(item, int):
+            return Boxes(self.tensor[item].view(1, -1))
+        return Boxes(self.tensor[item])
+
+
+class Instances:
+    """Per-image container of equally long fields (structures.py Instances): ``Instances(image_size, boxes=..., scores=..., classes=...)``."""
+
+    def __init__(self, image_size, **fields):
+        self.image_size = tuple(image_size)
+        self._fields = {}
+        for k, v in fields.items():
+            self.set(k, v)
+
+    def set(self, name, value):
+        if self._fields:
+            assert len(value) == len(self), f"field {name}: length {len(value)} != {len(self)}"
+        self._fields[name] = value
+
+    def __getattr__(self, name):
+        f = self.__dict__.get("_fields", {})
+        if name in f:
+            return f[name]
+        raise AttributeError(name)
+
+    def has(self, name):
+        return name in self._fields
+
+    def get_fields(self):
+        return self._fields
+
+    def __len__(self):
+        for v in self._fields.values():
+            return len(v)
+        return 0
+
+    def __getitem__(self, item) -> "Instances":
+        return Instances(self.image_size, **{k: v[item] for k, v in self._fields.items()})
+
+
+# ---- training-side ports (focoos/ports.py: DatasetEntry :938-944, TrainerArgs :970-1065)
+@dataclass
+class DatasetEntry:
+    """One training / evaluation sample: ``image`` CHW uint8 (or float) tensor, ``instances`` with ``boxes`` (Boxes, absolute xyxy) and
+    ``classes`` (int64 tensor), ``height`` / ``width`` of the original image."""
+    image: Optional[object] = None
+    height: Optional[int] = None
+    width: Optional[int] = None
+    instances: Optional[Instances] = None
+    file_name: Optional[str] = None
+    image_id: Optional[int] = None
+
+
+@dataclass
+class TrainerArgs:
+    """focoos/ports.py:970-1065 - same fields and defaults (hub syncing / visualisation fields are accepted and ignored by the engine's
+    trainer).  ``batch_size`` is the TOTAL batch over all GPUs (data/loaders.py:61-65)."""
+    run_name: str
+    output_dir: str = "./focoos_amd_runs"
+    ckpt_dir: Optional[str] = None
+    init_checkpoint: Optional[str] = None
+    resume: bool = False
+    num_gpus: int = 1
+    device: str = "cuda"
+    workers: int = 4
+    amp_enabled: bool = True
+    ddp_broadcast_buffers: bool = False
+    ddp_find_unused: bool = True
+    checkpointer_period: int = 1000
+    checkpointer_max_to_keep: int = 1
+    eval_period: int = 200
+    log_period: int = 20
+    samples: int = 9
+    seed: int = 42
+    early_stop: bool = True
+    patience: int = 10
+    ema_enabled: bool = False
+    ema_decay: float = 0.999
+    ema_warmup: int = 2000
+    learning_rate: float = 5e-4
+    weight_decay: float = 0.02
+    max_iters: int = 3000
+    batch_size: int = 16
+    scheduler: str = "MULTISTEP"
+    scheduler_extra: Optional[dict] = None
+    optimizer: str = "ADAMW"
+    optimizer_extra: Optional[dict] = None
+    weight_decay_norm: float = 0.0
+    weight_decay_embed: float = 0.0
+    backbone_multiplier: float = 0.1
+    decoder_multiplier: float = 1.0
+    head_multiplier: float = 1.0
+    freeze_bn: bool = False
+    clip_gradients: float = 0.1
+    size_divisibility: int = 0
+    gather_metric_period: int = 1
+    zero_grad_before_forward: bool = False
+    sync_to_hub: bool = False

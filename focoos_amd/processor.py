@@ -20,7 +20,7 @@ import torch
 
 from . import _lib
 from ._lib import check
-from .ports import DETRModelOutput, DynamicAxes, FocoosDet, FocoosDetections, MaskFormerModelOutput  # noqa: F401
+from .ports import DatasetEntry, DETRModelOutput, DynamicAxes, FocoosDet, FocoosDetections, MaskFormerModelOutput  # noqa: F401
 
 try:  # PIL is optional
     from PIL import Image
@@ -72,9 +72,11 @@ class DETRProcessor:
         """Returns (images, targets).  ``images`` is NHWC on ``device``: uint8 [B,H,W,3] when every input
         already has the target size (fused fast path), float32 [B,H,W,3] (0..255 scale, bilinearly resized)
         otherwise.  The engine's ``FAIDetr.forward`` accepts both, as well as the reference's NCHW float."""
-        if self.training:
-            raise ValueError("During training, inputs should be a list of DetectionDatasetDict")  # training path: later round
         lst = inputs if isinstance(inputs, list) else [inputs]
+        if len(lst) > 0 and isinstance(lst[0], DatasetEntry):
+            return self._preprocess_entries(lst, device)
+        if self.training:
+            raise ValueError("During training, inputs should be a list of DetectionDatasetDict")
         arrs = []
         for inp in lst:
             if Image is not None and isinstance(inp, Image.Image):
@@ -88,11 +90,15 @@ class DETRProcessor:
             if inp.shape[0] == 3 and inp.shape[-1] != 3:  # CHW -> HWC
                 inp = inp.permute(1, 2, 0)
             arrs.append(inp.contiguous())
+        if self._target_size() is None and any(tuple(a.shape[:2]) != tuple(arrs[0].shape[:2]) for a in arrs):
+            raise ValueError("images of different sizes need an image_size to resize to (the reference fails in torch.stack here)")
         tgt = self._target_size() or tuple(arrs[0].shape[:2])
         all_u8_same = all(a.dtype == torch.uint8 and tuple(a.shape[:2]) == tgt for a in arrs)
         if all_u8_same:
             batch = torch.stack(arrs, 0).to(device, non_blocking=True)
             return batch, []
+        if all(a.dtype != torch.uint8 and tuple(a.shape[:2]) == tgt for a in arrs):   # float images already at the target size
+            return torch.stack([a.to(torch.float32) for a in arrs], 0).to(device, non_blocking=True), []
         lib = _lib.load()
         out = torch.empty(len(arrs), tgt[0], tgt[1], 3, dtype=torch.float32, device=device)
         stream = torch.cuda.current_stream(device).cuda_stream
@@ -103,6 +109,37 @@ class DETRProcessor:
             check(lib.fx_resize_bilinear_u8(d.data_ptr(), a.shape[0], a.shape[1], out[i].data_ptr(), tgt[0], tgt[1], stream), "fx_resize_bilinear_u8")
             d.record_stream(torch.cuda.current_stream(device))
         return out, []
+
+    def _preprocess_entries(self, entries, device: torch.device):
+        """fai_detr/processor.py:81-101: a list of DatasetEntry -> (uint8 NHWC batch, [DETRTargets]): images stacked (equal sizes: the
+        training augmentations produce fixed-resolution crops; ImageList padding is not mirrored), ground-truth boxes absolute xyxy ->
+        normalised cxcywh, classes as they are.  Targets only in training mode."""
+        from .ports import DETRTargets
+
+        imgs = []
+        for e in entries:
+            im = e.image
+            if isinstance(im, np.ndarray):
+                im = torch.from_numpy(np.ascontiguousarray(im))
+            if im.dim() == 3 and im.shape[0] == 3 and im.shape[-1] != 3:
+                im = im.permute(1, 2, 0)
+            imgs.append(im.contiguous())
+        if any(tuple(i.shape) != tuple(imgs[0].shape) for i in imgs):
+            raise ValueError("training batches need equally sized images (resolution-fixing augmentations)")
+        batch = torch.stack(imgs, 0).to(device, non_blocking=True)
+        if batch.dtype != torch.uint8:
+            batch = batch.to(torch.float32)
+        targets = []
+        if self.training:
+            h, w = batch.shape[1:3]
+            scale = torch.tensor([w, h, w, h], dtype=torch.float32, device=device)
+            for e in entries:
+                inst = e.instances
+                assert inst is not None and inst.has("boxes") and inst.has("classes"), "boxes and classes are required for training"
+                bx = inst.boxes.tensor.to(device, torch.float32) / scale
+                cxcywh = torch.stack([(bx[:, 0] + bx[:, 2]) / 2, (bx[:, 1] + bx[:, 3]) / 2, bx[:, 2] - bx[:, 0], bx[:, 3] - bx[:, 1]], -1)
+                targets.append(DETRTargets(labels=inst.classes.to(device), boxes=cxcywh))
+        return batch, targets
 
     # ---- fai_detr/processor.py:153-217
     def postprocess(self, output: DETRModelOutput, inputs: ImageInput, class_names: Sequence[str] = (), top_k: Optional[int] = None,
@@ -129,6 +166,41 @@ class DETRProcessor:
         check(lib.fx_detr_postprocess(val.data_ptr(), idx.data_ptr(), boxes.data_ptr(), sizes.data_ptr(), B, Q, K, tk, float(threshold),
                                       labels.data_ptr(), queries.data_ptr(), obox.data_ptr(), count.data_ptr(), stream), "fx_detr_postprocess")
         return self.pack_detections(val, labels, obox, count, class_names)
+
+    # ---- fai_detr/processor.py:19-57,121-151 (trainer-side evaluation; seam B3)
+    def eval_postprocess(self, output: DETRModelOutput, batched_inputs: Sequence, top_k: Optional[int] = None):
+        """Per image: top-k over the flattened [Q*K] scores (fx_topk_rows_f32, exact torch.topk order), label = idx % K, box of
+        query idx // K, then detector_postprocess: scale the normalised boxes to the entry's (height, width), clip, drop empty
+        boxes.  ``batched_inputs[i]`` has ``.height`` / ``.width`` (DatasetEntry) or is a dict with those keys.
+        Returns ``[{"instances": Instances(image_size, boxes=Boxes, scores, classes)}, ...]``."""
+        from .ports import Boxes, Instances
+
+        top_k = top_k or self.top_k
+        probs, boxes = output.logits.contiguous().float(), output.boxes.contiguous().float()
+        B, Q, K = probs.shape
+        assert len(batched_inputs) == B, (len(batched_inputs), B)
+        dev = probs.device
+        if dev.type != "cuda":
+            raise _lib.FocoosAmdError("eval_postprocess runs the top-k on the GPU (fx_topk_rows_f32); no CPU fallback exists")
+        lib = _lib.load()
+        tk = min(top_k, Q * K)
+        val = torch.empty(B, tk, dtype=torch.float32, device=dev)
+        idx = torch.empty(B, tk, dtype=torch.int32, device=dev)
+        check(lib.fx_topk_rows_f32(probs.data_ptr(), Q * K, B, Q * K, tk, val.data_ptr(), idx.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
+              "fx_topk_rows_f32")
+        idx = idx.long()
+        labels, queries = idx % K, idx // K
+        results = []
+        for i in range(B):
+            ent = batched_inputs[i]
+            h = (ent.get("height") if isinstance(ent, dict) else getattr(ent, "height", None)) or 1
+            w = (ent.get("width") if isinstance(ent, dict) else getattr(ent, "width", None)) or 1
+            bx = Boxes(boxes[i][queries[i]].clone())
+            bx.scale(w / 1.0, h / 1.0)            # detector_postprocess: scale = output size / results.image_size, image_size = (1, 1)
+            bx.clip((h, w))
+            inst = Instances((h, w), boxes=bx, scores=val[i], classes=labels[i])
+            results.append({"instances": inst[bx.nonempty()]})
+        return results
 
     def _device(self) -> torch.device:
         if not torch.cuda.is_available():

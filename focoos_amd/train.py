@@ -1,5 +1,4 @@
-"""Training-side host pieces that already run on the gfx950 kernels (the full train step needs the conv/GEMM backward
-kernels, which are a later round):
+"""Training-side host pieces shared by the training step (train_detr.TrainStep) and the integration seams:
 
 * ``ms_deform_attn_core`` — autograd-aware drop-in for the function-pointer seam
   ``MSDeformableAttention.ms_deformable_attn_core`` (fai_detr/modelling.py:806; deformable.py:10-35): fx_msda_f32_fwd/bwd.

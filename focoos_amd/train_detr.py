@@ -334,6 +334,15 @@ class TrainStep:
                 p.grad = self.opt.grads[n]
         self.named = named
         self.reducer = BucketedGradAllReduce(self.opt.flat_g)
+        # what DistributedDataParallel does at construction (utils/distributed/dist.py:152): every rank starts from rank 0's parameters
+        # and buffers (the engine's parameters are created with torch.empty; ranks that loaded different checkpoints would drift silently)
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.broadcast(self.opt.flat_p, 0)
+            for _, b in model.named_buffers():
+                if b.is_floating_point() or b.dtype in (torch.int64, torch.int32):
+                    dist.broadcast(b, 0)
         # learning-rate schedule (trainer/solver/lr_scheduler.py): one device-side multiply of the per-chunk lr table per change
         self.scheduler, self.max_iters, self.scheduler_extra = scheduler, max_iters, dict(scheduler_extra or {})
         self.iteration, self._lr_factor = 0, 1.0
@@ -342,7 +351,10 @@ class TrainStep:
         if ema_decay is not None:   # the trainer's EMA hook (trainer/solver/ema.py): one pass over the flat parameter buffer per step
             from .train_data import FlatEMA
 
-            bufs = {n: b for n, b in model.named_buffers() if "running_" in n or "num_batches_tracked" in n}
+            # EMAState covers chain(named_parameters, named_buffers) (solver/ema.py): the frozen parameters (FrozenBN affine) and every buffer
+            # (running statistics, criterion.empty_weight) ride along as constants so that an EMA checkpoint loads in the reference
+            bufs = {n: b for n, b in model.named_buffers()}
+            bufs.update({n: p for n, p in model.named_parameters() if not p.requires_grad})
             self.ema = FlatEMA(self.opt.flat_p, {n: self.opt.params[n] for n, _ in named}, bufs, decay=ema_decay, warmups=ema_warmups)
 
     def step(self, images: torch.Tensor, targets: Sequence) -> Dict[str, torch.Tensor]:

@@ -1,0 +1,118 @@
+"""The engine's side of ``FocoosModel.train`` (focoos/models/focoos_model.py:221-274 -> focoos/trainer/trainer.py ``run_train`` :60-130,
+``TrainerLoop.run_step`` :723-773): one process per GPU, every rank steps ``TrainStep`` (HIP autograd graph + fused AdamW, gradients
+averaged with one bucketed RCCL all-reduce) over its shard of the total batch, rank 0 writes the artifacts the reference writes
+(``model_final.pth`` with the reference's state-dict keys, ``model_info.json``).
+
+What is mirrored: the data-parallel partitioning (``TrainerArgs.batch_size`` is the TOTAL batch; ``TrainingSampler`` strides one
+identically seeded permutation by rank; rank RNG seed = seed + rank), the optimizer / schedule / EMA hyper-parameters, freeze_bn vs
+batch statistics (SyncBN when num_gpus > 1, as ``trainer.py:333-334`` converts), the artifact names.  What is not: hub syncing,
+visualisation hooks, periodic COCO evaluation, early stopping (trainer-side features outside SURVEY §8)."""
+from __future__ import annotations
+
+import json
+import os
+import time
+from dataclasses import asdict
+from typing import Dict, List, Optional
+
+import torch
+
+from .ports import TrainerArgs
+
+WEIGHTS_NAME = "model_final.pth"    # focoos.ports.ArtifactName.WEIGHTS
+INFO_NAME = "model_info.json"       # focoos.ports.ArtifactName.INFO
+
+
+def _dist():
+    import torch.distributed as dist
+
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def run_train(args: TrainerArgs, data_train, data_val, model, processor, model_info, hub=None) -> Dict[str, float]:
+    """Per-rank training body.  ``model`` is the engine-backed FAIDetr mirror (its state_dict seeds the trainable graph and receives the
+    result); ``data_train[i]`` is a DatasetEntry.  Returns the last step's losses (floats) on every rank."""
+    from .train_data import TrainingSampler, per_rank_batch_size, rank_seed
+    from .train_detr import FAIDetrTrainable, TrainStep
+
+    if getattr(model, "family", "fai_detr") != "fai_detr":
+        raise NotImplementedError("training is built for the RT-DETR family; the mask families' backward (SURVEY A16) is not")
+    rank, world = _dist()
+    local = int(os.environ.get("LOCAL_RANK", rank))
+    dev = torch.device("cuda", local if world > 1 else (model.device.index or 0))
+    torch.cuda.set_device(dev)
+    torch.manual_seed(rank_seed(args.seed, rank))
+    norm = "FrozenBN" if args.freeze_bn else ("SyncBN" if world > 1 else "BN")
+    net = FAIDetrTrainable(model.config, norm=norm).to(dev)
+    net.load_state_dict(model.state_dict(), strict=True)
+    if args.init_checkpoint:
+        state = torch.load(args.init_checkpoint, map_location="cpu", weights_only=True)
+        net.load_state_dict(state.get("model", state), strict=False)
+    net.train()
+    stepper = TrainStep(net, lr=args.learning_rate, backbone_multiplier=args.backbone_multiplier, weight_decay=args.weight_decay,
+                        weight_decay_norm=args.weight_decay_norm, weight_decay_embed=args.weight_decay_embed, max_grad_norm=args.clip_gradients,
+                        ema_decay=args.ema_decay if args.ema_enabled else None, ema_warmups=args.ema_warmup, scheduler=args.scheduler,
+                        max_iters=args.max_iters, scheduler_extra=args.scheduler_extra)
+    bs = per_rank_batch_size(args.batch_size, world)
+    sampler = iter(TrainingSampler(len(data_train), shuffle=True, seed=args.seed, rank=rank, world_size=world))
+    processor.train(True)
+    losses: Dict[str, torch.Tensor] = {}
+    t0 = time.perf_counter()
+    for it in range(args.max_iters):
+        entries = [data_train[next(sampler)] for _ in range(bs)]
+        images, targets = processor.preprocess(entries, device=dev)
+        losses = stepper.step(images, targets)
+        if rank == 0 and args.log_period and (it + 1) % args.log_period == 0:
+            tot = float(sum(v.detach().float() for v in losses.values()))
+            print(f"[focoos_amd.train] iter {it + 1}/{args.max_iters} total_loss {tot:.4f} {(time.perf_counter() - t0) / (it + 1) * 1e3:.1f} ms/iter", flush=True)
+    torch.cuda.synchronize(dev)
+    out = {k: float(v.detach().float()) for k, v in losses.items()}
+    if rank == 0:
+        folder = os.path.join(args.output_dir, args.run_name.strip())
+        os.makedirs(folder, exist_ok=True)
+        state = stepper.ema.state_dict() if (args.ema_enabled and stepper.ema is not None) else {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        net_state = {k: v.detach().cpu() for k, v in net.state_dict().items()}
+        net_state.update({k: v.detach().cpu() for k, v in state.items() if k in net_state})
+        order = list(model.state_dict())            # the reference's key order (state_spec), as torch.save of the reference module writes it
+        full = {k: net_state[k] for k in order if k in net_state}
+        full.update({k: v for k, v in net_state.items() if k not in full})
+        torch.save({"model": full, "iteration": args.max_iters}, os.path.join(folder, WEIGHTS_NAME))
+        info = {k: getattr(model_info, k) for k in ("name", "model_family", "classes", "im_size", "task", "config", "description")}
+        info.update(name=args.run_name.strip(), weights_uri=os.path.join(folder, WEIGHTS_NAME), status="TRAINING_COMPLETED",
+                    train_args={k: v for k, v in asdict(args).items()}, final_losses=out)
+        with open(os.path.join(folder, INFO_NAME), "w") as f:
+            json.dump(info, f, indent=1, default=str)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier()
+    processor.eval()
+    return out
+
+
+def train(focoos_model, args: TrainerArgs, data_train, data_val=None, hub=None):
+    """FocoosModel.train (focoos_model.py:221-274): checks, one process per GPU through ``launch`` when num_gpus > 1, then reloads the
+    trained weights into the inference engine and returns to eval mode."""
+    from .launch import launch
+
+    assert len(data_train) > 0, "empty training set"
+    assert args.num_gpus, "Training without GPUs is not supported. num_gpus must be greater than 0"
+    if args.num_gpus > 1:
+        launch(run_train, args.num_gpus, dist_url="auto", args=(args, data_train, data_val, focoos_model.model, focoos_model.processor, focoos_model.model_info, hub))
+    else:
+        run_train(args, data_train, data_val, focoos_model.model, focoos_model.processor, focoos_model.model_info, hub)
+    folder = os.path.join(args.output_dir, args.run_name.strip())
+    model_path, info_path = os.path.join(folder, WEIGHTS_NAME), os.path.join(folder, INFO_NAME)
+    if not os.path.exists(model_path):
+        raise FileNotFoundError(f"Training did not end correctly, model file not found at {model_path}")
+    if not os.path.exists(info_path):
+        raise FileNotFoundError(f"Training did not end correctly, metadata file not found at {info_path}")
+    state = torch.load(model_path, map_location="cpu", weights_only=True)
+    focoos_model.model.load_state_dict(state["model"], strict=False)
+    focoos_model.model_info.name = args.run_name.strip()
+    focoos_model.model_info.weights_uri = model_path
+    focoos_model.model.eval()
+    focoos_model.processor.eval()
+    return focoos_model

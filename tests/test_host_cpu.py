@@ -211,3 +211,34 @@ def test_processor_manager_registry():
         assert type(ProcessorManager.get_processor("fai_detr", ModelRegistry.get_model_info("fai-detr-l-coco")["config"], 640)) is Custom
     finally:
         ProcessorManager._PROCESSOR_MAPPING["fai_detr"] = saved
+
+
+def test_trainer_ports_and_structures():
+    """TrainerArgs mirror (focoos/ports.py:970-1065) field-for-field against the reference when it is importable; Boxes / Instances helpers."""
+    import dataclasses
+
+    from focoos_amd.ports import Boxes, Instances, TrainerArgs
+
+    a = TrainerArgs(run_name="x")
+    assert a.batch_size == 16 and a.learning_rate == 5e-4 and a.clip_gradients == 0.1 and a.backbone_multiplier == 0.1 and a.scheduler == "MULTISTEP"
+    from oracle import ref_import
+
+    if ref_import.reference_available():
+        ref_import.install()
+        from focoos.ports import TrainerArgs as Ref
+
+        ref = {f.name: f.default for f in dataclasses.fields(Ref)}
+        mine = {f.name: f.default for f in dataclasses.fields(TrainerArgs)}
+        assert set(ref) == set(mine), set(ref) ^ set(mine)
+        for k in ref:
+            if k in ("output_dir", "num_gpus", "run_name"):
+                continue       # environment-dependent defaults (models dir, visible GPU count)
+            assert ref[k] == mine[k], (k, ref[k], mine[k])
+    b = Boxes(torch.tensor([[0.1, 0.1, 0.5, 0.5], [0.2, 0.2, 0.2, 0.9], [0.9, 0.9, 1.5, 1.2]]))
+    b.scale(100, 50)
+    b.clip((50, 100))
+    inst = Instances((50, 100), boxes=b, scores=torch.tensor([0.9, 0.8, 0.7]), classes=torch.tensor([1, 2, 3]))
+    kept = inst[b.nonempty()]
+    assert len(kept) == 2 and kept.classes.tolist() == [1, 3] and kept.boxes.tensor[1].tolist() == [90.0, 45.0, 100.0, 50.0]
+    with pytest.raises(AssertionError):
+        inst.set("bad", torch.zeros(2))

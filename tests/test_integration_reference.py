@@ -65,3 +65,53 @@ def test_register_replaces_bisenetformer_family_and_keeps_state_dict():
     cfg_ref = {k: v for k, v in cfgd.items() if k != "resolution"}
     model = cls(ConfigManager.from_dict(ModelFamily.BISENETFORMER, cfg_ref)).eval()
     assert list(model.state_dict()) == list(bf_state_spec(cfgd))   # checkpoint keys unchanged
+
+
+def test_register_installs_engine_processors_and_training_forward_contract():
+    """register() also replaces the three processors in the reference's ProcessorManager (device post-process behind model.infer()),
+    and the adapter's training forward is wired to the HIP training graph over the module's OWN parameters (share_parameters)."""
+    ref_import.install()
+    import torch
+    from focoos.model_manager import ConfigManager, ModelManager
+    from focoos.ports import ModelFamily
+    from focoos.processor.processor_manager import ProcessorManager
+
+    import focoos_amd.integration as fx
+    from focoos_amd.registry import ModelRegistry
+
+    fx.register()
+    cfgd = ModelRegistry.get_model_info("fai-detr-l-coco")["config"]
+    cfg = ConfigManager.from_dict(ModelFamily.DETR, dict(cfgd))
+    proc = ProcessorManager.get_processor(ModelFamily.DETR, cfg, 640)
+    assert type(proc).__name__ == "EngineDETRProcessor" and hasattr(proc, "eval_postprocess")   # the reference's own methods are inherited
+    assert type(ProcessorManager.get_processor(ModelFamily.MASKFORMER, ConfigManager.from_dict(
+        ModelFamily.MASKFORMER, dict(ModelRegistry.get_model_info("fai-mf-l-coco-ins")["config"])), 1024)).__name__ == "EngineMaskFormerProcessor"
+    # CPU tensors go through the reference's post-process (same class hierarchy), identical to the stock processor
+    from focoos.models.fai_detr.ports import DETRModelOutput
+
+    g = torch.Generator().manual_seed(0)
+    out = DETRModelOutput(logits=torch.rand(1, 300, 80, generator=g), boxes=torch.rand(1, 300, 4, generator=g), loss=None)
+    import numpy as np
+
+    dets = proc.postprocess(out, [np.zeros((480, 640, 3), np.uint8)], threshold=0.9)
+    assert len(dets) == 1 and all(d.conf > 0.9 for d in dets[0].detections)
+    # share_parameters: engine graph parameters become the reference module's Parameter objects (CPU stand-in for the HIP graph)
+    cls = ModelManager._models_family_map[ModelFamily.DETR.value]()
+    model = cls(cfg)
+    import copy
+
+    standin = copy.deepcopy(model.head.predictor.dec_score_classifier)     # any sub-tree with the same names works for the mechanism
+    n = fx.share_parameters(standin, model.head.predictor.dec_score_classifier)
+    assert n == len(list(standin.parameters())) and n > 0
+    for (k, p), (k2, q) in zip(standin.named_parameters(), model.head.predictor.dec_score_classifier.named_parameters()):
+        assert k == k2 and p is q
+    loss = sum((p.float() ** 2).sum() for p in standin.parameters())
+    loss.backward()
+    assert all(q.grad is not None for q in model.head.predictor.dec_score_classifier.parameters())   # gradients land in the reference module
+    # training forward on CPU is loud (no GPU here): the adapter never silently trains on a CPU path
+    if not torch.cuda.is_available():
+        from focoos_amd._lib import FocoosAmdError
+
+        model.train()
+        with pytest.raises(FocoosAmdError):
+            model(torch.zeros(1, 3, 64, 64), [])
