@@ -128,34 +128,72 @@ class FlatAdamW:
         self.flat_g.zero_()
 
 
+def notify_when_all_grads(tensors, callback, name):
+    """Autograd hooks on the activations that separate two parameter segments: once the gradient of EVERY tensor in ``tensors`` has
+    been computed, every layer after them has finished its backward (the autograd engine runs ready nodes latest-created first), so
+    those layers' parameter gradients are final and ``callback(name)`` may start their all-reduce."""
+    live = [t for t in tensors if t.requires_grad]
+    left = [len(live)]
+
+    def hook(_g):
+        left[0] -= 1
+        if left[0] == 0:
+            callback(name)
+
+    for t in live:
+        t.register_hook(hook)
+
+
 class BucketedGradAllReduce:
-    """Average a flat gradient buffer across data-parallel ranks in buckets with asynchronous all-reduce.
+    """Average a flat gradient buffer across data-parallel ranks in buckets with asynchronous all-reduce, OVERLAPPED with the rest
+    of backward - what DistributedDataParallel's reducer does for the reference (utils/distributed/dist.py:138-157).
     One process per GPU, ``torch.distributed`` backend "nccl" (= RCCL over xGMI) on MI355X, "gloo" in the CPU tests.
     xGMI is point-to-point (7 links/GPU), ring all-reduce is per-link bound: few large buckets (default 64 MiB) rather than
-    DDP's 25 MiB NVSwitch-tuned default; 173.7 MB of RT-DETR-L gradients = 3 collectives per step."""
+    DDP's 25 MiB NVSwitch-tuned default.
 
-    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 64 << 20, group=None):
+    ``segments``: element ranges [start, end) of the flat buffer whose gradients become final TOGETHER during backward, e.g.
+    [backbone | hybrid encoder | predictor head] for RT-DETR (parameter order = forward order, so backward finalises them last to
+    first).  Buckets never straddle a segment; ``launch_segment(i)`` - called from an autograd hook on the activation that separates
+    segment i from the layers before it - starts that segment's collectives while backward continues into the earlier layers.
+    ``launch()`` starts whatever has not been started (end of backward), ``wait()`` completes the step."""
+
+    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 64 << 20, group=None, segments: Optional[Sequence[Tuple[int, int]]] = None):
         import torch.distributed as dist
 
         self.dist, self.group = dist, group
         self.flat = flat_grad
         n = flat_grad.numel()
         per = max(1, bucket_bytes // flat_grad.element_size())
-        self.buckets = [(s, min(per, n - s)) for s in range(0, n, per)]
+        self.segments = [(int(a), int(b)) for a, b in (segments or [(0, n)])]
+        assert self.segments[0][0] == 0 and self.segments[-1][1] == n and all(self.segments[i][1] == self.segments[i + 1][0] for i in range(len(self.segments) - 1))
+        self.seg_buckets: List[List[Tuple[int, int]]] = [[(s, min(per, hi - s)) for s in range(lo, hi, per)] for lo, hi in self.segments]
+        self.buckets = [bk for sb in self.seg_buckets for bk in sb]
         self.handles: List = []
+        self.launched = [False] * len(self.segments)
+        self.log: List[Tuple[str, int]] = []      # ("segment", i) / ("backward_end", -1) in launch order: what the overlap test reads
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
 
-    def launch(self, first: int = 0, last: Optional[int] = None):
-        """Start the all-reduce of buckets [first, last) (call as soon as their gradients are final: overlap with backward)."""
+    def launch_segment(self, i: int):
+        """Start the all-reduce of segment i's buckets (idempotent within a step): its gradients are final."""
+        if self.launched[i]:
+            return
+        self.launched[i] = True
+        self.log.append(("segment", i))
         if self.world == 1:
             return
-        last = len(self.buckets) if last is None else last
-        for s, n in self.buckets[first:last]:
+        for s, n in self.seg_buckets[i]:
             self.handles.append(self.dist.all_reduce(self.flat[s:s + n], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def launch(self, first: int = 0, last: Optional[int] = None):
+        """End of backward: start every segment that no hook has started yet."""
+        self.log.append(("backward_end", -1))
+        for i in range(len(self.segments) - 1, -1, -1):
+            self.launch_segment(i)
 
     def wait(self):
         for h in self.handles:
             h.wait()
         self.handles.clear()
+        self.launched = [False] * len(self.segments)
         if self.world > 1:
             self.flat.div_(self.world)

@@ -291,9 +291,20 @@ class FAIDetrTrainable(nn.Module):
         from .train_nn import set_norm_mode
         set_norm_mode(self, norm)
 
+    grad_ready = None   # callable(segment_name) set by TrainStep: "head" / "encoder" gradients are final (overlapped all-reduce)
+
+    def _notify_when_all_grads(self, tensors, name: str):
+        if self.grad_ready is not None:
+            from .train import notify_when_all_grads
+
+            notify_when_all_grads(tensors, self.grad_ready, name)
+
     def forward(self, images: torch.Tensor, targets: Sequence, forced_topk=None, fixed_matches=None):
         f = self.pixel_decoder.backbone(images)
-        enc = self.pixel_decoder([f["res3"], f["res4"], f["res5"]])
+        feats = [f["res3"], f["res4"], f["res5"]]
+        self._notify_when_all_grads(feats, "encoder")
+        enc = self.pixel_decoder(feats)
+        self._notify_when_all_grads(list(enc), "head")
         out = self.head.predictor(enc, forced_topk)
         self.last_outputs = out
         return self.head.criterion(out, targets, fixed_matches)
@@ -333,7 +344,24 @@ class TrainStep:
                 p.data = self.opt.params[n]
                 p.grad = self.opt.grads[n]
         self.named = named
-        self.reducer = BucketedGradAllReduce(self.opt.flat_g)
+        # gradient all-reduce overlapped with backward: the flat buffer is [backbone | hybrid encoder | predictor] in parameter order;
+        # backward finalises the predictor's gradients first (hook on the encoder outputs), then the encoder's (hook on res3..5)
+        def seg_of(n):
+            return 0 if n.startswith("pixel_decoder.backbone.") else (1 if n.startswith("pixel_decoder.") else 2)
+
+        base = self.opt.flat_p.data_ptr()
+        segs = [seg_of(n) for n, _ in named]
+        offs = [(self.opt.params[n].data_ptr() - base) // 4 for n, _ in named]
+        segments = None
+        if segs == sorted(segs) and offs == sorted(offs) and set(segs) == {0, 1, 2}:   # the flat layout really is [backbone | encoder | head]
+            b1, b2 = offs[segs.index(1)], offs[segs.index(2)]
+            segments = [(0, b1), (b1, b2), (b2, self.opt.flat_g.numel())]
+        self._seg_index = {"backbone": 0, "encoder": 1, "head": 2} if segments else {}
+        self.reducer = BucketedGradAllReduce(self.opt.flat_g, segments=segments)
+        import os as _os
+
+        if self._seg_index and int(_os.environ.get("FX_DP_OVERLAP", "1")):
+            model.grad_ready = lambda name: self.reducer.launch_segment(self._seg_index[name])
         # what DistributedDataParallel does at construction (utils/distributed/dist.py:152): every rank starts from rank 0's parameters
         # and buffers (the engine's parameters are created with torch.empty; ranks that loaded different checkpoints would drift silently)
         import torch.distributed as dist
