@@ -100,6 +100,7 @@ SIGNATURES = {
     "fx_mask_set_loss_f32": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, C.c_float, C.c_float,
                              C.c_float, C.c_float, C.c_float, _vp, C.c_size_t, _vp, _vp],
     "fx_dwconv3x3s2_nhwc_bf16": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "fx_dwconv3x3s2_nhwc_f32out": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "fx_global_mean_nhwc_bf16": [_vp, _i, _vp, _i, _i, _i, _i, _vp],
     "fx_pooled_linear_f32": [_vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp],
     "fx_channel_gate_nhwc_bf16": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
@@ -116,11 +117,11 @@ SIGNATURES = {
     "fx_maxpool3x3s2_bwd_nhwc_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "fx_normalize_pad8": [_vp, _i, _vp, _vp, _vp, C.c_int64, _vp],
     "fx_stem_conv3x3s2_linear": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "fx_bn_stats_bf16": [_vp, _i, _vp, C.c_int64, _i, _vp],
+    "fx_bn_stats_bf16": [_vp, _i, _i, _vp, C.c_int64, _i, _vp],
     "fx_bn_finalize_f32": [_vp, C.c_float, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
-    "fx_bn_apply_bf16": [_vp, _i, _vp, _vp, _vp, _i, _i, _vp, _i, C.c_int64, _i, _vp],
-    "fx_bn_bwd_stats_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, C.c_int64, _i, _vp],
-    "fx_bn_bwd_apply_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, C.c_float, _vp, _i, _vp, _i, C.c_int64, _i, _vp],
+    "fx_bn_apply_bf16": [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, C.c_int64, _i, _vp],
+    "fx_bn_bwd_stats_bf16": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, C.c_int64, _i, _vp],
+    "fx_bn_bwd_apply_bf16": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, C.c_float, _vp, _i, _vp, _i, C.c_int64, _i, _vp],
     "fx_act_fwd_bf16": [_vp, _i, _vp, _i, C.c_int64, _i, _i, _vp],
     "fx_act_bwd_bf16": [_vp, _i, _vp, _i, _vp, _i, C.c_int64, _i, _i, _vp],
     "fx_colsum_bf16": [_vp, _i, _vp, C.c_int64, _i, _vp],
@@ -129,6 +130,13 @@ SIGNATURES = {
     "fx_cast_f32_bf16": [_vp, _vp, C.c_int64, _vp],
     "fx_mha_bwd_workspace_bytes": [_i, _i, _i, _i],
     "fx_mha_bwd_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, C.c_size_t, _vp],
+    "fx_mha_masked_bwd_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, C.c_size_t, _vp],
+    "fx_mask_set_loss_bwd_f32": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, C.c_float, C.c_float,
+                                 C.c_float, C.c_float, C.c_float, _vp, C.c_size_t, _vp, _vp, _i, _vp, _vp],
+    "fx_planes_to_rows_bf16": [_vp, _i, _i, _vp, _i, _i, _i, _vp],
+    "fx_dwconv3x3s2_bwd_nhwc_bf16": [_vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp],
+    "fx_rowdot_nhwc_bf16": [_vp, _i, _vp, _i, C.c_float, _vp, _i, _i, _i, _i, _i, _vp],
+    "fx_bcast_vec_nhwc_bf16": [_vp, _i, C.c_float, _vp, _i, _i, _i, _i, _vp],
     "fx_scatter_rows_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
     "fx_vfl_loss_bf16": [_vp, _i, _vp, _vp, _f, _f, _f, _vp, _vp, _i, C.c_int64, _i, _vp],
     "fx_stream_fork": [_vp, _vp],

@@ -308,8 +308,10 @@ extern "C" int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream_) {
   a.r_bytes = (unsigned)r_bytes;
   // Layers with a fragment-ordered weight copy: 3x3 / stride 1 -> halo kernel (pixels fetched once for all nine taps);
   // 1x1 with C, N multiples of 256 -> the same machinery with 256-channel LDS rows (conv3x3_flat.hip)
-  static const int c3_on = fx_tune("FX_CONV3_FLAT", 1), c3_min_m = fx_tune("FX_CONV3_MIN_M", 40000);
-  static const int pw_on = fx_tune("FX_PW_FLAT", 1), pw_min_m = fx_tune("FX_PW_MIN_M", 40000);
+  // (the two size thresholds are re-read per call - a getenv each, nothing under graph replay - so that kernel tests can route
+  // small shapes here while the end-to-end tests keep the production routing)
+  static const int c3_on = fx_tune("FX_CONV3_FLAT", 1), pw_on = fx_tune("FX_PW_FLAT", 1);
+  const int c3_min_m = fx_tune("FX_CONV3_MIN_M", 40000), pw_min_m = fx_tune("FX_PW_MIN_M", 40000);
   if (d->w_frag && ((uintptr_t)d->w_frag % 16) == 0 && d->stride == 1 && !d->pool2 && !d->out_f32) {
     const int mode = fx_c3_epilogue_mode(d->act, d->residual != nullptr, d->residual_after_act);
     if (c3_on && d->KH == 3 && d->KW == 3 && d->pad == 1 && !d->y_batch_stride && mode >= 0 && mode <= 3 && a.M >= c3_min_m &&

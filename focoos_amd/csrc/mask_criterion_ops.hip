@@ -1,4 +1,4 @@
-// Mask-classification training criterion of the MaskFormer / BiSeNetFormer families, forward values:
+// Mask-classification training criterion of the MaskFormer / BiSeNetFormer families, values and gradients:
 //   point_sample                                   focoos/nn/layers/point_rend.py:29-52 (F.grid_sample bilinear / zeros / align_corners=False)
 //   MaskHungarianMatcher.memory_efficient_forward  focoos/models/fai_mf/loss.py:661-723 (cost blocks; the assignment itself is fx_lsa_f32)
 //   SetCriterion.loss_labels (ce_loss) / loss_masks :411-431, :463-523 with get_uncertain_point_coords_with_randomness point_rend.py:73-128
@@ -175,14 +175,34 @@ __global__ __launch_bounds__(256) void mask_label_ce_kernel(const float* __restr
 // the k = num_points - n_extra with the smallest |logit| (torch.topk of -|logit|; ties -> lowest index), found by a 4-pass
 // radix select on the bit pattern of |x| with the samples recomputed per pass (4 taps each) instead of stored; then the
 // BCE / dice sums over those points plus the n_extra uniformly drawn ones, target values sampled bilinearly at the same points.
+// Transpose of ps_sample: the gradient v of a sampled value goes to its (in-bounds) taps with the same weights.
+__device__ __forceinline__ void ps_scatter(float* g, int H, int W, float cx, float cy, float v) {
+#pragma clang fp contract(off)
+  const float ix = ps_unnormalize(cx, W), iy = ps_unnormalize(cy, H);
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy;
+  const float w = ix - fx, e = 1.0f - w, n = iy - fy, s = 1.0f - n;
+  const bool xa = x0 >= 0 && x0 < W, xb = x0 + 1 >= 0 && x0 + 1 < W, ya = y0 >= 0 && y0 < H, yb = y0 + 1 >= 0 && y0 + 1 < H;
+  if (ya && xa) unsafeAtomicAdd(g + (int64_t)y0 * W + x0, v * (e * s));
+  if (ya && xb) unsafeAtomicAdd(g + (int64_t)y0 * W + x0 + 1, v * (w * s));
+  if (yb && xa) unsafeAtomicAdd(g + (int64_t)(y0 + 1) * W + x0, v * (e * n));
+  if (yb && xb) unsafeAtomicAdd(g + (int64_t)(y0 + 1) * W + x0 + 1, v * (w * n));
+}
+
+// BWD = false: the sums of one matched pair -> rows[n].  BWD = true (same selection, recomputed): d loss / d mask logit of every
+// selected point, g_bce * (sigmoid(x) - t) + g_dice * s (1 - s) * d dice / d s with dice = 1 - (2 st + 1) / (ss + tt + 1) from the
+// forward's rows[n], scattered to the four taps of the point in the pair's [h,w] plane of dmasks (zero-initialised by the caller;
+// the sample coordinates carry no gradient: the reference draws / selects them under no_grad, loss.py:487-497).
 #define MPL_THREADS 1024
-template <typename TT>
+template <typename TT, bool BWD>
 __global__ __launch_bounds__(MPL_THREADS) void mask_point_loss_kernel(const float* __restrict__ pred_masks, int h, int w, const TT* __restrict__ tgt_masks,
                                                                       int H, int W, const int32_t* __restrict__ tgt_offsets, int B, int Q,
                                                                       const int32_t* __restrict__ pred_idx, const int32_t* __restrict__ tgt_idx,
                                                                       const float* __restrict__ rand_over, int n_over,
                                                                       const float* __restrict__ rand_extra, int n_extra, int k_imp,
-                                                                      double* __restrict__ rows /*[N][4]: bce sum, sum s*t, sum s, sum t*/) {
+                                                                      double* __restrict__ rows /*[N][4]: bce sum, sum s*t, sum s, sum t*/,
+                                                                      float c_bce, float c_dice, const float* __restrict__ g3,
+                                                                      float* __restrict__ dmasks) {
   __shared__ unsigned hist[256];
   __shared__ unsigned s_prefix, s_need;
   __shared__ unsigned s_scan[MPL_THREADS];
@@ -238,12 +258,27 @@ __global__ __launch_bounds__(MPL_THREADS) void mask_point_loss_kernel(const floa
     __syncthreads();
   }
   unsigned tie_rank = s_scan[tid] - ties;   // ties before this thread's range
-  auto add_point = [&](float x, float t) {
-    bce += (double)(fmaxf(x, 0.0f) - x * t + log1pf(expf(-fabsf(x))));
+  float dice_a = 0.0f, dice_b = 0.0f;   // d dice / d s_p = dice_a * t_p + dice_b
+  float g_bce = 0.0f, g_dice = 0.0f;    // upstream gradients of loss_mask / loss_dice times their normalisations
+  float* gplane = nullptr;
+  if (BWD) {
+    g_bce = g3[1] * c_bce;
+    g_dice = g3[2] * c_dice;
+    const double ST = rows[(int64_t)n * 4 + 1], D = rows[(int64_t)n * 4 + 2] + rows[(int64_t)n * 4 + 3] + 1.0;
+    dice_a = (float)(-2.0 / D);
+    dice_b = (float)((2.0 * ST + 1.0) / (D * D));
+    gplane = dmasks + ((int64_t)b * Q + pred_idx[n]) * h * w;
+  }
+  auto add_point = [&](float x, float t, float cx, float cy) {
     const float s = 1.0f / (1.0f + expf(-x));
-    st += (double)(s * t);
-    ss += (double)s;
-    tt += (double)t;
+    if (BWD) {
+      ps_scatter(gplane, h, w, cx, cy, g_bce * (s - t) + g_dice * (s * (1.0f - s)) * (dice_a * t + dice_b));
+    } else {
+      bce += (double)(fmaxf(x, 0.0f) - x * t + log1pf(expf(-fabsf(x))));
+      st += (double)(s * t);
+      ss += (double)s;
+      tt += (double)t;
+    }
   };
   if (k_imp > 0)
     for (int i = i0; i < i1; ++i) {
@@ -252,13 +287,14 @@ __global__ __launch_bounds__(MPL_THREADS) void mask_point_loss_kernel(const floa
       const unsigned key = __float_as_uint(fabsf(x));
       bool take = key < prefix;
       if (key == prefix) take = tie_rank++ < need;
-      if (take) add_point(x, ps_sample(tm, H, W, cx, cy));
+      if (take) add_point(x, ps_sample(tm, H, W, cx, cy), cx, cy);
     }
   const float* re = rand_extra + (int64_t)n * n_extra * 2;
   for (int i = tid; i < n_extra; i += MPL_THREADS) {
     const float cx = re[2 * i], cy = re[2 * i + 1];
-    add_point(ps_sample(pm, h, w, cx, cy), ps_sample(tm, H, W, cx, cy));
+    add_point(ps_sample(pm, h, w, cx, cy), ps_sample(tm, H, W, cx, cy), cx, cy);
   }
+  if (BWD) return;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     bce += __shfl_xor(bce, o, 64); st += __shfl_xor(st, o, 64); ss += __shfl_xor(ss, o, 64); tt += __shfl_xor(tt, o, 64);
@@ -275,7 +311,7 @@ __global__ __launch_bounds__(MPL_THREADS) void mask_point_loss_kernel(const floa
 
 __global__ __launch_bounds__(256) void mask_loss_final_kernel(const double* __restrict__ ce_partial, int n_rows, const double* __restrict__ rows, int N,
                                                               int num_points, float num_masks, float w_ce, float w_mask, float w_dice,
-                                                              float* __restrict__ out3) {
+                                                              float* __restrict__ out3, double* __restrict__ wsum_out) {
   __shared__ double red[4][256];
   double a = 0.0, wsum = 0.0, lm = 0.0, ld = 0.0;
   for (int i = threadIdx.x; i < n_rows; i += 256) a += ce_partial[2 * i], wsum += ce_partial[2 * i + 1];
@@ -291,6 +327,7 @@ __global__ __launch_bounds__(256) void mask_loss_final_kernel(const double* __re
     __syncthreads();
   }
   if (threadIdx.x == 0) {
+    if (wsum_out) *wsum_out = red[1][0];
     out3[0] = w_ce * (float)(red[0][0] / red[1][0]);
     out3[1] = w_mask * (float)(red[2][0] / (double)num_masks);
     out3[2] = w_dice * (float)(red[3][0] / (double)num_masks);
@@ -299,7 +336,7 @@ __global__ __launch_bounds__(256) void mask_loss_final_kernel(const double* __re
 
 extern "C" size_t fx_mask_set_loss_workspace_bytes(int B, int Q, int sum_T) {
   if (B <= 0 || Q <= 0 || sum_T < 0) return 0;
-  return ((size_t)B * Q * 2 + (size_t)sum_T * 4) * sizeof(double);
+  return ((size_t)B * Q * 2 + (size_t)sum_T * 4 + 1) * sizeof(double);   // CE partials | pair sums | sum of the CE class weights
 }
 
 extern "C" int fx_mask_set_loss_f32(const float* logits, int ldl, const float* pred_masks, int h, int w, const void* tgt_masks, int tgt_is_u8, int H,
@@ -318,13 +355,78 @@ extern "C" int fx_mask_set_loss_f32(const float* logits, int ldl, const float* p
                      ce_partial);
   if (sum_T > 0) {
     if (tgt_is_u8)
-      hipLaunchKernelGGL(mask_point_loss_kernel<uint8_t>, dim3(sum_T), dim3(MPL_THREADS), 0, stream, pred_masks, h, w, (const uint8_t*)tgt_masks, H, W,
-                         tgt_offsets, B, Q, pred_idx, tgt_idx, rand_over, n_over, rand_extra, n_extra, num_points - n_extra, rows);
+      hipLaunchKernelGGL((mask_point_loss_kernel<uint8_t, false>), dim3(sum_T), dim3(MPL_THREADS), 0, stream, pred_masks, h, w, (const uint8_t*)tgt_masks,
+                         H, W, tgt_offsets, B, Q, pred_idx, tgt_idx, rand_over, n_over, rand_extra, n_extra, num_points - n_extra, rows, 0.0f, 0.0f,
+                         (const float*)nullptr, (float*)nullptr);
     else
-      hipLaunchKernelGGL(mask_point_loss_kernel<float>, dim3(sum_T), dim3(MPL_THREADS), 0, stream, pred_masks, h, w, (const float*)tgt_masks, H, W,
-                         tgt_offsets, B, Q, pred_idx, tgt_idx, rand_over, n_over, rand_extra, n_extra, num_points - n_extra, rows);
+      hipLaunchKernelGGL((mask_point_loss_kernel<float, false>), dim3(sum_T), dim3(MPL_THREADS), 0, stream, pred_masks, h, w, (const float*)tgt_masks, H,
+                         W, tgt_offsets, B, Q, pred_idx, tgt_idx, rand_over, n_over, rand_extra, n_extra, num_points - n_extra, rows, 0.0f, 0.0f,
+                         (const float*)nullptr, (float*)nullptr);
   }
   hipLaunchKernelGGL(mask_loss_final_kernel, dim3(1), dim3(256), 0, stream, ce_partial, B * Q, rows, sum_T, num_points, num_masks, w_ce, w_mask, w_dice,
-                     out3);
+                     out3, rows + (size_t)sum_T * 4);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Gradients of the three losses of one prediction set (the backward of fx_mask_set_loss_f32 under upstream gradients g[0..2]):
+//   dlogits[b,q,c] = g0 * w_ce * w[y] / sum_rows w[y] * (softmax_c - [c == y])        (F.cross_entropy with class weights, mean)
+//   dmasks: see mask_point_loss_kernel<.., true>; planes of unmatched queries stay zero.
+__global__ __launch_bounds__(256) void mask_label_ce_bwd_kernel(const float* __restrict__ logits, int ldl, const int32_t* __restrict__ tgt_labels,
+                                                                const int32_t* __restrict__ tgt_offsets, const int32_t* __restrict__ pred_idx,
+                                                                const int32_t* __restrict__ tgt_idx, int n_rows, int Q, int K, float eos_coef,
+                                                                const double* __restrict__ wsum, const float* __restrict__ g, float w_ce,
+                                                                float* __restrict__ dlogits, int lddl) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n_rows) return;
+  const int b = row / Q, q = row - b * Q;
+  const int t0 = tgt_offsets[b], T = tgt_offsets[b + 1] - t0;
+  int y = K;
+  for (int i = lane; i < T; i += 64)
+    if (pred_idx[t0 + i] == q) y = tgt_labels[t0 + tgt_idx[t0 + i]];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) y = min(y, __shfl_xor(y, o, 64));
+  const float* lp = logits + (int64_t)row * ldl;
+  float mx = -INFINITY;
+  for (int c = lane; c <= K; c += 64) mx = fmaxf(mx, lp[c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float se = 0.0f;
+  for (int c = lane; c <= K; c += 64) se += expf(lp[c] - mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+  const float coef = g[0] * w_ce * (y == K ? eos_coef : 1.0f) / (float)wsum[0];
+  float* dp = dlogits + (int64_t)row * lddl;
+  for (int c = lane; c <= K; c += 64) dp[c] = coef * (expf(lp[c] - mx) / se - (c == y ? 1.0f : 0.0f));
+}
+
+extern "C" int fx_mask_set_loss_bwd_f32(const float* logits, int ldl, const float* pred_masks, int h, int w, const void* tgt_masks, int tgt_is_u8, int H,
+                                        int W, const int32_t* tgt_labels, const int32_t* tgt_offsets, int sum_T, const int32_t* pred_idx,
+                                        const int32_t* tgt_idx, const float* rand_over, int n_over, const float* rand_extra, int n_extra,
+                                        int num_points, int B, int Q, int K, float eos_coef, float num_masks, float w_ce, float w_mask, float w_dice,
+                                        const void* workspace, size_t workspace_bytes, const float* grad3, float* dlogits, int lddl, float* dmasks,
+                                        fx_stream_t stream_) {
+  FX_CHECK_ARG(logits && pred_masks && tgt_offsets && workspace && grad3 && dlogits && dmasks && B > 0 && Q > 0 && K > 0);
+  FX_CHECK_ARG(ldl >= K + 1 && lddl >= K + 1 && h > 0 && w > 0 && H > 0 && W > 0 && sum_T >= 0 && num_points > 0 && n_extra >= 0 && n_extra <= num_points);
+  FX_CHECK_ARG(n_over >= num_points - n_extra && num_masks > 0.0f);
+  FX_CHECK_ARG(sum_T == 0 || (tgt_masks && tgt_labels && pred_idx && tgt_idx && (n_extra == 0 || rand_extra) && (num_points == n_extra || rand_over)));
+  FX_CHECK_ARG(workspace_bytes >= fx_mask_set_loss_workspace_bytes(B, Q, sum_T) && ((uintptr_t)workspace % 8) == 0);
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const double* ce_partial = reinterpret_cast<const double*>(workspace);
+  double* rows = const_cast<double*>(ce_partial) + (size_t)B * Q * 2;
+  hipLaunchKernelGGL(mask_label_ce_bwd_kernel, dim3((B * Q + 3) / 4), dim3(256), 0, stream, logits, ldl, tgt_labels, tgt_offsets, pred_idx, tgt_idx, B * Q, Q,
+                     K, eos_coef, rows + (size_t)sum_T * 4, grad3, w_ce, dlogits, lddl);
+  if (sum_T > 0) {
+    const float c_bce = w_mask / (num_masks * (float)num_points), c_dice = w_dice / num_masks;
+    if (tgt_is_u8)
+      hipLaunchKernelGGL((mask_point_loss_kernel<uint8_t, true>), dim3(sum_T), dim3(MPL_THREADS), 0, stream, pred_masks, h, w, (const uint8_t*)tgt_masks,
+                         H, W, tgt_offsets, B, Q, pred_idx, tgt_idx, rand_over, n_over, rand_extra, n_extra, num_points - n_extra, rows, c_bce, c_dice,
+                         grad3, dmasks);
+    else
+      hipLaunchKernelGGL((mask_point_loss_kernel<float, true>), dim3(sum_T), dim3(MPL_THREADS), 0, stream, pred_masks, h, w, (const float*)tgt_masks, H, W,
+                         tgt_offsets, B, Q, pred_idx, tgt_idx, rand_over, n_over, rand_extra, n_extra, num_points - n_extra, rows, c_bce, c_dice,
+                         grad3, dmasks);
+  }
   return fx_launch_status();
 }

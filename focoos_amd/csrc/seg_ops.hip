@@ -11,8 +11,9 @@
 // ------------------------------------------------------------------------------------------------
 // y[b,ho,wo,c] = bias[c] + sum_{kh,kw} w[kh*3+kw][c] * x[b, 2ho-1+kh, 2wo-1+kw, c]   (zero padding; AvgPool2d's default
 // count_include_pad=True is the same sum with w = 1/9).  x bf16 NHWC (row stride ldx), w f32 [9][C], bias f32 [C] or NULL.
+template <typename OT>
 __global__ __launch_bounds__(256) void dwconv3x3s2_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ w,
-                                                          const float* __restrict__ bias, bf16_t* __restrict__ y, int ldy, int B, int H, int W,
+                                                          const float* __restrict__ bias, OT* __restrict__ y, int ldy, int B, int H, int W,
                                                           int Ho, int Wo, int C8) {
   const int64_t total = (int64_t)B * Ho * Wo * C8;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -42,7 +43,13 @@ __global__ __launch_bounds__(256) void dwconv3x3s2_kernel(const bf16_t* __restri
         acc[4] = fmaf(v[4], w1.x, acc[4]); acc[5] = fmaf(v[5], w1.y, acc[5]); acc[6] = fmaf(v[6], w1.z, acc[6]); acc[7] = fmaf(v[7], w1.w, acc[7]);
       }
     }
-    *reinterpret_cast<uint4*>(y + (((int64_t)b * Ho + ho) * Wo + wo) * ldy + c8 * 8) = pack_bf16x8(acc);
+    OT* yp = y + (((int64_t)b * Ho + ho) * Wo + wo) * ldy + c8 * 8;
+    if constexpr (sizeof(OT) == 4) {
+      *reinterpret_cast<float4*>(yp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+      *reinterpret_cast<float4*>(yp + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    } else {
+      *reinterpret_cast<uint4*>(yp) = pack_bf16x8(acc);
+    }
   }
 }
 
@@ -54,8 +61,21 @@ extern "C" int fx_dwconv3x3s2_nhwc_bf16(const void* x, int ldx, const float* w, 
   const int64_t total = (int64_t)B * Ho * Wo * (C / 8);
   int64_t grid = (total + 255) / 256;
   if (grid > 256 * 32) grid = 256 * 32;
-  hipLaunchKernelGGL(dwconv3x3s2_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)x, ldx, w, bias,
+  hipLaunchKernelGGL(dwconv3x3s2_kernel<bf16_t>, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)x, ldx, w, bias,
                      (bf16_t*)y, ldy, B, H, W, Ho, Wo, C / 8);
+  return fx_launch_status();
+}
+
+extern "C" int fx_dwconv3x3s2_nhwc_f32out(const void* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int H, int W, int C,
+                                          fx_stream_t stream_) {
+  FX_CHECK_ARG(x && w && y && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0 && ldx >= C && ldy >= C && ldx % 8 == 0 && ldy % 8 == 0);
+  FX_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)w % 16) == 0);
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const int64_t total = (int64_t)B * Ho * Wo * (C / 8);
+  int64_t grid = (total + 255) / 256;
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(dwconv3x3s2_kernel<float>, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)x, ldx, w, bias, y,
+                     ldy, B, H, W, Ho, Wo, C / 8);
   return fx_launch_status();
 }
 

@@ -317,6 +317,21 @@ extern "C" int fx_normalize_pad8(const void* img, int is_f32, const float* mean,
 //   backward: da = dy * act'(a), a = z * scale + shift (recomputed, nothing but z is kept from the forward)
 //             fx_bn_bwd_stats_bf16 -> sums[c] = sum da (= dbeta), sums[C + c] = sum da * xhat (= dgamma), xhat = (z - mean) * rstd
 //             fx_bn_bwd_apply_bf16 -> dz = scale * (da - sums[c] / n - xhat * sums[C + c] / n)   [and da itself for a residual branch]
+// The conv output z is read as bf16 or - z_f32 - as fp32: with batch statistics y depends on z - mean, and a bf16 z keeps 8 bits of z,
+// not of z - mean; channels whose |mean| is several standard deviations lose most of their signal, and the error compounds over the
+// 50-100 normalised layers of a backbone.  The trainable graphs therefore keep z in fp32 (conv epilogue out_f32).
+template <typename ZT>
+__device__ __forceinline__ void bn_ld8(const ZT* __restrict__ p, float* v);
+template <>
+__device__ __forceinline__ void bn_ld8<bf16_t>(const bf16_t* __restrict__ p, float* v) {
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(p), v);
+}
+template <>
+__device__ __forceinline__ void bn_ld8<float>(const float* __restrict__ p, float* v) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+
 #define BN_ROWS(C) ((C) >= 256 ? 256 : 1024)   // rows per workgroup: narrow tensors have many more rows and 4-8x the row lanes
 __device__ __forceinline__ float bn_act_grad(float a, int act) {
   switch (act) {
@@ -331,8 +346,8 @@ __device__ __forceinline__ float bn_act_grad(float a, int act) {
 }
 
 // shared column-reduction skeleton: 32 column groups x 8 row lanes per workgroup, BN_ROWS rows, two sums per channel
-template <int MODE>  // 0: (z, z^2)   1: (da, da * xhat)
-__global__ __launch_bounds__(256) void bn_reduce_kernel(const bf16_t* __restrict__ z, int ldz, const bf16_t* __restrict__ dy, int lddy,
+template <int MODE, typename ZT>  // 0: (z, z^2)   1: (da, da * xhat)
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const ZT* __restrict__ z, int ldz, const bf16_t* __restrict__ dy, int lddy,
                                                         const bf16_t* __restrict__ res, int ldr, const float* __restrict__ scale, const float* __restrict__ shift,
                                                         const float* __restrict__ mean, const float* __restrict__ rstd, int act,
                                                         float* __restrict__ sums, int64_t rows, int C, int rpb) {
@@ -355,7 +370,7 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const bf16_t* __restrict
     }
     for (int64_t r = r0 + rl; r < r1; r += nrl) {
       float v[8];
-      unpack_bf16x8(*reinterpret_cast<const uint4*>(z + r * ldz + c0), v);
+      bn_ld8<ZT>(z + r * ldz + c0, v);
       if (MODE == 0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) s0[j] += v[j], s1[j] += v[j] * v[j];
@@ -385,25 +400,38 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const bf16_t* __restrict
   }
 }
 
-extern "C" int fx_bn_stats_bf16(const void* z, int ldz, float* sums, int64_t rows, int C, fx_stream_t stream_) {
+extern "C" int fx_bn_stats_bf16(const void* z, int ldz, int z_f32, float* sums, int64_t rows, int C, fx_stream_t stream_) {
   FX_CHECK_ARG(z && sums && rows > 0 && C > 0 && C % 8 == 0 && ldz >= C && ldz % 8 == 0);
-  hipLaunchKernelGGL(bn_reduce_kernel<0>, dim3((C + 255) / 256, (unsigned)((rows + BN_ROWS(C) - 1) / BN_ROWS(C))), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)z, ldz, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr, nullptr, 0, sums, rows, C, BN_ROWS(C));
+  const dim3 grid((C + 255) / 256, (unsigned)((rows + BN_ROWS(C) - 1) / BN_ROWS(C)));
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (z_f32)
+    hipLaunchKernelGGL((bn_reduce_kernel<0, float>), grid, dim3(256), 0, stream, (const float*)z, ldz, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr,
+                       nullptr, 0, sums, rows, C, BN_ROWS(C));
+  else
+    hipLaunchKernelGGL((bn_reduce_kernel<0, bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)z, ldz, nullptr, 0, nullptr, 0, nullptr, nullptr, nullptr,
+                       nullptr, 0, sums, rows, C, BN_ROWS(C));
   return fx_launch_status();
 }
 
-extern "C" int fx_bn_bwd_stats_bf16(const void* dy, int lddy, const void* z, int ldz, const void* residual, int ldr, const float* scale,
+extern "C" int fx_bn_bwd_stats_bf16(const void* dy, int lddy, const void* z, int ldz, int z_f32, const void* residual, int ldr, const float* scale,
                                     const float* shift, const float* mean, const float* rstd, int act, float* sums, int64_t rows, int C,
                                     fx_stream_t stream_) {
   FX_CHECK_ARG(!residual || (ldr >= C && ldr % 8 == 0));
   FX_CHECK_ARG(dy && z && scale && shift && mean && rstd && sums && rows > 0 && C > 0 && C % 8 == 0);
   FX_CHECK_ARG(ldz >= C && lddy >= C && ldz % 8 == 0 && lddy % 8 == 0);
-  hipLaunchKernelGGL(bn_reduce_kernel<1>, dim3((C + 255) / 256, (unsigned)((rows + BN_ROWS(C) - 1) / BN_ROWS(C))), dim3(256), 0,
-                     reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)z, ldz, (const bf16_t*)dy, lddy, (const bf16_t*)residual, ldr, scale, shift, mean, rstd, act, sums, rows, C, BN_ROWS(C));
+  const dim3 grid((C + 255) / 256, (unsigned)((rows + BN_ROWS(C) - 1) / BN_ROWS(C)));
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (z_f32)
+    hipLaunchKernelGGL((bn_reduce_kernel<1, float>), grid, dim3(256), 0, stream, (const float*)z, ldz, (const bf16_t*)dy, lddy, (const bf16_t*)residual, ldr,
+                       scale, shift, mean, rstd, act, sums, rows, C, BN_ROWS(C));
+  else
+    hipLaunchKernelGGL((bn_reduce_kernel<1, bf16_t>), grid, dim3(256), 0, stream, (const bf16_t*)z, ldz, (const bf16_t*)dy, lddy, (const bf16_t*)residual,
+                       ldr, scale, shift, mean, rstd, act, sums, rows, C, BN_ROWS(C));
   return fx_launch_status();
 }
 
-__global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict__ z, int ldz, const float* __restrict__ scale,
+template <typename ZT>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const ZT* __restrict__ z, int ldz, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, const bf16_t* __restrict__ res, int ldr, int act,
                                                        bf16_t* __restrict__ y, int ldy, int64_t rows, int C8) {
   const int64_t total = rows * C8;
@@ -411,7 +439,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
     const int c8 = (int)(i % C8);
     const int64_t r = i / C8;
     float v[8];
-    unpack_bf16x8(*reinterpret_cast<const uint4*>(z + r * ldz + c8 * 8), v);
+    bn_ld8<ZT>(z + r * ldz + c8 * 8, v);
     const float4 s0 = *reinterpret_cast<const float4*>(scale + c8 * 8), s1 = *reinterpret_cast<const float4*>(scale + c8 * 8 + 4);
     const float4 h0 = *reinterpret_cast<const float4*>(shift + c8 * 8), h1 = *reinterpret_cast<const float4*>(shift + c8 * 8 + 4);
     const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
@@ -431,15 +459,20 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const bf16_t* __restrict_
   }
 }
 
-extern "C" int fx_bn_apply_bf16(const void* z, int ldz, const float* scale, const float* shift, const void* residual, int ldr, int act, void* y,
+extern "C" int fx_bn_apply_bf16(const void* z, int ldz, int z_f32, const float* scale, const float* shift, const void* residual, int ldr, int act, void* y,
                                 int ldy, int64_t rows, int C, fx_stream_t stream_) {
   FX_CHECK_ARG(z && scale && shift && y && rows > 0 && C > 0 && C % 8 == 0 && ldz >= C && ldy >= C && ldz % 8 == 0 && ldy % 8 == 0);
   FX_CHECK_ARG(!residual || (ldr >= C && ldr % 8 == 0));
   int64_t total = rows * (C / 8);
   int64_t grid = (total + 255) / 256;
   if (grid > 256 * 32) grid = 256 * 32;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)z, ldz, scale, shift,
-                     (const bf16_t*)residual, ldr, act, (bf16_t*)y, ldy, rows, C / 8);
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (z_f32)
+    hipLaunchKernelGGL(bn_apply_kernel<float>, dim3((int)grid), dim3(256), 0, stream, (const float*)z, ldz, scale, shift, (const bf16_t*)residual, ldr, act,
+                       (bf16_t*)y, ldy, rows, C / 8);
+  else
+    hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3((int)grid), dim3(256), 0, stream, (const bf16_t*)z, ldz, scale, shift, (const bf16_t*)residual, ldr,
+                       act, (bf16_t*)y, ldy, rows, C / 8);
   return fx_launch_status();
 }
 
@@ -449,7 +482,8 @@ __device__ __forceinline__ void ld8(const float* __restrict__ p, float* f) {   /
   f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ z, int ldz,
+template <typename ZT>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restrict__ dy, int lddy, const ZT* __restrict__ z, int ldz,
                                                            const bf16_t* __restrict__ res, int ldr, const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd, int act,
                                                            const float* __restrict__ sums, float inv_n, bf16_t* __restrict__ da_out, int ldda,
@@ -460,7 +494,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
     const int c8 = (int)(i % C8);
     const int64_t r = i / C8;
     float v[8], g[8], o[8], d[8], rr[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unpack_bf16x8(*reinterpret_cast<const uint4*>(z + r * ldz + c8 * 8), v);
+    bn_ld8<ZT>(z + r * ldz + c8 * 8, v);
     unpack_bf16x8(*reinterpret_cast<const uint4*>(dy + r * lddy + c8 * 8), g);
     if (res) unpack_bf16x8(*reinterpret_cast<const uint4*>(res + r * ldr + c8 * 8), rr);
     float sc[8], sh[8], mu[8], rs[8], s0[8], s1[8];
@@ -478,7 +512,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
   }
 }
 
-extern "C" int fx_bn_bwd_apply_bf16(const void* dy, int lddy, const void* z, int ldz, const void* residual, int ldr, const float* scale,
+extern "C" int fx_bn_bwd_apply_bf16(const void* dy, int lddy, const void* z, int ldz, int z_f32, const void* residual, int ldr, const float* scale,
                                     const float* shift, const float* mean, const float* rstd, int act, const float* sums, float inv_n,
                                     void* da_out, int ldda, void* dz, int lddz, int64_t rows, int C, fx_stream_t stream_) {
   FX_CHECK_ARG(!residual || (ldr >= C && ldr % 8 == 0));
@@ -487,9 +521,13 @@ extern "C" int fx_bn_bwd_apply_bf16(const void* dy, int lddy, const void* z, int
   int64_t total = rows * (C / 8);
   int64_t grid = (total + 255) / 256;
   if (grid > 256 * 32) grid = 256 * 32;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)dy, lddy,
-                     (const bf16_t*)z, ldz, (const bf16_t*)residual, ldr, scale, shift, mean, rstd, act, sums, inv_n, (bf16_t*)da_out, ldda, (bf16_t*)dz, lddz,
-                     rows, C);
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (z_f32)
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((int)grid), dim3(256), 0, stream, (const bf16_t*)dy, lddy, (const float*)z, ldz,
+                       (const bf16_t*)residual, ldr, scale, shift, mean, rstd, act, sums, inv_n, (bf16_t*)da_out, ldda, (bf16_t*)dz, lddz, rows, C);
+  else
+    hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3((int)grid), dim3(256), 0, stream, (const bf16_t*)dy, lddy, (const bf16_t*)z, ldz,
+                       (const bf16_t*)residual, ldr, scale, shift, mean, rstd, act, sums, inv_n, (bf16_t*)da_out, ldda, (bf16_t*)dz, lddz, rows, C);
   return fx_launch_status();
 }
 

@@ -260,163 +260,7 @@ extern "C" int fx_cast_f32_bf16(const float* x, void* y, int64_t n, fx_stream_t 
   return fx_launch_status();
 }
 
-// ------------------------------------------------------------------------------------------------ attention backward
-// head_dim 32, Lk <= 512.  Pass 1 (one wave per query row): recompute p = softmax(q k^T / sqrt(32)) in fp32, D = dO . O,
-// dS = p * (dO V^T - D), dQ = dS K / sqrt(32); P and dS rows go to the workspace.  Pass 2 (one wave per key): dV = P^T dO,
-// dK = dS^T Q / sqrt(32).  O(L^2) workspace, no tiling: the sequences on this path are 300-400 tokens.
-#define MHA_MAXJ 8
-__global__ __launch_bounds__(256) void mha32_bwd_q_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ k, int ldk,
-                                                          const bf16_t* __restrict__ v, int ldv, const bf16_t* __restrict__ o, int ldo,
-                                                          const bf16_t* __restrict__ dout, int lddo, bf16_t* __restrict__ dq, int lddq,
-                                                          float* __restrict__ P, float* __restrict__ dS, int Lq, int Lk, int heads) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int bh = blockIdx.y, b = bh / heads, hd = bh % heads;
-  const int qi = blockIdx.x * 4 + wave;
-  if (qi >= Lq) return;
-  const float scale = 0.17677669529663687f;
-  float qr[32], dor[32], D = 0.0f;
-  {
-    const bf16_t* qp = q + ((int64_t)b * Lq + qi) * ldq + hd * 32;
-    const bf16_t* op = o + ((int64_t)b * Lq + qi) * ldo + hd * 32;
-    const bf16_t* dp = dout + ((int64_t)b * Lq + qi) * lddo + hd * 32;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float t[8], u[8], w[8];
-      unpack_bf16x8(*reinterpret_cast<const uint4*>(qp + c * 8), t);
-      unpack_bf16x8(*reinterpret_cast<const uint4*>(op + c * 8), u);
-      unpack_bf16x8(*reinterpret_cast<const uint4*>(dp + c * 8), w);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) qr[c * 8 + j] = t[j], dor[c * 8 + j] = w[j], D += w[j] * u[j];
-    }
-  }
-  float s[MHA_MAXJ], dpv[MHA_MAXJ];
-  float mx = -INFINITY;
-#pragma unroll
-  for (int t = 0; t < MHA_MAXJ; ++t) {
-    const int j = lane + 64 * t;
-    s[t] = -INFINITY;
-    dpv[t] = 0.0f;
-    if (j < Lk) {
-      const bf16_t* kp = k + ((int64_t)b * Lk + j) * ldk + hd * 32;
-      const bf16_t* vp = v + ((int64_t)b * Lk + j) * ldv + hd * 32;
-      float acc = 0.0f, accv = 0.0f;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float kk[8], vv[8];
-        unpack_bf16x8(*reinterpret_cast<const uint4*>(kp + c * 8), kk);
-        unpack_bf16x8(*reinterpret_cast<const uint4*>(vp + c * 8), vv);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc += qr[c * 8 + e] * kk[e], accv += dor[c * 8 + e] * vv[e];
-      }
-      s[t] = acc * scale;
-      dpv[t] = accv;
-      mx = fmaxf(mx, s[t]);
-    }
-  }
-  mx = wmax(mx);
-  float l = 0.0f;
-#pragma unroll
-  for (int t = 0; t < MHA_MAXJ; ++t) {
-    s[t] = (lane + 64 * t) < Lk ? __expf(s[t] - mx) : 0.0f;
-    l += s[t];
-  }
-  const float inv = 1.0f / wsum(l);
-  // D = sum_j p_j * dP_j from the fp32 probabilities recomputed here, not dO . O: the forward O is bf16-rounded, and
-  // with peaked softmaxes dP_j - D cancels to a few percent of its terms, which would amplify that rounding ~50x.
-  D = 0.0f;
-#pragma unroll
-  for (int t = 0; t < MHA_MAXJ; ++t) D += s[t] * inv * dpv[t];
-  D = wsum(D);
-  float dqa[32];
-#pragma unroll
-  for (int d = 0; d < 32; ++d) dqa[d] = 0.0f;
-  float* Prow = P + ((int64_t)bh * Lq + qi) * Lk;
-  float* Srow = dS + ((int64_t)bh * Lq + qi) * Lk;
-#pragma unroll
-  for (int t = 0; t < MHA_MAXJ; ++t) {
-    const int j = lane + 64 * t;
-    if (j < Lk) {
-      const float p = s[t] * inv;
-      const float ds = p * (dpv[t] - D);
-      Prow[j] = p;
-      Srow[j] = ds;
-      const bf16_t* kp = k + ((int64_t)b * Lk + j) * ldk + hd * 32;
-#pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        float kk[8];
-        unpack_bf16x8(*reinterpret_cast<const uint4*>(kp + c * 8), kk);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) dqa[c * 8 + e] += ds * kk[e];
-      }
-    }
-  }
-#pragma unroll
-  for (int d = 0; d < 32; ++d) dqa[d] = wsum(dqa[d]) * scale;
-  if (lane == 0) {
-    bf16_t* dp = dq + ((int64_t)b * Lq + qi) * lddq + hd * 32;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) *reinterpret_cast<uint4*>(dp + c * 8) = pack_bf16x8(dqa + c * 8);
-  }
-}
-
-__global__ __launch_bounds__(256) void mha32_bwd_kv_kernel(const bf16_t* __restrict__ q, int ldq, const bf16_t* __restrict__ dout, int lddo,
-                                                           const float* __restrict__ P, const float* __restrict__ dS, bf16_t* __restrict__ dk,
-                                                           int lddk, bf16_t* __restrict__ dv, int lddv, int Lq, int Lk, int heads) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int bh = blockIdx.y, b = bh / heads, hd = bh % heads;
-  const int j = blockIdx.x * 4 + wave;
-  if (j >= Lk) return;
-  const float scale = 0.17677669529663687f;
-  float dka[32], dva[32];
-#pragma unroll
-  for (int d = 0; d < 32; ++d) dka[d] = 0.0f, dva[d] = 0.0f;
-  for (int i = lane; i < Lq; i += 64) {
-    const float p = P[((int64_t)bh * Lq + i) * Lk + j], ds = dS[((int64_t)bh * Lq + i) * Lk + j];
-    const bf16_t* qp = q + ((int64_t)b * Lq + i) * ldq + hd * 32;
-    const bf16_t* dp = dout + ((int64_t)b * Lq + i) * lddo + hd * 32;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      float qq[8], dd[8];
-      unpack_bf16x8(*reinterpret_cast<const uint4*>(qp + c * 8), qq);
-      unpack_bf16x8(*reinterpret_cast<const uint4*>(dp + c * 8), dd);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) dka[c * 8 + e] += ds * qq[e], dva[c * 8 + e] += p * dd[e];
-    }
-  }
-#pragma unroll
-  for (int d = 0; d < 32; ++d) dka[d] = wsum(dka[d]) * scale, dva[d] = wsum(dva[d]);
-  if (lane == 0) {
-    bf16_t* kp = dk + ((int64_t)b * Lk + j) * lddk + hd * 32;
-    bf16_t* vp = dv + ((int64_t)b * Lk + j) * lddv + hd * 32;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      *reinterpret_cast<uint4*>(kp + c * 8) = pack_bf16x8(dka + c * 8);
-      *reinterpret_cast<uint4*>(vp + c * 8) = pack_bf16x8(dva + c * 8);
-    }
-  }
-}
-
-extern "C" size_t fx_mha_bwd_workspace_bytes(int B, int Lq, int Lk, int heads) {
-  if (B <= 0 || Lq <= 0 || Lk <= 0 || heads <= 0) return 0;
-  return (size_t)2 * B * heads * Lq * Lk * sizeof(float);
-}
-
-extern "C" int fx_mha_bwd_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o, int ldo, const void* dout,
-                               int lddo, void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int Lq, int Lk, int heads,
-                               void* workspace, size_t workspace_bytes, fx_stream_t stream_) {
-  FX_CHECK_ARG(q && k && v && o && dout && dq && dk && dv && workspace && B > 0 && Lq > 0 && Lk > 0 && heads > 0);
-  if (Lk > 64 * MHA_MAXJ) return FX_ERR_UNSUPPORTED;
-  FX_CHECK_ARG(workspace_bytes >= fx_mha_bwd_workspace_bytes(B, Lq, Lk, heads));
-  FX_CHECK_ARG(ldq % 8 == 0 && ldk % 8 == 0 && ldv % 8 == 0 && ldo % 8 == 0 && lddo % 8 == 0 && lddq % 8 == 0 && lddk % 8 == 0 && lddv % 8 == 0);
-  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  float* P = reinterpret_cast<float*>(workspace);
-  float* dS = P + (size_t)B * heads * Lq * Lk;
-  hipLaunchKernelGGL(mha32_bwd_q_kernel, dim3((Lq + 3) / 4, B * heads), dim3(256), 0, stream, (const bf16_t*)q, ldq, (const bf16_t*)k, ldk,
-                     (const bf16_t*)v, ldv, (const bf16_t*)o, ldo, (const bf16_t*)dout, lddo, (bf16_t*)dq, lddq, P, dS, Lq, Lk, heads);
-  hipLaunchKernelGGL(mha32_bwd_kv_kernel, dim3((Lk + 3) / 4, B * heads), dim3(256), 0, stream, (const bf16_t*)q, ldq, (const bf16_t*)dout, lddo, P,
-                     dS, (bf16_t*)dk, lddk, (bf16_t*)dv, lddv, Lq, Lk, heads);
-  return fx_launch_status();
-}
+// (attention backward: attn_bwd.hip)
 
 // ------------------------------------------------------------------------------------------------ gather backward
 // dsrc[b, idx[b,j], :] = dout[b, j, :]  (indices are a top-k result: unique per image; dsrc zeroed by the caller)

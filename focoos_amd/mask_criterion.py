@@ -1,5 +1,5 @@
 """Host mirrors of the mask-classification training criterion (MaskFormer and BiSeNetFormer share it) for the gfx950 kernels
-(forward values; no autograd this round):
+(values and gradients: the losses are torch.autograd nodes whose backward is fx_mask_set_loss_bwd_f32):
 
   MaskHungarianMatcher.forward   focoos/models/fai_mf/loss.py:661-742 (== bisenetformer/loss.py)  -> fx_point_sample_f32 +
                                                                                                    fx_mask_match_cost_f32 + fx_lsa_f32
@@ -102,6 +102,46 @@ class MaskHungarianMatcher:
     __call__ = forward
 
 
+class _MaskSetLossFn(torch.autograd.Function):
+    """(loss_ce, loss_mask, loss_dice) of one prediction set, weighted: fx_mask_set_loss_f32; backward fx_mask_set_loss_bwd_f32 with the
+    forward's random draws, matches and workspace (pair sums).  The Hungarian matches and the sample points carry no gradient, as in
+    the reference (matcher under no_grad loss.py:661; point selection under no_grad :487-497)."""
+
+    @staticmethod
+    def forward(ctx, logits, pm, crit, tg, pi, ti, num_masks):
+        lib = _lib.load()
+        B, Q, K1 = logits.shape
+        dev, P = logits.device, crit.num_points
+        h, w = pm.shape[-2:]
+        n_over = int(P * crit.oversample_ratio)
+        n_extra = P - int(crit.importance_sample_ratio * P)
+        r_over = crit.rand(max(tg.n, 1), n_over, 2, device=dev).float().contiguous() if tg.n else torch.zeros(1, n_over, 2, device=dev)
+        r_extra = (crit.rand(max(tg.n, 1), n_extra, 2, device=dev).float().contiguous() if (tg.n and n_extra > 0)
+                   else torch.zeros(1, max(n_extra, 1), 2, device=dev))
+        ws = torch.empty(lib.fx_mask_set_loss_workspace_bytes(B, Q, tg.n) // 8 + 1, dtype=torch.float64, device=dev)
+        out3 = torch.empty(3, dtype=torch.float32, device=dev)
+        wd = crit.weight_dict
+        args = (logits.data_ptr(), K1, pm.data_ptr(), h, w, tg.masks.data_ptr(), tg.is_u8, tg.H, tg.W, tg.labels.data_ptr(), tg.offsets.data_ptr(), tg.n,
+                pi.data_ptr(), ti.data_ptr(), r_over.data_ptr(), n_over, r_extra.data_ptr(), n_extra, P, B, Q, K1 - 1, float(crit.eos_coef),
+                float(num_masks), float(wd.get("loss_ce", 1.0)), float(wd.get("loss_mask", 1.0)), float(wd.get("loss_dice", 1.0)), ws.data_ptr(),
+                ws.numel() * 8)
+        check(lib.fx_mask_set_loss_f32(*args, out3.data_ptr(), _stream(dev)), "fx_mask_set_loss_f32")
+        ctx.args, ctx.keep = args, (tg, pi, ti, r_over, r_extra, ws)
+        ctx.save_for_backward(logits, pm)
+        return out3
+
+    @staticmethod
+    def backward(ctx, g3):
+        lib = _lib.load()
+        logits, pm = ctx.saved_tensors
+        g3 = g3.float().contiguous()
+        dlogits = torch.empty_like(logits)
+        dmasks = torch.zeros_like(pm)
+        check(lib.fx_mask_set_loss_bwd_f32(*ctx.args, g3.data_ptr(), dlogits.data_ptr(), logits.shape[-1], dmasks.data_ptr(), _stream(logits.device)),
+              "fx_mask_set_loss_bwd_f32")
+        return dlogits, dmasks, None, None, None, None, None
+
+
 class SetCriterion:
     def __init__(self, num_classes: int, matcher: MaskHungarianMatcher, weight_dict: Dict[str, float], losses=("labels", "masks"), eos_coef: float = 0.1,
                  num_points: int = 0, oversample_ratio: float = 3.0, importance_sample_ratio: float = 0.0, deep_supervision: bool = True,
@@ -113,43 +153,38 @@ class SetCriterion:
         self.deep_supervision = deep_supervision
         self.rand = rand or matcher.rand
 
-    def _one_set(self, out, tg: _MaskTargets, num_masks: float) -> torch.Tensor:
-        lib = _lib.load()
+    def _one_set(self, out, tg: _MaskTargets, num_masks: float, fixed=None) -> torch.Tensor:
         logits, pm = out["pred_logits"].float().contiguous(), out["pred_masks"].float().contiguous()
-        B, Q, K1 = logits.shape
-        dev, P = logits.device, self.num_points
-        h, w = pm.shape[-2:]
-        pi, ti = self.matcher.match_packed(logits, pm, tg)
-        n_over = int(P * self.oversample_ratio)
-        n_extra = P - int(self.importance_sample_ratio * P)
-        r_over = self.rand(max(tg.n, 1), n_over, 2, device=dev).float().contiguous() if tg.n else torch.zeros(1, n_over, 2, device=dev)
-        r_extra = (self.rand(max(tg.n, 1), n_extra, 2, device=dev).float().contiguous() if (tg.n and n_extra > 0)
-                   else torch.zeros(1, max(n_extra, 1), 2, device=dev))
-        ws = torch.empty(lib.fx_mask_set_loss_workspace_bytes(B, Q, tg.n) // 8 + 1, dtype=torch.float64, device=dev)
-        out3 = torch.empty(3, dtype=torch.float32, device=dev)
-        check(lib.fx_mask_set_loss_f32(logits.data_ptr(), K1, pm.data_ptr(), h, w, tg.masks.data_ptr(), tg.is_u8, tg.H, tg.W, tg.labels.data_ptr(),
-                                       tg.offsets.data_ptr(), tg.n, pi.data_ptr(), ti.data_ptr(), r_over.data_ptr(), n_over, r_extra.data_ptr(), n_extra, P,
-                                       B, Q, K1 - 1, float(self.eos_coef), float(num_masks), float(self.weight_dict.get("loss_ce", 1.0)),
-                                       float(self.weight_dict.get("loss_mask", 1.0)), float(self.weight_dict.get("loss_dice", 1.0)), ws.data_ptr(),
-                                       ws.numel() * 8, out3.data_ptr(), _stream(dev)), "fx_mask_set_loss_f32")
+        if fixed is None:
+            with torch.no_grad():
+                pi, ti = self.matcher.match_packed(logits.detach(), pm.detach(), tg)
+        else:
+            pi, ti = fixed
+            for _ in range(logits.shape[0]):   # keep the stream of random draws aligned with the reference's order (the matcher's points)
+                self.matcher.rand(1, self.matcher.num_points, 2, device=logits.device)
+        out3 = _MaskSetLossFn.apply(logits, pm, self, tg, pi, ti, float(num_masks))
         self.last_matches = (pi, ti)
         return out3
 
-    @torch.no_grad()
-    def forward(self, outputs: Dict, targets: Sequence) -> Dict[str, torch.Tensor]:
+    def forward(self, outputs: Dict, targets: Sequence, fixed_matches=None) -> Dict[str, torch.Tensor]:
+        """SetCriterion.forward (loss.py:545-592).  ``fixed_matches``: optional per-set (pred_idx, tgt_idx) int32 device tensors in the
+        packed target order (tests teacher-force the Hungarian matches with them)."""
         dev = outputs["pred_logits"].device
         tg = _MaskTargets(targets, dev)
-        num = torch.tensor([float(tg.n)], device=dev)
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            num = torch.tensor([float(tg.n)], device=dev)
             torch.distributed.all_reduce(num)  # loss.py:559-561
-            num = num / torch.distributed.get_world_size()
-        num_masks = max(float(num.item()), 1.0)
+            num_masks = max(float(num.item()) / torch.distributed.get_world_size(), 1.0)
+        else:
+            num_masks = max(float(tg.n), 1.0)   # single process: a host integer, the launch queue keeps running ahead
         losses = {}
         sets = [("", {k: v for k, v in outputs.items() if k != "aux_outputs"})]
         if self.deep_supervision:
             sets += [(f"_{i}", a) for i, a in enumerate(outputs.get("aux_outputs", []))]
-        for suffix, o in sets:
-            l3 = self._one_set(o, tg, num_masks)
+        self.all_matches = []
+        for j, (suffix, o) in enumerate(sets):
+            l3 = self._one_set(o, tg, num_masks, None if fixed_matches is None else fixed_matches[j])
+            self.all_matches.append(self.last_matches)
             losses[f"loss_ce{suffix}"], losses[f"loss_mask{suffix}"], losses[f"loss_dice{suffix}"] = l3[0], l3[1], l3[2]
         return losses
 

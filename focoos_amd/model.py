@@ -130,7 +130,8 @@ class FAIDetr(_EngineModel):
     def forward(self, images: torch.Tensor, targets: list = [], forced_topk: Optional[torch.Tensor] = None,
                 use_graph: bool = True) -> DETRModelOutput:
         if self.training or (targets is not None and len(targets) > 0):
-            raise NotImplementedError("training forward (loss) is not part of this round")
+            raise NotImplementedError("the engine-backed module is the inference graph; the training forward (losses) runs in "
+                                      "train_detr.FAIDetrTrainable, reached through FocoosModel.train / trainer.run_train")
         pl = self.engine.forward(self._to_nhwc(images), forced_topk=forced_topk, use_graph=use_graph)
         self.last_plan = pl
         return DETRModelOutput(logits=pl.probs.clone(), boxes=pl.boxes.clone(), loss=None)
@@ -157,7 +158,8 @@ class FAIMaskFormer(_EngineModel):
 
     def forward(self, images: torch.Tensor, targets: list = [], forced_attn=None, use_graph: bool = True) -> MaskFormerModelOutput:
         if self.training or (targets is not None and len(targets) > 0):
-            raise NotImplementedError("training forward (loss) is not part of this round")
+            raise NotImplementedError("the engine-backed module is the inference graph; the training forward (losses) runs in "
+                                      "train_detr.FAIDetrTrainable, reached through FocoosModel.train / trainer.run_train")
         pl = self.engine.forward(self._to_nhwc(images), forced_attn=forced_attn, use_graph=use_graph, full_masks=True)
         self.last_plan = pl
         return MaskFormerModelOutput(masks=pl.masks.clone(), logits=pl.probs.clone(), loss=None)

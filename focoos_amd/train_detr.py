@@ -331,7 +331,7 @@ class TrainStep:
         from .state_spec import state_spec
         from .train_data import optimizer_hyperparams
 
-        kinds = state_spec(model.config, "fai_detr")
+        kinds = state_spec(model.config, getattr(model, "family", "fai_detr"))   # FAIDetrTrainable / train_bf.BisenetFormerTrainable
         spec = []
         for n, p in named:   # per-parameter lr / weight decay exactly as get_optimizer_params (solver/build.py:39-101; pinned in tests/test_train_data_cpu.py)
             plr, pwd = optimizer_hyperparams(n, kinds[n][1], lr, weight_decay, weight_decay_norm, weight_decay_embed, backbone_multiplier)

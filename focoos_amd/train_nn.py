@@ -93,11 +93,11 @@ _DESC_CACHE: Dict[tuple, tuple] = {}
 
 
 def _conv_call(lib, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], N: int, KH: int, KW: int, stride: int, pad: int,
-               act: Optional[str], residual: Optional[torch.Tensor], res_mode: int = 0) -> torch.Tensor:
+               act: Optional[str], residual: Optional[torch.Tensor], res_mode: int = 0, out_f32: bool = False) -> torch.Tensor:
     """fx_conv2d_nhwc_bf16 on NHWC bf16 tensors; ``w`` is a packed [Npad][KH][KW][C] bf16 image.  ``res_mode``: 0 = add ``residual``
     before the activation, 2 = multiply by (residual > 0) - the ReLU backward of the layer that produced ``residual``."""
     B, H, W_, Cc = x.shape
-    key = (w.data_ptr(), bias.data_ptr() if bias is not None else 0, B, H, W_, Cc, N, KH, KW, stride, pad, act, residual is not None, res_mode)
+    key = (w.data_ptr(), bias.data_ptr() if bias is not None else 0, B, H, W_, Cc, N, KH, KW, stride, pad, act, residual is not None, res_mode, out_f32)
     ent = _DESC_CACHE.get(key)
     if ent is None:
         Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W_ + 2 * pad - KW) // stride + 1
@@ -107,13 +107,13 @@ def _conv_call(lib, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tenso
         d.B, d.H, d.W, d.C, d.ldx = B, H, W_, Cc, Cc
         d.Ho, d.Wo, d.N, d.ldy, d.ldr = Ho, Wo, N, N, N if residual is not None else 0
         d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad
-        d.pool2, d.act, d.out_f32, d.residual_after_act, d.y_batch_stride = 0, FX_ACT[act], 0, res_mode, 0
+        d.pool2, d.act, d.out_f32, d.residual_after_act, d.y_batch_stride = 0, FX_ACT[act], int(out_f32), res_mode, 0
         ent = (d, C.byref(d), (B, Ho, Wo, N))
         if len(_DESC_CACHE) > 4096:
             _DESC_CACHE.clear()
         _DESC_CACHE[key] = ent
     d, ref, oshape = ent
-    y = torch.empty(oshape, dtype=torch.bfloat16, device=x.device)
+    y = torch.empty(oshape, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
     d.x, d.y = x.data_ptr(), y.data_ptr()
     d.residual = residual.data_ptr() if residual is not None else None
     check(lib.fx_conv2d_nhwc_bf16(ref, _stream(x.device)), "fx_conv2d_nhwc_bf16")
@@ -177,7 +177,8 @@ def _bn_forward(layer, z: torch.Tensor, residual: Optional[torch.Tensor]):
     rows = z.numel() // N
     st = _stream(dev)
     sums = ARENA.zeros((2, N), dev)
-    check(lib.fx_bn_stats_bf16(z.data_ptr(), N, sums.data_ptr(), rows, N, st), "fx_bn_stats_bf16")
+    zf = int(z.dtype == torch.float32)   # fp32 pre-normalisation tensor (conv epilogue out_f32): y depends on z - mean
+    check(lib.fx_bn_stats_bf16(z.data_ptr(), N, zf, sums.data_ptr(), rows, N, st), "fx_bn_stats_bf16")
     world = _bn_sync_group(layer)
     if world > 1:
         import torch.distributed as dist
@@ -189,8 +190,8 @@ def _bn_forward(layer, z: torch.Tensor, residual: Optional[torch.Tensor]):
                                  norm.running_mean.data_ptr(), norm.running_var.data_ptr(), norm.num_batches_tracked.data_ptr(),
                                  stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), N, st), "fx_bn_finalize_f32")
     layer._stats_epoch = getattr(layer, "_stats_epoch", 0) + 1   # the kernel moved the running statistics behind autograd's back
-    y = torch.empty_like(z)
-    check(lib.fx_bn_apply_bf16(z.data_ptr(), N, stats[2].data_ptr(), stats[3].data_ptr(), residual.data_ptr() if residual is not None else None, N,
+    y = torch.empty(z.shape, dtype=torch.bfloat16, device=dev)
+    check(lib.fx_bn_apply_bf16(z.data_ptr(), N, zf, stats[2].data_ptr(), stats[3].data_ptr(), residual.data_ptr() if residual is not None else None, N,
                                FX_ACT[layer.act], y.data_ptr(), N, rows, N, st), "fx_bn_apply_bf16")
     return y, stats, n
 
@@ -205,16 +206,17 @@ def _bn_backward(layer, dy: torch.Tensor, z: torch.Tensor, residual: Optional[to
     st = _stream(dev)
     rp = residual.data_ptr() if residual is not None else None
     sums = ARENA.zeros((2, N), dev)
-    check(lib.fx_bn_bwd_stats_bf16(dy.data_ptr(), N, z.data_ptr(), N, rp, N, stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(),
+    zf = int(z.dtype == torch.float32)
+    check(lib.fx_bn_bwd_stats_bf16(dy.data_ptr(), N, z.data_ptr(), N, zf, rp, N, stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(),
                                    stats[1].data_ptr(), FX_ACT[layer.act], sums.data_ptr(), rows, N, st), "fx_bn_bwd_stats_bf16")
     local = sums
     if _bn_sync_group(layer) > 1:
         import torch.distributed as dist
         local = sums.clone()
         dist.all_reduce(sums)
-    dz = torch.empty_like(z)
-    da = torch.empty_like(z) if residual is not None else None
-    check(lib.fx_bn_bwd_apply_bf16(dy.data_ptr(), N, z.data_ptr(), N, rp, N, stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(),
+    dz = torch.empty(z.shape, dtype=torch.bfloat16, device=dev)
+    da = torch.empty(z.shape, dtype=torch.bfloat16, device=dev) if residual is not None else None
+    check(lib.fx_bn_bwd_apply_bf16(dy.data_ptr(), N, z.data_ptr(), N, zf, rp, N, stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(),
                                    stats[1].data_ptr(), FX_ACT[layer.act], sums.data_ptr(), 1.0 / n, da.data_ptr() if da is not None else None, N,
                                    dz.data_ptr(), N, rows, N, st), "fx_bn_bwd_apply_bf16")
     dgamma = dbeta = None
@@ -289,7 +291,7 @@ class _ConvBnTrainFn(torch.autograd.Function):
     def forward(ctx, x, weight, gamma, beta, residual, layer: "ConvNormLayer"):
         layer.sync_packed()
         N, Cc, KH, KW = weight.shape
-        z = _conv_call(layer.lib, x, layer.w_fwd, None, N, KH, KW, layer.stride, layer.pad, None, None)
+        z = _conv_call(layer.lib, x, layer.w_fwd, None, N, KH, KW, layer.stride, layer.pad, None, None, out_f32=True)
         y, stats, n = _bn_forward(layer, z, residual)
         ctx.layer, ctx.n = layer, n
         ctx.save_for_backward(x, z, residual, stats)
@@ -389,7 +391,7 @@ def set_norm_mode(module: nn.Module, mode: str) -> nn.Module:
     if mode not in ("FrozenBN", "BN", "SyncBN"):
         raise ValueError(f"unknown norm mode {mode!r}")
     for m in module.modules():
-        if isinstance(m, ConvNormLayer):
+        if isinstance(m, ConvNormLayer) or getattr(m, "has_batchnorm", False):   # train_bf.DwConvBn / VecBN carry the same attributes
             m.norm_mode = mode
             m._norm_h.weight.requires_grad_(mode != "FrozenBN")
             m._norm_h.bias.requires_grad_(mode != "FrozenBN")
@@ -471,8 +473,8 @@ def _stem_wgrad(layer, images, dz, scale):
 
 
 class StemConv(ConvNormLayer):
-    def __init__(self, lib, pixel_mean, pixel_std):
-        super().__init__(lib, 3, 32, 3, 2, "relu")
+    def __init__(self, lib, pixel_mean, pixel_std, names=("conv", "norm")):
+        super().__init__(lib, 3, 32, 3, 2, "relu", names=names)
         self.register_buffer("px_mean", torch.tensor(pixel_mean, dtype=torch.float32), persistent=False)
         self.register_buffer("px_inv_std", 1.0 / torch.tensor(pixel_std, dtype=torch.float32), persistent=False)
         self.stem_w = self.stem_b = None
@@ -732,7 +734,7 @@ class _PackedLinear:
         Np, Kp = _rup(N, 32), _rup(K, 32)  # both serve as the reduction dim of one of the two GEMMs (C % 32 == 0)
         self.Np, self.Kp = Np, Kp
         with torch.no_grad():
-            w = weight[r0:r1]
+            w = weight[r0:r1].flatten(1)   # [N, K, 1, 1] conv weights (train_bf.Conv1x1) are GEMM weights too
             if Np != N or Kp != K:
                 wp = torch.zeros(Np, Kp, dtype=torch.float32, device=dev)
                 wp[:N, :K] = w
@@ -808,6 +810,7 @@ class _LinearFn(torch.autograd.Function):
             else:
                 dw = None if direct else ARENA.zeros(ctx.wshape, dev)
                 wt = dw[r0:r1] if (same and not direct) else ARENA.zeros((Np, Kp), dev)
+            wshape_rows = (r1 - r0,) + tuple(ctx.wshape[1:])   # [N, K] or [N, K, 1, 1]
             bt = None
             if want_b:
                 bdirect = DIRECT_GRAD[0] and ctx.bparam.grad is not None
@@ -821,9 +824,9 @@ class _LinearFn(torch.autograd.Function):
                                                      1, 1, R, Kp, 1, R, Np, 1, 1, 1, 0, st), "fx_conv2d_wgrad_bias_nhwc_bf16")
             if not same:
                 if direct:
-                    ctx.wparam.grad[r0:r1] += wt[:N, :K]
+                    ctx.wparam.grad[r0:r1] += wt[:N, :K].reshape(wshape_rows)
                 else:
-                    dw[r0:r1] = wt[:N, :K]
+                    dw[r0:r1] = wt[:N, :K].reshape(wshape_rows)
             if want_b and Np != N:
                 if DIRECT_GRAD[0] and ctx.bparam.grad is not None:
                     ctx.bparam.grad[r0:r1] += bt[:N]
@@ -891,32 +894,42 @@ class LayerNorm(nn.Module):
 
 
 class _MHACoreFn(torch.autograd.Function):
-    """softmax(q k^T / sqrt(32)) v per head on projected [B, L, 256] bf16 tensors (fx_mha_bf16 / fx_mha_bwd_bf16)."""
+    """softmax(q k^T / sqrt(32) [masked]) v per head on projected [B, L, 256] bf16 tensors: fx_mha_masked_bf16 forward, the MFMA
+    backward fx_mha_masked_bwd_bf16 (attn_bwd.hip).  ``mask_bits``: int32 [B*Lq, ceil(Lk/32)] bitmap (bit set = key not allowed; rows
+    that forbid every key attend everywhere), or None."""
 
     @staticmethod
-    def forward(ctx, q, k, v, lib):
+    def forward(ctx, q, k, v, lib, mask_bits=None):
         B, Lq, Cc = q.shape
         Lk = k.shape[1]
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
         o = torch.empty_like(q)
-        check(lib.fx_mha_bf16(q.data_ptr(), Cc, k.data_ptr(), Cc, v.data_ptr(), Cc, o.data_ptr(), Cc, B, Lq, Lk, Cc // 32, _stream(q.device)), "fx_mha_bf16")
-        ctx.lib = lib
-        ctx.save_for_backward(q, k, v, o)
+        words = mask_bits.shape[1] if mask_bits is not None else 0
+        ws = None
+        nws = lib.fx_mha_workspace_bytes(B, Lq, Lk, Cc // 32, int(mask_bits is not None))
+        if nws > 0:   # few queries x many keys: key-sliced forward (flash-decoding) needs a scratch buffer
+            ws = torch.empty(nws, dtype=torch.uint8, device=q.device)
+        check(lib.fx_mha_masked_bf16(q.data_ptr(), Cc, k.data_ptr(), Cc, v.data_ptr(), Cc, o.data_ptr(), Cc, B, Lq, Lk, Cc // 32,
+                                     mask_bits.data_ptr() if mask_bits is not None else None, words, ws.data_ptr() if ws is not None else None, nws,
+                                     _stream(q.device)), "fx_mha_masked_bf16")
+        ctx.lib, ctx.mask_bits = lib, mask_bits
+        ctx.save_for_backward(q, k, v)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        q, k, v, o = ctx.saved_tensors
-        lib = ctx.lib
+        q, k, v = ctx.saved_tensors
+        lib, bits = ctx.lib, ctx.mask_bits
         B, Lq, Cc = q.shape
         Lk, H = k.shape[1], Cc // 32
         do = do.contiguous()
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         nb = lib.fx_mha_bwd_workspace_bytes(B, Lq, Lk, H)
         ws = torch.empty(nb, dtype=torch.uint8, device=q.device)
-        check(lib.fx_mha_bwd_bf16(q.data_ptr(), Cc, k.data_ptr(), Cc, v.data_ptr(), Cc, o.data_ptr(), Cc, do.data_ptr(), Cc, dq.data_ptr(), Cc,
-                                  dk.data_ptr(), Cc, dv.data_ptr(), Cc, B, Lq, Lk, H, ws.data_ptr(), nb, _stream(q.device)), "fx_mha_bwd_bf16")
-        return dq, dk, dv, None
+        check(lib.fx_mha_masked_bwd_bf16(q.data_ptr(), Cc, k.data_ptr(), Cc, v.data_ptr(), Cc, do.data_ptr(), Cc, dq.data_ptr(), Cc, dk.data_ptr(), Cc,
+                                         dv.data_ptr(), Cc, B, Lq, Lk, H, bits.data_ptr() if bits is not None else None,
+                                         bits.shape[1] if bits is not None else 0, ws.data_ptr(), nb, _stream(q.device)), "fx_mha_masked_bwd_bf16")
+        return dq, dk, dv, None, None
 
 
 class MultiheadAttention(nn.Module):
@@ -931,7 +944,7 @@ class MultiheadAttention(nn.Module):
         self.out_proj = Linear(lib, c, c)
         self._pq, self._pk, self._pv, self._pqk = _PackedLinear(), _PackedLinear(), _PackedLinear(), _PackedLinear()
 
-    def forward(self, q_in, k_in, v_in, residual=None):
+    def forward(self, q_in, k_in, v_in, residual=None, mask_bits=None):
         c, lib, W, b = self.c, self.lib, self.in_proj_weight, self.in_proj_bias
         if q_in is k_in:
             qk = _LinearFn.apply(q_in, W, b, None, self._pqk, lib, 0, 2 * c, None)
@@ -940,7 +953,7 @@ class MultiheadAttention(nn.Module):
             q = _LinearFn.apply(q_in, W, b, None, self._pq, lib, 0, c, None)
             k = _LinearFn.apply(k_in, W, b, None, self._pk, lib, c, 2 * c, None)
         v = _LinearFn.apply(v_in, W, b, None, self._pv, lib, 2 * c, 3 * c, None)
-        o = _MHACoreFn.apply(q, k, v, lib)
+        o = _MHACoreFn.apply(q, k, v, lib, mask_bits)
         return self.out_proj(o, residual=residual)
 
 
@@ -975,11 +988,17 @@ class _AddFn(torch.autograd.Function):
         out = torch.empty_like(x)
         check(lib.fx_add_rows_bf16(x.data_ptr(), Cc, y.data_ptr(), Cc, _rows(y), out.data_ptr(), Cc, _rows(x), Cc, _stream(x.device)), "fx_add_rows_bf16")
         ctx.same = y.shape == x.shape
+        ctx.yshape = tuple(y.shape)
         return out
 
     @staticmethod
     def backward(ctx, d):
-        return d, (d if ctx.same else None), None
+        if ctx.same:
+            return d, d, None
+        dy = None
+        if ctx.needs_input_grad[1]:   # a learned embedding broadcast over the batch (query_embed): sum over the repeats ([B, Q, 256]: glue)
+            dy = d.reshape(-1, *ctx.yshape).float().sum(0).to(d.dtype)
+        return d, dy, None
 
 
 # ================================================================================================ hybrid encoder (RT-DETR)

@@ -318,6 +318,9 @@ int fx_mask_set_loss_f32(const float* logits, int ldl, const float* pred_masks, 
  * w = 1/9 and no bias it is the block's AvgPool2d(3, 2, 1) skip (:128, count_include_pad=True).  C % 8 == 0. */
 int fx_dwconv3x3s2_nhwc_bf16(const void* x, int ldx, const float* w, const float* bias, void* y, int ldy, int B, int H, int W, int C,
                              fx_stream_t stream);
+/* Same with an fp32 output y f32 [B,Ho,Wo,ldy] (the pre-BatchNorm tensor of the batch-statistics training path, see fx_bn_stats_bf16). */
+int fx_dwconv3x3s2_nhwc_f32out(const void* x, int ldx, const float* w, const float* bias, float* y, int ldy, int B, int H, int W, int C,
+                               fx_stream_t stream);
 
 /* mean over the P pixels of each image: out f32 [B][ldo] (feat.mean(dim=(2,3)), modelling.py:161,187; adaptive_avg_pool2d :230). */
 int fx_global_mean_nhwc_bf16(const void* x, int ldx, float* out, int ldo, int B, int P, int C, fx_stream_t stream);
@@ -450,17 +453,19 @@ int fx_stem_conv3x3s2_linear(const void* x, int in_f32, const float* w, const fl
  *   backward: da = dy * act'(z * scale + shift [+ residual]);  fx_bn_bwd_stats_bf16 ACCUMULATES sums[c] += sum da (= dbeta),
  *             sums[C + c] += sum da * xhat (= dgamma), xhat = (z - mean) * rstd; (all-reduce for SyncBN);
  *             fx_bn_bwd_apply_bf16: dz = scale * (da - sums[c] * inv_n - xhat * sums[C + c] * inv_n); da_out (optional) = da,
- *             the gradient of the residual branch. */
-int fx_bn_stats_bf16(const void* z, int ldz, float* sums, int64_t rows, int C, fx_stream_t stream);
+ *             the gradient of the residual branch.
+ * z_f32 != 0: z is fp32 [rows][ldz] (the conv kernel's out_f32 epilogue) instead of bf16 - y depends on z - mean, and a bf16 z keeps
+ * 8 bits of z, not of z - mean; the trainable graphs keep the pre-normalisation tensor in fp32. */
+int fx_bn_stats_bf16(const void* z, int ldz, int z_f32, float* sums, int64_t rows, int C, fx_stream_t stream);
 int fx_bn_finalize_f32(const float* sums, float n, const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                        float* running_var, int64_t* num_batches_tracked, float* mean, float* rstd, float* scale, float* shift, int C,
                        fx_stream_t stream);
-int fx_bn_apply_bf16(const void* z, int ldz, const float* scale, const float* shift, const void* residual, int ldr, int act, void* y, int ldy,
+int fx_bn_apply_bf16(const void* z, int ldz, int z_f32, const float* scale, const float* shift, const void* residual, int ldr, int act, void* y, int ldy,
                      int64_t rows, int C, fx_stream_t stream);
-int fx_bn_bwd_stats_bf16(const void* dy, int lddy, const void* z, int ldz, const void* residual, int ldr, const float* scale,
+int fx_bn_bwd_stats_bf16(const void* dy, int lddy, const void* z, int ldz, int z_f32, const void* residual, int ldr, const float* scale,
                          const float* shift, const float* mean, const float* rstd, int act, float* sums, int64_t rows, int C,
                          fx_stream_t stream);
-int fx_bn_bwd_apply_bf16(const void* dy, int lddy, const void* z, int ldz, const void* residual, int ldr, const float* scale,
+int fx_bn_bwd_apply_bf16(const void* dy, int lddy, const void* z, int ldz, int z_f32, const void* residual, int ldr, const float* scale,
                          const float* shift, const float* mean, const float* rstd, int act, const float* sums, float inv_n, void* da_out,
                          int ldda, void* dz, int lddz, int64_t rows, int C, fx_stream_t stream);
 
@@ -481,12 +486,19 @@ int fx_layernorm_bwd_bf16(const void* dy, int lddy, const void* x, int ldx, cons
 int fx_resize_bilinear_bwd_nhwc_bf16(const void* dy, int lddy, void* dx, int lddx, int B, int H, int W, int C, int Ho, int Wo, fx_stream_t stream);
 int fx_cast_f32_bf16(const float* x, void* y, int64_t n, fx_stream_t stream);
 
-/* Backward of fx_mha_bf16 (head_dim 32, Lk <= 512): dq, dk, dv from q, k, v, the forward output o and dout.
- * workspace: fx_mha_bwd_workspace_bytes() (P and dS, fp32 [B*heads, Lq, Lk] each). */
+/* Backward of fx_mha_bf16 / fx_mha_masked_bf16 on the matrix cores (head_dim 32, any Lq / Lk): dq, dk, dv from the projected q, k, v
+ * and dout; `mask_bits` as in fx_mha_masked_bf16 (bit set = key not allowed; a query whose bits forbid every key attends
+ * everywhere - the reference clears such mask rows, bisenetformer/modelling.py:423-426).  Replaces what autograd derives for
+ * nn.MultiheadAttention's softmax(q k^T / sqrt(d)) v (focoos/nn/layers/transformer.py:83-106, 206-238, 583-601).
+ * workspace: fx_mha_bwd_workspace_bytes() = 3 floats per (image, head, query): log-sum-exp, D = sum_j P_ij dP_ij, mask-in-effect.
+ * `o` of the unmasked entry point is not read (kept for ABI stability). */
 size_t fx_mha_bwd_workspace_bytes(int B, int Lq, int Lk, int heads);
 int fx_mha_bwd_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* o, int ldo, const void* dout, int lddo,
                     void* dq, int lddq, void* dk, int lddk, void* dv, int lddv, int B, int Lq, int Lk, int heads, void* workspace,
                     size_t workspace_bytes, fx_stream_t stream);
+int fx_mha_masked_bwd_bf16(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const void* dout, int lddo, void* dq, int lddq,
+                           void* dk, int lddk, void* dv, int lddv, int B, int Lq, int Lk, int heads, const uint32_t* mask_bits, int ld_mask_words,
+                           void* workspace, size_t workspace_bytes, fx_stream_t stream);
 
 /* Backward of fx_gather_rows_bf16 for unique indices (top-k): dsrc[b, idx[b,j], :] = dout[b,j,:]; dsrc zeroed by the caller. */
 int fx_scatter_rows_bf16(const void* dout, int ldo, const int32_t* idx, int k, void* dsrc, int lds, int rows_per_batch, int B, int cols,
@@ -513,6 +525,37 @@ int fx_graph_destroy(void* graph_exec);
 /* Timing helper for bench.py: average duration in ms of `iters` graph replays measured with HIP events
  * recorded on `stream` itself. */
 int fx_graph_time(void* graph_exec, fx_stream_t stream, int iters, float* ms_avg);
+
+/* ---- training direction of the mask families (BASELINE config 5) ------------------------------------
+ * Gradients of fx_mask_set_loss_f32 (SetCriterion.loss_labels / loss_masks under autograd, focoos/models/fai_mf/loss.py:411-431,
+ * 463-523 == bisenetformer/loss.py): same arguments plus the forward's workspace (pair sums and CE weight sum are read from it),
+ * grad3 f32 [3] ON THE DEVICE = upstream gradients of (loss_ce, loss_mask, loss_dice); writes dlogits f32 [B,Q,lddl] (all K+1
+ * columns of every row) and ACCUMULATES into dmasks f32 [B,Q,h,w] (zero-initialised by the caller; only the planes of matched
+ * queries are touched).  The point selection is recomputed (deterministic); sample coordinates carry no gradient. */
+int fx_mask_set_loss_bwd_f32(const float* logits, int ldl, const float* pred_masks, int h, int w, const void* tgt_masks, int tgt_is_u8, int H, int W,
+                             const int32_t* tgt_labels, const int32_t* tgt_offsets, int sum_T, const int32_t* pred_idx, const int32_t* tgt_idx,
+                             const float* rand_over, int n_over, const float* rand_extra, int n_extra, int num_points, int B, int Q, int K,
+                             float eos_coef, float num_masks, float w_ce, float w_mask, float w_dice, const void* workspace, size_t workspace_bytes,
+                             const float* grad3, float* dlogits, int lddl, float* dmasks, fx_stream_t stream);
+
+/* rows[b][p][q] = bf16(planes[b][q][p]) (q < Q; zero for Q <= q < Qp, Qp % 8 == 0, Qp <= 240): the [B,Q,h*w] f32 mask-logit gradient as
+ * pixel-major bf16 rows - the operand layout of the two GEMMs behind the backward of einsum("bqc,bchw->bqhw")
+ * (bisenetformer/modelling.py:84). */
+int fx_planes_to_rows_bf16(const float* planes, int Q, int P, void* rows, int ld_rows, int Qp, int B, fx_stream_t stream);
+
+/* Backward of fx_dwconv3x3s2_nhwc_bf16 (CatBottleneck avd_layer / AvgPool2d(3,2,1) skip, focoos/nn/backbone/stdc.py:120-166):
+ * dx bf16 [B,H,W,C] (NULL: skipped) from dy bf16 [B,Ho,Wo,C] and w f32 [9][C]; dw f32 [9][C] += sum dy * x-tap (NULL: skipped;
+ * accumulated with atomics, zero-initialised by the caller). */
+int fx_dwconv3x3s2_bwd_nhwc_bf16(const void* dy, int lddy, const void* x, int ldx, const float* w, void* dx, int lddx, float* dw, int B, int H, int W,
+                                 int C, fx_stream_t stream);
+
+/* out[b][c] = scale * sum_p a[b,p,c] * (b ? b[b,p,c] : 1), f32 [B,ldo]: gradient of the attention gates (feat * atten) and of
+ * broadcast additions (bisenetformer/modelling.py:159-167, 186-212, 226-237).  splits > 1: pixel ranges + atomics (out zeroed by the caller). */
+int fx_rowdot_nhwc_bf16(const void* a, int lda, const void* b, int ldb, float scale, float* out, int ldo, int B, int P, int C, int splits,
+                        fx_stream_t stream);
+
+/* y[b,p,c] = bf16(scale * vec[b][c]): gradient of feat.mean((2,3)) towards feat (scale = 1/P). */
+int fx_bcast_vec_nhwc_bf16(const float* vec, int ldv, float scale, void* y, int ldy, int B, int P, int C, fx_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -32,7 +32,12 @@ def conv_x(sd: SD, prefix: str, x: torch.Tensor, stride: int = 1, relu: bool = T
 
 
 def _bn(sd: SD, prefix: str, y: torch.Tensor) -> torch.Tensor:
-    return F.batch_norm(y, sd[f"{prefix}.running_mean"], sd[f"{prefix}.running_var"], sd[f"{prefix}.weight"], sd[f"{prefix}.bias"], False, 0.0, 1e-5)
+    """nn.BatchNorm2d: running statistics, or (detr_oracle.BN_TRAINING set by the training oracle: model.train()) batch statistics
+    with the in-place running-statistics update."""
+    from .detr_oracle import BN_TRAINING
+
+    return F.batch_norm(y, sd[f"{prefix}.running_mean"], sd[f"{prefix}.running_var"], sd[f"{prefix}.weight"], sd[f"{prefix}.bias"], BN_TRAINING[0],
+                        0.1 if BN_TRAINING[0] else 0.0, 1e-5)
 
 
 def cat_bottleneck(sd: SD, prefix: str, x: torch.Tensor, stride: int) -> torch.Tensor:

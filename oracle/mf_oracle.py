@@ -123,13 +123,15 @@ def prediction_heads(sd: SD, x: torch.Tensor, mask_features: torch.Tensor, size:
 
 
 def masked_decoder(sd: SD, msf: List[torch.Tensor], mask_features: torch.Tensor, cfg: Dict,
-                   forced_attn: Optional[Sequence[torch.Tensor]] = None, collect: Optional[dict] = None, max_levels: int = 3):
+                   forced_attn: Optional[Sequence[torch.Tensor]] = None, collect: Optional[dict] = None, max_levels: int = 3,
+                   all_heads: Optional[list] = None):
     """MultiScaleMaskedTransformerDecoder.forward — fai_mf/modelling.py:453-549 (pre_norm=True, enforce_input_project=True,
     use_attn_masks=True; cross-attn first, then self-attn, then FFN; layers cycle over the 3 levels).
     ``forced_attn``: optional list (one per decoder layer) of boolean masks [B,Q,Lk] to teacher-force the masked attention
     (the discrete step whose flips near logit 0 are the H1-style hazard of this model).
     ``max_levels`` = 2 gives BiSeNetFormer's TransformerDecoder.forward (bisenetformer/modelling.py:375-447), the same
-    layer sequence cycling over two levels."""
+    layer sequence cycling over two levels.  ``all_heads``: list that receives (class logits, mask logits) of every prediction head
+    (the learnable queries + one per layer) - the deep-supervision outputs of the training forward."""
     H = "head.predictor"
     nl = int(cfg.get("transformer_predictor_dec_layers", 6))
     hd = int(cfg.get("transformer_predictor_hidden_dim", 256))
@@ -145,6 +147,8 @@ def masked_decoder(sd: SD, msf: List[torch.Tensor], mask_features: torch.Tensor,
     qe = sd[f"{H}.query_embed.weight"].unsqueeze(0).repeat(B, 1, 1)
     out = sd[f"{H}.query_feat.weight"].unsqueeze(0).repeat(B, 1, 1)
     cls, masks, attn = prediction_heads(sd, out, mask_features, sizes[0])
+    if all_heads is not None:   # training: every head is supervised (predictions_class / predictions_mask, modelling.py:489-545)
+        all_heads.append((cls, masks))
     used_masks = []
     for i in range(nl):
         lvl = i % nlev
@@ -165,6 +169,8 @@ def masked_decoder(sd: SD, msf: List[torch.Tensor], mask_features: torch.Tensor,
         if collect is not None:
             collect[f"dec{i}_out"] = out
         cls, masks, attn = prediction_heads(sd, out, mask_features, sizes[(i + 1) % nlev])
+        if all_heads is not None:
+            all_heads.append((cls, masks))
     if collect is not None:
         collect["attn_masks"] = used_masks
     return cls, masks

@@ -98,3 +98,52 @@ def synth_targets(seed: int, B: int, K: int, counts=(3, 0, 7, 1)):
         labels.append(torch.from_numpy(rs.randint(0, K, (t,)).astype(np.int64)))
         boxes.append(torch.from_numpy(np.concatenate([rs.uniform(0.2, 0.8, (t, 2)), rs.uniform(0.05, 0.35, (t, 2))], -1).astype(np.float32)))
     return labels, boxes
+
+
+# ================================================================================================ BiSeNetFormer (BASELINE config 5)
+def bf_train_outputs(sd: SD, cfg: Dict, images: torch.Tensor, forced_attn: Optional[Sequence[torch.Tensor]] = None, collect: Optional[dict] = None):
+    """BisenetFormer.forward in training mode up to the criterion (focoos/models/bisenetformer/modelling.py:594-609, TransformerDecoder.forward
+    :375-447): ``pred_logits`` / ``pred_masks`` of the last head + ``aux_outputs`` of the learnable-query head and the first
+    dec_layers - 1 layers (:438-447).  BatchNorm follows detr_oracle.BN_TRAINING (False = frozen / eval statistics).  The boolean attention
+    masks carry no gradient (``< 0`` of a detached tensor, :104-106)."""
+    from . import bf_oracle as BF
+    from . import mf_oracle as M
+
+    mean = torch.tensor(cfg.get("pixel_mean", [123.675, 116.28, 103.53]), dtype=torch.float32).view(-1, 1, 1)
+    std = torch.tensor(cfg.get("pixel_std", [58.395, 57.12, 57.375]), dtype=torch.float32).view(-1, 1, 1)
+    x = (images - mean) / std
+    feats = BF.stdc(sd, "pixel_decoder.backbone", x, tuple(cfg["backbone_config"].get("layers", (4, 5, 3))))
+    if collect is not None:
+        collect.update(feats)
+    mask_features, msf = BF.bisenet(sd, feats, collect)
+    heads: list = []
+    M.masked_decoder(sd, list(msf[:-1]), mask_features, cfg, forced_attn, collect, max_levels=2, all_heads=heads)
+    return {"pred_logits": heads[-1][0], "pred_masks": heads[-1][1], "aux_outputs": [{"pred_logits": a, "pred_masks": b} for a, b in heads[:-1]]}
+
+
+def bf_criterion(outputs, tgt_labels: Sequence[torch.Tensor], tgt_masks: Sequence[torch.Tensor], rand, cfg: Dict, fixed_matches=None):
+    """SetCriterion.forward of the mask families with the registry's weights (bisenetformer/modelling.py:551-575): dict of weighted losses
+    + the matches; ``rand`` = mask_criterion_oracle.RandStream of the torch.rand draws in the reference's order."""
+    from . import mask_criterion_oracle as MC
+
+    return MC.criterion(outputs, tgt_labels, tgt_masks, rand, int(cfg["num_classes"]), int(cfg.get("criterion_num_points", 12544)),
+                        weights=(float(cfg.get("weight_dict_loss_ce", 2)), float(cfg.get("weight_dict_loss_mask", 5)), float(cfg.get("weight_dict_loss_dice", 5))),
+                        cost_weights=(float(cfg.get("matcher_cost_class", 2)), float(cfg.get("matcher_cost_mask", 5)), float(cfg.get("matcher_cost_dice", 5))),
+                        eos_coef=float(cfg.get("criterion_eos_coef", 0.1)), fixed_matches=fixed_matches)
+
+
+def synth_mask_targets(seed: int, B: int, K: int, hw, counts=(3, 5)):
+    """Seeded blob-shaped instance targets at image resolution: per image labels i64 [T] and masks bool [T, H, W]."""
+    rs = np.random.RandomState(seed)
+    H, W = hw
+    yy, xx = np.mgrid[0:H, 0:W]
+    labels, masks = [], []
+    for b in range(B):
+        t = counts[b % len(counts)]
+        labels.append(torch.from_numpy(rs.randint(0, K, (t,)).astype(np.int64)))
+        m = np.zeros((t, H, W), bool)
+        for i in range(t):
+            cy, cx, ry, rx = rs.uniform(0, H), rs.uniform(0, W), rs.uniform(H / 8, H / 3), rs.uniform(W / 8, W / 3)
+            m[i] = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0
+        masks.append(torch.from_numpy(m))
+    return labels, masks

@@ -8,10 +8,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-# The halo 3x3 kernel is routed to from M >= 40000 pixels in production (smaller layers do not fill the chip); the parity
-# tests run small shapes through it too.  Read once by the library at its first convolution call.
-os.environ.setdefault("FX_CONV3_MIN_M", "0")
-os.environ.setdefault("FX_PW_MIN_M", "0")
+@pytest.fixture
+def flat_small_shapes(monkeypatch):
+    """The halo 3x3 / flat pointwise kernels are routed to from M >= 40000 pixels in production (smaller layers do not fill the
+    chip).  Kernel-level parity tests run small shapes through them by lowering the thresholds (re-read by the library per call);
+    end-to-end tests keep the production routing, i.e. they check the numerics a user gets at that size."""
+    monkeypatch.setenv("FX_CONV3_MIN_M", "0")
+    monkeypatch.setenv("FX_PW_MIN_M", "0")
 
 
 def pytest_configure(config):

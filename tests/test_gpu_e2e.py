@@ -241,11 +241,15 @@ def test_state_dict_roundtrip_and_loud_failures(setup):
     bad.pop("head.predictor.enc_score_classifier.bias")
     with pytest.raises(RuntimeError):
         model.load_state_dict(bad, strict=True)
-    with pytest.raises(NotImplementedError):
-        model.train(True)
+    model.train(True)  # nn.Module.train only flips the flag; the training graph lives behind FocoosModel.train (trainer.run_train)
+    try:
+        with pytest.raises(NotImplementedError):
+            model.forward(setup[5][:1])
+    finally:
+        model.eval()
 
 
-def test_batch_parts_equal_single_plan(setup):
+def test_batch_parts_equal_single_plan(setup, flat_small_shapes):
     """_MultiPlan (experimental, off by default): the batch cut into two parts with their own buffers, writing contiguous batch
     slices of the same output tensors, gives bit-identical results to the single plan when the parts run one after the other
     (use_graph=False).  Their CONCURRENT replay is not asserted: it is the unsafe experiment documented in engine._MultiPlan."""
@@ -268,11 +272,13 @@ def test_batch_parts_equal_single_plan(setup):
     assert torch.equal(outs[0][0][:2], outs[0][0][2:4])  # the repeated images give repeated rows
 
 
-def test_full_size_batch_properties(setup):
+def test_full_size_batch_properties(setup, flat_small_shapes):
     """BASELINE configs[1] at full size (bs=32, 640x640): size-independent properties of the whole path.
     (i) every image is computed independently of its batch position / neighbours: a permuted batch gives the permuted
     result bit-for-bit, and image i of the bs=32 step equals the same image run alone; (ii) replay is idempotent;
-    (iii) post-process invariants: scores sorted descending, counts = #scores > threshold, labels in range, x2>=x1, y2>=y1."""
+    (iii) post-process invariants: scores sorted descending, counts = #scores > threshold, labels in range, x2>=x1, y2>=y1.
+    Kernel routing is pinned (flat_small_shapes): in production a layer's kernel is chosen by M = B*H*W, so a bs=1 and a bs=32
+    run of the same image agree to bf16 rounding, not bit-for-bit; with one routing the batch position must not matter at all."""
     from focoos_amd.synth import synth_image_structured as sis
 
     g, cfg, sd, model, *_ = setup

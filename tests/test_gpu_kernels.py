@@ -606,7 +606,7 @@ FLAT_CASES = [
 
 
 @pytest.mark.parametrize("case", FLAT_CASES)
-def test_conv3x3_flat_halo_kernel(lib, case, monkeypatch):
+def test_conv3x3_flat_halo_kernel(lib, case, flat_small_shapes):
     B, H, W, Cc, N, act, res_after, pad = case
     assert lib.fx_conv3x3_flat_supported(Cc, N, W) == 1
     g = torch.Generator().manual_seed(300 + FLAT_CASES.index(case))
@@ -636,7 +636,7 @@ PW_FLAT_CASES = [
 
 
 @pytest.mark.parametrize("case", PW_FLAT_CASES)
-def test_pointwise_flat_kernel(lib, case):
+def test_pointwise_flat_kernel(lib, case, flat_small_shapes):
     B, H, W, Cc, N, act, has_res = case
     g = torch.Generator().manual_seed(400 + PW_FLAT_CASES.index(case))
     x = torch.randn(B, H, W, Cc, generator=g) + torch.linspace(-1, 1, Cc)[None, None, None, :]
@@ -652,7 +652,7 @@ def test_pointwise_flat_kernel(lib, case):
     assert (got - igemm).abs().max() / ref.abs().max() < 1.2e-2
 
 
-def test_pointwise_flat_batch_stride(lib):
+def test_pointwise_flat_batch_stride(lib, flat_small_shapes):
     """y_batch_stride (a level writing its rows of the [B, sum(HW), C] decoder memory) through the pointwise kernel."""
     B, H, W, Cc, N, S = 3, 5, 8, 256, 256, 100
     g = torch.Generator().manual_seed(7)

@@ -78,8 +78,8 @@ def test_matcher_and_criterion_vs_reference_golden():
     costs, matches = [], []
     orig = crit._one_set
 
-    def spy(o, tg, nm):
-        r = orig(o, tg, nm)
+    def spy(o, tg, nm, fixed=None):
+        r = orig(o, tg, nm, fixed)
         costs.append(matcher.last_cost.cpu())
         matches.append((crit.last_matches[0].cpu(), crit.last_matches[1].cpu(), tg.off_host.copy()))
         return r

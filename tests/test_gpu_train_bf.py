@@ -1,0 +1,170 @@
+"""The whole BiSeNetFormer training step (BASELINE config 5: forward in training mode, 7 supervised prediction
+heads, point-sampled Hungarian criterion, backward, optimizer) on the HIP autograd graph vs the CPU fp32 training oracle
+(oracle/train_oracle.bf_train_outputs / bf_criterion, pinned against the real reference fully in .train() by
+tests/test_oracle_vs_reference.py::test_bf_train_oracle_matches_reference_losses_and_gradients).
+Discrete choices are teacher-forced to the oracle's: the boolean attention masks (their `< 0` test flips under any rounding change), the
+Hungarian matches (the GPU matcher is checked bit-exactly in tests/test_gpu_mask_criterion.py) and the torch.rand draws of the point
+sampling (inputs of the C ABI).  Tolerances (bf16 activations / gradients, fp32 losses and weight gradients): each of the 21 losses within
+3 % (+1e-3) with frozen BatchNorm, 6 % with batch statistics; per-parameter gradient relative L2: see the asserts (measured values in
+DESIGN.md §2)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from focoos_amd.ports import MaskFormerTargets  # noqa: E402
+from focoos_amd.registry import ModelRegistry  # noqa: E402
+from focoos_amd.synth import synth_image_structured, synth_state_dict  # noqa: E402
+from oracle import detr_oracle as O  # noqa: E402
+from oracle import train_oracle as T  # noqa: E402
+from tests.helpers import rel_l2  # noqa: E402
+
+DEV = "cuda:0"
+
+
+class _DrawAndRecord:
+    """mask_criterion_oracle.RandStream interface that draws from a seeded generator and records, for the engine's replay."""
+
+    def __init__(self, seed):
+        self.g = torch.Generator().manual_seed(seed)
+        self.rec = []
+
+    def take(self, *shape):
+        t = torch.rand(*shape, generator=self.g)
+        self.rec.append(t)
+        return t
+
+
+class _Replay:
+    def __init__(self, tensors):
+        self.t, self.i = list(tensors), 0
+
+    def __call__(self, *shape, device):
+        t = self.t[self.i]
+        assert tuple(t.shape) == tuple(shape), (self.i, tuple(t.shape), shape)
+        self.i += 1
+        return t.to(device)
+
+
+def _cfg(num_points=2048):
+    cfg = ModelRegistry.get_model_info("bisenetformer-l-ade")["config"]
+    return dict(cfg, criterion_num_points=num_points)   # 12544 in the registry: minutes on the CPU oracle, same code path
+
+
+@pytest.mark.parametrize("norm", ["FrozenBN", "BN"])
+def test_bf_train_step_losses_and_gradients(norm):
+    from focoos_amd.train_bf import BisenetFormerTrainable
+
+    cfg = _cfg()
+    if norm == "BN":
+        # Batch statistics on a random-weight STDC (no residual connections) amplify ANY perturbation ~1.5x per CatBottleneck: through the
+        # 12 blocks of STDC-2 the 0.4 % bf16 rounding of the first activations grows to 60 % at res5 (measured; every block reproduces the
+        # oracle to 0.6 % when fed the oracle's input, and the frozen-statistics run of the same 12 blocks stays at 0.9 %).  The live-BN
+        # plumbing of the whole model - conv / depthwise / pooled-vector BatchNorms, their gradients and running statistics - is
+        # therefore compared on the 3-block STDC (layers 1-1-1: the same modules, a composition shallow enough to be well conditioned).
+        cfg = dict(cfg, backbone_config=dict(cfg["backbone_config"], layers=[1, 1, 1]))
+    sd = synth_state_dict(cfg, 31, family="bisenetformer")
+    nimg, (ih, iw) = (4, (192, 256)) if norm == "BN" else (2, (192, 256))
+    imgs = [synth_image_structured(60 + i, ih, iw) for i in range(nimg)]
+    labels, masks = T.synth_mask_targets(5, nimg, int(cfg["num_classes"]), (ih, iw), counts=(3, 5, 2, 4))
+
+    def trainable(k, v):
+        if not (v.dtype == torch.float32 and v.dim() > 0) or any(t in k for t in ("running_", "empty_weight")):
+            return False
+        is_bn = k.endswith((".bn.weight", ".bn.bias", ".bn_atten.weight", ".bn_atten.bias", ".avd_layer.1.weight", ".avd_layer.1.bias"))
+        return norm != "FrozenBN" or not is_bn
+
+    sdg = {k: (v.clone().requires_grad_(True) if trainable(k, v) else v.clone()) for k, v in sd.items()}
+    x = O.get_torch_batch(imgs, None)
+    col = {}
+    O.BN_TRAINING[0] = norm != "FrozenBN"
+    try:
+        outs = T.bf_train_outputs(sdg, cfg, x, collect=col)
+    finally:
+        O.BN_TRAINING[0] = False
+    rs = _DrawAndRecord(77)
+    losses_o, matches = T.bf_criterion(outs, labels, masks, rs, cfg)
+    sum(losses_o.values()).backward()
+    # ---- HIP autograd graph
+    model = BisenetFormerTrainable(cfg, norm=norm, rand=_Replay(rs.rec)).to(DEV)
+    model.load_state_dict(sd, strict=True)
+    assert sorted(model.state_dict().keys()) == sorted(sd.keys())
+    model.train()
+    targets = [MaskFormerTargets(labels=l.to(DEV), masks=m.to(DEV)) for l, m in zip(labels, masks)]
+    fixed = []
+    for m in matches:
+        pi = torch.tensor(np.concatenate([np.asarray(i) for i, _ in m]), dtype=torch.int32, device=DEV)
+        ti = torch.tensor(np.concatenate([np.asarray(j) for _, j in m]), dtype=torch.int32, device=DEV)
+        fixed.append((pi, ti))
+    x_u8 = torch.from_numpy(np.stack(imgs)).to(DEV)
+    losses = model(x_u8, targets, forced_attn=col["attn_masks"], fixed_matches=fixed)
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    assert sorted(losses) == sorted(losses_o) and len(losses) == 21
+    for k in losses_o:
+        a, b = float(losses[k]), float(losses_o[k])
+        assert abs(a - b) <= (6e-2 if norm == "BN" else 3e-2) * abs(b) + 1e-3, (k, a, b)
+    # the supervised mask logits of the last head against the oracle's (teacher-forced attention): a direct forward check
+    pm = model.last_outputs["pred_masks"].detach().float().cpu()
+    pm_err = rel_l2(pm, outs["pred_masks"].detach())
+    print(f"{norm}: last-head mask logits rel-L2 {pm_err:.4f}")
+    errs = []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        r = sdg[name]
+        if not (isinstance(r, torch.Tensor) and r.requires_grad):
+            continue
+        assert p.grad is not None, name
+        assert r.grad is not None, name
+        errs.append((rel_l2(p.grad.cpu(), r.grad), name, float(r.grad.norm())))
+    floor = 1e-3 * sorted(n for _, _, n in errs)[len(errs) // 2]
+    print("zero-gradient tensors skipped:", [n for _, n, g in errs if g < floor])
+    errs = [(e, n) for e, n, g in errs if g >= floor]
+    errs.sort(reverse=True)
+    print(f"{norm}: {len(errs)} parameter tensors; worst 8: {[(round(e, 4), n) for e, n in errs[:8]]}; median {errs[len(errs) // 2][0]:.4f}")
+    print("quartiles:", [round(errs[len(errs) * q // 4][0], 4) for q in (1, 2, 3)])
+    assert len(errs) > 180
+    if norm == "FrozenBN":
+        assert pm_err <= 4e-2
+    if norm == "BN":
+        dec = sorted(e for e, n in errs if n.startswith("head.predictor."))
+        assert dec[len(dec) // 2] <= 0.12, dec[len(dec) // 2]
+        assert errs[len(errs) // 2][0] <= 0.40 and errs[len(errs) // 10][0] <= 0.60, errs[:8]
+        msd = model.state_dict()
+        for k in ("pixel_decoder.backbone.features.0.bn.running_mean", "pixel_decoder.backbone.features.3.avd_layer.1.running_var",
+                  "pixel_decoder.cp.arm16.bn_atten.running_mean", "pixel_decoder.conv_out.bn.running_var"):
+            assert rel_l2(msd[k].cpu(), sdg[k]) <= 2e-2, k
+            assert not torch.equal(sdg[k], sd[k])
+    else:
+        assert errs[0][0] <= 0.25, errs[:8]
+        assert errs[len(errs) // 2][0] <= 0.08
+
+
+def test_bf_train_step_free_running_and_optimizer():
+    """TrainStep on the BiSeNetFormer graph, nothing teacher-forced (GPU Hungarian matcher, torch.rand on the device, attention masks
+    from the engine's own mask logits): losses finite and close to the teacher-forced values' scale, every trainable parameter receives
+    a gradient and moves, a second step runs on the updated weights, running statistics move under norm="BN"."""
+    from focoos_amd.train_bf import BisenetFormerTrainable
+    from focoos_amd.train_detr import TrainStep
+
+    cfg = _cfg(1024)
+    sd = synth_state_dict(cfg, 32, family="bisenetformer")
+    model = BisenetFormerTrainable(cfg, norm="BN").to(DEV)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    ts = TrainStep(model, lr=1e-4, max_grad_norm=0.1)
+    imgs = [synth_image_structured(90 + i, 128, 160) for i in range(4)]
+    labels, masks = T.synth_mask_targets(6, 4, int(cfg["num_classes"]), (128, 160), counts=(2, 0, 4, 1))   # one image without targets
+    targets = [MaskFormerTargets(labels=l.to(DEV), masks=m.to(DEV)) for l, m in zip(labels, masks)]
+    x_u8 = torch.from_numpy(np.stack(imgs)).to(DEV)
+    p0 = ts.opt.flat_p.clone()
+    l1 = {k: float(v) for k, v in ts.step(x_u8, targets).items()}
+    l2 = {k: float(v) for k, v in ts.step(x_u8, targets).items()}
+    torch.cuda.synchronize()
+    assert len(l1) == 21 and all(np.isfinite(v) for v in l1.values()) and all(np.isfinite(v) for v in l2.values())
+    assert not torch.equal(ts.opt.flat_p, p0)
+    dead = [n for n, _ in ts.named if float(ts.opt.grads[n].abs().max()) == 0.0]   # the flat gradient views still hold step 2's gradients
+    assert not dead, dead[:10]
+    assert int(model.state_dict()["pixel_decoder.backbone.features.0.bn.num_batches_tracked"]) == 2

@@ -342,9 +342,11 @@ def test_backbone_plus_hybrid_encoder_backward_vs_torch_autograd():
 
 @pytest.mark.parametrize("act,with_res,C,rows_shape", [("relu", True, 64, (3, 9, 11)), ("silu", True, 256, (2, 5, 7)), (None, False, 24, (4, 33, 17)),
                                                         ("gelu", False, 520, (1, 6, 5))])
-def test_batchnorm_train_kernels(lib, act, with_res, C, rows_shape):
+@pytest.mark.parametrize("z_f32", [0, 1])
+def test_batchnorm_train_kernels(lib, act, with_res, C, rows_shape, z_f32):
     """fx_bn_stats / finalize / apply and fx_bn_bwd_stats / apply vs torch fp32 autograd of
-    act(F.batch_norm(z, training=True) [+ residual]) on the same bf16-rounded inputs."""
+    act(F.batch_norm(z, training=True) [+ residual]) on the same bf16-rounded inputs; z read as bf16 or as fp32 (the form the
+    trainable graphs use: the conv epilogue writes the pre-normalisation tensor in fp32)."""
     from focoos_amd._lib import FX_ACT
 
     g = torch.Generator().manual_seed(C)
@@ -369,23 +371,25 @@ def test_batchnorm_train_kernels(lib, act, with_res, C, rows_shape):
     # kernels
     st = stream()
     zd, dyd = z.to(DEV), dy.to(DEV)
+    if z_f32:
+        zd = zd.float()
     rd = res.to(DEV) if with_res else None
     sums = torch.zeros(2, C, device=DEV)
-    check(lib.fx_bn_stats_bf16(zd.data_ptr(), C, sums.data_ptr(), rows, C, st))
+    check(lib.fx_bn_stats_bf16(zd.data_ptr(), C, z_f32, sums.data_ptr(), rows, C, st))
     stats = torch.empty(4, C, device=DEV)
     gd, bd, rmd, rvd = gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV)
     nbt = torch.zeros((), dtype=torch.long, device=DEV)
     check(lib.fx_bn_finalize_f32(sums.data_ptr(), float(rows), gd.data_ptr(), bd.data_ptr(), 1e-5, 0.1, rmd.data_ptr(), rvd.data_ptr(), nbt.data_ptr(),
                                  stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), C, st))
-    y = torch.empty_like(zd)
+    y = torch.empty_like(dyd)
     rp = rd.data_ptr() if with_res else None
-    check(lib.fx_bn_apply_bf16(zd.data_ptr(), C, stats[2].data_ptr(), stats[3].data_ptr(), rp, C, FX_ACT[act], y.data_ptr(), C, rows, C, st))
+    check(lib.fx_bn_apply_bf16(zd.data_ptr(), C, z_f32, stats[2].data_ptr(), stats[3].data_ptr(), rp, C, FX_ACT[act], y.data_ptr(), C, rows, C, st))
     bs = torch.zeros(2, C, device=DEV)
-    check(lib.fx_bn_bwd_stats_bf16(dyd.data_ptr(), C, zd.data_ptr(), C, rp, C, stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(),
+    check(lib.fx_bn_bwd_stats_bf16(dyd.data_ptr(), C, zd.data_ptr(), C, z_f32, rp, C, stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(),
                                    stats[1].data_ptr(), FX_ACT[act], bs.data_ptr(), rows, C, st))
-    dz = torch.empty_like(zd)
-    da = torch.empty_like(zd) if with_res else None
-    check(lib.fx_bn_bwd_apply_bf16(dyd.data_ptr(), C, zd.data_ptr(), C, rp, C, stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(),
+    dz = torch.empty_like(dyd)
+    da = torch.empty_like(dyd) if with_res else None
+    check(lib.fx_bn_bwd_apply_bf16(dyd.data_ptr(), C, zd.data_ptr(), C, z_f32, rp, C, stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(),
                                    stats[1].data_ptr(), FX_ACT[act], bs.data_ptr(), 1.0 / rows, da.data_ptr() if with_res else None, C, dz.data_ptr(), C,
                                    rows, C, st))
     torch.cuda.synchronize()
@@ -456,7 +460,7 @@ def test_bottleneck_pair_batch_stat(lib):
     """Two ResNet-vd bottlenecks (projection shortcut, then identity shortcut; 7 live BatchNorm layers) vs torch autograd of
     the same composition, twice: with straight-through bf16 rounding where the engine stores tensors (tight: proves the
     residual / two-consumer gradient wiring and the BN backward in composition) and in pure fp32 (loose: documents how far
-    bf16 storage of the pre-normalisation conv output moves gradients through ReLU sign flips)."""
+    bf16 storage of the layer outputs moves gradients through ReLU sign flips and the BN backward's cancellations)."""
     from focoos_amd.train_nn import BottleNeck, _Blocks, set_norm_mode
     from tests.helpers import rel_l2
 
@@ -483,12 +487,13 @@ def test_bottleneck_pair_batch_stat(lib):
 
     def reference(rb):
         """The same composition in torch fp32; ``rb`` = identity (the reference's arithmetic) or straight-through bf16 rounding
-        at the points where the engine STORES a tensor (weight image, conv output z, layer output)."""
+        at the points where the engine STORES a tensor in bf16 (weight image, layer output; the conv output in front of a live
+        BatchNorm stays fp32)."""
         ref = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and "running" not in k else v.clone()) for k, v in sd.items()}
         xt = x.float().permute(0, 3, 1, 2).requires_grad_(True)
 
         def cbn(p, h, act, res=None):
-            z = rb(F.conv2d(h, rb(ref[f"{p}.conv.weight"]), None, 1, (ref[f"{p}.conv.weight"].shape[-1] - 1) // 2))
+            z = F.conv2d(h, rb(ref[f"{p}.conv.weight"]), None, 1, (ref[f"{p}.conv.weight"].shape[-1] - 1) // 2)   # kept in fp32 by the engine
             a = F.batch_norm(z, ref[f"{p}.norm.running_mean"], ref[f"{p}.norm.running_var"], ref[f"{p}.norm.weight"], ref[f"{p}.norm.bias"], True, 0.1, 1e-5)
             if res is not None:
                 a = a + res

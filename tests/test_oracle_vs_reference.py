@@ -207,3 +207,76 @@ def test_train_oracle_batch_stat_batchnorm_matches_reference():
               "pixel_decoder.pan_blocks.0.conv2.norm.running_var", "head.predictor.input_proj.2.norm.running_mean"):
         np.testing.assert_allclose(sdg[k].numpy(), ref_sd[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
         assert not torch.equal(sdg[k], sd[k]), k
+
+
+def test_bf_train_oracle_matches_reference_losses_and_gradients():
+    """oracle/train_oracle.bf_train_outputs + bf_criterion (BiSeNetFormer training forward, 7 supervised prediction heads, point-sampled
+    Hungarian criterion) vs the REAL reference fully in .train() (BatchNorm on batch statistics): the 21 weighted losses on the
+    reference's own recorded torch.rand draws, gradients of parameters spread over the model incl. BatchNorm affine and the learned
+    queries, and the running-statistics update."""
+    ref_import.install()
+    import json
+    import os
+
+    from focoos.models.bisenetformer.ports import BisenetFormerTargets
+
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.synth import synth_image_structured, synth_state_dict
+    from oracle import detr_oracle as O
+    from oracle import mask_criterion_oracle as MC
+    from oracle import train_oracle as T
+
+    cfg = ModelRegistry.get_model_info("bisenetformer-l-ade")["config"]
+    cfg = dict(cfg, criterion_num_points=1024)   # 12544 points per pair x 21 point-sampling calls is minutes on CPU; same code path
+    ref_cfg = json.load(open(os.path.join(ref_import.REFERENCE_ROOT, "focoos/model_registry/bisenetformer-l-ade.json")))["config"]
+    ref_cfg = dict(ref_cfg, criterion_num_points=1024)
+    model, proc, _ = ref_import.build_reference_bf(ref_cfg)
+    sd = synth_state_dict(cfg, seed=12, family="bisenetformer")
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    imgs = [synth_image_structured(40 + i, 128, 160) for i in range(2)]
+    x = O.get_torch_batch(imgs, None)
+    labels, masks = T.synth_mask_targets(3, 2, int(cfg["num_classes"]), (128, 160), counts=(3, 5))
+    rec, orig_rand = [], torch.rand
+
+    def spy_rand(*a, **k):
+        t = orig_rand(*a, **k)
+        rec.append(t.clone())
+        return t
+
+    torch.rand = spy_rand
+    try:
+        out = model(x, [BisenetFormerTargets(labels=l, masks=m) for l, m in zip(labels, masks)])
+    finally:
+        torch.rand = orig_rand
+    ref_losses = out.loss
+    assert len(ref_losses) == 21
+    sum(ref_losses.values()).backward()
+    sdg = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and v.dim() > 0 and "running" not in k and "empty_weight" not in k
+               else v.clone()) for k, v in sd.items()}
+    O.BN_TRAINING[0] = True
+    try:
+        outs = T.bf_train_outputs(sdg, cfg, x)
+    finally:
+        O.BN_TRAINING[0] = False
+    losses, _ = T.bf_criterion(outs, labels, masks, MC.RandStream(rec), cfg)
+    assert sorted(losses) == sorted(ref_losses)
+    for k in ref_losses:
+        np.testing.assert_allclose(float(losses[k]), float(ref_losses[k]), rtol=5e-4, atol=1e-5, err_msg=k)
+    sum(losses.values()).backward()
+    named = dict(model.named_parameters())
+    for k in ("pixel_decoder.backbone.features.1.conv.weight", "pixel_decoder.backbone.features.6.avd_layer.0.weight",
+              "pixel_decoder.backbone.features.6.avd_layer.1.weight", "pixel_decoder.backbone.features.9.conv_list.2.bn.bias",
+              "pixel_decoder.cp.arm32.conv_atten.weight", "pixel_decoder.cp.arm16.bn_atten.weight", "pixel_decoder.cp.conv_avg.conv.weight",
+              "pixel_decoder.ffm.proj1.weight", "pixel_decoder.ffm.conv2.weight", "pixel_decoder.conv_out.conv.weight",
+              "head.predictor.query_embed.weight", "head.predictor.query_feat.weight", "head.predictor.input_proj.1.bias",
+              "head.predictor.transformer_cross_attention_layers.2.multihead_attn.in_proj_weight",
+              "head.predictor.forward_prediction_heads.mask_classifier.layers.2.weight", "head.predictor.forward_prediction_heads.classifier.bias"):
+        g_ref, g_mine = named[k].grad, sdg[k].grad
+        assert g_ref is not None and g_mine is not None, k
+        assert (g_mine - g_ref).abs().max() <= 5e-3 * g_ref.abs().max() + 1e-7, (k, float((g_mine - g_ref).abs().max()), float(g_ref.abs().max()))
+    ref_sd = model.state_dict()
+    for k in ("pixel_decoder.backbone.features.3.conv_list.1.bn.running_mean", "pixel_decoder.backbone.features.11.avd_layer.1.running_var",
+              "pixel_decoder.cp.arm32.bn_atten.running_mean", "pixel_decoder.conv_out.bn.running_var"):
+        np.testing.assert_allclose(sdg[k].numpy(), ref_sd[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+        assert not torch.equal(sdg[k], sd[k]), k
