@@ -53,11 +53,17 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=32)
     ap.add_argument("--dry-run", action="store_true", help="CPU-only plumbing check (gloo): no GPU work, fake step")
     ap.add_argument("--per-op", default="", help="write per-op timing table to this path")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="default run only: skip the short extra legs (RT-DETR / BiSeNetFormer training step, MaskFormer / BiSeNetFormer inference) "
+                         "reported under `other_configs` of the one JSON line")
+    ap.add_argument("--other-configs-budget", type=float, default=240.0, help="seconds after which the extra legs are abandoned (watchdog)")
     a = ap.parse_args()
+    a.default_run = len([x for x in sys.argv[1:] if x.startswith("--model") or x in ("--train", "--dry-run")]) == 0
     mf = a.model.startswith("fai-mf")
     a.family = "fai_mf" if mf else ("bisenetformer" if a.model.startswith("bisenetformer") else "fai_detr")
-    a.batch = a.batch or (16 if (mf or a.train) else 32)
-    a.size = a.size or (800 if mf else 640)
+    bf_train = a.train and a.family == "bisenetformer"   # BASELINE config 5: 1024 x 1024, 8 images per GPU
+    a.batch = a.batch or (8 if bf_train else (16 if (mf or a.train) else 32))
+    a.size = a.size or (1024 if bf_train else (800 if mf else 640))
     return a
 
 
@@ -216,13 +222,55 @@ def per_op_timing(eng, pl, args):
     return [a / reps for a in acc]
 
 
-def train_main(args, world, rank, local):
-    """BASELINE config 4 per GPU: 16 synthetic 640^2 images + COCO-shaped targets (T_i ~ U{1..20}, seed = rank*1000 + iter),
-    one optimisation step = forward (training mode, frozen BN) + criterion + backward + gradient all-reduce + AdamW."""
+ALG_GFLOP_PER_IMAGE_BF_1024 = 83.5   # bisenetformer-l-ade forward @1024^2 (FlopCounterMode on the reference)
+
+
+def _wgrad_roofline(nn_, stepper, imgs, targets):
+    """`roofline` of the training step's dominant kernel family (the weight-gradient kernel): one extra step outside the timed region with
+    every fx_conv2d_wgrad_partial launch bracketed by events on the stream it runs on; achieved = algorithmic FLOPs (2 M N K per
+    launch) / summed durations, and the algorithmic bytes (x + dz read once, the fp32 partial slabs written once) against HBM."""
+    import torch
+
+    orig = nn_._conv_param_grads
+    rec = []
+
+    def timed(layer, x, dz, scale):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig(layer, x, dz, scale)
+        e1.record()
+        B, H, W_, Cc = x.shape
+        _, Ho, Wo, N = dz.shape
+        k = layer.k
+        rec.append((e0, e1, 2.0 * B * Ho * Wo * N * Cc * k * k, 2.0 * (x.numel() + dz.numel()) + 4.0 * N * Cc * k * k))
+        return out
+
+    nn_._conv_param_grads = timed
+    try:
+        stepper.step(imgs, targets)
+    finally:
+        nn_._conv_param_grads = orig
+    torch.cuda.synchronize()
+    ms = sum(a.elapsed_time(b) for a, b, _, _ in rec)
+    fl, by = sum(r[2] for r in rec), sum(r[3] for r in rec)
+    tf, gbs = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
+    ai = fl / by
+    return {"bound": "mfma" if ai >= PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm", "kernel": "conv_wgrad_kernel (+ slab sum / unpack)",
+            "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "launches_per_step": len(rec), "ms_per_step": round(ms, 3), "arithmetic_intensity_flop_per_byte": round(ai, 1),
+            "hbm": {"achieved_gbs_algorithmic": round(gbs, 1), "peak_gbs": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4)},
+            "note": "events bracket the wgrad launch + its slab-sum/unpack pass of every conv layer (eager step, launches serial on one stream)"}
+
+
+def train_measure(args, world, rank, local, with_roofline=True):
+    """BASELINE config 4 per GPU: 16 synthetic 640^2 images + COCO-shaped targets (T_i ~ U{1..20}, seed = rank*1000 + iter);
+    config 5 (--model bisenetformer-l-ade): 8 synthetic 1024^2 images + 5-15 random rectangular masks per image, labels U{0..149}.
+    One optimisation step = forward (training mode) + criterion + backward + gradient all-reduce + AdamW."""
     import numpy as np
     import torch
 
-    from focoos_amd.ports import DETRTargets
+    from focoos_amd import train_nn
+    from focoos_amd.ports import DETRTargets, MaskFormerTargets
     from focoos_amd.registry import ModelRegistry
     from focoos_amd.synth import synth_image, synth_state_dict
     from focoos_amd.train_detr import FAIDetrTrainable, TrainStep
@@ -231,8 +279,17 @@ def train_main(args, world, rank, local):
     torch.cuda.set_device(local)
     cfg = ModelRegistry.get_model_info(args.model)["config"]
     K, B, S = int(cfg["num_classes"]), args.batch, args.size
-    model = FAIDetrTrainable(cfg, norm=args.norm).to(dev)
-    model.load_state_dict(synth_state_dict(cfg, 0), strict=True)
+    bf = args.family == "bisenetformer"
+    if bf:
+        from focoos_amd.train_bf import BisenetFormerTrainable
+
+        model = BisenetFormerTrainable(cfg, norm=args.norm).to(dev)
+    elif args.family == "fai_detr":
+        model = FAIDetrTrainable(cfg, norm=args.norm).to(dev)
+    else:
+        raise SystemExit(f"bench.py --train covers fai-detr-* and bisenetformer-* (got {args.model})")
+    model.load_state_dict(synth_state_dict(cfg, 0, family=args.family), strict=True)
+    model.train()
     stepper = TrainStep(model)
     imgs = torch.stack([torch.from_numpy(synth_image(rank * B + i, S, S)) for i in range(B)]).to(dev)
 
@@ -240,9 +297,17 @@ def train_main(args, world, rank, local):
         rs = np.random.RandomState(rank * 1000 + it)
         out = []
         for _ in range(B):
-            t = rs.randint(1, 21)
-            bx = np.concatenate([rs.uniform(0.2, 0.8, (t, 2)), rs.uniform(0.05, 0.35, (t, 2))], -1).astype(np.float32)
-            out.append(DETRTargets(labels=torch.from_numpy(rs.randint(0, K, (t,))).to(dev), boxes=torch.from_numpy(bx).to(dev)))
+            if bf:
+                t = rs.randint(5, 16)
+                m = np.zeros((t, S, S), bool)
+                for i in range(t):
+                    y0, x0 = rs.randint(0, S - 32), rs.randint(0, S - 32)
+                    m[i, y0:y0 + rs.randint(32, S // 2), x0:x0 + rs.randint(32, S // 2)] = True
+                out.append(MaskFormerTargets(labels=torch.from_numpy(rs.randint(0, K, (t,))).to(dev), masks=torch.from_numpy(m).to(dev)))
+            else:
+                t = rs.randint(1, 21)
+                bx = np.concatenate([rs.uniform(0.2, 0.8, (t, 2)), rs.uniform(0.05, 0.35, (t, 2))], -1).astype(np.float32)
+                out.append(DETRTargets(labels=torch.from_numpy(rs.randint(0, K, (t,))).to(dev), boxes=torch.from_numpy(bx).to(dev)))
         return out
 
     # targets of every step are created (and moved to HBM) BEFORE the timed region, like the images: a data loader hands them over
@@ -259,18 +324,33 @@ def train_main(args, world, rank, local):
     dt = max_over_ranks(time.perf_counter() - t0, world, False)
     total = float(sum(v.detach().float() for v in losses.values()))
     value = world * B * args.steps / dt
-    alg = 3 * ALG_GFLOP_PER_IMAGE * (S / 640.0) ** 2  # training ~ 3 x forward (fwd + dgrad + wgrad)
+    fwd = ALG_GFLOP_PER_IMAGE_BF_1024 * (S / 1024.0) ** 2 if bf else ALG_GFLOP_PER_IMAGE * (S / 640.0) ** 2
+    alg = 3 * fwd  # training ~ 3 x forward (fwd + dgrad + wgrad)
+    roof = _wgrad_roofline(train_nn, stepper, imgs, all_targets[0]) if (rank == 0 and with_roofline) else None
+    barrier(world, False)
+    out = None
     if rank == 0:
-        print(json.dumps({
+        crit = "point-sampled mask Hungarian set criterion over 7 prediction sets" if bf else "Hungarian set criterion over 7 prediction sets"
+        out = ({
             "metric": f"images/sec @ {S}^2 (train bs={B}/GPU)", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.model} training step: forward (train mode, norm={args.norm}) + Hungarian set criterion over 7 prediction "
-                                   f"sets + backward + gradient all-reduce + fused AdamW/clip, bs={B}/GPU, {S}x{S}, bf16 activations and gradients, "
+            "config": {"workload": f"{args.model} training step: forward (train mode, norm={args.norm}) + {crit} "
+                                   f"+ backward + gradient all-reduce + fused AdamW/clip, bs={B}/GPU, {S}x{S}, bf16 activations and gradients, "
                                    "fp32 master weights; HIP autograd nodes (eager launches, no graph)",
-                       "global_batch": B * world, "parallelism": f"dp{world} (RCCL all-reduce of one flat fp32 gradient buffer, 64 MiB buckets)"},
+                       "global_batch": B * world, "parallelism": f"dp{world} (RCCL all-reduce of one flat fp32 gradient buffer, 64 MiB buckets, "
+                                                                 "segments launched from backward hooks)"},
             "alg_gflop_per_image": round(alg, 1), "frac_of_bf16_mfma_roofline_whole_path": round(value / world * alg * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
-            "final_total_loss": round(total, 4)}))
+            "roofline": roof, "final_total_loss": round(total, 4)})
+    del stepper, model
+    torch.cuda.empty_cache()
+    return out
+
+
+def train_main(args, world, rank, local):
+    out = train_measure(args, world, rank, local)
+    if rank == 0:
+        print(json.dumps(out))
     if world > 1:
         import torch.distributed as dist
 
@@ -314,7 +394,62 @@ def run(args):
 
     if args.train:
         return train_main(args, world, rank, local)
+    out = infer_measure(args, world, rank, local, light=False)
+    if args.default_run and not args.no_other_configs:
+        other_configs(args, world, rank, local, out)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
 
+        dist.destroy_process_group()
+
+
+def other_configs(args, world, rank, local, out):
+    """The other BASELINE.json configs, measured briefly in the same run and nested under `other_configs` of the ONE JSON line (rank 0's
+    dict `out`): config 4 (RT-DETR training step, data-parallel over the same ranks), config 5 (BiSeNetFormer training step at 1024^2),
+    config 3 (MaskFormer inference at 800^2) and BiSeNetFormer inference.  Each leg is the same code as `--train` / `--model ...`
+    with fewer steps and without the per-kernel table.  A watchdog guards the headline: if the legs exceed their budget (or a
+    collective hangs), rank 0 prints the line with what has been measured and every rank exits."""
+    import copy
+    import threading
+
+    legs = {}
+    if rank == 0:
+        out["other_configs"] = legs
+
+    def bail():
+        if rank == 0:
+            legs["watchdog"] = f"extra legs abandoned after {args.other_configs_budget:.0f} s"
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    timer = threading.Timer(args.other_configs_budget + (0 if rank == 0 else 5), bail)
+    timer.daemon = True
+    timer.start()
+    plan = [("train_fai-detr-l-obj365_bs16_640_frozenbn", dict(train=True, model="fai-detr-l-obj365", family="fai_detr", batch=16, size=640, norm="FrozenBN", steps=6, warmup=2)),
+            ("train_bisenetformer-l-ade_bs8_1024_bn", dict(train=True, model="bisenetformer-l-ade", family="bisenetformer", batch=8, size=1024,
+                                                          norm="SyncBN" if world > 1 else "BN", steps=4, warmup=2)),
+            ("infer_fai-mf-l-coco-ins_bs16_800", dict(train=False, model="fai-mf-l-coco-ins", family="fai_mf", batch=16, size=800, steps=10, warmup=3)),
+            ("infer_bisenetformer-l-ade_bs32_640", dict(train=False, model="bisenetformer-l-ade", family="bisenetformer", batch=32, size=640, steps=10, warmup=3))]
+    for name, over in plan:
+        a = copy.copy(args)
+        for k, v in over.items():
+            setattr(a, k, v)
+        try:
+            r = train_measure(a, world, rank, local, with_roofline=False) if a.train else infer_measure(a, world, rank, local, light=True)
+            if rank == 0:
+                legs[name] = {k: r[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config", "alg_gflop_per_image",
+                                                "frac_of_bf16_mfma_roofline_whole_path") if k in r}
+        except Exception as e:   # a failed leg must not take the headline with it
+            if rank == 0:
+                legs[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+    timer.cancel()
+
+
+def infer_measure(args, world, rank, local, light=False):
+    """One inference measurement (the bench contract's timed region); returns rank 0's dict.  ``light``: no CPU baseline, no per-kernel
+    roofline table (the extra legs of the default run)."""
     import torch
 
     from focoos_amd.model import BisenetFormer, FAIDetr, FAIMaskFormer
@@ -325,7 +460,7 @@ def run(args):
     cfg = ModelRegistry.get_model_info(args.model)["config"]
     B = args.batch
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not light:
         cpu = cpu_baseline(args)
     bf = args.family == "bisenetformer"
     mf = args.family == "fai_mf" or bf     # the two mask families share the engine interface (engine_maskdec.py)
@@ -379,7 +514,7 @@ def run(args):
         "alg_gflop_per_image": round(alg, 2),
         "frac_of_bf16_mfma_roofline_whole_path": round(value / world * alg * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
     }
-    if rank == 0:
+    if rank == 0 and not light:
         # ---- roofline of the dominant kernel (live, in-sequence HIP-event timing; world==1 or rank 0 only)
         ms = per_op_timing(eng, pl, args)
         by = {}
@@ -407,7 +542,10 @@ def run(args):
             if hits:
                 n_ = sum(v["launches"] for v in hits)
                 traffic = round(sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in hits) / n_)
-                traffic_src = "profiles/pmc_hbm_latest.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes; bytes per launch, read side x2 per the gfx950 note)"
+                cal = pmc.get("__calibration__")
+                traffic_src = ("profiles/pmc_hbm_latest.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE in separate passes; bytes per launch; "
+                               + (f"counter units calibrated on known-byte kernels in the same passes: {cal['read_bytes_per_count']:.0f} B / FETCH count, "
+                                  f"{cal['write_bytes_per_count']:.0f} B / WRITE count)" if cal else "read side x2 per the gfx950 note, write side uncalibrated)"))
         except Exception:
             pass
         achieved, peak, unit = (tflops, PEAK_BF16_TFLOPS, "TFLOP/s") if bound == "mfma" else (gbs, PEAK_HBM_GBS, "GB/s")
@@ -436,11 +574,10 @@ def run(args):
             with open(args.per_op, "w") as f:
                 for nm, desc, t, tf in names:
                     f.write(f"{t:9.4f} ms  {tf:8.1f} TF/s  {nm}  {desc}\n")
-        print(json.dumps(out))
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.destroy_process_group()
+    barrier(world, False)
+    del pl, eng, model
+    torch.cuda.empty_cache()
+    return out if rank == 0 else None
 
 
 if __name__ == "__main__":

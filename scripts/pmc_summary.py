@@ -26,16 +26,40 @@ def load(path, counter):
     return agg
 
 
-def main(fetch_csv, write_csv, out_md, out_json):
+# known bytes per launch of scripts/pmc_calibrate.py's kernels: (read, write)
+CALIB = {"cast_f32_bf16_kernel": ((128 << 20) * 4, (128 << 20) * 2), "add_rows_kernel": ((128 << 20) * 4, (128 << 20) * 2)}
+
+
+def calibrate(fetch_csv, write_csv):
+    """bytes per counter unit from the known-byte kernels (both agree within a few percent on a healthy box); falls back to the
+    guide's factors (FETCH_SIZE KiB x 2 on gfx950, WRITE_SIZE KiB) when no calibration CSVs are given."""
     f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
+    fr, fw, detail = [], [], {}
+    for k, (rb, wb) in CALIB.items():
+        if k in f and k in w and f[k][0] and w[k][0]:
+            r_unit, w_unit = rb / (f[k][1] / f[k][0]), wb / (w[k][1] / w[k][0])
+            fr.append(r_unit)
+            fw.append(w_unit)
+            detail[k] = {"read_bytes_per_count": r_unit, "write_bytes_per_count": w_unit, "launches": f[k][0]}
+    if not fr:
+        return 2048.0, 1024.0, {}
+    return sum(fr) / len(fr), sum(fw) / len(fw), detail
+
+
+def main(fetch_csv, write_csv, out_md, out_json, calib_fetch=None, calib_write=None):
+    f, w = load(fetch_csv, "FETCH_SIZE"), load(write_csv, "WRITE_SIZE")
+    ru, wu, detail = calibrate(calib_fetch, calib_write) if calib_fetch and calib_write else (2048.0, 1024.0, {})
     res = {}
-    lines = ["# HBM traffic per kernel (rocprofv3 PMC, gfx950-corrected)", "",
-             "FETCH_SIZE x 1024 x 2 (gfx950: counter reports half of wide coalesced reads), WRITE_SIZE x 1024; per launch averages.", "",
+    src = (f"calibrated on known-byte kernels (scripts/pmc_calibrate.py): {ru:.1f} B per FETCH_SIZE count, {wu:.1f} B per WRITE_SIZE count"
+           if detail else "FETCH_SIZE x 1024 x 2 (gfx950: counter reports half of wide coalesced reads), WRITE_SIZE x 1024 (uncalibrated)")
+    lines = ["# HBM traffic per kernel (rocprofv3 PMC)", "", src + "; per launch averages.", "",
              "| kernel | launches | read MB/launch | write MB/launch | total MB/launch |", "|---|---:|---:|---:|---:|"]
+    if detail:
+        res["__calibration__"] = {"read_bytes_per_count": ru, "write_bytes_per_count": wu, "kernels": detail}
     for k in sorted(f, key=lambda k: -(f[k][1] * 2 + w.get(k, [0, 0])[1])):
         n = f[k][0]
-        rb = f[k][1] * 1024 * 2 / n
-        wb = (w[k][1] * 1024 / w[k][0]) if k in w and w[k][0] else 0.0
+        rb = f[k][1] * ru / n
+        wb = (w[k][1] * wu / w[k][0]) if k in w and w[k][0] else 0.0
         res[k] = {"launches": n, "fetch_bytes_per_launch": rb, "write_bytes_per_launch": wb}
         lines.append(f"| `{k[:90]}` | {n} | {rb / 1e6:.2f} | {wb / 1e6:.2f} | {(rb + wb) / 1e6:.2f} |")
     open(out_md, "w").write("\n".join(lines) + "\n")
@@ -44,4 +68,4 @@ def main(fetch_csv, write_csv, out_md, out_json):
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:5])
+    main(*sys.argv[1:7])
