@@ -6,7 +6,7 @@
   FAIMaskFormer             focoos/models/fai_mf/modelling.py:633-725
 
 Same names, argument meaning and error behaviour; the compute is the HIP engine (engine.py).
-``FocoosModel.train`` drives the HIP training step (trainer.py, RT-DETR family); ``.export()`` is out of scope and raises
+``FocoosModel.train`` drives the HIP training step (trainer.py; RT-DETR and BiSeNetFormer families); ``.export()`` is out of scope and raises
 NotImplementedError (loudly — never a silent fallback)."""
 from __future__ import annotations
 

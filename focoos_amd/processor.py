@@ -290,10 +290,47 @@ class MaskFormerProcessor(DETRProcessor):
         """fai_mf/processor.py:60-97 (inference branch): images are batched at their own size; mixed sizes cannot be stacked
         (base_processor.py:294 torch.stack) and are rejected here as well."""
         lst = inputs if isinstance(inputs, list) else [inputs]
+        if len(lst) > 0 and isinstance(lst[0], DatasetEntry):
+            return self._preprocess_mask_entries(lst, device)
         sizes = set(self.get_image_sizes(lst))
         if len(sizes) > 1:
             raise ValueError(f"MaskFormerProcessor does not resize: all images of a batch must share one size, got {sorted(sizes)}")
         return super().preprocess(inputs, device, dtype)
+
+    def _preprocess_mask_entries(self, entries, device: torch.device):
+        """fai_mf/processor.py:60-90 == bisenetformer/processor.py:60-86: a list of DatasetEntry -> (uint8 NHWC batch, [MaskFormerTargets]):
+        per image the classes and the ground-truth masks (``instances.masks``: a [T,h,w] tensor or an object with ``.tensor``) padded to
+        the batch's (h, w).  Targets only in training mode; images must share one size (ImageList padding is not mirrored)."""
+        from .ports import MaskFormerTargets
+
+        imgs = []
+        for e in entries:
+            im = e.image
+            if isinstance(im, np.ndarray):
+                im = torch.from_numpy(np.ascontiguousarray(im))
+            if im.dim() == 3 and im.shape[0] == 3 and im.shape[-1] != 3:
+                im = im.permute(1, 2, 0)
+            imgs.append(im.contiguous())
+        if any(tuple(i.shape) != tuple(imgs[0].shape) for i in imgs):
+            raise ValueError("training batches need equally sized images (resolution-fixing augmentations)")
+        batch = torch.stack(imgs, 0).to(device, non_blocking=True)
+        if batch.dtype != torch.uint8:
+            batch = batch.to(torch.float32)
+        targets = []
+        if self.training:
+            h, w = batch.shape[1:3]
+            for e in entries:
+                inst = e.instances
+                assert inst is not None and inst.has("masks"), "masks are required for training"
+                assert inst.has("classes"), "classes are required for training"
+                gm = inst.masks.tensor if hasattr(inst.masks, "tensor") else inst.masks
+                gm = torch.as_tensor(gm).to(device)
+                if len(gm) > 0 and tuple(gm.shape[1:]) != (h, w):
+                    pad = torch.zeros(gm.shape[0], h, w, dtype=gm.dtype, device=device)
+                    pad[:, : gm.shape[1], : gm.shape[2]] = gm
+                    gm = pad
+                targets.append(MaskFormerTargets(labels=torch.as_tensor(inst.classes).to(device), masks=gm))
+        return batch, targets
 
     def postprocess(self, output, inputs: ImageInput, class_names: Sequence[str] = (), top_k: Optional[int] = None,
                     threshold: Optional[float] = None, use_mask_score: Optional[bool] = None,

@@ -32,20 +32,25 @@ def _dist():
 
 
 def run_train(args: TrainerArgs, data_train, data_val, model, processor, model_info, hub=None) -> Dict[str, float]:
-    """Per-rank training body.  ``model`` is the engine-backed FAIDetr mirror (its state_dict seeds the trainable graph and receives the
-    result); ``data_train[i]`` is a DatasetEntry.  Returns the last step's losses (floats) on every rank."""
+    """Per-rank training body.  ``model`` is the engine-backed FAIDetr / BisenetFormer mirror (its state_dict seeds the trainable graph and
+    receives the result); ``data_train[i]`` is a DatasetEntry.  Returns the last step's losses (floats) on every rank."""
     from .train_data import TrainingSampler, per_rank_batch_size, rank_seed
     from .train_detr import FAIDetrTrainable, TrainStep
 
-    if getattr(model, "family", "fai_detr") != "fai_detr":
-        raise NotImplementedError("training is built for the RT-DETR family; the mask families' backward (SURVEY A16) is not")
+    family = getattr(model, "family", "fai_detr")
+    if family == "fai_detr":
+        trainable = FAIDetrTrainable
+    elif family == "bisenetformer":
+        from .train_bf import BisenetFormerTrainable as trainable
+    else:
+        raise NotImplementedError(f"training graphs exist for the RT-DETR and BiSeNetFormer families (BASELINE configs 4 / 5), not for {family!r}")
     rank, world = _dist()
     local = int(os.environ.get("LOCAL_RANK", rank))
     dev = torch.device("cuda", local if world > 1 else (model.device.index or 0))
     torch.cuda.set_device(dev)
     torch.manual_seed(rank_seed(args.seed, rank))
     norm = "FrozenBN" if args.freeze_bn else ("SyncBN" if world > 1 else "BN")
-    net = FAIDetrTrainable(model.config, norm=norm).to(dev)
+    net = trainable(model.config, norm=norm).to(dev)
     net.load_state_dict(model.state_dict(), strict=True)
     if args.init_checkpoint:
         state = torch.load(args.init_checkpoint, map_location="cpu", weights_only=True)

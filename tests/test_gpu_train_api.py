@@ -92,3 +92,52 @@ def test_eval_postprocess_matches_reference_arithmetic():
         assert inst.image_size == (h, w) and len(inst) == int(keep.sum())
         assert torch.equal(inst.classes.cpu(), lab[keep]) and torch.equal(inst.scores.cpu(), sc[keep])
         assert torch.allclose(inst.boxes.tensor.cpu(), bx[keep], atol=1e-4)
+
+
+def _mask_entries(n, size, nc, seed=0):
+    """DatasetEntry list for the mask families: CHW uint8 image + Instances(classes, masks = [T, H, W] bool rectangles)."""
+    from focoos_amd.ports import DatasetEntry, Instances
+    from focoos_amd.synth import synth_image_structured
+
+    rs = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        t = rs.randint(1, 5)
+        m = np.zeros((t, size, size), bool)
+        for j in range(t):
+            y0, x0 = rs.randint(0, size // 2), rs.randint(0, size // 2)
+            m[j, y0:y0 + rs.randint(16, size // 2), x0:x0 + rs.randint(16, size // 2)] = True
+        img = torch.from_numpy(synth_image_structured(50 + i, size, size)).permute(2, 0, 1).contiguous()
+        out.append(DatasetEntry(image=img, height=size, width=size,
+                                instances=Instances((size, size), classes=torch.from_numpy(rs.randint(0, nc, t)), masks=torch.from_numpy(m))))
+    return out
+
+
+def test_bisenetformer_model_train_runs_steps_and_reloads_weights(tmp_path):
+    """BASELINE config 5 through the public surface: ModelManager.get("bisenetformer-l-ade").train(args, data): the mask-family
+    branch of the processor's training preprocess, train_bf.BisenetFormerTrainable under TrainStep (live BatchNorm: freeze_bn=False),
+    artifacts with the reference's key order, weights reloaded into the inference engine."""
+    import json
+
+    from focoos_amd.model import ModelManager
+    from focoos_amd.ports import TrainerArgs
+
+    fm = ModelManager.get("bisenetformer-l-ade", seed=4, criterion_num_points=1024)
+    nc = fm.model.num_classes
+    data = _mask_entries(8, 256, nc)
+    before = {k: v.clone() for k, v in fm.model.state_dict().items()}
+    args = TrainerArgs(run_name="bf_run", output_dir=str(tmp_path), num_gpus=1, max_iters=3, batch_size=4, learning_rate=1e-4, freeze_bn=False,
+                       scheduler="FIXED", log_period=1, seed=3)
+    out = fm.train(args, data, data)
+    assert out is fm and not fm.model.training
+    folder = os.path.join(str(tmp_path), "bf_run")
+    ck = torch.load(os.path.join(folder, "model_final.pth"), map_location="cpu", weights_only=True)
+    assert list(ck["model"]) == list(before)
+    after = fm.model.state_dict()
+    changed = sum(not torch.equal(before[k], after[k]) for k in before if before[k].is_floating_point())
+    assert changed > 300                                           # weights, BatchNorm affine and running statistics moved
+    assert int(after["pixel_decoder.backbone.features.0.bn.num_batches_tracked"]) == int(before["pixel_decoder.backbone.features.0.bn.num_batches_tracked"]) + 3
+    info = json.load(open(os.path.join(folder, "model_info.json")))
+    assert len(info["final_losses"]) == 21 and all(np.isfinite(v) for v in info["final_losses"].values())
+    dets = fm.infer_batch([np.asarray(e.image.permute(1, 2, 0)) for e in data[:2]], threshold=0.01)
+    assert len(dets) == 2
