@@ -115,3 +115,31 @@ def test_register_installs_engine_processors_and_training_forward_contract():
         model.train()
         with pytest.raises(FocoosAmdError):
             model(torch.zeros(1, 3, 64, 64), [])
+
+
+def test_bisenetformer_adapter_shares_every_parameter_with_the_training_graph(monkeypatch):
+    """The BiSeNetFormer adapter's training forward runs train_bf.BisenetFormerTrainable over the reference module's OWN tensors: every
+    parameter and buffer of the HIP graph is matched by name and shape in the REAL reference module (share_parameters raises otherwise).
+    Structure only - built here without a GPU by stubbing the library handle; the numerics are tests/test_gpu_train_bf.py."""
+    ref_import.install()
+    import torch
+    from focoos.model_manager import ConfigManager, ModelManager
+    from focoos.ports import ModelFamily
+
+    import focoos_amd.integration as fx
+    from focoos_amd import _lib
+    from focoos_amd.registry import ModelRegistry
+
+    fx.register()
+    cfgd = ModelRegistry.get_model_info("bisenetformer-l-ade")["config"]
+    ref = ModelManager._models_family_map[ModelFamily.BISENETFORMER.value]()(ConfigManager.from_dict(ModelFamily.BISENETFORMER, {k: v for k, v in cfgd.items() if k != "resolution"}))
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(_lib, "load", lambda: None)
+    from focoos_amd.train_bf import BisenetFormerTrainable
+
+    net = BisenetFormerTrainable(cfgd, norm="BN")
+    n = fx.share_parameters(net, ref)
+    assert n == len(list(ref.state_dict())) == len(list(net.state_dict()))
+    refp = dict(ref.named_parameters())
+    assert all(p is refp[k] for k, p in net.named_parameters())
+    assert net.pixel_decoder.backbone.features[2].avd_layer._norm_h.running_mean is dict(ref.named_buffers())["pixel_decoder.backbone.features.2.avd_layer.1.running_mean"]
