@@ -96,7 +96,7 @@ SIGNATURES = {
     "fx_conv2d_wgrad_bias_nhwc_bf16": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "fx_point_sample_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "fx_mask_match_cost_f32": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, C.c_float, C.c_float, _i, _vp, _vp],
-    "fx_mask_set_loss_workspace_bytes": [_i, _i, _i],
+    "fx_mask_set_loss_workspace_bytes": [_i, _i, _i, _i],
     "fx_mask_set_loss_f32": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, C.c_float, C.c_float,
                              C.c_float, C.c_float, C.c_float, _vp, C.c_size_t, _vp, _vp],
     "fx_dwconv3x3s2_nhwc_bf16": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

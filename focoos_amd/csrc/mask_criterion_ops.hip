@@ -189,20 +189,18 @@ __device__ __forceinline__ void ps_scatter(float* g, int H, int W, float cx, flo
   if (yb && xb) unsafeAtomicAdd(g + (int64_t)(y0 + 1) * W + x0 + 1, v * (w * n));
 }
 
-// BWD = false: the sums of one matched pair -> rows[n].  BWD = true (same selection, recomputed): d loss / d mask logit of every
-// selected point, g_bce * (sigmoid(x) - t) + g_dice * s (1 - s) * d dice / d s with dice = 1 - (2 st + 1) / (ss + tt + 1) from the
-// forward's rows[n], scattered to the four taps of the point in the pair's [h,w] plane of dmasks (zero-initialised by the caller;
-// the sample coordinates carry no gradient: the reference draws / selects them under no_grad, loss.py:487-497).
+// Forward: one workgroup per matched pair.  The n_over candidate logits are sampled ONCE into the workspace (xs; 150 KB per pair at the
+// registry size: L2-resident), the four radix passes and the selection read them back with coalesced loads, and the selection is
+// recorded (sel[i] = 1) so that the backward neither re-samples the candidates nor repeats the select.
 #define MPL_THREADS 1024
-template <typename TT, bool BWD>
+template <typename TT>
 __global__ __launch_bounds__(MPL_THREADS) void mask_point_loss_kernel(const float* __restrict__ pred_masks, int h, int w, const TT* __restrict__ tgt_masks,
                                                                       int H, int W, const int32_t* __restrict__ tgt_offsets, int B, int Q,
                                                                       const int32_t* __restrict__ pred_idx, const int32_t* __restrict__ tgt_idx,
                                                                       const float* __restrict__ rand_over, int n_over,
                                                                       const float* __restrict__ rand_extra, int n_extra, int k_imp,
                                                                       double* __restrict__ rows /*[N][4]: bce sum, sum s*t, sum s, sum t*/,
-                                                                      float c_bce, float c_dice, const float* __restrict__ g3,
-                                                                      float* __restrict__ dmasks) {
+                                                                      float* __restrict__ xs_all /*[N][n_over]*/, uint8_t* __restrict__ sel_all /*[N][n_over]*/) {
   __shared__ unsigned hist[256];
   __shared__ unsigned s_prefix, s_need;
   __shared__ unsigned s_scan[MPL_THREADS];
@@ -213,6 +211,12 @@ __global__ __launch_bounds__(MPL_THREADS) void mask_point_loss_kernel(const floa
   const float* pm = pred_masks + ((int64_t)b * Q + pred_idx[n]) * h * w;
   const TT* tm = tgt_masks + (int64_t)(tgt_offsets[b] + tgt_idx[n]) * H * W;
   const float* ro = rand_over + (int64_t)n * n_over * 2;
+  float* xs = xs_all + (int64_t)n * n_over;
+  uint8_t* sel = sel_all + (int64_t)n * n_over;
+  if (k_imp > 0) {
+    for (int i = tid; i < n_over; i += MPL_THREADS) xs[i] = ps_sample(pm, h, w, ro[2 * i], ro[2 * i + 1]);
+    __syncthreads();   // the workgroup reads back its own global writes (same CU: L1 write-through + barrier)
+  }
   // ---- radix select: key of the k_imp-th smallest |x| (prefix), and how many keys equal to it are needed
   unsigned prefix = 0, need = (unsigned)k_imp;
   if (k_imp > 0) {
@@ -222,7 +226,7 @@ __global__ __launch_bounds__(MPL_THREADS) void mask_point_loss_kernel(const floa
       __syncthreads();
       const unsigned hi_mask = pass == 0 ? 0u : (0xffffffffu << (shift + 8));
       for (int i = tid; i < n_over; i += MPL_THREADS) {
-        const unsigned key = __float_as_uint(fabsf(ps_sample(pm, h, w, ro[2 * i], ro[2 * i + 1])));
+        const unsigned key = __float_as_uint(fabsf(xs[i]));
         if ((key & hi_mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
       }
       __syncthreads();
@@ -247,8 +251,7 @@ __global__ __launch_bounds__(MPL_THREADS) void mask_point_loss_kernel(const floa
   const int i0 = tid * chunk, i1 = min(n_over, i0 + chunk);
   unsigned ties = 0;
   if (k_imp > 0)
-    for (int i = i0; i < i1; ++i)
-      ties += __float_as_uint(fabsf(ps_sample(pm, h, w, ro[2 * i], ro[2 * i + 1]))) == prefix;
+    for (int i = i0; i < i1; ++i) ties += __float_as_uint(fabsf(xs[i])) == prefix;
   s_scan[tid] = ties;
   __syncthreads();
   for (int o = 1; o < MPL_THREADS; o <<= 1) {   // inclusive Hillis-Steele scan
@@ -258,43 +261,27 @@ __global__ __launch_bounds__(MPL_THREADS) void mask_point_loss_kernel(const floa
     __syncthreads();
   }
   unsigned tie_rank = s_scan[tid] - ties;   // ties before this thread's range
-  float dice_a = 0.0f, dice_b = 0.0f;   // d dice / d s_p = dice_a * t_p + dice_b
-  float g_bce = 0.0f, g_dice = 0.0f;    // upstream gradients of loss_mask / loss_dice times their normalisations
-  float* gplane = nullptr;
-  if (BWD) {
-    g_bce = g3[1] * c_bce;
-    g_dice = g3[2] * c_dice;
-    const double ST = rows[(int64_t)n * 4 + 1], D = rows[(int64_t)n * 4 + 2] + rows[(int64_t)n * 4 + 3] + 1.0;
-    dice_a = (float)(-2.0 / D);
-    dice_b = (float)((2.0 * ST + 1.0) / (D * D));
-    gplane = dmasks + ((int64_t)b * Q + pred_idx[n]) * h * w;
-  }
-  auto add_point = [&](float x, float t, float cx, float cy) {
+  auto add_point = [&](float x, float t) {
     const float s = 1.0f / (1.0f + expf(-x));
-    if (BWD) {
-      ps_scatter(gplane, h, w, cx, cy, g_bce * (s - t) + g_dice * (s * (1.0f - s)) * (dice_a * t + dice_b));
-    } else {
-      bce += (double)(fmaxf(x, 0.0f) - x * t + log1pf(expf(-fabsf(x))));
-      st += (double)(s * t);
-      ss += (double)s;
-      tt += (double)t;
-    }
+    bce += (double)(fmaxf(x, 0.0f) - x * t + log1pf(expf(-fabsf(x))));
+    st += (double)(s * t);
+    ss += (double)s;
+    tt += (double)t;
   };
   if (k_imp > 0)
     for (int i = i0; i < i1; ++i) {
-      const float cx = ro[2 * i], cy = ro[2 * i + 1];
-      const float x = ps_sample(pm, h, w, cx, cy);
+      const float x = xs[i];
       const unsigned key = __float_as_uint(fabsf(x));
       bool take = key < prefix;
       if (key == prefix) take = tie_rank++ < need;
-      if (take) add_point(x, ps_sample(tm, H, W, cx, cy), cx, cy);
+      sel[i] = take ? 1 : 0;
+      if (take) add_point(x, ps_sample(tm, H, W, ro[2 * i], ro[2 * i + 1]));
     }
   const float* re = rand_extra + (int64_t)n * n_extra * 2;
   for (int i = tid; i < n_extra; i += MPL_THREADS) {
     const float cx = re[2 * i], cy = re[2 * i + 1];
-    add_point(ps_sample(pm, h, w, cx, cy), ps_sample(tm, H, W, cx, cy), cx, cy);
+    add_point(ps_sample(pm, h, w, cx, cy), ps_sample(tm, H, W, cx, cy));
   }
-  if (BWD) return;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     bce += __shfl_xor(bce, o, 64); st += __shfl_xor(st, o, 64); ss += __shfl_xor(ss, o, 64); tt += __shfl_xor(tt, o, 64);
@@ -306,6 +293,50 @@ __global__ __launch_bounds__(MPL_THREADS) void mask_point_loss_kernel(const floa
     double a = 0.0;
     for (int i = 0; i < MPL_THREADS / 64; ++i) a += red[tid][i];
     rows[(int64_t)n * 4 + tid] = a;
+  }
+}
+
+// Backward: d loss / d mask logit of every selected point, g_bce * (sigmoid(x) - t) + g_dice * s (1 - s) * d dice / d s with
+// dice = 1 - (2 st + 1) / (ss + tt + 1) from the forward's rows[n], scattered to the four taps of the point in the pair's [h,w] plane of
+// dmasks (zero-initialised by the caller; the sample coordinates carry no gradient: the reference draws / selects them under no_grad,
+// loss.py:487-497).  blockIdx.y splits a pair's points over several workgroups (the forward left xs / sel in the workspace).
+__global__ __launch_bounds__(256) void mask_point_loss_bwd_kernel(const float* __restrict__ pred_masks, int h, int w, const void* __restrict__ tgt_masks,
+                                                                  int tgt_is_u8, int H, int W, const int32_t* __restrict__ tgt_offsets, int B, int Q,
+                                                                  const int32_t* __restrict__ pred_idx, const int32_t* __restrict__ tgt_idx,
+                                                                  const float* __restrict__ rand_over, int n_over,
+                                                                  const float* __restrict__ rand_extra, int n_extra, int k_imp,
+                                                                  const double* __restrict__ rows, const float* __restrict__ xs_all,
+                                                                  const uint8_t* __restrict__ sel_all, float c_bce, float c_dice,
+                                                                  const float* __restrict__ g3, float* __restrict__ dmasks) {
+  const int n = blockIdx.x;
+  int b = 0;
+  while (b + 1 < B && tgt_offsets[b + 1] <= n) ++b;
+  const int q = pred_idx[n];
+  const float* pm = pred_masks + ((int64_t)b * Q + q) * h * w;
+  const int64_t toff = (int64_t)(tgt_offsets[b] + tgt_idx[n]) * H * W;
+  const uint8_t* tm8 = reinterpret_cast<const uint8_t*>(tgt_masks) + toff;
+  const float* tmf = reinterpret_cast<const float*>(tgt_masks) + toff;
+  float* gplane = dmasks + ((int64_t)b * Q + q) * h * w;
+  const double ST = rows[(int64_t)n * 4 + 1], D = rows[(int64_t)n * 4 + 2] + rows[(int64_t)n * 4 + 3] + 1.0;
+  const float dice_a = (float)(-2.0 / D), dice_b = (float)((2.0 * ST + 1.0) / (D * D));   // d dice / d s_p = dice_a * t_p + dice_b
+  const float g_bce = g3[1] * c_bce, g_dice = g3[2] * c_dice;
+  auto point = [&](float x, float cx, float cy) {
+    const float t = tgt_is_u8 ? ps_sample(tm8, H, W, cx, cy) : ps_sample(tmf, H, W, cx, cy);
+    const float s = 1.0f / (1.0f + expf(-x));
+    ps_scatter(gplane, h, w, cx, cy, g_bce * (s - t) + g_dice * (s * (1.0f - s)) * (dice_a * t + dice_b));
+  };
+  const int stride = gridDim.y * 256, t0 = blockIdx.y * 256 + threadIdx.x;
+  if (k_imp > 0) {
+    const float* ro = rand_over + (int64_t)n * n_over * 2;
+    const float* xs = xs_all + (int64_t)n * n_over;
+    const uint8_t* sel = sel_all + (int64_t)n * n_over;
+    for (int i = t0; i < n_over; i += stride)
+      if (sel[i]) point(xs[i], ro[2 * i], ro[2 * i + 1]);
+  }
+  const float* re = rand_extra + (int64_t)n * n_extra * 2;
+  for (int i = t0; i < n_extra; i += stride) {
+    const float cx = re[2 * i], cy = re[2 * i + 1];
+    point(ps_sample(pm, h, w, cx, cy), cx, cy);
   }
 }
 
@@ -334,9 +365,11 @@ __global__ __launch_bounds__(256) void mask_loss_final_kernel(const double* __re
   }
 }
 
-extern "C" size_t fx_mask_set_loss_workspace_bytes(int B, int Q, int sum_T) {
-  if (B <= 0 || Q <= 0 || sum_T < 0) return 0;
-  return ((size_t)B * Q * 2 + (size_t)sum_T * 4 + 1) * sizeof(double);   // CE partials | pair sums | sum of the CE class weights
+// workspace: CE partials f64 [B*Q][2] | pair sums f64 [sum_T][4] | sum of the CE class weights f64 | candidate logits f32 [sum_T][n_over] |
+// selection flags u8 [sum_T][n_over]
+extern "C" size_t fx_mask_set_loss_workspace_bytes(int B, int Q, int sum_T, int n_over) {
+  if (B <= 0 || Q <= 0 || sum_T < 0 || n_over < 0) return 0;
+  return ((size_t)B * Q * 2 + (size_t)sum_T * 4 + 1) * sizeof(double) + (size_t)sum_T * n_over * 5 + 16;
 }
 
 extern "C" int fx_mask_set_loss_f32(const float* logits, int ldl, const float* pred_masks, int h, int w, const void* tgt_masks, int tgt_is_u8, int H,
@@ -347,21 +380,21 @@ extern "C" int fx_mask_set_loss_f32(const float* logits, int ldl, const float* p
   FX_CHECK_ARG(logits && pred_masks && tgt_offsets && workspace && out3 && B > 0 && Q > 0 && K > 0 && ldl >= K + 1 && h > 0 && w > 0 && H > 0 && W > 0);
   FX_CHECK_ARG(sum_T >= 0 && num_points > 0 && n_extra >= 0 && n_extra <= num_points && n_over >= num_points - n_extra && num_masks > 0.0f);
   FX_CHECK_ARG(sum_T == 0 || (tgt_masks && tgt_labels && pred_idx && tgt_idx && (n_extra == 0 || rand_extra) && (num_points == n_extra || rand_over)));
-  FX_CHECK_ARG(workspace_bytes >= fx_mask_set_loss_workspace_bytes(B, Q, sum_T) && ((uintptr_t)workspace % 8) == 0);
+  FX_CHECK_ARG(workspace_bytes >= fx_mask_set_loss_workspace_bytes(B, Q, sum_T, n_over) && ((uintptr_t)workspace % 8) == 0);
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   double* ce_partial = reinterpret_cast<double*>(workspace);
   double* rows = ce_partial + (size_t)B * Q * 2;
   hipLaunchKernelGGL(mask_label_ce_kernel, dim3((B * Q + 3) / 4), dim3(256), 0, stream, logits, ldl, tgt_labels, tgt_offsets, pred_idx, tgt_idx, B * Q, Q, K, eos_coef,
                      ce_partial);
+  float* xs = reinterpret_cast<float*>(rows + (size_t)sum_T * 4 + 1);
+  uint8_t* sel = reinterpret_cast<uint8_t*>(xs + (size_t)sum_T * n_over);
   if (sum_T > 0) {
     if (tgt_is_u8)
-      hipLaunchKernelGGL((mask_point_loss_kernel<uint8_t, false>), dim3(sum_T), dim3(MPL_THREADS), 0, stream, pred_masks, h, w, (const uint8_t*)tgt_masks,
-                         H, W, tgt_offsets, B, Q, pred_idx, tgt_idx, rand_over, n_over, rand_extra, n_extra, num_points - n_extra, rows, 0.0f, 0.0f,
-                         (const float*)nullptr, (float*)nullptr);
+      hipLaunchKernelGGL(mask_point_loss_kernel<uint8_t>, dim3(sum_T), dim3(MPL_THREADS), 0, stream, pred_masks, h, w, (const uint8_t*)tgt_masks, H, W,
+                         tgt_offsets, B, Q, pred_idx, tgt_idx, rand_over, n_over, rand_extra, n_extra, num_points - n_extra, rows, xs, sel);
     else
-      hipLaunchKernelGGL((mask_point_loss_kernel<float, false>), dim3(sum_T), dim3(MPL_THREADS), 0, stream, pred_masks, h, w, (const float*)tgt_masks, H,
-                         W, tgt_offsets, B, Q, pred_idx, tgt_idx, rand_over, n_over, rand_extra, n_extra, num_points - n_extra, rows, 0.0f, 0.0f,
-                         (const float*)nullptr, (float*)nullptr);
+      hipLaunchKernelGGL(mask_point_loss_kernel<float>, dim3(sum_T), dim3(MPL_THREADS), 0, stream, pred_masks, h, w, (const float*)tgt_masks, H, W,
+                         tgt_offsets, B, Q, pred_idx, tgt_idx, rand_over, n_over, rand_extra, n_extra, num_points - n_extra, rows, xs, sel);
   }
   hipLaunchKernelGGL(mask_loss_final_kernel, dim3(1), dim3(256), 0, stream, ce_partial, B * Q, rows, sum_T, num_points, num_masks, w_ce, w_mask, w_dice,
                      out3, rows + (size_t)sum_T * 4);
@@ -411,7 +444,7 @@ extern "C" int fx_mask_set_loss_bwd_f32(const float* logits, int ldl, const floa
   FX_CHECK_ARG(ldl >= K + 1 && lddl >= K + 1 && h > 0 && w > 0 && H > 0 && W > 0 && sum_T >= 0 && num_points > 0 && n_extra >= 0 && n_extra <= num_points);
   FX_CHECK_ARG(n_over >= num_points - n_extra && num_masks > 0.0f);
   FX_CHECK_ARG(sum_T == 0 || (tgt_masks && tgt_labels && pred_idx && tgt_idx && (n_extra == 0 || rand_extra) && (num_points == n_extra || rand_over)));
-  FX_CHECK_ARG(workspace_bytes >= fx_mask_set_loss_workspace_bytes(B, Q, sum_T) && ((uintptr_t)workspace % 8) == 0);
+  FX_CHECK_ARG(workspace_bytes >= fx_mask_set_loss_workspace_bytes(B, Q, sum_T, n_over) && ((uintptr_t)workspace % 8) == 0);
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const double* ce_partial = reinterpret_cast<const double*>(workspace);
   double* rows = const_cast<double*>(ce_partial) + (size_t)B * Q * 2;
@@ -419,14 +452,11 @@ extern "C" int fx_mask_set_loss_bwd_f32(const float* logits, int ldl, const floa
                      K, eos_coef, rows + (size_t)sum_T * 4, grad3, w_ce, dlogits, lddl);
   if (sum_T > 0) {
     const float c_bce = w_mask / (num_masks * (float)num_points), c_dice = w_dice / num_masks;
-    if (tgt_is_u8)
-      hipLaunchKernelGGL((mask_point_loss_kernel<uint8_t, true>), dim3(sum_T), dim3(MPL_THREADS), 0, stream, pred_masks, h, w, (const uint8_t*)tgt_masks,
-                         H, W, tgt_offsets, B, Q, pred_idx, tgt_idx, rand_over, n_over, rand_extra, n_extra, num_points - n_extra, rows, c_bce, c_dice,
-                         grad3, dmasks);
-    else
-      hipLaunchKernelGGL((mask_point_loss_kernel<float, true>), dim3(sum_T), dim3(MPL_THREADS), 0, stream, pred_masks, h, w, (const float*)tgt_masks, H, W,
-                         tgt_offsets, B, Q, pred_idx, tgt_idx, rand_over, n_over, rand_extra, n_extra, num_points - n_extra, rows, c_bce, c_dice,
-                         grad3, dmasks);
+    const float* xs = reinterpret_cast<const float*>(rows + (size_t)sum_T * 4 + 1);
+    const uint8_t* sel = reinterpret_cast<const uint8_t*>(xs + (size_t)sum_T * n_over);
+    const int split = sum_T >= 256 ? 2 : (sum_T >= 64 ? 8 : 16);   // >= 512 workgroups
+    hipLaunchKernelGGL(mask_point_loss_bwd_kernel, dim3(sum_T, split), dim3(256), 0, stream, pred_masks, h, w, tgt_masks, tgt_is_u8, H, W, tgt_offsets, B, Q,
+                       pred_idx, tgt_idx, rand_over, n_over, rand_extra, n_extra, num_points - n_extra, rows, xs, sel, c_bce, c_dice, grad3, dmasks);
   }
   return fx_launch_status();
 }

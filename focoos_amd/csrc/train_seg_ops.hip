@@ -109,9 +109,9 @@ extern "C" int fx_dwconv3x3s2_bwd_nhwc_bf16(const void* dy, int lddy, const void
   }
   if (dw) {
     const int64_t P = (int64_t)B * Ho * Wo;
-    int splits = (int)((P + 2047) / 2048);   // >= 64 pixels per pixel lane and workgroup
+    int splits = (int)((P + 511) / 512);   // >= 16 pixels per pixel lane and workgroup; the reduction tail is 9 atomics per channel and workgroup
     const int cgs = (C + 63) / 64;
-    if (splits * cgs > 2048) splits = 2048 / cgs;
+    if (splits * cgs > 1024) splits = 1024 / cgs;
     if (splits < 1) splits = 1;
     hipLaunchKernelGGL(dwconv3x3s2_wgrad_kernel, dim3(cgs, splits), dim3(256), 0, stream, (const bf16_t*)dy, lddy, (const bf16_t*)x, ldx, dw, B, H, W, Ho,
                        Wo, C);

@@ -118,7 +118,7 @@ class _MaskSetLossFn(torch.autograd.Function):
         r_over = crit.rand(max(tg.n, 1), n_over, 2, device=dev).float().contiguous() if tg.n else torch.zeros(1, n_over, 2, device=dev)
         r_extra = (crit.rand(max(tg.n, 1), n_extra, 2, device=dev).float().contiguous() if (tg.n and n_extra > 0)
                    else torch.zeros(1, max(n_extra, 1), 2, device=dev))
-        ws = torch.empty(lib.fx_mask_set_loss_workspace_bytes(B, Q, tg.n) // 8 + 1, dtype=torch.float64, device=dev)
+        ws = torch.empty(lib.fx_mask_set_loss_workspace_bytes(B, Q, tg.n, n_over) // 8 + 1, dtype=torch.float64, device=dev)
         out3 = torch.empty(3, dtype=torch.float32, device=dev)
         wd = crit.weight_dict
         args = (logits.data_ptr(), K1, pm.data_ptr(), h, w, tg.masks.data_ptr(), tg.is_u8, tg.H, tg.W, tg.labels.data_ptr(), tg.offsets.data_ptr(), tg.n,

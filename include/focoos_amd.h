@@ -305,7 +305,7 @@ int fx_mask_match_cost_f32(const float* logits, int ldl, const float* pred_pts, 
  * inputs: rand_over f32 [sumT][n_over][2] (the oversampled candidates; the num_points - n_extra with the smallest |logit| are kept),
  * rand_extra f32 [sumT][n_extra][2].  num_masks = the clamped, world-averaged target count of :557-561.  workspace:
  * fx_mask_set_loss_workspace_bytes(), 8-byte aligned.  Deterministic (fixed-order float64 reductions). */
-size_t fx_mask_set_loss_workspace_bytes(int B, int Q, int sum_T);
+size_t fx_mask_set_loss_workspace_bytes(int B, int Q, int sum_T, int n_over);
 int fx_mask_set_loss_f32(const float* logits, int ldl, const float* pred_masks, int h, int w, const void* tgt_masks, int tgt_is_u8, int H, int W,
                          const int32_t* tgt_labels, const int32_t* tgt_offsets, int sum_T, const int32_t* pred_idx, const int32_t* tgt_idx,
                          const float* rand_over, int n_over, const float* rand_extra, int n_extra, int num_points, int B, int Q, int K,
