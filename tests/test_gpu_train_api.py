@@ -141,3 +141,85 @@ def test_bisenetformer_model_train_runs_steps_and_reloads_weights(tmp_path):
     assert len(info["final_losses"]) == 21 and all(np.isfinite(v) for v in info["final_losses"].values())
     dets = fm.infer_batch([np.asarray(e.image.permute(1, 2, 0)) for e in data[:2]], threshold=0.01)
     assert len(dets) == 2
+
+
+class _StubReferenceModule:
+    """What integration.share_parameters needs from the reference module - named_parameters() / named_buffers() with the reference's
+    names - holding its OWN tensors, like the real FAIDetr / BisenetFormer nn.Module that an external trainer (TrainerLoop, DDP, EMA)
+    owns.  The reference package does not exist on the GPU box; the name-for-name match against the REAL modules is asserted on CPU
+    (tests/test_integration_reference.py)."""
+
+    def __init__(self, cfg, family, seed, frozen_bn):
+        from focoos_amd.state_spec import state_spec
+        from focoos_amd.synth import synth_state_dict
+
+        sd = synth_state_dict(cfg, seed, family=family)
+        self.params, self.buffers = {}, {}
+        for k, (_, kind) in state_spec(cfg, family).items():
+            if kind in ("bn_mean", "bn_var", "bn_nbt", "buf"):
+                self.buffers[k] = sd[k].to(DEV)
+            else:
+                self.params[k] = torch.nn.Parameter(sd[k].to(DEV), requires_grad=not (frozen_bn and kind in ("bn_w", "bn_b")) and "mask_features" not in k)
+
+    def named_parameters(self):
+        return self.params.items()
+
+    def named_buffers(self):
+        return self.buffers.items()
+
+
+@pytest.mark.parametrize("family", ["fai_detr", "bisenetformer"])
+def test_adapter_training_mechanics_with_external_optimizer(family):
+    """Seam B2 in training mode on the GPU: the HIP autograd graph runs over tensors OWNED by another module (share_parameters), gradients
+    land in that module's ``.grad`` fields, and an external torch optimizer - the reference's TrainerLoop keeps its own - steps them;
+    the engine notices the change (WEIGHTS_EPOCH) and the next forward uses the new weights."""
+    from focoos_amd import train_nn
+    from focoos_amd.integration import share_parameters
+    from focoos_amd.ports import DETRTargets, MaskFormerTargets
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.synth import synth_image_structured
+
+    if family == "fai_detr":
+        from focoos_amd.train_detr import FAIDetrTrainable as Net
+
+        cfg, norm = ModelRegistry.get_model_info("fai-detr-l-coco")["config"], "FrozenBN"
+    else:
+        from focoos_amd.train_bf import BisenetFormerTrainable as Net
+
+        cfg, norm = dict(ModelRegistry.get_model_info("bisenetformer-l-ade")["config"], criterion_num_points=1024), "BN"
+    ref = _StubReferenceModule(cfg, family, 8, norm == "FrozenBN")
+    net = Net(cfg, norm=norm).to(DEV)
+    n = share_parameters(net, ref)
+    assert n == len(ref.params) + len(ref.buffers)
+    assert all(p is ref.params[k] for k, p in net.named_parameters())
+    net.train()
+    opt = torch.optim.AdamW([p for p in ref.params.values() if p.requires_grad], lr=1e-4)
+    rs = np.random.RandomState(0)
+    x = torch.from_numpy(np.stack([synth_image_structured(70 + i, 128, 160) for i in range(4)])).to(DEV)
+    if family == "fai_detr":
+        tg = [DETRTargets(labels=torch.from_numpy(rs.randint(0, 80, (3,))).to(DEV),
+                          boxes=torch.from_numpy(np.concatenate([rs.uniform(0.3, 0.7, (3, 2)), rs.uniform(0.1, 0.3, (3, 2))], -1).astype(np.float32)).to(DEV)) for _ in range(4)]
+    else:
+        tg = []
+        for _ in range(4):
+            m = np.zeros((2, 128, 160), bool)
+            m[0, 10:70, 20:90] = True
+            m[1, 60:120, 80:150] = True
+            tg.append(MaskFormerTargets(labels=torch.from_numpy(rs.randint(0, 150, (2,))).to(DEV), masks=torch.from_numpy(m).to(DEV)))
+    before = {k: p.detach().clone() for k, p in ref.params.items() if p.requires_grad}
+    totals = []
+    for _ in range(3):
+        train_nn.WEIGHTS_EPOCH[0] += 1   # what the adapters do before every training forward
+        losses = net(x, tg)
+        total = sum(losses.values())
+        opt.zero_grad(set_to_none=True)
+        total.backward()
+        missing = [k for k, p in ref.params.items() if p.requires_grad and p.grad is None]
+        assert not missing, missing[:5]
+        opt.step()
+        totals.append(float(total))
+    torch.cuda.synchronize()
+    assert all(np.isfinite(t) for t in totals)
+    moved = sum(not torch.equal(before[k], ref.params[k].detach()) for k in before)
+    assert moved == len(before)
+    assert totals[-1] != totals[0]     # the forward sees the stepped weights (packed bf16 images rebuilt)
