@@ -161,15 +161,44 @@ def make_mf_engine_class():
                 self._fx_engine.load_state_dict(self.state_dict())
             self._fx_version = ver
 
+        def _fx_train_graph(self):
+            """train_mf.FAIMaskFormerTrainable over THIS module's parameters and buffers (see EngineBisenetFormer._fx_train_graph)."""
+            g = self.__dict__.get("_fx_train")
+            if g is None or g[1] != str(self.device):
+                from .train_mf import FAIMaskFormerTrainable
+
+                mods = list(self.modules())
+                sync = any(isinstance(m, torch.nn.SyncBatchNorm) for m in mods)
+                live = any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.weight is not None and m.weight.requires_grad for m in mods)
+                net = FAIMaskFormerTrainable(_config_to_dict(self.config), norm="SyncBN" if sync else ("BN" if live else "FrozenBN")).to(self.device)
+                share_parameters(net, self)
+                g = (net, str(self.device))
+                self.__dict__["_fx_train"] = g
+            g[0].train(self.training)
+            return g[0]
+
         def forward(self, images, targets=[]):
-            if self.training or (targets is not None and len(targets) > 0) or (torch.is_grad_enabled() and images.requires_grad) \
-                    or not _engine_can_run(images):
-                return super().forward(images, targets)  # training (no HIP training graph for fai-mf yet) / unsupported shapes: the reference's own graph
-            self._fx_sync()
+            if (torch.is_grad_enabled() and images.requires_grad) or not _engine_can_run(images):
+                return super().forward(images, targets)  # shapes / devices the engine has no plan for: the reference's own graph
             x = images
             if x.dim() == 4 and x.shape[1] == 3 and x.shape[-1] != 3:
                 x = x.permute(0, 2, 3, 1)
             x = (x if x.dtype == torch.uint8 else x.float()).contiguous()
+            if self.training and targets is not None and len(targets) > 0:
+                # FAIMaskFormer.forward in train mode (modelling.py:712-725): losses from the HIP training graph over this module's parameters
+                from . import train_nn
+
+                train_nn.WEIGHTS_EPOCH[0] += 1
+                net = self._fx_train_graph()
+                losses = net(x, targets)
+                with torch.no_grad():
+                    o = net.last_outputs
+                    logits = torch.softmax(o["pred_logits"].float(), -1)[..., :-1]
+                    masks = torch.sigmoid(o["pred_masks"])
+                return MaskFormerModelOutput(masks=masks, logits=logits, loss=losses)
+            if self.training or (targets is not None and len(targets) > 0):
+                return super().forward(images, targets)
+            self._fx_sync()
             pl = self._fx_engine.forward(x, full_masks=True)
             return MaskFormerModelOutput(masks=pl.masks.clone(), logits=pl.probs.clone(), loss=None)
 

@@ -42,8 +42,10 @@ def run_train(args: TrainerArgs, data_train, data_val, model, processor, model_i
         trainable = FAIDetrTrainable
     elif family == "bisenetformer":
         from .train_bf import BisenetFormerTrainable as trainable
+    elif family == "fai_mf":
+        from .train_mf import FAIMaskFormerTrainable as trainable
     else:
-        raise NotImplementedError(f"training graphs exist for the RT-DETR and BiSeNetFormer families (BASELINE configs 4 / 5), not for {family!r}")
+        raise NotImplementedError(f"no training graph for model family {family!r}")
     rank, world = _dist()
     local = int(os.environ.get("LOCAL_RANK", rank))
     dev = torch.device("cuda", local if world > 1 else (model.device.index or 0))

@@ -65,8 +65,10 @@ def conv2d_norm_act(sd: SD, prefix: str, x: torch.Tensor, padding: int, relu: bo
     """focoos.nn.layers.conv.Conv2d.forward — conv.py:33-69 (conv [+bias] -> BN eval if present -> activation)."""
     y = F.conv2d(x, sd[f"{prefix}.weight"], sd.get(f"{prefix}.bias"), padding=padding)
     if f"{prefix}.norm.weight" in sd:
+        from .detr_oracle import BN_TRAINING   # set by the training oracle only (model.train(): batch statistics + running-stat update)
+
         y = F.batch_norm(y, sd[f"{prefix}.norm.running_mean"], sd[f"{prefix}.norm.running_var"],
-                         sd[f"{prefix}.norm.weight"], sd[f"{prefix}.norm.bias"], training=False, eps=1e-5)
+                         sd[f"{prefix}.norm.weight"], sd[f"{prefix}.norm.bias"], training=BN_TRAINING[0], momentum=0.1 if BN_TRAINING[0] else 0.0, eps=1e-5)
     return F.relu(y) if relu else y
 
 

@@ -121,8 +121,26 @@ def bf_train_outputs(sd: SD, cfg: Dict, images: torch.Tensor, forced_attn: Optio
     return {"pred_logits": heads[-1][0], "pred_masks": heads[-1][1], "aux_outputs": [{"pred_logits": a, "pred_masks": b} for a, b in heads[:-1]]}
 
 
+def mf_train_outputs(sd: SD, cfg: Dict, images: torch.Tensor, forced_attn: Optional[Sequence[torch.Tensor]] = None, collect: Optional[dict] = None):
+    """FAIMaskFormer.forward in training mode up to the criterion (focoos/models/fai_mf/modelling.py:712-725, TransformerFPN :347-369,
+    MultiScaleMaskedTransformerDecoder.forward :453-549 with every prediction head supervised :489-549)."""
+    from . import mf_oracle as M
+
+    mean = torch.tensor(cfg.get("pixel_mean", [123.675, 116.28, 103.53]), dtype=torch.float32).view(-1, 1, 1)
+    std = torch.tensor(cfg.get("pixel_std", [58.395, 57.12, 57.375]), dtype=torch.float32).view(-1, 1, 1)
+    x = (images - mean) / std
+    feats = O.resnet_vd(sd, "pixel_decoder.backbone", x, O.RESNET_BLOCKS[int(cfg["backbone_config"].get("depth", 50))])
+    if collect is not None:
+        collect.update(feats)
+    mask_features, msf = M.transformer_fpn(sd, feats, cfg, collect)
+    heads: list = []
+    M.masked_decoder(sd, msf, mask_features, cfg, forced_attn, collect, all_heads=heads)
+    return {"pred_logits": heads[-1][0], "pred_masks": heads[-1][1], "aux_outputs": [{"pred_logits": a, "pred_masks": b} for a, b in heads[:-1]]}
+
+
 def bf_criterion(outputs, tgt_labels: Sequence[torch.Tensor], tgt_masks: Sequence[torch.Tensor], rand, cfg: Dict, fixed_matches=None):
-    """SetCriterion.forward of the mask families with the registry's weights (bisenetformer/modelling.py:551-575): dict of weighted losses
+    """SetCriterion.forward of the mask families (MaskFormer and BiSeNetFormer share it) with the registry's weights
+    (bisenetformer/modelling.py:551-575 == fai_mf/modelling.py:657-681): dict of weighted losses
     + the matches; ``rand`` = mask_criterion_oracle.RandStream of the torch.rand draws in the reference's order."""
     from . import mask_criterion_oracle as MC
 

@@ -159,7 +159,7 @@ class _StubReferenceModule:
             if kind in ("bn_mean", "bn_var", "bn_nbt", "buf"):
                 self.buffers[k] = sd[k].to(DEV)
             else:
-                self.params[k] = torch.nn.Parameter(sd[k].to(DEV), requires_grad=not (frozen_bn and kind in ("bn_w", "bn_b")) and "mask_features" not in k)
+                self.params[k] = torch.nn.Parameter(sd[k].to(DEV), requires_grad=not (frozen_bn and kind in ("bn_w", "bn_b")) and not (family == "fai_detr" and "mask_features" in k))
 
     def named_parameters(self):
         return self.params.items()
@@ -168,7 +168,7 @@ class _StubReferenceModule:
         return self.buffers.items()
 
 
-@pytest.mark.parametrize("family", ["fai_detr", "bisenetformer"])
+@pytest.mark.parametrize("family", ["fai_detr", "bisenetformer", "fai_mf"])
 def test_adapter_training_mechanics_with_external_optimizer(family):
     """Seam B2 in training mode on the GPU: the HIP autograd graph runs over tensors OWNED by another module (share_parameters), gradients
     land in that module's ``.grad`` fields, and an external torch optimizer - the reference's TrainerLoop keeps its own - steps them;
@@ -183,10 +183,14 @@ def test_adapter_training_mechanics_with_external_optimizer(family):
         from focoos_amd.train_detr import FAIDetrTrainable as Net
 
         cfg, norm = ModelRegistry.get_model_info("fai-detr-l-coco")["config"], "FrozenBN"
-    else:
+    elif family == "bisenetformer":
         from focoos_amd.train_bf import BisenetFormerTrainable as Net
 
         cfg, norm = dict(ModelRegistry.get_model_info("bisenetformer-l-ade")["config"], criterion_num_points=1024), "BN"
+    else:
+        from focoos_amd.train_mf import FAIMaskFormerTrainable as Net
+
+        cfg, norm = dict(ModelRegistry.get_model_info("fai-mf-l-coco-ins")["config"], criterion_num_points=1024), "FrozenBN"
     ref = _StubReferenceModule(cfg, family, 8, norm == "FrozenBN")
     net = Net(cfg, norm=norm).to(DEV)
     n = share_parameters(net, ref)
@@ -205,7 +209,7 @@ def test_adapter_training_mechanics_with_external_optimizer(family):
             m = np.zeros((2, 128, 160), bool)
             m[0, 10:70, 20:90] = True
             m[1, 60:120, 80:150] = True
-            tg.append(MaskFormerTargets(labels=torch.from_numpy(rs.randint(0, 150, (2,))).to(DEV), masks=torch.from_numpy(m).to(DEV)))
+            tg.append(MaskFormerTargets(labels=torch.from_numpy(rs.randint(0, int(cfg["num_classes"]), (2,))).to(DEV), masks=torch.from_numpy(m).to(DEV)))
     before = {k: p.detach().clone() for k, p in ref.params.items() if p.requires_grad}
     totals = []
     for _ in range(3):

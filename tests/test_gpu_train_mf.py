@@ -1,0 +1,131 @@
+"""The MaskFormer (fai-mf-*) training step on the HIP autograd graph vs the CPU fp32 training oracle
+(oracle/train_oracle.mf_train_outputs / bf_criterion, pinned against the real reference in .train() by
+tests/test_oracle_vs_reference.py::test_mf_train_oracle_matches_reference_losses_and_gradients).  Attention masks, Hungarian matches and
+the point-sampling draws are teacher-forced as in tests/test_gpu_train_bf.py.  Tolerances: 30 losses within 3 % (+1e-3) with frozen
+BatchNorm; per-parameter gradient relative L2 as asserted below (measured values in DESIGN.md §2)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from focoos_amd.ports import MaskFormerTargets  # noqa: E402
+from focoos_amd.registry import ModelRegistry  # noqa: E402
+from focoos_amd.synth import synth_image_structured, synth_state_dict  # noqa: E402
+from oracle import detr_oracle as O  # noqa: E402
+from oracle import train_oracle as T  # noqa: E402
+from tests.helpers import rel_l2  # noqa: E402
+from tests.test_gpu_train_bf import _DrawAndRecord, _Replay  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _cfg(depth, num_points=2048):
+    cfg = dict(ModelRegistry.get_model_info("fai-mf-l-coco-ins")["config"], criterion_num_points=num_points)
+    cfg["backbone_config"] = dict(cfg["backbone_config"], depth=depth)
+    return cfg
+
+
+@pytest.mark.parametrize("norm", ["FrozenBN", "BN"])
+def test_mf_train_step_losses_and_gradients(norm):
+    from focoos_amd.train_mf import FAIMaskFormerTrainable
+
+    cfg = _cfg(50)   # R50: the R101 of fai-mf-l is the same blocks, 17 more of them in res4
+    sd = synth_state_dict(cfg, 41, family="fai_mf")
+    for k in sd:     # keep the six pre-norm encoder layers' attention logits O(1) (see tests/test_gpu_train_conv.py on AIFI)
+        if ".transformer.encoder.layers." in k and k.endswith("self_attn.in_proj_weight"):
+            sd[k] = sd[k].clone()
+            sd[k][:512] *= 0.05
+    nimg, (ih, iw) = (4, (192, 256)) if norm == "BN" else (2, (192, 256))
+    imgs = [synth_image_structured(160 + i, ih, iw) for i in range(nimg)]
+    labels, masks = T.synth_mask_targets(7, nimg, int(cfg["num_classes"]), (ih, iw), counts=(3, 5, 2, 4))
+
+    def trainable(k, v):
+        if not (v.dtype == torch.float32 and v.dim() > 0) or any(t in k for t in ("running_", "empty_weight")):
+            return False
+        is_bn = k.endswith((".norm.weight", ".norm.bias")) and ".transformer." not in k
+        return norm != "FrozenBN" or not is_bn
+
+    sdg = {k: (v.clone().requires_grad_(True) if trainable(k, v) else v.clone()) for k, v in sd.items()}
+    x = O.get_torch_batch(imgs, None)
+    col = {}
+    O.BN_TRAINING[0] = norm != "FrozenBN"
+    try:
+        outs = T.mf_train_outputs(sdg, cfg, x, collect=col)
+    finally:
+        O.BN_TRAINING[0] = False
+    rs = _DrawAndRecord(78)
+    losses_o, matches = T.bf_criterion(outs, labels, masks, rs, cfg)
+    sum(losses_o.values()).backward()
+    model = FAIMaskFormerTrainable(cfg, norm=norm, rand=_Replay(rs.rec)).to(DEV)
+    model.load_state_dict(sd, strict=True)
+    assert sorted(model.state_dict().keys()) == sorted(sd.keys())
+    model.train()
+    targets = [MaskFormerTargets(labels=l.to(DEV), masks=m.to(DEV)) for l, m in zip(labels, masks)]
+    fixed = []
+    for m in matches:
+        pi = torch.tensor(np.concatenate([np.asarray(i) for i, _ in m]), dtype=torch.int32, device=DEV)
+        ti = torch.tensor(np.concatenate([np.asarray(j) for _, j in m]), dtype=torch.int32, device=DEV)
+        fixed.append((pi, ti))
+    x_u8 = torch.from_numpy(np.stack(imgs)).to(DEV)
+    losses = model(x_u8, targets, forced_attn=col["attn_masks"], fixed_matches=fixed)
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    assert sorted(losses) == sorted(losses_o) and len(losses) == 30
+    pm_err = rel_l2(model.last_outputs["pred_masks"].detach().float().cpu(), outs["pred_masks"].detach())
+    print(f"{norm}: last-head mask logits rel-L2 {pm_err:.4f}")
+    worst_loss = max(abs(float(losses[k]) - float(losses_o[k])) / (abs(float(losses_o[k])) + 1e-3) for k in losses_o)
+    print(f"{norm}: worst relative loss deviation {worst_loss:.4f}")
+    errs = []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        r = sdg[name]
+        if not (isinstance(r, torch.Tensor) and r.requires_grad):
+            continue
+        assert p.grad is not None, name
+        assert r.grad is not None, name
+        errs.append((rel_l2(p.grad.cpu(), r.grad), name, float(r.grad.norm())))
+    floor = 1e-3 * sorted(n for _, _, n in errs)[len(errs) // 2]
+    print("zero-gradient tensors skipped:", [n for _, n, g in errs if g < floor])
+    errs = [(e, n) for e, n, g in errs if g >= floor]
+    errs.sort(reverse=True)
+    print(f"{norm}: {len(errs)} parameter tensors; worst 8: {[(round(e, 4), n) for e, n in errs[:8]]}; median {errs[len(errs) // 2][0]:.4f}")
+    print("quartiles:", [round(errs[len(errs) * q // 4][0], 4) for q in (1, 2, 3)])
+    assert len(errs) > 250
+    for k in losses_o:
+        a, b = float(losses[k]), float(losses_o[k])
+        assert abs(a - b) <= (6e-2 if norm == "BN" else 3e-2) * abs(b) + 1e-3, (k, a, b)
+    if norm == "BN":
+        # live BatchNorm through ~60 normalised layers: same regime as the RT-DETR BN-mode test (tests/test_gpu_train_detr.py)
+        dec = sorted(e for e, n in errs if n.startswith("head.predictor."))
+        assert dec[len(dec) // 2] <= 0.15, dec[len(dec) // 2]
+        assert errs[len(errs) // 2][0] <= 0.40 and errs[len(errs) // 10][0] <= 0.60, errs[:8]
+    else:
+        assert pm_err <= 4e-2
+        assert errs[0][0] <= 0.25, errs[:8]
+        assert errs[len(errs) // 2][0] <= 0.08
+
+
+def test_mf_train_step_free_running_r101():
+    """TrainStep on the full fai-mf-l graph (R101), nothing teacher-forced: finite losses, every trainable tensor receives a gradient and moves."""
+    from focoos_amd.train_detr import TrainStep
+    from focoos_amd.train_mf import FAIMaskFormerTrainable
+
+    cfg = _cfg(101, 1024)
+    model = FAIMaskFormerTrainable(cfg, norm="FrozenBN").to(DEV)
+    model.load_state_dict(synth_state_dict(cfg, 42, family="fai_mf"), strict=True)
+    model.train()
+    ts = TrainStep(model, lr=1e-4, max_grad_norm=0.1)
+    imgs = [synth_image_structured(190 + i, 128, 160) for i in range(2)]
+    labels, masks = T.synth_mask_targets(8, 2, int(cfg["num_classes"]), (128, 160), counts=(3, 0))
+    targets = [MaskFormerTargets(labels=l.to(DEV), masks=m.to(DEV)) for l, m in zip(labels, masks)]
+    x_u8 = torch.from_numpy(np.stack(imgs)).to(DEV)
+    p0 = ts.opt.flat_p.clone()
+    l1 = {k: float(v) for k, v in ts.step(x_u8, targets).items()}
+    l2 = {k: float(v) for k, v in ts.step(x_u8, targets).items()}
+    torch.cuda.synchronize()
+    assert len(l1) == 30 and all(np.isfinite(v) for v in l1.values()) and all(np.isfinite(v) for v in l2.values())
+    assert not torch.equal(ts.opt.flat_p, p0)
+    dead = [n for n, _ in ts.named if float(ts.opt.grads[n].abs().max()) == 0.0]
+    assert not dead, dead[:10]

@@ -143,3 +143,28 @@ def test_bisenetformer_adapter_shares_every_parameter_with_the_training_graph(mo
     refp = dict(ref.named_parameters())
     assert all(p is refp[k] for k, p in net.named_parameters())
     assert net.pixel_decoder.backbone.features[2].avd_layer._norm_h.running_mean is dict(ref.named_buffers())["pixel_decoder.backbone.features.2.avd_layer.1.running_mean"]
+
+
+def test_maskformer_adapter_shares_every_parameter_with_the_training_graph(monkeypatch):
+    """Same structural check for the MaskFormer family: train_mf.FAIMaskFormerTrainable's parameter / buffer tree against the REAL FAIMaskFormer."""
+    ref_import.install()
+    import torch
+    from focoos.model_manager import ConfigManager, ModelManager
+    from focoos.ports import ModelFamily
+
+    import focoos_amd.integration as fx
+    from focoos_amd import _lib
+    from focoos_amd.registry import ModelRegistry
+
+    fx.register()
+    cfgd = ModelRegistry.get_model_info("fai-mf-l-coco-ins")["config"]
+    ref = ModelManager._models_family_map[ModelFamily.MASKFORMER.value]()(ConfigManager.from_dict(ModelFamily.MASKFORMER, {k: v for k, v in cfgd.items() if k != "resolution"}))
+    monkeypatch.setattr(torch.cuda, "is_available", lambda: True)
+    monkeypatch.setattr(_lib, "load", lambda: None)
+    from focoos_amd.train_mf import FAIMaskFormerTrainable
+
+    net = FAIMaskFormerTrainable(cfgd, norm="BN")
+    n = fx.share_parameters(net, ref)
+    assert n == len(list(ref.state_dict())) == len(list(net.state_dict()))
+    refp = dict(ref.named_parameters())
+    assert all(p is refp[k] for k, p in net.named_parameters())

@@ -324,3 +324,73 @@ def test_reference_fp16_amp_losses_vs_fp32_and_bf16_autocast():
     dev = {n: max(abs(res[n][k] - res["fp32"][k]) / (abs(res["fp32"][k]) + 1e-3) for k in res["fp32"]) for n in ("fp16", "bf16")}
     print("max relative loss deviation vs fp32:", dev)
     assert dev["fp16"] <= 1e-2 and dev["bf16"] <= 2.5e-2, dev
+
+
+def test_mf_train_oracle_matches_reference_losses_and_gradients():
+    """oracle/train_oracle.mf_train_outputs + bf_criterion (MaskFormer training forward: ResNet-vd, TransformerFPN with its pre-norm encoder,
+    10 supervised prediction heads, the shared point-sampled criterion) vs the REAL reference fully in .train(): the 30 weighted losses on
+    the reference's recorded torch.rand draws, gradients of parameters spread over the model, running statistics."""
+    ref_import.install()
+    import json
+    import os
+
+    from focoos.models.fai_mf.ports import MaskFormerTargets
+
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.synth import synth_image_structured, synth_state_dict
+    from oracle import detr_oracle as O
+    from oracle import mask_criterion_oracle as MC
+    from oracle import train_oracle as T
+
+    cfg = dict(ModelRegistry.get_model_info("fai-mf-l-coco-ins")["config"], criterion_num_points=1024)
+    cfg["backbone_config"] = dict(cfg["backbone_config"], depth=50)    # R50 instead of R101: the same code path, a third of the CPU time
+    ref_cfg = dict(json.load(open(os.path.join(ref_import.REFERENCE_ROOT, "focoos/model_registry/fai-mf-l-coco-ins.json")))["config"], criterion_num_points=1024)
+    ref_cfg["backbone_config"] = dict(ref_cfg["backbone_config"], depth=50)
+    model, proc, _ = ref_import.build_reference_mf(ref_cfg)
+    sd = synth_state_dict(cfg, seed=14, family="fai_mf")
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    imgs = [synth_image_structured(44 + i, 128, 160) for i in range(2)]
+    x = O.get_torch_batch(imgs, None)
+    labels, masks = T.synth_mask_targets(4, 2, int(cfg["num_classes"]), (128, 160), counts=(3, 4))
+    rec, orig_rand = [], torch.rand
+
+    def spy_rand(*a, **k):
+        t = orig_rand(*a, **k)
+        rec.append(t.clone())
+        return t
+
+    torch.rand = spy_rand
+    try:
+        out = model(x, [MaskFormerTargets(labels=l, masks=m) for l, m in zip(labels, masks)])
+    finally:
+        torch.rand = orig_rand
+    ref_losses = out.loss
+    assert len(ref_losses) == 30
+    sum(ref_losses.values()).backward()
+    sdg = {k: (v.clone().requires_grad_(True) if v.dtype == torch.float32 and v.dim() > 0 and "running" not in k and "empty_weight" not in k
+               else v.clone()) for k, v in sd.items()}
+    O.BN_TRAINING[0] = True
+    try:
+        outs = T.mf_train_outputs(sdg, cfg, x)
+    finally:
+        O.BN_TRAINING[0] = False
+    losses, _ = T.bf_criterion(outs, labels, masks, MC.RandStream(rec), cfg)
+    assert sorted(losses) == sorted(ref_losses)
+    for k in ref_losses:
+        np.testing.assert_allclose(float(losses[k]), float(ref_losses[k]), rtol=5e-4, atol=1e-5, err_msg=k)
+    sum(losses.values()).backward()
+    named = dict(model.named_parameters())
+    for k in ("pixel_decoder.backbone.res_layers.1.blocks.0.branch2b.conv.weight", "pixel_decoder.input_proj.bias",
+              "pixel_decoder.transformer.encoder.layers.3.self_attn.in_proj_weight", "pixel_decoder.transformer.encoder.norm.weight",
+              "pixel_decoder.adapter_2.weight", "pixel_decoder.layer_1.norm.weight", "pixel_decoder.layer_4.weight", "pixel_decoder.mask_features.bias",
+              "head.predictor.query_embed.weight", "head.predictor.input_proj.2.weight",
+              "head.predictor.transformer_cross_attention_layers.7.multihead_attn.in_proj_weight",
+              "head.predictor.forward_prediction_heads.mask_classifier.layers.0.weight"):
+        g_ref, g_mine = named[k].grad, sdg[k].grad
+        assert g_ref is not None and g_mine is not None, k
+        assert (g_mine - g_ref).abs().max() <= 5e-3 * g_ref.abs().max() + 1e-7, (k, float((g_mine - g_ref).abs().max()), float(g_ref.abs().max()))
+    ref_sd = model.state_dict()
+    for k in ("pixel_decoder.adapter_3.norm.running_mean", "pixel_decoder.layer_2.norm.running_var"):
+        np.testing.assert_allclose(sdg[k].numpy(), ref_sd[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
+        assert not torch.equal(sdg[k], sd[k]), k
