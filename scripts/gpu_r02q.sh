@@ -1,3 +1,5 @@
 #!/bin/bash
 out=$PWD/gpurun_out/r02q; mkdir -p $out
-timeout 900 python -m pytest tests/test_gpu_train_mf.py tests/test_gpu_train_api.py -q > $out/t_mf.log 2>&1; grep -E "^E  |passed|failed|Error" $out/t_mf.log | cut -c1-600 | tail -12
+timeout 400 python bench.py --model fai-mf-l-coco-ins --no-cpu-baseline --per-op $out/mf_per_op.txt > $out/mf_bench.json 2>/dev/null
+timeout 400 python bench.py --model bisenetformer-l-ade --no-cpu-baseline --per-op $out/bf_per_op.txt > $out/bf_bench.json 2>/dev/null
+head -c 200 $out/mf_bench.json; echo; head -c 200 $out/bf_bench.json; echo
