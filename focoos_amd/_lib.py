@@ -78,6 +78,8 @@ SIGNATURES = {
     "fx_enc_score_head_bf16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp, _i, _vp, _i, _vp],
     "fx_row_chain": [_vp, _i, _i, _i, _vp],
     "fx_topk_rows_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "fx_topk_rows_workspace_bytes": [_i, _i, _i],
+    "fx_topk_rows_ws_f32": [_vp, _i, _i, _i, _i, _vp, _vp, _vp, C.c_size_t, _vp],
     "fx_gather_rows_bf16": [_vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _vp],
     "fx_fill_rows_bf16": [_vp, _i, _i, _vp, _i, _vp, _i, _i, _vp],
     "fx_linear_k4_relu": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
@@ -175,6 +177,7 @@ def load() -> C.CDLL:
     lib.fx_mha_bwd_workspace_bytes.restype = C.c_size_t
     lib.fx_seg_postprocess_workspace_bytes.restype = C.c_size_t
     lib.fx_mask_set_loss_workspace_bytes.restype = C.c_size_t
+    lib.fx_topk_rows_workspace_bytes.restype = C.c_size_t
     lib.fx_error_string.argtypes = [C.c_int]
     lib.fx_error_string.restype = C.c_char_p
     if lib.fx_abi_version() != 1:

@@ -43,13 +43,24 @@ __device__ __forceinline__ float key_f32(uint32_t k) {
   return __uint_as_float(u);
 }
 
-__global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restrict__ scores, int ld, int n, int k, float* __restrict__ out_val,
+// Virtual rows: blockIdx.x = image * nchunk + chunk; the row is elements [chunk * chunk_len, ...) of the image's `n_total` scores
+// (nchunk = 1: the plain per-image form).  `src_idx` (optional, [images][n_total]): original index of every element - the second level of
+// the two-level form, whose elements are candidates of the first; the sort key and the output use the ORIGINAL index, so ties order
+// exactly as in a single pass (candidates of equal value sit in ascending original-index order: chunks are index ranges, and each
+// chunk's list is (value desc, index asc)).  Slots beyond the row's own length are padded (-inf, INT_MAX).
+__global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restrict__ scores, int ld, int n_total, int chunk_len, int nchunk, int k_out,
+                                                             const int32_t* __restrict__ src_idx, float* __restrict__ out_val,
                                                              int32_t* __restrict__ out_idx) {
   __shared__ uint32_t hist[256];
   __shared__ unsigned long long sel[TOPK_MAXK];
   __shared__ uint32_t s_prefix, s_remaining, s_count, s_base, s_wave_tot[16];
   const int tid = threadIdx.x;
-  const float* row = scores + (int64_t)blockIdx.x * ld;
+  const int img = blockIdx.x / nchunk, ch = blockIdx.x - img * nchunk;
+  const int base = ch * chunk_len;
+  const int n = min(chunk_len, n_total - base);
+  const int k = min(k_out, n);
+  const float* row = scores + (int64_t)img * ld + base;
+  const int32_t* sidx = src_idx ? src_idx + (int64_t)img * ld + base : nullptr;
 
   uint32_t prefix = 0, mask = 0;
   if (tid == 0) s_remaining = (uint32_t)k;
@@ -98,7 +109,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restr
     uint32_t key = f32_key(row[i]);
     if (key > T || (all_eq && key == T)) {
       uint32_t pos = atomicAdd(&s_count, 1u);
-      if (pos < TOPK_MAXK) sel[pos] = ((unsigned long long)key << 32) | (uint32_t)(0xffffffffu - (uint32_t)i);
+      if (pos < TOPK_MAXK) sel[pos] = ((unsigned long long)key << 32) | (uint32_t)(0xffffffffu - (uint32_t)(sidx ? sidx[i] : base + i));
     }
   }
   __syncthreads();
@@ -121,7 +132,7 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restr
       uint32_t rank = s_base + woff + wexcl;
       if (flag && rank < need_eq) {
         uint32_t pos = (uint32_t)(k - (int)need_eq) + rank;
-        if (pos < TOPK_MAXK) sel[pos] = ((unsigned long long)T << 32) | (uint32_t)(0xffffffffu - (uint32_t)i);
+        if (pos < TOPK_MAXK) sel[pos] = ((unsigned long long)T << 32) | (uint32_t)(0xffffffffu - (uint32_t)(sidx ? sidx[i] : base + i));
       }
       __syncthreads();
       if (tid == 0) s_base += tot;
@@ -149,17 +160,44 @@ __global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restr
       __syncthreads();
     }
   }
-  for (int i = tid; i < k; i += TOPK_THREADS) {
+  for (int i = tid; i < k_out; i += TOPK_THREADS) {
     unsigned long long e = sel[i];
-    out_val[(int64_t)blockIdx.x * k + i] = key_f32((uint32_t)(e >> 32));
-    out_idx[(int64_t)blockIdx.x * k + i] = (int32_t)(0xffffffffu - (uint32_t)(e & 0xffffffffull));
+    out_val[(int64_t)blockIdx.x * k_out + i] = i < k ? key_f32((uint32_t)(e >> 32)) : -INFINITY;
+    out_idx[(int64_t)blockIdx.x * k_out + i] = i < k ? (int32_t)(0xffffffffu - (uint32_t)(e & 0xffffffffull)) : 0x7fffffff;
   }
 }
 
 extern "C" int fx_topk_rows_f32(const float* scores, int ld, int B, int n, int k, float* out_val, int32_t* out_idx, fx_stream_t stream_) {
   FX_CHECK_ARG(scores && out_val && out_idx && B > 0 && n > 0 && k > 0 && k <= n && ld >= n);
   if (k > TOPK_MAXK) return FX_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(TOPK_THREADS), 0, reinterpret_cast<hipStream_t>(stream_), scores, ld, n, k, out_val, out_idx);
+  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(TOPK_THREADS), 0, reinterpret_cast<hipStream_t>(stream_), scores, ld, n, n, 1, k,
+                     (const int32_t*)nullptr, out_val, out_idx);
+  return fx_launch_status();
+}
+
+// Two-level form for long rows (the post-process top-k over Q*K = 109 500 scores per image runs as 32 workgroups in the one-level
+// form): level 1 = exact top-k of every 8192-element chunk (B * ceil(n / 8192) workgroups), level 2 = exact top-k of the <= 14 * k
+// candidates per image.  The global top-k is a subset of the union of the chunk top-ks, and tie order is preserved (see topk_kernel).
+#define TOPK_CHUNK 8192
+extern "C" size_t fx_topk_rows_workspace_bytes(int B, int n, int k) {
+  if (B <= 0 || n <= 0 || k <= 0) return 0;
+  const int nchunk = (n + TOPK_CHUNK - 1) / TOPK_CHUNK;
+  return nchunk > 1 ? (size_t)B * nchunk * k * 8 : 0;
+}
+
+extern "C" int fx_topk_rows_ws_f32(const float* scores, int ld, int B, int n, int k, float* out_val, int32_t* out_idx, void* workspace,
+                                   size_t workspace_bytes, fx_stream_t stream_) {
+  const size_t need = fx_topk_rows_workspace_bytes(B, n, k);
+  if (need == 0 || k > TOPK_CHUNK) return fx_topk_rows_f32(scores, ld, B, n, k, out_val, out_idx, stream_);
+  FX_CHECK_ARG(scores && out_val && out_idx && workspace && workspace_bytes >= need && k <= n && ld >= n && ((uintptr_t)workspace % 4) == 0);
+  if (k > TOPK_MAXK) return FX_ERR_UNSUPPORTED;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const int nchunk = (n + TOPK_CHUNK - 1) / TOPK_CHUNK;
+  float* cval = reinterpret_cast<float*>(workspace);
+  int32_t* cidx = reinterpret_cast<int32_t*>(cval + (size_t)B * nchunk * k);
+  hipLaunchKernelGGL(topk_kernel, dim3(B * nchunk), dim3(TOPK_THREADS), 0, stream, scores, ld, n, TOPK_CHUNK, nchunk, k, (const int32_t*)nullptr, cval, cidx);
+  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(TOPK_THREADS), 0, stream, (const float*)cval, nchunk * k, nchunk * k, nchunk * k, 1, k,
+                     (const int32_t*)cidx, out_val, out_idx);
   return fx_launch_status();
 }
 

@@ -777,7 +777,11 @@ class _Plan(_PlanBase):
         self.det_queries = self._io("det_queries", (B, tk), torch.int32)
         self.det_boxes = self._io("det_boxes", (B, tk, 4), torch.int32)
         self.det_count = self._io("det_count", (B,), torch.int32)
-        self._op(lib.fx_topk_rows_f32, self.probs.data_ptr(), Q * K, B, Q * K, tk, self.det_scores.data_ptr(), self.det_flat.data_ptr())
+        nws = int(lib.fx_topk_rows_workspace_bytes(B, Q * K, tk))   # two-level exact top-k: chunk candidates first (B * 14 workgroups instead of B)
+        self.topk_ws = torch.empty(max(nws, 8), dtype=torch.uint8, device=self.dev)
+        self.keep.append(self.topk_ws)
+        self._op(lib.fx_topk_rows_ws_f32, self.probs.data_ptr(), Q * K, B, Q * K, tk, self.det_scores.data_ptr(), self.det_flat.data_ptr(),
+                 self.topk_ws.data_ptr(), C.c_size_t(self.topk_ws.numel()))
         self.post_index = len(self.ops)
         self._op(lib.fx_detr_postprocess, self.det_scores.data_ptr(), self.det_flat.data_ptr(), self.boxes.data_ptr(), self.sizes.data_ptr(), B, Q,
                  K, tk, None, self.det_labels.data_ptr(), self.det_queries.data_ptr(), self.det_boxes.data_ptr(), self.det_count.data_ptr())

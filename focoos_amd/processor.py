@@ -162,7 +162,8 @@ class DETRProcessor:
         count = torch.empty(B, dtype=torch.int32, device=dev)
         sizes = torch.tensor(image_sizes, dtype=torch.int32).to(dev)
         stream = torch.cuda.current_stream(dev).cuda_stream
-        check(lib.fx_topk_rows_f32(probs.data_ptr(), Q * K, B, Q * K, tk, val.data_ptr(), idx.data_ptr(), stream), "fx_topk_rows_f32")
+        ws = torch.empty(max(int(lib.fx_topk_rows_workspace_bytes(B, Q * K, tk)), 8), dtype=torch.uint8, device=probs.device)
+        check(lib.fx_topk_rows_ws_f32(probs.data_ptr(), Q * K, B, Q * K, tk, val.data_ptr(), idx.data_ptr(), ws.data_ptr(), ws.numel(), stream), "fx_topk_rows_ws_f32")
         check(lib.fx_detr_postprocess(val.data_ptr(), idx.data_ptr(), boxes.data_ptr(), sizes.data_ptr(), B, Q, K, tk, float(threshold),
                                       labels.data_ptr(), queries.data_ptr(), obox.data_ptr(), count.data_ptr(), stream), "fx_detr_postprocess")
         return self.pack_detections(val, labels, obox, count, class_names)
@@ -186,8 +187,9 @@ class DETRProcessor:
         tk = min(top_k, Q * K)
         val = torch.empty(B, tk, dtype=torch.float32, device=dev)
         idx = torch.empty(B, tk, dtype=torch.int32, device=dev)
-        check(lib.fx_topk_rows_f32(probs.data_ptr(), Q * K, B, Q * K, tk, val.data_ptr(), idx.data_ptr(), torch.cuda.current_stream(dev).cuda_stream),
-              "fx_topk_rows_f32")
+        ws = torch.empty(max(int(lib.fx_topk_rows_workspace_bytes(B, Q * K, tk)), 8), dtype=torch.uint8, device=dev)
+        check(lib.fx_topk_rows_ws_f32(probs.data_ptr(), Q * K, B, Q * K, tk, val.data_ptr(), idx.data_ptr(), ws.data_ptr(), ws.numel(),
+                                      torch.cuda.current_stream(dev).cuda_stream), "fx_topk_rows_ws_f32")
         idx = idx.long()
         labels, queries = idx % K, idx // K
         results = []

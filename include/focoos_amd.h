@@ -207,6 +207,11 @@ int fx_row_chain(const fx_rc_stage* program_device, int n_stages, int rows, int 
 /* torch.topk(scores, k, dim=1) for f32 rows (modelling.py:1214; processor.py:147): for each of B rows
  * of length n writes the k largest values (descending; ties -> lower index first) and their indices. */
 int fx_topk_rows_f32(const float* scores, int ld, int B, int n, int k, float* out_val, int32_t* out_idx, fx_stream_t stream);
+/* Same result, two-level for long rows (n > 8192: chunk top-ks on B * ceil(n / 8192) workgroups, then the top-k of the candidates; exact incl.
+ * tie order); workspace: fx_topk_rows_workspace_bytes() (0: the one-level form is used). */
+size_t fx_topk_rows_workspace_bytes(int B, int n, int k);
+int fx_topk_rows_ws_f32(const float* scores, int ld, int B, int n, int k, float* out_val, int32_t* out_idx, void* workspace, size_t workspace_bytes,
+                        fx_stream_t stream);
 
 /* out[b,i,:] = src[b, idx[b,i], :] (the three gathers of modelling.py:1216-1229), bf16 rows of `cols`. */
 int fx_gather_rows_bf16(const void* src, int lds, int rows_per_batch, const int32_t* idx, int k, void* out, int ldo, int B, int cols,

@@ -360,6 +360,35 @@ def test_topk_exact(lib, cfg):
     assert torch.equal(val.cpu(), tv)  # same multiset of values as torch.topk (modelling.py:1214)
 
 
+@pytest.mark.parametrize("cfg", [(2, 109500, 300), (3, 30000, 300), (2, 8193, 300), (2, 20000, 1000), (1, 8500, 400)])
+def test_topk_two_level_exact(lib, cfg):
+    """fx_topk_rows_ws_f32 (chunk top-ks + top-k of the candidates) == one stable descending sort, incl. ties that straddle the cut,
+    span chunk boundaries (chunks of 8192) and a last chunk shorter than k."""
+    B, n, k = cfg
+    g = torch.Generator().manual_seed(n * 3 + k)
+    s = torch.sigmoid(torch.randn(B, n, generator=g) * 2)
+    s[0, ::7] = 0.9375                                   # thousands of equal values above most others: the cut falls inside the tie run
+    if B > 1:
+        s[1] = torch.round(s[1] * 64) / 64               # 65 distinct values: ties everywhere, in every chunk
+    if B > 2:
+        s[2] = 0.5                                       # all equal: the k lowest indices, all from chunk 0
+    sd_ = to_dev(s)
+    val = torch.empty(B, k, dtype=torch.float32, device=DEV)
+    idx = torch.empty(B, k, dtype=torch.int32, device=DEV)
+    nws = lib.fx_topk_rows_workspace_bytes(B, n, k)
+    assert nws > 0
+    ws = torch.empty(nws, dtype=torch.uint8, device=DEV)
+    check(lib.fx_topk_rows_ws_f32(sd_.data_ptr(), n, B, n, k, val.data_ptr(), idx.data_ptr(), ws.data_ptr(), nws, stream()))
+    torch.cuda.synchronize()
+    order = torch.sort(s, dim=1, descending=True, stable=True).indices[:, :k]
+    assert torch.equal(idx.cpu().long(), order), "indices must be bit-exact"
+    assert torch.equal(val.cpu(), s.gather(1, order))
+    # and identical to the one-level kernel
+    v1, i1 = torch.empty_like(val), torch.empty_like(idx)
+    check(lib.fx_topk_rows_f32(sd_.data_ptr(), n, B, n, k, v1.data_ptr(), i1.data_ptr(), stream()))
+    assert torch.equal(i1, idx) and torch.equal(v1, val)
+
+
 def test_rowmax_gather_fill(lib):
     g = torch.Generator().manual_seed(1)
     x = torch.randn(1000, 368, generator=g)
