@@ -14,6 +14,11 @@ CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libfocoos_amd.so")
 ARCH = "gfx950"
+# The kernels are compiled WITHOUT packed-fp32 VALU instructions (v_pk_mul/add/fma_f32, v_pk_mov_b32): on MI355X / ROCm 7.2 a wave that
+# executes them while waves of a second hardware queue are resident on its CU computes wrong values in lanes 48-63 of one operand
+# (DESIGN.md §5 "two-queue hazard": bisected to fx_bbox_head, per-lane dumps, 56-58 of 60 concurrent replays wrong with the feature on, 0 of
+# 60 with it off; single-queue execution is unaffected).  FX_PK_F32=1 re-enables them (the reproducer).
+EXTRA_FLAGS = [] if os.environ.get("FX_PK_F32", "0") == "1" else ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 
 
 def _hipcc() -> str:
@@ -43,7 +48,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = _hipcc()
     for src in sources():
         obj = os.path.join(LIB_DIR, os.path.basename(src).replace(".hip", ".o"))
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

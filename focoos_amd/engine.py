@@ -32,7 +32,7 @@ from ._lib import FX_ACT, FxConvDesc, FxPwChainDesc, FxRcStage, check
 from .state_spec import RESNET_BLOCKS
 
 BN_EPS = 1e-5
-DEFAULT_STREAMS = 1   # batch parts per step.  FX_STREAMS=2 (two half-batch parts on two streams) measured +7 % but is UNSAFE: see _MultiPlan
+DEFAULT_STREAMS = 2   # batch parts per step (two half-batch parts replayed concurrently: +9 %; see _MultiPlan).  FX_STREAMS=1: one part
 MIN_PART_BATCH = 4
 
 
@@ -926,15 +926,13 @@ class _Plan(_PlanBase):
 
 
 class _MultiPlan:
-    """EXPERIMENT, off by default (FX_STREAMS=2 / plan(..., nsplit=2)).  One step = `n` batch parts, each a complete plan of
-    B/n images with its own activation buffers, replayed concurrently on `n` streams so that an HBM-bound layer of one part
-    overlaps an MFMA-bound layer of another and fills its tail wave: +7 % on RT-DETR bs=32 (2727 -> 2973 img/s).
-    NOT SAFE on this stack (ROCm 7.2, MI355X): whenever the small decoder kernels of one part overlap the large conv kernels
-    of the other, some decoder rows are computed from stale inputs (30 of 40 replays had >= 1 wrong image; scripts/dev/
-    stability*.py).  Nothing is shared between the parts (guard bands around every buffer stay intact, FX_GUARD), the error
-    reproduces with plain eager launches on two streams and disappears with AMD_SERIALIZE_KERNEL=3, and a foreign torch matmul
-    stream beside ONE part does not trigger it - cross-queue visibility of kernel outputs between the per-XCD L2s is the open
-    suspect.  Parity comes first, so the product path runs one part; the class stays for the investigation.
+    """One step = `n` batch parts (default 2, FX_STREAMS), each a complete plan of B/n images with its own activation buffers, replayed
+    concurrently on `n` streams so that an HBM-bound layer of one part overlaps an MFMA-bound layer of another and fills its tail
+    wave: RT-DETR bs=32 3281 -> 3580 img/s.  Round 1 measured this and REJECTED it for correctness (30 of 40 replays had wrong decoder
+    rows); round 2 root-caused it: kernels containing packed-fp32 VALU instructions (v_pk_*_f32 / v_pk_mov_b32) compute wrong values in
+    lanes 48-63 when waves of a second hardware queue share their CU (first victim: fx_bbox_head; nothing is shared between the parts,
+    inputs bit-identical, per-lane dumps in DESIGN.md §5).  The library is compiled without that instruction class (build.py): 0 of 60
+    concurrent replays differ from the serial result (tests/test_gpu_two_streams.py asserts it).
     Inputs and outputs are single full-batch tensors (each part reads / writes its contiguous batch slice)."""
 
     def __init__(self, eng: _EngineBase, plan_cls, B: int, H: int, W: int, f32_input: bool, n: int, **kw):

@@ -1,10 +1,8 @@
-"""The two-queue hazard of DESIGN.md §5 as a test: the SAME two half-batch plans run (a) one after the other on one stream and
-(b) concurrently on two streams must give bit-identical buffers - they do not on ROCm 7.2 / MI355X, which is why the product
-path runs one part per step (FX_STREAMS=1).  Marked xfail: the day this passes, FX_STREAMS=2 (+8 % images/s) can become the default.
-Bisect evidence (scripts/dev/two_part_bisect.py, profiles/r02_two_queue_*.txt): the disturbed launch is fx_bbox_head of the victim
-queue (component 0 of some rows off by ~+0.2 although every input is bit-identical and cross-queue event fences separate the
-victim's launches), the disturbing launches are the bandwidth-heavy kernels of the other queue; generic probes of kernel->kernel
-visibility, LDS co-residency and wave reductions under a second queue's load are clean (tests/probes/two_queue_visibility.hip)."""
+"""Two concurrent batch parts (the default since round 2, engine._MultiPlan) must be bit-identical to the SAME two parts run one after
+the other on one stream.  Until round 2 they were not: kernels containing packed-fp32 VALU instructions compute wrong values in lanes
+48-63 when waves of a second hardware queue share their CU (bisection scripts/dev/two_part_bisect.py, profiles/
+r02_two_queue_*.txt).  The library is now compiled without that instruction class (focoos_amd/build.py); `FX_PK_F32=1 python -m
+focoos_amd.build --force` rebuilds the reproducer (56-58 of 60 replays wrong)."""
 import numpy as np
 import pytest
 import torch
@@ -12,7 +10,6 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.xfail(reason="cross-queue hazard on ROCm 7.2 / MI355X (DESIGN.md §5): concurrent batch parts are not bit-stable", strict=False)
 def test_two_concurrent_batch_parts_equal_serial_parts():
     from focoos_amd.model import FAIDetr
     from focoos_amd.registry import ModelRegistry
@@ -20,21 +17,54 @@ def test_two_concurrent_batch_parts_equal_serial_parts():
 
     cfg = ModelRegistry.get_model_info("fai-detr-l-obj365")["config"]
     eng = FAIDetr(cfg, device="cuda:0", seed=0).engine
-    B = 16
-    imgs = torch.from_numpy(np.stack([sis(100 + i, 320, 320) for i in range(B)])).to("cuda:0")
-    pl = eng.plan(B, 320, 320, False, 2)
+    B = 32
+    imgs = torch.from_numpy(np.stack([sis(100 + i) for i in range(B)])).to("cuda:0")
+    pl = eng.plan(B, 640, 640, False, 2)
     st = eng.stream
     with torch.cuda.stream(st):
         pl.input.copy_(imgs)
-        pl.sizes.copy_(torch.tensor([[320, 320]] * B, dtype=torch.int32))
+        pl.sizes.copy_(torch.tensor([[640, 640]] * B, dtype=torch.int32))
         for p in pl.parts:
             p._launch(p.ops, st.cuda_stream, 0.3)
     st.synchronize()
     ref = (pl.probs.clone(), pl.boxes.clone(), pl.det_count.clone())
     bad = 0
-    for _ in range(30):
+    for _ in range(60):
         with torch.cuda.stream(st):
             pl.run(st.cuda_stream, 0.3, None, True)
         st.synchronize()
         bad += not (torch.equal(ref[0], pl.probs) and torch.equal(ref[1], pl.boxes) and torch.equal(ref[2], pl.det_count))
-    assert bad == 0, f"{bad} of 30 concurrent replays differ from the serial result"
+    assert bad == 0, f"{bad} of 60 concurrent replays differ from the serial result"
+
+
+@pytest.mark.parametrize("family", ["fai_mf", "bisenetformer"])
+def test_two_concurrent_batch_parts_equal_serial_parts_mask_families(family):
+    """Same check for the MaskFormer (bs=8, 320x384) and BiSeNetFormer (bs=16, 384x512) engines: probabilities, low-resolution mask
+    probabilities and packed detections of 40 concurrent replays equal the serial run of the same two parts."""
+    from focoos_amd.model import BisenetFormer, FAIMaskFormer
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.synth import synth_image_structured as sis
+
+    if family == "fai_mf":
+        cfg, cls, B, H, W = ModelRegistry.get_model_info("fai-mf-l-coco-ins")["config"], FAIMaskFormer, 8, 320, 384
+    else:
+        cfg, cls, B, H, W = ModelRegistry.get_model_info("bisenetformer-l-ade")["config"], BisenetFormer, 16, 384, 512
+    eng = cls(cfg, device="cuda:0", seed=0).engine
+    imgs = torch.from_numpy(np.stack([sis(200 + i, H, W) for i in range(B)])).to("cuda:0")
+    pl = eng.plan(B, H, W, False, None, 2)
+    assert getattr(pl, "n", 1) == 2
+    st = eng.stream
+    with torch.cuda.stream(st):
+        pl.input.copy_(imgs)
+        for p in pl.parts:
+            p._launch(p.ops, st.cuda_stream, 0.3)
+    st.synchronize()
+    keys = ("probs", "mask_probs", "det_count", "det_scores", "det_boxes")
+    ref = {k: getattr(pl, k).clone() for k in keys}
+    bad = 0
+    for _ in range(40):
+        with torch.cuda.stream(st):
+            pl.run(st.cuda_stream, 0.3, None, True)
+        st.synchronize()
+        bad += not all(torch.equal(ref[k], getattr(pl, k)) for k in keys)
+    assert bad == 0, f"{bad} of 40 concurrent replays differ from the serial result"
