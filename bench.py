@@ -56,7 +56,7 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default run only: skip the short extra legs (RT-DETR / BiSeNetFormer training step, MaskFormer / BiSeNetFormer inference) "
                          "reported under `other_configs` of the one JSON line")
-    ap.add_argument("--other-configs-budget", type=float, default=240.0, help="seconds after which the extra legs are abandoned (watchdog)")
+    ap.add_argument("--other-configs-budget", type=float, default=180.0, help="seconds after which the extra legs are abandoned (watchdog)")
     a = ap.parse_args()
     a.default_run = len([x for x in sys.argv[1:] if x.startswith("--model") or x in ("--train", "--dry-run")]) == 0
     mf = a.model.startswith("fai-mf")
@@ -431,11 +431,12 @@ def other_configs(args, world, rank, local, out):
     timer = threading.Timer(args.other_configs_budget + (0 if rank == 0 else 5), bail)
     timer.daemon = True
     timer.start()
-    plan = [("train_fai-detr-l-obj365_bs16_640_frozenbn", dict(train=True, model="fai-detr-l-obj365", family="fai_detr", batch=16, size=640, norm="FrozenBN", steps=6, warmup=2)),
+    # inference legs first (replicas, no collective), the data-parallel training legs last
+    plan = [("infer_fai-mf-l-coco-ins_bs16_800", dict(train=False, model="fai-mf-l-coco-ins", family="fai_mf", batch=16, size=800, steps=10, warmup=3)),
+            ("infer_bisenetformer-l-ade_bs32_640", dict(train=False, model="bisenetformer-l-ade", family="bisenetformer", batch=32, size=640, steps=10, warmup=3)),
+            ("train_fai-detr-l-obj365_bs16_640_frozenbn", dict(train=True, model="fai-detr-l-obj365", family="fai_detr", batch=16, size=640, norm="FrozenBN", steps=6, warmup=2)),
             ("train_bisenetformer-l-ade_bs8_1024_bn", dict(train=True, model="bisenetformer-l-ade", family="bisenetformer", batch=8, size=1024,
-                                                          norm="SyncBN" if world > 1 else "BN", steps=4, warmup=2)),
-            ("infer_fai-mf-l-coco-ins_bs16_800", dict(train=False, model="fai-mf-l-coco-ins", family="fai_mf", batch=16, size=800, steps=10, warmup=3)),
-            ("infer_bisenetformer-l-ade_bs32_640", dict(train=False, model="bisenetformer-l-ade", family="bisenetformer", batch=32, size=640, steps=10, warmup=3))]
+                                                          norm="SyncBN" if world > 1 else "BN", steps=4, warmup=2))]
     for name, over in plan:
         a = copy.copy(args)
         for k, v in over.items():
