@@ -90,6 +90,8 @@ SIGNATURES = {
     "fx_lsa_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "fx_detr_set_loss_workspace_bytes": [_i, _i, _i],
     "fx_detr_set_loss_f32": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp],
+    "fx_detr_box_loss_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    "fx_detr_box_loss_bwd_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "fx_msda_f32_fwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "fx_msda_f32_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "fx_adamw_workspace_bytes": [],
@@ -108,7 +110,7 @@ SIGNATURES = {
     "fx_channel_gate_nhwc_bf16": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
     "fx_seg_postprocess_workspace_bytes": [_i, _i, _i, _i, _i, _i],
     "fx_seg_postprocess": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, C.c_float, _i, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "fx_pack_conv_weights_f32": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "fx_pack_conv_weights_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "fx_unpack_conv_wgrad_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "fx_conv2d_wgrad_splits": [_i, _i, _i, _i, _i, _i, _i],
     "fx_conv2d_wgrad_partial_nhwc_bf16": [_vp, _i, _vp, _i, _vp, C.c_int64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
@@ -116,7 +118,7 @@ SIGNATURES = {
     "fx_relu_bwd_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, C.c_int64, _i, _i, _vp],
     "fx_zero_insert2_nhwc_bf16": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "fx_avgpool2x2_bwd_nhwc_bf16": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
-    "fx_maxpool3x3s2_bwd_nhwc_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "fx_maxpool3x3s2_bwd_nhwc_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "fx_normalize_pad8": [_vp, _i, _vp, _vp, _vp, C.c_int64, _vp],
     "fx_stem_conv3x3s2_linear": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "fx_bn_stats_bf16": [_vp, _i, _i, _vp, C.c_int64, _i, _vp],

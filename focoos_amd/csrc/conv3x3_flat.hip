@@ -129,7 +129,8 @@ __global__ __launch_bounds__((WN* WM + LOADER) * 64, 1) void conv3x3_flat_kernel
     for (int a = 0; a < TN; ++a)
 #pragma unroll
       for (int gq = 0; gq < 4; ++gq) {
-        const float4 bb = *reinterpret_cast<const float4*>(p.bias + n0 + (wn * TN + a) * 32 + 8 * gq + 4 * half);
+        // bias == NULL: the input-gradient convolutions of the training path
+        const float4 bb = p.bias ? *reinterpret_cast<const float4*>(p.bias + n0 + (wn * TN + a) * 32 + 8 * gq + 4 * half) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int b = 0; b < TM; ++b) {
           acc[a][b][4 * gq] = bb.x; acc[a][b][4 * gq + 1] = bb.y; acc[a][b][4 * gq + 2] = bb.z; acc[a][b][4 * gq + 3] = bb.w;
@@ -272,6 +273,9 @@ __global__ __launch_bounds__((WN* WM + LOADER) * 64, 1) void conv3x3_flat_kernel
               v0 = v0 / (1.0f + __expf(-v0)); v1 = v1 / (1.0f + __expf(-v1)); v2 = v2 / (1.0f + __expf(-v2)); v3 = v3 / (1.0f + __expf(-v3));
             }
             if constexpr (RESMODE == 2) { v0 += r0; v1 += r1; v2 += r2; v3 += r3; }       // act(conv) + residual
+            if constexpr (RESMODE == 3) {   // act(conv) * (residual > 0): the ReLU backward of the layer that produced `residual`
+              v0 = r0 > 0.0f ? v0 : 0.0f; v1 = r1 > 0.0f ? v1 : 0.0f; v2 = r2 > 0.0f ? v2 : 0.0f; v3 = r3 > 0.0f ? v3 : 0.0f;
+            }
             uint2 o;
             o.x = pack_bf16x2(v0, v1);
             o.y = pack_bf16x2(v2, v3);
@@ -321,6 +325,8 @@ int fx_c3_epilogue_mode(int act, bool has_res, int res_after) {
   if (!has_res) return act == FX_ACT_RELU ? 0 : (act == FX_ACT_SILU ? 1 : (act == FX_ACT_NONE ? 3 : -1));
   if (act == FX_ACT_SILU && res_after == 1) return 2;
   if (act == FX_ACT_RELU && res_after == 0) return 4;
+  if (act == FX_ACT_NONE && res_after == 2) return 5;   // training: input gradient masked by the saved ReLU output
+  if (act == FX_ACT_NONE && res_after == 0) return 6;   // training: input gradient + the shortcut branch's gradient (pointwise only)
   return -1;
 }
 
@@ -357,6 +363,7 @@ int fx_launch_conv3x3_flat(const ConvArgs& c, const bf16_t* w_frag, hipStream_t 
     case 1: FX_C3_TILE(FX_ACT_SILU, 0)
     case 2: FX_C3_TILE(FX_ACT_SILU, 2)
     case 3: FX_C3_TILE(FX_ACT_NONE, 0)
+    case 5: FX_C3_TILE(FX_ACT_NONE, 3)
     default: return FX_ERR_UNSUPPORTED;
   }
 #undef FX_C3_TILE
@@ -374,6 +381,8 @@ int fx_launch_pw_flat(const ConvArgs& c, const bf16_t* w_frag, hipStream_t strea
       case 1: return launch_c3<1, 256, 2, 4, 4, 1, FX_ACT_SILU, 0, 0>(a, stream);
       case 3: return launch_c3<1, 256, 2, 4, 4, 1, FX_ACT_NONE, 0, 0>(a, stream);
       case 4: return launch_c3<1, 256, 2, 4, 4, 1, FX_ACT_RELU, 1, 0>(a, stream);
+      case 5: return launch_c3<1, 256, 2, 4, 4, 1, FX_ACT_NONE, 3, 0>(a, stream);
+      case 6: return launch_c3<1, 256, 2, 4, 4, 1, FX_ACT_NONE, 1, 0>(a, stream);
       default: return FX_ERR_UNSUPPORTED;
     }
   }
@@ -382,6 +391,8 @@ int fx_launch_pw_flat(const ConvArgs& c, const bf16_t* w_frag, hipStream_t strea
     case 1: return launch_c3<1, 256, 2, 4, 4, 1, FX_ACT_SILU, 0>(a, stream);
     case 3: return launch_c3<1, 256, 2, 4, 4, 1, FX_ACT_NONE, 0>(a, stream);
     case 4: return launch_c3<1, 256, 2, 4, 4, 1, FX_ACT_RELU, 1>(a, stream);
+    case 5: return launch_c3<1, 256, 2, 4, 4, 1, FX_ACT_NONE, 3>(a, stream);
+    case 6: return launch_c3<1, 256, 2, 4, 4, 1, FX_ACT_NONE, 1>(a, stream);
     default: return FX_ERR_UNSUPPORTED;
   }
 }

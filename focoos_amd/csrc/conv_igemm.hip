@@ -316,11 +316,11 @@ extern "C" int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream_) {
   const int c3_min_m = fx_tune("FX_CONV3_MIN_M", 20000), pw_min_m = fx_tune("FX_PW_MIN_M", 20000);
   if (d->w_frag && ((uintptr_t)d->w_frag % 16) == 0 && d->stride == 1 && !d->pool2 && !d->out_f32) {
     const int mode = fx_c3_epilogue_mode(d->act, d->residual != nullptr, d->residual_after_act);
-    if (c3_on && d->KH == 3 && d->KW == 3 && d->pad == 1 && !d->y_batch_stride && mode >= 0 && mode <= 3 && a.M >= c3_min_m &&
+    if (c3_on && d->KH == 3 && d->KW == 3 && d->pad == 1 && !d->y_batch_stride && ((mode >= 0 && mode <= 3) || mode == 5) && a.M >= c3_min_m &&
         fx_conv3x3_flat_supported(d->C, d->N, d->W))
       return fx_launch_conv3x3_flat(a, reinterpret_cast<const bf16_t*>(d->w_frag), stream);
     if (pw_on && d->KH == 1 && d->KW == 1 && d->pad == 0 && d->C % 256 == 0 && d->N % 256 == 0 && a.M >= pw_min_m &&
-        (mode == 0 || mode == 1 || mode == 3 || mode == 4))
+        (mode == 0 || mode == 1 || (mode >= 3 && mode <= 6)))
       return fx_launch_pw_flat(a, reinterpret_cast<const bf16_t*>(d->w_frag), stream);
   }
   // BK=64 (2 workgroups/CU, 64 KiB LDS) for deep-K compute-bound layers; BK=32 (4 workgroups/CU, 34 KiB LDS: more

@@ -28,14 +28,37 @@ __global__ __launch_bounds__(256) void pack_conv_weights_kernel(const float* __r
   }
 }
 
-extern "C" int fx_pack_conv_weights_f32(const float* w, const float* scale, void* w_fwd, void* w_dgrad, int N, int C, int KH, int KW,
-                                        fx_stream_t stream_) {
+// [rows][K] bf16 weight image -> MFMA fragment order [rows/32][K/16][lane][8] (fx_conv_desc.w_frag): lane l of fragment (nb, ks) holds
+// w[nb*32 + l%32][ks*16 + (l/32)*8 .. +8] - a permutation of 16-byte chunks, coalesced on the store side
+__global__ __launch_bounds__(256) void frag_from_rows_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ frag, int rows, int K) {
+  const int K16 = K / 16;
+  const int64_t total = (int64_t)rows * K / 8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int l = (int)(i & 63);
+    const int64_t f = i >> 6;
+    const int ks = (int)(f % K16);
+    const int nb = (int)(f / K16);
+    *reinterpret_cast<uint4*>(frag + i * 8) =
+        *reinterpret_cast<const uint4*>(w + ((int64_t)nb * 32 + (l & 31)) * K + ks * 16 + (l >> 5) * 8);
+  }
+}
+
+extern "C" int fx_pack_conv_weights_f32(const float* w, const float* scale, void* w_fwd, void* w_dgrad, void* w_fwd_frag, void* w_dgrad_frag,
+                                        int N, int C, int KH, int KW, fx_stream_t stream_) {
   FX_CHECK_ARG(w && (w_fwd || w_dgrad) && N > 0 && C > 0 && KH > 0 && KW > 0);
+  FX_CHECK_ARG(!w_fwd_frag || (w_fwd && N % 32 == 0 && (KH * KW * C) % 16 == 0 && ((uintptr_t)w_fwd_frag % 16) == 0 && ((uintptr_t)w_fwd % 16) == 0));
+  FX_CHECK_ARG(!w_dgrad_frag || (w_dgrad && C % 32 == 0 && (KH * KW * N) % 16 == 0 && ((uintptr_t)w_dgrad_frag % 16) == 0 && ((uintptr_t)w_dgrad % 16) == 0));
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   int64_t total = (int64_t)N * C * KH * KW;
   int64_t grid = (total + 255) / 256;
   if (grid > 4096) grid = 4096;
-  hipLaunchKernelGGL(pack_conv_weights_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), w, scale,
-                     (bf16_t*)w_fwd, (bf16_t*)w_dgrad, N, C, KH, KW);
+  hipLaunchKernelGGL(pack_conv_weights_kernel, dim3((int)grid), dim3(256), 0, stream, w, scale, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, N, C, KH, KW);
+  grid = (total / 8 + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  if (w_fwd_frag)
+    hipLaunchKernelGGL(frag_from_rows_kernel, dim3((int)grid), dim3(256), 0, stream, (const bf16_t*)w_fwd, (bf16_t*)w_fwd_frag, N, KH * KW * C);
+  if (w_dgrad_frag)
+    hipLaunchKernelGGL(frag_from_rows_kernel, dim3((int)grid), dim3(256), 0, stream, (const bf16_t*)w_dgrad, (bf16_t*)w_dgrad_frag, C, KH * KW * N);
   return fx_launch_status();
 }
 
@@ -219,10 +242,50 @@ extern "C" int fx_avgpool2x2_bwd_nhwc_bf16(const void* dp, int lddp, void* dx, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// MaxPool2d(3, 2, 1) backward, gather form (no atomics, deterministic): an input pixel receives dy of every window whose
-// arg-max it is.  PyTorch's CPU/GPU kernels keep the FIRST maximum in window scan order (kh-major) - after a ReLU ties
-// (zeros) are common, so the scan order is reproduced: a later tap wins only if strictly greater.
-__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ dy, int lddy,
+// MaxPool2d(3, 2, 1) backward, gather form (no atomics, deterministic), two passes:
+//   1. per output window: the tap (kh*3 + kw) of its maximum -> one byte per output element.  PyTorch's CPU/GPU kernels keep the FIRST
+//      maximum in window scan order (kh-major) - after a ReLU ties (zeros) are common, so the scan order is reproduced: a later tap wins
+//      only if strictly greater;
+//   2. per input pixel: dy of every window (1, 2 or 4 of them) whose recorded tap it is.
+// (A single pass that re-derives the arg-max of each of the up to 4 windows per input pixel reads 36 taps per pixel through the
+// caches: 0.75 ms for the [16,320,320,64] stem activation; the arg-max bytes cut that to 9 taps per WINDOW plus <= 4 x 24 bytes per pixel.)
+__global__ __launch_bounds__(256) void maxpool3x3s2_argmax_kernel(const bf16_t* __restrict__ x, int ldx, unsigned char* __restrict__ arg, int B,
+                                                                  int H, int W, int C8, int Ho, int Wo) {
+  const int64_t total = (int64_t)B * Ho * Wo * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    int64_t p = i / C8;
+    const int wo = (int)(p % Wo);
+    p /= Wo;
+    const int ho = (int)(p % Ho);
+    const int b = (int)(p / Ho);
+    float best[8];
+    int tap[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) best[j] = -INFINITY, tap[j] = -1;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int hi = ho * 2 - 1 + kh;
+      if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int wi = wo * 2 - 1 + kw;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        float f[8];
+        unpack_bf16x8(*reinterpret_cast<const uint4*>(x + (((int64_t)b * H + hi) * W + wi) * ldx + c8 * 8), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (f[j] > best[j] || tap[j] < 0) best[j] = f[j], tap[j] = kh * 3 + kw;
+      }
+    }
+    uint2 o;
+    o.x = (unsigned)tap[0] | ((unsigned)tap[1] << 8) | ((unsigned)tap[2] << 16) | ((unsigned)tap[3] << 24);
+    o.y = (unsigned)tap[4] | ((unsigned)tap[5] << 8) | ((unsigned)tap[6] << 16) | ((unsigned)tap[7] << 24);
+    *reinterpret_cast<uint2*>(arg + i * 8) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const unsigned char* __restrict__ arg, const bf16_t* __restrict__ dy, int lddy,
                                                                bf16_t* __restrict__ dx, int lddx, int B, int H, int W, int C8, int Ho,
                                                                int Wo) {
   const int64_t total = (int64_t)B * H * W * C8;
@@ -235,50 +298,52 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const bf16_t* __r
     const int b = (int)(p / H);
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // windows (ho, wo) with 2*ho - 1 <= yi <= 2*ho + 1
-    const int ho_lo = max((yi - 1 + 1) / 2, 0), ho_hi = min((yi + 1) / 2, Ho - 1);
-    const int wo_lo = max((xi - 1 + 1) / 2, 0), wo_hi = min((xi + 1) / 2, Wo - 1);
+    const int ho_lo = max(yi / 2, 0), ho_hi = min((yi + 1) / 2, Ho - 1);
+    const int wo_lo = max(xi / 2, 0), wo_hi = min((xi + 1) / 2, Wo - 1);
     for (int ho = ho_lo; ho <= ho_hi; ++ho)
       for (int wo = wo_lo; wo <= wo_hi; ++wo) {
-        float best[8];
-        int arg[8];
+        const unsigned me = (unsigned)((yi - (ho * 2 - 1)) * 3 + (xi - (wo * 2 - 1)));
+        const int64_t w = (((int64_t)b * Ho + ho) * Wo + wo);
+        const uint2 a = *reinterpret_cast<const uint2*>(arg + (w * C8 + c8) * 8);
+        if (a.x == me * 0x01010101u && a.y == a.x) {   // all eight channels chose this pixel
+          float g[8];
+          unpack_bf16x8(*reinterpret_cast<const uint4*>(dy + w * lddy + c8 * 8), g);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) best[j] = -INFINITY, arg[j] = -1;
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh) {
-          const int hi = ho * 2 - 1 + kh;
-          if ((unsigned)hi >= (unsigned)H) continue;
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int wi = wo * 2 - 1 + kw;
-            if ((unsigned)wi >= (unsigned)W) continue;
-            float f[8];
-            unpack_bf16x8(*reinterpret_cast<const uint4*>(x + (((int64_t)b * H + hi) * W + wi) * ldx + c8 * 8), f);
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (f[j] > best[j] || arg[j] < 0) best[j] = f[j], arg[j] = hi * W + wi;
-          }
+          for (int j = 0; j < 8; ++j) acc[j] += g[j];
+          continue;
         }
-        float g[8];
-        unpack_bf16x8(*reinterpret_cast<const uint4*>(dy + (((int64_t)b * Ho + ho) * Wo + wo) * lddy + c8 * 8), g);
-        const int me = yi * W + xi;
+        bool any = false;
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-          if (arg[j] == me) acc[j] += g[j];
+        for (int j = 0; j < 4; ++j) any |= ((a.x >> (8 * j)) & 0xffu) == me || ((a.y >> (8 * j)) & 0xffu) == me;
+        if (!any) continue;
+        float g[8];
+        unpack_bf16x8(*reinterpret_cast<const uint4*>(dy + w * lddy + c8 * 8), g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (((a.x >> (8 * j)) & 0xffu) == me) acc[j] += g[j];
+          if (((a.y >> (8 * j)) & 0xffu) == me) acc[4 + j] += g[4 + j];
+        }
       }
     *reinterpret_cast<uint4*>(dx + (((int64_t)b * H + yi) * W + xi) * lddx + c8 * 8) = pack_bf16x8(acc);
   }
 }
 
 extern "C" int fx_maxpool3x3s2_bwd_nhwc_bf16(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int B, int H, int W, int C,
-                                             fx_stream_t stream_) {
-  FX_CHECK_ARG(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0);
-  FX_CHECK_ARG(ldx >= C && lddy >= C && lddx >= C && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0);
+                                             void* workspace, fx_stream_t stream_) {
+  FX_CHECK_ARG(x && dy && dx && workspace && B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0);
+  FX_CHECK_ARG(ldx >= C && lddy >= C && lddx >= C && ldx % 8 == 0 && lddy % 8 == 0 && lddx % 8 == 0 && ((uintptr_t)workspace % 8) == 0);
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  int64_t total = (int64_t)B * H * W * (C / 8);
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  int64_t total = (int64_t)B * Ho * Wo * (C / 8);
   int64_t grid = (total + 255) / 256;
   if (grid > 256 * 32) grid = 256 * 32;
-  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)x, ldx,
-                     (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, B, H, W, C / 8, Ho, Wo);
+  hipLaunchKernelGGL(maxpool3x3s2_argmax_kernel, dim3((int)grid), dim3(256), 0, stream, (const bf16_t*)x, ldx, (unsigned char*)workspace, B, H, W,
+                     C / 8, Ho, Wo);
+  total = (int64_t)B * H * W * (C / 8);
+  grid = (total + 255) / 256;
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3((int)grid), dim3(256), 0, stream, (const unsigned char*)workspace, (const bf16_t*)dy, lddy,
+                     (bf16_t*)dx, lddx, B, H, W, C / 8, Ho, Wo);
   return fx_launch_status();
 }
 

@@ -185,24 +185,38 @@ class _VFLFn(torch.autograd.Function):
         return dl * g.to(dl.dtype), None, None, None, None, None
 
 
-def _box_xyxy(b):
-    cx, cy, w, h = b.unbind(-1)
-    return torch.stack([cx - 0.5 * w, cy - 0.5 * h, cx + 0.5 * w, cy + 0.5 * h], -1)
+class _BoxLossFn(torch.autograd.Function):
+    """loss_bbox, loss_giou of one prediction set (weights and 1 / num_boxes applied) through fx_detr_box_loss_f32; also fills the
+    per-query VFL targets ``cls`` / ``score`` (no gradient: the IoU target is detached in the reference, modelling.py:474-476)."""
 
+    @staticmethod
+    def forward(ctx, boxes, tg: _Targets, pi, ti, K, scale_bbox, scale_giou, cls, score):
+        lib = _lib.load()
+        B, Q, _ = boxes.shape
+        bx = boxes.contiguous()
+        dev = bx.device
+        loss2 = torch.empty(2, dtype=torch.float32, device=dev)
+        pair_grad = torch.empty(max(tg.n, 1), 8, dtype=torch.float32, device=dev)
+        check(lib.fx_detr_box_loss_f32(bx.data_ptr(), tg.labels.data_ptr(), tg.boxes.data_ptr(), tg.offsets.data_ptr(), pi.data_ptr(), ti.data_ptr(),
+                                       B, Q, K, tg.n, float(scale_bbox), float(scale_giou), cls.data_ptr(), score.data_ptr(), loss2.data_ptr(),
+                                       pair_grad.data_ptr(), _stream(dev)), "fx_detr_box_loss_f32")
+        ctx.tg, ctx.pi, ctx.shape = tg, pi, (B, Q)
+        ctx.save_for_backward(pair_grad)
+        return loss2[0], loss2[1]
 
-def _pair_iou_giou(a, b):
-    """IoU and GIoU of matched pairs (focoos/utils/box.py:27-64 restricted to the diagonal), xyxy."""
-    area_a = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1])
-    area_b = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
-    lt, rb = torch.max(a[:, :2], b[:, :2]), torch.min(a[:, 2:], b[:, 2:])
-    wh = (rb - lt).clamp(min=0)
-    inter = wh[:, 0] * wh[:, 1]
-    union = area_a + area_b - inter
-    iou = inter / union
-    lt2, rb2 = torch.min(a[:, :2], b[:, :2]), torch.max(a[:, 2:], b[:, 2:])
-    wh2 = (rb2 - lt2).clamp(min=0)
-    area = wh2[:, 0] * wh2[:, 1]
-    return iou, iou - (area - union) / (area + 1e-5)
+    @staticmethod
+    def backward(ctx, g_bbox, g_giou):
+        lib = _lib.load()
+        (pair_grad,) = ctx.saved_tensors
+        B, Q = ctx.shape
+        dev = pair_grad.device
+        dboxes = torch.empty(B, Q, 4, dtype=torch.float32, device=dev)
+        g1 = None if g_bbox is None else g_bbox.float().contiguous()
+        g2 = None if g_giou is None else g_giou.float().contiguous()
+        check(lib.fx_detr_box_loss_bwd_f32(pair_grad.data_ptr(), ctx.tg.offsets.data_ptr(), ctx.pi.data_ptr(), B, Q, ctx.tg.n,
+                                           None if g1 is None else g1.data_ptr(), None if g2 is None else g2.data_ptr(), dboxes.data_ptr(),
+                                           _stream(dev)), "fx_detr_box_loss_bwd_f32")
+        return dboxes, None, None, None, None, None, None, None, None
 
 
 class SetCriterionTrain(nn.Module):
@@ -217,31 +231,19 @@ class SetCriterionTrain(nn.Module):
         self.alpha, self.gamma = alpha, gamma
         self.register_buffer("empty_weight", torch.ones(nc + 1))  # checkpoint key head.criterion.empty_weight
 
-    def _one_set(self, out, tg: _Targets, slot_b, num_boxes, fixed=None):
+    def _one_set(self, out, tg: _Targets, num_boxes, fixed=None):
         logits, boxes = out["pred_logits"], out["pred_boxes"].float()
         B, Q, K = logits.shape
         dev = logits.device
         if fixed is None:
             pi, ti = self.matcher.match_packed(logits.detach(), boxes.detach(), tg)
         else:
-            pi, ti = fixed
+            pi, ti = (t.to(torch.int32).contiguous() for t in fixed)
         losses = {}
-        cls = torch.full((B * Q,), K, dtype=torch.int32, device=dev)
-        score = torch.zeros(B * Q, dtype=torch.float32, device=dev)
-        if tg.n:
-            q = pi[: tg.n].long()
-            t = tg.offsets[:-1].long()[slot_b] + ti[: tg.n].long()
-            src = boxes[slot_b, q]
-            tb = tg.boxes[t]
-            iou, giou = _pair_iou_giou(_box_xyxy(src), _box_xyxy(tb))
-            flat = slot_b * Q + q
-            cls[flat] = tg.labels[t]
-            score[flat] = iou.detach()
-            losses["loss_bbox"] = self.w["loss_bbox"] * (src - tb).abs().sum() / num_boxes
-            losses["loss_giou"] = self.w["loss_giou"] * (1 - giou).sum() / num_boxes
-        else:
-            z = boxes.sum() * 0
-            losses["loss_bbox"], losses["loss_giou"] = z, z
+        cls = torch.empty(B * Q, dtype=torch.int32, device=dev)      # filled by the kernel: matched label or K (no object)
+        score = torch.empty(B * Q, dtype=torch.float32, device=dev)  # IoU of the matched pair or 0
+        losses["loss_bbox"], losses["loss_giou"] = _BoxLossFn.apply(boxes, tg, pi, ti, K, self.w["loss_bbox"] / num_boxes,
+                                                                    self.w["loss_giou"] / num_boxes, cls, score)
         losses["loss_vfl"] = _VFLFn.apply(logits, cls, score, self.alpha, self.gamma, self.w["loss_vfl"] / num_boxes)
         return losses, (pi, ti)
 
@@ -254,11 +256,10 @@ class SetCriterionTrain(nn.Module):
             num_boxes = max(float(num.item()) / torch.distributed.get_world_size(), 1.0)
         else:
             num_boxes = max(float(tg.n), 1.0)     # single process: a host integer - no device round trip, the launch queue keeps running ahead
-        slot_b = h2d_i32(np.repeat(np.arange(len(targets)), np.diff(tg.off_host)), dev).long()
         sets = [("", outputs)] + [(f"_{i}", a) for i, a in enumerate(outputs.get("aux_outputs", []))]
         losses, matches = {}, []
         for j, (suffix, o) in enumerate(sets):
-            l, m = self._one_set(o, tg, slot_b, num_boxes, None if fixed_matches is None else fixed_matches[j])
+            l, m = self._one_set(o, tg, num_boxes, None if fixed_matches is None else fixed_matches[j])
             matches.append(m)
             for k, v in l.items():
                 losses[k + suffix] = v

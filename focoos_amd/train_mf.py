@@ -93,7 +93,7 @@ class ConvBias(nn.Module):
                 self.w_dgrad = torch.zeros(Cp, k, k, N, dtype=torch.bfloat16, device=dev)
                 self.shift = torch.zeros(Np, dtype=torch.float32, device=dev)
             self.shift[:N] = b
-            check(self.lib.fx_pack_conv_weights_f32(w.data_ptr(), None, self.w_fwd.data_ptr(), self.w_dgrad.data_ptr(), N, Cc, k, k, _stream(dev)),
+            check(self.lib.fx_pack_conv_weights_f32(w.data_ptr(), None, self.w_fwd.data_ptr(), self.w_dgrad.data_ptr(), None, None, N, Cc, k, k, _stream(dev)),
                   "fx_pack_conv_weights_f32")
         self._ver = ver
 

@@ -93,16 +93,20 @@ _DESC_CACHE: Dict[tuple, tuple] = {}
 
 
 def _conv_call(lib, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], N: int, KH: int, KW: int, stride: int, pad: int,
-               act: Optional[str], residual: Optional[torch.Tensor], res_mode: int = 0, out_f32: bool = False) -> torch.Tensor:
-    """fx_conv2d_nhwc_bf16 on NHWC bf16 tensors; ``w`` is a packed [Npad][KH][KW][C] bf16 image.  ``res_mode``: 0 = add ``residual``
-    before the activation, 2 = multiply by (residual > 0) - the ReLU backward of the layer that produced ``residual``."""
+               act: Optional[str], residual: Optional[torch.Tensor], res_mode: int = 0, out_f32: bool = False,
+               w_frag: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fx_conv2d_nhwc_bf16 on NHWC bf16 tensors; ``w`` is a packed [Npad][KH][KW][C] bf16 image, ``w_frag`` its optional copy in MFMA
+    fragment order (routes eligible layers to the halo / pointwise kernels).  ``res_mode``: 0 = add ``residual`` before the activation,
+    2 = multiply by (residual > 0) - the ReLU backward of the layer that produced ``residual``."""
     B, H, W_, Cc = x.shape
-    key = (w.data_ptr(), bias.data_ptr() if bias is not None else 0, B, H, W_, Cc, N, KH, KW, stride, pad, act, residual is not None, res_mode, out_f32)
+    key = (w.data_ptr(), bias.data_ptr() if bias is not None else 0, B, H, W_, Cc, N, KH, KW, stride, pad, act, residual is not None, res_mode, out_f32,
+           w_frag.data_ptr() if w_frag is not None else 0)
     ent = _DESC_CACHE.get(key)
     if ent is None:
         Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W_ + 2 * pad - KW) // stride + 1
         d = FxConvDesc()
         d.w = w.data_ptr()
+        d.w_frag = w_frag.data_ptr() if w_frag is not None else None
         d.bias = bias.data_ptr() if bias is not None else None
         d.B, d.H, d.W, d.C, d.ldx = B, H, W_, Cc, Cc
         d.Ho, d.Wo, d.N, d.ldy, d.ldr = Ho, Wo, N, N, N if residual is not None else 0
@@ -120,6 +124,18 @@ def _conv_call(lib, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tenso
     return y
 
 
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _frag_eligible(rows: int, cin: int, k: int) -> bool:
+    """Shapes fx_conv2d_nhwc_bf16 can run on the kernels of conv3x3_flat.hip, given the weight copy in fragment order (``rows`` output
+    channels, ``cin`` input channels of the convolution that USES the image - swapped for the input-gradient convolution)."""
+    if k == 3:
+        return rows in (64, 128, 256) and cin % 64 == 0
+    return k == 1 and rows % 256 == 0 and cin % 256 == 0
+
+
 class _ConvBnActFn(torch.autograd.Function):
     """y = act(conv(x, W * s) + (beta - mu * s) [+ residual]) with s = gamma / sqrt(var + eps) frozen."""
 
@@ -129,7 +145,8 @@ class _ConvBnActFn(torch.autograd.Function):
         layer.sync_packed()
         N, Cc, KH, KW = weight.shape
         fused = layer.act in (None, "relu")
-        z = _conv_call(lib, x, layer.w_fwd, layer.shift, N, KH, KW, layer.stride, layer.pad, layer.act if fused else None, residual)
+        z = _conv_call(lib, x, layer.w_fwd, layer.shift, N, KH, KW, layer.stride, layer.pad, layer.act if fused else None, residual,
+                       w_frag=layer.w_fwd_frag)
         y = z if fused else _act_fwd(lib, z, layer.act)  # SiLU / GELU: the backward needs the pre-activation
         ctx.layer = layer
         ctx.has_res = residual is not None
@@ -280,7 +297,7 @@ def _conv_input_grad(layer, dz: torch.Tensor, x_shape) -> torch.Tensor:
     else:  # stride 2: zero-insert, then the stride-1 transposed filter
         src = torch.empty(B, H, W_, N, dtype=torch.bfloat16, device=dev)
         check(lib.fx_zero_insert2_nhwc_bf16(dz.data_ptr(), N, src.data_ptr(), N, B, Ho, Wo, H, W_, N, _stream(dev)), "fx_zero_insert2_nhwc_bf16")
-    return _conv_call(lib, src, layer.w_dgrad, None, Cc, layer.k, layer.k, 1, layer.pad, None, None)
+    return _conv_call(lib, src, layer.w_dgrad, None, Cc, layer.k, layer.k, 1, layer.pad, None, None, w_frag=layer.w_dgrad_frag)
 
 
 class _ConvBnTrainFn(torch.autograd.Function):
@@ -336,6 +353,7 @@ class ConvNormLayer(nn.Module):
         norm.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
         self._packed_version = None
         self.w_fwd = self.w_dgrad = self.scale = self.shift = None
+        self.w_fwd_frag = self.w_dgrad_frag = None   # MFMA-fragment-order copies for the halo / pointwise kernels (eligible shapes only)
 
     @property
     def batch_stats(self) -> bool:
@@ -375,8 +393,12 @@ class ConvNormLayer(nn.Module):
             if self.w_fwd is None or self.w_fwd.device != dev:
                 self.w_fwd = torch.zeros(Np, k, k, Cc, dtype=torch.bfloat16, device=dev)
                 self.w_dgrad = torch.zeros(Cp, k, k, N, dtype=torch.bfloat16, device=dev)
+                self.w_fwd_frag = (torch.empty(N * k * k * Cc, dtype=torch.bfloat16, device=dev)
+                                   if self.stride == 1 and _frag_eligible(N, Cc, k) else None)
+                self.w_dgrad_frag = torch.empty(N * k * k * Cc, dtype=torch.bfloat16, device=dev) if _frag_eligible(Cc, N, k) else None
             check(self.lib.fx_pack_conv_weights_f32(w.data_ptr(), None if live else self.scale.data_ptr(), self.w_fwd.data_ptr(),
-                                                    self.w_dgrad.data_ptr(), N, Cc, k, k, _stream(dev)), "fx_pack_conv_weights_f32")
+                                                    self.w_dgrad.data_ptr(), _ptr(self.w_fwd_frag), _ptr(self.w_dgrad_frag), N, Cc, k, k,
+                                                    _stream(dev)), "fx_pack_conv_weights_f32")
         self._packed_version = ver
 
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -522,8 +544,9 @@ class _PoolFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         if ctx.kind == "max":
-            check(lib.fx_maxpool3x3s2_bwd_nhwc_bf16(x.data_ptr(), Cc, dy.data_ptr(), Cc, dx.data_ptr(), Cc, B, H, W_, Cc, _stream(x.device)),
-                  "fx_maxpool3x3s2_bwd_nhwc_bf16")
+            arg = torch.empty(dy.numel(), dtype=torch.uint8, device=x.device)   # arg-max tap per output element
+            check(lib.fx_maxpool3x3s2_bwd_nhwc_bf16(x.data_ptr(), Cc, dy.data_ptr(), Cc, dx.data_ptr(), Cc, B, H, W_, Cc, arg.data_ptr(),
+                                                    _stream(x.device)), "fx_maxpool3x3s2_bwd_nhwc_bf16")
         else:
             check(lib.fx_avgpool2x2_bwd_nhwc_bf16(dy.data_ptr(), Cc, dx.data_ptr(), Cc, B, H, W_, Cc, _stream(x.device)), "fx_avgpool2x2_bwd_nhwc_bf16")
         return dx, None, None
@@ -556,8 +579,8 @@ class _BottleneckFn(torch.autograd.Function):
         lib = a_l.lib
         for l in (a_l, b_l, c_l):
             l.sync_packed()
-        a = _conv_call(lib, x, a_l.w_fwd, a_l.shift, a_l.cout, 1, 1, 1, 0, "relu", None)
-        b = _conv_call(lib, a, b_l.w_fwd, b_l.shift, b_l.cout, 3, 3, b_l.stride, 1, "relu", None)
+        a = _conv_call(lib, x, a_l.w_fwd, a_l.shift, a_l.cout, 1, 1, 1, 0, "relu", None, w_frag=a_l.w_fwd_frag)
+        b = _conv_call(lib, a, b_l.w_fwd, b_l.shift, b_l.cout, 3, 3, b_l.stride, 1, "relu", None, w_frag=b_l.w_fwd_frag)
         pooled = None
         if blk.has_short:
             s_l = blk.short.conv if isinstance(blk.short, _Short) else blk.short
@@ -568,10 +591,10 @@ class _BottleneckFn(torch.autograd.Function):
                 pooled = torch.empty(B, (H + 1) // 2, (W_ + 1) // 2, Cc, dtype=torch.bfloat16, device=x.device)
                 check(lib.fx_avgpool2x2_nhwc_bf16(x.data_ptr(), Cc, pooled.data_ptr(), Cc, B, H, W_, Cc, _stream(x.device)), "fx_avgpool2x2_nhwc_bf16")
                 sx = pooled
-            short = _conv_call(lib, sx, s_l.w_fwd, s_l.shift, s_l.cout, 1, 1, 1, 0, None, None)
+            short = _conv_call(lib, sx, s_l.w_fwd, s_l.shift, s_l.cout, 1, 1, 1, 0, None, None, w_frag=s_l.w_fwd_frag)
         else:
             short = x
-        y = _conv_call(lib, b, c_l.w_fwd, c_l.shift, c_l.cout, 1, 1, 1, 0, "relu", short)
+        y = _conv_call(lib, b, c_l.w_fwd, c_l.shift, c_l.cout, 1, 1, 1, 0, "relu", short, w_frag=c_l.w_fwd_frag)
         ctx.blk = blk
         ctx.save_for_backward(x, a, b, y, pooled)
         return y
@@ -589,7 +612,7 @@ class _BottleneckFn(torch.autograd.Function):
         check(lib.fx_relu_bwd_bf16(dy.data_ptr(), N, None, 0, y.data_ptr(), N, dz_c.data_ptr(), N, B * Ho * Wo, N, 1, st), "fx_relu_bwd_bf16")
         need = ctx.needs_input_grad
         dwc = _conv_param_grads(c_l, b, dz_c, c_l.scale) if need[3] else None
-        dz_b = _conv_call(lib, dz_c, c_l.w_dgrad, None, c_l.cin, 1, 1, 1, 0, None, b, res_mode=2)       # dgrad_c * relu'(b)
+        dz_b = _conv_call(lib, dz_c, c_l.w_dgrad, None, c_l.cin, 1, 1, 1, 0, None, b, res_mode=2, w_frag=c_l.w_dgrad_frag)       # dgrad_c * relu'(b)
         dwb = _conv_param_grads(b_l, a, dz_b, b_l.scale) if need[2] else None
         if b_l.stride == 1:
             src = dz_b
@@ -598,7 +621,7 @@ class _BottleneckFn(torch.autograd.Function):
             src = torch.empty(Ba, Ha, Wa, b_l.cout, dtype=torch.bfloat16, device=dev)
             check(lib.fx_zero_insert2_nhwc_bf16(dz_b.data_ptr(), b_l.cout, src.data_ptr(), b_l.cout, Ba, dz_b.shape[1], dz_b.shape[2], Ha, Wa, b_l.cout, st),
                   "fx_zero_insert2_nhwc_bf16")
-        dz_a = _conv_call(lib, src, b_l.w_dgrad, None, b_l.cin, 3, 3, 1, 1, None, a, res_mode=2)       # dgrad_b * relu'(a)
+        dz_a = _conv_call(lib, src, b_l.w_dgrad, None, b_l.cin, 3, 3, 1, 1, None, a, res_mode=2, w_frag=b_l.w_dgrad_frag)       # dgrad_b * relu'(a)
         dwa = _conv_param_grads(a_l, x, dz_a, a_l.scale) if need[1] else None
         dws = None
         if blk.has_short:
@@ -607,7 +630,7 @@ class _BottleneckFn(torch.autograd.Function):
             dws = _conv_param_grads(s_l, sx, dz_c, s_l.scale) if need[4] else None
             dshort = None
             if need[0]:
-                dshort = _conv_call(lib, dz_c, s_l.w_dgrad, None, s_l.cin, 1, 1, 1, 0, None, None)
+                dshort = _conv_call(lib, dz_c, s_l.w_dgrad, None, s_l.cin, 1, 1, 1, 0, None, None, w_frag=s_l.w_dgrad_frag)
                 if pooled is not None:
                     dxs = torch.empty_like(x)
                     check(lib.fx_avgpool2x2_bwd_nhwc_bf16(dshort.data_ptr(), s_l.cin, dxs.data_ptr(), s_l.cin, x.shape[0], x.shape[1], x.shape[2], s_l.cin, st),
@@ -615,7 +638,7 @@ class _BottleneckFn(torch.autograd.Function):
                     dshort = dxs
         else:
             dshort = dz_c
-        dx = _conv_call(lib, dz_a, a_l.w_dgrad, None, a_l.cin, 1, 1, 1, 0, None, dshort) if need[0] else None   # + shortcut gradient in the epilogue
+        dx = _conv_call(lib, dz_a, a_l.w_dgrad, None, a_l.cin, 1, 1, 1, 0, None, dshort, w_frag=a_l.w_dgrad_frag) if need[0] else None   # + shortcut gradient in the epilogue
         return dx, dwa, dwb, dwc, dws, None
 
 
@@ -743,7 +766,7 @@ class _PackedLinear:
             if self.w_fwd is None or self.w_fwd.device != dev:
                 self.w_fwd = torch.zeros(_rup(Np, 128), 1, 1, Kp, dtype=torch.bfloat16, device=dev)
                 self.w_t = torch.zeros(_rup(Kp, 128), 1, 1, Np, dtype=torch.bfloat16, device=dev)
-            check(lib.fx_pack_conv_weights_f32(w.data_ptr(), None, self.w_fwd.data_ptr(), self.w_t.data_ptr(), Np, Kp, 1, 1, _stream(dev)),
+            check(lib.fx_pack_conv_weights_f32(w.data_ptr(), None, self.w_fwd.data_ptr(), self.w_t.data_ptr(), None, None, Np, Kp, 1, 1, _stream(dev)),
                   "fx_pack_conv_weights_f32")
             if self.bias is None or self.bias.device != dev or self.bias.numel() != _rup(Np, 128):
                 self.bias = torch.zeros(_rup(Np, 128), dtype=torch.float32, device=dev)   # allocated (and its padding zeroed) once

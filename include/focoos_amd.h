@@ -375,6 +375,18 @@ int fx_detr_set_loss_f32(const float* logits, int ldl, const float* boxes, const
                          float num_boxes, float focal_alpha, float focal_gamma, float w_vfl, float w_bbox, float w_giou, void* workspace,
                          float* out3, fx_stream_t stream);
 
+/* SetCriterion.loss_boxes (fai_detr/modelling.py:513-530) of one prediction set together with its gradient and the per-query targets of
+ * loss_labels_vfl (:464-480), one launch (training path): loss2 = {scale_bbox * sum_pairs L1, scale_giou * sum_pairs (1 - GIoU)} with
+ * scale_* = weight / num_boxes; q_cls i32 [B*Q] = matched target label or K, q_score f32 [B*Q] = IoU of the matched pair or 0;
+ * pair_grad f32 [sum_T][8] = d loss2[0] / d box (4) | d loss2[1] / d box (4) of every matched pair (cxcywh; autograd's conventions
+ * for max / min ties, clamp and sgn).  boxes f32 [B,Q,4] contiguous.  Deterministic.
+ * fx_detr_box_loss_bwd_f32 writes all of dboxes f32 [B,Q,4] = g_bbox * d loss2[0] + g_giou * d loss2[1] (g_*: device scalars, NULL = 0). */
+int fx_detr_box_loss_f32(const float* boxes, const int32_t* tgt_labels, const float* tgt_boxes, const int32_t* tgt_offsets,
+                         const int32_t* pred_idx, const int32_t* tgt_idx, int B, int Q, int K, int sum_T, float scale_bbox, float scale_giou,
+                         int32_t* q_cls, float* q_score, float* loss2, float* pair_grad, fx_stream_t stream);
+int fx_detr_box_loss_bwd_f32(const float* pair_grad, const int32_t* tgt_offsets, const int32_t* pred_idx, int B, int Q, int sum_T,
+                             const float* g_bbox, const float* g_giou, float* dboxes, fx_stream_t stream);
+
 /* ms_deform_attn_core in fp32 with its backward - the autograd half of seam B4 (focoos/nn/layers/deformable.py:10-35;
  * fai_detr/modelling.py:806,880).  value f32 [B,S,M*32], loc f32 [B,Q,M,L,P,2], attn f32 [B,Q,M,L,P] (contiguous),
  * out / grad_out f32 [B,Q,M*32].  bwd zeroes grad_value [B,S,M*32] itself, then accumulates with fp32 atomics;
@@ -411,8 +423,11 @@ int fx_conv2d_wgrad_bias_nhwc_bf16(const void* x, int ldx, const void* dz, int l
 /* Master weights fp32 [N][C][KH][KW] (reference / checkpoint layout) -> bf16 images for the MFMA kernels, optionally
  * multiplied by a per-out-channel scale (frozen BatchNorm folded): w_fwd [Npad][KH][KW][C] (fx_conv2d_nhwc_bf16 layout) and
  * w_dgrad [Cpad][KH][KW][N] = flipped + transposed filter: for a stride-1 "same" conv, dX = fx_conv2d_nhwc_bf16(dZ, w_dgrad).
- * Either output may be NULL; padding rows are not touched (zero them once). */
-int fx_pack_conv_weights_f32(const float* w, const float* scale, void* w_fwd, void* w_dgrad, int N, int C, int KH, int KW, fx_stream_t stream);
+ * Either output may be NULL; padding rows are not touched (zero them once).  w_fwd_frag / w_dgrad_frag (optional; need the matching
+ * image, N % 32 == 0 resp. C % 32 == 0): second copies in MFMA fragment order - fx_conv_desc.w_frag of the forward / input-gradient
+ * convolution, which routes eligible layers to the halo / pointwise kernels of conv3x3_flat.hip. */
+int fx_pack_conv_weights_f32(const float* w, const float* scale, void* w_fwd, void* w_dgrad, void* w_fwd_frag, void* w_dgrad_frag, int N, int C,
+                             int KH, int KW, fx_stream_t stream);
 
 /* dw_master[n][c][kh][kw] (+)= scale[n] * dw_eff[n][kh][kw][c]; dw_eff rows have C_eff >= C channels (stem: 3 of 8). */
 int fx_unpack_conv_wgrad_f32(const float* dw_eff, const float* scale, float* dw_master, int N, int C, int KH, int KW, int C_eff, int accumulate,
@@ -437,10 +452,11 @@ int fx_relu_bwd_bf16(const void* dy, int lddy, const void* dy2, int lddy2, const
 int fx_zero_insert2_nhwc_bf16(const void* dz, int lddz, void* u, int ldu, int B, int Ho, int Wo, int H, int W, int C, fx_stream_t stream);
 
 /* Backward of fx_avgpool2x2_nhwc_bf16 (AvgPool2d(2,2,0,ceil_mode=True)) and fx_maxpool3x3s2_nhwc_bf16 (first maximum in
- * window scan order receives the gradient, like PyTorch); dx is [B,H,W,C]. */
+ * window scan order receives the gradient, like PyTorch); dx is [B,H,W,C].  The max-pool backward needs a workspace of
+ * B * Ho * Wo * C bytes (8-byte aligned): the arg-max tap of every output element. */
 int fx_avgpool2x2_bwd_nhwc_bf16(const void* dp, int lddp, void* dx, int lddx, int B, int H, int W, int C, fx_stream_t stream);
 int fx_maxpool3x3s2_bwd_nhwc_bf16(const void* x, int ldx, const void* dy, int lddy, void* dx, int lddx, int B, int H, int W, int C,
-                                  fx_stream_t stream);
+                                  void* workspace, fx_stream_t stream);
 
 /* (img - mean) * inv_std as bf16 NHWC with the 3 channels padded to 8: the stem conv's input for its weight gradient. */
 int fx_normalize_pad8(const void* img, int is_f32, const float* mean, const float* inv_std, void* out, int64_t pixels, fx_stream_t stream);

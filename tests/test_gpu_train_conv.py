@@ -105,7 +105,7 @@ def test_pack_unpack_and_elementwise_backward(lib):
     wf = torch.zeros(128, k, k, Cc, dtype=torch.bfloat16, device=DEV)
     wd = torch.zeros(128, k, k, N, dtype=torch.bfloat16, device=DEV)
     wdv, sd = w.to(DEV), s.to(DEV)
-    check(lib.fx_pack_conv_weights_f32(wdv.data_ptr(), sd.data_ptr(), wf.data_ptr(), wd.data_ptr(), N, Cc, k, k, stream()))
+    check(lib.fx_pack_conv_weights_f32(wdv.data_ptr(), sd.data_ptr(), wf.data_ptr(), wd.data_ptr(), None, None, N, Cc, k, k, stream()))
     torch.cuda.synchronize()
     ws = (w * s.view(-1, 1, 1, 1)).bfloat16()
     assert torch.equal(wf[:N].cpu(), ws.permute(0, 2, 3, 1)) and float(wf[N:].abs().max()) == 0
@@ -140,7 +140,8 @@ def test_pool_backward(lib, hw):
     ref = xt.grad.permute(0, 2, 3, 1)
     xd, dyd = x.to(DEV), dy.permute(0, 2, 3, 1).contiguous().to(DEV)
     dx = torch.empty_like(xd)
-    check(lib.fx_maxpool3x3s2_bwd_nhwc_bf16(xd.data_ptr(), 16, dyd.data_ptr(), 16, dx.data_ptr(), 16, 2, H, W, 16, stream()))
+    arg = torch.empty(dyd.numel(), dtype=torch.uint8, device=DEV)   # workspace: arg-max tap per output element
+    check(lib.fx_maxpool3x3s2_bwd_nhwc_bf16(xd.data_ptr(), 16, dyd.data_ptr(), 16, dx.data_ptr(), 16, 2, H, W, 16, arg.data_ptr(), stream()))
     torch.cuda.synchronize()
     assert (dx.float().cpu() - ref).abs().max() <= 2e-2 * ref.abs().max()  # sums of up to 4 bf16 gradients, rounded once
     assert ((dx.float().cpu() != 0) == (ref != 0)).all()               # identical routing (arg-max choice incl. ties)
@@ -621,3 +622,40 @@ def test_fused_bottleneck_node_matches_per_layer_nodes():
     worst = max(rel_l2(grads[True][n], grads[False][n]) for n in grads[True])
     print("fused vs per-layer weight gradients, worst rel-L2:", worst)
     assert worst <= 2e-2
+
+
+def test_training_convs_on_the_flat_kernels_match_the_implicit_gemm_routing(monkeypatch):
+    """Training forward / input-gradient convolutions given the fragment-order weight copies (fx_pack_conv_weights_f32's w_*_frag outputs)
+    run on the halo 3x3 / flat pointwise kernels from 20000 output pixels; here the thresholds are lowered so that a small ResNet50-vd
+    pass goes through them (incl. the training-only epilogues: ReLU mask of a saved activation, shortcut-gradient add), and the result is
+    compared with the same pass routed to the implicit-GEMM kernels: same products, different summation order."""
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.synth import synth_image_structured, synth_state_dict
+    from focoos_amd.train_nn import ResNetVd
+    from tests.helpers import rel_l2
+
+    cfg = ModelRegistry.get_model_info("fai-detr-l-coco")["config"]
+    sd = synth_state_dict(cfg, 12)
+    pre = "pixel_decoder.backbone."
+    bsd = {k[len(pre):]: v for k, v in sd.items() if k.startswith(pre)}
+    x_u8 = torch.from_numpy(np.stack([synth_image_structured(50 + i, 128, 160) for i in range(2)])).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    proj = {k: torch.randn(c, generator=g).to(DEV) for k, c in (("res2", 256), ("res3", 512), ("res4", 1024), ("res5", 2048))}
+    res = {}
+    for flat in (True, False):
+        monkeypatch.setenv("FX_CONV3_MIN_M", "0" if flat else "2000000000")
+        monkeypatch.setenv("FX_PW_MIN_M", "0" if flat else "2000000000")
+        net = ResNetVd(50).to(DEV)
+        net.load_state_dict(bsd, strict=True)
+        outs = net(x_u8)
+        (sum((outs[k].float() * proj[k]).sum() for k in proj) * 1e-2).backward()
+        torch.cuda.synchronize()
+        res[flat] = ({k: v.detach().float().clone() for k, v in outs.items()}, {n: p.grad.clone() for n, p in net.named_parameters() if p.requires_grad})
+        frags = [m for m in net.modules() if getattr(m, "w_fwd_frag", None) is not None or getattr(m, "w_dgrad_frag", None) is not None]
+        assert len(frags) >= 20, len(frags)   # 3x3 of res2-res4 and the 256-multiple pointwise layers of res4 / res5 carry fragment copies
+    for k in proj:
+        assert rel_l2(res[True][0][k], res[False][0][k]) <= 1e-2, k
+    worst = max((rel_l2(res[True][1][n], res[False][1][n]), n) for n in res[True][1])
+    print("flat vs implicit-GEMM routing, worst weight-gradient rel-L2:", worst)
+    assert worst[0] <= 3e-2, worst
+    assert any(not torch.equal(res[True][1][n], res[False][1][n]) for n in res[True][1])   # the routing did change
