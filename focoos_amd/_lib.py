@@ -28,6 +28,16 @@ class FxConvDesc(C.Structure):
     ]
 
 
+class FxPackEntry(C.Structure):
+    """include/focoos_amd.h fx_pack_entry"""
+    _fields_ = [
+        ("w", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p), ("w_fwd", C.c_void_p), ("w_dgrad", C.c_void_p),
+        ("w_fwd_frag", C.c_void_p), ("w_dgrad_frag", C.c_void_p), ("bias_out", C.c_void_p),
+        ("N", C.c_int32), ("C", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("ld_fwd", C.c_int32), ("ld_dgrad", C.c_int32),
+        ("first_block", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
 class FxPwChainDesc(C.Structure):
     _fields_ = [
         ("x1", C.c_void_p), ("x2", C.c_void_p), ("residual", C.c_void_p), ("w1", C.c_void_p), ("bias1", C.c_void_p), ("y1", C.c_void_p),
@@ -142,6 +152,11 @@ SIGNATURES = {
     "fx_rowdot_nhwc_bf16": [_vp, _i, _vp, _i, C.c_float, _vp, _i, _i, _i, _i, _i, _vp],
     "fx_bcast_vec_nhwc_bf16": [_vp, _i, C.c_float, _vp, _i, _i, _i, _i, _vp],
     "fx_scatter_rows_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
+    "fx_pack_weights_many_f32": [_vp, _i, _i, _vp],
+    "fx_pack_frag_bf16": [_vp, _vp, _i, _i, _vp],
+    "fx_pack_linear_weights_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "fx_box_refine_f32": [_vp, _vp, _vp, C.c_int64, _f, _vp],
+    "fx_box_refine_bwd_f32": [_vp, _vp, _vp, _vp, _vp, C.c_int64, _f, _vp],
     "fx_vfl_loss_bf16": [_vp, _i, _vp, _vp, _f, _f, _f, _vp, _vp, _i, C.c_int64, _i, _vp],
     "fx_stream_fork": [_vp, _vp],
     "fx_stream_join": [_vp, _vp],

@@ -60,8 +60,8 @@ class _Targets:
         self.tmax = max(sizes + [0])
         self.offsets = h2d_i32(self.off_host, device)
         if self.n:
-            self.labels = torch.cat([t.labels.to(torch.int32) for t in targets]).to(device).contiguous()
-            self.boxes = torch.cat([t.boxes.float() for t in targets]).to(device).contiguous()
+            self.labels = torch.cat([t.labels for t in targets]).to(device=device, dtype=torch.int32).contiguous()
+            self.boxes = torch.cat([t.boxes for t in targets]).to(device=device, dtype=torch.float32).contiguous()
         else:
             self.labels = torch.zeros(1, dtype=torch.int32, device=device)
             self.boxes = torch.zeros(1, 4, device=device)

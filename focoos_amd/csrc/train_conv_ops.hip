@@ -43,6 +43,16 @@ __global__ __launch_bounds__(256) void frag_from_rows_kernel(const bf16_t* __res
   }
 }
 
+extern "C" int fx_pack_frag_bf16(const void* w_rows, void* frag, int rows, int K, fx_stream_t stream_) {
+  FX_CHECK_ARG(w_rows && frag && rows > 0 && K > 0 && rows % 32 == 0 && K % 16 == 0);
+  FX_CHECK_ARG(((uintptr_t)w_rows % 16) == 0 && ((uintptr_t)frag % 16) == 0);
+  int64_t grid = ((int64_t)rows * K / 8 + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(frag_from_rows_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)w_rows,
+                     (bf16_t*)frag, rows, K);
+  return fx_launch_status();
+}
+
 extern "C" int fx_pack_conv_weights_f32(const float* w, const float* scale, void* w_fwd, void* w_dgrad, void* w_fwd_frag, void* w_dgrad_frag,
                                         int N, int C, int KH, int KW, fx_stream_t stream_) {
   FX_CHECK_ARG(w && (w_fwd || w_dgrad) && N > 0 && C > 0 && KH > 0 && KW > 0);
@@ -59,6 +69,89 @@ extern "C" int fx_pack_conv_weights_f32(const float* w, const float* scale, void
     hipLaunchKernelGGL(frag_from_rows_kernel, dim3((int)grid), dim3(256), 0, stream, (const bf16_t*)w_fwd, (bf16_t*)w_fwd_frag, N, KH * KW * C);
   if (w_dgrad_frag)
     hipLaunchKernelGGL(frag_from_rows_kernel, dim3((int)grid), dim3(256), 0, stream, (const bf16_t*)w_dgrad, (bf16_t*)w_dgrad_frag, C, KH * KW * N);
+  return fx_launch_status();
+}
+
+// nn.Linear master weights fp32 [N][K] (+ bias) -> the bf16 images of the forward GEMM (w_fwd [.][Kp], row n) and of the input-gradient
+// GEMM (w_t [.][Np], row k), dimensions padded to the kernels' granules (padding pre-zeroed by the caller, never touched), and the
+// bias into its padded fp32 vector: one launch per layer and step instead of pad + transpose + copy launches.
+__global__ __launch_bounds__(256) void pack_linear_weights_kernel(const float* __restrict__ w, const float* __restrict__ bias,
+                                                                  bf16_t* __restrict__ w_fwd, bf16_t* __restrict__ w_t, float* __restrict__ bias_out,
+                                                                  int N, int K, int Np, int Kp) {
+  const int64_t total = (int64_t)N * K;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int k = (int)(i % K), n = (int)(i / K);
+    const bf16_t b = f32_to_bf16(w[i]);
+    w_fwd[(int64_t)n * Kp + k] = b;
+    w_t[(int64_t)k * Np + n] = b;
+    if (k == 0 && bias_out) bias_out[n] = bias[n];
+  }
+}
+
+extern "C" int fx_pack_linear_weights_f32(const float* w, const float* bias, void* w_fwd, void* w_t, float* bias_out, int N, int K, int Np, int Kp,
+                                          fx_stream_t stream_) {
+  FX_CHECK_ARG(w && w_fwd && w_t && N > 0 && K > 0 && Np >= N && Kp >= K && (!bias_out || bias));
+  int64_t grid = ((int64_t)N * K + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(pack_linear_weights_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), w, bias, (bf16_t*)w_fwd,
+                     (bf16_t*)w_t, bias_out, N, K, Np, Kp);
+  return fx_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// All weight images of a model in ONE launch (multi-tensor form of fx_pack_conv_weights_f32 / fx_pack_linear_weights_f32): after every
+// optimizer step each of the ~190 layers of RT-DETR needs its bf16 images rebuilt from the fp32 masters - ~340 launches of a few
+// microseconds each, bound by launch latency on the GPU and by the Python launch path on the host.  A table entry describes one layer;
+// a workgroup finds its entry by binary search over the entries' first workgroup index and converts 2048 master elements.  The
+// fragment-order copies are written straight from the masters (index arithmetic instead of a second pass over the packed image).
+__device__ __forceinline__ int64_t frag_offset(int row, int k, int K) {
+  return ((((int64_t)(row >> 5) * (K >> 4) + (k >> 4)) * 64 + (row & 31) + 32 * ((k >> 3) & 1)) << 3) + (k & 7);
+}
+
+__global__ __launch_bounds__(256) void pack_weights_many_kernel(const fx_pack_entry* __restrict__ tab, int n_entries) {
+  __shared__ int s_e;
+  if (threadIdx.x == 0) {
+    int lo = 0, hi = n_entries - 1;
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (tab[mid].first_block <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    s_e = lo;
+  }
+  __syncthreads();
+  const fx_pack_entry e = tab[s_e];
+  const int N = e.N, C = e.C, KH = e.KH, KW = e.KW;
+  const int64_t total = (int64_t)N * C * KH * KW;
+  const int64_t base = (int64_t)((int)blockIdx.x - e.first_block) * 2048;
+  const float* __restrict__ w = e.w;
+  bf16_t* __restrict__ w_fwd = (bf16_t*)e.w_fwd;
+  bf16_t* __restrict__ w_dgrad = (bf16_t*)e.w_dgrad;
+  bf16_t* __restrict__ f_fwd = (bf16_t*)e.w_fwd_frag;
+  bf16_t* __restrict__ f_dgrad = (bf16_t*)e.w_dgrad_frag;
+  const int Kf = KH * KW * C, Kd = KH * KW * N;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int64_t i = base + j * 256 + threadIdx.x;
+    if (i >= total) break;
+    int kw = (int)(i % KW);
+    int64_t r = i / KW;
+    int kh = (int)(r % KH);
+    r /= KH;
+    const int c = (int)(r % C), n = (int)(r / C);
+    const bf16_t b = f32_to_bf16(w[i] * (e.scale ? e.scale[n] : 1.0f));
+    const int kf = (kh * KW + kw) * C + c;
+    const int kd = ((KH - 1 - kh) * KW + (KW - 1 - kw)) * N + n;
+    if (w_fwd) w_fwd[(int64_t)n * e.ld_fwd + kf] = b;
+    if (w_dgrad) w_dgrad[(int64_t)c * e.ld_dgrad + kd] = b;
+    if (f_fwd) f_fwd[frag_offset(n, kf, Kf)] = b;
+    if (f_dgrad) f_dgrad[frag_offset(c, kd, Kd)] = b;
+    if (e.bias_out && i < N) e.bias_out[i] = e.bias[i];
+  }
+}
+
+extern "C" int fx_pack_weights_many_f32(const fx_pack_entry* entries_dev, int n_entries, int total_blocks, fx_stream_t stream_) {
+  FX_CHECK_ARG(entries_dev && n_entries > 0 && total_blocks > 0);
+  hipLaunchKernelGGL(pack_weights_many_kernel, dim3(total_blocks), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), entries_dev, n_entries);
   return fx_launch_status();
 }
 

@@ -319,3 +319,48 @@ extern "C" int fx_vfl_loss_bf16(const void* logits, int ld, const int32_t* cls, 
                      cls, score, alpha, gamma, scale, loss_out, (bf16_t*)dlogits, lddl, rows, K);
   return fx_launch_status();
 }
+
+
+// ------------------------------------------------------------------------------------------------ iterative box refinement
+// TransformerDecoder (fai_detr/modelling.py:996-1013): box = sigmoid(delta + inverse_sigmoid(ref)), inverse_sigmoid(x) =
+// log(clamp(clamp(x, 0, 1), eps) / clamp(1 - clamp(x, 0, 1), eps)), eps = 1e-5 (focoos/nn/layers/functional.py).  delta bf16 (the bbox head's
+// output), ref / box fp32, n elements.  Backward: ds = g * box * (1 - box); d delta = ds; d ref = ds * d inverse_sigmoid / d ref with
+// autograd's clamp conventions (gradient passes where the input is inside the closed clamp range).
+__global__ __launch_bounds__(256) void box_refine_kernel(const bf16_t* __restrict__ delta, const float* __restrict__ ref, float* __restrict__ box,
+                                                          int64_t n, float eps) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float x = fminf(fmaxf(ref[i], 0.0f), 1.0f);
+    const float u = logf(fmaxf(x, eps) / fmaxf(1.0f - x, eps)) + bf16_to_f32(delta[i]);
+    box[i] = 1.0f / (1.0f + expf(-u));
+  }
+}
+
+__global__ __launch_bounds__(256) void box_refine_bwd_kernel(const float* __restrict__ g, const float* __restrict__ box, const float* __restrict__ ref,
+                                                              bf16_t* __restrict__ d_delta, float* __restrict__ d_ref, int64_t n, float eps) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float s = box[i];
+    const float ds = g[i] * s * (1.0f - s);
+    d_delta[i] = f32_to_bf16(ds);
+    if (d_ref) {
+      const float r = ref[i];
+      const float x = fminf(fmaxf(r, 0.0f), 1.0f);
+      const float inside = (r >= 0.0f && r <= 1.0f) ? 1.0f : 0.0f;
+      const float dinv = (x >= eps ? 1.0f / x : 0.0f) + (1.0f - x >= eps ? 1.0f / (1.0f - x) : 0.0f);
+      d_ref[i] = ds * dinv * inside;
+    }
+  }
+}
+
+extern "C" int fx_box_refine_f32(const void* delta, const float* ref, float* box, int64_t n, float eps, fx_stream_t stream_) {
+  FX_CHECK_ARG(delta && ref && box && n > 0 && eps > 0.0f);
+  hipLaunchKernelGGL(box_refine_kernel, dim3(ew_grid(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)delta, ref, box, n, eps);
+  return fx_launch_status();
+}
+
+extern "C" int fx_box_refine_bwd_f32(const float* grad_box, const float* box, const float* ref, void* d_delta, float* d_ref, int64_t n, float eps,
+                                     fx_stream_t stream_) {
+  FX_CHECK_ARG(grad_box && box && ref && d_delta && n > 0 && eps > 0.0f);
+  hipLaunchKernelGGL(box_refine_bwd_kernel, dim3(ew_grid(n)), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), grad_box, box, ref,
+                     (bf16_t*)d_delta, d_ref, n, eps);
+  return fx_launch_status();
+}

@@ -172,6 +172,7 @@ class BucketedGradAllReduce:
         self.launched = [False] * len(self.segments)
         self.log: List[Tuple[str, int]] = []      # ("segment", i) / ("backward_end", -1) in launch order: what the overlap test reads
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.before_collective = None   # optional callable: orders the current stream after gradient producers on other streams
 
     def launch_segment(self, i: int):
         """Start the all-reduce of segment i's buckets (idempotent within a step): its gradients are final."""
@@ -181,6 +182,8 @@ class BucketedGradAllReduce:
         self.log.append(("segment", i))
         if self.world == 1:
             return
+        if self.before_collective is not None:
+            self.before_collective()
         for s, n in self.seg_buckets[i]:
             self.handles.append(self.dist.all_reduce(self.flat[s:s + n], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
 

@@ -12,6 +12,7 @@ max/top-k index selection (no gradient), and the L1 / GIoU losses on the <= sum(
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -39,9 +40,34 @@ class MLP(nn.Module):
         return x
 
 
-def inverse_sigmoid(x: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
-    x = x.clip(min=0.0, max=1.0)
-    return torch.log(x.clip(min=eps) / (1 - x).clip(min=eps))
+INV_SIGMOID_EPS = 1e-5   # focoos/nn/layers/functional.py:4
+
+
+class _BoxRefineFn(torch.autograd.Function):
+    """sigmoid(delta + inverse_sigmoid(ref)) - the iterative box refinement of the decoder (fai_detr/modelling.py:1003, 1010) - as one
+    launch each way (fx_box_refine_f32) instead of ~8 elementwise launches forward and ~15 backward.  delta bf16 [..., 4] (the bbox
+    head's output), ref fp32 [..., 4] (may be detached); returns fp32."""
+
+    @staticmethod
+    def forward(ctx, delta, ref):
+        lib = _lib.load()
+        delta, ref = delta.contiguous(), ref.contiguous()
+        box = torch.empty_like(ref)
+        check(lib.fx_box_refine_f32(delta.data_ptr(), ref.data_ptr(), box.data_ptr(), ref.numel(), INV_SIGMOID_EPS, _stream(ref.device)),
+              "fx_box_refine_f32")
+        ctx.save_for_backward(box, ref)
+        return box
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        box, ref = ctx.saved_tensors
+        g = g.contiguous()
+        d_delta = torch.empty(box.shape, dtype=torch.bfloat16, device=box.device)
+        d_ref = torch.empty_like(box) if ctx.needs_input_grad[1] else None
+        check(lib.fx_box_refine_bwd_f32(g.data_ptr(), box.data_ptr(), ref.data_ptr(), d_delta.data_ptr(), d_ref.data_ptr() if d_ref is not None else None,
+                                        box.numel(), INV_SIGMOID_EPS, _stream(box.device)), "fx_box_refine_bwd_f32")
+        return d_delta, d_ref
 
 
 class MSDeformableAttention(nn.Module):
@@ -155,10 +181,10 @@ class TransformerPredictor(nn.Module):
         for i, layer in enumerate(self.decoder.layers):
             qpos = self.query_pos_head(ref_detach.to(torch.bfloat16))
             out = layer(out, ref_detach.unsqueeze(2), memory, shapes, qpos)
-            delta = self.dec_bbox_classifier[i](out).float()
-            inter = torch.sigmoid(delta + inverse_sigmoid(ref_detach))
+            delta = self.dec_bbox_classifier[i](out)
+            inter = _BoxRefineFn.apply(delta, ref_detach)
             logits.append(self.dec_score_classifier[i](out))
-            boxes.append(inter if i == 0 else torch.sigmoid(delta + inverse_sigmoid(ref)))
+            boxes.append(inter if i == 0 else _BoxRefineFn.apply(delta, ref))
             ref, ref_detach = inter, inter.detach()
         return {"pred_logits": logits[-1], "pred_boxes": boxes[-1],
                 "aux_outputs": [{"pred_logits": a, "pred_boxes": b} for a, b in zip(logits[:-1], boxes[:-1])]
@@ -359,6 +385,14 @@ class TrainStep:
             segments = [(0, b1), (b1, b2), (b2, self.opt.flat_g.numel())]
         self._seg_index = {"backbone": 0, "encoder": 1, "head": 2} if segments else {}
         self.reducer = BucketedGradAllReduce(self.opt.flat_g, segments=segments)
+        # side stream for the weight-gradient launches (FX_WGRAD_STREAM=0: everything on one stream); from the per-device pool the
+        # engines use, so that it maps to a hardware queue of its own
+        self.wgrad_stream = None
+        if os.environ.get("FX_WGRAD_STREAM", "1") != "0" and torch.device(self.opt.dev).type == "cuda":
+            from .engine import _device_stream
+
+            self.wgrad_stream = _device_stream(torch.device(self.opt.dev), 1)
+        self.reducer.before_collective = self._join_wgrads   # a segment's gradients are final only once its queued wgrads have run
         import os as _os
 
         if self._seg_index and int(_os.environ.get("FX_DP_OVERLAP", "1")):
@@ -386,6 +420,9 @@ class TrainStep:
             bufs.update({n: p for n, p in model.named_parameters() if not p.requires_grad})
             self.ema = FlatEMA(self.opt.flat_p, {n: self.opt.params[n] for n, _ in named}, bufs, decay=ema_decay, warmups=ema_warmups)
 
+    def _join_wgrads(self):
+        self._nn.wgrad_join(self.opt.dev)
+
     def step(self, images: torch.Tensor, targets: Sequence) -> Dict[str, torch.Tensor]:
         nn_ = self._nn
         if self.scheduler is not None:
@@ -402,13 +439,19 @@ class TrainStep:
         nn_.ARENA.arm(self.opt.numel + (8 << 20), self.opt.dev)   # staging for the 3x3 weight gradients + padded heads
         nn_.DIRECT_GRAD[0] = True
         nn_.pin_stream(self.opt.dev, True)   # one stream-handle lookup per step instead of one per launch (backward runs on this stream too)
+        dev = torch.device(self.opt.dev)
+        nn_.pack_all(dev)    # every weight image the optimizer step made stale, one launch (layers not seen yet pack themselves lazily)
+        if self.wgrad_stream is not None:
+            nn_.WGRAD_STREAM[dev] = self.wgrad_stream   # weight gradients overlap the input-gradient chain (train_nn._wgrad_fork)
         try:
             losses = self.model(images, targets)
-            total = sum(losses.values())
+            total = torch.stack(list(losses.values())).sum()   # 2 launches instead of one add per loss term
             total.backward()
         finally:
             nn_.DIRECT_GRAD[0] = False
             nn_.pin_stream(self.opt.dev, False)
+            self._join_wgrads()
+            nn_.WGRAD_STREAM.pop(dev, None)
         self.reducer.launch()
         self.reducer.wait()
         self.opt.step()

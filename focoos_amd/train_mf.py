@@ -21,7 +21,7 @@ from ._lib import check
 from .engine_maskdec import pos_embed_sine_normalized
 from .train_bf import Conv1x1, TransformerDecoder, _CriterionHolder
 from .train_nn import (ARENA, DIRECT_GRAD, WEIGHTS_EPOCH, ConvNormLayer, LayerNorm, Linear, MultiheadAttention, ResNetVd, _AddFn, _conv_call,
-                       _conv_input_grad, _conv_param_grads, _stream, set_norm_mode)
+                       _conv_input_grad, _conv_param_grads, _frag_eligible, _ptr, _stream, set_norm_mode)
 
 
 class ConvNormFlat(ConvNormLayer):
@@ -40,7 +40,7 @@ class _ConvBiasFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, layer: "ConvBias"):
         layer.sync_packed()
         N, Cc, KH, KW = weight.shape
-        y = _conv_call(layer.lib, x, layer.w_fwd, layer.shift, N, KH, KW, 1, layer.pad, None, None)
+        y = _conv_call(layer.lib, x, layer.w_fwd, layer.shift, N, KH, KW, 1, layer.pad, None, None, w_frag=layer.w_fwd_frag)
         ctx.layer = layer
         ctx.save_for_backward(x)
         return y
@@ -77,7 +77,7 @@ class ConvBias(nn.Module):
         self.bias = nn.Parameter(torch.zeros(cout))
         object.__setattr__(self, "_conv_h", self)
         self._ver = None
-        self.w_fwd = self.w_dgrad = self.shift = None
+        self.w_fwd = self.w_dgrad = self.shift = self.w_fwd_frag = self.w_dgrad_frag = None
 
     def sync_packed(self):
         w, b = self.weight, self.bias
@@ -92,9 +92,11 @@ class ConvBias(nn.Module):
                 self.w_fwd = torch.zeros(Np, k, k, Cc, dtype=torch.bfloat16, device=dev)
                 self.w_dgrad = torch.zeros(Cp, k, k, N, dtype=torch.bfloat16, device=dev)
                 self.shift = torch.zeros(Np, dtype=torch.float32, device=dev)
+                self.w_fwd_frag = torch.empty(N * k * k * Cc, dtype=torch.bfloat16, device=dev) if _frag_eligible(N, Cc, k) else None
+                self.w_dgrad_frag = torch.empty(N * k * k * Cc, dtype=torch.bfloat16, device=dev) if _frag_eligible(Cc, N, k) else None
             self.shift[:N] = b
-            check(self.lib.fx_pack_conv_weights_f32(w.data_ptr(), None, self.w_fwd.data_ptr(), self.w_dgrad.data_ptr(), None, None, N, Cc, k, k, _stream(dev)),
-                  "fx_pack_conv_weights_f32")
+            check(self.lib.fx_pack_conv_weights_f32(w.data_ptr(), None, self.w_fwd.data_ptr(), self.w_dgrad.data_ptr(), _ptr(self.w_fwd_frag),
+                                                    _ptr(self.w_dgrad_frag), N, Cc, k, k, _stream(dev)), "fx_pack_conv_weights_f32")
         self._ver = ver
 
     def forward(self, x):

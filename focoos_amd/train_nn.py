@@ -17,13 +17,14 @@ order; every FLOP and every byte moved inside a node is a HIP kernel of this rep
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Dict, List, Optional
 
 import torch
 from torch import nn
 
 from . import _lib
-from ._lib import FX_ACT, FxConvDesc, check
+from ._lib import FX_ACT, FxConvDesc, FxPackEntry, check
 from .state_spec import RESNET_BLOCKS
 
 BN_EPS = 1e-5
@@ -87,6 +88,78 @@ def pin_stream(dev, on: bool) -> None:
 def _stream(dev) -> C.c_void_p:
     h = _STREAM_PIN.get(dev)
     return h if h is not None else C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+# Weight gradients are off backward's critical path (nothing in backward consumes them): with a side stream installed here (TrainStep
+# does, for the duration of a step) they are launched on it and overlap the input-gradient chain on the main stream - the same effect
+# as the two concurrent batch parts of the inference step: a ~250 TFLOP/s wgrad kernel and a bandwidth-bound dgrad / elementwise kernel
+# fill each other's idle units.  Only when the kernels accumulate straight into the flat gradient views (DIRECT_GRAD): a gradient
+# handed back to autograd would be consumed on the main stream.  The owner joins the streams before it reads the gradients.
+WGRAD_STREAM: Dict[torch.device, "torch.cuda.Stream"] = {}
+
+
+_WGRAD_KEEP: List = []   # operands of the launches queued on the side stream, released when the owner joins the streams
+
+
+def _wgrad_fork(dev, *tensors):
+    """The side stream for a weight-gradient launch (None: stay on the main stream), ordered after everything queued on the main
+    stream so far.  ``tensors`` (temporaries / saved activations the launch reads) are kept referenced until the owner joins the
+    streams (wgrad_join) - cheaper on the host than the caching allocator's per-tensor record_stream, at the price of the temporaries
+    of one backward pass staying allocated until its end."""
+    side = WGRAD_STREAM.get(dev)
+    if side is None:
+        return None
+    check(_lib.load().fx_stream_fork(_stream(dev), C.c_void_p(side.cuda_stream)), "fx_stream_fork")
+    _WGRAD_KEEP.append(tensors)
+    return side
+
+
+def wgrad_join(dev) -> None:
+    """Order the current stream of ``dev`` after the weight-gradient side stream and release the operands held for it."""
+    side = WGRAD_STREAM.get(torch.device(dev))
+    if side is not None:
+        torch.cuda.current_stream(torch.device(dev)).wait_stream(side)
+    _WGRAD_KEEP.clear()
+
+
+# ---- all weight images in one launch -------------------------------------------------------------------------------------------
+# Every layer rebuilds its bf16 images lazily (sync_packed / _PackedLinear.sync) when its master weight changed.  A training step
+# changes ALL of them, and ~190 small pack launches per step cost more on the host (Python launch path) and on the GPU (launch latency)
+# than the conversion itself; layers therefore register here once packed, and TrainStep calls pack_all() at the top of a step: one
+# fx_pack_weights_many_f32 launch over a device table of the stale layers, whose versions are then stamped so that the lazy path
+# finds nothing to do.  The table is cached as long as the pointers in it are unchanged.
+_PACK_REGISTRY: "weakref.WeakSet" = weakref.WeakSet()
+_PACK_TABLE: Dict[torch.device, tuple] = {}
+
+
+def pack_all(dev) -> int:
+    """Rebuild every stale registered weight image on ``dev`` with one launch; returns the number of layers packed."""
+    dev = torch.device(dev)
+    pend = []
+    for o in list(_PACK_REGISTRY):
+        f = o.pack_fields(dev)
+        if f is not None:
+            pend.append((o, f))
+    if len(pend) < 4:   # a handful: the lazy per-layer path
+        return 0
+    pend.sort(key=lambda of: of[1][1][0])   # by master pointer: a stable order keeps the cached table valid
+    key = tuple(f[1] for _, f in pend)
+    cached = _PACK_TABLE.get(dev)
+    if cached is None or cached[0] != key:
+        arr = (FxPackEntry * len(pend))()
+        blocks = 0
+        for e, (_, (_, (w, scale, bias, w_fwd, w_dgrad, f_fwd, f_dgrad, bias_out, N, Cc, KH, KW, ld_fwd, ld_dgrad))) in zip(arr, pend):
+            e.w, e.scale, e.bias, e.w_fwd, e.w_dgrad, e.w_fwd_frag, e.w_dgrad_frag, e.bias_out = w, scale, bias, w_fwd, w_dgrad, f_fwd, f_dgrad, bias_out
+            e.N, e.C, e.KH, e.KW, e.ld_fwd, e.ld_dgrad, e.first_block = N, Cc, KH, KW, ld_fwd, ld_dgrad, blocks
+            blocks += (N * Cc * KH * KW + 2047) // 2048
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        cached = (key, host.to(dev), len(pend), blocks)
+        _PACK_TABLE[dev] = cached
+    _, table, n, blocks = cached
+    check(_lib.load().fx_pack_weights_many_f32(table.data_ptr(), n, blocks, _stream(dev)), "fx_pack_weights_many_f32")
+    for o, (ver, _) in pend:
+        o.pack_stamp(ver)
+    return n
 
 
 _DESC_CACHE: Dict[tuple, tuple] = {}
@@ -267,7 +340,10 @@ def _conv_param_grads(layer, x: torch.Tensor, dz: torch.Tensor, scale: Optional[
     lib, dev = layer.lib, x.device
     B, H, W_, Cc = x.shape
     _, Ho, Wo, N = dz.shape
-    st = _stream(dev)
+    wparam = layer._conv_h.weight
+    direct = DIRECT_GRAD[0] and wparam.grad is not None
+    side = _wgrad_fork(dev, x, dz) if direct else None
+    st = C.c_void_p(side.cuda_stream) if side is not None else _stream(dev)
     k = layer.k
     key = (B, Ho, Wo, Cc, N, k)
     S = layer._wgrad_splits.get(key) if hasattr(layer, "_wgrad_splits") else None
@@ -280,8 +356,6 @@ def _conv_param_grads(layer, x: torch.Tensor, dz: torch.Tensor, scale: Optional[
     ws = _wgrad_workspace(S * slab, dev)
     check(lib.fx_conv2d_wgrad_partial_nhwc_bf16(x.data_ptr(), Cc, dz.data_ptr(), N, ws.data_ptr(), slab, S, B, H, W_, Cc, Ho, Wo, N, k, k,
                                                 layer.stride, layer.pad, st), "fx_conv2d_wgrad_partial_nhwc_bf16")
-    wparam = layer._conv_h.weight
-    direct = DIRECT_GRAD[0] and wparam.grad is not None
     dw = wparam.grad if direct else torch.empty(N, Cc, k, k, dtype=torch.float32, device=dev)
     check(lib.fx_unpack_conv_wgrad_sum_f32(ws.data_ptr(), slab, S, scale.data_ptr() if scale is not None else None, dw.data_ptr(), N, Cc, k, k, Cc,
                                            int(direct), st), "fx_unpack_conv_wgrad_sum_f32")
@@ -371,15 +445,17 @@ class ConvNormLayer(nn.Module):
         self._shift_n = (norm.bias.double() - norm.running_mean.double() * self.scale.double()).float().contiguous()
         self._norm_version = ver
 
-    def sync_packed(self):
-        """(Re)build the bf16 weight images when the master weight changed (optimizer step, load_state_dict).  With batch
-        statistics the images hold the plain weights (the normalisation is a separate pass); otherwise BN is folded in."""
+    def _pack_version(self):
         w = self._conv_h.weight
         live = self.batch_stats
-        ver = (w._version, self._norm_h.weight._version, self._norm_h.running_var._version, w.device, WEIGHTS_EPOCH[0], live,
-               0 if live else getattr(self, "_stats_epoch", 0))
-        if ver == self._packed_version:
-            return
+        return (w._version, self._norm_h.weight._version, self._norm_h.running_var._version, w.device, WEIGHTS_EPOCH[0], live,
+                0 if live else getattr(self, "_stats_epoch", 0))
+
+    def _prepare_images(self):
+        """Allocate the images (first use / device change) and refresh the folded-BatchNorm scale and shift; returns the arguments of the
+        pack kernels: (w, scale, bias, w_fwd, w_dgrad, w_fwd_frag, w_dgrad_frag, bias_out, N, C, KH, KW, ld_fwd, ld_dgrad) as integers."""
+        w = self._conv_h.weight
+        live = self.batch_stats
         dev = w.device
         N, Cc, k = self.cout, self.cin, self.k
         with torch.no_grad():
@@ -396,9 +472,29 @@ class ConvNormLayer(nn.Module):
                 self.w_fwd_frag = (torch.empty(N * k * k * Cc, dtype=torch.bfloat16, device=dev)
                                    if self.stride == 1 and _frag_eligible(N, Cc, k) else None)
                 self.w_dgrad_frag = torch.empty(N * k * k * Cc, dtype=torch.bfloat16, device=dev) if _frag_eligible(Cc, N, k) else None
-            check(self.lib.fx_pack_conv_weights_f32(w.data_ptr(), None if live else self.scale.data_ptr(), self.w_fwd.data_ptr(),
-                                                    self.w_dgrad.data_ptr(), _ptr(self.w_fwd_frag), _ptr(self.w_dgrad_frag), N, Cc, k, k,
-                                                    _stream(dev)), "fx_pack_conv_weights_f32")
+        return (w.data_ptr(), None if live else self.scale.data_ptr(), None, self.w_fwd.data_ptr(), self.w_dgrad.data_ptr(),
+                _ptr(self.w_fwd_frag), _ptr(self.w_dgrad_frag), None, N, Cc, k, k, k * k * Cc, k * k * N)
+
+    def sync_packed(self):
+        """(Re)build the bf16 weight images when the master weight changed (optimizer step, load_state_dict).  With batch
+        statistics the images hold the plain weights (the normalisation is a separate pass); otherwise BN is folded in."""
+        ver = self._pack_version()
+        if ver == self._packed_version:
+            return
+        f = self._prepare_images()
+        check(self.lib.fx_pack_conv_weights_f32(f[0], f[1], f[3], f[4], f[5], f[6], f[8], f[9], f[10], f[11], _stream(self._conv_h.weight.device)),
+              "fx_pack_conv_weights_f32")
+        self._packed_version = ver
+        _PACK_REGISTRY.add(self)
+
+    def pack_fields(self, dev):
+        """For pack_all: (version, pack-kernel arguments) when the images are stale and live on ``dev``, else None."""
+        if self._conv_h.weight.device != dev:
+            return None
+        ver = self._pack_version()
+        return None if ver == self._packed_version else (ver, self._prepare_images())
+
+    def pack_stamp(self, ver):
         self._packed_version = ver
 
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -745,33 +841,54 @@ class _PackedLinear:
 
     def __init__(self):
         self.ver = None
-        self.w_fwd = self.w_t = self.bias = None
+        self.w_fwd = self.w_t = self.bias = self.w_fwd_frag = self.w_t_frag = None
         self.Np = self.Kp = 0
 
-    def sync(self, lib, weight, bias, r0, r1):
-        ver = (weight._version, None if bias is None else bias._version, weight.device, r0, r1, WEIGHTS_EPOCH[0])
-        if ver == self.ver:
-            return
+    def _version(self, weight, bias, r0, r1):
+        return (weight._version, None if bias is None else bias._version, weight.device, r0, r1, WEIGHTS_EPOCH[0])
+
+    def _prepare(self, weight, bias, r0, r1):
         dev = weight.device
         N, K = r1 - r0, weight.shape[1]
         Np, Kp = _rup(N, 32), _rup(K, 32)  # both serve as the reduction dim of one of the two GEMMs (C % 32 == 0)
         self.Np, self.Kp = Np, Kp
         with torch.no_grad():
-            w = weight[r0:r1].flatten(1)   # [N, K, 1, 1] conv weights (train_bf.Conv1x1) are GEMM weights too
-            if Np != N or Kp != K:
-                wp = torch.zeros(Np, Kp, dtype=torch.float32, device=dev)
-                wp[:N, :K] = w
-                w = wp
-            w = w.contiguous()
+            w = weight[r0:r1]   # rows of a contiguous [N_total, K(, 1, 1)] master ([N, K, 1, 1] conv weights of train_bf.Conv1x1 are GEMM weights too)
+            assert w.is_contiguous()
             if self.w_fwd is None or self.w_fwd.device != dev:
                 self.w_fwd = torch.zeros(_rup(Np, 128), 1, 1, Kp, dtype=torch.bfloat16, device=dev)
                 self.w_t = torch.zeros(_rup(Kp, 128), 1, 1, Np, dtype=torch.bfloat16, device=dev)
-            check(lib.fx_pack_conv_weights_f32(w.data_ptr(), None, self.w_fwd.data_ptr(), self.w_t.data_ptr(), None, None, Np, Kp, 1, 1, _stream(dev)),
-                  "fx_pack_conv_weights_f32")
+                ok = _frag_eligible(Np, Kp, 1) and Np == N and Kp == K   # 256-multiples both ways: the flat pointwise kernel, forward and input gradient
+                self.w_fwd_frag = torch.empty(Np * Kp, dtype=torch.bfloat16, device=dev) if ok else None
+                self.w_t_frag = torch.empty(Np * Kp, dtype=torch.bfloat16, device=dev) if ok else None
             if self.bias is None or self.bias.device != dev or self.bias.numel() != _rup(Np, 128):
                 self.bias = torch.zeros(_rup(Np, 128), dtype=torch.float32, device=dev)   # allocated (and its padding zeroed) once
-            if bias is not None:
-                self.bias[:N] = bias[r0:r1]
+            bsrc = bias[r0:r1] if bias is not None else None
+        return (w.data_ptr(), None, _ptr(bsrc), self.w_fwd.data_ptr(), self.w_t.data_ptr(), _ptr(self.w_fwd_frag), _ptr(self.w_t_frag),
+                self.bias.data_ptr() if bsrc is not None else None, N, K, 1, 1, Kp, Np)
+
+    def sync(self, lib, weight, bias, r0, r1):
+        ver = self._version(weight, bias, r0, r1)
+        if ver == self.ver:
+            return
+        f = self._prepare(weight, bias, r0, r1)
+        dev = weight.device
+        check(lib.fx_pack_linear_weights_f32(f[0], f[2], f[3], f[4], f[7], f[8], f[9], f[13], f[12], _stream(dev)), "fx_pack_linear_weights_f32")
+        if self.w_fwd_frag is not None:   # (the multi-tensor path writes the fragment copies itself)
+            check(lib.fx_pack_frag_bf16(self.w_fwd.data_ptr(), self.w_fwd_frag.data_ptr(), self.Np, self.Kp, _stream(dev)), "fx_pack_frag_bf16")
+            check(lib.fx_pack_frag_bf16(self.w_t.data_ptr(), self.w_t_frag.data_ptr(), self.Kp, self.Np, _stream(dev)), "fx_pack_frag_bf16")
+        self.ver = ver
+        self._src = (weight, bias, r0, r1)
+        _PACK_REGISTRY.add(self)
+
+    def pack_fields(self, dev):
+        weight, bias, r0, r1 = self._src
+        if weight.device != dev:
+            return None
+        ver = self._version(weight, bias, r0, r1)
+        return None if ver == self.ver else (ver, self._prepare(weight, bias, r0, r1))
+
+    def pack_stamp(self, ver):
         self.ver = ver
 
 
@@ -794,7 +911,7 @@ class _LinearFn(torch.autograd.Function):
         x2 = _pad_last(x.reshape(1, 1, -1, K), Kp)
         res2 = _pad_last(residual.reshape(1, 1, -1, N), Np) if residual is not None else None
         fused = act in (None, "relu")
-        z = _conv_call(lib, x2, pack.w_fwd, pack.bias, Np, 1, 1, 1, 0, act if fused else None, res2)
+        z = _conv_call(lib, x2, pack.w_fwd, pack.bias, Np, 1, 1, 1, 0, act if fused else None, res2, w_frag=pack.w_fwd_frag)
         y = z if fused else _act_fwd(lib, z, act)
         ctx.lib, ctx.pack, ctx.rng, ctx.act, ctx.has_res, ctx.has_bias = lib, pack, (r0, r1), act, residual is not None, bias is not None
         ctx.wshape, ctx.K = tuple(weight.shape), K
@@ -802,6 +919,45 @@ class _LinearFn(torch.autograd.Function):
         ctx.save_for_backward(x2, y if fused else z)
         out = y.reshape(*x.shape[:-1], Np)
         return out if Np == N else out[..., :N].contiguous()
+
+    @staticmethod
+    def _param_grads(ctx, x2, dz, want_w, want_b, direct, bdirect, st):
+        """Weight (+ bias) gradient of the layer; returns (dw, db) for autograd, both None when the kernels wrote the flat views."""
+        lib, pack, (r0, r1) = ctx.lib, ctx.pack, ctx.rng
+        dev = x2.device
+        N, K, Np, Kp = r1 - r0, ctx.K, pack.Np, pack.Kp
+        R = x2.shape[2]
+        dw = db = None
+        same = Np == N and Kp == K
+        if direct and same:
+            wt = ctx.wparam.grad[r0:r1]
+        else:
+            dw = None if direct else ARENA.zeros(ctx.wshape, dev)
+            wt = dw[r0:r1] if (same and not direct) else ARENA.zeros((Np, Kp), dev)
+        wshape_rows = (r1 - r0,) + tuple(ctx.wshape[1:])   # [N, K] or [N, K, 1, 1]
+        bt = None
+        if want_b:
+            if bdirect and Np == N:
+                bt = ctx.bparam.grad[r0:r1]
+            else:
+                db = None if bdirect else ARENA.zeros((ctx.wshape[0],), dev)
+                bt = db[r0:r1] if (Np == N and not bdirect) else ARENA.zeros((Np,), dev)
+        # one launch: weight gradient + bias gradient (column sums of the dZ tiles it stages anyway)
+        check(lib.fx_conv2d_wgrad_bias_nhwc_bf16(x2.data_ptr(), Kp, dz.data_ptr(), Np, wt.data_ptr(), bt.data_ptr() if bt is not None else None,
+                                                 1, 1, R, Kp, 1, R, Np, 1, 1, 1, 0, st), "fx_conv2d_wgrad_bias_nhwc_bf16")
+        if not same:
+            if direct:
+                ctx.wparam.grad[r0:r1] += wt[:N, :K].reshape(wshape_rows)
+            else:
+                dw[r0:r1] = wt[:N, :K].reshape(wshape_rows)
+        if want_b and Np != N:
+            if bdirect:
+                ctx.bparam.grad[r0:r1] += bt[:N]
+            else:
+                db[r0:r1] = bt[:N]
+        if not want_w:
+            dw = None
+        return dw, db
 
     @staticmethod
     def backward(ctx, dy):
@@ -821,42 +977,19 @@ class _LinearFn(torch.autograd.Function):
             dz = _act_bwd(lib, dy2, saved, act)
         dx = None
         if ctx.needs_input_grad[0]:
-            dxp = _conv_call(lib, dz, pack.w_t, None, Kp, 1, 1, 1, 0, None, None).reshape(dy.shape[:-1] + (Kp,))
+            dxp = _conv_call(lib, dz, pack.w_t, None, Kp, 1, 1, 1, 0, None, None, w_frag=pack.w_t_frag).reshape(dy.shape[:-1] + (Kp,))
             dx = dxp if Kp == K else dxp[..., :K].contiguous()
         dw = db = None
         want_w, want_b = ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
         if want_w or want_b:
-            same = Np == N and Kp == K
             direct = DIRECT_GRAD[0] and ctx.wparam.grad is not None  # kernels accumulate into the pre-zeroed flat gradients
-            if direct and same:
-                wt = ctx.wparam.grad[r0:r1]
+            bdirect = want_b and DIRECT_GRAD[0] and ctx.bparam.grad is not None
+            side = _wgrad_fork(dev, x2, dz) if (direct and (bdirect or not want_b)) else None   # nothing handed back to autograd: off the critical path
+            if side is not None:
+                with torch.cuda.stream(side):
+                    _LinearFn._param_grads(ctx, x2, dz, want_w, want_b, direct, bdirect, C.c_void_p(side.cuda_stream))
             else:
-                dw = None if direct else ARENA.zeros(ctx.wshape, dev)
-                wt = dw[r0:r1] if (same and not direct) else ARENA.zeros((Np, Kp), dev)
-            wshape_rows = (r1 - r0,) + tuple(ctx.wshape[1:])   # [N, K] or [N, K, 1, 1]
-            bt = None
-            if want_b:
-                bdirect = DIRECT_GRAD[0] and ctx.bparam.grad is not None
-                if bdirect and Np == N:
-                    bt = ctx.bparam.grad[r0:r1]
-                else:
-                    db = None if bdirect else ARENA.zeros((ctx.wshape[0],), dev)
-                    bt = db[r0:r1] if (Np == N and not bdirect) else ARENA.zeros((Np,), dev)
-            # one launch: weight gradient + bias gradient (column sums of the dZ tiles it stages anyway)
-            check(lib.fx_conv2d_wgrad_bias_nhwc_bf16(x2.data_ptr(), Kp, dz.data_ptr(), Np, wt.data_ptr(), bt.data_ptr() if bt is not None else None,
-                                                     1, 1, R, Kp, 1, R, Np, 1, 1, 1, 0, st), "fx_conv2d_wgrad_bias_nhwc_bf16")
-            if not same:
-                if direct:
-                    ctx.wparam.grad[r0:r1] += wt[:N, :K].reshape(wshape_rows)
-                else:
-                    dw[r0:r1] = wt[:N, :K].reshape(wshape_rows)
-            if want_b and Np != N:
-                if DIRECT_GRAD[0] and ctx.bparam.grad is not None:
-                    ctx.bparam.grad[r0:r1] += bt[:N]
-                else:
-                    db[r0:r1] = bt[:N]
-            if not want_w:
-                dw = None
+                dw, db = _LinearFn._param_grads(ctx, x2, dz, want_w, want_b, direct, bdirect, st)
         dres = None
         if ctx.has_res:
             dres = (dz if Np == N else dz[..., :N].contiguous()).reshape(dy.shape)

@@ -429,6 +429,35 @@ int fx_conv2d_wgrad_bias_nhwc_bf16(const void* x, int ldx, const void* dz, int l
 int fx_pack_conv_weights_f32(const float* w, const float* scale, void* w_fwd, void* w_dgrad, void* w_fwd_frag, void* w_dgrad_frag, int N, int C,
                              int KH, int KW, fx_stream_t stream);
 
+/* [rows][K] bf16 weight image (row stride K) -> MFMA fragment order (fx_conv_desc.w_frag); rows % 32 == 0, K % 16 == 0. */
+int fx_pack_frag_bf16(const void* w_rows, void* frag, int rows, int K, fx_stream_t stream);
+
+/* nn.Linear master weights fp32 [N][K] (+ bias [N]) -> bf16 images of the forward GEMM (w_fwd, row stride Kp) and of the
+ * input-gradient GEMM (w_t = transpose, row stride Np) and the bias into its padded fp32 vector; Np >= N, Kp >= K: the padding is
+ * never written (zero it once). */
+int fx_pack_linear_weights_f32(const float* w, const float* bias, void* w_fwd, void* w_t, float* bias_out, int N, int K, int Np, int Kp,
+                               fx_stream_t stream);
+
+/* Multi-tensor form of the two functions above: every weight image of a model rebuilt in one launch.  `entries_dev` is a device
+ * array; entry e converts master w [N][C][KH][KW] (a Linear: KH = KW = 1, C = K) times scale[n] (NULL: 1) into w_fwd (row n at
+ * n * ld_fwd, column (kh*KW + kw)*C + c), w_dgrad (row c at c * ld_dgrad, column ((KH-1-kh)*KW + (KW-1-kw))*N + n), their
+ * fragment-order copies (NULL: none; rows % 32 == 0, columns % 16 == 0) and copies bias [N] to bias_out (NULL: none).  Workgroups
+ * first_block .. first_block + ceil(N*C*KH*KW / 2048) - 1 belong to entry e (ascending, gap-free); total_blocks = their sum. */
+typedef struct {
+  const float* w;
+  const float* scale;
+  const float* bias;
+  void* w_fwd;
+  void* w_dgrad;
+  void* w_fwd_frag;
+  void* w_dgrad_frag;
+  float* bias_out;
+  int32_t N, C, KH, KW;
+  int32_t ld_fwd, ld_dgrad;
+  int32_t first_block, reserved;
+} fx_pack_entry;
+int fx_pack_weights_many_f32(const fx_pack_entry* entries_dev, int n_entries, int total_blocks, fx_stream_t stream);
+
 /* dw_master[n][c][kh][kw] (+)= scale[n] * dw_eff[n][kh][kw][c]; dw_eff rows have C_eff >= C channels (stem: 3 of 8). */
 int fx_unpack_conv_wgrad_f32(const float* dw_eff, const float* scale, float* dw_master, int N, int C, int KH, int KW, int C_eff, int accumulate,
                              fx_stream_t stream);
@@ -530,6 +559,13 @@ int fx_scatter_rows_bf16(const void* dout, int ldo, const int32_t* idx, int k, v
  * dlogits (optional, bf16 [rows][lddl]) = scale * w * (sigmoid(x) - t); scale = loss weight / num_boxes. */
 int fx_vfl_loss_bf16(const void* logits, int ld, const int32_t* cls, const float* score, float alpha, float gamma, float scale, float* loss_out,
                      void* dlogits, int lddl, int64_t rows, int K, fx_stream_t stream);
+
+/* Iterative box refinement of the decoder (fai_detr/modelling.py:996-1013): box = sigmoid(delta + inverse_sigmoid(ref)), eps as
+ * focoos/nn/layers/functional.py's inverse_sigmoid (1e-5).  delta bf16, ref / box fp32, n elements.  Backward: d_delta bf16, d_ref fp32 (NULL:
+ * ref was detached), autograd's clamp conventions. */
+int fx_box_refine_f32(const void* delta, const float* ref, float* box, int64_t n, float eps, fx_stream_t stream);
+int fx_box_refine_bwd_f32(const float* grad_box, const float* box, const float* ref, void* d_delta, float* d_ref, int64_t n, float eps,
+                          fx_stream_t stream);
 
 /* Fork: `side` waits for everything queued on `main` so far; join: `main` waits for `side`.  Valid inside
  * fx_graph_begin/fx_graph_end (the side stream joins the capture), which turns two launch sequences into independent

@@ -80,3 +80,30 @@ print("aten ops (non-view) per step:", sum(cnt.by.values()))
 for where, n in cnt.by.most_common(90):
     ops = ", ".join(f"{o.replace('aten::', '')}x{c}" for o, c in cnt.ops[where].most_common(8))
     print(f"{n:5d}  {where[:70]:70s} {ops[:150]}")
+
+# ---- per-layer weight-gradient table (events around _conv_param_grads: wgrad + slab sum + unpack)
+from focoos_amd import train_nn
+orig = train_nn._conv_param_grads
+rec = []
+
+
+def timed(layer, x, dz, scale):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); out = orig(layer, x, dz, scale); e1.record()
+    rec.append((e0, e1, tuple(x.shape), tuple(dz.shape), layer.k, layer.stride))
+    return out
+
+
+train_nn._conv_param_grads = timed
+stepper.wgrad_stream = None   # events are recorded on the main stream
+stepper.step(imgs, tg[7])
+train_nn._conv_param_grads = orig
+torch.cuda.synchronize()
+rows = collections.defaultdict(lambda: [0, 0.0])
+for e0, e1, xs, zs, k, st in rec:
+    r = rows[(xs, zs, k, st)]; r[0] += 1; r[1] += e0.elapsed_time(e1)
+print(f"conv weight gradients: {len(rec)} calls, {sum(r[1] for r in rows.values()):.3f} ms")
+for (xs, zs, k, st), (n, ms) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+    fl = 2.0 * zs[0] * zs[1] * zs[2] * zs[3] * xs[3] * k * k
+    by = 2.0 * (np.prod(xs) + np.prod(zs))
+    print(f"  x{xs} dz{zs} k{k} s{st}: {n} calls {ms:7.3f} ms  {ms / n * 1e3:7.1f} us each  {fl / (ms / n * 1e-3) / 1e12:6.1f} TF/s  {by / (ms / n * 1e-3) / 1e9:7.1f} GB/s alg")

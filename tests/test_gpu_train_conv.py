@@ -659,3 +659,63 @@ def test_training_convs_on_the_flat_kernels_match_the_implicit_gemm_routing(monk
     print("flat vs implicit-GEMM routing, worst weight-gradient rel-L2:", worst)
     assert worst[0] <= 3e-2, worst
     assert any(not torch.equal(res[True][1][n], res[False][1][n]) for n in res[True][1])   # the routing did change
+
+
+def test_pack_all_matches_the_per_layer_packing():
+    """train_nn.pack_all (fx_pack_weights_many_f32: every stale weight image of the registered layers in one launch, fragment-order copies
+    written straight from the masters) vs the lazy per-layer path (fx_pack_conv_weights_f32 / fx_pack_linear_weights_f32 +
+    fx_pack_frag_bf16): bit-identical images, folded-BatchNorm scale included; versions stamped so that the lazy path has nothing to do."""
+    from focoos_amd import train_nn
+    from focoos_amd.train_nn import BottleNeck, Linear
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(9)
+    blocks = [BottleNeck(lib, 256, 64, 1, True, False), BottleNeck(lib, 1024, 256, 1, True, False), BottleNeck(lib, 256, 128, 2, False, False)]
+    lins = [Linear(lib, 256, 256), Linear(lib, 256, 365), Linear(lib, 4, 512, act="relu"), Linear(lib, 256, 1024, bias=False)]
+    mods = torch.nn.ModuleList(blocks + lins).to(DEV)
+    with torch.no_grad():
+        for p in mods.parameters():
+            p.copy_(torch.randn(p.shape, generator=g).to(DEV) * 0.1)
+        for m in mods.modules():
+            if hasattr(m, "running_var"):
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g).to(DEV) + 0.5)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g).to(DEV) * 0.1)
+    x = {256: torch.randn(2, 8, 8, 256, generator=g).bfloat16().to(DEV), 1024: torch.randn(2, 8, 8, 1024, generator=g).bfloat16().to(DEV),
+         4: torch.randn(2, 8, 8, 4, generator=g).bfloat16().to(DEV)}
+    for b in blocks:
+        b(x[b.branch2a.cin])                       # lazy packing registers the layers
+    for l in lins:
+        l(x[l.weight.shape[1]])
+    convs = [m for m in mods.modules() if isinstance(m, train_nn.ConvNormLayer)]
+    packs = [l._pack for l in lins]
+
+    def images():
+        out = []
+        for c in convs:
+            out += [c.w_fwd, c.w_dgrad, c.w_fwd_frag, c.w_dgrad_frag, c.shift]
+        for pk in packs:
+            out += [pk.w_fwd, pk.w_t, pk.w_fwd_frag, pk.w_t_frag, pk.bias]
+        return [None if t is None else t.clone() for t in out]
+
+    with torch.no_grad():
+        for p in mods.parameters():
+            p.mul_(1.25).add_(0.01)                 # new weights (in place: versions move)
+    n = train_nn.pack_all(DEV)
+    assert n == len(convs) + len(packs), (n, len(convs), len(packs))
+    multi = images()
+    assert all(c.pack_fields(torch.device(DEV)) is None for c in convs) and all(pk.pack_fields(torch.device(DEV)) is None for pk in packs)
+    assert train_nn.pack_all(DEV) == 0             # nothing stale
+    for c in convs:
+        c._packed_version = None
+        c.sync_packed()
+    for l, pk in zip(lins, packs):
+        pk.ver = None
+        pk.sync(lib, l.weight, l.bias, 0, l.weight.shape[0])
+    torch.cuda.synchronize()
+    lazy = images()
+    assert sum(t is not None for t in multi) >= 40
+    for a, b in zip(multi, lazy):
+        assert (a is None) == (b is None)
+        if a is not None:
+            assert torch.equal(a, b)
+    assert any(c.w_fwd_frag is not None for c in convs) and any(c.w_dgrad_frag is not None for c in convs) and packs[0].w_fwd_frag is not None

@@ -57,3 +57,31 @@ def test_flat_adamw_matches_torch_adamw_with_clipping():
         assert abs(float(opt.total_norm) - float(total)) <= 1e-5 * float(total)
         for (name, _, _, _), p in zip(shapes, ref_params):
             assert (opt.params[name].cpu() - p.detach()).abs().max() < 2e-6, (step, name)
+
+
+def test_box_refine_forward_backward_vs_torch_autograd():
+    """sigmoid(delta + inverse_sigmoid(ref)) (fai_detr/modelling.py:1003, 1010; functional.py:4-6) as fx_box_refine_f32 / _bwd vs torch
+    autograd of the reference expression on the same bf16 deltas: fp32 both sides -> 1e-6 absolute forward, 1e-5 relative backward.
+    ref includes the clamp edges (0, 1, below eps, outside [0, 1])."""
+    from focoos_amd.train_detr import _BoxRefineFn
+
+    g = torch.Generator().manual_seed(5)
+    delta = (torch.randn(3, 50, 4, generator=g) * 2).bfloat16()
+    ref = torch.rand(3, 50, 4, generator=g)
+    ref[0, 0] = torch.tensor([0.0, 1.0, 1e-7, 0.5])
+    ref[0, 1] = torch.tensor([-0.1, 1.2, 1.0 - 1e-7, 1e-5])
+    go = torch.randn(3, 50, 4, generator=g)
+    dc, rc = delta.float().requires_grad_(), ref.clone().requires_grad_()
+    out_c = torch.sigmoid(dc + O.inverse_sigmoid(rc))
+    out_c.backward(go)
+    dg, rg = delta.to(DEV).requires_grad_(), ref.to(DEV).requires_grad_()
+    out_g = _BoxRefineFn.apply(dg, rg)
+    out_g.backward(go.to(DEV))
+    torch.cuda.synchronize()
+    assert (out_g.detach().cpu() - out_c.detach()).abs().max() <= 1e-6
+    assert (dg.grad.float().cpu() - dc.grad).abs().max() <= 8e-3 * dc.grad.abs().max()          # bf16 gradient
+    assert (rg.grad.cpu() - rc.grad).abs().max() <= 1e-5 * rc.grad.abs().max(), (rg.grad.cpu() - rc.grad).abs().max()
+    # detached reference points: no gradient tensor for them
+    dg2 = delta.to(DEV).requires_grad_()
+    _BoxRefineFn.apply(dg2, ref.to(DEV)).backward(go.to(DEV))
+    assert torch.equal(dg2.grad, dg.grad)
