@@ -392,6 +392,7 @@ class TrainStep:
             from .engine import _device_stream
 
             self.wgrad_stream = _device_stream(torch.device(self.opt.dev), 1)
+        self.packer = self._nn.WeightPacker(model)
         self.reducer.before_collective = self._join_wgrads   # a segment's gradients are final only once its queued wgrads have run
         import os as _os
 
@@ -440,7 +441,7 @@ class TrainStep:
         nn_.DIRECT_GRAD[0] = True
         nn_.pin_stream(self.opt.dev, True)   # one stream-handle lookup per step instead of one per launch (backward runs on this stream too)
         dev = torch.device(self.opt.dev)
-        nn_.pack_all(dev)    # every weight image the optimizer step made stale, one launch (layers not seen yet pack themselves lazily)
+        self.packer.pack(dev)   # every weight image the optimizer step made stale, one launch (layers not seen yet pack themselves lazily)
         if self.wgrad_stream is not None:
             nn_.WGRAD_STREAM[dev] = self.wgrad_stream   # weight gradients overlap the input-gradient chain (train_nn._wgrad_fork)
         try:

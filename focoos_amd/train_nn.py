@@ -17,7 +17,6 @@ order; every FLOP and every byte moved inside a node is a HIP kernel of this rep
 from __future__ import annotations
 
 import ctypes as C
-import weakref
 from typing import Dict, List, Optional
 
 import torch
@@ -125,41 +124,53 @@ def wgrad_join(dev) -> None:
 # ---- all weight images in one launch -------------------------------------------------------------------------------------------
 # Every layer rebuilds its bf16 images lazily (sync_packed / _PackedLinear.sync) when its master weight changed.  A training step
 # changes ALL of them, and ~190 small pack launches per step cost more on the host (Python launch path) and on the GPU (launch latency)
-# than the conversion itself; layers therefore register here once packed, and TrainStep calls pack_all() at the top of a step: one
-# fx_pack_weights_many_f32 launch over a device table of the stale layers, whose versions are then stamped so that the lazy path
-# finds nothing to do.  The table is cached as long as the pointers in it are unchanged.
-_PACK_REGISTRY: "weakref.WeakSet" = weakref.WeakSet()
-_PACK_TABLE: Dict[torch.device, tuple] = {}
+# than the conversion itself.  TrainStep therefore owns a WeightPacker: at the top of a step ONE fx_pack_weights_many_f32 launch over a
+# device table of the model's stale layers, whose versions are then stamped so that the lazy path finds nothing to do.  The table is
+# cached as long as the pointers in it are unchanged.
+class WeightPacker:
+    def __init__(self, model: nn.Module):
+        self.model = model
+        self.items: List = []
+        self.table = None     # (key, device table, entries, workgroups)
 
+    def _collect(self):
+        out = []
+        for m in self.model.modules():
+            if hasattr(m, "pack_fields"):
+                out.append(m)
+            for v in vars(m).values():
+                if isinstance(v, _PackedLinear):
+                    out.append(v)
+        return out
 
-def pack_all(dev) -> int:
-    """Rebuild every stale registered weight image on ``dev`` with one launch; returns the number of layers packed."""
-    dev = torch.device(dev)
-    pend = []
-    for o in list(_PACK_REGISTRY):
-        f = o.pack_fields(dev)
-        if f is not None:
-            pend.append((o, f))
-    if len(pend) < 4:   # a handful: the lazy per-layer path
-        return 0
-    pend.sort(key=lambda of: of[1][1][0])   # by master pointer: a stable order keeps the cached table valid
-    key = tuple(f[1] for _, f in pend)
-    cached = _PACK_TABLE.get(dev)
-    if cached is None or cached[0] != key:
-        arr = (FxPackEntry * len(pend))()
-        blocks = 0
-        for e, (_, (_, (w, scale, bias, w_fwd, w_dgrad, f_fwd, f_dgrad, bias_out, N, Cc, KH, KW, ld_fwd, ld_dgrad))) in zip(arr, pend):
-            e.w, e.scale, e.bias, e.w_fwd, e.w_dgrad, e.w_fwd_frag, e.w_dgrad_frag, e.bias_out = w, scale, bias, w_fwd, w_dgrad, f_fwd, f_dgrad, bias_out
-            e.N, e.C, e.KH, e.KW, e.ld_fwd, e.ld_dgrad, e.first_block = N, Cc, KH, KW, ld_fwd, ld_dgrad, blocks
-            blocks += (N * Cc * KH * KW + 2047) // 2048
-        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        cached = (key, host.to(dev), len(pend), blocks)
-        _PACK_TABLE[dev] = cached
-    _, table, n, blocks = cached
-    check(_lib.load().fx_pack_weights_many_f32(table.data_ptr(), n, blocks, _stream(dev)), "fx_pack_weights_many_f32")
-    for o, (ver, _) in pend:
-        o.pack_stamp(ver)
-    return n
+    def pack(self, dev) -> int:
+        """Rebuild every stale weight image of the model on ``dev`` with one launch; returns the number of layers packed (0: nothing
+        stale, or the layers have not been through their first lazy packing yet)."""
+        dev = torch.device(dev)
+        if not self.items:
+            self.items = self._collect()
+        pend = []
+        for o in self.items:
+            f = o.pack_fields(dev)
+            if f is not None:
+                pend.append((o, f))
+        if len(pend) < 4:   # a handful: the lazy per-layer path
+            return 0
+        key = tuple(f[1] for _, f in pend)
+        if self.table is None or self.table[0] != key:
+            arr = (FxPackEntry * len(pend))()
+            blocks = 0
+            for e, (_, (_, (w, scale, bias, w_fwd, w_dgrad, f_fwd, f_dgrad, bias_out, N, Cc, KH, KW, ld_fwd, ld_dgrad))) in zip(arr, pend):
+                e.w, e.scale, e.bias, e.w_fwd, e.w_dgrad, e.w_fwd_frag, e.w_dgrad_frag, e.bias_out = w, scale, bias, w_fwd, w_dgrad, f_fwd, f_dgrad, bias_out
+                e.N, e.C, e.KH, e.KW, e.ld_fwd, e.ld_dgrad, e.first_block = N, Cc, KH, KW, ld_fwd, ld_dgrad, blocks
+                blocks += (N * Cc * KH * KW + 2047) // 2048
+            host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self.table = (key, host.to(dev), len(pend), blocks)
+        _, table, n, blocks = self.table
+        check(_lib.load().fx_pack_weights_many_f32(table.data_ptr(), n, blocks, _stream(dev)), "fx_pack_weights_many_f32")
+        for o, (ver, _) in pend:
+            o.pack_stamp(ver)
+        return n
 
 
 _DESC_CACHE: Dict[tuple, tuple] = {}
@@ -485,7 +496,6 @@ class ConvNormLayer(nn.Module):
         check(self.lib.fx_pack_conv_weights_f32(f[0], f[1], f[3], f[4], f[5], f[6], f[8], f[9], f[10], f[11], _stream(self._conv_h.weight.device)),
               "fx_pack_conv_weights_f32")
         self._packed_version = ver
-        _PACK_REGISTRY.add(self)
 
     def pack_fields(self, dev):
         """For pack_all: (version, pack-kernel arguments) when the images are stale and live on ``dev``, else None."""
@@ -613,6 +623,9 @@ class StemConv(ConvNormLayer):
                 self.stem_b = self._shift_n
                 self.stem_w = (w * self.scale.view(-1, 1, 1, 1)).permute(2, 3, 1, 0).contiguous()  # [kh][kw][c][n] fp32 (tiny: 864 values)
         self._packed_version = ver
+
+    def pack_fields(self, dev):   # fp32 [kh][kw][c][n] weights through its own sync_packed: not part of the multi-tensor packing
+        return None
 
     def forward(self, images: torch.Tensor) -> torch.Tensor:  # type: ignore[override]
         if self.batch_stats:
@@ -841,7 +854,7 @@ class _PackedLinear:
 
     def __init__(self):
         self.ver = None
-        self.w_fwd = self.w_t = self.bias = self.w_fwd_frag = self.w_t_frag = None
+        self.w_fwd = self.w_t = self.bias = self.w_fwd_frag = self.w_t_frag = self._src = None
         self.Np = self.Kp = 0
 
     def _version(self, weight, bias, r0, r1):
@@ -879,9 +892,10 @@ class _PackedLinear:
             check(lib.fx_pack_frag_bf16(self.w_t.data_ptr(), self.w_t_frag.data_ptr(), self.Kp, self.Np, _stream(dev)), "fx_pack_frag_bf16")
         self.ver = ver
         self._src = (weight, bias, r0, r1)
-        _PACK_REGISTRY.add(self)
 
     def pack_fields(self, dev):
+        if self._src is None:    # not through its first (lazy) packing yet
+            return None
         weight, bias, r0, r1 = self._src
         if weight.device != dev:
             return None

@@ -59,7 +59,7 @@ SKIP = {"aten::view", "aten::_unsafe_view", "aten::reshape", "aten::select", "at
 class Count(TorchDispatchMode):
     def __init__(self):
         super().__init__()
-        self.by = collections.Counter(); self.ops = collections.defaultdict(collections.Counter)
+        self.by = collections.Counter(); self.ops = collections.defaultdict(collections.Counter); self.bw = collections.Counter()
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         name = func.name().split(".")[0]
@@ -70,6 +70,9 @@ class Count(TorchDispatchMode):
                     where = f"{fr.filename.split('focoos_amd/')[-1]}:{fr.lineno} {fr.name}"
                     break
             self.by[where] += 1; self.ops[where][name] += 1
+            if where.startswith("<backward"):
+                shp = tuple(tuple(a.shape) for a in args if isinstance(a, torch.Tensor))
+                self.bw[(name, shp, str(args[0].dtype) if args and isinstance(args[0], torch.Tensor) else "")] += 1
         return func(*args, **(kwargs or {}))
 
 
@@ -80,6 +83,10 @@ print("aten ops (non-view) per step:", sum(cnt.by.values()))
 for where, n in cnt.by.most_common(90):
     ops = ", ".join(f"{o.replace('aten::', '')}x{c}" for o, c in cnt.ops[where].most_common(8))
     print(f"{n:5d}  {where[:70]:70s} {ops[:150]}")
+
+print("backward-thread aten ops by (op, shapes):")
+for (name, shp, dt), n in cnt.bw.most_common(45):
+    print(f"{n:5d}  {name:28s} {dt:16s} {shp}")
 
 # ---- per-layer weight-gradient table (events around _conv_param_grads: wgrad + slab sum + unpack)
 from focoos_amd import train_nn

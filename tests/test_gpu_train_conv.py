@@ -662,7 +662,7 @@ def test_training_convs_on_the_flat_kernels_match_the_implicit_gemm_routing(monk
 
 
 def test_pack_all_matches_the_per_layer_packing():
-    """train_nn.pack_all (fx_pack_weights_many_f32: every stale weight image of the registered layers in one launch, fragment-order copies
+    """train_nn.WeightPacker (fx_pack_weights_many_f32: every stale weight image of the registered layers in one launch, fragment-order copies
     written straight from the masters) vs the lazy per-layer path (fx_pack_conv_weights_f32 / fx_pack_linear_weights_f32 +
     fx_pack_frag_bf16): bit-identical images, folded-BatchNorm scale included; versions stamped so that the lazy path has nothing to do."""
     from focoos_amd import train_nn
@@ -700,11 +700,12 @@ def test_pack_all_matches_the_per_layer_packing():
     with torch.no_grad():
         for p in mods.parameters():
             p.mul_(1.25).add_(0.01)                 # new weights (in place: versions move)
-    n = train_nn.pack_all(DEV)
+    packer = train_nn.WeightPacker(mods)
+    n = packer.pack(DEV)
     assert n == len(convs) + len(packs), (n, len(convs), len(packs))
     multi = images()
     assert all(c.pack_fields(torch.device(DEV)) is None for c in convs) and all(pk.pack_fields(torch.device(DEV)) is None for pk in packs)
-    assert train_nn.pack_all(DEV) == 0             # nothing stale
+    assert packer.pack(DEV) == 0                   # nothing stale
     for c in convs:
         c._packed_version = None
         c.sync_packed()
