@@ -64,6 +64,7 @@ SIGNATURES = {
     "fx_abi_version": [],
     "fx_device_info": [_i, C.POINTER(C.c_int), C.c_char_p, _i],
     "fx_conv2d_nhwc_bf16": [C.POINTER(FxConvDesc), _vp],
+    "fx_conv2d_variant": [_vp, C.c_char_p, _i],
     "fx_pw_chain_supported": [_i, _i, _i, _i],
     "fx_conv3x3_flat_supported": [_i, _i, _i],
     "fx_pw_chain_bf16": [C.POINTER(FxPwChainDesc), _vp],

@@ -11,6 +11,8 @@
 // next tile's global loads issued before the MFMA block of the current tile (guide T14), one barrier
 // per K-step.  im2col addressing is done on the fly: a K-step never straddles a filter tap because
 // BK divides C.  Zero padding / M tails are predicated loads.
+#include <stdio.h>
+
 #include "conv_common.h"
 
 template <int BM, int BN, int BK, int WM, int WN, bool POOL, int NSTAGE = 2>
@@ -261,7 +263,8 @@ static int launch_conv(ConvArgs& a, hipStream_t stream) {
   return fx_launch_status();
 }
 
-extern "C" int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream_) {
+// Validates a descriptor and fills the kernel arguments (shared by the launch and by fx_conv2d_variant).
+static int conv_prepare(const fx_conv_desc* d, ConvArgs& a) {
   FX_CHECK_ARG(d && d->x && d->w && d->y);
   FX_CHECK_ARG(d->B > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->N > 0);
   FX_CHECK_ARG(d->C > 0 && d->C % 32 == 0 && d->ldx >= d->C && d->ldx % 8 == 0);
@@ -286,8 +289,6 @@ extern "C" int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream_) {
   const int64_t w_bytes = Npad * d->KH * d->KW * d->C * 2;
   const int64_t r_bytes = d->residual ? (((int64_t)d->B * d->Ho * d->Wo - 1) * d->ldr + Nstore) * 2 : 0;
   if (x_bytes >= 0xFFFFFFF0ll || w_bytes >= 0xFFFFFFF0ll || r_bytes >= 0xFFFFFFF0ll) return FX_ERR_UNSUPPORTED;
-  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  ConvArgs a;
   a.x = reinterpret_cast<const bf16_t*>(d->x);
   a.w = reinterpret_cast<const bf16_t*>(d->w);
   a.bias = d->bias;
@@ -306,6 +307,13 @@ extern "C" int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream_) {
   a.x_bytes = (unsigned)x_bytes;
   a.w_bytes = (unsigned)w_bytes;
   a.r_bytes = (unsigned)r_bytes;
+  return FX_OK;
+}
+
+// Which kernel runs a layer - ONE routing function for the launch and for the label bench.py reports (fx_conv2d_variant).
+enum ConvRoute { R_C3_FLAT, R_PW_FLAT, R_SMALL_M, R_DMA, R_POOL, R_K64_N128, R_K64_N64, R_K64_N32, R_K32_N128, R_K32_N64, R_K32_N32, R_UNSUPPORTED };
+
+static ConvRoute conv_route(const fx_conv_desc* d, const ConvArgs& a) {
   // Layers with a fragment-ordered weight copy: 3x3 / stride 1 -> halo kernel (pixels fetched once for all nine taps);
   // 1x1 with C, N multiples of 256 -> the same machinery with 256-channel LDS rows (conv3x3_flat.hip)
   // (the two size thresholds are re-read per call - a getenv each, nothing under graph replay - so that kernel tests can route
@@ -318,10 +326,10 @@ extern "C" int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream_) {
     const int mode = fx_c3_epilogue_mode(d->act, d->residual != nullptr, d->residual_after_act);
     if (c3_on && d->KH == 3 && d->KW == 3 && d->pad == 1 && !d->y_batch_stride && ((mode >= 0 && mode <= 3) || mode == 5) && a.M >= c3_min_m &&
         fx_conv3x3_flat_supported(d->C, d->N, d->W))
-      return fx_launch_conv3x3_flat(a, reinterpret_cast<const bf16_t*>(d->w_frag), stream);
+      return R_C3_FLAT;
     if (pw_on && d->KH == 1 && d->KW == 1 && d->pad == 0 && d->C % 256 == 0 && d->N % 256 == 0 && a.M >= pw_min_m &&
         (mode == 0 || mode == 1 || (mode >= 3 && mode <= 6)))
-      return fx_launch_pw_flat(a, reinterpret_cast<const bf16_t*>(d->w_frag), stream);
+      return R_PW_FLAT;
   }
   // BK=64 (2 workgroups/CU, 64 KiB LDS) for deep-K compute-bound layers; BK=32 (4 workgroups/CU, 34 KiB LDS: more
   // tiles and bytes in flight per CU) for the short-K layers, which are HBM/latency-bound.
@@ -329,19 +337,55 @@ extern "C" int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream_) {
   static const int small_m = fx_tune("FX_SMALL_M", 16384);
   // Small-M GEMMs (decoder / 20x20 level: a few hundred tiles, latency-bound): 64x64 tiles with a 256-deep K slab per
   // step - for K = 256 the whole reduction is ONE load phase (all 16 loads per lane in flight at once), no K loop.
-  if (!d->pool2 && a.M <= small_m && d->C % 256 == 0 && a.Ktot <= 1024) return launch_conv<64, 64, 256, 2, 2, false, 1>(a, stream);
+  if (!d->pool2 && a.M <= small_m && d->C % 256 == 0 && a.Ktot <= 1024) return R_SMALL_M;
   const bool k64 = (d->C % 64 == 0) && (a.Ktot >= k64_min);
-  if (!d->pool2 && fx_conv_dma_eligible(a)) return fx_launch_conv_dma(a, stream);
-  if (d->pool2) {
-    if (d->C % 64 != 0) return FX_ERR_UNSUPPORTED;
-    return launch_conv<128, 128, 64, 2, 2, true>(a, stream);
+  if (!d->pool2 && fx_conv_dma_eligible(a)) return R_DMA;
+  if (d->pool2) return d->C % 64 != 0 ? R_UNSUPPORTED : R_POOL;
+  if (k64) return d->N > 64 ? R_K64_N128 : (d->N > 32 ? R_K64_N64 : R_K64_N32);
+  return d->N > 64 ? R_K32_N128 : (d->N > 32 ? R_K32_N64 : R_K32_N32);
+}
+
+extern "C" int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream_) {
+  ConvArgs a;
+  const int rc = conv_prepare(d, a);
+  if (rc != FX_OK) return rc;
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  switch (conv_route(d, a)) {
+    case R_C3_FLAT: return fx_launch_conv3x3_flat(a, reinterpret_cast<const bf16_t*>(d->w_frag), stream);
+    case R_PW_FLAT: return fx_launch_pw_flat(a, reinterpret_cast<const bf16_t*>(d->w_frag), stream);
+    case R_SMALL_M: return launch_conv<64, 64, 256, 2, 2, false, 1>(a, stream);
+    case R_DMA: return fx_launch_conv_dma(a, stream);
+    case R_POOL: return launch_conv<128, 128, 64, 2, 2, true>(a, stream);
+    case R_K64_N128: return launch_conv<128, 128, 64, 2, 2, false>(a, stream);
+    case R_K64_N64: return launch_conv<128, 64, 64, 2, 2, false>(a, stream);
+    case R_K64_N32: return launch_conv<128, 32, 64, 4, 1, false>(a, stream);
+    case R_K32_N128: return launch_conv<128, 128, 32, 2, 2, false>(a, stream);
+    case R_K32_N64: return launch_conv<128, 64, 32, 2, 2, false>(a, stream);
+    case R_K32_N32: return launch_conv<128, 32, 32, 4, 1, false>(a, stream);
+    default: return FX_ERR_UNSUPPORTED;
   }
-  if (k64) {
-    if (d->N > 64) return launch_conv<128, 128, 64, 2, 2, false>(a, stream);
-    if (d->N > 32) return launch_conv<128, 64, 64, 2, 2, false>(a, stream);
-    return launch_conv<128, 32, 64, 4, 1, false>(a, stream);
+}
+
+// The label of the kernel fx_conv2d_nhwc_bf16 would run for this descriptor (pointers only checked for presence / alignment): what
+// bench.py groups its per-kernel roofline by.  Writes a NUL-terminated string, e.g. "conv3x3_flat<256>", "conv_igemm<128,128,64>".
+extern "C" int fx_conv2d_variant(const fx_conv_desc* d, char* out, int cap) {
+  FX_CHECK_ARG(out && cap >= 48);
+  ConvArgs a;
+  const int rc = conv_prepare(d, a);
+  if (rc != FX_OK) return rc;
+  switch (conv_route(d, a)) {
+    case R_C3_FLAT: snprintf(out, cap, "conv3x3_flat<%d>", d->N); break;
+    case R_PW_FLAT: snprintf(out, cap, "pw_flat<K%d>", d->C); break;
+    case R_SMALL_M: snprintf(out, cap, "conv_igemm<64,64,256,1stage>"); break;
+    case R_DMA: snprintf(out, cap, "conv_igemm_dma<256,%d>", d->N % 256 == 0 ? 256 : 128); break;
+    case R_POOL: snprintf(out, cap, "conv_igemm<128,128,64,pool>"); break;
+    case R_K64_N128: snprintf(out, cap, "conv_igemm<128,128,64>"); break;
+    case R_K64_N64: snprintf(out, cap, "conv_igemm<128,64,64>"); break;
+    case R_K64_N32: snprintf(out, cap, "conv_igemm<128,32,64>"); break;
+    case R_K32_N128: snprintf(out, cap, "conv_igemm<128,128,32>"); break;
+    case R_K32_N64: snprintf(out, cap, "conv_igemm<128,64,32>"); break;
+    case R_K32_N32: snprintf(out, cap, "conv_igemm<128,32,32>"); break;
+    default: return FX_ERR_UNSUPPORTED;
   }
-  if (d->N > 64) return launch_conv<128, 128, 32, 2, 2, false>(a, stream);
-  if (d->N > 32) return launch_conv<128, 64, 32, 2, 2, false>(a, stream);
-  return launch_conv<128, 32, 32, 4, 1, false>(a, stream);
+  return FX_OK;
 }

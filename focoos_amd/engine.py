@@ -491,21 +491,10 @@ class _PlanBase:
         # bookkeeping for bench.py: which template instance runs and the ALGORITHMIC flops of the reference layer(s)
         # this launch replaces (RepVGG 1x1 branch counted although it is re-parameterised away).
         M = x.B * Ho * Wo
-        bk = 64 if (pc.C % 64 == 0 and (pool2 or pc.KH * pc.KW * pc.C >= 1024)) else 32  # mirrors the C dispatch (FX_K64_MIN_KTOT)
-        bn = 128 if (pc.N > 64 or pool2) else (64 if pc.N > 32 else 32)
         flops = 2.0 * M * pc.N * pc.KH * pc.KW * pc.C + extra_flops_per_pixel * M
-        variant = f"conv_igemm<128,{bn},{bk}{',pool' if pool2 else ''}>"
-        ktot = pc.KH * pc.KW * pc.C
-        if not pool2 and M <= 16384 and pc.C % 256 == 0 and ktot <= 1024:
-            variant = "conv_igemm<64,64,256,1stage>"
-        elif not pool2 and pc.C % 64 == 0 and ktot >= 1024 and M >= 40000 and pc.N % 128 == 0:  # fx_conv_dma_eligible
-            variant = f"conv_igemm_dma<256,{256 if pc.N % 256 == 0 else 128}>"
-        if (pc.wf is not None and pc.KH == 3 and stride == 1 and not pool2 and not out_f32 and not y_batch_stride and M >= 40000
-                and int(os.environ.get("FX_CONV3_FLAT", "1")) and self.lib.fx_conv3x3_flat_supported(pc.C, pc.N, x.W) == 1):
-            variant = f"conv3x3_flat<{pc.N}>"
-        elif (pc.wf is not None and pc.KH == 1 and stride == 1 and not pool2 and not out_f32 and M >= 40000 and pc.C % 256 == 0 and pc.N % 256 == 0
-                and int(os.environ.get("FX_PW_FLAT", "1")) and not (residual is not None and res_after) and act != "gelu"):
-            variant = f"pw_flat<K{pc.C}>"
+        label = C.create_string_buffer(64)   # the library's own routing decision for this descriptor (fx_conv2d_variant), not a Python mirror of it
+        check(self.lib.fx_conv2d_variant(C.byref(d), label, 64), "fx_conv2d_variant")
+        variant = label.value.decode()
         # algorithmic (compulsory) HBM bytes of this launch: input read once, output written once, residual, weights
         alg_bytes = 2.0 * x.B * x.H * x.W * pc.C + (4.0 if out_f32 else 2.0) * M * pc.N + (2.0 * M * pc.N if residual is not None else 0.0) \
             + 2.0 * pc.N * pc.KH * pc.KW * pc.C
@@ -956,6 +945,8 @@ class _MultiPlan:
         self._io_full: Dict[str, torch.Tensor] = {}
         self.parts = [plan_cls(eng, B // n, H, W, f32_input, parent=self, index=i, **kw) for i in range(n)]
         self.side = [_device_stream(self.dev, 1 + i) for i in range(n - 1)]
+        if os.environ.get("FX_PARTS_SERIAL") == "1":   # profiling aid: the same parts back to back on ONE stream (per-kernel durations without overlap)
+            self.side = [eng.stream] * (n - 1)
         self.graph = None
         self.graph_thr = None
         # bench.py's per-op view: the parts' launch lists back to back

@@ -72,6 +72,10 @@ typedef struct fx_conv_desc {
                                  (conv3x3_flat.hip: the pixels are fetched once for all nine taps).  NULL: implicit GEMM. */
 } fx_conv_desc;
 int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream);
+/* Label of the kernel fx_conv2d_nhwc_bf16 runs for this descriptor ("conv3x3_flat<256>", "pw_flat<K512>", "conv_igemm<128,128,64>",
+ * "conv_igemm_dma<256,128>", ...): the same routing function decides the launch and the label, so a measurement grouped by it cannot
+ * drift from what ran.  out: at least 48 bytes. */
+int fx_conv2d_variant(const fx_conv_desc* d, char* out, int cap);
 /* 1 iff fx_conv2d_nhwc_bf16 would run a 3x3/s1/p1 layer of C input / N output channels and image width W on the halo kernel
  * (given w_frag): N in {64,128,256}, C % 64 == 0 and the halo tile fits the 160 KiB LDS. */
 int fx_conv3x3_flat_supported(int C, int N, int W);

@@ -242,3 +242,43 @@ def test_trainer_ports_and_structures():
     assert len(kept) == 2 and kept.classes.tolist() == [1, 3] and kept.boxes.tensor[1].tolist() == [90.0, 45.0, 100.0, 50.0]
     with pytest.raises(AssertionError):
         inst.set("bad", torch.zeros(2))
+
+
+def test_conv_routing_labels(lib_path, monkeypatch):
+    """fx_conv2d_variant = the label of the kernel fx_conv2d_nhwc_bf16 routes a descriptor to (one routing function for both; host logic,
+    no launch): the production thresholds (flat kernels from 20 000 output pixels, small-M tile up to 16 384) and the error path."""
+    import ctypes as C
+
+    from focoos_amd import _lib
+    from focoos_amd._lib import FX_ACT, FxConvDesc
+
+    lib = _lib.load()
+    for k in ("FX_CONV3_MIN_M", "FX_PW_MIN_M"):
+        monkeypatch.delenv(k, raising=False)
+
+    def label(B, H, W, Cc, N, k, stride=1, frag=True, act="relu", pool2=0, out_f32=0):
+        d = FxConvDesc()
+        d.x = d.w = d.y = d.bias = 0x10000
+        d.w_frag = 0x20000 if frag else None
+        pad = (k - 1) // 2
+        d.B, d.H, d.W, d.C, d.ldx = B, H, W, Cc, Cc
+        d.Ho, d.Wo = ((H + 1) // 2, (W + 1) // 2) if pool2 else ((H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1)
+        d.N, d.ldy, d.ldr = N, (N + 7) // 8 * 8, 0
+        d.KH, d.KW, d.stride, d.pad, d.pool2, d.act, d.out_f32 = k, k, stride, pad, pool2, FX_ACT[act], out_f32
+        buf = C.create_string_buffer(64)
+        rc = lib.fx_conv2d_variant(C.byref(d), buf, 64)
+        return buf.value.decode() if rc == 0 else rc
+
+    assert label(16, 40, 40, 256, 256, 3) == "conv3x3_flat<256>"            # M = 25 600: a 16-image part's 40x40 level
+    assert label(8, 40, 40, 256, 256, 3) == "conv_igemm<128,128,64>"          # M = 12 800 < 20 000
+    assert label(16, 80, 80, 256, 256, 3, frag=False) == "conv_igemm_dma<256,256>"   # no fragment copy: implicit GEMM (DMA tiles from 40 000 pixels)
+    assert label(16, 40, 40, 256, 256, 3, out_f32=1).startswith("conv_igemm")   # fp32 pre-BatchNorm output: not on the halo kernel
+    assert label(16, 40, 40, 1024, 256, 1) == "pw_flat<K1024>"
+    assert label(16, 20, 20, 512, 512, 3) == "conv_igemm<128,128,64>"          # M = 6400, N = 512: not a halo shape
+    assert label(16, 20, 20, 256, 1024, 1) == "conv_igemm<64,64,256,1stage>"   # small M, K <= 1024
+    assert label(16, 160, 160, 64, 256, 1, frag=False) == "conv_igemm<128,128,32>"
+    assert label(16, 320, 320, 32, 32, 3, frag=False) == "conv_igemm<128,32,32>"
+    assert label(16, 160, 160, 256, 512, 1, pool2=1, frag=False) == "conv_igemm<128,128,64,pool>"
+    assert label(16, 40, 40, 250, 256, 3) == -1                                # C % 32 != 0: FX_ERR_INVALID_ARG, as the launch would return
+    monkeypatch.setenv("FX_CONV3_MIN_M", "0")
+    assert label(2, 16, 16, 64, 64, 3) == "conv3x3_flat<64>"                   # the kernel tests' lowered threshold
