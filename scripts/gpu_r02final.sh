@@ -16,6 +16,7 @@ timeout 300 python bench.py --model fai-mf-l-coco-ins --no-cpu-baseline --per-op
 timeout 300 python bench.py --model bisenetformer-l-ade --no-cpu-baseline --per-op $out/${TAG}_bf_per_op_hipevent.txt > $out/${TAG}_bf_bench.json 2> $out/${TAG}_bf_bench.err
 cd /tmp
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o $TAG -- python $ROOT/bench.py --no-cpu-baseline --no-other-configs --steps 10 --warmup 3 > $out/prof.log 2>&1
+FX_PARTS_SERIAL=1 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_serial -o ${TAG}_serial -- python $ROOT/bench.py --no-cpu-baseline --no-other-configs --steps 10 --warmup 3 > $out/prof_serial.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_train -o ${TAG}_train -- python $ROOT/bench.py --train --no-cpu-baseline --steps 6 --warmup 3 > $out/prof_train.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_bf_train -o ${TAG}_bf_train -- python $ROOT/bench.py --train --model bisenetformer-l-ade --norm BN --no-cpu-baseline --steps 4 --warmup 2 > $out/prof_bf_train.log 2>&1
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/pmc_fetch -o f -- python $ROOT/bench.py --no-cpu-baseline --no-other-configs --steps 3 --warmup 2 > $out/pmc_fetch.log 2>&1
@@ -26,7 +27,7 @@ cd $ROOT
 F=$(find $out/pmc_fetch -name '*counter_collection.csv' | head -1); W=$(find $out/pmc_write -name '*counter_collection.csv' | head -1)
 CF=$(find $out/cal_fetch -name '*counter_collection.csv' | head -1); CW=$(find $out/cal_write -name '*counter_collection.csv' | head -1)
 python scripts/pmc_summary.py $F $W $out/${TAG}_pmc_hbm.md $out/${TAG}_pmc_hbm.json $CF $CW | head -12
-for d in prof prof_train prof_bf_train; do find $out/$d -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $out/${TAG}_${d}_kernel_stats.csv; done
+for d in prof prof_serial prof_train prof_bf_train; do find $out/$d -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $out/${TAG}_${d}_kernel_stats.csv; done
 find $out -name '*kernel_trace.csv' -delete; find $out -name '*counter_collection.csv' -size +20M -delete
 head -c 300 $out/${TAG}_bench.json; echo; tail -2 $out/${TAG}_bench.err | cut -c1-300
 python -c "
