@@ -34,7 +34,7 @@ class FxPackEntry(C.Structure):
         ("w", C.c_void_p), ("scale", C.c_void_p), ("bias", C.c_void_p), ("w_fwd", C.c_void_p), ("w_dgrad", C.c_void_p),
         ("w_fwd_frag", C.c_void_p), ("w_dgrad_frag", C.c_void_p), ("bias_out", C.c_void_p),
         ("N", C.c_int32), ("C", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("ld_fwd", C.c_int32), ("ld_dgrad", C.c_int32),
-        ("first_block", C.c_int32), ("reserved", C.c_int32),
+        ("first_block", C.c_int32), ("n_offset", C.c_int32), ("n_total", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -105,6 +105,8 @@ SIGNATURES = {
     "fx_detr_box_loss_bwd_f32": [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "fx_msda_f32_fwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "fx_msda_f32_bwd": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "fx_msda_train_fwd": [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "fx_msda_train_bwd": [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "fx_adamw_workspace_bytes": [],
     "fx_adamw_step_f32": [_vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp],
     "fx_conv2d_wgrad_nhwc_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],

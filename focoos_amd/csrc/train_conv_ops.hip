@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void pack_weights_many_kernel(const fx_pack_en
   bf16_t* __restrict__ w_dgrad = (bf16_t*)e.w_dgrad;
   bf16_t* __restrict__ f_fwd = (bf16_t*)e.w_fwd_frag;
   bf16_t* __restrict__ f_dgrad = (bf16_t*)e.w_dgrad_frag;
-  const int Kf = KH * KW * C, Kd = KH * KW * N;
+  const int Kf = KH * KW * C, Kd = KH * KW * e.n_total;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     const int64_t i = base + j * 256 + threadIdx.x;
@@ -139,13 +139,14 @@ __global__ __launch_bounds__(256) void pack_weights_many_kernel(const fx_pack_en
     r /= KH;
     const int c = (int)(r % C), n = (int)(r / C);
     const bf16_t b = f32_to_bf16(w[i] * (e.scale ? e.scale[n] : 1.0f));
+    const int ng = e.n_offset + n;   // output channel within the (possibly shared) images
     const int kf = (kh * KW + kw) * C + c;
-    const int kd = ((KH - 1 - kh) * KW + (KW - 1 - kw)) * N + n;
-    if (w_fwd) w_fwd[(int64_t)n * e.ld_fwd + kf] = b;
+    const int kd = ((KH - 1 - kh) * KW + (KW - 1 - kw)) * e.n_total + ng;
+    if (w_fwd) w_fwd[(int64_t)ng * e.ld_fwd + kf] = b;
     if (w_dgrad) w_dgrad[(int64_t)c * e.ld_dgrad + kd] = b;
-    if (f_fwd) f_fwd[frag_offset(n, kf, Kf)] = b;
+    if (f_fwd) f_fwd[frag_offset(ng, kf, Kf)] = b;
     if (f_dgrad) f_dgrad[frag_offset(c, kd, Kd)] = b;
-    if (e.bias_out && i < N) e.bias_out[i] = e.bias[i];
+    if (e.bias_out && i < N) e.bias_out[e.n_offset + i] = e.bias[i];
   }
 }
 

@@ -36,8 +36,22 @@ __device__ __forceinline__ Tap4 make_taps(float lx, float ly, int Hl, int Wl) {
   return t;
 }
 
-template <bool BWD>
-__global__ __launch_bounds__(256) void msda_f32_kernel(const float* __restrict__ value, const int32_t* __restrict__ shapes,
+// value element type: fp32 (the reference-shaped entry points) or bf16 (the training graph reads the value projection's bf16 output in
+// place - a column slice of the six layers' shared [B,S,6*256] buffer, row stride ldv - instead of an fp32 copy of it)
+__device__ __forceinline__ void msda_ld4(const float* p, float* v) {
+  const float4 x = *reinterpret_cast<const float4*>(p);
+  v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+}
+__device__ __forceinline__ void msda_ld4(const bf16_t* p, float* v) {
+  const uint2 x = *reinterpret_cast<const uint2*>(p);
+  v[0] = __uint_as_float(x.x << 16); v[1] = __uint_as_float(x.x & 0xffff0000u);
+  v[2] = __uint_as_float(x.y << 16); v[3] = __uint_as_float(x.y & 0xffff0000u);
+}
+__device__ __forceinline__ float msda_ld1(const float* p) { return *p; }
+__device__ __forceinline__ float msda_ld1(const bf16_t* p) { return bf16_to_f32(*p); }
+
+template <bool BWD, typename VT>
+__global__ __launch_bounds__(256) void msda_f32_kernel(const VT* __restrict__ value, int ldv, const int32_t* __restrict__ shapes,
                                                         const int32_t* __restrict__ lstart, int L, int P, const float* __restrict__ loc,
                                                         const float* __restrict__ attn, const float* __restrict__ grad_out, float* __restrict__ out,
                                                         float* __restrict__ grad_value, float* __restrict__ grad_loc, float* __restrict__ grad_attn,
@@ -48,7 +62,7 @@ __global__ __launch_bounds__(256) void msda_f32_kernel(const float* __restrict__
   const int b = bq / Q;
   const int h = lane >> 3, cg = lane & 7;
   const int LP = L * P, CH = M * 32;
-  const int64_t vbase = (int64_t)b * S * CH + h * 32 + cg * 4;
+  const int64_t vbase = (int64_t)b * S * ldv + h * 32 + cg * 4;
   const float* locp = loc + ((int64_t)bq * M + h) * LP * 2;
   const float* attp = attn + ((int64_t)bq * M + h) * LP;
   float go[4] = {0.f, 0.f, 0.f, 0.f};
@@ -59,7 +73,7 @@ __global__ __launch_bounds__(256) void msda_f32_kernel(const float* __restrict__
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   for (int l = 0; l < L; ++l) {
     const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
-    const int64_t lbase = vbase + (int64_t)lstart[l] * CH;
+    const int64_t lbase = vbase + (int64_t)lstart[l] * ldv;
     for (int pt = 0; pt < P; ++pt) {
       const int i = l * P + pt;
       const float aw = attp[i];
@@ -68,8 +82,7 @@ __global__ __launch_bounds__(256) void msda_f32_kernel(const float* __restrict__
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         if (t.idx[k] >= 0) {
-          const float4 x = *reinterpret_cast<const float4*>(value + lbase + (int64_t)t.idx[k] * CH);
-          v[k][0] = x.x; v[k][1] = x.y; v[k][2] = x.z; v[k][3] = x.w;
+          msda_ld4(value + lbase + (int64_t)t.idx[k] * ldv, v[k]);
         } else {
           v[k][0] = v[k][1] = v[k][2] = v[k][3] = 0.f;
         }
@@ -89,7 +102,7 @@ __global__ __launch_bounds__(256) void msda_f32_kernel(const float* __restrict__
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           if (t.idx[k] >= 0) {
-            float* gv = grad_value + lbase + (int64_t)t.idx[k] * CH;
+            float* gv = grad_value + lbase + (int64_t)t.idx[k] * ldv;
             const float wk = aw * t.w[k];
 #pragma unroll
             for (int c = 0; c < 4; ++c) unsafeAtomicAdd(gv + c, wk * go[c]);  // hardware fp32 atomic (plain atomicAdd lowers to a CAS loop)
@@ -117,10 +130,11 @@ __global__ __launch_bounds__(256) void msda_f32_kernel(const float* __restrict__
 // channels (one 128-byte line) of two heads, so a tap costs 8 line-wide L2 atomic requests instead of the 32 quarter-filled
 // ones of the forward's lane layout (4 channels per lane) - the L2 atomic units, not the gathers, bound this kernel.
 // (A wave per sampling point - 12x the waves - was measured slower: 1.25 vs 1.06 ms per layer; the request count is what matters.)
-__global__ __launch_bounds__(256) void msda_f32_bwd_kernel(const float* __restrict__ value, const int32_t* __restrict__ shapes,
+template <typename VT>
+__global__ __launch_bounds__(256) void msda_f32_bwd_kernel(const VT* __restrict__ value, int ldv, const int32_t* __restrict__ shapes,
                                                             const int32_t* __restrict__ lstart, int L, int P, const float* __restrict__ loc,
                                                             const float* __restrict__ attn, const float* __restrict__ grad_out,
-                                                            float* __restrict__ grad_value, float* __restrict__ grad_loc,
+                                                            float* __restrict__ grad_value, int ldg, float* __restrict__ grad_loc,
                                                             float* __restrict__ grad_attn, int B, int S, int Q, int M) {
   const int lane = threadIdx.x & 63;
   const int bq = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -133,7 +147,8 @@ __global__ __launch_bounds__(256) void msda_f32_bwd_kernel(const float* __restri
   for (int hp = 0; hp < 4; ++hp) go[hp] = grad_out[(int64_t)bq * CH + (hp * 2 + hh) * 32 + c];
   for (int l = 0; l < L; ++l) {
     const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
-    const int64_t lbase0 = (int64_t)b * S * CH + (int64_t)lstart[l] * CH + c;
+    const int64_t lbase0 = ((int64_t)b * S + lstart[l]) * ldv + c;
+    const int64_t gbase0 = ((int64_t)b * S + lstart[l]) * ldg + c;
     for (int pt = 0; pt < P; ++pt) {
       const int i = l * P + pt;
 #pragma unroll
@@ -142,17 +157,17 @@ __global__ __launch_bounds__(256) void msda_f32_bwd_kernel(const float* __restri
         const int64_t pidx = ((int64_t)bq * M + h) * LP + i;
         const float aw = attn[pidx];
         const Tap4 t = make_taps(loc[2 * pidx], loc[2 * pidx + 1], Hl, Wl);
-        const int64_t lbase = lbase0 + h * 32;
+        const int64_t lbase = lbase0 + h * 32, gbase = gbase0 + h * 32;
         float v[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = t.idx[k] >= 0 ? value[lbase + (int64_t)t.idx[k] * CH] : 0.f;
+        for (int k = 0; k < 4; ++k) v[k] = t.idx[k] >= 0 ? msda_ld1(value + lbase + (int64_t)t.idx[k] * ldv) : 0.f;
         const float g = go[hp];
         float g_a = g * (t.w[0] * v[0] + t.w[1] * v[1] + t.w[2] * v[2] + t.w[3] * v[3]);
         float g_x = g * ((v[1] - v[0]) * (1.f - t.ty) + (v[3] - v[2]) * t.ty);
         float g_y = g * ((v[2] - v[0]) * (1.f - t.tx) + (v[3] - v[1]) * t.tx);
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          if (t.idx[k] >= 0) unsafeAtomicAdd(grad_value + lbase + (int64_t)t.idx[k] * CH, aw * t.w[k] * g);
+          if (t.idx[k] >= 0) unsafeAtomicAdd(grad_value + gbase + (int64_t)t.idx[k] * ldg, aw * t.w[k] * g);
 #pragma unroll
         for (int o = 1; o < 32; o <<= 1) {
           g_a += __shfl_xor(g_a, o, 64);
@@ -170,26 +185,52 @@ __global__ __launch_bounds__(256) void msda_f32_bwd_kernel(const float* __restri
   }
 }
 
-extern "C" int fx_msda_f32_fwd(const float* value, const int32_t* spatial_shapes, const int32_t* level_start, int L, int P, const float* loc,
-                               const float* attn, float* out, int B, int S, int Q, int M, fx_stream_t stream_) {
+// value: fp32 or bf16 (value_bf16), row stride ldv elements (>= M*32; a column slice of a wider buffer is fine), 16-byte (fp32) /
+// 8-byte (bf16) aligned rows.  grad_value: fp32, row stride ldg; zeroed here unless zero_grad_value == 0 (several launches accumulating
+// into column slices of one buffer zero it once, themselves).
+extern "C" int fx_msda_train_fwd(const void* value, int value_bf16, int ldv, const int32_t* spatial_shapes, const int32_t* level_start, int L, int P,
+                                 const float* loc, const float* attn, float* out, int B, int S, int Q, int M, fx_stream_t stream_) {
   FX_CHECK_ARG(value && spatial_shapes && level_start && loc && attn && out && B > 0 && S > 0 && Q > 0 && L > 0 && P > 0);
   if (M != 8) return FX_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(msda_f32_kernel<false>, dim3((B * Q + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), value, spatial_shapes,
-                     level_start, L, P, loc, attn, nullptr, out, nullptr, nullptr, nullptr, B, S, Q, M);
+  FX_CHECK_ARG(ldv >= M * 32 && ldv % 4 == 0 && ((uintptr_t)value % (value_bf16 ? 8 : 16)) == 0);
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (value_bf16)
+    hipLaunchKernelGGL((msda_f32_kernel<false, bf16_t>), dim3((B * Q + 3) / 4), dim3(256), 0, stream, (const bf16_t*)value, ldv, spatial_shapes,
+                       level_start, L, P, loc, attn, nullptr, out, nullptr, nullptr, nullptr, B, S, Q, M);
+  else
+    hipLaunchKernelGGL((msda_f32_kernel<false, float>), dim3((B * Q + 3) / 4), dim3(256), 0, stream, (const float*)value, ldv, spatial_shapes,
+                       level_start, L, P, loc, attn, nullptr, out, nullptr, nullptr, nullptr, B, S, Q, M);
   return fx_launch_status();
+}
+
+extern "C" int fx_msda_train_bwd(const void* value, int value_bf16, int ldv, const int32_t* spatial_shapes, const int32_t* level_start, int L, int P,
+                                 const float* loc, const float* attn, const float* grad_out, float* grad_value, int ldg, int zero_grad_value,
+                                 float* grad_loc, float* grad_attn, int B, int S, int Q, int M, fx_stream_t stream_) {
+  FX_CHECK_ARG(value && spatial_shapes && level_start && loc && attn && grad_out && grad_value && grad_loc && grad_attn);
+  FX_CHECK_ARG(B > 0 && S > 0 && Q > 0 && L > 0 && P > 0);
+  if (M != 8) return FX_ERR_UNSUPPORTED;
+  FX_CHECK_ARG(ldv >= M * 32 && ldg >= M * 32 && (!zero_grad_value || ldg == M * 32));
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (zero_grad_value && hipMemsetAsync(grad_value, 0, (size_t)B * S * M * 32 * sizeof(float), stream) != hipSuccess) return FX_ERR_RUNTIME;
+  if (value_bf16)
+    hipLaunchKernelGGL(msda_f32_bwd_kernel<bf16_t>, dim3((B * Q + 3) / 4), dim3(256), 0, stream, (const bf16_t*)value, ldv, spatial_shapes, level_start, L,
+                       P, loc, attn, grad_out, grad_value, ldg, grad_loc, grad_attn, B, S, Q, M);
+  else
+    hipLaunchKernelGGL(msda_f32_bwd_kernel<float>, dim3((B * Q + 3) / 4), dim3(256), 0, stream, (const float*)value, ldv, spatial_shapes, level_start, L,
+                       P, loc, attn, grad_out, grad_value, ldg, grad_loc, grad_attn, B, S, Q, M);
+  return fx_launch_status();
+}
+
+extern "C" int fx_msda_f32_fwd(const float* value, const int32_t* spatial_shapes, const int32_t* level_start, int L, int P, const float* loc,
+                               const float* attn, float* out, int B, int S, int Q, int M, fx_stream_t stream_) {
+  return fx_msda_train_fwd(value, 0, M * 32, spatial_shapes, level_start, L, P, loc, attn, out, B, S, Q, M, stream_);
 }
 
 extern "C" int fx_msda_f32_bwd(const float* value, const int32_t* spatial_shapes, const int32_t* level_start, int L, int P, const float* loc,
                                const float* attn, const float* grad_out, float* grad_value, float* grad_loc, float* grad_attn, int B, int S, int Q,
                                int M, fx_stream_t stream_) {
-  FX_CHECK_ARG(value && spatial_shapes && level_start && loc && attn && grad_out && grad_value && grad_loc && grad_attn);
-  FX_CHECK_ARG(B > 0 && S > 0 && Q > 0 && L > 0 && P > 0);
-  if (M != 8) return FX_ERR_UNSUPPORTED;
-  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
-  if (hipMemsetAsync(grad_value, 0, (size_t)B * S * M * 32 * sizeof(float), stream) != hipSuccess) return FX_ERR_RUNTIME;
-  hipLaunchKernelGGL(msda_f32_bwd_kernel, dim3((B * Q + 3) / 4), dim3(256), 0, stream, value, spatial_shapes, level_start, L, P, loc, attn, grad_out,
-                     grad_value, grad_loc, grad_attn, B, S, Q, M);
-  return fx_launch_status();
+  return fx_msda_train_bwd(value, 0, M * 32, spatial_shapes, level_start, L, P, loc, attn, grad_out, grad_value, M * 32, 1, grad_loc, grad_attn, B, S, Q,
+                           M, stream_);
 }
 
 // ------------------------------------------------------------------------------------------------

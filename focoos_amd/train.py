@@ -52,10 +52,65 @@ class _MSDAFunction(torch.autograd.Function):
         return gv.view(B, S, M, D).to(d0), None, None, gl.to(d1), ga.to(d2)
 
 
-def ms_deform_attn_core(value: torch.Tensor, value_spatial_shapes, sampling_locations: torch.Tensor, attention_weights: torch.Tensor) -> torch.Tensor:
-    """Same signature and semantics as the reference's ``ms_deform_attn_core_pytorch``; differentiable w.r.t. value,
-    sampling_locations and attention_weights.  value [B,S,M,D=32], locations [B,Q,M,L,P,2] in [0,1], weights [B,Q,M,L,P]."""
-    dev = value.device
+class ValueGradSink:
+    """Shared fp32 gradient buffer of a value projection that G deformable-attention layers read as column slices ([B,S,G*256]): every
+    layer's backward accumulates into its slice; the G-th (last) one hands the whole buffer to autograd, the others return None - no
+    per-layer fp32 buffers, zero-fills, casts or G-1 memory-sized gradient additions."""
+
+    def __init__(self, G: int):
+        self.G, self.count, self.buf = G, 0, None
+
+
+class _MSDAGroupFunction(torch.autograd.Function):
+    """ms_deform_attn_core on slice ``g`` of a shared bf16 value tensor [B,S,G*M*32] (fx_msda_train_fwd / _bwd)."""
+
+    @staticmethod
+    def forward(ctx, value_all, sink: ValueGradSink, g: int, shapes_t, starts_t, loc, attn):
+        lib = _lib.load()
+        B, S, Nt = value_all.shape
+        M, D = 8, 32
+        Q, L, P = loc.shape[1], loc.shape[3], loc.shape[4]
+        assert value_all.dtype == torch.bfloat16 and value_all.is_contiguous() and Nt == sink.G * M * D
+        lc, aw = loc.float().contiguous(), attn.float().contiguous()
+        out = torch.empty(B, Q, M * D, dtype=torch.float32, device=value_all.device)
+        check(lib.fx_msda_train_fwd(value_all.data_ptr() + g * M * D * 2, 1, Nt, shapes_t.data_ptr(), starts_t.data_ptr(), L, P, lc.data_ptr(),
+                                    aw.data_ptr(), out.data_ptr(), B, S, Q, M, _stream(value_all.device)), "fx_msda_train_fwd")
+        ctx.save_for_backward(value_all, shapes_t, starts_t, lc, aw)
+        ctx.sink, ctx.g, ctx.dims = sink, g, (B, S, Q, M, D, L, P, Nt)
+        ctx.in_dtypes = (loc.dtype, attn.dtype)
+        return out.to(torch.bfloat16)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        value_all, shapes_t, starts_t, lc, aw = ctx.saved_tensors
+        B, S, Q, M, D, L, P, Nt = ctx.dims
+        sink, g = ctx.sink, ctx.g
+        go = grad_out.float().contiguous()
+        if sink.buf is None:
+            sink.buf = torch.zeros(B, S, Nt, dtype=torch.float32, device=value_all.device)
+        gl, ga = torch.empty_like(lc), torch.empty_like(aw)
+        check(lib.fx_msda_train_bwd(value_all.data_ptr() + g * M * D * 2, 1, Nt, shapes_t.data_ptr(), starts_t.data_ptr(), L, P, lc.data_ptr(),
+                                    aw.data_ptr(), go.data_ptr(), sink.buf.data_ptr() + g * M * D * 4, Nt, 0, gl.data_ptr(), ga.data_ptr(), B, S, Q, M,
+                                    _stream(value_all.device)), "fx_msda_train_bwd")
+        sink.count += 1
+        gv = None
+        if sink.count == sink.G:   # every layer has accumulated its slice
+            gv = sink.buf.to(torch.bfloat16)
+            sink.buf, sink.count = None, 0
+        d1, d2 = ctx.in_dtypes
+        return gv, None, None, None, None, gl.to(d1), ga.to(d2)
+
+
+def ms_deform_attn_grouped(value_all: torch.Tensor, sink: ValueGradSink, g: int, value_spatial_shapes, sampling_locations: torch.Tensor,
+                           attention_weights: torch.Tensor) -> torch.Tensor:
+    """ms_deform_attn_core for layer ``g`` of G layers whose value projections were computed together: value_all bf16 [B,S,G*256]; returns
+    bf16 [B,Q,256].  All G layers must take part in a backward pass (the last one to run delivers the value gradient)."""
+    st, ss = _shape_tensors(value_spatial_shapes, value_all.device)
+    return _MSDAGroupFunction.apply(value_all, sink, g, st, ss, sampling_locations, attention_weights)
+
+
+def _shape_tensors(value_spatial_shapes, dev):
     shapes = [(int(h), int(w)) for h, w in value_spatial_shapes]
     starts, acc = [], 0
     for h, w in shapes:
@@ -64,7 +119,13 @@ def ms_deform_attn_core(value: torch.Tensor, value_spatial_shapes, sampling_loca
     key = (tuple(shapes), str(dev))
     if key not in _SHAPE_CACHE:  # cached: no host->device copy per call
         _SHAPE_CACHE[key] = (torch.tensor(shapes, dtype=torch.int32, device=dev), torch.tensor(starts, dtype=torch.int32, device=dev))
-    st, ss = _SHAPE_CACHE[key]
+    return _SHAPE_CACHE[key]
+
+
+def ms_deform_attn_core(value: torch.Tensor, value_spatial_shapes, sampling_locations: torch.Tensor, attention_weights: torch.Tensor) -> torch.Tensor:
+    """Same signature and semantics as the reference's ``ms_deform_attn_core_pytorch``; differentiable w.r.t. value,
+    sampling_locations and attention_weights.  value [B,S,M,D=32], locations [B,Q,M,L,P,2] in [0,1], weights [B,Q,M,L,P]."""
+    st, ss = _shape_tensors(value_spatial_shapes, value.device)
     return _MSDAFunction.apply(value, st, ss, sampling_locations, attention_weights)
 
 

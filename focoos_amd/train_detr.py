@@ -22,8 +22,9 @@ from torch import nn
 from . import _lib
 from ._lib import check
 from .criterion import h2d_i32, BoxHungarianMatcher, _Targets
-from .train import ms_deform_attn_core
-from .train_nn import (ConvNormLayer, HybridEncoder, LayerNorm, Linear, MultiheadAttention, ResNetVd, _AddFn, _Layers, _stream)
+from .train import ValueGradSink, ms_deform_attn_core, ms_deform_attn_grouped
+from .train_nn import (ConvNormLayer, HybridEncoder, LayerNorm, Linear, MultiheadAttention, ResNetVd, _AddFn, _Layers, _LinearGroupFn, _PackedLinearGroup,
+                       _stream)
 
 
 class MLP(nn.Module):
@@ -81,15 +82,20 @@ class MSDeformableAttention(nn.Module):
         self.value_proj = Linear(lib, c, c)
         self.output_proj = Linear(lib, c, c)
 
-    def forward(self, query, ref_points, memory, shapes, residual):
+    def forward(self, query, ref_points, memory, shapes, residual, value_all=None, sink=None, g=0):
+        """``value_all`` / ``sink`` / ``g``: the value projections of all decoder layers computed together by the predictor (bf16
+        [B,S,G*256]; this layer reads column slice g); without them the layer projects ``memory`` itself (the reference's form)."""
         B, Q, _ = query.shape
         S = memory.shape[1]
-        value = self.value_proj(memory).view(B, S, self.h, self.c // self.h)
         off = self.sampling_offsets(query).float().view(B, Q, self.h, self.l, self.p, 2)
         aw = torch.softmax(self.attention_weights(query).float().view(B, Q, self.h, self.l * self.p), -1).view(B, Q, self.h, self.l, self.p)
         loc = ref_points[:, :, None, :, None, :2] + off / self.p * ref_points[:, :, None, :, None, 2:] * 0.5
-        out = ms_deform_attn_core(value, shapes, loc, aw)
-        return self.output_proj(out.to(torch.bfloat16), residual=residual)
+        if value_all is not None:
+            out = ms_deform_attn_grouped(value_all, sink, g, shapes, loc, aw)
+        else:
+            value = self.value_proj(memory).view(B, S, self.h, self.c // self.h)
+            out = ms_deform_attn_core(value, shapes, loc, aw).to(torch.bfloat16)
+        return self.output_proj(out, residual=residual)
 
 
 class TransformerDecoderLayer(nn.Module):
@@ -106,10 +112,10 @@ class TransformerDecoderLayer(nn.Module):
         self.linear2 = Linear(lib, ffn, c)
         self.norm3 = LayerNorm(lib, c)
 
-    def forward(self, tgt, ref_input, memory, shapes, qpos):
+    def forward(self, tgt, ref_input, memory, shapes, qpos, value_all=None, sink=None, g=0):
         qk = _AddFn.apply(tgt, qpos, self.lib)
         tgt = self.norm1(self.self_attn(qk, qk, tgt, residual=tgt))
-        tgt = self.norm2(self.cross_attn(_AddFn.apply(tgt, qpos, self.lib), ref_input, memory, shapes, residual=tgt))
+        tgt = self.norm2(self.cross_attn(_AddFn.apply(tgt, qpos, self.lib), ref_input, memory, shapes, residual=tgt, value_all=value_all, sink=sink, g=g))
         return self.norm3(self.linear2(self.linear1(tgt), residual=tgt))
 
 
@@ -142,6 +148,8 @@ class TransformerPredictor(nn.Module):
         self.dec_score_classifier = nn.ModuleList([Linear(lib, c, nc) for _ in range(nl)])
         self.dec_bbox_classifier = nn.ModuleList([MLP(lib, c, c, 4, 3) for _ in range(nl)])
         self._anchor_cache = {}
+        self._value_group = _PackedLinearGroup()   # the six value projections as one GEMM (what the inference plan calls value_all)
+        self._sink = None
 
     def _anchors(self, shapes, dev, grid_size=0.05, eps=1e-2):
         key = (tuple(shapes), dev)
@@ -178,9 +186,16 @@ class TransformerPredictor(nn.Module):
         ref_detach = torch.sigmoid(ref_unact.detach())
         ref = ref_detach
         logits, boxes = [], []
+        # every layer's cross-attention projects the same memory: one GEMM with 6 x 256 outputs; the layers read column slices of it and
+        # accumulate the value gradient into slices of one fp32 buffer (train.ValueGradSink)
+        if self._sink is not None and self._sink.count:
+            raise _lib.FocoosAmdError("the previous backward pass did not reach every decoder layer's deformable attention: value gradient incomplete")
+        vps = [l.cross_attn.value_proj for l in self.decoder.layers]
+        value_all = _LinearGroupFn.apply(memory, self._value_group, self.lib, *[v.weight for v in vps], *[v.bias for v in vps])
+        sink = self._sink = ValueGradSink(len(vps))
         for i, layer in enumerate(self.decoder.layers):
             qpos = self.query_pos_head(ref_detach.to(torch.bfloat16))
-            out = layer(out, ref_detach.unsqueeze(2), memory, shapes, qpos)
+            out = layer(out, ref_detach.unsqueeze(2), memory, shapes, qpos, value_all=value_all, sink=sink, g=i)
             delta = self.dec_bbox_classifier[i](out)
             inter = _BoxRefineFn.apply(delta, ref_detach)
             logits.append(self.dec_score_classifier[i](out))

@@ -139,7 +139,7 @@ class WeightPacker:
             if hasattr(m, "pack_fields"):
                 out.append(m)
             for v in vars(m).values():
-                if isinstance(v, _PackedLinear):
+                if isinstance(v, (_PackedLinear, _PackedLinearGroup)):
                     out.append(v)
         return out
 
@@ -158,14 +158,18 @@ class WeightPacker:
             return 0
         key = tuple(f[1] for _, f in pend)
         if self.table is None or self.table[0] != key:
-            arr = (FxPackEntry * len(pend))()
+            # one table entry per master tensor: a layer contributes one field tuple, a group of masters sharing images a tuple of them
+            entries = [t for _, (_, fs) in pend for t in (fs if isinstance(fs[0], tuple) else (fs,))]
+            arr = (FxPackEntry * len(entries))()
             blocks = 0
-            for e, (_, (_, (w, scale, bias, w_fwd, w_dgrad, f_fwd, f_dgrad, bias_out, N, Cc, KH, KW, ld_fwd, ld_dgrad))) in zip(arr, pend):
+            for e, t in zip(arr, entries):
+                w, scale, bias, w_fwd, w_dgrad, f_fwd, f_dgrad, bias_out, N, Cc, KH, KW, ld_fwd, ld_dgrad = t[:14]
                 e.w, e.scale, e.bias, e.w_fwd, e.w_dgrad, e.w_fwd_frag, e.w_dgrad_frag, e.bias_out = w, scale, bias, w_fwd, w_dgrad, f_fwd, f_dgrad, bias_out
                 e.N, e.C, e.KH, e.KW, e.ld_fwd, e.ld_dgrad, e.first_block = N, Cc, KH, KW, ld_fwd, ld_dgrad, blocks
+                e.n_offset, e.n_total = (t[14], t[15]) if len(t) > 14 else (0, N)
                 blocks += (N * Cc * KH * KW + 2047) // 2048
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-            self.table = (key, host.to(dev), len(pend), blocks)
+            self.table = (key, host.to(dev), len(entries), blocks)
         _, table, n, blocks = self.table
         check(_lib.load().fx_pack_weights_many_f32(table.data_ptr(), n, blocks, _stream(dev)), "fx_pack_weights_many_f32")
         for o, (ver, _) in pend:
@@ -906,6 +910,63 @@ class _PackedLinear:
         self.ver = ver
 
 
+class _PackedLinearGroup:
+    """bf16 images of G equally shaped [N, K] fp32 weights (+ biases) stacked along the output dimension: ONE forward GEMM with G*N outputs
+    and ONE input-gradient GEMM whose reduction runs over all G*N channels - the six value projections of the decoder read the same
+    ``memory`` (the inference plan's ``value_all``).  N, K multiples of 32."""
+
+    def __init__(self):
+        self.ver = None
+        self.w_fwd = self.w_t = self.bias = self.w_fwd_frag = self.w_t_frag = self._src = None
+        self.G = self.N = self.K = 0
+
+    def _version(self, weights, biases):
+        return (tuple(w._version for w in weights), tuple(b._version for b in biases), weights[0].device, WEIGHTS_EPOCH[0])
+
+    def _prepare(self, weights, biases):
+        dev = weights[0].device
+        G, (N, K) = len(weights), weights[0].shape
+        assert N % 32 == 0 and K % 32 == 0 and all(tuple(w.shape) == (N, K) and w.is_contiguous() for w in weights)
+        self.G, self.N, self.K = G, N, K
+        Nt = G * N
+        if self.w_fwd is None or self.w_fwd.device != dev:
+            self.w_fwd = torch.zeros(_rup(Nt, 128), 1, 1, K, dtype=torch.bfloat16, device=dev)
+            self.w_t = torch.zeros(_rup(K, 128), 1, 1, Nt, dtype=torch.bfloat16, device=dev)
+            self.bias = torch.zeros(_rup(Nt, 128), dtype=torch.float32, device=dev)
+            ok = _frag_eligible(Nt, K, 1)
+            self.w_fwd_frag = torch.empty(Nt * K, dtype=torch.bfloat16, device=dev) if ok else None
+            self.w_t_frag = torch.empty(Nt * K, dtype=torch.bfloat16, device=dev) if ok else None
+        return tuple((w.data_ptr(), None, b.data_ptr(), self.w_fwd.data_ptr(), self.w_t.data_ptr(), _ptr(self.w_fwd_frag), _ptr(self.w_t_frag),
+                      self.bias.data_ptr(), N, K, 1, 1, K, Nt, g * N, Nt) for g, (w, b) in enumerate(zip(weights, biases)))
+
+    def sync(self, lib, weights, biases):
+        ver = self._version(weights, biases)
+        if ver == self.ver:
+            return
+        dev = weights[0].device
+        N, K, Nt = weights[0].shape[0], weights[0].shape[1], len(weights) * weights[0].shape[0]
+        for g, f in enumerate(self._prepare(weights, biases)):   # lazy path: one launch per master into its rows / columns of the shared images
+            check(lib.fx_pack_linear_weights_f32(f[0], f[2], f[3] + g * N * K * 2, f[4] + g * N * 2, f[7] + g * N * 4, N, K, Nt, K, _stream(dev)),
+                  "fx_pack_linear_weights_f32")
+        if self.w_fwd_frag is not None:
+            check(lib.fx_pack_frag_bf16(self.w_fwd.data_ptr(), self.w_fwd_frag.data_ptr(), Nt, K, _stream(dev)), "fx_pack_frag_bf16")
+            check(lib.fx_pack_frag_bf16(self.w_t.data_ptr(), self.w_t_frag.data_ptr(), K, Nt, _stream(dev)), "fx_pack_frag_bf16")
+        self.ver = ver
+        self._src = (tuple(weights), tuple(biases))
+
+    def pack_fields(self, dev):
+        if self._src is None:
+            return None
+        weights, biases = self._src
+        if weights[0].device != dev:
+            return None
+        ver = self._version(weights, biases)
+        return None if ver == self.ver else (ver, self._prepare(weights, biases))
+
+    def pack_stamp(self, ver):
+        self.ver = ver
+
+
 def _pad_last(t: torch.Tensor, n: int) -> torch.Tensor:
     if t.shape[-1] == n:
         return t.contiguous()
@@ -1008,6 +1069,49 @@ class _LinearFn(torch.autograd.Function):
         if ctx.has_res:
             dres = (dz if Np == N else dz[..., :N].contiguous()).reshape(dy.shape)
         return dx, dw, db, dres, None, None, None, None, None
+
+
+class _LinearGroupFn(torch.autograd.Function):
+    """y[..., g*N:(g+1)*N] = x @ W_g^T + b_g for G equally shaped Linear layers reading the same input: one forward GEMM with G*N
+    outputs, one input-gradient GEMM over all G*N channels (the sum over the layers happens inside the reduction), G weight-gradient
+    launches on column slices of dy.  args: x [..., K] bf16, then G weights, then G biases."""
+
+    @staticmethod
+    def forward(ctx, x, group: _PackedLinearGroup, lib, *wb):
+        G = len(wb) // 2
+        weights, biases = wb[:G], wb[G:]
+        group.sync(lib, weights, biases)
+        N, K = weights[0].shape
+        x2 = x.reshape(1, 1, -1, K).contiguous()
+        y = _conv_call(lib, x2, group.w_fwd, group.bias, G * N, 1, 1, 1, 0, None, None, w_frag=group.w_fwd_frag)
+        ctx.group, ctx.lib, ctx.G, ctx.N, ctx.K = group, lib, G, N, K
+        ctx.params = (weights, biases)
+        ctx.save_for_backward(x2)
+        return y.reshape(*x.shape[:-1], G * N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        group, lib, G, N, K = ctx.group, ctx.lib, ctx.G, ctx.N, ctx.K
+        weights, biases = ctx.params
+        dev = x2.device
+        R = x2.shape[2]
+        dz = dy.reshape(1, 1, R, G * N).contiguous()
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _conv_call(lib, dz, group.w_t, None, K, 1, 1, 1, 0, None, None, w_frag=group.w_t_frag).reshape(dy.shape[:-1] + (K,))
+        direct = DIRECT_GRAD[0] and all(w.grad is not None for w in weights) and all(b.grad is not None for b in biases)
+        side = _wgrad_fork(dev, x2, dz) if direct else None
+        st = C.c_void_p(side.cuda_stream) if side is not None else _stream(dev)
+        dws, dbs = [], []
+        for g in range(G):
+            wt = weights[g].grad if direct else ARENA.zeros((N, K), dev)
+            bt = biases[g].grad if direct else ARENA.zeros((N,), dev)
+            check(lib.fx_conv2d_wgrad_bias_nhwc_bf16(x2.data_ptr(), K, dz.data_ptr() + g * N * 2, G * N, wt.data_ptr(), bt.data_ptr(),
+                                                     1, 1, R, K, 1, R, N, 1, 1, 1, 0, st), "fx_conv2d_wgrad_bias_nhwc_bf16")
+            dws.append(None if direct else wt)
+            dbs.append(None if direct else bt)
+        return (dx, None, None) + tuple(dws) + tuple(dbs)
 
 
 class Linear(nn.Module):

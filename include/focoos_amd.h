@@ -400,6 +400,15 @@ int fx_msda_f32_fwd(const float* value, const int32_t* spatial_shapes, const int
 int fx_msda_f32_bwd(const float* value, const int32_t* spatial_shapes, const int32_t* level_start, int L, int P, const float* loc,
                     const float* attn, const float* grad_out, float* grad_value, float* grad_loc, float* grad_attn, int B, int S, int Q, int M,
                     fx_stream_t stream);
+/* The same pair with a typed, strided value operand (the training graph: the six decoder layers share one value projection whose
+ * bf16 output [B,S,6*M*32] each layer reads as a column slice - no fp32 copy - and whose fp32 gradient they accumulate into column
+ * slices of one buffer): value fp32 or bf16 (value_bf16), row stride ldv elements; grad_value fp32, row stride ldg, zeroed by the call
+ * only when zero_grad_value != 0 (then ldg must be M*32). */
+int fx_msda_train_fwd(const void* value, int value_bf16, int ldv, const int32_t* spatial_shapes, const int32_t* level_start, int L, int P,
+                      const float* loc, const float* attn, float* out, int B, int S, int Q, int M, fx_stream_t stream);
+int fx_msda_train_bwd(const void* value, int value_bf16, int ldv, const int32_t* spatial_shapes, const int32_t* level_start, int L, int P,
+                      const float* loc, const float* attn, const float* grad_out, float* grad_value, int ldg, int zero_grad_value,
+                      float* grad_loc, float* grad_attn, int B, int S, int Q, int M, fx_stream_t stream);
 
 /* Fused multi-tensor AdamW + global-norm gradient clipping over one flat fp32 buffer (replaces the
  * ~500 single-tensor param groups of focoos/trainer/solver/build.py:39-138 and the clip of :29-36 / trainer.py:758-760).
@@ -444,7 +453,7 @@ int fx_pack_linear_weights_f32(const float* w, const float* bias, void* w_fwd, v
 
 /* Multi-tensor form of the two functions above: every weight image of a model rebuilt in one launch.  `entries_dev` is a device
  * array; entry e converts master w [N][C][KH][KW] (a Linear: KH = KW = 1, C = K) times scale[n] (NULL: 1) into w_fwd (row n at
- * n * ld_fwd, column (kh*KW + kw)*C + c), w_dgrad (row c at c * ld_dgrad, column ((KH-1-kh)*KW + (KW-1-kw))*N + n), their
+ * (n_offset + n) * ld_fwd, column (kh*KW + kw)*C + c), w_dgrad (row c at c * ld_dgrad, column ((KH-1-kh)*KW + (KW-1-kw))*n_total + n_offset + n), their
  * fragment-order copies (NULL: none; rows % 32 == 0, columns % 16 == 0) and copies bias [N] to bias_out (NULL: none).  Workgroups
  * first_block .. first_block + ceil(N*C*KH*KW / 2048) - 1 belong to entry e (ascending, gap-free); total_blocks = their sum. */
 typedef struct {
@@ -458,7 +467,10 @@ typedef struct {
   float* bias_out;
   int32_t N, C, KH, KW;
   int32_t ld_fwd, ld_dgrad;
-  int32_t first_block, reserved;
+  int32_t first_block;
+  int32_t n_offset, n_total; /* this entry's N output channels are channels n_offset .. n_offset+N-1 of images with n_total output channels
+                                (several masters sharing one image, e.g. the six value projections of the decoder); plain layer: 0, N */
+  int32_t reserved;
 } fx_pack_entry;
 int fx_pack_weights_many_f32(const fx_pack_entry* entries_dev, int n_entries, int total_blocks, fx_stream_t stream);
 
