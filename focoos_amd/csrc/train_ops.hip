@@ -5,6 +5,8 @@
 
 #include "common.h"
 
+int fx_tune(const char* env_name, int default_value);  // conv_igemm.hip: integer tuning knob from the environment
+
 // ------------------------------------------------------------------------------------------------
 // ms_deform_attn_core (focoos/nn/layers/deformable.py:10-35), fp32.  One wave per (batch, query); lane = (head = lane>>3,
 // 4 channels = (lane&7)*4), M*D = 256.  Forward writes out[b,q,h*32+c]; backward scatters grad_value with fp32 atomics
@@ -135,21 +137,28 @@ __global__ __launch_bounds__(256) void msda_f32_bwd_kernel(const VT* __restrict_
                                                             const int32_t* __restrict__ lstart, int L, int P, const float* __restrict__ loc,
                                                             const float* __restrict__ attn, const float* __restrict__ grad_out,
                                                             float* __restrict__ grad_value, int ldg, float* __restrict__ grad_loc,
-                                                            float* __restrict__ grad_attn, int B, int S, int Q, int M) {
+                                                            float* __restrict__ grad_attn, int B, int S, int Q, int M, int lsplit, int psplit) {
   const int lane = threadIdx.x & 63;
-  const int bq = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // lsplit = L: one wave per (batch, query, LEVEL) - B*Q waves alone (4800 for 16 x 300) are ~5 per SIMD, too few to hide the
+  // loc -> taps -> value-load dependency chain of every sampling point; the atomic request count is unchanged
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int per_q = lsplit * psplit;
+  const int bq = unit / per_q;
   if (bq >= B * Q) return;
+  const int sub = unit - bq * per_q;
+  const int l_lo = lsplit > 1 ? sub / psplit : 0, l_hi = lsplit > 1 ? l_lo + 1 : L;
+  const int pt_lo = (sub % psplit) * (P / psplit), pt_hi = pt_lo + P / psplit;
   const int b = bq / Q;
   const int hh = lane >> 5, c = lane & 31;
   const int LP = L * P, CH = M * 32;
   float go[4];
 #pragma unroll
   for (int hp = 0; hp < 4; ++hp) go[hp] = grad_out[(int64_t)bq * CH + (hp * 2 + hh) * 32 + c];
-  for (int l = 0; l < L; ++l) {
+  for (int l = l_lo; l < l_hi; ++l) {
     const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
     const int64_t lbase0 = ((int64_t)b * S + lstart[l]) * ldv + c;
     const int64_t gbase0 = ((int64_t)b * S + lstart[l]) * ldg + c;
-    for (int pt = 0; pt < P; ++pt) {
+    for (int pt = pt_lo; pt < pt_hi; ++pt) {
       const int i = l * P + pt;
 #pragma unroll
       for (int hp = 0; hp < 4; ++hp) {
@@ -212,12 +221,17 @@ extern "C" int fx_msda_train_bwd(const void* value, int value_bf16, int ldv, con
   FX_CHECK_ARG(ldv >= M * 32 && ldg >= M * 32 && (!zero_grad_value || ldg == M * 32));
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (zero_grad_value && hipMemsetAsync(grad_value, 0, (size_t)B * S * M * 32 * sizeof(float), stream) != hipSuccess) return FX_ERR_RUNTIME;
+  static const int split_on = fx_tune("FX_MSDA_BWD_LEVEL_SPLIT", 1);
+  static const int psplit_env = fx_tune("FX_MSDA_BWD_POINT_SPLIT", 1);
+  const int lsplit = split_on ? L : 1;
+  const int psplit = (split_on && psplit_env > 0 && P % psplit_env == 0) ? psplit_env : 1;
+  const dim3 grid((B * Q * lsplit * psplit + 3) / 4);
   if (value_bf16)
-    hipLaunchKernelGGL(msda_f32_bwd_kernel<bf16_t>, dim3((B * Q + 3) / 4), dim3(256), 0, stream, (const bf16_t*)value, ldv, spatial_shapes, level_start, L,
-                       P, loc, attn, grad_out, grad_value, ldg, grad_loc, grad_attn, B, S, Q, M);
+    hipLaunchKernelGGL(msda_f32_bwd_kernel<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)value, ldv, spatial_shapes, level_start, L, P, loc, attn,
+                       grad_out, grad_value, ldg, grad_loc, grad_attn, B, S, Q, M, lsplit, psplit);
   else
-    hipLaunchKernelGGL(msda_f32_bwd_kernel<float>, dim3((B * Q + 3) / 4), dim3(256), 0, stream, (const float*)value, ldv, spatial_shapes, level_start, L,
-                       P, loc, attn, grad_out, grad_value, ldg, grad_loc, grad_attn, B, S, Q, M);
+    hipLaunchKernelGGL(msda_f32_bwd_kernel<float>, grid, dim3(256), 0, stream, (const float*)value, ldv, spatial_shapes, level_start, L, P, loc, attn,
+                       grad_out, grad_value, ldg, grad_loc, grad_attn, B, S, Q, M, lsplit, psplit);
   return fx_launch_status();
 }
 
