@@ -172,7 +172,10 @@ extern "C" int fx_layernorm_bwd_bf16(const void* dy, int lddy, const void* x, in
   FX_CHECK_ARG(dy && x && gamma && dx && rows > 0);
   if (cols != 256) return FX_ERR_UNSUPPORTED;
   FX_CHECK_ARG(lddy >= cols && ldx >= cols && lddx >= cols && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0);
-  int grid = (rows + 3) / 4;
+  // every workgroup ends with 512 fp32 atomics onto the same dgamma / dbeta addresses: ~64 rows per workgroup keep that tail short
+  // (one workgroup per 4 rows made the 4800-row decoder LayerNorms 36 us each - 1024-deep contention per address)
+  int grid = (rows + 63) / 64;
+  if (grid < 64) grid = (rows + 3) / 4 < 64 ? (rows + 3) / 4 : 64;
   if (grid > 1024) grid = 1024;
   hipLaunchKernelGGL(layernorm256_bwd_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)dy, lddy,
                      (const bf16_t*)x, ldx, gamma, (bf16_t*)dx, lddx, dgamma, dbeta, rows);
