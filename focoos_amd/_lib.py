@@ -155,6 +155,7 @@ SIGNATURES = {
     "fx_rowdot_nhwc_bf16": [_vp, _i, _vp, _i, C.c_float, _vp, _i, _i, _i, _i, _i, _vp],
     "fx_bcast_vec_nhwc_bf16": [_vp, _i, C.c_float, _vp, _i, _i, _i, _i, _vp],
     "fx_scatter_rows_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
+    "fx_pack_entry_blocks": [_i, _i, _i, _i],
     "fx_pack_weights_many_f32": [_vp, _i, _i, _vp],
     "fx_pack_frag_bf16": [_vp, _vp, _i, _i, _vp],
     "fx_pack_linear_weights_f32": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

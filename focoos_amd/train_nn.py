@@ -162,12 +162,16 @@ class WeightPacker:
             entries = [t for _, (_, fs) in pend for t in (fs if isinstance(fs[0], tuple) else (fs,))]
             arr = (FxPackEntry * len(entries))()
             blocks = 0
+            lib = _lib.load()
             for e, t in zip(arr, entries):
                 w, scale, bias, w_fwd, w_dgrad, f_fwd, f_dgrad, bias_out, N, Cc, KH, KW, ld_fwd, ld_dgrad = t[:14]
                 e.w, e.scale, e.bias, e.w_fwd, e.w_dgrad, e.w_fwd_frag, e.w_dgrad_frag, e.bias_out = w, scale, bias, w_fwd, w_dgrad, f_fwd, f_dgrad, bias_out
                 e.N, e.C, e.KH, e.KW, e.ld_fwd, e.ld_dgrad, e.first_block = N, Cc, KH, KW, ld_fwd, ld_dgrad, blocks
                 e.n_offset, e.n_total = (t[14], t[15]) if len(t) > 14 else (0, N)
-                blocks += (N * Cc * KH * KW + 2047) // 2048
+                nb = int(lib.fx_pack_entry_blocks(N, Cc, KH, KW))
+                if nb <= 0:
+                    raise _lib.FocoosAmdError(f"fx_pack_entry_blocks({N}, {Cc}, {KH}, {KW}) = {nb}")
+                blocks += nb
             host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
             self.table = (key, host.to(dev), len(entries), blocks)
         _, table, n, blocks = self.table

@@ -455,7 +455,8 @@ int fx_pack_linear_weights_f32(const float* w, const float* bias, void* w_fwd, v
  * array; entry e converts master w [N][C][KH][KW] (a Linear: KH = KW = 1, C = K) times scale[n] (NULL: 1) into w_fwd (row n at
  * (n_offset + n) * ld_fwd, column (kh*KW + kw)*C + c), w_dgrad (row c at c * ld_dgrad, column ((KH-1-kh)*KW + (KW-1-kw))*n_total + n_offset + n), their
  * fragment-order copies (NULL: none; rows % 32 == 0, columns % 16 == 0) and copies bias [N] to bias_out (NULL: none).  Workgroups
- * first_block .. first_block + ceil(N*C*KH*KW / 2048) - 1 belong to entry e (ascending, gap-free); total_blocks = their sum. */
+ * first_block .. first_block + fx_pack_entry_blocks(N, C, KH, KW) - 1 belong to entry e (ascending, gap-free); total_blocks = their sum.
+ * The image base pointers, ld_fwd and ld_dgrad must be 16-byte / 8-element aligned for the vector stores to be taken (else element stores). */
 typedef struct {
   const float* w;
   const float* scale;
@@ -472,6 +473,7 @@ typedef struct {
                                 (several masters sharing one image, e.g. the six value projections of the decoder); plain layer: 0, N */
   int32_t reserved;
 } fx_pack_entry;
+int fx_pack_entry_blocks(int N, int C, int KH, int KW);   /* workgroups of one entry (tiles of 8 output channels x <= 2304 (channel, tap) elements); -1: unsupported filter size */
 int fx_pack_weights_many_f32(const fx_pack_entry* entries_dev, int n_entries, int total_blocks, fx_stream_t stream);
 
 /* dw_master[n][c][kh][kw] (+)= scale[n] * dw_eff[n][kh][kw][c]; dw_eff rows have C_eff >= C channels (stem: 3 of 8). */

@@ -688,12 +688,22 @@ def test_pack_all_matches_the_per_layer_packing():
         l(x[l.weight.shape[1]])
     convs = [m for m in mods.modules() if isinstance(m, train_nn.ConvNormLayer)]
     packs = [l._pack for l in lins]
+    # three equally shaped Linears sharing one image (the decoder's value projections): a group object on one of the modules
+    glins = [Linear(lib, 256, 256).to(DEV) for _ in range(3)]
+    with torch.no_grad():
+        for l in glins:
+            l.weight.copy_(torch.randn(256, 256, generator=g).to(DEV) * 0.1)
+            l.bias.copy_(torch.randn(256, generator=g).to(DEV) * 0.1)
+    mods.extend(glins)
+    group = train_nn._PackedLinearGroup()
+    glins[0]._group = group
+    train_nn._LinearGroupFn.apply(x[256], group, lib, *[l.weight for l in glins], *[l.bias for l in glins])
 
     def images():
         out = []
         for c in convs:
             out += [c.w_fwd, c.w_dgrad, c.w_fwd_frag, c.w_dgrad_frag, c.shift]
-        for pk in packs:
+        for pk in packs + [group]:
             out += [pk.w_fwd, pk.w_t, pk.w_fwd_frag, pk.w_t_frag, pk.bias]
         return [None if t is None else t.clone() for t in out]
 
@@ -702,9 +712,9 @@ def test_pack_all_matches_the_per_layer_packing():
             p.mul_(1.25).add_(0.01)                 # new weights (in place: versions move)
     packer = train_nn.WeightPacker(mods)
     n = packer.pack(DEV)
-    assert n == len(convs) + len(packs), (n, len(convs), len(packs))
+    assert n == len(convs) + len(packs) + 3, (n, len(convs), len(packs))   # the group contributes one table entry per master
     multi = images()
-    assert all(c.pack_fields(torch.device(DEV)) is None for c in convs) and all(pk.pack_fields(torch.device(DEV)) is None for pk in packs)
+    assert all(c.pack_fields(torch.device(DEV)) is None for c in convs) and all(pk.pack_fields(torch.device(DEV)) is None for pk in packs + [group])
     assert packer.pack(DEV) == 0                   # nothing stale
     for c in convs:
         c._packed_version = None
@@ -712,6 +722,8 @@ def test_pack_all_matches_the_per_layer_packing():
     for l, pk in zip(lins, packs):
         pk.ver = None
         pk.sync(lib, l.weight, l.bias, 0, l.weight.shape[0])
+    group.ver = None
+    group.sync(lib, [l.weight for l in glins], [l.bias for l in glins])
     torch.cuda.synchronize()
     lazy = images()
     assert sum(t is not None for t in multi) >= 40
