@@ -138,7 +138,7 @@ SIGNATURES = {
     "fx_bn_finalize_f32": [_vp, C.c_float, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp],
     "fx_bn_apply_bf16": [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, C.c_int64, _i, _vp],
     "fx_bn_bwd_stats_bf16": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, C.c_int64, _i, _vp],
-    "fx_bn_bwd_apply_bf16": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, C.c_float, _vp, _i, _vp, _i, C.c_int64, _i, _vp],
+    "fx_bn_bwd_apply_bf16": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, C.c_float, _vp, _i, _vp, _i, C.c_int64, _i, _vp, _vp, _vp],
     "fx_act_fwd_bf16": [_vp, _i, _vp, _i, C.c_int64, _i, _i, _vp],
     "fx_act_bwd_bf16": [_vp, _i, _vp, _i, _vp, _i, C.c_int64, _i, _i, _vp],
     "fx_colsum_bf16": [_vp, _i, _vp, C.c_int64, _i, _vp],

@@ -699,7 +699,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ res, int ldr, const float* __restrict__ scale, const float* __restrict__ shift,
                                                            const float* __restrict__ mean, const float* __restrict__ rstd, int act,
                                                            const float* __restrict__ sums, float inv_n, bf16_t* __restrict__ da_out, int ldda,
-                                                           bf16_t* __restrict__ dz, int lddz, int64_t rows, int C) {
+                                                           bf16_t* __restrict__ dz, int lddz, int64_t rows, int C, float* __restrict__ dgamma_acc,
+                                                           float* __restrict__ dbeta_acc) {
+  // the affine gradients ARE the reduction results (dbeta = sums[c], dgamma = sums[C + c]): one workgroup adds them to the parameter
+  // gradients here instead of two tiny tensor-add launches per BatchNorm layer
+  if (blockIdx.x == 0 && dgamma_acc)
+    for (int c = threadIdx.x; c < C; c += 256) {
+      dgamma_acc[c] += sums[C + c];
+      dbeta_acc[c] += sums[c];
+    }
   const int C8 = C / 8;
   const int64_t total = rows * C8;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -726,8 +734,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const bf16_t* __restr
 
 extern "C" int fx_bn_bwd_apply_bf16(const void* dy, int lddy, const void* z, int ldz, int z_f32, const void* residual, int ldr, const float* scale,
                                     const float* shift, const float* mean, const float* rstd, int act, const float* sums, float inv_n,
-                                    void* da_out, int ldda, void* dz, int lddz, int64_t rows, int C, fx_stream_t stream_) {
+                                    void* da_out, int ldda, void* dz, int lddz, int64_t rows, int C, float* dgamma_acc, float* dbeta_acc,
+                                    fx_stream_t stream_) {
   FX_CHECK_ARG(!residual || (ldr >= C && ldr % 8 == 0));
+  FX_CHECK_ARG(!dgamma_acc == !dbeta_acc);
   FX_CHECK_ARG(dy && z && scale && shift && mean && rstd && sums && dz && rows > 0 && C > 0 && C % 8 == 0);
   FX_CHECK_ARG(ldz >= C && lddy >= C && lddz >= C && ldz % 8 == 0 && lddy % 8 == 0 && lddz % 8 == 0 && (!da_out || (ldda >= C && ldda % 8 == 0)));
   int64_t total = rows * (C / 8);
@@ -736,10 +746,12 @@ extern "C" int fx_bn_bwd_apply_bf16(const void* dy, int lddy, const void* z, int
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   if (z_f32)
     hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3((int)grid), dim3(256), 0, stream, (const bf16_t*)dy, lddy, (const float*)z, ldz,
-                       (const bf16_t*)residual, ldr, scale, shift, mean, rstd, act, sums, inv_n, (bf16_t*)da_out, ldda, (bf16_t*)dz, lddz, rows, C);
+                       (const bf16_t*)residual, ldr, scale, shift, mean, rstd, act, sums, inv_n, (bf16_t*)da_out, ldda, (bf16_t*)dz, lddz, rows, C,
+                       dgamma_acc, dbeta_acc);
   else
     hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3((int)grid), dim3(256), 0, stream, (const bf16_t*)dy, lddy, (const bf16_t*)z, ldz,
-                       (const bf16_t*)residual, ldr, scale, shift, mean, rstd, act, sums, inv_n, (bf16_t*)da_out, ldda, (bf16_t*)dz, lddz, rows, C);
+                       (const bf16_t*)residual, ldr, scale, shift, mean, rstd, act, sums, inv_n, (bf16_t*)da_out, ldda, (bf16_t*)dz, lddz, rows, C,
+                       dgamma_acc, dbeta_acc);
   return fx_launch_status();
 }
 

@@ -325,13 +325,16 @@ def _bn_backward(layer, dy: torch.Tensor, z: torch.Tensor, residual: Optional[to
         dist.all_reduce(sums)
     dz = torch.empty(z.shape, dtype=torch.bfloat16, device=dev)
     da = torch.empty(z.shape, dtype=torch.bfloat16, device=dev) if residual is not None else None
+    norm = layer._norm_h
+    direct = want_affine and DIRECT_GRAD[0] and norm.weight.grad is not None and norm.bias.grad is not None
+    fused = direct and local is sums    # the kernel adds the (local) sums to the parameter gradients itself
     check(lib.fx_bn_bwd_apply_bf16(dy.data_ptr(), N, z.data_ptr(), N, zf, rp, N, stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(),
                                    stats[1].data_ptr(), FX_ACT[layer.act], sums.data_ptr(), 1.0 / n, da.data_ptr() if da is not None else None, N,
-                                   dz.data_ptr(), N, rows, N, st), "fx_bn_bwd_apply_bf16")
+                                   dz.data_ptr(), N, rows, N, norm.weight.grad.data_ptr() if fused else None,
+                                   norm.bias.grad.data_ptr() if fused else None, st), "fx_bn_bwd_apply_bf16")
     dgamma = dbeta = None
-    if want_affine:
-        norm = layer._norm_h
-        if DIRECT_GRAD[0] and norm.weight.grad is not None and norm.bias.grad is not None:
+    if want_affine and not fused:
+        if direct:    # SyncBN: `sums` was all-reduced, the parameter gradients take this rank's share
             norm.weight.grad.add_(local[1])
             norm.bias.grad.add_(local[0])
         else:

@@ -521,7 +521,9 @@ int fx_stem_conv3x3s2_linear(const void* x, int in_f32, const float* w, const fl
  *   backward: da = dy * act'(z * scale + shift [+ residual]);  fx_bn_bwd_stats_bf16 ACCUMULATES sums[c] += sum da (= dbeta),
  *             sums[C + c] += sum da * xhat (= dgamma), xhat = (z - mean) * rstd; (all-reduce for SyncBN);
  *             fx_bn_bwd_apply_bf16: dz = scale * (da - sums[c] * inv_n - xhat * sums[C + c] * inv_n); da_out (optional) = da,
- *             the gradient of the residual branch.
+ *             the gradient of the residual branch; dgamma_acc / dbeta_acc (both or neither): dgamma_acc[c] += sums[C + c],
+ *             dbeta_acc[c] += sums[c] - the affine gradients accumulated into the parameter gradients by the same launch (pass the
+ *             LOCAL sums' buffers only when sums has not been all-reduced).
  * z_f32 != 0: z is fp32 [rows][ldz] (the conv kernel's out_f32 epilogue) instead of bf16 - y depends on z - mean, and a bf16 z keeps
  * 8 bits of z, not of z - mean; the trainable graphs keep the pre-normalisation tensor in fp32. */
 int fx_bn_stats_bf16(const void* z, int ldz, int z_f32, float* sums, int64_t rows, int C, fx_stream_t stream);
@@ -535,7 +537,7 @@ int fx_bn_bwd_stats_bf16(const void* dy, int lddy, const void* z, int ldz, int z
                          fx_stream_t stream);
 int fx_bn_bwd_apply_bf16(const void* dy, int lddy, const void* z, int ldz, int z_f32, const void* residual, int ldr, const float* scale,
                          const float* shift, const float* mean, const float* rstd, int act, const float* sums, float inv_n, void* da_out,
-                         int ldda, void* dz, int lddz, int64_t rows, int C, fx_stream_t stream);
+                         int ldda, void* dz, int lddz, int64_t rows, int C, float* dgamma_acc, float* dbeta_acc, fx_stream_t stream);
 
 /* ---- training path, token-space layers (A17): correctness-first fp32-math kernels ----------------------------------
  * Activation on a saved pre-activation z (FX_ACT_RELU/SILU/GELU): y = act(z); dz = dy * act'(z). */

@@ -390,9 +390,10 @@ def test_batchnorm_train_kernels(lib, act, with_res, C, rows_shape, z_f32):
                                    stats[1].data_ptr(), FX_ACT[act], bs.data_ptr(), rows, C, st))
     dz = torch.empty_like(dyd)
     da = torch.empty_like(dyd) if with_res else None
+    gacc, bacc = torch.full((C,), 0.5, device=DEV), torch.full((C,), -0.25, device=DEV)   # accumulated INTO: dgamma / dbeta land on top
     check(lib.fx_bn_bwd_apply_bf16(dyd.data_ptr(), C, zd.data_ptr(), C, z_f32, rp, C, stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(),
                                    stats[1].data_ptr(), FX_ACT[act], bs.data_ptr(), 1.0 / rows, da.data_ptr() if with_res else None, C, dz.data_ptr(), C,
-                                   rows, C, st))
+                                   rows, C, gacc.data_ptr(), bacc.data_ptr(), st))
     torch.cuda.synchronize()
     assert int(nbt) == 1
     np.testing.assert_allclose(rmd.cpu().numpy(), rm_ref.numpy(), rtol=1e-4, atol=1e-5)
@@ -401,6 +402,7 @@ def test_batchnorm_train_kernels(lib, act, with_res, C, rows_shape, z_f32):
     assert (y.float().cpu() - nhwc(yt)).abs().max() <= 2e-2 * nhwc(yt).abs().max()      # one bf16 rounding of the output
     np.testing.assert_allclose(bs[0].cpu().numpy(), bt.grad.numpy(), rtol=2e-3, atol=2e-3)
     np.testing.assert_allclose(bs[1].cpu().numpy(), gt.grad.numpy(), rtol=2e-3, atol=2e-3 * float(gt.grad.abs().max()))
+    assert torch.equal(gacc, bs[1] + 0.5) and torch.equal(bacc, bs[0] - 0.25)          # the launch's own accumulation into the parameter gradients
     assert (dz.float().cpu() - nhwc(zt.grad)).abs().max() <= 1e-2 * nhwc(zt.grad).abs().max() + 1e-6
     if with_res:
         assert (da.float().cpu() - nhwc(rt.grad)).abs().max() <= 1e-2 * nhwc(rt.grad).abs().max()
