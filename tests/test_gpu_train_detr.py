@@ -179,7 +179,7 @@ def test_weight_gradient_side_stream_matches_single_stream(monkeypatch, norm="Fr
 
     cfg = ModelRegistry.get_model_info("fai-detr-l-coco")["config"]
     sd = synth_state_dict(cfg, 6)
-    B, S = 8, 384
+    B, S = 16, 640      # the benchmark's batch: the overlap pattern of the measured step
     runs = {}
     for side in ("1", "0"):
         monkeypatch.setenv("FX_WGRAD_STREAM", side)
@@ -188,7 +188,7 @@ def test_weight_gradient_side_stream_matches_single_stream(monkeypatch, norm="Fr
         ts = TrainStep(model, lr=0.0, weight_decay=0.0)           # lr = 0: every step starts from the same weights
         assert (ts.wgrad_stream is not None) == (side == "1")
         out = []
-        for it in range(4):
+        for it in range(6):
             imgs = torch.from_numpy(np.stack([synth_image_structured(200 + it * B + i, S, S) for i in range(B)])).to(DEV)
             labels, boxes = T.synth_targets(40 + it, B, 80, counts=tuple(1 + (3 * i + it) % 9 for i in range(B)))
             targets = [DETRTargets(labels=l.to(DEV), boxes=b.to(DEV)) for l, b in zip(labels, boxes)]
