@@ -282,3 +282,19 @@ def test_conv_routing_labels(lib_path, monkeypatch):
     assert label(16, 40, 40, 250, 256, 3) == -1                                # C % 32 != 0: FX_ERR_INVALID_ARG, as the launch would return
     monkeypatch.setenv("FX_CONV3_MIN_M", "0")
     assert label(2, 16, 16, 64, 64, 3) == "conv3x3_flat<64>"                   # the kernel tests' lowered threshold
+
+
+def test_pack_entry_blocks(lib_path):
+    """fx_pack_entry_blocks = workgroups of one fx_pack_weights_many_f32 table entry: tiles of 8 output channels x at most 2304
+    (input channel, tap) elements, the channel chunk a multiple of 8 (host logic; the Python packer sums these into first_block)."""
+    from focoos_amd import _lib
+
+    lib = _lib.load()
+    assert lib.fx_pack_entry_blocks(256, 256, 3, 3) == 32 * 1          # 256 x 9 = 2304: one chunk
+    assert lib.fx_pack_entry_blocks(512, 512, 3, 3) == 64 * 2          # two chunks of 256 channels
+    assert lib.fx_pack_entry_blocks(2048, 512, 1, 1) == 256 * 1        # pointwise: up to 2304 channels per tile
+    assert lib.fx_pack_entry_blocks(365, 256, 1, 1) == 46              # ragged last tile of 5 output channels
+    assert lib.fx_pack_entry_blocks(4, 4, 1, 1) == 1
+    assert lib.fx_pack_entry_blocks(64, 3000, 1, 1) == 8 * 2
+    assert lib.fx_pack_entry_blocks(64, 64, 17, 17) == -1              # 289 taps: more than a tile holds 8 channels of
+    assert lib.fx_pack_entry_blocks(0, 64, 1, 1) == -1
