@@ -225,7 +225,7 @@ def per_op_timing(eng, pl, args):
 ALG_GFLOP_PER_IMAGE_BF_1024 = 83.5   # bisenetformer-l-ade forward @1024^2 (FlopCounterMode on the reference)
 
 
-def _wgrad_roofline(nn_, stepper, imgs, targets):
+def _wgrad_roofline(nn_, stepper, imgs, targets, family="fai_detr"):
     """`roofline` of the training step's dominant kernel family (the weight-gradient kernel): one extra step outside the timed region with
     every fx_conv2d_wgrad_partial launch bracketed by events on the stream it runs on; achieved = algorithmic FLOPs (2 M N K per
     launch) / summed durations, and the algorithmic bytes (x + dz read once, the fp32 partial slabs written once) against HBM."""
@@ -257,8 +257,21 @@ def _wgrad_roofline(nn_, stepper, imgs, targets):
     fl, by = sum(r[2] for r in rec), sum(r[3] for r in rec)
     tf, gbs = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
     ai = fl / by
+    # HBM bytes per launch of the weight-gradient kernel from the committed PMC passes of the RT-DETR training step (same recipe and
+    # calibration as the inference line; None for the other families / when the file is absent)
+    traffic, traffic_src = None, None
+    try:
+        if family == "fai_detr":
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_train_hbm_latest.json")))
+            hit = next(v for k, v in pmc.items() if k.startswith("conv_wgrad_kernel"))
+            traffic = round(hit["fetch_bytes_per_launch"] + hit["write_bytes_per_launch"])
+            traffic_src = ("profiles/pmc_train_hbm_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --train`, calibrated counter "
+                           "units; average over ALL conv_wgrad_kernel launches of a step - the 96 conv layers the event bracket covers plus the ~100 smaller Linear layers - partial-slab stores included)")
+    except Exception:
+        pass
     return {"bound": "mfma" if ai >= PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm", "kernel": "conv_wgrad_kernel (+ slab sum / unpack)",
-            "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": None,
+            "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+            "traffic_source": traffic_src, "alg_bytes_per_launch": round(by / max(len(rec), 1)),
             "launches_per_step": len(rec), "ms_per_step": round(ms, 3), "arithmetic_intensity_flop_per_byte": round(ai, 1),
             "hbm": {"achieved_gbs_algorithmic": round(gbs, 1), "peak_gbs": PEAK_HBM_GBS, "frac": round(gbs / PEAK_HBM_GBS, 4)},
             "note": "events bracket the wgrad launch + its slab-sum/unpack pass of every conv layer in one extra step run with the weight gradients on the main stream (in the timed steps they run on a side stream, concurrently with the input-gradient chain)"}
@@ -331,7 +344,7 @@ def train_measure(args, world, rank, local, with_roofline=True):
     fwd = (ALG_GFLOP_PER_IMAGE_BF_1024 * (S / 1024.0) ** 2 if bf else
            (ALG_GFLOP_PER_IMAGE_MF_800 * (S / 800.0) ** 2 if args.family == "fai_mf" else ALG_GFLOP_PER_IMAGE * (S / 640.0) ** 2))
     alg = 3 * fwd  # training ~ 3 x forward (fwd + dgrad + wgrad)
-    roof = _wgrad_roofline(train_nn, stepper, imgs, all_targets[0]) if (rank == 0 and with_roofline) else None
+    roof = _wgrad_roofline(train_nn, stepper, imgs, all_targets[0], args.family) if (rank == 0 and with_roofline) else None
     barrier(world, False)
     out = None
     if rank == 0:

@@ -23,10 +23,12 @@ timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $ou
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o w -- python $ROOT/bench.py --no-cpu-baseline --no-other-configs --steps 3 --warmup 2 > $out/pmc_write.log 2>&1
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/cal_fetch -o f -- python $ROOT/scripts/pmc_calibrate.py > $out/cal_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/cal_write -o w -- python $ROOT/scripts/pmc_calibrate.py > $out/cal_write.log 2>&1
+for c in FETCH_SIZE WRITE_SIZE; do timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_train_$c -o t -- python $ROOT/bench.py --train --no-cpu-baseline --steps 2 --warmup 1 > $out/pmc_train_$c.log 2>&1; done
 cd $ROOT
 F=$(find $out/pmc_fetch -name '*counter_collection.csv' | head -1); W=$(find $out/pmc_write -name '*counter_collection.csv' | head -1)
 CF=$(find $out/cal_fetch -name '*counter_collection.csv' | head -1); CW=$(find $out/cal_write -name '*counter_collection.csv' | head -1)
 python scripts/pmc_summary.py $F $W $out/${TAG}_pmc_hbm.md $out/${TAG}_pmc_hbm.json $CF $CW | head -12
+python scripts/pmc_summary.py $out/pmc_train_FETCH_SIZE/t_counter_collection.csv $out/pmc_train_WRITE_SIZE/t_counter_collection.csv $out/${TAG}_train_pmc_hbm.md $out/${TAG}_train_pmc_hbm.json $CF $CW | head -8   # -> profiles/pmc_train_hbm_latest.json (run the training bench line after copying it)
 for d in prof prof_serial prof_train prof_bf_train; do find $out/$d -name '*kernel_stats.csv' | head -1 | xargs -I{} cp {} $out/${TAG}_${d}_kernel_stats.csv; done
 find $out -name '*kernel_trace.csv' -delete; find $out -name '*counter_collection.csv' -size +20M -delete
 head -c 300 $out/${TAG}_bench.json; echo; tail -2 $out/${TAG}_bench.err | cut -c1-300
