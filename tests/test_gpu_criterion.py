@@ -230,6 +230,13 @@ def test_box_loss_with_gradient_vs_torch_autograd(counts):
         gref = bt.grad
     else:
         ref, gref = torch.zeros(2), torch.zeros(B, Q, 4)
+    if n:   # the same through the oracle's SetCriterion restatement (pinned to the reference's golden losses): full [n, n] IoU matrices, diagonal taken
+        bo = boxes.clone().requires_grad_(True)
+        indices = [(torch.as_tensor(a, dtype=torch.int64), torch.as_tensor(b_, dtype=torch.int64)) for a, b_ in zip(pi_l, ti_l)]
+        lo = CO.set_criterion_losses(torch.zeros(B, Q, K), bo, labels, tboxes, indices, float(n))
+        (1.3 * lo["loss_bbox"] + 0.7 * lo["loss_giou"]).backward()
+        assert abs(float(lo["loss_bbox"]) - float(ref[0])) <= 1e-5 * max(float(ref[0]), 1.0) and abs(float(lo["loss_giou"]) - float(ref[1])) <= 1e-5 * max(float(ref[1]), 1.0)
+        assert (bo.grad - gref).abs().max() <= 1e-5 * max(float(gref.abs().max()), 1e-3)
     assert torch.equal(cls.cpu(), cls_ref)
     assert (score.cpu() - score_ref).abs().max() <= 1e-6
     assert (loss2.cpu() - ref).abs().max() <= 1e-5 * max(float(ref.abs().max()), 1.0)
