@@ -24,7 +24,9 @@ timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $ou
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/cal_fetch -o f -- python $ROOT/scripts/pmc_calibrate.py > $out/cal_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/cal_write -o w -- python $ROOT/scripts/pmc_calibrate.py > $out/cal_write.log 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do timeout 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc_train_$c -o t -- python $ROOT/bench.py --train --no-cpu-baseline --steps 2 --warmup 1 > $out/pmc_train_$c.log 2>&1; done
+FX_PARTS_SERIAL=1 timeout 200 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY --kernel-trace --output-format csv -d $out/pmc_sq -o s -- python $ROOT/bench.py --no-cpu-baseline --no-other-configs --steps 2 --warmup 1 > $out/pmc_sq.log 2>&1
 cd $ROOT
+python scripts/pmc_sq_summary.py $out/${TAG}_sq_counters.md $(find $out/pmc_sq -name '*counter_collection.csv' | head -1) | head -5
 F=$(find $out/pmc_fetch -name '*counter_collection.csv' | head -1); W=$(find $out/pmc_write -name '*counter_collection.csv' | head -1)
 CF=$(find $out/cal_fetch -name '*counter_collection.csv' | head -1); CW=$(find $out/cal_write -name '*counter_collection.csv' | head -1)
 python scripts/pmc_summary.py $F $W $out/${TAG}_pmc_hbm.md $out/${TAG}_pmc_hbm.json $CF $CW | head -12
