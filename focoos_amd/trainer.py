@@ -12,6 +12,8 @@ from __future__ import annotations
 import json
 import os
 import time
+import warnings
+from collections import OrderedDict
 from dataclasses import asdict
 from typing import Dict, List, Optional
 
@@ -31,9 +33,52 @@ def _dist():
     return 0, 1
 
 
+class ModelSnapshot:
+    """What ``run_train`` reads from the engine-backed model, in picklable form.  ``launch`` starts its ranks with ``spawn``, which
+    pickles the arguments: the engine (ctypes library handle, HIP streams, captured graphs, device tensors) cannot travel, so the
+    ranks receive the family, the config and the fp32 state dict on the CPU and build their own training graph from them."""
+
+    def __init__(self, model):
+        self.family = getattr(model, "family", "fai_detr")
+        self.config = dict(model.config)
+        self._state = OrderedDict((k, v.detach().cpu()) for k, v in model.state_dict().items())
+        self.device = torch.device("cuda", 0)
+
+    def state_dict(self):
+        return OrderedDict(self._state)
+
+
+def check_supported(args: TrainerArgs) -> None:
+    """TrainerArgs fields that change the training arithmetic of the reference and that this trainer does not implement are refused,
+    never ignored (fields that only steer hub syncing / visualisation / periodic evaluation / early stopping are accepted: see the
+    module docstring).  Reference: ``build_optimizer`` solver/build.py:39-138, ``TrainerLoop`` trainer/trainer.py:600-773."""
+    if str(args.optimizer).upper() != "ADAMW":
+        raise NotImplementedError(f"TrainerArgs.optimizer={args.optimizer!r}: the engine's optimizer is the fused AdamW (fx_adamw_step_f32)")
+    if args.optimizer_extra:
+        raise NotImplementedError("TrainerArgs.optimizer_extra is not supported by the fused AdamW step")
+    if args.resume:
+        raise NotImplementedError("TrainerArgs.resume: periodic checkpoints are not written, so there is nothing to resume from "
+                                  "(use init_checkpoint with a model_final.pth)")
+    if float(args.decoder_multiplier) != 1.0 or float(args.head_multiplier) != 1.0:
+        raise NotImplementedError("TrainerArgs.decoder_multiplier / head_multiplier != 1.0 are not supported (only backbone_multiplier)")
+    if not args.amp_enabled:
+        warnings.warn("TrainerArgs.amp_enabled=False: the engine always computes in bf16 with fp32 master weights")
+
+
+def _spawned_rank(args, data_train, data_val, snapshot, family, config, im_size, model_info, hub):
+    """Body of one ``launch`` worker: the processor is rebuilt from its configuration (it may hold device buffers)."""
+    from .model import ProcessorManager
+
+    processor = ProcessorManager.get_processor(family, config, image_size=im_size)
+    return run_train(args, data_train, data_val, snapshot, processor, model_info, hub)
+
+
 def run_train(args: TrainerArgs, data_train, data_val, model, processor, model_info, hub=None) -> Dict[str, float]:
-    """Per-rank training body.  ``model`` is the engine-backed FAIDetr / BisenetFormer mirror (its state_dict seeds the trainable graph and
-    receives the result); ``data_train[i]`` is a DatasetEntry.  Returns the last step's losses (floats) on every rank."""
+    """Per-rank training body.  ``model`` is the engine-backed FAIDetr / BisenetFormer mirror or its ``ModelSnapshot`` (its state_dict
+    seeds the trainable graph); ``data_train[i]`` is a DatasetEntry.  Returns the last step's losses (floats) on every rank.
+    Ignored TrainerArgs fields (trainer-side features outside SURVEY §8): ckpt_dir, checkpointer_period / _max_to_keep, eval_period,
+    samples, early_stop, patience, workers, ddp_*, gather_metric_period, zero_grad_before_forward, sync_to_hub, size_divisibility."""
+    check_supported(args)
     from .train_data import TrainingSampler, per_rank_batch_size, rank_seed
     from .train_detr import FAIDetrTrainable, TrainStep
 
@@ -106,8 +151,11 @@ def train(focoos_model, args: TrainerArgs, data_train, data_val=None, hub=None):
 
     assert len(data_train) > 0, "empty training set"
     assert args.num_gpus, "Training without GPUs is not supported. num_gpus must be greater than 0"
+    check_supported(args)
     if args.num_gpus > 1:
-        launch(run_train, args.num_gpus, dist_url="auto", args=(args, data_train, data_val, focoos_model.model, focoos_model.processor, focoos_model.model_info, hub))
+        launch(_spawned_rank, args.num_gpus, dist_url="auto",
+               args=(args, data_train, data_val, ModelSnapshot(focoos_model.model), focoos_model.model.family, dict(focoos_model.model_info.config),
+                     focoos_model.model_info.im_size, focoos_model.model_info, hub))
     else:
         run_train(args, data_train, data_val, focoos_model.model, focoos_model.processor, focoos_model.model_info, hub)
     folder = os.path.join(args.output_dir, args.run_name.strip())
