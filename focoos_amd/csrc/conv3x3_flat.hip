@@ -30,17 +30,7 @@ struct C3Args {
   int HW;            // pixels per image
   int64_t y_bstride;  // elements between images of y (0: contiguous)
   unsigned x_bytes, r_bytes;
-  unsigned long long* dbg;   // probe builds only (ABL & 16): per-wave phase time stamps of workgroup 0
 };
-
-// Workgroup barrier WITHOUT the fence of __syncthreads(): hipcc turns that fence into s_waitcnt vmcnt(0) whenever an LDS-DMA it
-// knows of may be in flight, which would also drain the (asm-issued, invisible) weight ring.  The waits that matter are written
-// by hand next to each use of this barrier.
-__device__ __forceinline__ void c3_barrier() {
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-}
 
 // KT = 9: 3x3 / stride 1 / pad 1, LDS rows of CC = 64 channels, nine taps = nine flat row offsets.
 // KT = 1: pointwise (1x1) layer on the same machinery: LDS rows of CC = 256 channels, the "taps" are the CC/64 channel
@@ -48,27 +38,15 @@ __device__ __forceinline__ void c3_barrier() {
 // LOADER = 0: no loader wave (layers whose whole K is ONE chunk, e.g. 256-channel pointwise layers: nothing to stream behind the
 //         MFMAs) - a 4-wave workgroup at <= 256 VGPRs fits twice on a CU (two waves per SIMD: one workgroup's epilogue and
 //         prologue overlap the other's MFMAs), which the 5-wave form cannot.
-//         With several chunks the consumers stream the next chunk themselves: DPT LDS-DMA instructions per wave and tap, issued
-//         behind the first MFMAs of the tap's second k-step (always DPT of them - surplus ones zero-fill a scratch KiB - so that
-//         the counted vmcnt waits of the weight ring stay exact).  This is the form for tiles whose accumulators need more than
-//         256 registers per lane (4 waves, one per SIMD, nothing left for a fifth wave) and for 8-wave tiles (two per SIMD).
-// OCC:    minimum waves per SIMD (launch bound): 2 caps the kernel at 256 registers.
-// ABL:    ablation switches of scripts/probes/c3_probe.hip (1: weight ring never refilled, 2: pixel fragments read once,
-//         4: no DMA after the first chunk, 8: no output stores, 16: s_memtime stamps of workgroup 0 in p.dbg, 32: chunk-end wait
-//         vmcnt(0) instead of the counted one); 0 in the product.
-template <int KT, int CC, int TN, int TM, int WN, int WM, int ACT, int RESMODE, int LOADER = 1, int OCC = 1, int ABL = 0>
-__global__ __launch_bounds__((WN* WM + LOADER) * 64, OCC) void conv3x3_flat_kernel(const C3Args p) {
+template <int KT, int CC, int TN, int TM, int WN, int WM, int ACT, int RESMODE, int LOADER = 1>
+__global__ __launch_bounds__((WN* WM + LOADER) * 64, 1) void conv3x3_flat_kernel(const C3Args p) {
   constexpr int NW = WN * WM, NT = (NW + LOADER) * 64, NDW = NW + LOADER;   // NDW: waves sharing the first-chunk / residual DMA
-  constexpr int DPT = NW >= 8 ? 1 : 2;               // in-loop DMA instructions per wave and tap (LOADER == 0, several chunks)
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int RL = CC / 8, ROWB = CC * 2;
   constexpr int KJ = 4;                              // k16 steps per tap (64 channels)
   constexpr int NTAP = KT == 9 ? 9 : CC / 64;        // ring cycles per chunk
   constexpr int PF = KJ;  // weight-fragment ring: one slot per k-step of a tap, refilled for the next tap
   constexpr int RLT = BN / 8;
-  constexpr bool INLOOP = LOADER == 0 && KT == 9;                 // consumers stream chunk cc+1 inside the tap loop
-  constexpr int DW = (INLOOP && !(ABL & 4)) ? DPT : 0;           // DMA instructions between a ring slot's refill and its use
-  constexpr int ENDW = (ABL & (1 | 32)) ? 0 : KJ * TN + DW;             // chunk end: everything older than the last tap's requests has landed
   static_assert(TN <= 2 && (KT == 9 ? CC == 64 : CC % 64 == 0), "tap = 64 channels = 4 k-steps");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -114,14 +92,6 @@ __global__ __launch_bounds__((WN* WM + LOADER) * 64, OCC) void conv3x3_flat_kern
     }
   };
 
-  int dbg_slot = 0;
-  auto stamp = [&]() {
-    if constexpr (ABL & 16) {
-      if (blockIdx.x == 0 && lane == 0 && !is_loader) p.dbg[wave * 16 + dbg_slot] = __builtin_amdgcn_s_memtime();
-      ++dbg_slot;
-    }
-  };
-  stamp();
   // ---- consumer state
   f32x16 acc[TN][TM];
   bf16x8 ar[PF][TN];
@@ -143,9 +113,7 @@ __global__ __launch_bounds__((WN* WM + LOADER) * 64, OCC) void conv3x3_flat_kern
     for (int cc = 0; cc < NCH; ++cc) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();  // chunk cc has landed; every consumer is done with chunk cc-1 (the other buffer)
-      if constexpr (!(ABL & 4)) {
-        if (cc + 1 < NCH) dma_chunk(cc + 1, smem + ((cc + 1) & 1) * buf_bytes, 0, 1);
-      }
+      if (cc + 1 < NCH) dma_chunk(cc + 1, smem + ((cc + 1) & 1) * buf_bytes, 0, 1);
     }
     __syncthreads();  // E1: the halo buffers are dead; the output tile T (aliases them) may be written
     if constexpr (RESMODE != 0) {
@@ -155,7 +123,7 @@ __global__ __launch_bounds__((WN* WM + LOADER) * 64, OCC) void conv3x3_flat_kern
     }
     __syncthreads();  // E3: output tile complete
   } else {
-    if (!LOADER && wave == 0 && lane < 8) *reinterpret_cast<uint4*>(smem + (NCH > 1 ? 2 : 1) * buf_bytes + lane * 16) = make_uint4(0, 0, 0, 0);  // zero row
+    if (!LOADER && wave == 0 && lane < 8) *reinterpret_cast<uint4*>(smem + buf_bytes + lane * 16) = make_uint4(0, 0, 0, 0);  // zero row
     dma_chunk(0, smem, wave, NDW);   // this wave's share of the first chunk (hipcc waits for it at the first barrier)
 #pragma unroll
     for (int a = 0; a < TN; ++a)
@@ -193,8 +161,6 @@ __global__ __launch_bounds__((WN* WM + LOADER) * 64, OCC) void conv3x3_flat_kern
         ar[i][a] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         c3_ldg_async(ar[i][a], a_ptr(a, 0, i));
       }
-    const int ninstr_chunk = p.HLp * RL / 64;
-    const int scratch_off = (NCH > 1 ? 2 : 1) * buf_bytes + 128;   // INLOOP: 1 KiB behind the zero row that surplus DMA slots fill
     const int zrow = (NCH > 1 ? 2 : 1) * buf_bytes;  // 128 zero bytes behind the halo buffers: where a masked (pixel, tap) reads its operand from
     // per-lane constants of the k16 steps: byte offset of the lane's 16-byte chunk before the row swizzle
     int hc[KJ];
@@ -217,28 +183,14 @@ __global__ __launch_bounds__((WN* WM + LOADER) * 64, OCC) void conv3x3_flat_kern
     };
     for (int cc = 0; cc < NCH; ++cc) {
       if (cc == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the first chunk
-      if constexpr (INLOOP) {
-        // this wave's share of chunk cc was requested before the last tap of chunk cc-1: it is older than that tap's
-        // KJ * TN ring refills and DW scratch DMAs, the only requests that may still be in flight
-        if (cc > 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(ENDW) : "memory");
-        c3_barrier();
-      } else {
-        __syncthreads();  // chunk cc has landed; every consumer is done with chunk cc-1 (the other buffer)
-      }
-      stamp();
+      __syncthreads();  // chunk cc has landed; every consumer is done with chunk cc-1 (the other buffer)
       const int bufo = (cc & 1) * buf_bytes;
       const int ccn = cc + 1 < NCH ? cc + 1 : cc;
-      unsigned char* nbuf = smem + ((cc + 1) & 1) * buf_bytes;
-      const bool stream_next = cc + 1 < NCH;
       int ra[TM], sw[TM];
       tap_setup(0, KT == 9 ? -p.W - 1 : 0, bufo, ra, sw);
       bf16x8 xb[2][TM];
 #pragma unroll
       for (int b = 0; b < TM; ++b) xb[0][b] = *reinterpret_cast<const bf16x8*>(smem + ((hc[0] ^ sw[b]) + ra[b]));   // tap 0: column offset 0
-      if constexpr (ABL & 2) {
-#pragma unroll
-        for (int b = 0; b < TM; ++b) xb[1][b] = xb[0][b];
-      }
       // The tap loop is a real loop (one ring cycle of KJ k-steps per tap): fully unrolled, hipcc hoists 36 steps' worth of
       // addresses and loads and spills hundreds of registers.
 #pragma unroll 1
@@ -256,9 +208,7 @@ __global__ __launch_bounds__((WN* WM + LOADER) * 64, OCC) void conv3x3_flat_kern
         auto kstep = [&](auto jc) {   // j must be a compile-time constant: it is the immediate offset of the asm weight loads
           constexpr int j = decltype(jc)::value;
           constexpr bool tap_end = j + 1 == KJ;
-          if constexpr (!(ABL & 1)) {
-            if constexpr (TN == 1) c3_wait<(KJ - 1) * TN + DW>(ar[j][0]); else c3_wait<(KJ - 1) * TN + DW>(ar[j][0], ar[j][1]);
-          }
+          if constexpr (TN == 1) c3_wait<(KJ - 1) * TN>(ar[j][0]); else c3_wait<(KJ - 1) * TN>(ar[j][0], ar[j][1]);
           // One wave per SIMD issues in order: an MFMA occupies the matrix pipe for 32 cycles but only 4 issue cycles, so the
           // other work of the step is INTERLEAVED between the MFMAs (pinned with sched_barrier: left alone, hipcc groups the 8
           // MFMAs back to back and the wave's address / LDS / load instructions wait behind them):
@@ -269,32 +219,14 @@ __global__ __launch_bounds__((WN* WM + LOADER) * 64, OCC) void conv3x3_flat_kern
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
               acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j][a], xb[j & 1][b], acc[a][b], 0, 0, 0);
-              if constexpr (!(ABL & 2)) {
-                if (a == 0) {
-                  if constexpr (!tap_end) {
-                    xb[(j + 1) & 1][b] = *reinterpret_cast<const bf16x8*>(smem + (((co + hc[tap_end ? 0 : j + 1]) ^ sw[b]) + ra[b]));
-                  } else {
-                    if (!last_tap) xb[0][b] = *reinterpret_cast<const bf16x8*>(smem + (((con + hc[0]) ^ swn[b]) + ran[b]));
-                  }
+              if (a == 0) {
+                if constexpr (!tap_end) {
+                  xb[(j + 1) & 1][b] = *reinterpret_cast<const bf16x8*>(smem + (((co + hc[tap_end ? 0 : j + 1]) ^ sw[b]) + ra[b]));
+                } else {
+                  if (!last_tap) xb[0][b] = *reinterpret_cast<const bf16x8*>(smem + (((con + hc[0]) ^ swn[b]) + ran[b]));
                 }
               }
-              if constexpr (DW > 0 && j == 1) {
-                // slot t * DPT + b of this wave's share of chunk cc+1; the last tap and the last chunk issue the same
-                // number of instructions into the scratch KiB (zero fill, no memory traffic)
-                if (a == 0 && b < DPT) {
-                  const int i = (t * DPT + b) * NW + wave;
-                  const bool real = stream_next && !last_tap && i < ninstr_chunk;
-                  const int q = i * 64 + lane;
-                  const int r = q / RL, pc = q % RL;
-                  const int f = lo + r;
-                  const bool ok = real && f >= 0 && f < p.M;
-                  pw_dma16(xr, real ? nbuf + i * 1024 : smem + scratch_off,
-                           ok ? (unsigned)(f * p.ldx + (cc + 1) * CC + pw_swz<RL>(r, pc) * 8) * 2u : FX_OOB);
-                }
-              }
-              if constexpr (!(ABL & 1)) {
-                if (b == TM - 1) c3_ldg_async<j * 1024>(ar[j][a], wnext[a]);
-              }
+              if (b == TM - 1) c3_ldg_async<j * 1024>(ar[j][a], wnext[a]);
               __builtin_amdgcn_sched_barrier(0);
             }
           }
@@ -307,7 +239,6 @@ __global__ __launch_bounds__((WN* WM + LOADER) * 64, OCC) void conv3x3_flat_kern
         }
       }
     }
-    stamp();
     // drain the hidden loads before their registers are reused by the epilogue
 #pragma unroll
     for (int i = 0; i < PF; ++i) {
@@ -352,12 +283,11 @@ __global__ __launch_bounds__((WN* WM + LOADER) * 64, OCC) void conv3x3_flat_kern
           }
 
     __syncthreads();  // E3
-    stamp();
   }
   for (int q = tid; q < BM * RLT; q += NT) {
     const int row = q / RLT, lc = q % RLT;
     const int m = m0 + row;
-    if (m < p.M && !((ABL & 8) && p.H > 0)) {
+    if (m < p.M) {
       const uint4 v = *reinterpret_cast<const uint4*>(T + row * (BN * 2) + (pw_swz<RLT>(row, lc) << 4));
       size_t yo = (size_t)m * p.ldy;
       if (p.y_bstride) {
@@ -367,28 +297,19 @@ __global__ __launch_bounds__((WN* WM + LOADER) * 64, OCC) void conv3x3_flat_kern
       *reinterpret_cast<uint4*>(p.y + yo + n0 + lc * 8) = v;
     }
   }
-  if constexpr (ABL & 16) {
-    __syncthreads();
-    stamp();
-  }
 }
 
-template <int KT, int CC, int TN, int TM, int WN, int WM, int ACT, int RESMODE, int LOADER = 1, int OCC = 1, int ABL = 0>
+template <int KT, int CC, int TN, int TM, int WN, int WM, int ACT, int RESMODE, int LOADER = 1>
 static int launch_c3(C3Args& a, hipStream_t stream) {
   constexpr int NW = WN * WM, BM = WM * TM * 32, BN = WN * TN * 32, RL = CC / 8;
   constexpr int RPI = 64 / RL > 0 ? 64 / RL : 1;  // rows per DMA instruction
-  constexpr bool INLOOP = LOADER == 0 && KT == 9;
-  constexpr int DPT = NW >= 8 ? 1 : 2;
   const int HL = BM + (KT == 9 ? 2 * a.W + 2 : 0);
   a.HLp = (HL + RPI - 1) / RPI * RPI;
-  const int nch = a.C / CC;
-  // chunk buffer(s) + the zero row (+ the scratch KiB of the in-loop DMA form)
-  const int halo = (nch > 1 ? 2 : 1) * a.HLp * CC * 2 + 128 + (INLOOP ? 1024 : 0), tile = BM * BN * 2;
+  const int halo = (a.C / CC > 1 ? 2 : 1) * a.HLp * CC * 2 + 128, tile = BM * BN * 2;  // chunk buffer(s) + the zero row
   const int smem = halo > tile ? halo : tile;
   if (smem > 160 * 1024) return FX_ERR_UNSUPPORTED;
-  if (!LOADER && !INLOOP && a.C != CC) return FX_ERR_UNSUPPORTED;
-  if (INLOOP && nch > 1 && a.HLp * RL / 64 > 8 * DPT * NW) return FX_ERR_UNSUPPORTED;   // taps 0-7 carry the next chunk
-  auto kern = conv3x3_flat_kernel<KT, CC, TN, TM, WN, WM, ACT, RESMODE, LOADER, OCC, ABL>;
+  if (!LOADER && a.C != CC) return FX_ERR_UNSUPPORTED;
+  auto kern = conv3x3_flat_kernel<KT, CC, TN, TM, WN, WM, ACT, RESMODE, LOADER>;
   static int attr_smem = 0;
   if (smem > attr_smem) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return FX_ERR_RUNTIME;
@@ -427,7 +348,10 @@ static void c3_fill(C3Args& a, const ConvArgs& c, const bf16_t* w_frag) {
 }
 
 int fx_launch_conv3x3_flat(const ConvArgs& c, const bf16_t* w_frag, hipStream_t stream) {
-  // round 3: the k-plane kernel wherever its plane fits the LDS (FX_C3_KPLANE=0: the round-2 kernel, for A/B runs)
+  // round 3: the k-plane kernel (conv3x3_kplane.hip) wherever its plane fits the LDS; FX_C3_KPLANE=0 keeps the round-2 kernel
+  // below for A/B runs.  (What was tried on this kernel before the rewrite - consumers issuing the chunk DMA themselves for
+  // 8-wave / 256-register tiles - is in the history of scripts/probes/c3_probe.hip and profiles/r03_c3_probe_*.txt: LDS-DMA and
+  // register loads of one wave do not retire in order, so counted vmcnt waits over a mixed queue read stale fragments under load.)
   static const int kplane_on = fx_tune("FX_C3_KPLANE", 1);
   if (kplane_on && fx_conv3x3_kplane_supported(c.C, c.N, c.W)) return fx_launch_conv3x3_kplane(c, w_frag, stream);
   C3Args a;

@@ -72,6 +72,8 @@ __global__ void cmp_kernel(const bf16_t* got, const float* ref, long n, float* o
   atomicMax(reinterpret_cast<int*>(out) + 1, __float_as_int(r));
 }
 
+static unsigned long long* g_dbg = nullptr;
+
 struct Variant {
   std::string name;
   bool check;     // results comparable with the reference
@@ -80,20 +82,20 @@ struct Variant {
   std::function<int(C3Args&, hipStream_t)> launch;
 };
 
-template <int TN, int TM, int WN, int WM, int LOADER, int OCC, int ABL>
-static Variant mk(const char* name) {
-  return Variant{name, (ABL & 15) == 0, (ABL & 16) != 0, WN * WM,
-                 [](C3Args& a, hipStream_t s) { return launch_c3<9, 64, TN, TM, WN, WM, FX_ACT_SILU, 0, LOADER, OCC, ABL>(a, s); }};
+template <int TN, int TM, int WN, int WM>
+static Variant mk(const char* name) {   // the round-2 kernel (conv3x3_flat.hip), as shipped
+  return Variant{name, true, false, WN * WM, [](C3Args& a, hipStream_t s) { return launch_c3<9, 64, TN, TM, WN, WM, FX_ACT_SILU, 0>(a, s); }};
 }
 
 template <int TN, int TM, int WN, int WM, int HLP, int ABL>
 static Variant mkk(const char* name) {
   return Variant{name, (ABL & 15) == 0, (ABL & 16) != 0, WN * WM, [](C3Args& a, hipStream_t s) {
                    C3KArgs k{};
-                   (void)hipMemsetAsync(a.dbg, 0, 16 * 16 * 8, s);
+                   k.dbg = g_dbg;
+                   (void)hipMemsetAsync(g_dbg, 0, 16 * 16 * 8, s);
                    k.x = a.x; k.wp = a.wp; k.bias = a.bias; k.res = a.res; k.y = a.y;
                    k.H = a.H; k.W = a.W; k.C = a.C; k.N = a.N; k.ldx = a.ldx; k.ldy = a.ldy; k.ldr = a.ldr; k.M = a.M;
-                   k.HW = a.HW; k.y_bstride = a.y_bstride; k.x_bytes = a.x_bytes; k.r_bytes = a.r_bytes; k.dbg = a.dbg;
+                   k.HW = a.HW; k.y_bstride = a.y_bstride; k.x_bytes = a.x_bytes; k.r_bytes = a.r_bytes;
                    return launch_c3k<TN, TM, WN, WM, HLP, FX_ACT_SILU, 0, ABL>(k, s);
                  }};
 }
@@ -104,14 +106,15 @@ int main(int argc, char** argv) {
   struct Shape { int B, H, W; };
   const Shape shapes[] = {{16, 40, 40}, {32, 40, 40}, {16, 80, 80}, {32, 80, 80}, {3, 20, 20}};
   std::vector<Variant> V;
-  //           TN TM WN WM L  OCC ABL
-  V.push_back(mk<2, 4, 4, 1, 1, 1, 0>("cur 4+1w 128x256                "));
-  V.push_back(mk<2, 4, 4, 1, 1, 1, 16>("cur + stamps                    "));
-  V.push_back(mk<2, 4, 4, 1, 1, 1, 19>("cur  abl: no weight, no pixel   "));
+  V.push_back(mk<2, 4, 4, 1>("r02 flat 4+1w 128x256           "));
   //            TN TM WN WM HLP ABL
   V.push_back(mkk<2, 4, 4, 1, 320, 0>("kplane 4+1w 128x256             "));
   V.push_back(mkk<2, 4, 4, 1, 320, 16 + 64>("kplane + stamps                 "));
-  V.push_back(mkk<2, 4, 2, 2, 448, 0>("kplane 4+1w 256x128 (2m x 2n)   "));
+  V.push_back(mkk<2, 4, 4, 1, 320, 1>("kplane abl: no weight refill    "));
+  V.push_back(mkk<2, 4, 4, 1, 320, 2>("kplane abl: no pixel reads      "));
+  V.push_back(mkk<2, 4, 4, 1, 320, 3>("kplane abl: no weight, no pixel "));
+  V.push_back(mkk<2, 4, 4, 1, 576, 0>("kplane 128x256, HLP 576         "));
+  V.push_back(mkk<2, 4, 2, 2, 512, 0>("kplane 4+1w 256x128 (2m x 2n)   "));
 
   hipStream_t st;
   HIPCHECK(hipStreamCreate(&st));
@@ -148,6 +151,7 @@ int main(int argc, char** argv) {
     float *dref, *dstat;
     unsigned long long* ddbg;
     HIPCHECK(hipMalloc(&ddbg, 16 * 16 * 8));
+    g_dbg = ddbg;
     HIPCHECK(hipMalloc(&dx, hx.size() * 2));
     HIPCHECK(hipMalloc(&dy, (size_t)M * N * 2));
     HIPCHECK(hipMalloc(&dref, (size_t)M * N * 4));
@@ -160,7 +164,7 @@ int main(int argc, char** argv) {
     a.x = dx; a.wp = dwf; a.bias = db; a.res = nullptr; a.y = dy;
     a.H = sh.H; a.W = sh.W; a.C = C; a.N = N; a.ldx = C; a.ldy = N; a.ldr = 0; a.M = (int)M;
     a.act = FX_ACT_SILU; a.res_after = 0; a.HLp = 0; a.HW = sh.H * sh.W; a.y_bstride = 0;
-    a.x_bytes = (unsigned)(hx.size() * 2); a.r_bytes = 0; a.dbg = ddbg;
+    a.x_bytes = (unsigned)(hx.size() * 2); a.r_bytes = 0;
 
     const double flop = 2.0 * M * N * K;
     printf("\n== B=%d H=%d W=%d  M=%ld  (%.1f GFLOP) ==\n", sh.B, sh.H, sh.W, M, flop * 1e-9);
