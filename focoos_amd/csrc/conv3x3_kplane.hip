@@ -397,18 +397,20 @@ static int launch_c3k(C3KArgs& a, hipStream_t stream) {
 }
 
 // ---- product entry points (declared in conv_common.h)
-// Tiles: N = 256: 128 pixels x 256 channels (4 waves side by side over N); N = 128: 256 x 128 (2 x 2 waves);
+// Tiles: N a multiple of 256: 128 pixels x 256 channels (4 waves side by side over N); N = 128: 256 x 128 (2 x 2 waves);
 // N = 64: 512 x 64 (4 waves over M, all four reading the same weight fragments - the whole filter is 72 KiB, L1/L2 resident).
 // Plane heights: the smallest instantiated HLP >= BM + 2W + 2 whose buffers fit the 160 KiB LDS.
 static int c3k_plan(int C, int N, int W) {   // 0: not covered, else HLP
   if (C % 64 != 0) return 0;
   const int nbuf = C > 64 ? 2 : 1;
-  const int BM = N == 256 ? 128 : (N == 128 ? 256 : (N == 64 ? 512 : 0));
+  static const int wide_n = fx_tune("FX_C3K_WIDE_N", 1);   // 0: only N = 256 (A/B knob for the N = 512 layers of res5)
+  const bool n256 = N == 256 || (wide_n && N > 0 && N % 256 == 0);
+  const int BM = n256 ? 128 : (N == 128 ? 256 : (N == 64 ? 512 : 0));
   if (!BM) return 0;
   const int need = (BM + 2 * W + 2 + 63) / 64 * 64;
   static const int opts256[] = {320, 576}, opts128[] = {512}, opts64[] = {960};
-  const int* opts = N == 256 ? opts256 : (N == 128 ? opts128 : opts64);
-  const int nopt = N == 256 ? 2 : 1;
+  const int* opts = n256 ? opts256 : (N == 128 ? opts128 : opts64);
+  const int nopt = n256 ? 2 : 1;
   for (int i = 0; i < nopt; ++i)
     if (opts[i] >= need && nbuf * 8 * (opts[i] + 1) * 16 <= 160 * 1024) return opts[i];
   return 0;

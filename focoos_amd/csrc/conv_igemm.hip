@@ -319,9 +319,11 @@ static ConvRoute conv_route(const fx_conv_desc* d, const ConvArgs& a) {
   // (the two size thresholds are re-read per call - a getenv each, nothing under graph replay - so that kernel tests can route
   // small shapes here while the end-to-end tests keep the production routing)
   static const int c3_on = fx_tune("FX_CONV3_FLAT", 1), pw_on = fx_tune("FX_PW_FLAT", 1);
-  // 20 000 pixels: a half-batch part (16 images) of the two-part step still routes its 40x40 layers (M = 25 600) here - measured with two
-  // concurrent parts: RT-DETR 3586 -> 3739 img/s, MaskFormer 1180 -> 1266, BiSeNetFormer 7053 -> 7352 against the 40 000 of the one-part tuning
-  const int c3_min_m = fx_tune("FX_CONV3_MIN_M", 20000), pw_min_m = fx_tune("FX_PW_MIN_M", 20000);
+  // 5 000 pixels (round 3; was 20 000): with two concurrent half-batch parts a layer's own latency matters less than the CU time it
+  // occupies - the 20x20-level layers (M = 6 400 per part) fill only 50-100 workgroups of the flat kernels, but those run at 2-3x the
+  // per-CU rate of the implicit-GEMM tiles and the other part's launches take the idle CUs: RT-DETR 3883 -> 3990 img/s
+  // (profiles/r03_threshold_sweep.txt); one part alone (FX_STREAMS=1) 3334 -> 3420
+  const int c3_min_m = fx_tune("FX_CONV3_MIN_M", 5000), pw_min_m = fx_tune("FX_PW_MIN_M", 5000);
   if (d->w_frag && ((uintptr_t)d->w_frag % 16) == 0 && d->stride == 1 && !d->pool2 && !d->out_f32) {
     const int mode = fx_c3_epilogue_mode(d->act, d->residual != nullptr, d->residual_after_act);
     if (c3_on && d->KH == 3 && d->KW == 3 && d->pad == 1 && !d->y_batch_stride && ((mode >= 0 && mode <= 3) || mode == 5) && a.M >= c3_min_m &&

@@ -10,7 +10,7 @@ if ROOT not in sys.path:
 
 @pytest.fixture
 def flat_small_shapes(monkeypatch):
-    """The halo 3x3 / flat pointwise kernels are routed to from M >= 20000 pixels in production (smaller layers do not fill the
+    """The halo 3x3 / flat pointwise kernels are routed to from M >= 5000 pixels in production (smaller layers do not fill the
     chip).  Kernel-level parity tests run small shapes through them by lowering the thresholds (re-read by the library per call);
     end-to-end tests keep the production routing, i.e. they check the numerics a user gets at that size."""
     monkeypatch.setenv("FX_CONV3_MIN_M", "0")

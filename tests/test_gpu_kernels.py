@@ -631,6 +631,10 @@ FLAT_CASES = [
     (2, 20, 20, 256, 256, "silu", True, 0),     # RepVGG / CSP: SiLU then + residual, 128 x 256 tile, image boundary inside a tile
     (1, 40, 40, 256, 256, "silu", False, 0),
     (5, 6, 7, 64, 256, "relu", False, 0),       # several tiny images per tile: every tap crosses image borders
+    (2, 20, 20, 512, 512, "relu", False, 0),    # res5 branch2b: eight channel chunks, two 256-channel output tiles per pixel tile
+    (1, 5, 200, 256, 256, "silu", True, 0),     # W = 200 (MaskFormer FPN): the 576-row plane instantiation, residual epilogue through LDS
+    (1, 7, 160, 64, 64, "relu", False, 0),      # W = 160 (res2): 512-pixel tile, one chunk
+    (1, 9, 100, 128, 128, None, False, 16),     # W = 100 (MaskFormer res3), strided input rows, no activation
 ]
 
 

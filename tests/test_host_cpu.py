@@ -246,7 +246,7 @@ def test_trainer_ports_and_structures():
 
 def test_conv_routing_labels(lib_path, monkeypatch):
     """fx_conv2d_variant = the label of the kernel fx_conv2d_nhwc_bf16 routes a descriptor to (one routing function for both; host logic,
-    no launch): the production thresholds (flat kernels from 20 000 output pixels, small-M tile up to 16 384) and the error path."""
+    no launch): the production thresholds (flat kernels from 5 000 output pixels, small-M tile up to 16 384) and the error path."""
     import ctypes as C
 
     from focoos_amd import _lib
@@ -270,12 +270,14 @@ def test_conv_routing_labels(lib_path, monkeypatch):
         return buf.value.decode() if rc == 0 else rc
 
     assert label(16, 40, 40, 256, 256, 3) == "conv3x3_flat<256>"            # M = 25 600: a 16-image part's 40x40 level
-    assert label(8, 40, 40, 256, 256, 3) == "conv_igemm<128,128,64>"          # M = 12 800 < 20 000
+    assert label(8, 40, 40, 256, 256, 3) == "conv3x3_flat<256>"               # M = 12 800 >= 5 000
+    assert label(2, 40, 40, 256, 256, 3) == "conv_igemm<128,128,64>"          # M = 3 200 < 5 000
     assert label(16, 80, 80, 256, 256, 3, frag=False) == "conv_igemm_dma<256,256>"   # no fragment copy: implicit GEMM (DMA tiles from 40 000 pixels)
     assert label(16, 40, 40, 256, 256, 3, out_f32=1).startswith("conv_igemm")   # fp32 pre-BatchNorm output: not on the halo kernel
     assert label(16, 40, 40, 1024, 256, 1) == "pw_flat<K1024>"
-    assert label(16, 20, 20, 512, 512, 3) == "conv_igemm<128,128,64>"          # M = 6400, N = 512: not a halo shape
-    assert label(16, 20, 20, 256, 1024, 1) == "conv_igemm<64,64,256,1stage>"   # small M, K <= 1024
+    assert label(16, 20, 20, 512, 512, 3) == "conv3x3_flat<512>"               # res5 branch2b of a 16-image part: two 256-channel tiles per pixel tile
+    assert label(16, 20, 20, 256, 1024, 1) == "pw_flat<K256>"                  # M = 6400 >= 5000
+    assert label(4, 20, 20, 256, 1024, 1) == "conv_igemm<64,64,256,1stage>"    # small M, K <= 1024
     assert label(16, 160, 160, 64, 256, 1, frag=False) == "conv_igemm<128,128,32>"
     assert label(16, 320, 320, 32, 32, 3, frag=False) == "conv_igemm<128,32,32>"
     assert label(16, 160, 160, 256, 512, 1, pool2=1, frag=False) == "conv_igemm<128,128,64,pool>"
