@@ -62,6 +62,7 @@ _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 # name -> argtypes (every function returns int unless noted); mirrors include/focoos_amd.h
 SIGNATURES = {
     "fx_abi_version": [],
+    "fx_build_flags": [],
     "fx_device_info": [_i, C.POINTER(C.c_int), C.c_char_p, _i],
     "fx_conv2d_nhwc_bf16": [C.POINTER(FxConvDesc), _vp],
     "fx_conv2d_variant": [_vp, C.c_char_p, _i],
@@ -205,6 +206,25 @@ def load() -> C.CDLL:
         raise FocoosAmdError(f"ABI version mismatch: library {lib.fx_abi_version()} != binding 1")
     _lib = lib
     return lib
+
+
+_warned_pk = False
+
+
+def two_queue_safe() -> bool:
+    """False when the loaded library contains packed-fp32 code (fx_build_flags bit 0: FX_PK_F32 builds - the reproducer of the two-queue
+    hazard): callers then keep everything on ONE hardware queue (one batch part, no weight-gradient side stream).
+    FX_ALLOW_PK_TWO_QUEUES=1 overrides (the reproducer itself: tests/test_gpu_two_streams.py, scripts/dev/pk_bisect.sh)."""
+    global _warned_pk
+    if not (load().fx_build_flags() & 1) or os.environ.get("FX_ALLOW_PK_TWO_QUEUES") == "1":
+        return True
+    if not _warned_pk:
+        import warnings
+
+        warnings.warn("libfocoos_amd was built with packed-fp32 instructions (FX_PK_F32): concurrent batch parts and the weight-gradient "
+                      "side stream are disabled (two-queue hazard); rebuild without FX_PK_F32 for the default configuration")
+        _warned_pk = True
+    return False
 
 
 def check(rc: int, what: str = "") -> None:

@@ -18,7 +18,23 @@ ARCH = "gfx950"
 # executes them while waves of a second hardware queue are resident on its CU computes wrong values in lanes 48-63 of one operand
 # (DESIGN.md §5 "two-queue hazard": bisected to fx_bbox_head, per-lane dumps, 56-58 of 60 concurrent replays wrong with the feature on, 0 of
 # 60 with it off; single-queue execution is unaffected).  FX_PK_F32=1 re-enables them (the reproducer).
-EXTRA_FLAGS = [] if os.environ.get("FX_PK_F32", "0") == "1" else ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+NO_PK_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+STAMP_PATH = os.path.join(LIB_DIR, "build_stamp.txt")
+
+
+def _pk_units():
+    """Translation units compiled WITH packed-fp32 instructions: none (default), all (FX_PK_F32=1) or a comma-separated list of
+    file names (FX_PK_F32=select_ops.hip,token_ops.hip - the per-unit bisection of scripts/dev/pk_bisect.sh)."""
+    v = os.environ.get("FX_PK_F32", "0")
+    if v in ("", "0"):
+        return set()
+    if v == "1":
+        return {os.path.basename(s) for s in sources()}
+    return {u.strip() for u in v.split(",") if u.strip()}
+
+
+def _stamp() -> str:
+    return "arch=%s pk_units=%s" % (ARCH, ",".join(sorted(_pk_units())) or "-")
 
 
 def _hipcc() -> str:
@@ -33,32 +49,56 @@ def sources():
 
 
 def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+    """Sources, headers or this recipe newer than the library, or a library built with other flags (the stamp file: a library once
+    built with FX_PK_F32=1 must not be silently reused by a default run - ADVICE r2)."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(STAMP_PATH):
         return True
+    with open(STAMP_PATH) as f:
+        if f.read().strip() != _stamp():
+            return True
     t = os.path.getmtime(LIB_PATH)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(PKG, "..", "include", "*.h"))
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(PKG, "..", "include", "*.h")) + [os.path.abspath(__file__)]
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = True, out_path: str = None) -> str:
+    """Compile every csrc/*.hip for gfx950 and link the shared library (`out_path`: a variant library next to the product one, used by
+    the packed-fp32 bisection; the product path keeps its stamp file)."""
+    if out_path is None and not force and not needs_build():
         return LIB_PATH
+    target = out_path or LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
+    objdir = LIB_DIR if out_path is None else (target + ".obj")
+    os.makedirs(objdir, exist_ok=True)
     objs = []
     hipcc = _hipcc()
+    pk = _pk_units()
     for src in sources():
-        obj = os.path.join(LIB_DIR, os.path.basename(src).replace(".hip", ".o"))
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + EXTRA_FLAGS + ["-c", src, "-o", obj]
+        base = os.path.basename(src)
+        obj = os.path.join(objdir, base.replace(".hip", ".o"))
+        flags = [] if base in pk else NO_PK_FLAGS
+        if base == "runtime.hip":
+            flags = flags + [f"-DFX_BUILD_FLAGS={1 if pk else 0}"]
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + flags + ["-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", target] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    return LIB_PATH
+    if out_path is None:
+        with open(STAMP_PATH, "w") as f:
+            f.write(_stamp() + "\n")
+    else:
+        shutil.rmtree(objdir, ignore_errors=True)
+    return target
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    out = None
+    for a in sys.argv[1:]:
+        if a.startswith("--out="):
+            out = os.path.abspath(a[len("--out="):])
+    print(build(force="--force" in sys.argv, out_path=out))

@@ -13,6 +13,11 @@ int fx_tune(const char* env_name, int default_value) {
 
 extern "C" int fx_abi_version(void) { return FX_ABI_VERSION; }
 
+#ifndef FX_BUILD_FLAGS
+#define FX_BUILD_FLAGS 0
+#endif
+extern "C" int fx_build_flags(void) { return FX_BUILD_FLAGS; }
+
 extern "C" const char* fx_error_string(int code) {
   switch (code) {
     case FX_OK: return "ok";

@@ -4,8 +4,59 @@
 // with the reference's int64 indices: top-k order is (value descending, index ascending).
 #include "common.h"
 
+// Per-kernel bisection of the two-queue failure (scripts/dev/pk_bisect.sh kernels): when this unit is compiled WITH packed-fp32
+// instructions and -DFX_SELECT_PK_MASK=<bits>, only the kernels whose bit is set keep them.  In the product build (packed fp32 off for the
+// whole unit) FX_SEL_PK expands to nothing.
+#ifdef FX_SELECT_PK_MASK
+#define FX_SEL_NOPK __attribute__((target("no-packed-fp32-ops")))
+#if (FX_SELECT_PK_MASK >> 0) & 1
+#define FX_SEL_PK_0
+#else
+#define FX_SEL_PK_0 FX_SEL_NOPK
+#endif
+#if (FX_SELECT_PK_MASK >> 1) & 1
+#define FX_SEL_PK_1
+#else
+#define FX_SEL_PK_1 FX_SEL_NOPK
+#endif
+#if (FX_SELECT_PK_MASK >> 2) & 1
+#define FX_SEL_PK_2
+#else
+#define FX_SEL_PK_2 FX_SEL_NOPK
+#endif
+#if (FX_SELECT_PK_MASK >> 3) & 1
+#define FX_SEL_PK_3
+#else
+#define FX_SEL_PK_3 FX_SEL_NOPK
+#endif
+#if (FX_SELECT_PK_MASK >> 4) & 1
+#define FX_SEL_PK_4
+#else
+#define FX_SEL_PK_4 FX_SEL_NOPK
+#endif
+#if (FX_SELECT_PK_MASK >> 5) & 1
+#define FX_SEL_PK_5
+#else
+#define FX_SEL_PK_5 FX_SEL_NOPK
+#endif
+#if (FX_SELECT_PK_MASK >> 6) & 1
+#define FX_SEL_PK_6
+#else
+#define FX_SEL_PK_6 FX_SEL_NOPK
+#endif
+#if (FX_SELECT_PK_MASK >> 7) & 1
+#define FX_SEL_PK_7
+#else
+#define FX_SEL_PK_7 FX_SEL_NOPK
+#endif
+#define FX_SEL_PK(i) FX_SEL_PK_##i
+#else
+#define FX_SEL_PK(i)
+#endif
+
+
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ x, int ldx, float* __restrict__ out, int rows, int cols) {
+__global__ FX_SEL_PK(0) __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ x, int ldx, float* __restrict__ out, int rows, int cols) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -48,7 +99,7 @@ __device__ __forceinline__ float key_f32(uint32_t k) {
 // the two-level form, whose elements are candidates of the first; the sort key and the output use the ORIGINAL index, so ties order
 // exactly as in a single pass (candidates of equal value sit in ascending original-index order: chunks are index ranges, and each
 // chunk's list is (value desc, index asc)).  Slots beyond the row's own length are padded (-inf, INT_MAX).
-__global__ __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restrict__ scores, int ld, int n_total, int chunk_len, int nchunk, int k_out,
+__global__ FX_SEL_PK(1) __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restrict__ scores, int ld, int n_total, int chunk_len, int nchunk, int k_out,
                                                              const int32_t* __restrict__ src_idx, float* __restrict__ out_val,
                                                              int32_t* __restrict__ out_idx) {
   __shared__ uint32_t hist[256];
@@ -202,7 +253,7 @@ extern "C" int fx_topk_rows_ws_f32(const float* scores, int ld, int B, int n, in
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ src, int lds, int rpb, const int32_t* __restrict__ idx,
+__global__ FX_SEL_PK(2) __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ src, int lds, int rpb, const int32_t* __restrict__ idx,
                                                            int k, bf16_t* __restrict__ out, int ldo, int B, int C8) {
   int64_t total = (int64_t)B * k * C8;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -224,7 +275,7 @@ extern "C" int fx_gather_rows_bf16(const void* src, int lds, int rows_per_batch,
   return fx_launch_status();
 }
 
-__global__ __launch_bounds__(256) void fill_rows_kernel(bf16_t* __restrict__ x, int ldx, int rpb, const int32_t* __restrict__ rows_idx, int n_idx,
+__global__ FX_SEL_PK(3) __launch_bounds__(256) void fill_rows_kernel(bf16_t* __restrict__ x, int ldx, int rpb, const int32_t* __restrict__ rows_idx, int n_idx,
                                                          const bf16_t* __restrict__ rowv, int B, int C8) {
   int64_t total = (int64_t)B * n_idx * C8;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -249,7 +300,7 @@ extern "C" int fx_fill_rows_bf16(void* x, int ldx, int rows_per_batch, const int
 
 // ------------------------------------------------------------------------------------------------
 // relu(ref[r,0:4] @ W^T + b): K = 4 is too thin for MFMA; 8 outputs per lane, fully coalesced stores.
-__global__ __launch_bounds__(256) void linear_k4_relu_kernel(const float* __restrict__ ref, const float* __restrict__ w,
+__global__ FX_SEL_PK(4) __launch_bounds__(256) void linear_k4_relu_kernel(const float* __restrict__ ref, const float* __restrict__ w,
                                                               const float* __restrict__ bias, bf16_t* __restrict__ out, int ldo, int rows, int N8) {
   int64_t total = (int64_t)rows * N8;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -281,7 +332,7 @@ __device__ __forceinline__ float inv_sigmoid(float x) {
   return __logf(fmaxf(x, 1e-5f) / fmaxf(1.0f - x, 1e-5f));
 }
 
-__global__ __launch_bounds__(256) void bbox_head_kernel(const bf16_t* __restrict__ h, int ldh, const float* __restrict__ w,
+__global__ FX_SEL_PK(5) __launch_bounds__(256) void bbox_head_kernel(const bf16_t* __restrict__ h, int ldh, const float* __restrict__ w,
                                                          const float* __restrict__ bias, const float* __restrict__ ref,
                                                          const float* __restrict__ anchors, const int32_t* __restrict__ idx, int rpb, int mode,
                                                          float* __restrict__ new_ref, float* __restrict__ unact_out, int rows, int K) {
@@ -327,7 +378,7 @@ extern "C" int fx_bbox_head(const void* h, int ldh, const float* w, const float*
 }
 
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void detr_head_out_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ ref,
+__global__ FX_SEL_PK(6) __launch_bounds__(256) void detr_head_out_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ ref,
                                                              float* __restrict__ probs, float* __restrict__ boxes, int rows, int K) {
   int64_t total = (int64_t)rows * K;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -356,7 +407,7 @@ extern "C" int fx_detr_head_out(const float* logits, int ldl, const float* ref_c
 
 // DETRProcessor.postprocess tail: label/query split, box scale + round-half-even (torch.round) -> int32,
 // count of scores above the threshold (scores are sorted, so the kept ones form a prefix).
-__global__ __launch_bounds__(256) void detr_postprocess_kernel(const float* __restrict__ tv, const int32_t* __restrict__ ti,
+__global__ FX_SEL_PK(7) __launch_bounds__(256) void detr_postprocess_kernel(const float* __restrict__ tv, const int32_t* __restrict__ ti,
                                                                 const float* __restrict__ boxes, const int32_t* __restrict__ sizes, int Q, int K,
                                                                 int top_k, float thr, int32_t* __restrict__ labels, int32_t* __restrict__ queries,
                                                                 int32_t* __restrict__ obox, int32_t* __restrict__ count) {

@@ -365,6 +365,8 @@ class DetrEngine(_EngineBase):
         one hipGraph (default from FX_STREAMS, see _MultiPlan)."""
         if nsplit is None:
             nsplit = int(os.environ.get("FX_STREAMS", str(DEFAULT_STREAMS)))
+        if nsplit > 1 and not _lib.two_queue_safe():
+            nsplit = 1
         while nsplit > 1 and (B % nsplit or B // nsplit < MIN_PART_BATCH):
             nsplit -= 1
         key = (B, H, W, f32_input, nsplit)

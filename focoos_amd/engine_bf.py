@@ -127,6 +127,8 @@ class BfEngine(_EngineBase):
         full = self.full_masks if full_masks is None else bool(full_masks)
         if nsplit is None:
             nsplit = int(os.environ.get("FX_STREAMS", str(DEFAULT_STREAMS)))
+        if nsplit > 1 and not _lib.two_queue_safe():
+            nsplit = 1
         while nsplit > 1 and (B % nsplit or B // nsplit < MIN_PART_BATCH):
             nsplit -= 1
         key = (B, H, W, f32_input, full, nsplit)

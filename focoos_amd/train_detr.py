@@ -403,7 +403,7 @@ class TrainStep:
         # side stream for the weight-gradient launches (FX_WGRAD_STREAM=0: everything on one stream); from the per-device pool the
         # engines use, so that it maps to a hardware queue of its own
         self.wgrad_stream = None
-        if os.environ.get("FX_WGRAD_STREAM", "1") != "0" and torch.device(self.opt.dev).type == "cuda":
+        if os.environ.get("FX_WGRAD_STREAM", "1") != "0" and torch.device(self.opt.dev).type == "cuda" and _lib.two_queue_safe():
             from .engine import _device_stream
 
             self.wgrad_stream = _device_stream(torch.device(self.opt.dev), 1)

@@ -34,6 +34,10 @@ enum { FX_ACT_NONE = 0, FX_ACT_RELU = 1, FX_ACT_SILU = 2, FX_ACT_GELU = 3 };
 typedef void* fx_stream_t; /* hipStream_t */
 
 int fx_abi_version(void);
+/* How the library was compiled: bit 0 = at least one translation unit was built WITH packed-fp32 VALU instructions (the
+ * configuration in which two concurrent hardware queues corrupted results); the host refuses concurrent
+ * batch parts / the weight-gradient side stream on such a build. */
+int fx_build_flags(void);
 const char* fx_error_string(int code);
 /* Device sanity: returns FX_OK iff device 0..n has a gfx950 agent; writes CU count / arch name. */
 int fx_device_info(int device, int* cu_count, char* arch_name, int arch_name_len);
