@@ -378,6 +378,11 @@ int fx_launch_conv3x3_flat(const ConvArgs& c, const bf16_t* w_frag, hipStream_t 
 
 // Pointwise (1x1) layers with C % 256 == 0 and N % 256 == 0: 128 pixels x 256 channels per workgroup, K in 256-channel chunks
 int fx_launch_pw_flat(const ConvArgs& c, const bf16_t* w_frag, hipStream_t stream) {
+  // round 3: layers whose reduction fits the LDS (K = 256 / 512) on the resident-tile kernel (conv_pw_kplane.hip); FX_PW_KPLANE=0
+  // keeps the round-2 kernel below for A/B runs
+  static const int kplane_on = fx_tune("FX_PW_KPLANE", 1);
+  if (kplane_on && fx_pw_kplane_supported(c.C, c.N, fx_c3_epilogue_mode(c.act, c.res != nullptr, c.res_after)) && c.N * 4 + 128 * c.C * 2 + (c.res ? 65536 : 0) <= 160 * 1024)
+    return fx_launch_pw_kplane(c, w_frag, stream);
   C3Args a;
   c3_fill(a, c, w_frag);
   static const int no_loader = fx_tune("FX_PW_NO_LOADER", 1);

@@ -55,5 +55,8 @@ int fx_launch_conv3x3_flat(const ConvArgs& c, const bf16_t* w_frag, hipStream_t 
 // conv3x3_kplane.hip: the round-3 form of the same layer class (k-plane LDS layout, immediate-offset fragment reads, direct stores)
 extern "C" int fx_conv3x3_kplane_supported(int C, int N, int W);
 int fx_launch_conv3x3_kplane(const ConvArgs& c, const bf16_t* w_frag, hipStream_t stream);
+// conv_pw_kplane.hip: pointwise layers with the whole reduction resident in LDS (K = 256 / 512), one workgroup per pixel tile over all N
+bool fx_pw_kplane_supported(int C, int N, int mode);
+int fx_launch_pw_kplane(const ConvArgs& c, const bf16_t* w_frag, hipStream_t stream);
 int fx_c3_epilogue_mode(int act, bool has_res, int res_after);  // epilogue variant (3x3 kernel: 0-3, 5; pointwise: 0, 1, 3-6), -1: none
 int fx_launch_pw_flat(const ConvArgs& c, const bf16_t* w_frag, hipStream_t stream);  // 1x1, C % 256 == 0, N % 256 == 0

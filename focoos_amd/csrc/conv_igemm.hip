@@ -329,8 +329,11 @@ static ConvRoute conv_route(const fx_conv_desc* d, const ConvArgs& a) {
     if (c3_on && d->KH == 3 && d->KW == 3 && d->pad == 1 && !d->y_batch_stride && ((mode >= 0 && mode <= 3) || mode == 5) && a.M >= c3_min_m &&
         fx_conv3x3_flat_supported(d->C, d->N, d->W))
       return R_C3_FLAT;
+    // pointwise (FX_PW_SMALL_TILES = t > 0: below 20 000 pixels only layers with >= t (pixel tile x 256-channel tile) pairs - the narrow
+    // 20x20-level layers are faster on the 64x64-tile kernels in isolation (serial kernel sum 10.34 -> 10.25 ms at t = 200), but the
+    // two-part step is not: 4190 vs 4170 img/s, profiles/r03_threshold_sweep.txt - so the rule is off)
     if (pw_on && d->KH == 1 && d->KW == 1 && d->pad == 0 && d->C % 256 == 0 && d->N % 256 == 0 && a.M >= pw_min_m &&
-        (mode == 0 || mode == 1 || (mode >= 3 && mode <= 6)))
+        (a.M >= 20000 || (int64_t)((a.M + 127) / 128) * (d->N / 256) >= fx_tune("FX_PW_SMALL_TILES", 0)) && (mode == 0 || mode == 1 || (mode >= 3 && mode <= 6)))
       return R_PW_FLAT;
   }
   // BK=64 (2 workgroups/CU, 64 KiB LDS) for deep-K compute-bound layers; BK=32 (4 workgroups/CU, 34 KiB LDS: more

@@ -276,7 +276,7 @@ def test_conv_routing_labels(lib_path, monkeypatch):
     assert label(16, 40, 40, 256, 256, 3, out_f32=1).startswith("conv_igemm")   # fp32 pre-BatchNorm output: not on the halo kernel
     assert label(16, 40, 40, 1024, 256, 1) == "pw_flat<K1024>"
     assert label(16, 20, 20, 512, 512, 3) == "conv3x3_flat<512>"               # res5 branch2b of a 16-image part: two 256-channel tiles per pixel tile
-    assert label(16, 20, 20, 256, 1024, 1) == "pw_flat<K256>"                  # M = 6400 >= 5000
+    assert label(16, 20, 20, 512, 2048, 1) == "pw_flat<K512>"                  # M = 6400 >= 5000: res5 branch2c of a 16-image part
     assert label(4, 20, 20, 256, 1024, 1) == "conv_igemm<64,64,256,1stage>"    # small M, K <= 1024
     assert label(16, 160, 160, 64, 256, 1, frag=False) == "conv_igemm<128,128,32>"
     assert label(16, 320, 320, 32, 32, 3, frag=False) == "conv_igemm<128,32,32>"
