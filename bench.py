@@ -344,6 +344,18 @@ def train_measure(args, world, rank, local, with_roofline=True):
     fwd = (ALG_GFLOP_PER_IMAGE_BF_1024 * (S / 1024.0) ** 2 if bf else
            (ALG_GFLOP_PER_IMAGE_MF_800 * (S / 800.0) ** 2 if args.family == "fai_mf" else ALG_GFLOP_PER_IMAGE * (S / 640.0) ** 2))
     alg = 3 * fwd  # training ~ 3 x forward (fwd + dgrad + wgrad)
+    # data-parallel consistency: after the timed steps every rank must hold bit-identical fp32 master weights (same all-reduced
+    # gradients, same optimizer arithmetic).  Checked with one MIN and one MAX all-reduce of a float64 checksum.
+    dp_check = None
+    if world > 1:
+        import torch.distributed as dist
+
+        chk = stepper.opt.flat_p.double().sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dp_check = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "master_weights_identical_across_ranks": bool((lo == hi).item()),
+                    "checksum": float(chk.item())}
     roof = _wgrad_roofline(train_nn, stepper, imgs, all_targets[0], args.family) if (rank == 0 and with_roofline) else None
     barrier(world, False)
     out = None
@@ -360,7 +372,7 @@ def train_measure(args, world, rank, local, with_roofline=True):
                        "global_batch": B * world, "parallelism": f"dp{world} (RCCL all-reduce of one flat fp32 gradient buffer, 64 MiB buckets, "
                                                                  "segments launched from backward hooks)"},
             "alg_gflop_per_image": round(alg, 1), "frac_of_bf16_mfma_roofline_whole_path": round(value / world * alg * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
-            "roofline": roof, "final_total_loss": round(total, 4)})
+            "roofline": roof, "final_total_loss": round(total, 4), "dp_check": dp_check})
     del stepper, model
     torch.cuda.empty_cache()
     return out

@@ -100,6 +100,7 @@ SIGNATURES = {
     "fx_detr_postprocess": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp],
     "fx_detr_match_cost_f32": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _vp, _vp],
     "fx_lsa_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "fx_lsa_status_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _vp],
     "fx_detr_set_loss_workspace_bytes": [_i, _i, _i],
     "fx_detr_set_loss_f32": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _f, _f, _f, _vp, _vp, _vp],
     "fx_detr_box_loss_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp, _vp, _vp],

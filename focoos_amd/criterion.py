@@ -67,6 +67,28 @@ class _Targets:
             self.boxes = torch.zeros(1, 4, device=device)
 
 
+_LSA_STATUS: Dict[torch.device, torch.Tensor] = {}
+
+
+def lsa_status(device) -> torch.Tensor:
+    """The per-device sticky status word of the Hungarian solves (fx_lsa_status_f32: bit 0 = an assignment was infeasible, bit 1 = NaN / -inf costs)."""
+    device = torch.device(device)
+    if device not in _LSA_STATUS:
+        _LSA_STATUS[device] = torch.zeros(1, dtype=torch.int32, device=device)
+    return _LSA_STATUS[device]
+
+
+def raise_if_infeasible(device) -> None:
+    """Reads (one 4-byte D2H copy: a synchronisation - call it where the host waits anyway) and clears the status word; raises what
+    SciPy's ``linear_sum_assignment`` raises inside the reference matcher (fai_detr/modelling.py:749-750) when the costs are inf / NaN."""
+    st = _LSA_STATUS.get(torch.device(device))
+    if st is not None:
+        bits = int(st.item())
+        if bits:
+            st.zero_()
+            raise ValueError("matrix contains invalid numeric entries" if bits & 2 else "cost matrix is infeasible")
+
+
 class BoxHungarianMatcher:
     def __init__(self, cost_class: float = 2, cost_bbox: float = 5, cost_giou: float = 2, use_focal_loss: bool = True, alpha: float = 0.25,
                  gamma: float = 2.0):
@@ -81,8 +103,9 @@ class BoxHungarianMatcher:
         dev = logits.device
         logits, boxes = logits.float().contiguous(), boxes.float().contiguous()
         # Identity-like defaults instead of uninitialised memory: if the assignment is infeasible (NaN / inf costs after a diverged
-        # step) fx_lsa_f32 leaves an image's slots untouched, and the criterion would otherwise index boxes[slot, garbage].  The
-        # reference raises from SciPy in that case; here the step produces a (meaningless but in-bounds) loss and the NaNs surface in it.
+        # step) the solver leaves an image's slots untouched, and the criterion would otherwise index boxes[slot, garbage].  The
+        # reference raises from SciPy in that case; here the kernel sets the device status word and the host raises the same error at its
+        # next synchronisation point (raise_if_infeasible: the matcher's public forward, TrainStep.check / the trainer's log points).
         pi = torch.zeros(max(tg.n, 1), dtype=torch.int32, device=dev)
         ti = torch.zeros(max(tg.n, 1), dtype=torch.int32, device=dev)
         if tg.n:
@@ -91,13 +114,15 @@ class BoxHungarianMatcher:
             check(lib.fx_detr_match_cost_f32(logits.data_ptr(), K, boxes.data_ptr(), tg.labels.data_ptr(), tg.boxes.data_ptr(), tg.offsets.data_ptr(), B, Q,
                                              K, tg.tmax, float(self.cost_class), float(self.cost_bbox), float(self.cost_giou), float(self.alpha),
                                              float(self.gamma), cost.data_ptr(), st), "fx_detr_match_cost_f32")
-            check(lib.fx_lsa_f32(cost.data_ptr(), B, Q, tg.tmax, tg.offsets.data_ptr(), pi.data_ptr(), ti.data_ptr(), st), "fx_lsa_f32")
+            check(lib.fx_lsa_status_f32(cost.data_ptr(), B, Q, tg.tmax, tg.offsets.data_ptr(), pi.data_ptr(), ti.data_ptr(), lsa_status(dev).data_ptr(), st),
+                  "fx_lsa_status_f32")
         return pi, ti
 
     @torch.no_grad()
     def forward(self, outputs: Dict[str, torch.Tensor], targets: Sequence) -> List[Tuple[torch.Tensor, torch.Tensor]]:
         tg = _Targets(targets, outputs["pred_logits"].device)
         pi, ti = self.match_packed(outputs["pred_logits"], outputs["pred_boxes"], tg)
+        raise_if_infeasible(outputs["pred_logits"].device)     # the reference raises here (SciPy); this call synchronises anyway (.cpu() below)
         pi, ti, o = pi.cpu().long(), ti.cpu().long(), tg.off_host
         return [(pi[o[b]:o[b + 1]], ti[o[b]:o[b + 1]]) for b in range(len(targets))]
 

@@ -95,7 +95,7 @@ __device__ __forceinline__ LsaBest lsa_merge(const LsaBest& a, const LsaBest& b)
 }
 
 __global__ __launch_bounds__(64) void lsa_kernel(const float* __restrict__ cost, int Q, int Tmax, const int32_t* __restrict__ toff,
-                                                  int32_t* __restrict__ pred_idx, int32_t* __restrict__ tgt_idx) {
+                                                  int32_t* __restrict__ pred_idx, int32_t* __restrict__ tgt_idx, int32_t* __restrict__ status) {
   __shared__ double u[LSA_MAXT], v[LSA_MAXQ], spc[LSA_MAXQ];
   __shared__ int path[LSA_MAXQ], row4col[LSA_MAXQ], remaining[LSA_MAXQ], col4row[LSA_MAXT];
   __shared__ unsigned char SR[LSA_MAXT], SC[LSA_MAXQ];
@@ -106,6 +106,17 @@ __global__ __launch_bounds__(64) void lsa_kernel(const float* __restrict__ cost,
   if (T <= 0) return;
   const float* C = cost + (int64_t)b * Q * Tmax;  // C[q*Tmax + t]; transposed problem: row = t, col = q
   const double INF = __longlong_as_double(0x7ff0000000000000ll);
+  {  // SciPy validates first: NaN or -inf anywhere -> ValueError("matrix contains invalid numeric entries") (scipy/optimize/_lsap.c)
+    bool invalid = false;
+    for (int idx = lane; idx < Q * T; idx += 64) {
+      const float c = C[(int64_t)(idx / T) * Tmax + idx % T];
+      invalid |= (c != c) || (c == -__builtin_inff());
+    }
+    if (__ballot(invalid) != 0ull) {
+      if (lane == 0 && status) atomicOr(status, 2);
+      return;
+    }
+  }
   for (int j = lane; j < Q; j += 64) { v[j] = 0.0; row4col[j] = -1; path[j] = -1; }
   for (int i = lane; i < T; i += 64) { u[i] = 0.0; col4row[i] = -1; }
   __syncthreads();
@@ -141,21 +152,31 @@ __global__ __launch_bounds__(64) void lsa_kernel(const float* __restrict__ cost,
       }
       __syncthreads();  // all spc/path updates visible; everyone has read s_i/s_num/s_min
       if (lane == 0) {
-        SR[i] = 1;
-        const int index = best.un_it >= 0 ? best.un_it : best.as_it;
-        const int j = remaining[index];
         s_min = best.val;
-        if (row4col[j] == -1) s_sink = j; else s_i = row4col[j];
-        SC[j] = 1;
-        remaining[index] = remaining[num - 1];
-        s_num = num - 1;
+        if (!(best.val < INF)) {
+          // SciPy: "if (lowest == INFINITY) return -1" BEFORE the column is taken (rectangular_lsap.cpp) - a row whose reachable
+          // costs are all inf / NaN.  (Until round 3 the sink was set first: with a NaN row the duals became inf and the search
+          // could run past its candidate list.)
+          s_sink = -2;
+        } else {
+          SR[i] = 1;
+          const int index = best.un_it >= 0 ? best.un_it : best.as_it;
+          const int j = remaining[index];
+          if (row4col[j] == -1) s_sink = j; else s_i = row4col[j];
+          SC[j] = 1;
+          remaining[index] = remaining[num - 1];
+          s_num = num - 1;
+        }
       }
       __syncthreads();
-      if (s_sink != -1 || !(s_min < INF)) break;
+      if (s_sink != -1) break;
     }
     const double minv = s_min;
     const int sink = s_sink;
-    if (sink < 0) return;  // infeasible (inf/nan costs): leave outputs untouched, like SciPy raising
+    if (sink < 0) {  // infeasible (inf / nan costs): outputs untouched; SciPy raises "cost matrix is infeasible" here - the flag lets the host do so
+      if (lane == 0 && status) atomicOr(status, 1);
+      return;
+    }
     // dual updates (SciPy order of operations: u[cur] += minVal; u[i] += minVal - spc[col4row[i]]; v[j] -= minVal - spc[j])
     for (int i = lane; i < T; i += 64)
       if (i == cur) u[i] += minv; else if (SR[i]) u[i] += minv - spc[col4row[i]];
@@ -185,14 +206,19 @@ __global__ __launch_bounds__(64) void lsa_kernel(const float* __restrict__ cost,
   }
 }
 
-extern "C" int fx_lsa_f32(const float* cost, int B, int Q, int Tmax, const int32_t* tgt_offsets, int32_t* pred_idx, int32_t* tgt_idx,
-                          fx_stream_t stream_) {
+extern "C" int fx_lsa_status_f32(const float* cost, int B, int Q, int Tmax, const int32_t* tgt_offsets, int32_t* pred_idx, int32_t* tgt_idx,
+                                 int32_t* status, fx_stream_t stream_) {
   FX_CHECK_ARG(tgt_offsets && B > 0 && Q > 0 && Tmax >= 0);
   if (Tmax == 0) return FX_OK;
   FX_CHECK_ARG(cost && pred_idx && tgt_idx);
   if (Q > LSA_MAXQ || Tmax > LSA_MAXT || Tmax > Q) return FX_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(lsa_kernel, dim3(B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream_), cost, Q, Tmax, tgt_offsets, pred_idx, tgt_idx);
+  hipLaunchKernelGGL(lsa_kernel, dim3(B), dim3(64), 0, reinterpret_cast<hipStream_t>(stream_), cost, Q, Tmax, tgt_offsets, pred_idx, tgt_idx, status);
   return fx_launch_status();
+}
+
+extern "C" int fx_lsa_f32(const float* cost, int B, int Q, int Tmax, const int32_t* tgt_offsets, int32_t* pred_idx, int32_t* tgt_idx,
+                          fx_stream_t stream_) {
+  return fx_lsa_status_f32(cost, B, Q, Tmax, tgt_offsets, pred_idx, tgt_idx, nullptr, stream_);
 }
 
 // ------------------------------------------------------------------------------------------------

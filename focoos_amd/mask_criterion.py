@@ -87,7 +87,10 @@ class MaskHungarianMatcher:
             check(lib.fx_mask_match_cost_f32(logits.data_ptr(), K1, pp.data_ptr(), tp.data_ptr(), tg.labels.data_ptr(), tg.offsets.data_ptr(), B, Q, K1 - 1,
                                              P, tg.tmax, float(self.cost_class), float(self.cost_mask), float(self.cost_dice), int(self.cls_sigmoid),
                                              cost.data_ptr(), st), "fx_mask_match_cost_f32")
-            check(lib.fx_lsa_f32(cost.data_ptr(), B, Q, tg.tmax, tg.offsets.data_ptr(), pi.data_ptr(), ti.data_ptr(), st), "fx_lsa_f32")
+            from .criterion import lsa_status
+
+            check(lib.fx_lsa_status_f32(cost.data_ptr(), B, Q, tg.tmax, tg.offsets.data_ptr(), pi.data_ptr(), ti.data_ptr(), lsa_status(dev).data_ptr(), st),
+                  "fx_lsa_status_f32")
             self.last_cost = cost
         return pi, ti
 

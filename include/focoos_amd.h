@@ -373,6 +373,12 @@ int fx_detr_match_cost_f32(const float* logits, int ldl, const float* boxes, con
  * tie rule, so the int indices are identical to SciPy's.  Writes, at tgt_offsets[b].., the matched query indices in
  * ascending order (pred_idx) and their targets (tgt_idx).  Needs T_b <= Q <= 1024. */
 int fx_lsa_f32(const float* cost, int B, int Q, int Tmax, const int32_t* tgt_offsets, int32_t* pred_idx, int32_t* tgt_idx, fx_stream_t stream);
+/* The same with a device status word: bit 0 is OR-ed in when an image's assignment is infeasible (+inf costs: SciPy's "cost matrix is
+ * infeasible"), bit 1 when its cost block holds NaN or -inf (SciPy's "matrix contains invalid numeric entries") - the two cases in which
+ * linear_sum_assignment raises inside the reference matcher (fai_detr/modelling.py:749-750); the image's output slots stay untouched.  The word is sticky: the host reads and
+ * clears it where it synchronises anyway (focoos_amd/criterion.py: raise_if_infeasible). */
+int fx_lsa_status_f32(const float* cost, int B, int Q, int Tmax, const int32_t* tgt_offsets, int32_t* pred_idx, int32_t* tgt_idx, int32_t* status,
+                      fx_stream_t stream);
 
 /* SetCriterion.loss_labels_vfl + loss_boxes of one prediction set (modelling.py:464-497, 513-530, weights :576-579):
  * out3 = {w_vfl * loss_vfl, w_bbox * loss_bbox, w_giou * loss_giou}.  workspace: fx_detr_set_loss_workspace_bytes() bytes,

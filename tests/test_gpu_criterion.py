@@ -70,6 +70,65 @@ def test_lsa_bit_exact_vs_scipy():
     assert lib.fx_lsa_f32(None, 1, 2000, 5, None, None, None, stream()) == -1
 
 
+def test_lsa_infeasible_costs_raise_like_scipy():
+    """NaN / inf costs (a diverged step): SciPy's linear_sum_assignment raises "cost matrix is infeasible" inside the reference matcher
+    (fai_detr/modelling.py:749-750).  The kernel cannot raise: it sets the sticky status word of fx_lsa_status_f32, and the host mirror raises
+    the same ValueError at its next synchronisation point - the matcher's public forward does so itself."""
+    from focoos_amd.criterion import BoxHungarianMatcher, lsa_status, raise_if_infeasible
+    from types import SimpleNamespace
+
+    lib = _lib.load()
+    # 1. the C ABI: status bit set for the block with a NaN column, indices of the feasible block still exact
+    rs = np.random.RandomState(3)
+    Q = 50
+    good, bad = rs.rand(Q, 6).astype(np.float32), rs.rand(Q, 4).astype(np.float32)
+    bad[:, 2] = np.nan
+    with pytest.raises(ValueError):
+        linear_sum_assignment(bad)
+    cost = np.zeros((2, Q, 6), np.float32)
+    cost[0], cost[1, :, :4] = good, bad
+    off = torch.tensor([0, 6, 10], dtype=torch.int32, device=DEV)
+    cd = torch.from_numpy(cost).to(DEV)
+    pi = torch.zeros(10, dtype=torch.int32, device=DEV)
+    ti = torch.zeros(10, dtype=torch.int32, device=DEV)
+    st = torch.zeros(1, dtype=torch.int32, device=DEV)
+    check(lib.fx_lsa_status_f32(cd.data_ptr(), 2, Q, 6, off.data_ptr(), pi.data_ptr(), ti.data_ptr(), st.data_ptr(), stream()), "fx_lsa_status_f32")
+    torch.cuda.synchronize()
+    assert int(st.item()) == 2          # NaN entries: SciPy's "matrix contains invalid numeric entries"
+    r, c = linear_sum_assignment(good)
+    assert np.array_equal(pi[:6].cpu().numpy(), r) and np.array_equal(ti[:6].cpu().numpy(), c)
+    assert int(pi[6:].abs().sum()) == 0   # the infeasible image's slots are untouched
+    # +inf column: every assignment of that target costs inf -> SciPy's "cost matrix is infeasible", bit 0
+    bad2 = rs.rand(Q, 4).astype(np.float32)
+    bad2[:, 1] = np.inf
+    with pytest.raises(ValueError, match="infeasible"):
+        linear_sum_assignment(bad2)
+    cost[1, :, :4] = bad2
+    cd = torch.from_numpy(cost).to(DEV)
+    st.zero_()
+    pi.zero_()
+    check(lib.fx_lsa_status_f32(cd.data_ptr(), 2, Q, 6, off.data_ptr(), pi.data_ptr(), ti.data_ptr(), st.data_ptr(), stream()), "fx_lsa_status_f32")
+    torch.cuda.synchronize()
+    assert int(st.item()) == 1 and np.array_equal(pi[:6].cpu().numpy(), r) and int(pi[6:].abs().sum()) == 0
+    # 2. the host mirror: NaN logits -> NaN costs -> ValueError from the matcher, as from the reference's; the flag is cleared by raising
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(2, Q, 20, generator=g).to(DEV)
+    boxes = (torch.rand(2, Q, 4, generator=g) * 0.5 + 0.25).to(DEV)
+    tgts = [SimpleNamespace(labels=torch.tensor([1, 2, 3]), boxes=torch.rand(3, 4, generator=g) * 0.5 + 0.25),
+            SimpleNamespace(labels=torch.tensor([4]), boxes=torch.rand(1, 4, generator=g) * 0.5 + 0.25)]
+    m = BoxHungarianMatcher()
+    ok = m({"pred_logits": logits, "pred_boxes": boxes}, tgts)
+    assert [len(p) for p, _ in ok] == [3, 1]
+    logits_nan = logits.clone()
+    logits_nan[1] = float("nan")
+    with pytest.raises(ValueError, match="invalid numeric entries"):
+        m({"pred_logits": logits_nan, "pred_boxes": boxes}, tgts)
+    assert int(lsa_status(DEV).item()) == 0
+    raise_if_infeasible(DEV)   # nothing pending
+    again = m({"pred_logits": logits, "pred_boxes": boxes}, tgts)
+    assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(ok, again))
+
+
 def test_matcher_and_losses_vs_reference_golden():
     lib = _lib.load()
     g = load_golden("detr_criterion.npz")

@@ -86,9 +86,13 @@ def test_stage_parity_teacher_forced(setup):
 # (decoder); encoder scores max |d| 0.067-0.069 (mean 0.013, score std 0.53); final logits max |d| 0.09-0.11 at std 1.9, i.e.
 # probabilities max |d| 0.016-0.024 (mean 2e-4) and boxes max |d| 0.0046-0.0055 - the maxima over 219 000 values move by +-30 % between
 # equivalent kernel selections (fused / unfused layers), so the gates are the measured maxima x 1.25-1.45, not x 1.0.
-TOL_SCORE = 1e-1   # encoder class-score logits feeding the top-300 selection
-TOL_PROB = 3e-2    # final class probabilities
-TOL_BOX = 8e-3     # final boxes, normalised units (= 5 px at 640)
+# Round 3: gates at measured x 1.25 (profiles/r03_parity_probe.txt: scores 0.068, probabilities 0.014-0.024, boxes
+# 0.0049-0.0055).  The score tolerance cannot go to 2e-2 by keeping `memory` in fp32: rounding the oracle's fp32 memory to bf16 moves the
+# scores by 0.011 at most, while a 0.3-0.9 % relative perturbation of memory - the error the bf16 backbone + encoder arrive with - moves them
+# by 0.10-0.27 (scripts/dev/score_sensitivity.py, profiles/r03_score_sensitivity.txt): the score error is upstream of the head's input.
+TOL_SCORE = 8.5e-2  # encoder class-score logits feeding the top-300 selection
+TOL_PROB = 2.5e-2   # final class probabilities
+TOL_BOX = 7e-3      # final boxes, normalised units (= 4.5 px at 640)
 
 
 def test_free_running_index_parity_outside_margins(setup):
@@ -110,13 +114,15 @@ def test_free_running_index_parity_outside_margins(setup):
         cutoff = sc_o[i].topk(300).values[-1].item()
         must_in = set(torch.nonzero(sc_o[i] > cutoff + 2 * TOL_SCORE).flatten().tolist())
         must_out = set(torch.nonzero(sc_o[i] < cutoff - 2 * TOL_SCORE).flatten().tolist())
-        assert len(must_in) >= 60 and len(must_out) >= 6000, (len(must_in), len(must_out))   # the margin test is not vacuous
+        assert len(must_in) >= 75 and len(must_out) >= 6500, (len(must_in), len(must_out))   # the margin test is not vacuous
         assert must_in <= mine, sorted(must_in - mine)[:8]
         assert not (mine & must_out), sorted(mine & must_out)[:8]
         ref = set(g["enc_topk"][i].tolist())      # the REAL reference's set (golden): same statement, plus the overlap as a number
         assert (must_in <= ref) and not (ref & must_out)
         overlap.append(len(mine & ref))
-        assert overlap[-1] >= 270, overlap
+        print(f"free-running top-300 overlap with the real reference, image {i}: {overlap[-1]}/300; outside the +-{2 * TOL_SCORE:.2f} band: "
+              f"{len(must_in)} must-select, {len(must_out)} must-reject, all honoured")
+        assert overlap[-1] >= 275, overlap
         # within the set the engine's ORDER follows its own scores exactly (descending, ties to the lower index)
         v = sc_e[i][mine_all[i]]
         assert (v[:-1] >= v[1:]).all()
