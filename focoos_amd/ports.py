@@ -137,6 +137,51 @@ class Boxes:
         return Boxes(self.tensor[item])
 
 
+class BitMasks:
+    """[N,H,W] boolean masks of one image (structures.py:292-420, the subset the mask families' eval_postprocess returns): indexing,
+    length and the tight boxes of ``get_bounding_boxes`` (:384-398: [x0, y0, x1 + 1, y1 + 1]; an empty mask gives zeros)."""
+
+    def __init__(self, tensor):
+        import torch
+
+        tensor = torch.as_tensor(tensor)
+        assert tensor.dim() == 3, tensor.size()
+        self.tensor = tensor.to(torch.bool)
+        self.image_size = tuple(tensor.shape[1:])
+
+    def __len__(self):
+        return self.tensor.shape[0]
+
+    def __getitem__(self, item):
+        import torch
+
+        if isinstance(item, int):
+            return BitMasks(self.tensor[item].unsqueeze(0))
+        m = self.tensor[item]
+        assert m.dim() == 3, f"indexing with {item} gave shape {tuple(m.shape)}"
+        return BitMasks(m)
+
+    def nonempty(self):
+        return self.tensor.flatten(1).any(dim=1)
+
+    def get_bounding_boxes(self) -> "Boxes":
+        import torch
+
+        n, h, w = self.tensor.shape
+        boxes = torch.zeros(n, 4, dtype=torch.float32)
+        if n:
+            xs, ys = self.tensor.any(dim=1), self.tensor.any(dim=2)            # [N,W], [N,H]
+            ok = (xs.any(dim=1) & ys.any(dim=1)).cpu()
+            ar_w, ar_h = torch.arange(w, device=xs.device), torch.arange(h, device=ys.device)
+            x0 = torch.where(xs, ar_w, w).amin(dim=1)
+            x1 = torch.where(xs, ar_w, -1).amax(dim=1) + 1
+            y0 = torch.where(ys, ar_h, h).amin(dim=1)
+            y1 = torch.where(ys, ar_h, -1).amax(dim=1) + 1
+            b = torch.stack([x0, y0, x1, y1], dim=1).to(torch.float32).cpu()
+            boxes[ok] = b[ok]
+        return Boxes(boxes)
+
+
 class Instances:
     """Per-image container of equally long fields (structures.py Instances): ``Instances(image_size, boxes=..., scores=..., classes=...)``."""
 

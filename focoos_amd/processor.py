@@ -17,6 +17,7 @@ from typing import List, Optional, Sequence, Tuple, Union
 
 import numpy as np
 import torch
+import torch.nn.functional as F
 
 from . import _lib
 from ._lib import check
@@ -288,6 +289,44 @@ class MaskFormerProcessor(DETRProcessor):
         self.use_mask_score = bool(config.get("use_mask_score", False))
         self.predict_all_pixels = bool(config.get("predict_all_pixels", False))
 
+    # ---- trainer-side evaluation (fai_mf/processor.py:99-166 == bisenetformer/processor.py:95-157): plain tensor arithmetic on the model
+    # output, on whatever device it lives - the reference's own code path here is PyTorch too
+    def semantic_inference(self, mask_cls: torch.Tensor, mask_pred: torch.Tensor) -> torch.Tensor:
+        """:99-105 - per-class score maps [K,H,W] = sum_q class probability x mask probability."""
+        return torch.einsum("qc,qhw->chw", mask_cls, mask_pred)
+
+    def instance_inference(self, mask_cls: torch.Tensor, mask_pred: torch.Tensor):
+        """:107-144 - the top_k (query, class) pairs of the [Q,K] scores; score = class score x mean mask probability inside the
+        thresholded mask (with the reference's 1e-3 scaling of the binary mask and its + 1e-6); tight boxes of the masks."""
+        from .ports import BitMasks, Instances
+
+        image_size = tuple(mask_pred.shape[-2:])
+        nq = mask_pred.shape[0]
+        labels = torch.arange(self.num_classes, device=mask_cls.device).unsqueeze(0).repeat(nq, 1).flatten(0, 1)
+        scores_per_image, topk_indices = mask_cls.flatten(0, 1).topk(self.top_k, sorted=False)
+        labels_per_image = labels[topk_indices]
+        mask_pred = mask_pred[topk_indices // self.num_classes]
+        bin_masks = (mask_pred > self.mask_threshold) * 1e-3
+        mask_scores = (bin_masks.flatten(1) * mask_pred.flatten(1)).sum(1) / (bin_masks.flatten(1).sum(1) + 1e-6)
+        masks = BitMasks(bin_masks.float())
+        return Instances(image_size, boxes=masks.get_bounding_boxes(), masks=masks, scores=scores_per_image * mask_scores, classes=labels_per_image)
+
+    def eval_postprocess(self, output, batched_inputs: Sequence, top_k: Optional[int] = None):
+        """:146-166 (ABC: base_processor.py:161): per image, crop the predicted masks to the un-padded extent, resize them bilinearly to
+        the original (height, width) and run the configured inference ("instance" -> {"instances": Instances}, "semantic" -> {"sem_seg":
+        [K,H,W]}).  ``output``: MaskFormerModelOutput / BisenetFormerOutput (``logits`` [B,Q,K], ``masks`` [B,Q,h,w])."""
+        semantic = self.config.get("postprocessing_type", "instance") == "semantic"
+        fn = self.semantic_inference if semantic else self.instance_inference
+        results = []
+        for i, entry in enumerate(batched_inputs):
+            size = tuple(entry.image.shape[-2:])
+            m = output.masks[i]
+            stride = size[1] // m.shape[2]
+            m = m[:, : 1 + size[0] // stride, : 1 + size[1] // stride]
+            m = F.interpolate(m.unsqueeze(0), size=(int(entry.height), int(entry.width)), mode="bilinear", align_corners=False)[0]
+            results.append({("sem_seg" if semantic else "instances"): fn(output.logits[i], m)})
+        return results
+
     def preprocess(self, inputs: ImageInput, device: torch.device, dtype: torch.dtype = torch.float32):
         """fai_mf/processor.py:60-97 (inference branch): images are batched at their own size; mixed sizes cannot be stacked
         (base_processor.py:294 torch.stack) and are rejected here as well."""
@@ -414,8 +453,8 @@ class MaskFormerProcessor(DETRProcessor):
 class BisenetFormerProcessor(MaskFormerProcessor):
     """Mirror of focoos/models/bisenetformer/processor.py:25-300 - the same processor as MaskFormerProcessor (the reference files
     are line-for-line copies) for the "semantic" / "instance" configurations; ``postprocess`` covers both the threshold branch and
-    the predict_all_pixels branch (per-pixel argmax over queries, ``fx_seg_postprocess``).  The trainer-side
-    ``eval_postprocess`` (semantic_inference einsum, :95-101, 134-157) belongs to the evaluator and is not mirrored."""
+    the predict_all_pixels branch (per-pixel argmax over queries, ``fx_seg_postprocess``).  The trainer-side ``eval_postprocess``
+    (semantic_inference einsum / instance_inference, :95-157) is inherited from MaskFormerProcessor (the reference files are copies)."""
 
     _postprocessing_types = ("semantic", "instance")
     _export_output_names = ("logits", "masks")

@@ -168,3 +168,53 @@ def test_maskformer_adapter_shares_every_parameter_with_the_training_graph(monke
     assert n == len(list(ref.state_dict())) == len(list(net.state_dict()))
     refp = dict(ref.named_parameters())
     assert all(p is refp[k] for k, p in net.named_parameters())
+
+
+@pytest.mark.parametrize("family,ptype", [("fai_mf", "instance"), ("bisenetformer", "semantic"), ("bisenetformer", "instance")])
+def test_mask_eval_postprocess_equals_reference(family, ptype):
+    """Trainer-side eval_postprocess of the mask families (fai_mf/processor.py:99-166, bisenetformer/processor.py:95-157) on the same random
+    model output: our processors against the REAL reference processors - instance fields (scores, classes, boxes, masks) and the semantic
+    score maps, incl. the crop to the un-padded extent and the resize to the original (height, width)."""
+    ref_import.install()
+    import torch
+    from focoos.model_manager import ConfigManager
+    from focoos.ports import DatasetEntry as RefEntry
+    from focoos.ports import ModelFamily
+
+    from focoos_amd.ports import BisenetFormerOutput, DatasetEntry, MaskFormerModelOutput
+    from focoos_amd.processor import BisenetFormerProcessor, MaskFormerProcessor
+    from focoos_amd.registry import ModelRegistry
+
+    name = "fai-mf-l-coco-ins" if family == "fai_mf" else "bisenetformer-l-ade"
+    cfgd = dict(ModelRegistry.get_model_info(name)["config"])
+    cfgd.update(postprocessing_type=ptype, top_k=20)
+    fam = ModelFamily.MASKFORMER if family == "fai_mf" else ModelFamily.BISENETFORMER
+    rcfg = ConfigManager.from_dict(fam, {k: v for k, v in cfgd.items() if k != "resolution"})
+    if family == "fai_mf":
+        from focoos.models.fai_mf.ports import MaskFormerModelOutput as RefOut
+        from focoos.models.fai_mf.processor import MaskFormerProcessor as RefProc
+        mine, mk = MaskFormerProcessor(cfgd), MaskFormerModelOutput
+    else:
+        from focoos.models.bisenetformer.ports import BisenetFormerOutput as RefOut
+        from focoos.models.bisenetformer.processor import BisenetFormerProcessor as RefProc
+        mine, mk = BisenetFormerProcessor(cfgd), BisenetFormerOutput
+    ref = RefProc(rcfg)
+    g = torch.Generator().manual_seed(5)
+    B, Q, K = 2, 12, int(cfgd["num_classes"])
+    logits = torch.softmax(torch.randn(B, Q, K + 1, generator=g) * 2, -1)[..., :-1]
+    masks = torch.sigmoid(torch.randn(B, Q, 24, 32, generator=g) * 3)          # stride 4 of a padded 96 x 128 batch
+    sizes = [((90, 120), (181, 240)), ((96, 128), (96, 128))]                   # (augmented image size, original size)
+    ents_r = [RefEntry(image=torch.zeros(3, *a), height=o[0], width=o[1]) for a, o in sizes]
+    ents_m = [DatasetEntry(image=torch.zeros(3, *a), height=o[0], width=o[1]) for a, o in sizes]
+    want = ref.eval_postprocess(RefOut(masks=masks, logits=logits, loss=None), ents_r)
+    got = mine.eval_postprocess(mk(masks=masks, logits=logits, loss=None), ents_m)
+    assert len(want) == len(got) == 2
+    for w, m_ in zip(want, got):
+        assert set(w) == set(m_)
+        if ptype == "semantic":
+            assert torch.allclose(w["sem_seg"], m_["sem_seg"], atol=1e-6) and w["sem_seg"].shape[0] == K
+        else:
+            wi, mi = w["instances"], m_["instances"]
+            assert wi.image_size == mi.image_size and len(wi) == len(mi) == 20
+            assert torch.equal(wi.classes, mi.classes) and torch.allclose(wi.scores, mi.scores, atol=1e-6)
+            assert torch.equal(wi.masks.tensor, mi.masks.tensor) and torch.equal(wi.boxes.tensor, mi.boxes.tensor)
