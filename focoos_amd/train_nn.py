@@ -224,7 +224,7 @@ def _frag_eligible(rows: int, cin: int, k: int) -> bool:
     """Shapes fx_conv2d_nhwc_bf16 can run on the kernels of conv3x3_flat.hip, given the weight copy in fragment order (``rows`` output
     channels, ``cin`` input channels of the convolution that USES the image - swapped for the input-gradient convolution)."""
     if k == 3:
-        return rows in (64, 128, 256) and cin % 64 == 0
+        return (rows in (64, 128) or rows % 256 == 0) and cin % 64 == 0
     return k == 1 and rows % 256 == 0 and cin % 256 == 0
 
 
