@@ -17,6 +17,8 @@
 // pw_common.h), rows = B operand from LDS.  With 32 rows a fragment is used by one MFMA only: the chain is bound by the
 // weight stream from L2 (~2 MB per workgroup and layer), not by the matrix cores - which is still 5-10x less time than the
 // launch-bound form.
+#include <stdlib.h>
+
 #include "pw_common.h"
 
 enum { RC_LOAD = 0, RC_GEMM = 1, RC_GEMM_LN = 2, RC_ADD = 3, RC_K4 = 4, RC_BBOX = 5 };
@@ -29,14 +31,24 @@ __device__ __forceinline__ float rc_inv_sigmoid(float x) {
 // byte offset of 16-byte chunk `chunk` of row `row` in a [32][K] buffer (K >= 128: 16 chunks per 256-byte bank window)
 __device__ __forceinline__ int rc_off(int row, int chunk, int rowb) { return row * rowb + ((chunk ^ (row & 15)) << 4); }
 
-__global__ __launch_bounds__(512, 1) void row_chain_kernel(const fx_rc_stage* __restrict__ prog, int nstages, int M) {
+// bias_off: LDS byte offset of a 12 KiB scratch behind the program's own buffers (round 3).  Per-stage s_memtime stamps of the post-MSDA
+// chain (scripts/dev/rc_stage_stamps.py; 136k cycles): the GEMM stages stream 2 MB of weights per workgroup at ~8.7 TB/s of aggregate L2
+// bandwidth (150 workgroups pulling the same fragments - that is their bound: a 16-deep ring changed nothing), but the two VALU stages
+// K4 and BBOX took 19k cycles EACH for ~130 kFLOP: every thread walked its fp32 weights with dependent global loads.  Both now copy
+// their weights into the scratch with one coalesced pass and compute from LDS (K4 with lane = row, so that a wave reads two
+// addresses per instruction: broadcasts).  A GEMM stage keeps its bias vector there (no global load per 32-channel pass).
+#define RC_SCRATCH 12288
+__global__ __launch_bounds__(512, 1) void row_chain_kernel(const fx_rc_stage* __restrict__ prog, int nstages, int M, int bias_off, unsigned long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* biasL = reinterpret_cast<float*>(smem + bias_off);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l32 = lane & 31, half = lane >> 5;
   const int m0 = blockIdx.x * 32;
 
+  if (dbg && blockIdx.x == 0 && tid == 0) dbg[0] = __builtin_amdgcn_s_memtime();
   for (int si = 0; si < nstages; ++si) {
+    if (dbg && blockIdx.x == 0 && tid == 0) dbg[1 + si] = __builtin_amdgcn_s_memtime();
     const fx_rc_stage st = prog[si];   // wave-uniform: scalar loads
     const int K = st.K, N = st.N;
     if (st.type == RC_LOAD) {
@@ -62,26 +74,35 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(const fx_rc_stage* __
         *reinterpret_cast<uint4*>(smem + st.dst + o) = pack_bf16x8(fa);
       }
     } else if (st.type == RC_K4) {
-      // Y[row][n] = relu(b[n] + sum_k ref[row][k] * W[n][k]); ref from the LDS hand-over area (aux >= 0) or from global
-      const float* w = reinterpret_cast<const float*>(st.w);
+      // Y[row][n] = relu(b[n] + sum_k ref[row][k] * W[n][k]); ref from the LDS hand-over area (aux >= 0) or from global.  N <= 512.
+      float4* wL = reinterpret_cast<float4*>(smem + bias_off);            // [N] rows of 4 weights
+      float* bL = reinterpret_cast<float*>(smem + bias_off + 8192);       // [N]
+      for (int n = tid; n < N; n += 512) {
+        wL[n] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(st.w) + (size_t)n * 4);
+        bL[n] = st.bias[n];
+      }
+      const int m = m0 + l32;
+      float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (st.aux >= 0) r = *reinterpret_cast<const float4*>(smem + st.aux + l32 * 16);
+      else if (m < M) r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(st.g0) + (size_t)m * 4);
+      __syncthreads();
+      // lane = row; (wave, half, it) -> 8-channel chunk c: the weights of a chunk are the same for all 32 rows (two addresses per wave)
       const int cpr = N >> 3;
-      for (int q = tid; q < 32 * cpr; q += 512) {
-        const int row = q / cpr, c = q - row * cpr;
-        const int m = m0 + row;
-        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (st.aux >= 0) r = *reinterpret_cast<const float4*>(smem + st.aux + row * 16);
-        else if (m < M) r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(st.g0) + (size_t)m * 4);
+      for (int c = wave * 2 + half; c < cpr; c += 16) {
         float v[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-          const float4 wv = *reinterpret_cast<const float4*>(w + (size_t)(c * 8 + i) * 4);
-          v[i] = fmaxf(st.bias[c * 8 + i] + r.x * wv.x + r.y * wv.y + r.z * wv.z + r.w * wv.w, 0.0f);
+          const float4 wv = wL[c * 8 + i];
+          v[i] = fmaxf(bL[c * 8 + i] + r.x * wv.x + r.y * wv.y + r.z * wv.z + r.w * wv.w, 0.0f);
         }
-        *reinterpret_cast<uint4*>(smem + st.dst + rc_off(row, c, N * 2)) = pack_bf16x8(v);
+        *reinterpret_cast<uint4*>(smem + st.dst + rc_off(l32, c, N * 2)) = pack_bf16x8(v);
       }
     } else if (st.type == RC_BBOX) {
       // 32 rows x 4 outputs, K = 256: 8 threads per row, 32 channels each
-      const float* w = reinterpret_cast<const float*>(st.w);
+      float* wLb = reinterpret_cast<float*>(smem + bias_off);   // [4][K] fp32, K = 256
+      for (int q = tid; q < K; q += 512) *reinterpret_cast<float4*>(wLb + q * 4) = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(st.w) + q * 4);
+      __syncthreads();
+      const float* w = wLb;
       const int row = (tid >> 3) & 31, part = tid & 7;   // threads 256..511 recompute rows 0..31 and store nothing
       float acc4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -124,20 +145,23 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(const fx_rc_stage* __
         const int ic = i < total ? i : total - 1;
         return wb + ((size_t)(wave + ((ic >> ksh) << 3)) * KS + (ic & (KS - 1))) * 512;
       };
-      if (npass > 0) {
-        bf16x8 ar[8];
+      bf16x8 ar[8];
+      if (npass > 0) {   // the ring's first fragments go out before the bias copy: one L2 round trip covers both
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
           ar[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
           c3_ldg_async(ar[i], frag(i));
         }
+      }
+      for (int n = tid; n < N; n += 512) biasL[n] = st.bias ? st.bias[n] : 0.0f;
+      __syncthreads();
+      if (npass > 0) {
         for (int ps = 0; ps < npass; ++ps) {
           const int nb = wave + ps * 8;
           f32x16 acc;
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
-            float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (st.bias) bb = *reinterpret_cast<const float4*>(st.bias + nb * 32 + 8 * gq + 4 * half);
+            const float4 bb = *reinterpret_cast<const float4*>(biasL + nb * 32 + 8 * gq + 4 * half);
             acc[4 * gq] = bb.x; acc[4 * gq + 1] = bb.y; acc[4 * gq + 2] = bb.z; acc[4 * gq + 3] = bb.w;
           }
 #pragma unroll 1
@@ -255,16 +279,21 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(const fx_rc_stage* __
     }
     __syncthreads();   // stage boundary: the next stage reads what this one wrote
   }
+  if (dbg && blockIdx.x == 0 && tid == 0) dbg[1 + nstages] = __builtin_amdgcn_s_memtime();
 }
 
 extern "C" int fx_row_chain(const fx_rc_stage* program_device, int n_stages, int rows, int lds_bytes, fx_stream_t stream_) {
-  FX_CHECK_ARG(program_device && n_stages > 0 && n_stages <= 64 && rows > 0 && lds_bytes > 0 && lds_bytes <= 160 * 1024);
+  FX_CHECK_ARG(program_device && n_stages > 0 && n_stages <= 64 && rows > 0 && lds_bytes > 0 && lds_bytes % 16 == 0 && lds_bytes + RC_SCRATCH <= 160 * 1024);
   static int attr_smem = 0;
-  if (lds_bytes > attr_smem) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(row_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+  if (lds_bytes + RC_SCRATCH > attr_smem) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(row_chain_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes + RC_SCRATCH) != hipSuccess)
       return FX_ERR_RUNTIME;
-    attr_smem = lds_bytes;
+    attr_smem = lds_bytes + RC_SCRATCH;
   }
-  hipLaunchKernelGGL(row_chain_kernel, dim3((rows + 31) / 32), dim3(512), lds_bytes, reinterpret_cast<hipStream_t>(stream_), program_device, n_stages, rows);
+  // diagnostic (scripts/dev/rc_stage_stamps.py): FX_RC_DBG = address of a device buffer of 64 x u64 that receives the s_memtime stamps of
+  // workgroup 0 at every stage boundary; unset (the product): null, the kernel skips the stamps
+  static unsigned long long* const dbg = reinterpret_cast<unsigned long long*>((uintptr_t)strtoull(getenv("FX_RC_DBG") ? getenv("FX_RC_DBG") : "0", nullptr, 0));
+  hipLaunchKernelGGL(row_chain_kernel, dim3((rows + 31) / 32), dim3(512), lds_bytes + RC_SCRATCH, reinterpret_cast<hipStream_t>(stream_), program_device, n_stages,
+                     rows, lds_bytes, dbg);
   return fx_launch_status();
 }
