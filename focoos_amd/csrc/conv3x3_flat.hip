@@ -332,7 +332,7 @@ int fx_c3_epilogue_mode(int act, bool has_res, int res_after) {
 
 // 1 iff fx_conv2d_nhwc_bf16 routes this 3x3 shape to the halo kernel (the halo tile must fit the 160 KiB LDS)
 extern "C" int fx_conv3x3_flat_supported(int C, int N, int W) {
-  if (fx_conv3x3_kplane_supported(C, N, W)) return 1;
+  if (fx_conv3x3_kplane_supported(C, N, W) || fx_conv3x3_c32_supported(C, N, W, 0)) return 1;
   if (C % 64 != 0 || !(N == 64 || N == 128 || N == 256)) return 0;
   const int BM = N == 256 ? 128 : 256;
   const int HLp = (BM + 2 * W + 2 + 7) / 8 * 8;
@@ -353,6 +353,7 @@ int fx_launch_conv3x3_flat(const ConvArgs& c, const bf16_t* w_frag, hipStream_t 
   // 8-wave / 256-register tiles - is in the history of scripts/probes/c3_probe.hip and profiles/r03_c3_probe_*.txt: LDS-DMA and
   // register loads of one wave do not retire in order, so counted vmcnt waits over a mixed queue read stale fragments under load.)
   static const int kplane_on = fx_tune("FX_C3_KPLANE", 1);
+  if (c.C == 32) return fx_launch_conv3x3_c32(c, w_frag, stream);
   if (kplane_on && fx_conv3x3_kplane_supported(c.C, c.N, c.W)) return fx_launch_conv3x3_kplane(c, w_frag, stream);
   C3Args a;
   c3_fill(a, c, w_frag);

@@ -400,6 +400,13 @@ static int launch_c3k(C3KArgs& a, hipStream_t stream) {
 // Tiles: N a multiple of 256: 128 pixels x 256 channels (4 waves side by side over N); N = 128: 256 x 128 (2 x 2 waves);
 // N = 64: 512 x 64 (4 waves over M, all four reading the same weight fragments - the whole filter is 72 KiB, L1/L2 resident).
 // Plane heights: the smallest instantiated HLP >= BM + 2W + 2 whose buffers fit the 160 KiB LDS.
+// small-M form of the N % 256 tile: 64 pixels x 256 channels (2 x 2 accumulator blocks per wave) - twice the workgroups for the
+// 20x20-level layers (M = 6 400 per 16-image part: 50 -> 100 pixel tiles), each with half the MFMA work
+static bool c3k_small_m(int M, int N, int W) {
+  static const int thr = fx_tune("FX_C3K_SMALL_M", 16000);
+  return N % 256 == 0 && M <= thr && 64 + 2 * W + 2 <= 192;
+}
+
 static int c3k_plan(int C, int N, int W) {   // 0: not covered, else HLP
   if (C % 64 != 0) return 0;
   const int nbuf = C > 64 ? 2 : 1;
@@ -426,8 +433,10 @@ int fx_launch_conv3x3_kplane(const ConvArgs& c, const bf16_t* w_frag, hipStream_
   a.H = c.H; a.W = c.W; a.C = c.C; a.N = c.N; a.ldx = c.ldx; a.ldy = c.ldy; a.ldr = c.ldr; a.M = c.M;
   a.HW = c.Ho * c.Wo; a.y_bstride = c.y_bstride; a.x_bytes = c.x_bytes; a.r_bytes = c.r_bytes; a.dbg = nullptr;
   const int mode = fx_c3_epilogue_mode(c.act, c.res != nullptr, c.res_after);
+  const bool small = c3k_small_m(c.M, c.N, c.W);
 #define FX_C3K_TILE(ACT_, RM_)                                                             \
   {                                                                                        \
+    if (small) return launch_c3k<2, 2, 4, 1, 192, ACT_, RM_>(a, stream);                   \
     if (c.N == 64) return launch_c3k<2, 4, 1, 4, 960, ACT_, RM_>(a, stream);               \
     if (c.N == 128) return launch_c3k<2, 4, 2, 2, 512, ACT_, RM_>(a, stream);              \
     if (hlp == 320) return launch_c3k<2, 4, 4, 1, 320, ACT_, RM_>(a, stream);              \

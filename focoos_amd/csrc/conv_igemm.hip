@@ -326,8 +326,9 @@ static ConvRoute conv_route(const fx_conv_desc* d, const ConvArgs& a) {
   const int c3_min_m = fx_tune("FX_CONV3_MIN_M", 5000), pw_min_m = fx_tune("FX_PW_MIN_M", 5000);
   if (d->w_frag && ((uintptr_t)d->w_frag % 16) == 0 && d->stride == 1 && !d->pool2 && !d->out_f32) {
     const int mode = fx_c3_epilogue_mode(d->act, d->residual != nullptr, d->residual_after_act);
+    static const int c32_on = fx_tune("FX_C3_C32", 1);
     if (c3_on && d->KH == 3 && d->KW == 3 && d->pad == 1 && !d->y_batch_stride && ((mode >= 0 && mode <= 3) || mode == 5) && a.M >= c3_min_m &&
-        fx_conv3x3_flat_supported(d->C, d->N, d->W))
+        fx_conv3x3_flat_supported(d->C, d->N, d->W) && (d->C != 32 || (c32_on && fx_conv3x3_c32_supported(d->C, d->N, d->W, mode))))
       return R_C3_FLAT;
     // pointwise (FX_PW_SMALL_TILES = t > 0: below 20 000 pixels only layers with >= t (pixel tile x 256-channel tile) pairs - the narrow
     // 20x20-level layers are faster on the 64x64-tile kernels in isolation (serial kernel sum 10.34 -> 10.25 ms at t = 200), but the
@@ -379,7 +380,7 @@ extern "C" int fx_conv2d_variant(const fx_conv_desc* d, char* out, int cap) {
   const int rc = conv_prepare(d, a);
   if (rc != FX_OK) return rc;
   switch (conv_route(d, a)) {
-    case R_C3_FLAT: snprintf(out, cap, "conv3x3_flat<%d>", d->N); break;
+    case R_C3_FLAT: snprintf(out, cap, d->C == 32 ? "conv3x3_c32<%d>" : "conv3x3_flat<%d>", d->N); break;
     case R_PW_FLAT: snprintf(out, cap, "pw_flat<K%d>", d->C); break;
     case R_SMALL_M: snprintf(out, cap, "conv_igemm<64,64,256,1stage>"); break;
     case R_DMA: snprintf(out, cap, "conv_igemm_dma<256,%d>", d->N % 256 == 0 ? 256 : 128); break;

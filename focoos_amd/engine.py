@@ -124,7 +124,8 @@ class _EngineBase:
         if bias is not None:
             b[:N] = bias
         wf = None
-        if (KH == 3 and KW == 3 and (N in (64, 128) or N % 256 == 0) and Cc % 64 == 0) or (KH == 1 and KW == 1 and N % 256 == 0 and Cc % 256 == 0):
+        if ((KH == 3 and KW == 3 and (N in (64, 128) or N % 256 == 0) and Cc % 64 == 0) or (KH == 1 and KW == 1 and N % 256 == 0 and Cc % 256 == 0)
+                or (KH == 3 and KW == 3 and Cc == 32 and N in (32, 64))):   # the stem's conv1_2 / conv1_3 (conv3x3_c32.hip)
             # second copy in MFMA fragment order (fx_conv_desc.w_frag) for the halo / pointwise kernels of conv3x3_flat.hip:
             # k = (kh*KW + kw)*C + c
             wf = self._pack_frag(W4.permute(0, 2, 3, 1).reshape(N, KH * KW * Cc))

@@ -635,6 +635,9 @@ FLAT_CASES = [
     (1, 5, 200, 256, 256, "silu", True, 0),     # W = 200 (MaskFormer FPN): the 576-row plane instantiation, residual epilogue through LDS
     (1, 7, 160, 64, 64, "relu", False, 0),      # W = 160 (res2): 512-pixel tile, one chunk
     (1, 9, 100, 128, 128, None, False, 16),     # W = 100 (MaskFormer res3), strided input rows, no activation
+    (2, 20, 24, 32, 32, "relu", False, 0),      # 32 input channels (conv3x3_c32.hip): conv1_2 class, several images per 512-pixel tile
+    (1, 5, 320, 32, 64, "relu", False, 0),      # conv1_3 at the benchmark's width, M = 1600 (3 full tiles + a tail)
+    (1, 3, 400, 32, 64, None, False, 32),       # MaskFormer's 400-wide stem: the 1344-row plane, strided input rows, no activation
 ]
 
 
