@@ -59,19 +59,23 @@ __device__ __forceinline__ float c3k_act(float v, std::integral_constant<int, FX
 // HLP: rows per plane (compile time: the k-step offsets are immediates); a launch needs BM + 2W + 2 <= HLP.
 // ABL: ablation / instrumentation switches of scripts/probes/c3_probe.hip (1: ring never refilled, 2: fragments read once,
 //      4: no DMA after the first chunk, 8: no output stores, 16: s_memtime stamps of workgroup 0); 0 in the product.
-template <int TN, int TM, int WN, int WM, int HLP, int ACT, int RESMODE, int ABL = 0>
-__global__ __launch_bounds__((WN* WM + 1) * 64, 1) void conv3x3_kplane_kernel(const C3KArgs p) {
-  constexpr int NW = WN * WM, NT = (NW + 1) * 64, NDW = NW + 1;
+// LD:  1 = loader wave (default).  0 = none: one-chunk layers (C = 64) without a residual have nothing to stream after the first chunk,
+//      which the consumer waves fetch themselves anyway - the workgroup is then WN x WM waves at <= 256 registers and TWO of them
+//      share a CU when their LDS allows (res2's 3x3 layers at W = 160: 2 x 78 KiB), one's halo fetch / stores beside the other's MFMAs.
+template <int TN, int TM, int WN, int WM, int HLP, int ACT, int RESMODE, int ABL = 0, int LD = 1>
+__global__ __launch_bounds__((WN* WM + LD) * 64, LD ? 1 : 2) void conv3x3_kplane_kernel(const C3KArgs p) {
+  constexpr int NW = WN * WM, NT = (NW + LD) * 64, NDW = NW + LD;
+  static_assert(LD == 1 || RESMODE == 0, "the loader-less form has no residual path");
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int KJ = 4, PF = KJ;
   constexpr int PLANE = (HLP + 1) * 16, BUF = 8 * PLANE;
   constexpr int RLT = BN / 8;
-  static_assert(TN <= 2 && HLP % 64 == 0 && 3 * PLANE < 65536, "k-step offsets are 16-bit immediates");
+  static_assert(TN <= 2 && HLP % 32 == 0 && 3 * PLANE < 65536, "k-step offsets are 16-bit immediates");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool is_loader = wave == NW;
+  const bool is_loader = LD && wave == NW;
   const int l32 = lane & 31, half = lane >> 5;
   const int wn = wave % WN, wm = wave / WN;
   const int nNt = p.N / BN;
@@ -85,13 +89,15 @@ __global__ __launch_bounds__((WN* WM + 1) * 64, 1) void conv3x3_kplane_kernel(co
   // chunk cc -> buf: instructions first, first + step, ...; instruction i = (row block i / 8, channel piece i % 8): the eight
   // pieces of a row block are issued back to back, so the 64 lines they share are fetched once
   auto dma_chunk = [&](int cc, unsigned char* buf, int first, int step) {
-    const int ninstr = (p.HLp >> 6) * 8;
+    const int ninstr = ((p.HLp + 63) >> 6) * 8;
     for (int i = first; i < ninstr; i += step) {
       const int blk = i >> 3, c = i & 7;
-      const int f = lo + blk * 64 + lane;
+      const int r = blk * 64 + lane;
+      const int f = lo + r;
       const bool ok = f >= 0 && f < p.M;
       const int pln = (c & 1) * 4 + (c >> 1);   // piece c = channels [8c, 8c+8) = k-step c/2, half c%2
-      pw_dma16(xr, buf + pln * PLANE + blk * 1024, ok ? (unsigned)(f * p.ldx + cc * 64 + c * 8) * 2u : FX_OOB);
+      // (p.HLp is a multiple of 32: the upper half of the last instruction may lie behind the plane - those lanes stay out of it)
+      if (r < p.HLp) pw_dma16(xr, buf + pln * PLANE + blk * 1024, ok ? (unsigned)(f * p.ldx + cc * 64 + c * 8) * 2u : FX_OOB);
     }
   };
   auto dma_res = [&](int first) {   // residual tile -> T
@@ -146,6 +152,7 @@ __global__ __launch_bounds__((WN* WM + 1) * 64, 1) void conv3x3_kplane_kernel(co
     bf16x8 ar[PF][TN];
     unsigned mask9[TM];
     int row0[TM];      // byte address of the lane's piece of pixel block b at tap offset 0, k-step 0, buffer 0
+    if (!LD && wave == 0 && lane < 8) *reinterpret_cast<uint4*>(smem + lane * PLANE + HLP * 16) = make_uint4(0, 0, 0, 0);   // zero rows
     // first the requests with the longest way to go (weights: first touch of this launch, L2 / HBM), then the DMA share of the
     // first chunk; the bias loads and the mask arithmetic below run while both are in flight
     // weights: fragment (n-block, k16 step) = 512 elements; k = tap * C + channel, so the four k-steps of a (tap, chunk)
@@ -376,23 +383,23 @@ __global__ __launch_bounds__((WN* WM + 1) * 64, 1) void conv3x3_kplane_kernel(co
   }
 }
 
-template <int TN, int TM, int WN, int WM, int HLP, int ACT, int RESMODE, int ABL = 0>
+template <int TN, int TM, int WN, int WM, int HLP, int ACT, int RESMODE, int ABL = 0, int LD = 1>
 static int launch_c3k(C3KArgs& a, hipStream_t stream) {
   constexpr int NW = WN * WM, BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int PLANE = (HLP + 1) * 16, BUF = 8 * PLANE;
   const int HL = BM + 2 * a.W + 2;
-  a.HLp = (HL + 63) / 64 * 64;
-  if (a.HLp > HLP || a.C % 64 != 0 || a.N % BN != 0) return FX_ERR_UNSUPPORTED;
+  a.HLp = (HL + 31) / 32 * 32;
+  if (a.HLp > HLP || a.C % 64 != 0 || a.N % BN != 0 || (!LD && a.C != 64)) return FX_ERR_UNSUPPORTED;
   const int halo = (a.C > 64 ? 2 : 1) * BUF, tile = BM * BN * 2;
   const int smem = halo > tile ? halo : tile;
   if (smem > 160 * 1024) return FX_ERR_UNSUPPORTED;
-  auto kern = conv3x3_kplane_kernel<TN, TM, WN, WM, HLP, ACT, RESMODE, ABL>;
+  auto kern = conv3x3_kplane_kernel<TN, TM, WN, WM, HLP, ACT, RESMODE, ABL, LD>;
   static int attr_smem = 0;
   if (smem > attr_smem) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return FX_ERR_RUNTIME;
     attr_smem = smem;
   }
-  hipLaunchKernelGGL(kern, dim3(((a.M + BM - 1) / BM) * (a.N / BN)), dim3((NW + 1) * 64), smem, stream, a);
+  hipLaunchKernelGGL(kern, dim3(((a.M + BM - 1) / BM) * (a.N / BN)), dim3((NW + LD) * 64), smem, stream, a);
   return fx_launch_status();
 }
 
@@ -434,6 +441,13 @@ int fx_launch_conv3x3_kplane(const ConvArgs& c, const bf16_t* w_frag, hipStream_
   a.HW = c.Ho * c.Wo; a.y_bstride = c.y_bstride; a.x_bytes = c.x_bytes; a.r_bytes = c.r_bytes; a.dbg = nullptr;
   const int mode = fx_c3_epilogue_mode(c.act, c.res != nullptr, c.res_after);
   const bool small = c3k_small_m(c.M, c.N, c.W);
+  // res2's 3x3 layers (64 -> 64, one chunk, no residual): 256-pixel tiles on four waves, no loader, two workgroups per CU
+  static const int duo_on = fx_tune("FX_C3K_DUO", 1);
+  if (duo_on && c.N == 64 && c.C == 64 && !c.res && 256 + 2 * c.W + 2 <= 608) {
+    if (mode == 0) return launch_c3k<2, 2, 1, 4, 608, FX_ACT_RELU, 0, 0, 0>(a, stream);
+    if (mode == 1) return launch_c3k<2, 2, 1, 4, 608, FX_ACT_SILU, 0, 0, 0>(a, stream);
+    if (mode == 3) return launch_c3k<2, 2, 1, 4, 608, FX_ACT_NONE, 0, 0, 0>(a, stream);
+  }
 #define FX_C3K_TILE(ACT_, RM_)                                                             \
   {                                                                                        \
     if (small) return launch_c3k<2, 2, 4, 1, 192, ACT_, RM_>(a, stream);                   \
