@@ -173,6 +173,16 @@ def pmc_kernel_prefix(variant: str) -> str:
     m = re.match(r"conv3x3_flat<(\d+)>", variant)
     if m:
         return {"64": "conv3x3_flat_kernel<9,64,1,4,2,2", "128": "conv3x3_flat_kernel<9,64,2,4,2,2", "256": "conv3x3_flat_kernel<9,64,2,4,4,1"}[m.group(1)]
+    m = re.match(r"conv3x3_kplane<(\d+)>", variant)   # tile forms of the N class (the 256-channel tile also serves N = 512; 64-pixel form for small M)
+    if m:
+        return {"64": ("conv3x3_kplane_kernel<2,2,1,4,", "conv3x3_kplane_kernel<2,4,1,4,"), "128": "conv3x3_kplane_kernel<2,4,2,2,"}.get(
+            m.group(1), ("conv3x3_kplane_kernel<2,4,4,1,", "conv3x3_kplane_kernel<2,2,4,1,"))
+    m = re.match(r"conv3x3_c32<(\d+)>", variant)
+    if m:
+        return f"conv3x3_c32_kernel<{int(m.group(1)) // 32},"
+    m = re.match(r"pw_kplane<K(\d+)>", variant)
+    if m:
+        return f"conv_pw_kplane_kernel<{m.group(1)},"
     if variant.startswith("pw_flat"):
         return "conv3x3_flat_kernel<1,256"
     m = re.match(r"pw_chain<(\d+),(\d+),(\d+)>", variant)
@@ -573,7 +583,7 @@ def infer_measure(args, world, rank, local, light=False):
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_hbm_latest.json")))
             key = pmc_kernel_prefix(name)
-            hits = [v for k, v in pmc.items() if key and k.replace(" ", "").startswith(key)]
+            hits = [v for k, v in pmc.items() if key and k.replace(" ", "").startswith(key)]   # key: a prefix or a tuple of prefixes
             if hits:
                 n_ = sum(v["launches"] for v in hits)
                 traffic = round(sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in hits) / n_)

@@ -380,8 +380,20 @@ extern "C" int fx_conv2d_variant(const fx_conv_desc* d, char* out, int cap) {
   const int rc = conv_prepare(d, a);
   if (rc != FX_OK) return rc;
   switch (conv_route(d, a)) {
-    case R_C3_FLAT: snprintf(out, cap, d->C == 32 ? "conv3x3_c32<%d>" : "conv3x3_flat<%d>", d->N); break;
-    case R_PW_FLAT: snprintf(out, cap, "pw_flat<K%d>", d->C); break;
+    case R_C3_FLAT: {   // the same decision fx_launch_conv3x3_flat takes
+      static const int kplane_on = fx_tune("FX_C3_KPLANE", 1);
+      const char* fmt = d->C == 32 ? "conv3x3_c32<%d>" : ((kplane_on && fx_conv3x3_kplane_supported(d->C, d->N, d->W)) ? "conv3x3_kplane<%d>" : "conv3x3_flat<%d>");
+      snprintf(out, cap, fmt, d->N);
+      break;
+    }
+    case R_PW_FLAT: {
+      static const int pwk_on = fx_tune("FX_PW_KPLANE", 1);
+      const int mode = fx_c3_epilogue_mode(d->act, d->residual != nullptr, d->residual_after_act);
+      const bool res_tile = d->residual != nullptr;
+      const bool kp = pwk_on && fx_pw_kplane_supported(d->C, d->N, mode) && d->N * 4 + 128 * d->C * 2 + (res_tile ? 65536 : 0) <= 160 * 1024;
+      snprintf(out, cap, kp ? "pw_kplane<K%d>" : "pw_flat<K%d>", d->C);
+      break;
+    }
     case R_SMALL_M: snprintf(out, cap, "conv_igemm<64,64,256,1stage>"); break;
     case R_DMA: snprintf(out, cap, "conv_igemm_dma<256,%d>", d->N % 256 == 0 ? 256 : 128); break;
     case R_POOL: snprintf(out, cap, "conv_igemm<128,128,64,pool>"); break;

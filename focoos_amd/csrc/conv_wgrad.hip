@@ -43,6 +43,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* base) {
   return __builtin_bit_cast(bf16x8, v);
 }
 
+// PW: 1x1 / stride 1 / pad 0 - the pixel IS the input row: no im2col arithmetic at all (round 3: the generic form spent ~25 VALU instructions
+// per staged row on two divisions and the tap bounds - more issue time than the step's MFMAs; SQ counters: MFMA busy 12 %).
+template <bool PW>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * WG_TILE];  // [stage][dZ tile | X tile]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -86,18 +89,52 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
     q += ((q + 1) * d <= m);
     return q;
   };
-  auto load = [&](uint4* rz, uint4* rx, int mbase) {
+  // Generic form: (image, output row, output column) of this thread's WG_LD staged rows, carried from step to step (every row advances
+  // by WG_BP pixels per step: add the quotient / remainder of WG_BP by Wo, one carry into the row, one into the image) instead of two
+  // divisions per row and step.
+  int pb[WG_LD], pho[WG_LD], pwo[WG_LD];
+  const int q64 = WG_BP / p.Wo, r64 = WG_BP - q64 * p.Wo;
+  const bool carried = WG_BP < HoWo;   // images smaller than a step (tiny test shapes): the divisions stay
+  if constexpr (!PW) {
+#pragma unroll
+    for (int i = 0; i < WG_LD; ++i) {
+      const int m = m_lo + r0 + 16 * i;
+      pb[i] = fdiv(m, HoWo, inv_howo);
+      const int rem = m - pb[i] * HoWo;
+      pho[i] = fdiv(rem, p.Wo, inv_wo);
+      pwo[i] = rem - pho[i] * p.Wo;
+    }
+  }
+  auto load = [&](uint4* rz, uint4* rx, int mbase) {   // called with mbase = m_lo, m_lo + WG_BP, ... in order: the carried state is that of mbase
 #pragma unroll
     for (int i = 0; i < WG_LD; ++i) {
       const int m = mbase + r0 + 16 * i;
       const bool ok = m < m_hi;
       rz[i] = buf_load16(zr, (ok && n_ok) ? ((unsigned)m * (unsigned)p.lddz + nch) * 2u : FX_OOB);
-      const int mm = ok ? m : 0;
-      const int b = fdiv(mm, HoWo, inv_howo), rem = mm - b * HoWo;
-      const int ho = fdiv(rem, p.Wo, inv_wo), wo = rem - ho * p.Wo;
-      const int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;
-      const bool in = ok && kc_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-      rx[i] = buf_load16(xr, in ? ((unsigned)((b * p.H + hi) * p.W + wi) * (unsigned)p.ldx + cch) * 2u : FX_OOB);
+      if constexpr (PW) {
+        rx[i] = buf_load16(xr, (ok && kc_ok) ? ((unsigned)m * (unsigned)p.ldx + kc) * 2u : FX_OOB);
+      } else {
+        if (!carried) {
+          const int mm = ok ? m : 0;
+          pb[i] = fdiv(mm, HoWo, inv_howo);
+          const int rem = mm - pb[i] * HoWo;
+          pho[i] = fdiv(rem, p.Wo, inv_wo);
+          pwo[i] = rem - pho[i] * p.Wo;
+        }
+        const int hi = pho[i] * p.stride - p.pad + kh, wi = pwo[i] * p.stride - p.pad + kw;
+        const bool in = ok && kc_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+        rx[i] = buf_load16(xr, in ? ((unsigned)((pb[i] * p.H + hi) * p.W + wi) * (unsigned)p.ldx + cch) * 2u : FX_OOB);
+        // advance to the same row of the next step
+        int wo = pwo[i] + r64, ho = pho[i] + q64;
+        const bool cw = wo >= p.Wo;
+        wo -= cw ? p.Wo : 0;
+        ho += cw ? 1 : 0;
+        const bool ch = ho >= p.Ho;      // carried: WG_BP < Ho * Wo, at most one carry into the image index
+        ho -= ch ? p.Ho : 0;
+        pb[i] += ch ? 1 : 0;
+        pwo[i] = wo;
+        pho[i] = ho;
+      }
     }
   };
   auto store = [&](const uint4* rz, const uint4* rx, int s) {
@@ -206,8 +243,8 @@ extern "C" int fx_conv2d_wgrad_nhwc_bf16(const void* x, int ldx, const void* dz,
 }
 
 // pixel split of one launch: enough workgroups to fill the chip `occ` times over, chunks a multiple of the K-step
-static void wgrad_split(int M, int tiles, int occ, int* mchunk_out, int* splits_out) {
-  int want = (256 * occ + tiles - 1) / tiles;
+static void wgrad_split(int M, int tiles, int wgs, int* mchunk_out, int* splits_out) {
+  int want = (wgs + tiles - 1) / tiles;
   int mchunk = (M + want - 1) / want;
   if (mchunk < 512) mchunk = 512;
   mchunk = (mchunk + WG_BP - 1) / WG_BP * WG_BP;
@@ -243,11 +280,16 @@ static int wgrad_launch(const void* x, int ldx, const void* dz, int lddz, float*
   // atomics: every split adds one full pass of fp32 atomics over dW, and the L2 atomic units sustain only ~0.6 TB/s - few splits.
   // partial stores: plain coalesced stores (summed later by fx_unpack_conv_wgrad_sum_f32) - more splits, more parallelism.
   int S;
-  wgrad_split(a.M, tiles, split_stride ? 4 : 2, &a.mchunk, &S);
+  // workgroups the partial-slab form aims for: fewer pixel splits = fewer fp32 slabs to write and sum, and the weight gradients run
+  // beside the input-gradient chain, which fills the rest of the chip
+  static const int wgs_split = fx_tune("FX_WGRAD_WGS", 256);
+  wgrad_split(a.M, tiles, split_stride ? wgs_split : 512, &a.mchunk, &S);
   FX_CHECK_ARG(!split_stride || (S == expect_splits && split_stride >= (long long)N * a.Ktot));
   a.split_stride = split_stride;
   a.tiles = tiles;
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(tiles * S), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), a);
+  const bool pw = KH == 1 && KW == 1 && stride == 1 && pad == 0;
+  if (pw) hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(tiles * S), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), a);
+  else hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(tiles * S), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), a);
   return fx_launch_status();
 }
 
@@ -259,7 +301,8 @@ extern "C" int fx_conv2d_wgrad_bias_nhwc_bf16(const void* x, int ldx, const void
 extern "C" int fx_conv2d_wgrad_splits(int B, int Ho, int Wo, int C, int N, int KH, int KW) {
   if (B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || N <= 0 || KH <= 0 || KW <= 0) return 0;
   int mchunk, S;
-  wgrad_split(B * Ho * Wo, ((N + 127) / 128) * ((KH * KW * C + 127) / 128), 4, &mchunk, &S);
+  static const int wgs_split = fx_tune("FX_WGRAD_WGS", 256);
+  wgrad_split(B * Ho * Wo, ((N + 127) / 128) * ((KH * KW * C + 127) / 128), wgs_split, &mchunk, &S);
   return S;
 }
 

@@ -269,21 +269,21 @@ def test_conv_routing_labels(lib_path, monkeypatch):
         rc = lib.fx_conv2d_variant(C.byref(d), buf, 64)
         return buf.value.decode() if rc == 0 else rc
 
-    assert label(16, 40, 40, 256, 256, 3) == "conv3x3_flat<256>"            # M = 25 600: a 16-image part's 40x40 level
-    assert label(8, 40, 40, 256, 256, 3) == "conv3x3_flat<256>"               # M = 12 800 >= 5 000
+    assert label(16, 40, 40, 256, 256, 3) == "conv3x3_kplane<256>"            # M = 25 600: a 16-image part's 40x40 level
+    assert label(8, 40, 40, 256, 256, 3) == "conv3x3_kplane<256>"               # M = 12 800 >= 5 000
     assert label(2, 40, 40, 256, 256, 3) == "conv_igemm<128,128,64>"          # M = 3 200 < 5 000
     assert label(16, 80, 80, 256, 256, 3, frag=False) == "conv_igemm_dma<256,256>"   # no fragment copy: implicit GEMM (DMA tiles from 40 000 pixels)
     assert label(16, 40, 40, 256, 256, 3, out_f32=1).startswith("conv_igemm")   # fp32 pre-BatchNorm output: not on the halo kernel
     assert label(16, 40, 40, 1024, 256, 1) == "pw_flat<K1024>"
-    assert label(16, 20, 20, 512, 512, 3) == "conv3x3_flat<512>"               # res5 branch2b of a 16-image part: two 256-channel tiles per pixel tile
-    assert label(16, 20, 20, 512, 2048, 1) == "pw_flat<K512>"                  # M = 6400 >= 5000: res5 branch2c of a 16-image part
+    assert label(16, 20, 20, 512, 512, 3) == "conv3x3_kplane<512>"               # res5 branch2b of a 16-image part: two 256-channel tiles per pixel tile
+    assert label(16, 20, 20, 512, 2048, 1) == "pw_kplane<K512>"                  # M = 6400 >= 5000: res5 branch2c of a 16-image part
     assert label(4, 20, 20, 256, 1024, 1) == "conv_igemm<64,64,256,1stage>"    # small M, K <= 1024
     assert label(16, 160, 160, 64, 256, 1, frag=False) == "conv_igemm<128,128,32>"
     assert label(16, 320, 320, 32, 32, 3, frag=False) == "conv_igemm<128,32,32>"
     assert label(16, 160, 160, 256, 512, 1, pool2=1, frag=False) == "conv_igemm<128,128,64,pool>"
     assert label(16, 40, 40, 250, 256, 3) == -1                                # C % 32 != 0: FX_ERR_INVALID_ARG, as the launch would return
     monkeypatch.setenv("FX_CONV3_MIN_M", "0")
-    assert label(2, 16, 16, 64, 64, 3) == "conv3x3_flat<64>"                   # the kernel tests' lowered threshold
+    assert label(2, 16, 16, 64, 64, 3) == "conv3x3_kplane<64>"                   # the kernel tests' lowered threshold
 
 
 def test_pack_entry_blocks(lib_path):
