@@ -194,6 +194,170 @@ __global__ __launch_bounds__(256) void msda_f32_bwd_kernel(const VT* __restrict_
   }
 }
 
+// ---- the backward without L2 atomics (fx_msda_train_bwd_slab): two kernels.
+// (1) msda_point_grad_kernel: grad_loc / grad_attn in the FORWARD's lane layout (lane = head x 4 channels, 8-byte value loads) - the
+//     atomic form above needs lane = channel so that an atomic covers whole lines, and pays for it with 2-byte gathers (148 us of its
+//     304 us per layer are gathers); without the atomics the gathers cost what the forward's do.
+// (2) msda_bwd_value_kernel: the value gradient by BINNING.  A workgroup owns (batch, head, slab of whole rows of one level, at most
+//     MS_PIX pixels).  It computes the taps of all Q*P sampling points of its (batch, head, level) twice: once to count the taps per
+//     pixel (LDS integer atomics), then - after an exclusive scan of the counts - to file every tap (query, weight) under its pixel.
+//     Each half-wave then sums the entries of one pixel at a time (lane = channel; grad_out rows staged in LDS) and stores the pixel
+//     once, as bf16 - the dtype the value projection's backward reads - so the shared gradient buffer needs no zero-fill, no fp32
+//     image and no cast, and there is no floating-point atomic anywhere.  (First attempt, kept in profiles/r03_msda_bwd.txt: the same
+//     slabs with ds_add_f32 accumulation - 580 us per layer, 377 us of it the LDS float atomics at ~3 cycles per lane.)
+constexpr int MS_PIX = 3200;   // pixels per slab: level 80 x 80 = two slabs -> 4 slabs x 128 (batch, head) = 512 workgroups = 2 per CU
+constexpr int MS_MAXL = 8;
+
+struct MsdaBinArgs {
+  int L, P, B, S, Q, M, ldg;
+  int H[MS_MAXL], W[MS_MAXL], start[MS_MAXL], rows[MS_MAXL], slab0[MS_MAXL + 1];
+};
+
+__device__ __forceinline__ float msda_go1(const float* p) { return *p; }
+__device__ __forceinline__ float msda_go1(const bf16_t* p) { return bf16_to_f32(*p); }
+
+template <typename VT, typename GT>
+__global__ __launch_bounds__(256) void msda_point_grad_kernel(const VT* __restrict__ value, int ldv, const int32_t* __restrict__ shapes,
+                                                               const int32_t* __restrict__ lstart, int L, int P, const float* __restrict__ loc,
+                                                               const float* __restrict__ attn, const GT* __restrict__ grad_out,
+                                                               float* __restrict__ grad_loc, float* __restrict__ grad_attn, int B, int S, int Q, int M) {
+  const int lane = threadIdx.x & 63;
+  const int unit = blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per (batch, query, level)
+  const int bq = unit / L;
+  if (bq >= B * Q) return;
+  const int l = unit - bq * L;
+  const int b = bq / Q;
+  const int h = lane >> 3, cg = lane & 7;
+  const int LP = L * P, CH = M * 32;
+  float go[4];
+  msda_ld4(grad_out + (int64_t)bq * CH + h * 32 + cg * 4, go);
+  const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
+  const int64_t lbase = ((int64_t)b * S + lstart[l]) * ldv + h * 32 + cg * 4;
+  const int64_t pbase = ((int64_t)bq * M + h) * LP + l * P;
+  for (int pt = 0; pt < P; ++pt) {
+    const float aw = attn[pbase + pt];
+    const Tap4 t = make_taps(loc[2 * (pbase + pt)], loc[2 * (pbase + pt) + 1], Hl, Wl);
+    float v[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (t.idx[k] >= 0) {
+        msda_ld4(value + lbase + (int64_t)t.idx[k] * ldv, v[k]);
+      } else {
+        v[k][0] = v[k][1] = v[k][2] = v[k][3] = 0.f;
+      }
+    }
+    float g_a = 0.f, g_x = 0.f, g_y = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      g_a += go[c] * (t.w[0] * v[0][c] + t.w[1] * v[1][c] + t.w[2] * v[2][c] + t.w[3] * v[3][c]);
+      g_x += go[c] * ((v[1][c] - v[0][c]) * (1.f - t.ty) + (v[3][c] - v[2][c]) * t.ty);
+      g_y += go[c] * ((v[2][c] - v[0][c]) * (1.f - t.tx) + (v[3][c] - v[1][c]) * t.tx);
+    }
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      g_a += __shfl_xor(g_a, o, 64);
+      g_x += __shfl_xor(g_x, o, 64);
+      g_y += __shfl_xor(g_y, o, 64);
+    }
+    if (cg == 0) {
+      grad_attn[pbase + pt] = g_a;
+      grad_loc[2 * (pbase + pt) + 0] = aw * g_x * (float)Wl;   // d(ix)/d(loc_x) = W, d(iy)/d(loc_y) = H
+      grad_loc[2 * (pbase + pt) + 1] = aw * g_y * (float)Hl;
+    }
+  }
+}
+
+template <typename GT>
+__global__ __launch_bounds__(512) void msda_bwd_value_kernel(MsdaBinArgs a, const float* __restrict__ loc, const float* __restrict__ attn,
+                                                             const GT* __restrict__ grad_out, bf16_t* __restrict__ gv) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char ms_smem[];
+  int* cnt = reinterpret_cast<int*>(ms_smem);                              // [MS_PIX]: tap count -> start offset -> end offset per pixel
+  int* wsum = cnt + MS_PIX;                                                // [8] wave totals of the scan
+  uint2* ent = reinterpret_cast<uint2*>(wsum + 8);                         // [Q*P*4]: (query, weight bits), filed by pixel
+  GT* goL = reinterpret_cast<GT*>(ent + (size_t)a.Q * a.P * 4);            // [Q][32]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slab = blockIdx.x, b = blockIdx.y / a.M, h = blockIdx.y - b * a.M;
+  int l = 0;
+  while (l + 1 < a.L && slab >= a.slab0[l + 1]) ++l;
+  const int Hl = a.H[l], Wl = a.W[l];
+  const int r0 = (slab - a.slab0[l]) * a.rows[l];
+  const int r1 = r0 + a.rows[l] < Hl ? r0 + a.rows[l] : Hl;
+  const int p0 = r0 * Wl, np = (r1 - r0) * Wl;
+  const int P = a.P, LP = a.L * P, CH = a.M * 32, NPT = a.Q * P;
+  // grad_out rows of this (batch, head): 4 channels per thread and load
+  for (int i = tid; i < a.Q * 8; i += 512) {
+    const GT* src = grad_out + ((int64_t)b * a.Q + (i >> 3)) * CH + h * 32 + (i & 7) * 4;
+    if (sizeof(GT) == 2) reinterpret_cast<uint2*>(goL)[i] = *reinterpret_cast<const uint2*>(src);
+    else reinterpret_cast<float4*>(goL)[i] = *reinterpret_cast<const float4*>(src);
+  }
+  for (int i = tid; i < np; i += 512) cnt[i] = 0;
+  __syncthreads();
+  // pass 1: taps per pixel
+  for (int i = tid; i < NPT; i += 512) {
+    const int q = i / P, pt = i - q * P;
+    const int64_t pidx = (((int64_t)b * a.Q + q) * a.M + h) * LP + l * P + pt;
+    const float2 xy = *reinterpret_cast<const float2*>(loc + 2 * pidx);
+    const Tap4 t = make_taps(xy.x, xy.y, Hl, Wl);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = t.idx[k] - p0;
+      if (t.idx[k] >= 0 && (unsigned)r < (unsigned)np) atomicAdd(cnt + r, 1);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of cnt[0, np): a run of consecutive pixels per thread, wave scan of the run totals, wave totals through LDS
+  {
+    const int run = (np + 511) / 512;
+    const int i0 = tid * run, i1 = i0 + run < np ? i0 + run : np;
+    int tot = 0;
+    for (int i = i0; i < i1; ++i) tot += cnt[i];
+    int inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(inc, o, 64);
+      if (lane >= o) inc += up;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = inc - tot;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    for (int i = i0; i < i1; ++i) {
+      const int n = cnt[i];
+      cnt[i] = base;
+      base += n;
+    }
+  }
+  __syncthreads();
+  // pass 2: file every tap under its pixel (the returning atomic advances the pixel's cursor: afterwards cnt[p] = END of pixel p)
+  for (int i = tid; i < NPT; i += 512) {
+    const int q = i / P, pt = i - q * P;
+    const int64_t pidx = (((int64_t)b * a.Q + q) * a.M + h) * LP + l * P + pt;
+    const float2 xy = *reinterpret_cast<const float2*>(loc + 2 * pidx);
+    const float aw = attn[pidx];
+    const Tap4 t = make_taps(xy.x, xy.y, Hl, Wl);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int r = t.idx[k] - p0;
+      if (t.idx[k] >= 0 && (unsigned)r < (unsigned)np) {
+        const int slot = atomicAdd(cnt + r, 1);
+        ent[slot] = make_uint2((unsigned)q, __float_as_uint(aw * t.w[k]));
+      }
+    }
+  }
+  __syncthreads();
+  // sum per pixel: half-wave = pixel, lane = channel
+  const int hw = tid >> 5, c = tid & 31;
+  for (int p = hw; p < np; p += 16) {
+    const int s = p ? cnt[p - 1] : 0, e = cnt[p];
+    float acc = 0.f;
+    for (int j = s; j < e; ++j) {
+      const uint2 en = ent[j];
+      acc += __uint_as_float(en.y) * msda_go1(goL + en.x * 32 + c);
+    }
+    gv[((int64_t)b * a.S + a.start[l] + p0 + p) * a.ldg + h * 32 + c] = f32_to_bf16(acc);
+  }
+}
+
 // value: fp32 or bf16 (value_bf16), row stride ldv elements (>= M*32; a column slice of a wider buffer is fine), 16-byte (fp32) /
 // 8-byte (bf16) aligned rows.  grad_value: fp32, row stride ldg; zeroed here unless zero_grad_value == 0 (several launches accumulating
 // into column slices of one buffer zero it once, themselves).
@@ -232,6 +396,66 @@ extern "C" int fx_msda_train_bwd(const void* value, int value_bf16, int ldv, con
   else
     hipLaunchKernelGGL(msda_f32_bwd_kernel<float>, grid, dim3(256), 0, stream, (const float*)value, ldv, spatial_shapes, level_start, L, P, loc, attn,
                        grad_out, grad_value, ldg, grad_loc, grad_attn, B, S, Q, M, lsplit, psplit);
+  return fx_launch_status();
+}
+
+// The same backward without floating-point atomics (kernels above): grad_value_bf16 [B,S,ldg] bf16 - the M*32 columns of this layer are
+// fully overwritten (no zero-fill needed, nothing accumulated across calls).  grad_out fp32 or bf16 (grad_out_bf16).  shapes_host: the
+// L (H, W) pairs on the host (the slab grid is sized from them).  FX_ERR_UNSUPPORTED when a level is wider than MS_PIX pixels or the
+// taps of Q*P points do not fit the LDS (fx_msda_bwd_slab_supported tells beforehand).
+static int msda_slab_smem(int P, int Q, int go_bf16) { return (MS_PIX + 8) * 4 + Q * P * 4 * 8 + Q * 32 * (go_bf16 ? 2 : 4); }
+
+extern "C" int fx_msda_bwd_slab_supported(const int32_t* shapes_host, int L, int P, int Q, int M, int grad_out_bf16) {
+  if (!shapes_host || M != 8 || L < 1 || L > MS_MAXL || P < 1 || Q < 1 || Q >= (1 << 24)) return 0;
+  for (int l = 0; l < L; ++l)
+    if (shapes_host[2 * l] < 1 || shapes_host[2 * l + 1] < 1 || shapes_host[2 * l + 1] > MS_PIX) return 0;
+  return msda_slab_smem(P, Q, grad_out_bf16) <= 160 * 1024 ? 1 : 0;
+}
+
+extern "C" int fx_msda_train_bwd_slab(const void* value, int value_bf16, int ldv, const int32_t* spatial_shapes, const int32_t* level_start,
+                                      const int32_t* shapes_host, int L, int P, const float* loc, const float* attn, const void* grad_out,
+                                      int grad_out_bf16, void* grad_value_bf16, int ldg, float* grad_loc, float* grad_attn, int B, int S, int Q,
+                                      int M, fx_stream_t stream_) {
+  FX_CHECK_ARG(value && spatial_shapes && level_start && shapes_host && loc && attn && grad_out && grad_value_bf16 && grad_loc && grad_attn);
+  FX_CHECK_ARG(B > 0 && S > 0 && Q > 0 && L > 0 && P > 0);
+  if (!fx_msda_bwd_slab_supported(shapes_host, L, P, Q, M, grad_out_bf16)) return FX_ERR_UNSUPPORTED;
+  FX_CHECK_ARG(ldv >= M * 32 && ldv % 4 == 0 && ((uintptr_t)value % (value_bf16 ? 8 : 16)) == 0);
+  FX_CHECK_ARG(ldg >= M * 32 && ((uintptr_t)grad_value_bf16 % 2) == 0 && ((uintptr_t)grad_out % (grad_out_bf16 ? 8 : 16)) == 0);
+  MsdaBinArgs a;
+  a.L = L; a.P = P; a.B = B; a.S = S; a.Q = Q; a.M = M; a.ldg = ldg;
+  int start = 0, slabs = 0;
+  for (int l = 0; l < MS_MAXL; ++l) {
+    if (l < L) {
+      const int H = shapes_host[2 * l], W = shapes_host[2 * l + 1];
+      a.H[l] = H; a.W[l] = W; a.start[l] = start; a.rows[l] = MS_PIX / W < H ? MS_PIX / W : H; a.slab0[l] = slabs;
+      start += H * W;
+      slabs += (H + a.rows[l] - 1) / a.rows[l];
+    } else {
+      a.H[l] = a.W[l] = a.start[l] = a.rows[l] = 0; a.slab0[l] = slabs;
+    }
+  }
+  a.slab0[MS_MAXL] = slabs;
+  FX_CHECK_ARG(start == S);
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const dim3 grid((B * Q * L + 3) / 4);
+#define FX_MSDA_PG(VT_, GT_)                                                                                                                   \
+  hipLaunchKernelGGL((msda_point_grad_kernel<VT_, GT_>), grid, dim3(256), 0, stream, (const VT_*)value, ldv, spatial_shapes, level_start, L, P, \
+                     loc, attn, (const GT_*)grad_out, grad_loc, grad_attn, B, S, Q, M)
+  if (value_bf16 && grad_out_bf16) FX_MSDA_PG(bf16_t, bf16_t);
+  else if (value_bf16) FX_MSDA_PG(bf16_t, float);
+  else if (grad_out_bf16) FX_MSDA_PG(float, bf16_t);
+  else FX_MSDA_PG(float, float);
+#undef FX_MSDA_PG
+  const int smem = msda_slab_smem(P, Q, grad_out_bf16);
+  static int attr_smem[2] = {0, 0};
+  const void* kern = grad_out_bf16 ? reinterpret_cast<const void*>(msda_bwd_value_kernel<bf16_t>) : reinterpret_cast<const void*>(msda_bwd_value_kernel<float>);
+  if (smem > attr_smem[grad_out_bf16 ? 1 : 0]) {
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return FX_ERR_RUNTIME;
+    attr_smem[grad_out_bf16 ? 1 : 0] = smem;
+  }
+  bf16_t* gv = reinterpret_cast<bf16_t*>(grad_value_bf16);
+  if (grad_out_bf16) hipLaunchKernelGGL(msda_bwd_value_kernel<bf16_t>, dim3(slabs, B * M), dim3(512), smem, stream, a, loc, attn, (const bf16_t*)grad_out, gv);
+  else hipLaunchKernelGGL(msda_bwd_value_kernel<float>, dim3(slabs, B * M), dim3(512), smem, stream, a, loc, attn, (const float*)grad_out, gv);
   return fx_launch_status();
 }
 

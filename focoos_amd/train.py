@@ -11,8 +11,10 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Iterable, List, Optional, Sequence, Tuple
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -65,7 +67,7 @@ class _MSDAGroupFunction(torch.autograd.Function):
     """ms_deform_attn_core on slice ``g`` of a shared bf16 value tensor [B,S,G*M*32] (fx_msda_train_fwd / _bwd)."""
 
     @staticmethod
-    def forward(ctx, value_all, sink: ValueGradSink, g: int, shapes_t, starts_t, loc, attn):
+    def forward(ctx, value_all, sink: ValueGradSink, g: int, shapes_t, starts_t, loc, attn, shapes_host=None):
         lib = _lib.load()
         B, S, Nt = value_all.shape
         M, D = 8, 32
@@ -77,6 +79,7 @@ class _MSDAGroupFunction(torch.autograd.Function):
                                     aw.data_ptr(), out.data_ptr(), B, S, Q, M, _stream(value_all.device)), "fx_msda_train_fwd")
         ctx.save_for_backward(value_all, shapes_t, starts_t, lc, aw)
         ctx.sink, ctx.g, ctx.dims = sink, g, (B, S, Q, M, D, L, P, Nt)
+        ctx.shapes_host = shapes_host
         ctx.in_dtypes = (loc.dtype, attn.dtype)
         return out.to(torch.bfloat16)
 
@@ -86,20 +89,32 @@ class _MSDAGroupFunction(torch.autograd.Function):
         value_all, shapes_t, starts_t, lc, aw = ctx.saved_tensors
         B, S, Q, M, D, L, P, Nt = ctx.dims
         sink, g = ctx.sink, ctx.g
-        go = grad_out.float().contiguous()
-        if sink.buf is None:
-            sink.buf = torch.zeros(B, S, Nt, dtype=torch.float32, device=value_all.device)
+        sh = ctx.shapes_host
+        go_bf16 = grad_out.dtype == torch.bfloat16
+        slab = (sh is not None and os.environ.get("FX_MSDA_BWD_SLAB", "1") != "0"
+                and lib.fx_msda_bwd_slab_supported(sh.ctypes.data, L, P, Q, M, int(go_bf16)) == 1)
         gl, ga = torch.empty_like(lc), torch.empty_like(aw)
-        check(lib.fx_msda_train_bwd(value_all.data_ptr() + g * M * D * 2, 1, Nt, shapes_t.data_ptr(), starts_t.data_ptr(), L, P, lc.data_ptr(),
-                                    aw.data_ptr(), go.data_ptr(), sink.buf.data_ptr() + g * M * D * 4, Nt, 0, gl.data_ptr(), ga.data_ptr(), B, S, Q, M,
-                                    _stream(value_all.device)), "fx_msda_train_bwd")
+        if slab:
+            go = grad_out.contiguous() if go_bf16 else grad_out.float().contiguous()
+            if sink.buf is None:   # every layer overwrites its 256 columns: no zero-fill, no fp32 image, no cast
+                sink.buf = torch.empty(B, S, Nt, dtype=torch.bfloat16, device=value_all.device)
+            check(lib.fx_msda_train_bwd_slab(value_all.data_ptr() + g * M * D * 2, 1, Nt, shapes_t.data_ptr(), starts_t.data_ptr(), sh.ctypes.data, L, P,
+                                             lc.data_ptr(), aw.data_ptr(), go.data_ptr(), int(go_bf16), sink.buf.data_ptr() + g * M * D * 2, Nt,
+                                             gl.data_ptr(), ga.data_ptr(), B, S, Q, M, _stream(value_all.device)), "fx_msda_train_bwd_slab")
+        else:
+            go = grad_out.float().contiguous()
+            if sink.buf is None:
+                sink.buf = torch.zeros(B, S, Nt, dtype=torch.float32, device=value_all.device)
+            check(lib.fx_msda_train_bwd(value_all.data_ptr() + g * M * D * 2, 1, Nt, shapes_t.data_ptr(), starts_t.data_ptr(), L, P, lc.data_ptr(),
+                                        aw.data_ptr(), go.data_ptr(), sink.buf.data_ptr() + g * M * D * 4, Nt, 0, gl.data_ptr(), ga.data_ptr(), B, S, Q, M,
+                                        _stream(value_all.device)), "fx_msda_train_bwd")
         sink.count += 1
         gv = None
-        if sink.count == sink.G:   # every layer has accumulated its slice
-            gv = sink.buf.to(torch.bfloat16)
+        if sink.count == sink.G:   # every layer has delivered its slice
+            gv = sink.buf if sink.buf.dtype == torch.bfloat16 else sink.buf.to(torch.bfloat16)
             sink.buf, sink.count = None, 0
         d1, d2 = ctx.in_dtypes
-        return gv, None, None, None, None, gl.to(d1), ga.to(d2)
+        return gv, None, None, None, None, gl.to(d1), ga.to(d2), None
 
 
 def ms_deform_attn_grouped(value_all: torch.Tensor, sink: ValueGradSink, g: int, value_spatial_shapes, sampling_locations: torch.Tensor,
@@ -107,7 +122,19 @@ def ms_deform_attn_grouped(value_all: torch.Tensor, sink: ValueGradSink, g: int,
     """ms_deform_attn_core for layer ``g`` of G layers whose value projections were computed together: value_all bf16 [B,S,G*256]; returns
     bf16 [B,Q,256].  All G layers must take part in a backward pass (the last one to run delivers the value gradient)."""
     st, ss = _shape_tensors(value_spatial_shapes, value_all.device)
-    return _MSDAGroupFunction.apply(value_all, sink, g, st, ss, sampling_locations, attention_weights)
+    return _MSDAGroupFunction.apply(value_all, sink, g, st, ss, sampling_locations, attention_weights, _shape_host(value_spatial_shapes))
+
+
+def _shape_host(value_spatial_shapes) -> np.ndarray:
+    key = tuple((int(h), int(w)) for h, w in value_spatial_shapes)
+    if key not in _SHAPE_HOST:
+        _SHAPE_HOST[key] = np.ascontiguousarray(np.array(key, dtype=np.int32).reshape(-1))
+    return _SHAPE_HOST[key]
+
+
+_SHAPE_HOST: Dict = {}
+# value gradient of the grouped form by binning in LDS (fx_msda_train_bwd_slab: no floating-point atomics, bf16 out) wherever
+# fx_msda_bwd_slab_supported says the shapes fit; FX_MSDA_BWD_SLAB=0 keeps the fp32-atomic form (fx_msda_train_bwd) for A/B runs.
 
 
 def _shape_tensors(value_spatial_shapes, dev):

@@ -419,6 +419,18 @@ int fx_msda_train_fwd(const void* value, int value_bf16, int ldv, const int32_t*
 int fx_msda_train_bwd(const void* value, int value_bf16, int ldv, const int32_t* spatial_shapes, const int32_t* level_start, int L, int P,
                       const float* loc, const float* attn, const float* grad_out, float* grad_value, int ldg, int zero_grad_value,
                       float* grad_loc, float* grad_attn, int B, int S, int Q, int M, fx_stream_t stream);
+/* fx_msda_train_bwd without floating-point atomics: grad_loc / grad_attn by one kernel in the forward's lane layout, the value gradient
+ * by binning - a workgroup per (batch, head, slab of rows of one level) files the taps of all Q*P sampling points under their pixels in
+ * LDS and sums them pixel by pixel - stored once, as bf16 (the dtype the value projection's backward reads): grad_value_bf16 [B,S,ldg],
+ * this layer's M*32 columns fully overwritten - no zero-fill, no accumulation across calls.  grad_out fp32 or bf16 (grad_out_bf16).
+ * shapes_host = the L (H, W) pairs in host memory; spatial_shapes / level_start as above (device).  fx_msda_bwd_slab_supported: 1 iff
+ * the shapes are covered (every W <= 3200, the Q*P*4 taps + Q grad_out rows fit the 160 KiB LDS); else the call returns
+ * FX_ERR_UNSUPPORTED and the caller keeps fx_msda_train_bwd. */
+int fx_msda_bwd_slab_supported(const int32_t* shapes_host, int L, int P, int Q, int M, int grad_out_bf16);
+int fx_msda_train_bwd_slab(const void* value, int value_bf16, int ldv, const int32_t* spatial_shapes, const int32_t* level_start,
+                           const int32_t* shapes_host, int L, int P, const float* loc, const float* attn, const void* grad_out,
+                           int grad_out_bf16, void* grad_value_bf16, int ldg, float* grad_loc, float* grad_attn, int B, int S, int Q, int M,
+                           fx_stream_t stream);
 
 /* Fused multi-tensor AdamW + global-norm gradient clipping over one flat fp32 buffer (replaces the
  * ~500 single-tensor param groups of focoos/trainer/solver/build.py:39-138 and the clip of :29-36 / trainer.py:758-760).

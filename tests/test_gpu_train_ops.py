@@ -87,32 +87,43 @@ def test_box_refine_forward_backward_vs_torch_autograd():
     assert torch.equal(dg2.grad, dg.grad)
 
 
-def test_grouped_msda_matches_the_per_layer_function():
-    """ms_deform_attn_grouped (G layers reading column slices of one bf16 value tensor, value gradient accumulated into slices of one
-    fp32 buffer and delivered by the last layer to run: fx_msda_train_fwd / _bwd) vs ms_deform_attn_core on the same bf16-rounded values,
-    layer by layer: identical forward (same kernel code, typed loads), gradients equal up to the order of the fp32 atomics."""
+@pytest.mark.parametrize("slab", ["1", "0"])
+@pytest.mark.parametrize("shapes,Q", [(MSDA_SHAPES, 40), ([[80, 80], [40, 40], [20, 20]], 300), ([[3, 400], [7, 9]], 161)])
+def test_grouped_msda_matches_the_per_layer_function(shapes, Q, slab, monkeypatch):
+    """ms_deform_attn_grouped (G layers reading column slices of one bf16 value tensor, value gradients delivered together by the last
+    layer to run) vs ms_deform_attn_core on the same bf16-rounded values, layer by layer: identical forward (same kernel code, typed
+    loads), identical location / weight gradients, value gradient equal up to the order of the fp32 additions and the bf16 rounding of
+    the delivered tensor.  Both forms of the value gradient: LDS slabs (fx_msda_train_bwd_slab: several slabs per level, more queries
+    than one staging pass, sampling points outside the map) and fp32 L2 atomics (fx_msda_train_bwd)."""
     from focoos_amd.train import ValueGradSink, ms_deform_attn_grouped
 
-    G, B, Q = 3, 2, 40
-    S = sum(h * w for h, w in MSDA_SHAPES)
+    monkeypatch.setenv("FX_MSDA_BWD_SLAB", slab)
+    G, B = 3, 2
+    S = sum(h * w for h, w in shapes)
     g = torch.Generator().manual_seed(8)
     value_all = torch.randn(B, S, G * 256, generator=g).bfloat16().to(DEV).requires_grad_()
-    locs = [torch.rand(B, Q, 8, len(MSDA_SHAPES), 4, 2, generator=g).to(DEV).requires_grad_() for _ in range(G)]
-    aws = [torch.softmax(torch.randn(B, Q, 8, len(MSDA_SHAPES) * 4, generator=g), -1).view(B, Q, 8, len(MSDA_SHAPES), 4).to(DEV).requires_grad_() for _ in range(G)]
+    locs = [(torch.rand(B, Q, 8, len(shapes), 4, 2, generator=g) * 1.2 - 0.1).to(DEV).requires_grad_() for _ in range(G)]
+    aws = [torch.softmax(torch.randn(B, Q, 8, len(shapes) * 4, generator=g), -1).view(B, Q, 8, len(shapes), 4).to(DEV).requires_grad_() for _ in range(G)]
     gos = [torch.randn(B, Q, 256, generator=g).bfloat16().to(DEV) for _ in range(G)]
     sink = ValueGradSink(G)
-    outs = [ms_deform_attn_grouped(value_all, sink, i, MSDA_SHAPES, locs[i], aws[i]) for i in range(G)]
+    outs = [ms_deform_attn_grouped(value_all, sink, i, shapes, locs[i], aws[i]) for i in range(G)]
     torch.autograd.backward(outs, gos)
     torch.cuda.synchronize()
     assert sink.count == 0 and sink.buf is None            # delivered and reset
     gv_all = value_all.grad.float()
+    assert torch.isfinite(gv_all).all()
     for i in range(G):
         v = value_all.detach()[:, :, i * 256:(i + 1) * 256].float().reshape(B, S, 8, 32).requires_grad_()
         lc, aw = locs[i].detach().clone().requires_grad_(), aws[i].detach().clone().requires_grad_()
-        ref = ms_deform_attn_core(v, MSDA_SHAPES, lc, aw)
+        ref = ms_deform_attn_core(v, shapes, lc, aw)
         ref.backward(gos[i].float())
         torch.cuda.synchronize()
         assert torch.equal(outs[i].detach(), ref.detach().to(torch.bfloat16))
-        assert torch.equal(locs[i].grad, lc.grad) and torch.equal(aws[i].grad, aw.grad)
+        if slab == "0":   # same kernel code for the point gradients
+            assert torch.equal(locs[i].grad, lc.grad) and torch.equal(aws[i].grad, aw.grad)
+        else:             # the slab form reduces over (8 lanes x 4 channels) instead of 32 lanes: fp32 summation order
+            assert (locs[i].grad - lc.grad).abs().max() <= 2e-5 * lc.grad.abs().max()
+            assert (aws[i].grad - aw.grad).abs().max() <= 2e-5 * aw.grad.abs().max()
         gref = v.grad.reshape(B, S, 256)
-        assert (gv_all[:, :, i * 256:(i + 1) * 256] - gref).abs().max() <= 1e-2 * gref.abs().max()   # bf16 rounding of the delivered gradient
+        # bf16 rounding of the delivered gradient (2^-9 relative) + fp32 summation order
+        assert ((gv_all[:, :, i * 256:(i + 1) * 256] - gref).abs() <= 4e-3 * gref.abs() + 1e-5 * gref.abs().max()).all()

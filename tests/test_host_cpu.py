@@ -300,3 +300,26 @@ def test_pack_entry_blocks(lib_path):
     assert lib.fx_pack_entry_blocks(64, 3000, 1, 1) == 8 * 2
     assert lib.fx_pack_entry_blocks(64, 64, 17, 17) == -1              # 289 taps: more than a tile holds 8 channels of
     assert lib.fx_pack_entry_blocks(0, 64, 1, 1) == -1
+
+
+def test_msda_slab_backward_support_predicate():
+    """fx_msda_bwd_slab_supported (host logic of csrc/train_ops.hip): RT-DETR's decoder shapes are covered, a level wider than a slab
+    or more taps than the LDS holds are not (the caller then keeps the fp32-atomic backward)."""
+    import ctypes as C
+
+    import numpy as np
+
+    from focoos_amd import _lib
+
+    lib = _lib.load()
+
+    def ok(shapes, P, Q, bf16=1, M=8):
+        a = np.ascontiguousarray(np.array(shapes, dtype=np.int32).reshape(-1))
+        return lib.fx_msda_bwd_slab_supported(a.ctypes.data, len(shapes), P, Q, M, bf16)
+
+    assert ok([[80, 80], [40, 40], [20, 20]], 4, 300) == 1
+    assert ok([[80, 80], [40, 40], [20, 20]], 4, 300, bf16=0) == 1
+    assert ok([[80, 80], [40, 40], [20, 20]], 4, 500) == 1
+    assert ok([[100, 100], [50, 50], [25, 25]], 4, 13125) == 0      # the mask families' pixel-decoder encoder: every pixel is a query
+    assert ok([[2, 4000]], 4, 10) == 0
+    assert ok([[8, 8]], 4, 10, M=4) == 0
