@@ -3,6 +3,8 @@
 // stride-1 convolution.  All are HBM-bound elementwise kernels, 8 bf16 (16 B) per lane.
 #include "common.h"
 
+int fx_tune(const char* env_name, int default_value);  // conv_igemm.hip: integer tuning knob from the environment
+
 // ------------------------------------------------------------------------------------------------
 // Master weights (reference layout [N][C][KH][KW], fp32) -> the two bf16 images the MFMA kernels read:
 //   w_fwd [Npad][KH][KW][C]            : forward / weight layout of fx_conv2d_nhwc_bf16, optional per-out-channel scale
@@ -252,14 +254,57 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(float* __restrict__ part,
   }
 }
 
+// The two passes above in one, for partial slabs: walks the SOURCE order [n][kh][kw][c] with float4 loads (every slab read once, coalesced),
+// sums the pixel-range partials in registers and scatters the four results to dw[n][c][kh][kw] (4-byte stores KH*KW*4 bytes apart - one
+// slab's worth of writes, merged in L2) - instead of a slab-sum pass that writes the sum back and a second pass that re-reads it.
+__global__ __launch_bounds__(256) void unpack_sum_kernel(const float* __restrict__ part, int64_t split_stride, int splits, const float* __restrict__ scale,
+                                                         float* __restrict__ dw, int N, int C, int KH, int KW, int Ceff, int accumulate) {
+  const int c4n = Ceff / 4, taps = KH * KW;
+  const int64_t n4 = (int64_t)N * taps * c4n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    const int c0 = (int)(i % c4n) * 4;
+    const int64_t r = i / c4n;
+    const int tap = (int)(r % taps), n = (int)(r / taps);
+    float4 a = reinterpret_cast<const float4*>(part)[i];
+    int s = 1;
+    for (; s + 3 < splits; s += 4) {
+      const float4 b0 = reinterpret_cast<const float4*>(part + (int64_t)s * split_stride)[i];
+      const float4 b1 = reinterpret_cast<const float4*>(part + (int64_t)(s + 1) * split_stride)[i];
+      const float4 b2 = reinterpret_cast<const float4*>(part + (int64_t)(s + 2) * split_stride)[i];
+      const float4 b3 = reinterpret_cast<const float4*>(part + (int64_t)(s + 3) * split_stride)[i];
+      a.x += (b0.x + b1.x) + (b2.x + b3.x); a.y += (b0.y + b1.y) + (b2.y + b3.y);
+      a.z += (b0.z + b1.z) + (b2.z + b3.z); a.w += (b0.w + b1.w) + (b2.w + b3.w);
+    }
+    for (; s < splits; ++s) {
+      const float4 b = reinterpret_cast<const float4*>(part + (int64_t)s * split_stride)[i];
+      a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const float sc = scale ? scale[n] : 1.0f;
+    const float v[4] = {a.x * sc, a.y * sc, a.z * sc, a.w * sc};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (c0 + k < C) {
+        float* dst = dw + ((int64_t)n * C + c0 + k) * taps + tap;
+        *dst = accumulate ? *dst + v[k] : v[k];
+      }
+    }
+  }
+}
+
 static int unpack_launch(const float* dw_eff, int64_t split_stride, int splits, const float* scale, float* dw_master, int N, int C, int KH, int KW,
                          int C_eff, int accumulate, fx_stream_t stream_) {
   FX_CHECK_ARG(dw_eff && dw_master && N > 0 && C > 0 && KH > 0 && KW > 0 && C_eff >= C && splits >= 1);
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const int64_t slab = (int64_t)N * KH * KW * C_eff;
-  if (splits > 1 && slab % 4 == 0 && split_stride % 4 == 0 && ((uintptr_t)dw_eff % 16) == 0) {
+  static const int fused = fx_tune("FX_UNPACK_FUSED", 1);
+  if (splits > 1 && C_eff % 4 == 0 && split_stride % 4 == 0 && ((uintptr_t)dw_eff % 16) == 0) {
     int64_t grid = (slab / 4 + 255) / 256;
     if (grid > 8192) grid = 8192;
+    if (fused) {
+      hipLaunchKernelGGL(unpack_sum_kernel, dim3((int)grid), dim3(256), 0, stream, dw_eff, split_stride, splits, scale, dw_master, N, C, KH, KW, C_eff,
+                         accumulate);
+      return fx_launch_status();
+    }
     hipLaunchKernelGGL(slab_sum_kernel, dim3((int)grid), dim3(256), 0, stream, const_cast<float*>(dw_eff), split_stride, splits, slab / 4);
     splits = 1;
   }

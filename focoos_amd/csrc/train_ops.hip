@@ -207,6 +207,7 @@ __global__ __launch_bounds__(256) void msda_f32_bwd_kernel(const VT* __restrict_
 //     slabs with ds_add_f32 accumulation - 580 us per layer, 377 us of it the LDS float atomics at ~3 cycles per lane.)
 constexpr int MS_PIX = 3200;   // pixels per slab: level 80 x 80 = two slabs -> 4 slabs x 128 (batch, head) = 512 workgroups = 2 per CU
 constexpr int MS_MAXL = 8;
+constexpr int MS_HOT = 96;     // entries from which a pixel is summed by the whole workgroup
 
 struct MsdaBinArgs {
   int L, P, B, S, Q, M, ldg;
@@ -273,7 +274,10 @@ __global__ __launch_bounds__(512) void msda_bwd_value_kernel(MsdaBinArgs a, cons
   extern __shared__ __attribute__((aligned(16))) unsigned char ms_smem[];
   int* cnt = reinterpret_cast<int*>(ms_smem);                              // [MS_PIX]: tap count -> start offset -> end offset per pixel
   int* wsum = cnt + MS_PIX;                                                // [8] wave totals of the scan
-  uint2* ent = reinterpret_cast<uint2*>(wsum + 8);                         // [Q*P*4]: (query, weight bits), filed by pixel
+  int* hotn = wsum + 8;                                                    // [1] (+1 pad) number of set-aside pixels
+  float* part = reinterpret_cast<float*>(hotn + 2);                        // [16][32] partial sums of a set-aside pixel
+  int* hot = reinterpret_cast<int*>(part + 512);                           // [Q*P*4 / MS_HOT + 2] set-aside pixels
+  uint2* ent = reinterpret_cast<uint2*>(hot + (a.Q * a.P * 4 / MS_HOT + 2) / 2 * 2);   // [Q*P*4]: (query, weight bits), filed by pixel
   GT* goL = reinterpret_cast<GT*>(ent + (size_t)a.Q * a.P * 4);            // [Q][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int slab = blockIdx.x, b = blockIdx.y / a.M, h = blockIdx.y - b * a.M;
@@ -291,6 +295,7 @@ __global__ __launch_bounds__(512) void msda_bwd_value_kernel(MsdaBinArgs a, cons
     else reinterpret_cast<float4*>(goL)[i] = *reinterpret_cast<const float4*>(src);
   }
   for (int i = tid; i < np; i += 512) cnt[i] = 0;
+  if (tid == 0) *hotn = 0;
   __syncthreads();
   // pass 1: taps per pixel
   for (int i = tid; i < NPT; i += 512) {
@@ -345,16 +350,56 @@ __global__ __launch_bounds__(512) void msda_bwd_value_kernel(MsdaBinArgs a, cons
     }
   }
   __syncthreads();
-  // sum per pixel: half-wave = pixel, lane = channel
+  // sum per pixel: half-wave = pixel, lane = channel; four entries in flight.  Pixels with MS_HOT or more entries (queries crowd on a few
+  // pixels of the coarse level) are set aside and summed afterwards by all 16 half-waves together.
   const int hw = tid >> 5, c = tid & 31;
+  const int64_t orow = ((int64_t)b * a.S + a.start[l] + p0) * a.ldg + h * 32 + c;
   for (int p = hw; p < np; p += 16) {
     const int s = p ? cnt[p - 1] : 0, e = cnt[p];
-    float acc = 0.f;
-    for (int j = s; j < e; ++j) {
-      const uint2 en = ent[j];
-      acc += __uint_as_float(en.y) * msda_go1(goL + en.x * 32 + c);
+    if (e - s >= MS_HOT) {
+      if (c == 0) hot[atomicAdd(hotn, 1)] = p;
+      continue;
     }
-    gv[((int64_t)b * a.S + a.start[l] + p0 + p) * a.ldg + h * 32 + c] = f32_to_bf16(acc);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int j = s;
+    for (; j + 4 <= e; j += 4) {
+      const uint2 e0 = ent[j], e1 = ent[j + 1], e2 = ent[j + 2], e3 = ent[j + 3];
+      a0 += __uint_as_float(e0.y) * msda_go1(goL + e0.x * 32 + c);
+      a1 += __uint_as_float(e1.y) * msda_go1(goL + e1.x * 32 + c);
+      a2 += __uint_as_float(e2.y) * msda_go1(goL + e2.x * 32 + c);
+      a3 += __uint_as_float(e3.y) * msda_go1(goL + e3.x * 32 + c);
+    }
+    for (; j < e; ++j) {
+      const uint2 en = ent[j];
+      a0 += __uint_as_float(en.y) * msda_go1(goL + en.x * 32 + c);
+    }
+    gv[orow + (int64_t)p * a.ldg] = f32_to_bf16((a0 + a1) + (a2 + a3));
+  }
+  __syncthreads();
+  const int nhot = *hotn;
+  for (int k = 0; k < nhot; ++k) {
+    const int p = hot[k];
+    const int s = p ? cnt[p - 1] : 0, e = cnt[p];
+    float a0 = 0.f, a1 = 0.f;
+    int j = s + hw;
+    for (; j + 16 < e; j += 32) {
+      const uint2 e0 = ent[j], e1 = ent[j + 16];
+      a0 += __uint_as_float(e0.y) * msda_go1(goL + e0.x * 32 + c);
+      a1 += __uint_as_float(e1.y) * msda_go1(goL + e1.x * 32 + c);
+    }
+    if (j < e) {
+      const uint2 en = ent[j];
+      a0 += __uint_as_float(en.y) * msda_go1(goL + en.x * 32 + c);
+    }
+    part[hw * 32 + c] = a0 + a1;
+    __syncthreads();
+    if (hw == 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) t += part[i * 32 + c];
+      gv[orow + (int64_t)p * a.ldg] = f32_to_bf16(t);
+    }
+    __syncthreads();
   }
 }
 
@@ -403,7 +448,9 @@ extern "C" int fx_msda_train_bwd(const void* value, int value_bf16, int ldv, con
 // fully overwritten (no zero-fill needed, nothing accumulated across calls).  grad_out fp32 or bf16 (grad_out_bf16).  shapes_host: the
 // L (H, W) pairs on the host (the slab grid is sized from them).  FX_ERR_UNSUPPORTED when a level is wider than MS_PIX pixels or the
 // taps of Q*P points do not fit the LDS (fx_msda_bwd_slab_supported tells beforehand).
-static int msda_slab_smem(int P, int Q, int go_bf16) { return (MS_PIX + 8) * 4 + Q * P * 4 * 8 + Q * 32 * (go_bf16 ? 2 : 4); }
+static int msda_slab_smem(int P, int Q, int go_bf16) {
+  return (MS_PIX + 8 + 2 + 512 + (Q * P * 4 / MS_HOT + 2) / 2 * 2) * 4 + Q * P * 4 * 8 + Q * 32 * (go_bf16 ? 2 : 4);
+}
 
 extern "C" int fx_msda_bwd_slab_supported(const int32_t* shapes_host, int L, int P, int Q, int M, int grad_out_bf16) {
   if (!shapes_host || M != 8 || L < 1 || L > MS_MAXL || P < 1 || Q < 1 || Q >= (1 << 24)) return 0;

@@ -88,8 +88,9 @@ def test_box_refine_forward_backward_vs_torch_autograd():
 
 
 @pytest.mark.parametrize("slab", ["1", "0"])
-@pytest.mark.parametrize("shapes,Q", [(MSDA_SHAPES, 40), ([[80, 80], [40, 40], [20, 20]], 300), ([[3, 400], [7, 9]], 161)])
-def test_grouped_msda_matches_the_per_layer_function(shapes, Q, slab, monkeypatch):
+@pytest.mark.parametrize("shapes,Q,crowd", [(MSDA_SHAPES, 40, False), ([[80, 80], [40, 40], [20, 20]], 300, False), ([[3, 400], [7, 9]], 161, False),
+                                            ([[80, 80], [40, 40], [20, 20]], 300, True)])
+def test_grouped_msda_matches_the_per_layer_function(shapes, Q, crowd, slab, monkeypatch):
     """ms_deform_attn_grouped (G layers reading column slices of one bf16 value tensor, value gradients delivered together by the last
     layer to run) vs ms_deform_attn_core on the same bf16-rounded values, layer by layer: identical forward (same kernel code, typed
     loads), identical location / weight gradients, value gradient equal up to the order of the fp32 additions and the bf16 rounding of
@@ -102,7 +103,10 @@ def test_grouped_msda_matches_the_per_layer_function(shapes, Q, slab, monkeypatc
     S = sum(h * w for h, w in shapes)
     g = torch.Generator().manual_seed(8)
     value_all = torch.randn(B, S, G * 256, generator=g).bfloat16().to(DEV).requires_grad_()
-    locs = [(torch.rand(B, Q, 8, len(shapes), 4, 2, generator=g) * 1.2 - 0.1).to(DEV).requires_grad_() for _ in range(G)]
+    if crowd:   # every query samples around one spot: thousands of taps on a handful of pixels (the set-aside path of the binned kernel)
+        locs = [(0.37 + 0.004 * torch.randn(B, Q, 8, len(shapes), 4, 2, generator=g)).to(DEV).requires_grad_() for _ in range(G)]
+    else:
+        locs = [(torch.rand(B, Q, 8, len(shapes), 4, 2, generator=g) * 1.2 - 0.1).to(DEV).requires_grad_() for _ in range(G)]
     aws = [torch.softmax(torch.randn(B, Q, 8, len(shapes) * 4, generator=g), -1).view(B, Q, 8, len(shapes), 4).to(DEV).requires_grad_() for _ in range(G)]
     gos = [torch.randn(B, Q, 256, generator=g).bfloat16().to(DEV) for _ in range(G)]
     sink = ValueGradSink(G)
@@ -126,4 +130,4 @@ def test_grouped_msda_matches_the_per_layer_function(shapes, Q, slab, monkeypatc
             assert (aws[i].grad - aw.grad).abs().max() <= 2e-5 * aw.grad.abs().max()
         gref = v.grad.reshape(B, S, 256)
         # bf16 rounding of the delivered gradient (2^-9 relative) + fp32 summation order
-        assert ((gv_all[:, :, i * 256:(i + 1) * 256] - gref).abs() <= 4e-3 * gref.abs() + 1e-5 * gref.abs().max()).all()
+        assert ((gv_all[:, :, i * 256:(i + 1) * 256] - gref).abs() <= 4e-3 * gref.abs() + 2e-5 * gref.abs().max()).all()
