@@ -382,7 +382,7 @@ int fx_launch_pw_flat(const ConvArgs& c, const bf16_t* w_frag, hipStream_t strea
   // round 3: layers whose reduction fits the LDS (K = 256 / 512) on the resident-tile kernel (conv_pw_kplane.hip); FX_PW_KPLANE=0
   // keeps the round-2 kernel below for A/B runs
   static const int kplane_on = fx_tune("FX_PW_KPLANE", 1);
-  if (kplane_on && fx_pw_kplane_supported(c.C, c.N, fx_c3_epilogue_mode(c.act, c.res != nullptr, c.res_after)) && c.N * 4 + 128 * c.C * 2 + (c.res ? 65536 : 0) <= 160 * 1024)
+  if (kplane_on && fx_pw_kplane_supported(c.C, c.N, fx_c3_epilogue_mode(c.act, c.res != nullptr, c.res_after)) && c.N * 4 + 128 * c.C * 2 <= 160 * 1024)
     return fx_launch_pw_kplane(c, w_frag, stream);
   C3Args a;
   c3_fill(a, c, w_frag);

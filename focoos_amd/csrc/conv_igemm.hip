@@ -390,7 +390,7 @@ extern "C" int fx_conv2d_variant(const fx_conv_desc* d, char* out, int cap) {
       static const int pwk_on = fx_tune("FX_PW_KPLANE", 1);
       const int mode = fx_c3_epilogue_mode(d->act, d->residual != nullptr, d->residual_after_act);
       const bool res_tile = d->residual != nullptr;
-      const bool kp = pwk_on && fx_pw_kplane_supported(d->C, d->N, mode) && d->N * 4 + 128 * d->C * 2 + (res_tile ? 65536 : 0) <= 160 * 1024;
+      const bool kp = pwk_on && fx_pw_kplane_supported(d->C, d->N, mode) && d->N * 4 + 128 * d->C * 2 <= 160 * 1024;
       snprintf(out, cap, kp ? "pw_kplane<K%d>" : "pw_flat<K%d>", d->C);
       break;
     }

@@ -9,14 +9,18 @@
 //     address register per 32-pixel block, set once per launch - no address arithmetic in the loop, no swizzle;
 //   * weights: MFMA A operand in fragment order from L2 through the 4-slot register ring, one continuous stream over the n-tiles
 //     (scalar-base loads, the pointer update is SALU work);
-//   * residual (K = 256 only: 64 KiB tile T next to the 64 KiB pixel tile): the loader wave DMAs the residual of n-tile i into T while
-//     the consumers run the K loop of n-tile i; the epilogue reads it in the accumulator layout;
 //   * epilogue: bias (accumulator init) + residual / activation in registers, v_permlane32_swap pairs -> 16-byte row stores straight to
-//     memory (no output tile in LDS, no barrier unless there is a residual).
+//     memory (no output tile in LDS, no barrier);
+//   * residual: read in the epilogue with the SAME 16-byte-per-lane addressing as the stores (one row block ahead), and taken back to
+//     the accumulator layout by the same v_permlane32_swap pairs (the swap is its own inverse).  (First form of this kernel: a fifth
+//     wave DMA-ing a 64 KiB residual tile into LDS per n-tile, two barriers per n-tile, one workgroup per CU - 9.7 us per n-tile where
+//     the MFMAs take 2; now the workgroup is four waves and two of them share a CU, one's epilogue beside the other's K loop.)
 // Per 128-pixel tile of branch2c: 64 KiB in + 4 x (64 KiB residual + 64 KiB out) against 4 x 2 us of MFMAs: HBM-bound as it should be.
 #include <type_traits>
 
 #include "pw_common.h"
+
+int fx_tune(const char* env_name, int default_value);  // conv_igemm.hip
 
 struct PWKArgs {
   const bf16_t* x;
@@ -44,28 +48,24 @@ __device__ __forceinline__ float pwk_act(float v, std::integral_constant<int, FX
 __device__ __forceinline__ float pwk_act(float v, std::integral_constant<int, FX_ACT_SILU>) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 __device__ __forceinline__ float pwk_act(float v, std::integral_constant<int, FX_ACT_NONE>) { return v; }
 
-// K: reduction length (256 / 512), resident.  4 consumer waves side by side over a 256-channel n-tile (2 x 4 accumulator blocks each:
-// 128 pixels x 64 channels).  RESMODE: 0 none, 1 act(conv + residual), 3 act(conv) * (residual > 0).  With a residual a fifth
-// wave (the loader) streams the residual tiles; without one the workgroup is four waves at <= 256 registers, so that TWO workgroups
-// share a CU when the pixel tile is 64 KiB (K = 256): one's epilogue (conversion + stores, nothing for the matrix cores) runs beside
-// the other's K loop.
+// K: reduction length (256 / 512), resident.  4 waves side by side over a 256-channel n-tile (2 x 4 accumulator blocks each:
+// 128 pixels x 64 channels).  RESMODE: 0 none, 1 act(conv + residual), 3 act(conv) * (residual > 0).  Four waves at <= 256
+// registers, so that TWO workgroups share a CU when the pixel tile is 64 KiB (K = 256): one's epilogue (residual loads, conversion,
+// stores - nothing for the matrix cores) runs beside the other's K loop.
 template <int K, int ACT, int RESMODE>
-__global__ __launch_bounds__(RESMODE != 0 ? 320 : 256, RESMODE != 0 ? 1 : 2) void conv_pw_kplane_kernel(const PWKArgs p) {
+__global__ __launch_bounds__(256, 2) void conv_pw_kplane_kernel(const PWKArgs p) {
   constexpr int TN = 2, TM = 4, NW = 4, BM = 128, BN = 256;
-  constexpr int NTHR = RESMODE != 0 ? 320 : 256, NDW = NTHR / 64;
+  constexpr int NTHR = 256, NDW = NTHR / 64;
   constexpr int KS = K / 16;                 // k16 steps
   constexpr int PLANE = BM * 16, XBYTES = 2 * KS * PLANE;   // = BM * K * 2
   constexpr int PF = 4;
-  constexpr int RLT = BN / 8;
-  static_assert(KS % PF == 0 && (KS - 1) * PLANE < 65536 && (RESMODE == 0 || XBYTES + BM * BN * 2 <= 160 * 1024), "plane offsets are 16-bit immediates");
+  static_assert(KS % PF == 0 && (KS - 1) * PLANE < 65536, "plane offsets are 16-bit immediates");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* T = smem + XBYTES;   // residual tile [BM][BN] bf16, rows of BN*2 bytes, pw_swz<RLT> (RESMODE != 0 only)
-  // the bias vector, staged once: an ordinary global load inside the n-tile loop would make hipcc drain the (asm-issued) weight ring
-  float* biasL = reinterpret_cast<float*>(smem + XBYTES + (RESMODE != 0 ? BM * BN * 2 : 0));
+  // the bias vector, staged once: an ordinary global load inside the K loop would make hipcc drain the (asm-issued) weight ring
+  float* biasL = reinterpret_cast<float*>(smem + XBYTES);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool is_loader = RESMODE != 0 && wave == NW;
   const int l32 = lane & 31, half = lane >> 5;
   const int m0 = fx_xcd_remap(blockIdx.x, gridDim.x) * BM;
   const int nt_first = blockIdx.y * p.ntg;
@@ -84,33 +84,6 @@ __global__ __launch_bounds__(RESMODE != 0 ? 320 : 256, RESMODE != 0 ? 1 : 2) voi
       pw_dma16(xr, smem + pln * PLANE + blk * 1024, m < p.M ? (unsigned)(m * p.ldx + c * 8) * 2u : FX_OOB);
     }
   }
-  auto dma_res = [&](int nt) {   // residual tile of n-tile nt -> T (loader only)
-    const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)p.res, 0, p.r_bytes, 0x00020000);
-    for (int i = 0; i < BM * RLT / 64; ++i) {
-      const int q = i * 64 + lane;
-      const int r = q / RLT, pc = q % RLT;
-      const int lc = pw_swz<RLT>(r, pc);
-      const int m = m0 + r;
-      pw_dma16(rr, T + i * 1024, m < p.M ? (unsigned)(m * p.ldr + nt * BN + lc * 8) * 2u : FX_OOB);
-    }
-  };
-
-  if (is_loader) {
-    if constexpr (RESMODE != 0) dma_res(nt_first);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();   // S: the pixel tile has landed
-    if constexpr (RESMODE != 0) {
-      for (int nt = nt_first; nt < NT; ++nt) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();   // B1(nt): residual nt is in T
-        __syncthreads();   // B2(nt): the consumers have read it
-        if (nt + 1 < NT) dma_res(nt + 1);
-      }
-    }
-    return;
-  }
-
-  // ---- consumers
   f32x16 acc[TN][TM];
   bf16x8 ar[PF][TN];
   const unsigned wvoff = lane * 16;
@@ -177,10 +150,24 @@ __global__ __launch_bounds__(RESMODE != 0 ? 320 : 256, RESMODE != 0 ? 1 : 2) voi
       };
       c3_static_for<PF>(kstep);
     }
-    // ---- epilogue of n-tile nt
-    if constexpr (RESMODE != 0) __syncthreads();   // B1: residual tile in T
+    // ---- epilogue of n-tile nt.  Residual: rr[.][a*2+g2] = the 16 bytes this lane will store at (row, a*32 + g2*16 + half*8), one
+    // row block ahead of its use.  (Ordinary loads: they are younger than the ring refills in flight, so the compiler's own vmcnt
+    // waits stay correct - a wait for them also covers the refills, which the next n-tile needs first thing anyway.)
+    uint4 rr[2][TN * 2];
+    auto ld_res = [&](int b, uint4* dst) {
+      const int m = min(m0 + b * 32 + l32, p.M - 1);
+      const bf16_t* rrow = p.res + (size_t)m * p.ldr + n0 + wave * TN * 32 + half * 8;
+#pragma unroll
+      for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2) dst[a * 2 + g2] = *reinterpret_cast<const uint4*>(rrow + a * 32 + g2 * 16);
+    };
+    if constexpr (RESMODE != 0) ld_res(0, rr[0]);
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
+      if constexpr (RESMODE != 0) {
+        if (b + 1 < TM) ld_res(b + 1, rr[(b + 1) & 1]);
+      }
       const int row = b * 32 + l32;
       const int m = m0 + row;
       size_t yo = (size_t)m * p.ldy;
@@ -194,17 +181,20 @@ __global__ __launch_bounds__(RESMODE != 0 ? 320 : 256, RESMODE != 0 ? 1 : 2) voi
       for (int a = 0; a < TN; ++a)
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2) {
-          unsigned pk[2][2];
+          unsigned pk[2][2], rq[2][2] = {{0u, 0u}, {0u, 0u}};
+          if constexpr (RESMODE != 0) {   // store layout -> accumulator layout: the inverse of the swaps below
+            const uint4 R = rr[b & 1][a * 2 + g2];
+            const auto s0 = __builtin_amdgcn_permlane32_swap(R.x, R.z, false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(R.y, R.w, false, false);
+            rq[0][0] = s0[0]; rq[1][0] = s0[1];
+            rq[0][1] = s1[0]; rq[1][1] = s1[1];
+          }
 #pragma unroll
           for (int q = 0; q < 2; ++q) {
             const int gq = 2 * g2 + q;
-            float v[4], r[4] = {0.f, 0.f, 0.f, 0.f};
-            if constexpr (RESMODE != 0) {
-              const int chunk = (wave * TN + a) * 4 + gq;
-              const uint2 rv = *reinterpret_cast<const uint2*>(T + row * (BN * 2) + (pw_swz<RLT>(row, chunk) << 4) + half * 8);
-              r[0] = __uint_as_float(rv.x << 16); r[1] = __uint_as_float(rv.x & 0xffff0000u);
-              r[2] = __uint_as_float(rv.y << 16); r[3] = __uint_as_float(rv.y & 0xffff0000u);
-            }
+            float v[4];
+            const float r[4] = {__uint_as_float(rq[q][0] << 16), __uint_as_float(rq[q][0] & 0xffff0000u), __uint_as_float(rq[q][1] << 16),
+                                __uint_as_float(rq[q][1] & 0xffff0000u)};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               v[e] = acc[a][b][4 * gq + e];
@@ -224,7 +214,6 @@ __global__ __launch_bounds__(RESMODE != 0 ? 320 : 256, RESMODE != 0 ? 1 : 2) voi
           if (live) *reinterpret_cast<uint4*>(yrow + a * 32 + g2 * 16) = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
         }
     }
-    if constexpr (RESMODE != 0) __syncthreads();   // B2: T may be refilled
   }
   // the ring's last refills are still in flight: let them land before the wave ends (their registers are dead, but an asm load
   // must not outlive its wave's register allocation)
@@ -238,12 +227,15 @@ template <int K, int ACT, int RESMODE>
 static int launch_pwk(PWKArgs& a, hipStream_t stream) {
   static const int one_per_cu = fx_tune("FX_PWK_ONE_PER_CU", 0);   // A/B knob: pad the LDS request so that one workgroup owns a CU
   constexpr int BM = 128, BN = 256;
-  int smem = BM * K * 2 + (RESMODE != 0 ? BM * BN * 2 : 0) + a.N * 4;
+  int smem = BM * K * 2 + a.N * 4;
   if (smem > 160 * 1024) return FX_ERR_UNSUPPORTED;
   if (one_per_cu && smem < 96 * 1024) smem = 96 * 1024;
-  // n-tiles per workgroup: all of them when the pixel tiles alone fill the chip, else spread (>= ~256 workgroups)
+  // n-tiles per workgroup: all of them when the pixel tiles alone fill the chip, else spread over more workgroups (two 64 KiB pixel
+  // tiles share a CU)
   const int mt = (a.M + BM - 1) / BM, NT = a.N / BN;
-  int groups = mt >= 192 ? 1 : (256 + mt - 1) / mt;
+  static const int target = fx_tune("FX_PWK_TARGET_WGS", 512);
+  const int want = K == 256 ? target : target / 2;
+  int groups = mt >= want * 3 / 4 ? 1 : (want + mt - 1) / mt;
   if (groups > NT) groups = NT;
   a.ntg = (NT + groups - 1) / groups;
   groups = (NT + a.ntg - 1) / a.ntg;
@@ -253,16 +245,16 @@ static int launch_pwk(PWKArgs& a, hipStream_t stream) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return FX_ERR_RUNTIME;
     attr_smem = smem;
   }
-  hipLaunchKernelGGL(kern, dim3(mt, groups), dim3(RESMODE != 0 ? 320 : 256), smem, stream, a);
+  hipLaunchKernelGGL(kern, dim3(mt, groups), dim3(256), smem, stream, a);
   return fx_launch_status();
 }
 
-// 1 iff fx_launch_pw_kplane covers (C, N, epilogue mode): K = 256 with every pointwise epilogue but the two-operand training one,
-// K = 512 without a residual
+// 1 iff fx_launch_pw_kplane covers (C, N, epilogue mode): K = 256 / 512 with every pointwise epilogue but the two-operand training one
 bool fx_pw_kplane_supported(int C, int N, int mode) {
   if (N <= 0 || N % 256 != 0 || N > 4096) return false;
+  static const int k512_res = fx_tune("FX_PWK_K512_RES", 1);   // A/B knob: K = 512 layers with a residual (else conv3x3_flat.hip's KT = 1 form)
   if (C == 256) return mode == 0 || mode == 1 || mode == 3 || mode == 4 || mode == 5;
-  if (C == 512) return mode == 0 || mode == 1 || mode == 3;
+  if (C == 512) return mode == 0 || mode == 1 || mode == 3 || (k512_res && (mode == 4 || mode == 5));
   return false;
 }
 
@@ -286,6 +278,8 @@ int fx_launch_pw_kplane(const ConvArgs& c, const bf16_t* w_frag, hipStream_t str
       case 0: return launch_pwk<512, FX_ACT_RELU, 0>(a, stream);
       case 1: return launch_pwk<512, FX_ACT_SILU, 0>(a, stream);
       case 3: return launch_pwk<512, FX_ACT_NONE, 0>(a, stream);
+      case 4: return launch_pwk<512, FX_ACT_RELU, 1>(a, stream);
+      case 5: return launch_pwk<512, FX_ACT_NONE, 3>(a, stream);
     }
   }
   return FX_ERR_UNSUPPORTED;

@@ -252,6 +252,15 @@ static void wgrad_split(int M, int tiles, int wgs, int* mchunk_out, int* splits_
   *splits_out = (M + mchunk - 1) / mchunk;
 }
 
+// workgroups the partial-slab form aims for.  Large filters (N x K >= 128 Ki fp32 per slab): one workgroup per CU - fewer pixel splits
+// = fewer slabs to write and sum, and the weight gradients run beside the input-gradient chain, which fills the rest of the chip
+// (RT-DETR step 588 -> 600 img/s).  Small filters (the narrow layers of STDC / the stem): the slabs are cheap and the pixel range per
+// workgroup is what matters - four workgroups per CU as before.
+static int wgrad_target_wgs(int N, int Ktot) {
+  static const int big = fx_tune("FX_WGRAD_WGS", 256), small = fx_tune("FX_WGRAD_WGS_SMALL", 1024);
+  return (int64_t)N * Ktot >= 128 * 1024 ? big : small;
+}
+
 static int wgrad_launch(const void* x, int ldx, const void* dz, int lddz, float* dw, long long split_stride, int expect_splits, float* dbias, int B, int H,
                         int W, int C, int Ho, int Wo, int N, int KH, int KW, int stride, int pad, fx_stream_t stream_) {
   FX_CHECK_ARG(x && dz && dw && B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && N > 0 && C > 0);
@@ -280,10 +289,7 @@ static int wgrad_launch(const void* x, int ldx, const void* dz, int lddz, float*
   // atomics: every split adds one full pass of fp32 atomics over dW, and the L2 atomic units sustain only ~0.6 TB/s - few splits.
   // partial stores: plain coalesced stores (summed later by fx_unpack_conv_wgrad_sum_f32) - more splits, more parallelism.
   int S;
-  // workgroups the partial-slab form aims for: fewer pixel splits = fewer fp32 slabs to write and sum, and the weight gradients run
-  // beside the input-gradient chain, which fills the rest of the chip
-  static const int wgs_split = fx_tune("FX_WGRAD_WGS", 256);
-  wgrad_split(a.M, tiles, split_stride ? wgs_split : 512, &a.mchunk, &S);
+  wgrad_split(a.M, tiles, split_stride ? wgrad_target_wgs(N, a.Ktot) : 512, &a.mchunk, &S);
   FX_CHECK_ARG(!split_stride || (S == expect_splits && split_stride >= (long long)N * a.Ktot));
   a.split_stride = split_stride;
   a.tiles = tiles;
@@ -301,8 +307,7 @@ extern "C" int fx_conv2d_wgrad_bias_nhwc_bf16(const void* x, int ldx, const void
 extern "C" int fx_conv2d_wgrad_splits(int B, int Ho, int Wo, int C, int N, int KH, int KW) {
   if (B <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || N <= 0 || KH <= 0 || KW <= 0) return 0;
   int mchunk, S;
-  static const int wgs_split = fx_tune("FX_WGRAD_WGS", 256);
-  wgrad_split(B * Ho * Wo, ((N + 127) / 128) * ((KH * KW * C + 127) / 128), wgs_split, &mchunk, &S);
+  wgrad_split(B * Ho * Wo, ((N + 127) / 128) * ((KH * KW * C + 127) / 128), wgrad_target_wgs(N, KH * KW * C), &mchunk, &S);
   return S;
 }
 

@@ -668,6 +668,8 @@ PW_FLAT_CASES = [
     (1, 1, 1000, 512, 512, "silu", False),     # CSP conv1|conv2: two K chunks (double-buffered), M tail
     (1, 37, 11, 1024, 256, "relu", False),     # res4 branch2a: four K chunks
     (1, 1, 777, 256, 1536, None, False),       # the six value_proj's as one GEMM
+    (2, 13, 9, 512, 2048, "relu", True),       # res5 branch2c: K = 512 resident + residual (direct 16-byte residual loads), M tail
+    (1, 1, 130, 256, 512, "relu", True),       # one full tile + a 2-row tail: residual rows past M are clamped, not read out of bounds
 ]
 
 
