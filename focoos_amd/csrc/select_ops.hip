@@ -119,26 +119,49 @@ __global__ FX_SEL_PK(1) __launch_bounds__(TOPK_THREADS) void topk_kernel(const f
     const int shift = 24 - 8 * pass;
     if (tid < 256) hist[tid] = 0;
     __syncthreads();
-    for (int i = tid; i < n; i += TOPK_THREADS) {
-      uint32_t key = f32_key(row[i]);
-      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+    for (int i0 = 0; i0 < n; i0 += TOPK_THREADS) {
+      const int i = i0 + tid;
+      const bool in = i < n;
+      const uint32_t key = in ? f32_key(row[i]) : 0u;
+      bool live = in && (key & mask) == prefix;
+      const uint32_t bin = (key >> shift) & 255u;
+      // scores crowd into one or two bins per digit: one atomic per (wave, bin) for the first few distinct bins of the wave, plain
+      // atomics for whatever is left (same-address LDS atomics serialise per lane otherwise)
+#pragma unroll 1
+      for (int it = 0; it < 4; ++it) {
+        const unsigned long long act = __ballot(live);
+        if (!act) break;
+        const uint32_t lead = __builtin_amdgcn_readlane(bin, (int)__builtin_ctzll(act));
+        const unsigned long long same = __ballot(live && bin == lead);
+        if ((tid & 63) == (int)__builtin_ctzll(act)) atomicAdd(&hist[lead], (uint32_t)__popcll(same));
+        if (bin == lead) live = false;
+      }
+      if (live) atomicAdd(&hist[bin], 1u);
     }
     __syncthreads();
-    if (tid == 0) {
-      uint32_t rem = s_remaining, c = 0;
-      int bin = 0;
-      for (int bb = 255; bb >= 0; --bb) {
-        uint32_t hcount = hist[bb];
-        if (c + hcount >= rem) {
-          bin = bb;
-          rem -= c;
-          break;
-        }
-        c += hcount;
+    if (tid < 64) {   // wave 0: lane l owns bins 4l..4l+3; suffix sums over the lanes locate the bin where the count from the top reaches `rem`
+      const uint32_t rem = s_remaining;
+      const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+      const uint32_t mine = h0 + h1 + h2 + h3;
+      uint32_t suf = mine;   // inclusive suffix sum: bins of lanes >= tid
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_down(suf, o, 64);
+        if (tid + o < 64) suf += v;
       }
-      s_remaining = rem;  // still needed among keys whose digits so far equal prefix|bin
-      s_prefix = prefix | ((uint32_t)bin << shift);
-      s_count = hist[bin];  // after the last pass: number of elements with key == T
+      const uint32_t above = suf - mine;   // count in bins above this lane's
+      if (above < rem && suf >= rem) {     // exactly one lane
+        uint32_t c = above;
+        int bin;
+        uint32_t hb;
+        if (c + h3 >= rem) { bin = 4 * tid + 3; hb = h3; }
+        else if ((c += h3) + h2 >= rem) { bin = 4 * tid + 2; hb = h2; }
+        else if ((c += h2) + h1 >= rem) { bin = 4 * tid + 1; hb = h1; }
+        else { c += h1; bin = 4 * tid; hb = h0; }
+        s_remaining = rem - c;  // still needed among keys whose digits so far equal prefix|bin
+        s_prefix = prefix | ((uint32_t)bin << shift);
+        s_count = hb;           // after the last pass: number of elements with key == T
+      }
     }
     __syncthreads();
     prefix = s_prefix;
@@ -195,21 +218,35 @@ __global__ FX_SEL_PK(1) __launch_bounds__(TOPK_THREADS) void topk_kernel(const f
   // bitonic sort, descending, of the smallest power of two >= k entries (zeros pad at the end)
   int ns = 1;
   while (ns < k) ns <<= 1;
+  // strides <= 64 keep a compare-exchange pair inside one 128-entry window: wave w runs all of them for window w back to back (LDS
+  // operations of a wave are ordered; no workgroup barrier), only the wider strides are workgroup steps
+  auto cmpx = [&](int t, int size, int stride) {
+    const int lo = (t / stride) * (stride * 2) + (t % stride);
+    const int hi = lo + stride;
+    const bool desc = ((lo & size) == 0);
+    const unsigned long long a = sel[lo], bq = sel[hi];
+    const bool swap = desc ? (a < bq) : (a > bq);
+    if (swap) {
+      sel[lo] = bq;
+      sel[hi] = a;
+    }
+  };
+  const int lane_s = tid & 63, wv_s = tid >> 6;
   for (int size = 2; size <= ns; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int t = tid; t < ns / 2; t += TOPK_THREADS) {
-        int lo = (t / stride) * (stride * 2) + (t % stride);
-        int hi = lo + stride;
-        bool desc = ((lo & size) == 0);
-        unsigned long long a = sel[lo], bq = sel[hi];
-        bool swap = desc ? (a < bq) : (a > bq);
-        if (swap) {
-          sel[lo] = bq;
-          sel[hi] = a;
-        }
-      }
+    int stride = size >> 1;
+    for (; stride > 64; stride >>= 1) {
+      for (int t = tid; t < ns / 2; t += TOPK_THREADS) cmpx(t, size, stride);
       __syncthreads();
     }
+    for (int w = wv_s; w * 128 < ns; w += TOPK_THREADS / 64) {
+      for (int st = stride; st > 0; st >>= 1) {
+        if (w * 64 + lane_s < ns / 2) cmpx(w * 64 + lane_s, size, st);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+    }
+    __syncthreads();
   }
   for (int i = tid; i < k_out; i += TOPK_THREADS) {
     unsigned long long e = sel[i];

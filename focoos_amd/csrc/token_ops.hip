@@ -3,6 +3,8 @@
 // All are HBM/L2-bound wavefront kernels; rows are 256 channels = one 512-byte line per wave.
 #include "common.h"
 
+int fx_tune(const char* env_name, int default_value);  // conv_igemm.hip
+
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void add_rows_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ y, int ldy,
                                                         int y_rows, bf16_t* __restrict__ out, int ldo, int rows, int C8) {
@@ -436,6 +438,101 @@ __global__ __launch_bounds__(256) void msda_kernel(const bf16_t* __restrict__ va
   *reinterpret_cast<uint2*>(out + (int64_t)bq * ldo + h * 32 + cg * 4) = o;
 }
 
+// L = 3 levels x P = 4 points (every deformable layer of the three model families): the loops unrolled, a level's 16 taps requested
+// together (clamped address, zero weight for taps outside the map - no branch between the loads), offsets / logits read as float4.
+// The generic kernel above walks the 12 points one after another, each waiting for its own four taps: ~12 dependent L2 round trips
+// per wave with under five waves per SIMD to hide them (32 us for 16 x 300 queries); here a wave waits three times.
+template <int MODE>
+__global__ __launch_bounds__(256) void msda_l3p4_kernel(const bf16_t* __restrict__ value, int ldv, const int32_t* __restrict__ shapes,
+                                                         const int32_t* __restrict__ lstart, const float* __restrict__ loc, int ld_loc,
+                                                         const float* __restrict__ attn, int ld_attn, const float* __restrict__ ref,
+                                                         bf16_t* __restrict__ out, int ldo, int B, int S, int Q) {
+  constexpr int L = 3, P = 4, LP = 12;
+  const int lane = threadIdx.x & 63;
+  const int bq = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (bq >= B * Q) return;
+  const int b = bq / Q;
+  const int h = lane >> 3, cg = lane & 7;
+  const bf16_t* vb = value + (int64_t)b * S * ldv + h * 32 + cg * 4;
+  const float4* locp = reinterpret_cast<const float4*>(loc + (int64_t)bq * ld_loc + h * LP * 2);
+  const float4* attp = reinterpret_cast<const float4*>(attn + (int64_t)bq * ld_attn + h * LP);
+  float lxy[LP * 2], aw[LP];
+#pragma unroll
+  for (int i = 0; i < LP / 2; ++i) {
+    const float4 v = locp[i];
+    lxy[4 * i] = v.x; lxy[4 * i + 1] = v.y; lxy[4 * i + 2] = v.z; lxy[4 * i + 3] = v.w;
+  }
+#pragma unroll
+  for (int i = 0; i < LP / 4; ++i) {
+    const float4 v = attp[i];
+    aw[4 * i] = v.x; aw[4 * i + 1] = v.y; aw[4 * i + 2] = v.z; aw[4 * i + 3] = v.w;
+  }
+  int Hs[L], Ws[L], st[L];
+#pragma unroll
+  for (int l = 0; l < L; ++l) { Hs[l] = shapes[2 * l]; Ws[l] = shapes[2 * l + 1]; st[l] = lstart[l]; }
+  if (MODE == 1) {
+    const float4 rp = *reinterpret_cast<const float4*>(ref + (int64_t)bq * 4);
+    float amax = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) amax = fmaxf(amax, aw[i]);
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) { aw[i] = __expf(aw[i] - amax); sum += aw[i]; }
+    const float ainv = 1.0f / sum;
+#pragma unroll
+    for (int i = 0; i < LP; ++i) {
+      aw[i] *= ainv;
+      lxy[2 * i] = rp.x + lxy[2 * i] / (float)P * rp.z * 0.5f;
+      lxy[2 * i + 1] = rp.y + lxy[2 * i + 1] / (float)P * rp.w * 0.5f;
+    }
+  }
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int l = 0; l < L; ++l) {
+    const int Hl = Hs[l], Wl = Ws[l];
+    const bf16_t* vl = vb + (int64_t)st[l] * ldv;
+    uint2 t[P][4];
+    float w[P][4];
+#pragma unroll
+    for (int pt = 0; pt < P; ++pt) {
+      const int i = l * P + pt;
+      const float gx = 2.0f * lxy[2 * i] - 1.0f, gy = 2.0f * lxy[2 * i + 1] - 1.0f;
+      const float ix = ((gx + 1.0f) * (float)Wl - 1.0f) * 0.5f, iy = ((gy + 1.0f) * (float)Hl - 1.0f) * 0.5f;
+      const float fx0 = floorf(ix), fy0 = floorf(iy);
+      const int x0 = (int)fx0, y0 = (int)fy0;
+      const float tx = ix - fx0, ty = iy - fy0;
+      const bool xin0 = (unsigned)x0 < (unsigned)Wl, xin1 = (unsigned)(x0 + 1) < (unsigned)Wl;
+      const bool yin0 = (unsigned)y0 < (unsigned)Hl, yin1 = (unsigned)(y0 + 1) < (unsigned)Hl;
+      w[pt][0] = (yin0 && xin0) ? aw[i] * (1.f - tx) * (1.f - ty) : 0.f;
+      w[pt][1] = (yin0 && xin1) ? aw[i] * tx * (1.f - ty) : 0.f;
+      w[pt][2] = (yin1 && xin0) ? aw[i] * (1.f - tx) * ty : 0.f;
+      w[pt][3] = (yin1 && xin1) ? aw[i] * tx * ty : 0.f;
+      const int xc0 = min(max(x0, 0), Wl - 1), xc1 = min(max(x0 + 1, 0), Wl - 1);
+      const int yc0 = min(max(y0, 0), Hl - 1), yc1 = min(max(y0 + 1, 0), Hl - 1);
+      t[pt][0] = *reinterpret_cast<const uint2*>(vl + (int64_t)(yc0 * Wl + xc0) * ldv);
+      t[pt][1] = *reinterpret_cast<const uint2*>(vl + (int64_t)(yc0 * Wl + xc1) * ldv);
+      t[pt][2] = *reinterpret_cast<const uint2*>(vl + (int64_t)(yc1 * Wl + xc0) * ldv);
+      t[pt][3] = *reinterpret_cast<const uint2*>(vl + (int64_t)(yc1 * Wl + xc1) * ldv);
+    }
+    // same summation order as the generic kernel: the four taps of a point first (s), then acc += aw * s - here with aw folded into
+    // the tap weights, which changes the rounding by an ulp; parity tests hold both to the same tolerance
+#pragma unroll
+    for (int pt = 0; pt < P; ++pt) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        acc[0] += w[pt][k] * __uint_as_float(t[pt][k].x << 16);
+        acc[1] += w[pt][k] * __uint_as_float(t[pt][k].x & 0xffff0000u);
+        acc[2] += w[pt][k] * __uint_as_float(t[pt][k].y << 16);
+        acc[3] += w[pt][k] * __uint_as_float(t[pt][k].y & 0xffff0000u);
+      }
+    }
+  }
+  uint2 o;
+  o.x = pack_bf16x2(acc[0], acc[1]);
+  o.y = pack_bf16x2(acc[2], acc[3]);
+  *reinterpret_cast<uint2*>(out + (int64_t)bq * ldo + h * 32 + cg * 4) = o;
+}
+
 extern "C" int fx_msda_bf16(const void* value, int ldv, const int32_t* spatial_shapes, const int32_t* level_start, int L, int P,
                             const float* loc, int ld_loc, const float* attn, int ld_attn, const float* ref, int mode, void* out, int ldo,
                             int B, int S, int Q, int M, fx_stream_t stream_) {
@@ -446,6 +543,19 @@ extern "C" int fx_msda_bf16(const void* value, int ldv, const int32_t* spatial_s
   FX_CHECK_ARG(ld_loc >= M * L * P * 2 && ld_attn >= M * L * P);
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   dim3 grid((B * Q + 3) / 4), block(256);
+  static const int fast = fx_tune("FX_MSDA_L3P4", 1);
+  // the unrolled form needs 16-byte rows of offsets / logits (float4 loads); NaN values in the map are the one thing it treats
+  // differently from the generic kernel (a zero-weight clamped tap reads them): value projections are finite
+  if (fast && L == 3 && P == 4 && ld_loc % 4 == 0 && ld_attn % 4 == 0 && ((uintptr_t)loc % 16) == 0 && ((uintptr_t)attn % 16) == 0 &&
+      (mode == 0 || ((uintptr_t)ref % 16) == 0)) {
+    if (mode == 0)
+      hipLaunchKernelGGL(msda_l3p4_kernel<0>, grid, block, 0, stream, (const bf16_t*)value, ldv, spatial_shapes, level_start, loc, ld_loc, attn, ld_attn,
+                         ref, (bf16_t*)out, ldo, B, S, Q);
+    else
+      hipLaunchKernelGGL(msda_l3p4_kernel<1>, grid, block, 0, stream, (const bf16_t*)value, ldv, spatial_shapes, level_start, loc, ld_loc, attn, ld_attn,
+                         ref, (bf16_t*)out, ldo, B, S, Q);
+    return fx_launch_status();
+  }
   if (mode == 0)
     hipLaunchKernelGGL(msda_kernel<0>, grid, block, 0, stream, (const bf16_t*)value, ldv, spatial_shapes, level_start, L, P, loc, ld_loc,
                        attn, ld_attn, ref, (bf16_t*)out, ldo, B, S, Q, M);
