@@ -38,6 +38,7 @@ __device__ __forceinline__ int rc_off(int row, int chunk, int rowb) { return row
 // their weights into the scratch with one coalesced pass and compute from LDS (K4 with lane = row, so that a wave reads two
 // addresses per instruction: broadcasts).  A GEMM stage keeps its bias vector there (no global load per 32-channel pass).
 #define RC_SCRATCH 12288
+#define RC_RING 8    // weight fragments in flight per wave (16 measured the same: the stages are not waiting on this stream's round trips)
 __global__ __launch_bounds__(512, 1) void row_chain_kernel(const fx_rc_stage* __restrict__ prog, int nstages, int M, int bias_off, unsigned long long* dbg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* biasL = reinterpret_cast<float*>(smem + bias_off);
@@ -145,10 +146,10 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(const fx_rc_stage* __
         const int ic = i < total ? i : total - 1;
         return wb + ((size_t)(wave + ((ic >> ksh) << 3)) * KS + (ic & (KS - 1))) * 512;
       };
-      bf16x8 ar[8];
+      bf16x8 ar[RC_RING];
       if (npass > 0) {   // the ring's first fragments go out before the bias copy: one L2 round trip covers both
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < RC_RING; ++i) {
           ar[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
           c3_ldg_async(ar[i], frag(i));
         }
@@ -156,26 +157,15 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(const fx_rc_stage* __
       for (int n = tid; n < N; n += 512) biasL[n] = st.bias ? st.bias[n] : 0.0f;
       __syncthreads();
       if (npass > 0) {
-        for (int ps = 0; ps < npass; ++ps) {
-          const int nb = wave + ps * 8;
-          f32x16 acc;
+        f32x16 acc;
+        auto init_acc = [&](int nb) {
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
             const float4 bb = *reinterpret_cast<const float4*>(biasL + nb * 32 + 8 * gq + 4 * half);
             acc[4 * gq] = bb.x; acc[4 * gq + 1] = bb.y; acc[4 * gq + 2] = bb.z; acc[4 * gq + 3] = bb.w;
           }
-#pragma unroll 1
-          for (int ks0 = 0; ks0 < KS; ks0 += 8) {
-            auto step = [&](auto ic) {
-              constexpr int i = decltype(ic)::value;
-              const bf16x8 xb = *reinterpret_cast<const bf16x8*>(smem + st.src + rc_off(l32, (ks0 + i) * 2 + half, rowb));
-              c3_wait<7>(ar[i]);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[i], xb, acc, 0, 0, 0);
-              c3_ldg_async(ar[i], frag(ps * KS + ks0 + i + 8));
-            };
-            c3_static_for<8>(step);
-          }
-          // epilogue: lane = row l32, channels nb*32 + 8*gq + 4*half + 0..3
+        };
+        auto epilogue = [&](int nb) {   // lane = row l32, channels nb*32 + 8*gq + 4*half + 0..3
           const int m = m0 + l32;
 #pragma unroll
           for (int gq = 0; gq < 4; ++gq) {
@@ -193,18 +183,51 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(const fx_rc_stage* __
               else *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(st.g0) + (size_t)m * st.ld + n) = o;
             }
           }
+        };
+        // The stream's LAST group of eight fragments is peeled off the loops: nothing is left to request behind it, so its waits count
+        // down (loads return in order) and the stage ends without draining eight throw-away re-reads - one L2 round trip per stage.
+        // (Peeled, not branched: two paths that both rewrite the ring registers would meet in a phi, and a register copy of a fragment
+        // whose load is still in flight reads garbage - hipcc does not know about the asm loads.)
+        // activation fragment of k-step ks (k-steps wrap: the read issued behind a pass's last MFMA is the next pass's first)
+        auto xfrag = [&](int ks) { return *reinterpret_cast<const bf16x8*>(smem + st.src + rc_off(l32, (ks & (KS - 1)) * 2 + half, rowb)); };
+        bf16x8 xb[2];
+        xb[0] = xfrag(0);
+        for (int ps = 0; ps < npass; ++ps) {
+          const int nb = wave + ps * 8;
+          init_acc(nb);
+          const int kend = ps == npass - 1 ? KS - RC_RING : KS;
+#pragma unroll 1
+          for (int ks0 = 0; ks0 < kend; ks0 += RC_RING) {
+            auto step = [&](auto ic) {
+              constexpr int i = decltype(ic)::value;
+              xb[(i + 1) & 1] = xfrag(ks0 + i + 1);   // next k-step's rows (wraps to k-step 0 for the next pass), one MFMA ahead of its use
+              c3_wait<RC_RING - 1>(ar[i]);
+              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[i], xb[i & 1], acc, 0, 0, 0);
+              c3_ldg_async(ar[i], frag(ps * KS + ks0 + i + RC_RING));
+            };
+            c3_static_for<RC_RING>(step);
+          }
+          if (ps < npass - 1) epilogue(nb);
         }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) c3_wait<0>(ar[i]);
+        {
+          auto step_tail = [&](auto ic) {
+            constexpr int i = decltype(ic)::value;
+            if constexpr (i + 1 < RC_RING) xb[(i + 1) & 1] = xfrag(KS - RC_RING + i + 1);
+            c3_wait<RC_RING - 1 - i>(ar[i]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[i], xb[i & 1], acc, 0, 0, 0);
+          };
+          c3_static_for<RC_RING>(step_tail);
+          epilogue(wave + (npass - 1) * 8);
+        }
       }
     } else if (st.type == RC_GEMM_LN) {
       // N = 256: wave -> channels [32*wave, +32); LayerNorm over the row on the fp32 accumulators
       const int KS = K >> 4, rowb = K * 2;
       float* red = reinterpret_cast<float*>(smem + st.ld2);   // [8 waves][32 rows] reduction scratch (LDS byte offset in ld2)
       const bf16_t* w = reinterpret_cast<const bf16_t*>(st.w) + (size_t)wave * KS * 512 + lane * 8;
-      bf16x8 ar[8];
+      bf16x8 ar[RC_RING];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) {
+      for (int i = 0; i < RC_RING; ++i) {
         ar[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
         c3_ldg_async(ar[i], w + (size_t)i * 512);
       }
@@ -214,20 +237,29 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(const fx_rc_stage* __
         const float4 bb = *reinterpret_cast<const float4*>(st.bias + wave * 32 + 8 * gq + 4 * half);
         acc[4 * gq] = bb.x; acc[4 * gq + 1] = bb.y; acc[4 * gq + 2] = bb.z; acc[4 * gq + 3] = bb.w;
       }
+      auto xfrag = [&](int ks) { return *reinterpret_cast<const bf16x8*>(smem + st.src + rc_off(l32, ks * 2 + half, rowb)); };
+      bf16x8 xb[2];
+      xb[0] = xfrag(0);
 #pragma unroll 1
-      for (int ks0 = 0; ks0 < KS; ks0 += 8) {
+      for (int ks0 = 0; ks0 < KS - RC_RING; ks0 += RC_RING) {
         auto step = [&](auto ic) {
           constexpr int i = decltype(ic)::value;
-          const bf16x8 xb = *reinterpret_cast<const bf16x8*>(smem + st.src + rc_off(l32, (ks0 + i) * 2 + half, rowb));
-          c3_wait<7>(ar[i]);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[i], xb, acc, 0, 0, 0);
-          const int kn = ks0 + i + 8;
-          c3_ldg_async(ar[i], w + (size_t)(kn < KS ? kn : KS - 1) * 512);
+          xb[(i + 1) & 1] = xfrag(ks0 + i + 1);
+          c3_wait<RC_RING - 1>(ar[i]);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[i], xb[i & 1], acc, 0, 0, 0);
+          c3_ldg_async(ar[i], w + (size_t)(ks0 + i + RC_RING) * 512);
         };
-        c3_static_for<8>(step);
+        c3_static_for<RC_RING>(step);
       }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) c3_wait<0>(ar[i]);
+      {   // last eight fragments: counted-down waits, no refills, no drain (see RC_GEMM)
+        auto step_tail = [&](auto ic) {
+          constexpr int i = decltype(ic)::value;
+          if constexpr (i + 1 < RC_RING) xb[(i + 1) & 1] = xfrag(KS - RC_RING + i + 1);
+          c3_wait<RC_RING - 1 - i>(ar[i]);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[i], xb[i & 1], acc, 0, 0, 0);
+        };
+        c3_static_for<RC_RING>(step_tail);
+      }
       if (st.aux >= 0) {   // + residual (bf16 LDS buffer [32][256])
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
