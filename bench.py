@@ -273,10 +273,11 @@ def _wgrad_roofline(nn_, stepper, imgs, targets, family="fai_detr"):
     try:
         if family == "fai_detr":
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_train_hbm_latest.json")))
-            hit = next(v for k, v in pmc.items() if k.startswith("conv_wgrad_kernel"))
-            traffic = round(hit["fetch_bytes_per_launch"] + hit["write_bytes_per_launch"])
+            hits = [v for k, v in pmc.items() if k.startswith("conv_wgrad_kernel")]   # the pointwise and the im2col instantiation
+            n_ = sum(v["launches"] for v in hits)
+            traffic = round(sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in hits) / n_)
             traffic_src = ("profiles/pmc_train_hbm_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --train`, calibrated counter "
-                           "units; average over ALL conv_wgrad_kernel launches of a step - the 96 conv layers the event bracket covers plus the ~100 smaller Linear layers - partial-slab stores included)")
+                           "units; launch-weighted average over ALL conv_wgrad_kernel launches of a step, both instantiations - the 96 conv layers the event bracket covers plus the ~100 smaller Linear layers - partial-slab stores included)")
     except Exception:
         pass
     return {"bound": "mfma" if ai >= PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm", "kernel": "conv_wgrad_kernel (+ slab sum / unpack)",
