@@ -118,6 +118,36 @@ class BoxHungarianMatcher:
                   "fx_lsa_status_f32")
         return pi, ti
 
+    def match_packed_sets(self, logits_list, boxes_list, tg: _Targets):
+        """match_packed for S prediction sets of one shape against the SAME targets (the main output + the auxiliary decoder / encoder
+        sets of SetCriterion.forward, modelling.py:572-611) as ONE cost launch and ONE assignment launch over S*B virtual images: the
+        solver is one wave per image, so S launches of B waves each leave the GPU empty S times in a row (7 x 88 us per RT-DETR step).
+        Returns [(pi, ti)] * S - the slices are exactly what S match_packed calls return (indices are local to an image)."""
+        S = len(logits_list)
+        if S == 1 or tg.n == 0:
+            return [self.match_packed(l, b, tg) for l, b in zip(logits_list, boxes_list)]
+        lib = _lib.load()
+        B, Q, K = logits_list[0].shape
+        dev = logits_list[0].device
+        logits = torch.stack([l.float() for l in logits_list]).contiguous()       # [S,B,Q,K]
+        boxes = torch.stack([b.float() for b in boxes_list]).contiguous()
+        sup = getattr(tg, "_super", None)
+        if sup is None or sup[0] != S:
+            off = np.concatenate([tg.off_host[:-1] + s * tg.n for s in range(S)] + [np.array([S * tg.n], np.int32)]).astype(np.int32)
+            sup = (S, h2d_i32(off, dev), tg.labels.repeat(S).contiguous(), tg.boxes.repeat(S, 1).contiguous())
+            tg._super = sup
+        _, offsets, labels, tboxes = sup
+        pi = torch.zeros(S * tg.n, dtype=torch.int32, device=dev)
+        ti = torch.zeros(S * tg.n, dtype=torch.int32, device=dev)
+        cost = torch.empty(S * B, Q, tg.tmax, dtype=torch.float32, device=dev)
+        st = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        check(lib.fx_detr_match_cost_f32(logits.data_ptr(), K, boxes.data_ptr(), labels.data_ptr(), tboxes.data_ptr(), offsets.data_ptr(), S * B, Q,
+                                         K, tg.tmax, float(self.cost_class), float(self.cost_bbox), float(self.cost_giou), float(self.alpha),
+                                         float(self.gamma), cost.data_ptr(), st), "fx_detr_match_cost_f32")
+        check(lib.fx_lsa_status_f32(cost.data_ptr(), S * B, Q, tg.tmax, offsets.data_ptr(), pi.data_ptr(), ti.data_ptr(), lsa_status(dev).data_ptr(), st),
+              "fx_lsa_status_f32")
+        return [(pi[s * tg.n:(s + 1) * tg.n], ti[s * tg.n:(s + 1) * tg.n]) for s in range(S)]
+
     @torch.no_grad()
     def forward(self, outputs: Dict[str, torch.Tensor], targets: Sequence) -> List[Tuple[torch.Tensor, torch.Tensor]]:
         tg = _Targets(targets, outputs["pred_logits"].device)

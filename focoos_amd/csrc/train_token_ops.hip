@@ -130,9 +130,21 @@ __global__ __launch_bounds__(256) void layernorm256_bwd_kernel(const bf16_t* __r
   float ag[4] = {0, 0, 0, 0}, ab[4] = {0, 0, 0, 0};
   const float4 gm = *reinterpret_cast<const float4*>(gamma + lane * 4);
   const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-    uint2 xv = *reinterpret_cast<const uint2*>(x + (int64_t)row * ldx + lane * 4);
-    uint2 dv = *reinterpret_cast<const uint2*>(dy + (int64_t)row * lddy + lane * 4);
+  // a wave walks ~16 rows: the next row's loads are issued before this row's four wave reductions (the loop was one memory round
+  // trip per row: 24 us for the decoder's 4800-row LayerNorms, 21 of them on the critical path of a training step)
+  const int step = gridDim.x * 4;
+  int row = blockIdx.x * 4 + wave;
+  uint2 xn = make_uint2(0, 0), dn = make_uint2(0, 0);
+  if (row < rows) {
+    xn = *reinterpret_cast<const uint2*>(x + (int64_t)row * ldx + lane * 4);
+    dn = *reinterpret_cast<const uint2*>(dy + (int64_t)row * lddy + lane * 4);
+  }
+  for (; row < rows; row += step) {
+    const uint2 xv = xn, dv = dn;
+    if (row + step < rows) {
+      xn = *reinterpret_cast<const uint2*>(x + (int64_t)(row + step) * ldx + lane * 4);
+      dn = *reinterpret_cast<const uint2*>(dy + (int64_t)(row + step) * lddy + lane * 4);
+    }
     const float v[4] = {__uint_as_float(xv.x << 16), __uint_as_float(xv.x & 0xffff0000u), __uint_as_float(xv.y << 16),
                         __uint_as_float(xv.y & 0xffff0000u)};
     const float d[4] = {__uint_as_float(dv.x << 16), __uint_as_float(dv.x & 0xffff0000u), __uint_as_float(dv.y << 16),

@@ -298,6 +298,9 @@ class SetCriterionTrain(nn.Module):
         else:
             num_boxes = max(float(tg.n), 1.0)     # single process: a host integer - no device round trip, the launch queue keeps running ahead
         sets = [("", outputs)] + [(f"_{i}", a) for i, a in enumerate(outputs.get("aux_outputs", []))]
+        if fixed_matches is None and os.environ.get("FX_LSA_BATCHED", "1") != "0" and len({tuple(o["pred_logits"].shape) for _, o in sets}) == 1:
+            # the assignments of all prediction sets in one launch (they are independent, and each is only B waves of work)
+            fixed_matches = self.matcher.match_packed_sets([o["pred_logits"].detach() for _, o in sets], [o["pred_boxes"].detach() for _, o in sets], tg)
         losses, matches = {}, []
         for j, (suffix, o) in enumerate(sets):
             l, m = self._one_set(o, tg, num_boxes, None if fixed_matches is None else fixed_matches[j])

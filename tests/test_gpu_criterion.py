@@ -304,3 +304,29 @@ def test_box_loss_with_gradient_vs_torch_autograd(counts):
     check(lib.fx_detr_box_loss_bwd_f32(pg.data_ptr(), off_d.data_ptr(), pid.data_ptr(), B, Q, n, None, None, dboxes.data_ptr(), stream()))
     torch.cuda.synchronize()
     assert float(dboxes.abs().max()) == 0.0
+
+
+def test_batched_matching_of_all_prediction_sets_equals_per_set_matching():
+    """BoxHungarianMatcher.match_packed_sets (all prediction sets of a step against the same targets as ONE cost launch + ONE assignment
+    launch over S*B virtual images) returns exactly the S per-set results of match_packed; images without targets and a set count of 1
+    included."""
+    from focoos_amd.criterion import BoxHungarianMatcher, _Targets
+    from focoos_amd.ports import DETRTargets
+
+    g = torch.Generator().manual_seed(21)
+    B, Q, K, S = 5, 60, 17, 4
+    sizes = [7, 0, 13, 1, 20]
+    targets = [DETRTargets(labels=torch.randint(0, K, (t,), generator=g).to(DEV),
+                           boxes=torch.cat([torch.rand(t, 2, generator=g) * 0.6 + 0.2, torch.rand(t, 2, generator=g) * 0.3 + 0.05], -1).to(DEV)) for t in sizes]
+    tg = _Targets(targets, DEV)
+    logits = [torch.randn(B, Q, K, generator=g).bfloat16().to(DEV) for _ in range(S)]
+    boxes = [torch.cat([torch.rand(B, Q, 2, generator=g) * 0.6 + 0.2, torch.rand(B, Q, 2, generator=g) * 0.3 + 0.05], -1).to(DEV) for _ in range(S)]
+    m = BoxHungarianMatcher()
+    single = [m.match_packed(l, b, tg) for l, b in zip(logits, boxes)]
+    batched = m.match_packed_sets(logits, boxes, tg)
+    torch.cuda.synchronize()
+    assert len(batched) == S
+    for (p0, t0), (p1, t1) in zip(single, batched):
+        assert torch.equal(p0, p1) and torch.equal(t0, t1)
+    one = m.match_packed_sets(logits[:1], boxes[:1], tg)
+    assert torch.equal(one[0][0], single[0][0]) and torch.equal(one[0][1], single[0][1])
