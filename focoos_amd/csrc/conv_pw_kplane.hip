@@ -249,12 +249,12 @@ static int launch_pwk(PWKArgs& a, hipStream_t stream) {
   return fx_launch_status();
 }
 
-// 1 iff fx_launch_pw_kplane covers (C, N, epilogue mode): K = 256 / 512 with every pointwise epilogue but the two-operand training one
+// 1 iff fx_launch_pw_kplane covers (C, N, epilogue mode): K = 256 / 512 with every pointwise epilogue
 bool fx_pw_kplane_supported(int C, int N, int mode) {
   if (N <= 0 || N % 256 != 0 || N > 4096) return false;
   static const int k512_res = fx_tune("FX_PWK_K512_RES", 1);   // A/B knob: K = 512 layers with a residual (else conv3x3_flat.hip's KT = 1 form)
-  if (C == 256) return mode == 0 || mode == 1 || mode == 3 || mode == 4 || mode == 5;
-  if (C == 512) return mode == 0 || mode == 1 || mode == 3 || (k512_res && (mode == 4 || mode == 5));
+  if (C == 256) return mode == 0 || mode == 1 || mode == 3 || mode == 4 || mode == 5 || mode == 6;
+  if (C == 512) return mode == 0 || mode == 1 || mode == 3 || (k512_res && (mode == 4 || mode == 5 || mode == 6));
   return false;
 }
 
@@ -272,6 +272,7 @@ int fx_launch_pw_kplane(const ConvArgs& c, const bf16_t* w_frag, hipStream_t str
       case 3: return launch_pwk<256, FX_ACT_NONE, 0>(a, stream);
       case 4: return launch_pwk<256, FX_ACT_RELU, 1>(a, stream);
       case 5: return launch_pwk<256, FX_ACT_NONE, 3>(a, stream);
+      case 6: return launch_pwk<256, FX_ACT_NONE, 1>(a, stream);   // training: input gradient + the shortcut branch's gradient
     }
   } else {
     switch (mode) {
@@ -280,6 +281,7 @@ int fx_launch_pw_kplane(const ConvArgs& c, const bf16_t* w_frag, hipStream_t str
       case 3: return launch_pwk<512, FX_ACT_NONE, 0>(a, stream);
       case 4: return launch_pwk<512, FX_ACT_RELU, 1>(a, stream);
       case 5: return launch_pwk<512, FX_ACT_NONE, 3>(a, stream);
+      case 6: return launch_pwk<512, FX_ACT_NONE, 1>(a, stream);
     }
   }
   return FX_ERR_UNSUPPORTED;

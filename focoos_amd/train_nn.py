@@ -345,11 +345,18 @@ def _bn_backward(layer, dy: torch.Tensor, z: torch.Tensor, residual: Optional[to
 _WGRAD_WS: Dict[torch.device, torch.Tensor] = {}
 
 
+_WGRAD_WS_RETIRED: List[torch.Tensor] = []
+
+
 def _wgrad_workspace(numel: int, dev) -> torch.Tensor:
     """One reusable fp32 staging buffer for the per-pixel-range partial weight gradients (launches are serial on one stream and
     each unpack consumes the partials before the next layer overwrites them)."""
     ws = _WGRAD_WS.get(dev)
     if ws is None or ws.numel() < numel:
+        if ws is not None:
+            # launches queued earlier on the side stream may still be reading the old buffer: it is retired, not freed (the caching
+            # allocator would hand its memory to the next allocation of the main stream); growth happens a handful of times per process
+            _WGRAD_WS_RETIRED.append(ws)
         ws = torch.empty(max(numel, 16 << 20), dtype=torch.float32, device=dev)
         _WGRAD_WS[dev] = ws
     return ws
