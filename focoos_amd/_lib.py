@@ -24,7 +24,7 @@ class FxConvDesc(C.Structure):
         ("Ho", C.c_int32), ("Wo", C.c_int32), ("N", C.c_int32), ("ldy", C.c_int32), ("ldr", C.c_int32),
         ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("pool2", C.c_int32), ("act", C.c_int32), ("out_f32", C.c_int32), ("residual_after_act", C.c_int32),
-        ("y_batch_stride", C.c_int64), ("w_frag", C.c_void_p),
+        ("y_batch_stride", C.c_int64), ("w_frag", C.c_void_p), ("mask", C.c_void_p), ("ldm", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

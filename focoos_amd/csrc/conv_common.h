@@ -19,6 +19,9 @@ struct ConvArgs {
   int M, Ktot, nNt, Nstore;
   unsigned x_bytes, w_bytes, r_bytes;  // buffer sizes for the bounds-checked buffer loads (< 4 GiB)
   int64_t y_bstride;          // 0: contiguous
+  const bf16_t* mask;         // optional: result *= (mask > 0) (implicit-GEMM kernels only)
+  int ldm;
+  unsigned m_bytes;
 };
 
 // Byte offset of 16-byte chunk `chunk` of tile row `row` in an LDS tile with BK bf16 per row.  The XOR swizzle makes the

@@ -223,6 +223,12 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void conv_igemm_kernel(con
 #pragma unroll
           for (int i = 0; i < 8; ++i) v[i] = rf[i] > 0.0f ? v[i] : 0.0f;
         }
+        if (p.mask) {   // ReLU backward of the layer that consumes this gradient (see fx_conv_desc.mask)
+          float mf[8];
+          unpack_bf16x8(*reinterpret_cast<const uint4*>(p.mask + (size_t)m * p.ldm + n), mf);
+#pragma unroll
+          for (int i = 0; i < 8; ++i) v[i] = mf[i] > 0.0f ? v[i] : 0.0f;
+        }
         int64_t yoff;
         if (p.y_bstride) {
           int bb = m / HoWo;
@@ -307,6 +313,15 @@ static int conv_prepare(const fx_conv_desc* d, ConvArgs& a) {
   a.x_bytes = (unsigned)x_bytes;
   a.w_bytes = (unsigned)w_bytes;
   a.r_bytes = (unsigned)r_bytes;
+  a.mask = reinterpret_cast<const bf16_t*>(d->mask);
+  a.ldm = d->ldm;
+  a.m_bytes = 0;
+  if (d->mask) {
+    FX_CHECK_ARG(d->ldm >= Nstore && d->ldm % 8 == 0 && ((uintptr_t)d->mask % 16) == 0 && !d->out_f32 && !d->pool2);
+    const int64_t m_bytes = (((int64_t)d->B * d->Ho * d->Wo - 1) * d->ldm + Nstore) * 2;
+    if (m_bytes >= 0xFFFFFFF0ll) return FX_ERR_UNSUPPORTED;
+    a.m_bytes = (unsigned)m_bytes;
+  }
   return FX_OK;
 }
 
@@ -324,7 +339,7 @@ static ConvRoute conv_route(const fx_conv_desc* d, const ConvArgs& a) {
   // per-CU rate of the implicit-GEMM tiles and the other part's launches take the idle CUs: RT-DETR 3883 -> 3990 img/s
   // (profiles/r03_threshold_sweep.txt); one part alone (FX_STREAMS=1) 3334 -> 3420
   const int c3_min_m = fx_tune("FX_CONV3_MIN_M", 5000), pw_min_m = fx_tune("FX_PW_MIN_M", 5000);
-  if (d->w_frag && ((uintptr_t)d->w_frag % 16) == 0 && d->stride == 1 && !d->pool2 && !d->out_f32) {
+  if (!d->mask && d->w_frag && ((uintptr_t)d->w_frag % 16) == 0 && d->stride == 1 && !d->pool2 && !d->out_f32) {
     const int mode = fx_c3_epilogue_mode(d->act, d->residual != nullptr, d->residual_after_act);
     static const int c32_on = fx_tune("FX_C3_C32", 1);
     if (c3_on && d->KH == 3 && d->KW == 3 && d->pad == 1 && !d->y_batch_stride && ((mode >= 0 && mode <= 3) || mode == 5) && a.M >= c3_min_m &&
@@ -345,7 +360,7 @@ static ConvRoute conv_route(const fx_conv_desc* d, const ConvArgs& a) {
   // step - for K = 256 the whole reduction is ONE load phase (all 16 loads per lane in flight at once), no K loop.
   if (!d->pool2 && a.M <= small_m && d->C % 256 == 0 && a.Ktot <= 1024) return R_SMALL_M;
   const bool k64 = (d->C % 64 == 0) && (a.Ktot >= k64_min);
-  if (!d->pool2 && fx_conv_dma_eligible(a)) return R_DMA;
+  if (!d->pool2 && !d->mask && fx_conv_dma_eligible(a)) return R_DMA;
   if (d->pool2) return d->C % 64 != 0 ? R_UNSUPPORTED : R_POOL;
   if (k64) return d->N > 64 ? R_K64_N128 : (d->N > 32 ? R_K64_N64 : R_K64_N32);
   return d->N > 64 ? R_K32_N128 : (d->N > 32 ? R_K32_N64 : R_K32_N32);

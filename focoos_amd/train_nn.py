@@ -17,6 +17,7 @@ order; every FLOP and every byte moved inside a node is a HIP kernel of this rep
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -186,13 +187,13 @@ _DESC_CACHE: Dict[tuple, tuple] = {}
 
 def _conv_call(lib, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], N: int, KH: int, KW: int, stride: int, pad: int,
                act: Optional[str], residual: Optional[torch.Tensor], res_mode: int = 0, out_f32: bool = False,
-               w_frag: Optional[torch.Tensor] = None) -> torch.Tensor:
+               w_frag: Optional[torch.Tensor] = None, mask: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fx_conv2d_nhwc_bf16 on NHWC bf16 tensors; ``w`` is a packed [Npad][KH][KW][C] bf16 image, ``w_frag`` its optional copy in MFMA
     fragment order (routes eligible layers to the halo / pointwise kernels).  ``res_mode``: 0 = add ``residual`` before the activation,
     2 = multiply by (residual > 0) - the ReLU backward of the layer that produced ``residual``."""
     B, H, W_, Cc = x.shape
     key = (w.data_ptr(), bias.data_ptr() if bias is not None else 0, B, H, W_, Cc, N, KH, KW, stride, pad, act, residual is not None, res_mode, out_f32,
-           w_frag.data_ptr() if w_frag is not None else 0)
+           w_frag.data_ptr() if w_frag is not None else 0, mask is not None)
     ent = _DESC_CACHE.get(key)
     if ent is None:
         Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W_ + 2 * pad - KW) // stride + 1
@@ -212,6 +213,7 @@ def _conv_call(lib, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tenso
     y = torch.empty(oshape, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
     d.x, d.y = x.data_ptr(), y.data_ptr()
     d.residual = residual.data_ptr() if residual is not None else None
+    d.mask, d.ldm = (mask.data_ptr(), N) if mask is not None else (None, 0)   # result *= (mask > 0): [B,Ho,Wo,N] bf16 (fx_conv_desc.mask)
     check(lib.fx_conv2d_nhwc_bf16(ref, _stream(x.device)), "fx_conv2d_nhwc_bf16")
     return y
 
@@ -735,8 +737,12 @@ class _BottleneckFn(torch.autograd.Function):
         st = _stream(dev)
         dy = dy.contiguous()
         B, Ho, Wo, N = y.shape
-        dz_c = torch.empty_like(y)   # gradient of conv_c's output AND of the shortcut branch (pre-activation residual add)
-        check(lib.fx_relu_bwd_bf16(dy.data_ptr(), N, None, 0, y.data_ptr(), N, dz_c.data_ptr(), N, B * Ho * Wo, N, 1, st), "fx_relu_bwd_bf16")
+        if getattr(blk, "_premasked_ptr", 0) == dy.data_ptr() and dy.dtype == y.dtype:
+            dz_c = dy   # the next block's backward already applied relu'(y) in the epilogue of its branch2a input gradient (below)
+        else:
+            dz_c = torch.empty_like(y)   # gradient of conv_c's output AND of the shortcut branch (pre-activation residual add)
+            check(lib.fx_relu_bwd_bf16(dy.data_ptr(), N, None, 0, y.data_ptr(), N, dz_c.data_ptr(), N, B * Ho * Wo, N, 1, st), "fx_relu_bwd_bf16")
+        blk._premasked_ptr = 0
         need = ctx.needs_input_grad
         dwc = _conv_param_grads(c_l, b, dz_c, c_l.scale) if need[3] else None
         dz_b = _conv_call(lib, dz_c, c_l.w_dgrad, None, c_l.cin, 1, 1, 1, 0, None, b, res_mode=2, w_frag=c_l.w_dgrad_frag)       # dgrad_c * relu'(b)
@@ -765,7 +771,16 @@ class _BottleneckFn(torch.autograd.Function):
                     dshort = dxs
         else:
             dshort = dz_c
-        dx = _conv_call(lib, dz_a, a_l.w_dgrad, None, a_l.cin, 1, 1, 1, 0, None, dshort, w_frag=a_l.w_dgrad_frag) if need[0] else None   # + shortcut gradient in the epilogue
+        # + shortcut gradient in the epilogue; and, when x is nothing but the previous block's ReLU output (premask_input), x that block's
+        # relu'(.) as well - its backward then starts from dz_c directly (one pass over the widest tensors of the stage less per block)
+        prev = getattr(blk, "_prev_block", None)
+        pm = x if (prev is not None and PREMASK[0] and need[0]) else None
+        dx = _conv_call(lib, dz_a, a_l.w_dgrad, None, a_l.cin, 1, 1, 1, 0, None, dshort, w_frag=None if pm is not None else a_l.w_dgrad_frag,
+                        mask=pm) if need[0] else None
+        if pm is not None:
+            # tell the previous block which tensor arrives pre-masked (by address: if autograd hands it anything else - a copy, a sum - it
+            # applies its own ReLU backward, and masking twice is the identity)
+            prev._premasked_ptr = dx.data_ptr()
         return dx, dwa, dwb, dwc, dws, None
 
 
@@ -778,6 +793,7 @@ class BottleNeck(nn.Module):
         self.branch2b = ConvNormLayer(lib, width, width, 3, stride, "relu")
         self.branch2c = ConvNormLayer(lib, width, width * 4, 1, 1, "relu")  # ReLU applied AFTER the residual add (fused epilogue)
         self.has_short = not shortcut
+        self._premasked_ptr = 0   # address of an output gradient that arrives with relu'(output) already applied (see _BottleneckFn.backward)
         if self.has_short:
             self.short = ConvNormLayer(lib, ch_in, width * 4, 1, 1, None) if (first_stage or stride == 1) else _Short(lib, ch_in, width * 4)
 
@@ -791,10 +807,19 @@ class BottleNeck(nn.Module):
         return self.branch2c(out, residual=short)  # relu(conv + bn + short)
 
 
+# ReLU backward of a bottleneck's output fused into the NEXT block's branch2a input-gradient convolution (fx_conv_desc.mask), for the stages
+# whose block-input gradient runs on the implicit-GEMM kernels (res2 / res3: branch width <= 128 - the widest tensors of the network; the
+# deeper stages' pointwise layers run on the resident-tile kernel, which has no second epilogue operand).  FX_PREMASK=0: off.
+PREMASK = [os.environ.get("FX_PREMASK", "1") != "0"]
+
+
 class _Blocks(nn.Module):
     def __init__(self, blocks):
         super().__init__()
         self.blocks = nn.ModuleList(blocks)
+        for prev, cur in zip(blocks[:-1], blocks[1:]):   # cur's input is prev's ReLU output and nothing else consumes it
+            if isinstance(cur, BottleNeck) and isinstance(prev, BottleNeck) and cur.branch2a.cout <= 128:
+                object.__setattr__(cur, "_prev_block", prev)   # plain reference: not a registered submodule
 
     def forward(self, x):
         for b in self.blocks:

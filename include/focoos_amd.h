@@ -74,6 +74,11 @@ typedef struct fx_conv_desc {
                                  Wp[nb][ks][l][i] = w[nb*32 + l%32][ks*16 + (l/32)*8 + i] (k = (kh*KW + kw)*C + c).  When present,
                                  3x3 / stride-1 / pad-1 layers with N in {64,128,256}, C % 64 == 0 run on the halo kernel
                                  (conv3x3_flat.hip: the pixels are fetched once for all nine taps).  NULL: implicit GEMM. */
+  const void* mask;           /* optional bf16 [B,Ho,Wo,ldm]: the result is multiplied by (mask > 0) after residual / activation - the ReLU
+                                 backward of the layer that CONSUMES y's gradient, fused into the producer of that gradient (training:
+                                 a bottleneck's block-input gradient = branch2a input gradient + shortcut gradient, masked by the block
+                                 input = the previous block's ReLU output; resnet.py:107-121).  Runs on the implicit-GEMM kernels only. */
+  int32_t ldm, reserved0;
 } fx_conv_desc;
 int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream);
 /* Label of the kernel fx_conv2d_nhwc_bf16 runs for this descriptor ("conv3x3_flat<256>", "pw_flat<K512>", "conv_igemm<128,128,64>",
