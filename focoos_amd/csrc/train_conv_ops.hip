@@ -260,11 +260,11 @@ __global__ __launch_bounds__(256) void slab_sum_kernel(float* __restrict__ part,
 __global__ __launch_bounds__(256) void unpack_sum_kernel(const float* __restrict__ part, int64_t split_stride, int splits, const float* __restrict__ scale,
                                                          float* __restrict__ dw, int N, int C, int KH, int KW, int Ceff, int accumulate) {
   const int c4n = Ceff / 4, taps = KH * KW;
-  const int64_t n4 = (int64_t)N * taps * c4n;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-    const int c0 = (int)(i % c4n) * 4;
-    const int64_t r = i / c4n;
-    const int tap = (int)(r % taps), n = (int)(r / taps);
+  const int n4 = N * taps * c4n;   // < 2^31 (checked by the launcher): 32-bit index arithmetic (three 64-bit divisions per element cost more than the loads)
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+    const int r = i / c4n;
+    const int c0 = (i - r * c4n) * 4;
+    const int n = r / taps, tap = r - n * taps;
     float4 a = reinterpret_cast<const float4*>(part)[i];
     int s = 1;
     for (; s + 3 < splits; s += 4) {
@@ -297,7 +297,7 @@ static int unpack_launch(const float* dw_eff, int64_t split_stride, int splits, 
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const int64_t slab = (int64_t)N * KH * KW * C_eff;
   static const int fused = fx_tune("FX_UNPACK_FUSED", 1);
-  if (splits > 1 && C_eff % 4 == 0 && split_stride % 4 == 0 && ((uintptr_t)dw_eff % 16) == 0) {
+  if (splits > 1 && C_eff % 4 == 0 && split_stride % 4 == 0 && ((uintptr_t)dw_eff % 16) == 0 && slab < (1ll << 31)) {
     int64_t grid = (slab / 4 + 255) / 256;
     if (grid > 8192) grid = 8192;
     if (fused) {
