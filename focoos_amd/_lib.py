@@ -110,6 +110,8 @@ SIGNATURES = {
     "fx_msda_train_fwd": [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "fx_msda_train_bwd": [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "fx_msda_bwd_slab_supported": [_vp, _i, _i, _i, _i, _i],
+    "fx_msda_prep_bf16": [_vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "fx_msda_prep_bwd_bf16": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "fx_msda_train_bwd_slab": [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "fx_adamw_workspace_bytes": [],
     "fx_adamw_step_f32": [_vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp],

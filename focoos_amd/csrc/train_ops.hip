@@ -506,6 +506,73 @@ extern "C" int fx_msda_train_bwd_slab(const void* value, int value_bf16, int ldv
   return fx_launch_status();
 }
 
+// ---- sampling locations / attention weights of one deformable layer from its raw projections, and the way back
+// (MSDeformableAttention.forward, fai_detr/modelling.py:866-879, 4-d reference branch):
+//   aw  = softmax over the L*P logits of a (query, head);   loc = ref_xy + off / P * ref_wh * 0.5
+// One launch each way instead of ~7 elementwise launches forward (casts, softmax, views, mul / div / add) and ~8 backward - the decoder
+// phases of a training step are bound by their launch count, not by their arithmetic.  One thread per (query, head).
+__global__ __launch_bounds__(256) void msda_prep_kernel(const bf16_t* __restrict__ off, int ld_off, const bf16_t* __restrict__ logit, int ld_logit,
+                                                        const float* __restrict__ ref, float* __restrict__ loc, float* __restrict__ aw, int BQ, int M,
+                                                        int LP, int P) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= BQ * M) return;
+  const int bq = i / M, h = i - bq * M;
+  const float4 r = *reinterpret_cast<const float4*>(ref + (int64_t)bq * 4);
+  const bf16_t* op = off + (int64_t)bq * ld_off + h * LP * 2;
+  const bf16_t* lp = logit + (int64_t)bq * ld_logit + h * LP;
+  float* locp = loc + ((int64_t)bq * M + h) * LP * 2;
+  float* awp = aw + ((int64_t)bq * M + h) * LP;
+  float mx = -INFINITY;
+  for (int k = 0; k < LP; ++k) mx = fmaxf(mx, bf16_to_f32(lp[k]));
+  float sum = 0.f;
+  for (int k = 0; k < LP; ++k) sum += expf(bf16_to_f32(lp[k]) - mx);
+  for (int k = 0; k < LP; ++k) {
+    awp[k] = expf(bf16_to_f32(lp[k]) - mx) / sum;
+    locp[2 * k] = r.x + bf16_to_f32(op[2 * k]) / (float)P * r.z * 0.5f;
+    locp[2 * k + 1] = r.y + bf16_to_f32(op[2 * k + 1]) / (float)P * r.w * 0.5f;
+  }
+}
+
+__global__ __launch_bounds__(256) void msda_prep_bwd_kernel(const float* __restrict__ grad_loc, const float* __restrict__ grad_attn,
+                                                            const float* __restrict__ aw, const float* __restrict__ ref, bf16_t* __restrict__ grad_off,
+                                                            int ld_off, bf16_t* __restrict__ grad_logit, int ld_logit, int BQ, int M, int LP, int P) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= BQ * M) return;
+  const int bq = i / M, h = i - bq * M;
+  const float4 r = *reinterpret_cast<const float4*>(ref + (int64_t)bq * 4);
+  const float sx = r.z * 0.5f / (float)P, sy = r.w * 0.5f / (float)P;
+  const float* gl = grad_loc + ((int64_t)bq * M + h) * LP * 2;
+  const float* ga = grad_attn + ((int64_t)bq * M + h) * LP;
+  const float* awp = aw + ((int64_t)bq * M + h) * LP;
+  bf16_t* go = grad_off + (int64_t)bq * ld_off + h * LP * 2;
+  bf16_t* gg = grad_logit + (int64_t)bq * ld_logit + h * LP;
+  float dot = 0.f;
+  for (int k = 0; k < LP; ++k) dot += awp[k] * ga[k];
+  for (int k = 0; k < LP; ++k) {
+    gg[k] = f32_to_bf16(awp[k] * (ga[k] - dot));   // softmax backward
+    go[2 * k] = f32_to_bf16(gl[2 * k] * sx);
+    go[2 * k + 1] = f32_to_bf16(gl[2 * k + 1] * sy);
+  }
+}
+
+extern "C" int fx_msda_prep_bf16(const void* off, int ld_off, const void* logit, int ld_logit, const float* ref, float* loc, float* aw, int BQ, int M,
+                                 int L, int P, fx_stream_t stream_) {
+  FX_CHECK_ARG(off && logit && ref && loc && aw && BQ > 0 && M > 0 && L > 0 && P > 0 && ld_off >= M * L * P * 2 && ld_logit >= M * L * P);
+  FX_CHECK_ARG(((uintptr_t)ref % 16) == 0);
+  hipLaunchKernelGGL(msda_prep_kernel, dim3((BQ * M + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)off, ld_off,
+                     (const bf16_t*)logit, ld_logit, ref, loc, aw, BQ, M, L * P, P);
+  return fx_launch_status();
+}
+
+extern "C" int fx_msda_prep_bwd_bf16(const float* grad_loc, const float* grad_attn, const float* aw, const float* ref, void* grad_off, int ld_off,
+                                     void* grad_logit, int ld_logit, int BQ, int M, int L, int P, fx_stream_t stream_) {
+  FX_CHECK_ARG(grad_loc && grad_attn && aw && ref && grad_off && grad_logit && BQ > 0 && M > 0 && L > 0 && P > 0);
+  FX_CHECK_ARG(ld_off >= M * L * P * 2 && ld_logit >= M * L * P && ((uintptr_t)ref % 16) == 0);
+  hipLaunchKernelGGL(msda_prep_bwd_kernel, dim3((BQ * M + 255) / 256), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), grad_loc, grad_attn, aw,
+                     ref, (bf16_t*)grad_off, ld_off, (bf16_t*)grad_logit, ld_logit, BQ, M, L * P, P);
+  return fx_launch_status();
+}
+
 extern "C" int fx_msda_f32_fwd(const float* value, const int32_t* spatial_shapes, const int32_t* level_start, int L, int P, const float* loc,
                                const float* attn, float* out, int B, int S, int Q, int M, fx_stream_t stream_) {
   return fx_msda_train_fwd(value, 0, M * 32, spatial_shapes, level_start, L, P, loc, attn, out, B, S, Q, M, stream_);

@@ -85,36 +85,88 @@ class _MSDAGroupFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        lib = _lib.load()
         value_all, shapes_t, starts_t, lc, aw = ctx.saved_tensors
-        B, S, Q, M, D, L, P, Nt = ctx.dims
-        sink, g = ctx.sink, ctx.g
-        sh = ctx.shapes_host
-        go_bf16 = grad_out.dtype == torch.bfloat16
-        slab = (sh is not None and os.environ.get("FX_MSDA_BWD_SLAB", "1") != "0"
-                and lib.fx_msda_bwd_slab_supported(sh.ctypes.data, L, P, Q, M, int(go_bf16)) == 1)
-        gl, ga = torch.empty_like(lc), torch.empty_like(aw)
-        if slab:
-            go = grad_out.contiguous() if go_bf16 else grad_out.float().contiguous()
-            if sink.buf is None:   # every layer overwrites its 256 columns: no zero-fill, no fp32 image, no cast
-                sink.buf = torch.empty(B, S, Nt, dtype=torch.bfloat16, device=value_all.device)
-            check(lib.fx_msda_train_bwd_slab(value_all.data_ptr() + g * M * D * 2, 1, Nt, shapes_t.data_ptr(), starts_t.data_ptr(), sh.ctypes.data, L, P,
-                                             lc.data_ptr(), aw.data_ptr(), go.data_ptr(), int(go_bf16), sink.buf.data_ptr() + g * M * D * 2, Nt,
-                                             gl.data_ptr(), ga.data_ptr(), B, S, Q, M, _stream(value_all.device)), "fx_msda_train_bwd_slab")
-        else:
-            go = grad_out.float().contiguous()
-            if sink.buf is None:
-                sink.buf = torch.zeros(B, S, Nt, dtype=torch.float32, device=value_all.device)
-            check(lib.fx_msda_train_bwd(value_all.data_ptr() + g * M * D * 2, 1, Nt, shapes_t.data_ptr(), starts_t.data_ptr(), L, P, lc.data_ptr(),
-                                        aw.data_ptr(), go.data_ptr(), sink.buf.data_ptr() + g * M * D * 4, Nt, 0, gl.data_ptr(), ga.data_ptr(), B, S, Q, M,
-                                        _stream(value_all.device)), "fx_msda_train_bwd")
-        sink.count += 1
-        gv = None
-        if sink.count == sink.G:   # every layer has delivered its slice
-            gv = sink.buf if sink.buf.dtype == torch.bfloat16 else sink.buf.to(torch.bfloat16)
-            sink.buf, sink.count = None, 0
+        gv, gl, ga = _msda_group_backward(value_all, shapes_t, starts_t, lc, aw, grad_out, ctx.sink, ctx.g, ctx.dims, ctx.shapes_host)
         d1, d2 = ctx.in_dtypes
         return gv, None, None, None, None, gl.to(d1), ga.to(d2), None
+
+
+def _msda_group_backward(value_all, shapes_t, starts_t, lc, aw, grad_out, sink, g, dims, sh):
+    """Backward core of the grouped deformable attention: (value gradient or None, grad_loc f32, grad_attn f32)."""
+    lib = _lib.load()
+    B, S, Q, M, D, L, P, Nt = dims
+    go_bf16 = grad_out.dtype == torch.bfloat16
+    slab = (sh is not None and os.environ.get("FX_MSDA_BWD_SLAB", "1") != "0"
+            and lib.fx_msda_bwd_slab_supported(sh.ctypes.data, L, P, Q, M, int(go_bf16)) == 1)
+    gl, ga = torch.empty_like(lc), torch.empty_like(aw)
+    if slab:
+        go = grad_out.contiguous() if go_bf16 else grad_out.float().contiguous()
+        if sink.buf is None:   # every layer overwrites its 256 columns: no zero-fill, no fp32 image, no cast
+            sink.buf = torch.empty(B, S, Nt, dtype=torch.bfloat16, device=value_all.device)
+        check(lib.fx_msda_train_bwd_slab(value_all.data_ptr() + g * M * D * 2, 1, Nt, shapes_t.data_ptr(), starts_t.data_ptr(), sh.ctypes.data, L, P,
+                                         lc.data_ptr(), aw.data_ptr(), go.data_ptr(), int(go_bf16), sink.buf.data_ptr() + g * M * D * 2, Nt,
+                                         gl.data_ptr(), ga.data_ptr(), B, S, Q, M, _stream(value_all.device)), "fx_msda_train_bwd_slab")
+    else:
+        go = grad_out.float().contiguous()
+        if sink.buf is None:
+            sink.buf = torch.zeros(B, S, Nt, dtype=torch.float32, device=value_all.device)
+        check(lib.fx_msda_train_bwd(value_all.data_ptr() + g * M * D * 2, 1, Nt, shapes_t.data_ptr(), starts_t.data_ptr(), L, P, lc.data_ptr(),
+                                    aw.data_ptr(), go.data_ptr(), sink.buf.data_ptr() + g * M * D * 4, Nt, 0, gl.data_ptr(), ga.data_ptr(), B, S, Q, M,
+                                    _stream(value_all.device)), "fx_msda_train_bwd")
+    sink.count += 1
+    gv = None
+    if sink.count == sink.G:   # every layer has delivered its slice
+        gv = sink.buf if sink.buf.dtype == torch.bfloat16 else sink.buf.to(torch.bfloat16)
+        sink.buf, sink.count = None, 0
+    return gv, gl, ga
+
+
+class _MSDAGroupRawFunction(torch.autograd.Function):
+    """_MSDAGroupFunction fed with the layer's RAW projections: sampling offsets bf16 [B,Q,M*L*P*2], attention logits bf16 [B,Q,M*L*P] and the
+    (detached) reference boxes f32 [B,Q,4] - softmax and location arithmetic of MSDeformableAttention.forward (fai_detr/modelling.py:866-879)
+    happen in fx_msda_prep_bf16 / fx_msda_prep_bwd_bf16: 2 launches forward and 3 backward instead of ~9 and ~11."""
+
+    @staticmethod
+    def forward(ctx, value_all, sink: ValueGradSink, g: int, shapes_t, starts_t, off, logit, ref, shapes_host, M: int, L: int, P: int):
+        lib = _lib.load()
+        B, S, Nt = value_all.shape
+        D = 32
+        Q = off.shape[1]
+        dev = value_all.device
+        assert value_all.dtype == torch.bfloat16 and value_all.is_contiguous() and Nt == sink.G * M * D
+        off, logit, ref = off.contiguous(), logit.contiguous(), ref.float().contiguous()
+        assert off.dtype == torch.bfloat16 and logit.dtype == torch.bfloat16 and off.shape[-1] == M * L * P * 2 and logit.shape[-1] == M * L * P
+        lc = torch.empty(B, Q, M, L, P, 2, dtype=torch.float32, device=dev)
+        aw = torch.empty(B, Q, M, L, P, dtype=torch.float32, device=dev)
+        st = _stream(dev)
+        check(lib.fx_msda_prep_bf16(off.data_ptr(), M * L * P * 2, logit.data_ptr(), M * L * P, ref.data_ptr(), lc.data_ptr(), aw.data_ptr(), B * Q, M, L, P,
+                                    st), "fx_msda_prep_bf16")
+        out = torch.empty(B, Q, M * D, dtype=torch.float32, device=dev)
+        check(lib.fx_msda_train_fwd(value_all.data_ptr() + g * M * D * 2, 1, Nt, shapes_t.data_ptr(), starts_t.data_ptr(), L, P, lc.data_ptr(),
+                                    aw.data_ptr(), out.data_ptr(), B, S, Q, M, st), "fx_msda_train_fwd")
+        ctx.save_for_backward(value_all, shapes_t, starts_t, lc, aw, ref)
+        ctx.sink, ctx.g, ctx.dims, ctx.shapes_host = sink, g, (B, S, Q, M, D, L, P, Nt), shapes_host
+        return out.to(torch.bfloat16)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        value_all, shapes_t, starts_t, lc, aw, ref = ctx.saved_tensors
+        B, S, Q, M, D, L, P, Nt = ctx.dims
+        gv, gl, ga = _msda_group_backward(value_all, shapes_t, starts_t, lc, aw, grad_out, ctx.sink, ctx.g, ctx.dims, ctx.shapes_host)
+        g_off = torch.empty(B, Q, M * L * P * 2, dtype=torch.bfloat16, device=value_all.device)
+        g_logit = torch.empty(B, Q, M * L * P, dtype=torch.bfloat16, device=value_all.device)
+        check(lib.fx_msda_prep_bwd_bf16(gl.data_ptr(), ga.data_ptr(), aw.data_ptr(), ref.data_ptr(), g_off.data_ptr(), M * L * P * 2, g_logit.data_ptr(),
+                                        M * L * P, B * Q, M, L, P, _stream(value_all.device)), "fx_msda_prep_bwd_bf16")
+        return gv, None, None, None, None, g_off, g_logit, None, None, None, None, None
+
+
+def ms_deform_attn_grouped_raw(value_all: torch.Tensor, sink: ValueGradSink, g: int, value_spatial_shapes, offsets: torch.Tensor, logits: torch.Tensor,
+                               ref_boxes: torch.Tensor, heads: int, levels: int, points: int) -> torch.Tensor:
+    """ms_deform_attn_grouped from the raw projections of the layer (see _MSDAGroupRawFunction); ref_boxes [B,Q,4] carries no gradient."""
+    st, ss = _shape_tensors(value_spatial_shapes, value_all.device)
+    return _MSDAGroupRawFunction.apply(value_all, sink, g, st, ss, offsets, logits, ref_boxes.detach(), _shape_host(value_spatial_shapes), heads, levels,
+                                       points)
 
 
 def ms_deform_attn_grouped(value_all: torch.Tensor, sink: ValueGradSink, g: int, value_spatial_shapes, sampling_locations: torch.Tensor,

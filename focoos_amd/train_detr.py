@@ -22,7 +22,7 @@ from torch import nn
 from . import _lib
 from ._lib import check
 from .criterion import h2d_i32, BoxHungarianMatcher, _Targets
-from .train import ValueGradSink, ms_deform_attn_core, ms_deform_attn_grouped
+from .train import ValueGradSink, ms_deform_attn_core, ms_deform_attn_grouped, ms_deform_attn_grouped_raw
 from .train_nn import (ConvNormLayer, HybridEncoder, LayerNorm, Linear, MultiheadAttention, ResNetVd, _AddFn, _Layers, _LinearGroupFn, _PackedLinearGroup,
                        _stream)
 
@@ -42,6 +42,7 @@ class MLP(nn.Module):
 
 
 INV_SIGMOID_EPS = 1e-5   # focoos/nn/layers/functional.py:4
+RAW_MSDA = [os.environ.get("FX_MSDA_RAW", "1") != "0"]   # decoder cross-attention from the raw projections (train._MSDAGroupRawFunction); 0: the torch-op form
 
 
 class _BoxRefineFn(torch.autograd.Function):
@@ -87,6 +88,12 @@ class MSDeformableAttention(nn.Module):
         [B,S,G*256]; this layer reads column slice g); without them the layer projects ``memory`` itself (the reference's form)."""
         B, Q, _ = query.shape
         S = memory.shape[1]
+        if (value_all is not None and RAW_MSDA[0] and ref_points.shape[-1] == 4 and ref_points.shape[2] == 1 and not ref_points.requires_grad
+                and query.dtype == torch.bfloat16):
+            # softmax + location arithmetic inside the sampling node (fx_msda_prep_bf16): ~15 elementwise launches per layer less
+            out = ms_deform_attn_grouped_raw(value_all, sink, g, shapes, self.sampling_offsets(query), self.attention_weights(query),
+                                             ref_points.reshape(B, Q, 4), self.h, self.l, self.p)
+            return self.output_proj(out, residual=residual)
         off = self.sampling_offsets(query).float().view(B, Q, self.h, self.l, self.p, 2)
         aw = torch.softmax(self.attention_weights(query).float().view(B, Q, self.h, self.l * self.p), -1).view(B, Q, self.h, self.l, self.p)
         loc = ref_points[:, :, None, :, None, :2] + off / self.p * ref_points[:, :, None, :, None, 2:] * 0.5
@@ -361,8 +368,9 @@ class TrainStep:
     buckets), global-norm clipping + AdamW in one fused kernel.  Parameters and their gradients live in the optimizer's flat
     buffers (the gradient kernels accumulate straight into the flat gradient views); per-parameter lr / weight decay follow
     build_optimizer (solver/build.py:39-138: backbone lr x0.1, weight_decay_norm on the parameters of normalisation modules).
-    The step is launched eagerly (~5 800 launches, host-bound at ~75 ms): capturing forward+backward in a hipGraph through
-    torch.cuda.make_graphed_callables was tried and dead-locked inside the capture on this stack, so it is not used."""
+    The step is launched eagerly (round 3: ~1 700 launches, 20-22 ms of host issue against 24-26 ms of GPU time on two streams - DESIGN.md
+    §5 / §7): capturing forward+backward in a hipGraph through torch.cuda.make_graphed_callables was tried in round 1 and dead-locked inside
+    the capture on this stack, so it is not used."""
 
     def __init__(self, model: FAIDetrTrainable, lr: float = 1e-4, backbone_multiplier: float = 0.1, weight_decay: float = 1e-4,
                  weight_decay_norm: float = 0.0, weight_decay_embed: float = 0.0, max_grad_norm: float = 0.1, ema_decay: Optional[float] = None, ema_warmups: int = 2000, scheduler: Optional[str] = None,

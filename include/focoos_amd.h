@@ -437,6 +437,15 @@ int fx_msda_train_bwd_slab(const void* value, int value_bf16, int ldv, const int
                            int grad_out_bf16, void* grad_value_bf16, int ldg, float* grad_loc, float* grad_attn, int B, int S, int Q, int M,
                            fx_stream_t stream);
 
+/* Sampling locations and attention weights of one deformable layer from its raw bf16 projections, and the gradients back to them
+ * (MSDeformableAttention.forward, fai_detr/modelling.py:866-879, 4-d reference points, detached): aw = softmax over the L*P logits of a
+ * (query, head); loc = ref_xy + off / P * ref_wh * 0.5.  off [BQ, >= M*L*P*2], logit [BQ, >= M*L*P] bf16 rows; ref f32 [BQ,4];
+ * loc f32 [BQ,M,L,P,2], aw f32 [BQ,M,L,P] - the operands of fx_msda_train_fwd / _bwd.  One launch each way instead of ~7 + ~8. */
+int fx_msda_prep_bf16(const void* off, int ld_off, const void* logit, int ld_logit, const float* ref, float* loc, float* aw, int BQ, int M, int L,
+                      int P, fx_stream_t stream);
+int fx_msda_prep_bwd_bf16(const float* grad_loc, const float* grad_attn, const float* aw, const float* ref, void* grad_off, int ld_off,
+                          void* grad_logit, int ld_logit, int BQ, int M, int L, int P, fx_stream_t stream);
+
 /* Fused multi-tensor AdamW + global-norm gradient clipping over one flat fp32 buffer (replaces the
  * ~500 single-tensor param groups of focoos/trainer/solver/build.py:39-138 and the clip of :29-36 / trainer.py:758-760).
  * The buffer is cut into chunks (chunk_start i64, chunk_len i32 <= 65536) each carrying its tensor's lr / weight_decay;

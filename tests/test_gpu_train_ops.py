@@ -131,3 +131,40 @@ def test_grouped_msda_matches_the_per_layer_function(shapes, Q, crowd, slab, mon
         gref = v.grad.reshape(B, S, 256)
         # bf16 rounding of the delivered gradient (2^-9 relative) + fp32 summation order
         assert ((gv_all[:, :, i * 256:(i + 1) * 256] - gref).abs() <= 4e-3 * gref.abs() + 2e-5 * gref.abs().max()).all()
+
+
+def test_raw_projection_msda_node_matches_the_torch_op_prelude():
+    """ms_deform_attn_grouped_raw (softmax + location arithmetic of MSDeformableAttention.forward inside the node: fx_msda_prep_bf16 /
+    fx_msda_prep_bwd_bf16) vs the same arithmetic as torch ops in front of ms_deform_attn_grouped: equal forward, gradients of the raw
+    projections equal to bf16 rounding."""
+    from focoos_amd.train import ValueGradSink, ms_deform_attn_grouped, ms_deform_attn_grouped_raw
+
+    shapes = [[80, 80], [40, 40], [20, 20]]
+    B, Q, M, L, P = 2, 77, 8, 3, 4
+    S = sum(h * w for h, w in shapes)
+    g = torch.Generator().manual_seed(31)
+    value_all = torch.randn(B, S, 256, generator=g).bfloat16().to(DEV)
+    off0 = (torch.randn(B, Q, M * L * P * 2, generator=g) * 3).bfloat16().to(DEV)
+    lg0 = (torch.randn(B, Q, M * L * P, generator=g) * 2).bfloat16().to(DEV)
+    ref = torch.cat([torch.rand(B, Q, 2, generator=g), torch.rand(B, Q, 2, generator=g) * 0.4 + 0.02], -1).to(DEV)
+    go = torch.randn(B, Q, 256, generator=g).bfloat16().to(DEV)
+    outs, grads = [], []
+    for raw in (False, True):
+        v = value_all.clone().requires_grad_()
+        off, lg = off0.clone().requires_grad_(), lg0.clone().requires_grad_()
+        sink = ValueGradSink(1)
+        if raw:
+            out = ms_deform_attn_grouped_raw(v, sink, 0, shapes, off, lg, ref, M, L, P)
+        else:
+            o = off.float().view(B, Q, M, L, P, 2)
+            aw = torch.softmax(lg.float().view(B, Q, M, L * P), -1).view(B, Q, M, L, P)
+            r4 = ref.unsqueeze(2)
+            loc = r4[:, :, None, :, None, :2] + o / P * r4[:, :, None, :, None, 2:] * 0.5
+            out = ms_deform_attn_grouped(v, sink, 0, shapes, loc, aw)
+        out.backward(go)
+        torch.cuda.synchronize()
+        outs.append(out.detach().float())
+        grads.append((v.grad.float(), off.grad.float(), lg.grad.float()))
+    assert (outs[0] - outs[1]).abs().max() <= 2e-2 * outs[0].abs().max()
+    for a, b in zip(grads[0], grads[1]):
+        assert (a - b).abs().max() <= 1.2e-2 * a.abs().max(), (a - b).abs().max() / a.abs().max()
