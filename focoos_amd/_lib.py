@@ -131,6 +131,7 @@ SIGNATURES = {
     "fx_seg_postprocess": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, C.c_float, _i, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "fx_pack_conv_weights_f32": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "fx_unpack_conv_wgrad_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "fx_linear_wgrad_bias_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "fx_conv2d_wgrad_splits": [_i, _i, _i, _i, _i, _i, _i],
     "fx_conv2d_wgrad_partial_nhwc_bf16": [_vp, _i, _vp, _i, _vp, C.c_int64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "fx_unpack_conv_wgrad_sum_f32": [_vp, C.c_int64, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

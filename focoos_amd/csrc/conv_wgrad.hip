@@ -26,6 +26,7 @@ struct WgradArgs {
   int KH, KW, stride, pad;
   int M, Ktot, nKt, mchunk, tiles;
   long long split_stride;  // 0: fp32 atomics into one dW; else pixel range `by` stores its partial tile sums at dw + by * split_stride
+  int n_store, k_store, ld_dw;   // rows / columns of dW actually stored and its row stride (N, Ktot, Ktot unless the operands are zero-padded views of a narrower layer)
   unsigned x_bytes, dz_bytes;
 };
 
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[r0 * 128 + cc * 8 + j] = bsum[j];
     __syncthreads();
-    if (tid < 128 && n0 + tid < p.N) {
+    if (tid < 128 && n0 + tid < p.n_store) {
       float t = 0.0f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) t += red[r * 128 + tid];
@@ -226,9 +227,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int n = n0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (n < p.N && kcol < p.Ktot) {
-          if (p.split_stride) p.dw[(int64_t)by * p.split_stride + (int64_t)n * p.Ktot + kcol] = acc[a][b][r];
-          else unsafeAtomicAdd(p.dw + (int64_t)n * p.Ktot + kcol, acc[a][b][r]);
+        if (n < p.n_store && kcol < p.k_store) {
+          if (p.split_stride) p.dw[(int64_t)by * p.split_stride + (int64_t)n * p.ld_dw + kcol] = acc[a][b][r];
+          else unsafeAtomicAdd(p.dw + (int64_t)n * p.ld_dw + kcol, acc[a][b][r]);
         }
       }
     }
@@ -262,7 +263,8 @@ static int wgrad_target_wgs(int N, int Ktot) {
 }
 
 static int wgrad_launch(const void* x, int ldx, const void* dz, int lddz, float* dw, long long split_stride, int expect_splits, float* dbias, int B, int H,
-                        int W, int C, int Ho, int Wo, int N, int KH, int KW, int stride, int pad, fx_stream_t stream_) {
+                        int W, int C, int Ho, int Wo, int N, int KH, int KW, int stride, int pad, fx_stream_t stream_, int n_store = 0, int k_store = 0,
+                        int ld_dw = 0) {
   FX_CHECK_ARG(x && dz && dw && B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && N > 0 && C > 0);
   FX_CHECK_ARG(C % 8 == 0 && N % 8 == 0 && ldx >= C && lddz >= N && ldx % 8 == 0 && lddz % 8 == 0);
   FX_CHECK_ARG(KH >= 1 && KW >= 1 && stride >= 1 && pad >= 0);
@@ -293,6 +295,10 @@ static int wgrad_launch(const void* x, int ldx, const void* dz, int lddz, float*
   FX_CHECK_ARG(!split_stride || (S == expect_splits && split_stride >= (long long)N * a.Ktot));
   a.split_stride = split_stride;
   a.tiles = tiles;
+  a.n_store = n_store > 0 ? n_store : N;
+  a.k_store = k_store > 0 ? k_store : a.Ktot;
+  a.ld_dw = ld_dw > 0 ? ld_dw : a.Ktot;
+  FX_CHECK_ARG(a.n_store <= N && a.k_store <= a.Ktot && a.ld_dw >= a.k_store);
   const bool pw = KH == 1 && KW == 1 && stride == 1 && pad == 0;
   if (pw) hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(tiles * S), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), a);
   else hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(tiles * S), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), a);
@@ -302,6 +308,16 @@ static int wgrad_launch(const void* x, int ldx, const void* dz, int lddz, float*
 extern "C" int fx_conv2d_wgrad_bias_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, float* dw, float* dbias, int B, int H, int W,
                                               int C, int Ho, int Wo, int N, int KH, int KW, int stride, int pad, fx_stream_t stream_) {
   return wgrad_launch(x, ldx, dz, lddz, dw, 0, 0, dbias, B, H, W, C, Ho, Wo, N, KH, KW, stride, pad, stream_);
+}
+
+// Linear layer whose operands are zero-padded views of a narrower layer (bbox heads N = 4, class heads N = 365, query-pos head K = 4: the
+// kernels want K % 32 == 0 and N % 8 == 0): x [R][ldx] with Kp valid-or-zero columns, dz [R][lddz] with Np; ONLY the n_store x k_store
+// corner of dW (row stride ld_dw) and the first n_store bias gradients are accumulated - straight into the master gradient, instead of a
+// padded staging matrix + slice + add per layer and step.
+extern "C" int fx_linear_wgrad_bias_bf16(const void* x, int ldx, const void* dz, int lddz, float* dw, int ld_dw, float* dbias, int R, int Kp, int Np,
+                                         int k_store, int n_store, fx_stream_t stream_) {
+  FX_CHECK_ARG(k_store > 0 && n_store > 0 && k_store <= Kp && n_store <= Np && ld_dw >= k_store);
+  return wgrad_launch(x, ldx, dz, lddz, dw, 0, 0, dbias, 1, 1, R, Kp, 1, R, Np, 1, 1, 1, 0, stream_, n_store, k_store, ld_dw);
 }
 
 extern "C" int fx_conv2d_wgrad_splits(int B, int Ho, int Wo, int C, int N, int KH, int KW) {

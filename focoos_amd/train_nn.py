@@ -1043,6 +1043,14 @@ class _LinearFn(torch.autograd.Function):
         R = x2.shape[2]
         dw = db = None
         same = Np == N and Kp == K
+        if direct and not same and (bdirect or not want_b) and ctx.wparam.grad.is_contiguous():
+            # padded operands of a narrow layer (N = 4 / 365, K = 4): the kernel accumulates the valid corner straight into the master
+            # gradients (fx_linear_wgrad_bias_bf16) - no padded staging matrix, slice and add per layer
+            wg = ctx.wparam.grad[r0:r1]
+            bg = ctx.bparam.grad[r0:r1] if want_b else None
+            check(lib.fx_linear_wgrad_bias_bf16(x2.data_ptr(), Kp, dz.data_ptr(), Np, wg.data_ptr(), K, bg.data_ptr() if bg is not None else None, R, Kp, Np,
+                                                K, N, st), "fx_linear_wgrad_bias_bf16")
+            return None, None
         if direct and same:
             wt = ctx.wparam.grad[r0:r1]
         else:

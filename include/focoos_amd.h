@@ -516,6 +516,11 @@ int fx_pack_weights_many_f32(const fx_pack_entry* entries_dev, int n_entries, in
 int fx_unpack_conv_wgrad_f32(const float* dw_eff, const float* scale, float* dw_master, int N, int C, int KH, int KW, int C_eff, int accumulate,
                              fx_stream_t stream);
 
+/* Weight (+ bias) gradient of a Linear layer whose operands are zero-padded views of a narrower layer (N = 4 / 365, K = 4 of the detection
+ * heads): x bf16 [R][ldx] (Kp columns, the padding zero), dz bf16 [R][lddz] (Np columns); accumulates (fp32 atomics) only the
+ * n_store x k_store corner of dW, row stride ld_dw, and dbias[0, n_store) - i.e. straight into the master gradient of the unpadded layer. */
+int fx_linear_wgrad_bias_bf16(const void* x, int ldx, const void* dz, int lddz, float* dw, int ld_dw, float* dbias, int R, int Kp, int Np, int k_store,
+                              int n_store, fx_stream_t stream);
 /* The same weight gradient without atomics: pixel range s (0 <= s < splits = fx_conv2d_wgrad_splits(...)) STORES its partial sums at
  * partials + s * split_stride (f32 [N][KH][KW][C] each; split_stride >= N*KH*KW*C; nothing needs zeroing), and
  * fx_unpack_conv_wgrad_sum_f32 adds the slabs while it re-lays the gradient out for the master weight.  The L2 atomic units sustain
