@@ -195,7 +195,7 @@ int fx_enc_score_head_bf16(const void* memory, int ldm, const uint8_t* valid, in
  * stages are bf16 in MFMA fragment order (see fx_pw_chain_desc).  Stage types:
  *   0 LOAD     dst <- g0[row, 0:K] (bf16 global, row stride ld)
  *   1 GEMM     act(src[32,K] . w^T + bias) -> dst (LDS, if >= 0; N in {256,512,1024}) and / or g0[row, 0:N] (row stride ld;
- *              f32 if flags&1 else bf16); N % 32 == 0, K % 64 == 0
+ *              f32 if flags&1 else bf16); N % 32 == 0, K % 128 == 0 (the weight stream moves in groups of eight 16-channel fragments)
  *   2 GEMM_LN  LayerNorm_256(src . w^T + bias + aux) * gamma + beta -> dst and optionally g0 (bf16); eps 1e-5; ld2 = LDS byte
  *              offset of a 512-byte reduction scratch
  *   3 ADD      dst <- src + aux  (K columns)
