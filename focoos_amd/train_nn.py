@@ -17,6 +17,7 @@ order; every FLOP and every byte moved inside a node is a HIP kernel of this rep
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 import os
 from typing import Dict, List, Optional
 
@@ -735,14 +736,17 @@ class _BottleneckFn(torch.autograd.Function):
         a_l, b_l, c_l = blk.branch2a, blk.branch2b, blk.branch2c
         lib, dev = a_l.lib, x.device
         st = _stream(dev)
+        ref = blk._premasked_ref
+        premasked = ref is not None and ref() is dy   # the very tensor the next block's backward produced (not a copy, not a sum)
+        blk._premasked_ref = None
         dy = dy.contiguous()
         B, Ho, Wo, N = y.shape
-        if getattr(blk, "_premasked_ptr", 0) == dy.data_ptr() and dy.dtype == y.dtype:
+        if premasked and dy.dtype == y.dtype:
             dz_c = dy   # the next block's backward already applied relu'(y) in the epilogue of its branch2a input gradient (below)
+            PREMASK_HITS[0] += 1
         else:
             dz_c = torch.empty_like(y)   # gradient of conv_c's output AND of the shortcut branch (pre-activation residual add)
             check(lib.fx_relu_bwd_bf16(dy.data_ptr(), N, None, 0, y.data_ptr(), N, dz_c.data_ptr(), N, B * Ho * Wo, N, 1, st), "fx_relu_bwd_bf16")
-        blk._premasked_ptr = 0
         need = ctx.needs_input_grad
         dwc = _conv_param_grads(c_l, b, dz_c, c_l.scale) if need[3] else None
         dz_b = _conv_call(lib, dz_c, c_l.w_dgrad, None, c_l.cin, 1, 1, 1, 0, None, b, res_mode=2, w_frag=c_l.w_dgrad_frag)       # dgrad_c * relu'(b)
@@ -778,9 +782,9 @@ class _BottleneckFn(torch.autograd.Function):
         dx = _conv_call(lib, dz_a, a_l.w_dgrad, None, a_l.cin, 1, 1, 1, 0, None, dshort, w_frag=None if pm is not None else a_l.w_dgrad_frag,
                         mask=pm) if need[0] else None
         if pm is not None:
-            # tell the previous block which tensor arrives pre-masked (by address: if autograd hands it anything else - a copy, a sum - it
-            # applies its own ReLU backward, and masking twice is the identity)
-            prev._premasked_ptr = dx.data_ptr()
+            # tell the previous block which tensor arrives pre-masked - by object identity through a weak reference: if autograd hands it
+            # anything else (a copy, a sum of several gradients) it applies its own ReLU backward, and masking twice is the identity
+            prev._premasked_ref = weakref.ref(dx)
         return dx, dwa, dwb, dwc, dws, None
 
 
@@ -793,7 +797,7 @@ class BottleNeck(nn.Module):
         self.branch2b = ConvNormLayer(lib, width, width, 3, stride, "relu")
         self.branch2c = ConvNormLayer(lib, width, width * 4, 1, 1, "relu")  # ReLU applied AFTER the residual add (fused epilogue)
         self.has_short = not shortcut
-        self._premasked_ptr = 0   # address of an output gradient that arrives with relu'(output) already applied (see _BottleneckFn.backward)
+        self._premasked_ref = None   # weak reference to an output gradient that arrives with relu'(output) already applied (see _BottleneckFn.backward)
         if self.has_short:
             self.short = ConvNormLayer(lib, ch_in, width * 4, 1, 1, None) if (first_stage or stride == 1) else _Short(lib, ch_in, width * 4)
 
@@ -811,6 +815,7 @@ class BottleNeck(nn.Module):
 # whose block-input gradient runs on the implicit-GEMM kernels (res2 / res3: branch width <= 128 - the widest tensors of the network; the
 # deeper stages' pointwise layers run on the resident-tile kernel, which has no second epilogue operand).  FX_PREMASK=0: off.
 PREMASK = [os.environ.get("FX_PREMASK", "1") != "0"]
+PREMASK_HITS = [0]   # backward passes that started from a pre-masked gradient (tests assert the hand-over really happens)
 
 
 class _Blocks(nn.Module):

@@ -606,6 +606,7 @@ def test_fused_bottleneck_node_matches_per_layer_nodes():
     g = torch.Generator().manual_seed(3)
     proj = {k: torch.randn(c, generator=g).to(DEV) for k, c in (("res2", 256), ("res3", 512), ("res4", 1024), ("res5", 2048))}
     grads = {}
+    hits0 = train_nn.PREMASK_HITS[0]
     for fused in (True, False):
         train_nn.FUSED_BLOCKS[0] = fused
         try:
@@ -621,6 +622,9 @@ def test_fused_bottleneck_node_matches_per_layer_nodes():
         if fused:
             feats_fused = feats
     assert all(torch.equal(feats[k], feats_fused[k]) for k in feats)          # identical forward launches
+    # res2 (3 blocks) and res3 (4 blocks): the input gradient of blocks 1.. arrives at block i-1 with relu'(output) already applied
+    # (fx_conv_desc.mask) - the hand-over by tensor identity must really have happened: 2 + 3 backward passes without their ReLU pass
+    assert train_nn.PREMASK_HITS[0] - hits0 == (5 if train_nn.PREMASK[0] else 0)
     worst = max(rel_l2(grads[True][n], grads[False][n]) for n in grads[True])
     print("fused vs per-layer weight gradients, worst rel-L2:", worst)
     assert worst <= 2e-2
