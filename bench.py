@@ -374,7 +374,7 @@ def train_measure(args, world, rank, local, with_roofline=True):
         crit = ("point-sampled mask Hungarian set criterion over 7 prediction sets" if bf else
                 ("point-sampled mask Hungarian set criterion over 10 prediction sets" if args.family == "fai_mf" else "Hungarian set criterion over 7 prediction sets"))
         out = ({
-            "metric": f"images/sec @ {S}^2 (train bs={B}/GPU)", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "metric": f"images/sec @ {S}^2 (train bs={B}/GPU" + ("; bf16 variant of BASELINE configs[4], which names fp16" if bf else "") + ")", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": f"{args.model} training step: forward (train mode, norm={args.norm}) + {crit} "

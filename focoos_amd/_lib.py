@@ -185,6 +185,9 @@ def lib_path() -> str:
     return os.environ.get("FOCOOS_AMD_LIB", LIB_PATH)
 
 
+FX_ABI_VERSION = 2   # = include/focoos_amd.h (tests/test_host_cpu.py compares the two)
+
+
 def load() -> C.CDLL:
     """Load the HIP library; raise loudly when it is absent (no fallback)."""
     global _lib
@@ -208,8 +211,8 @@ def load() -> C.CDLL:
     lib.fx_topk_rows_workspace_bytes.restype = C.c_size_t
     lib.fx_error_string.argtypes = [C.c_int]
     lib.fx_error_string.restype = C.c_char_p
-    if lib.fx_abi_version() != 1:
-        raise FocoosAmdError(f"ABI version mismatch: library {lib.fx_abi_version()} != binding 1")
+    if lib.fx_abi_version() != FX_ABI_VERSION:
+        raise FocoosAmdError(f"ABI version mismatch: library {lib.fx_abi_version()} != binding {FX_ABI_VERSION} (stale libfocoos_amd.so: rebuild)")
     _lib = lib
     return lib
 

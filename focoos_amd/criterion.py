@@ -78,10 +78,18 @@ def lsa_status(device) -> torch.Tensor:
     return _LSA_STATUS[device]
 
 
-def raise_if_infeasible(device) -> None:
+def raise_if_infeasible(device, all_ranks: bool = False) -> None:
     """Reads (one 4-byte D2H copy: a synchronisation - call it where the host waits anyway) and clears the status word; raises what
-    SciPy's ``linear_sum_assignment`` raises inside the reference matcher (fai_detr/modelling.py:749-750) when the costs are inf / NaN."""
+    SciPy's ``linear_sum_assignment`` raises inside the reference matcher (fai_detr/modelling.py:749-750) when the costs are inf / NaN.
+    ``all_ranks``: under data parallelism the word is first MAX-all-reduced, so that EVERY rank raises in the same step - a rank raising
+    alone would leave the others blocked in the next gradient all-reduce (every rank must make this call at the same point)."""
+    import torch.distributed as dist
+
     st = _LSA_STATUS.get(torch.device(device))
+    multi = all_ranks and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if multi:
+        st = lsa_status(device)          # a rank that never matched still takes part in the collective
+        dist.all_reduce(st, op=dist.ReduceOp.MAX)
     if st is not None:
         bits = int(st.item())
         if bits:
@@ -105,7 +113,7 @@ class BoxHungarianMatcher:
         # Identity-like defaults instead of uninitialised memory: if the assignment is infeasible (NaN / inf costs after a diverged
         # step) the solver leaves an image's slots untouched, and the criterion would otherwise index boxes[slot, garbage].  The
         # reference raises from SciPy in that case; here the kernel sets the device status word and the host raises the same error at its
-        # next synchronisation point (raise_if_infeasible: the matcher's public forward, TrainStep.check / the trainer's log points).
+        # next synchronisation point (raise_if_infeasible: the matcher's public forward, TrainStep.check - every `check_every` steps - and the trainer's log points).
         pi = torch.zeros(max(tg.n, 1), dtype=torch.int32, device=dev)
         ti = torch.zeros(max(tg.n, 1), dtype=torch.int32, device=dev)
         if tg.n:

@@ -208,6 +208,10 @@ __global__ __launch_bounds__(256) void msda_f32_bwd_kernel(const VT* __restrict_
 constexpr int MS_PIX = 3200;   // pixels per slab: level 80 x 80 = two slabs -> 4 slabs x 128 (batch, head) = 512 workgroups = 2 per CU
 constexpr int MS_MAXL = 8;
 constexpr int MS_HOT = 96;     // entries from which a pixel is summed by the whole workgroup
+// ints reserved for the set-aside pixel list, rounded so that (MS_PIX + 8 + 2 + 512 + this) is a multiple of 4 ints = 16 bytes
+__host__ __device__ constexpr int msda_hot_ints(int Q, int P) {
+  return ((MS_PIX + 8 + 2 + 512 + (Q * P * 4 / MS_HOT + 2)) + 3) / 4 * 4 - (MS_PIX + 8 + 2 + 512);
+}
 
 struct MsdaBinArgs {
   int L, P, B, S, Q, M, ldg;
@@ -277,7 +281,9 @@ __global__ __launch_bounds__(512) void msda_bwd_value_kernel(MsdaBinArgs a, cons
   int* hotn = wsum + 8;                                                    // [1] (+1 pad) number of set-aside pixels
   float* part = reinterpret_cast<float*>(hotn + 2);                        // [16][32] partial sums of a set-aside pixel
   int* hot = reinterpret_cast<int*>(part + 512);                           // [Q*P*4 / MS_HOT + 2] set-aside pixels
-  uint2* ent = reinterpret_cast<uint2*>(hot + (a.Q * a.P * 4 / MS_HOT + 2) / 2 * 2);   // [Q*P*4]: (query, weight bits), filed by pixel
+  // `ent` starts on a 16-byte boundary (MS_HOT_INTS pads the set-aside list) and holds Q*P*4 8-byte entries (a multiple of 32 bytes), so goL -
+  // written with 16-byte stores in the fp32 instantiation - is 16-byte aligned too (it was 8-byte aligned for Q*P = 1200)
+  uint2* ent = reinterpret_cast<uint2*>(hot + msda_hot_ints(a.Q, a.P));   // [Q*P*4]: (query, weight bits), filed by pixel
   GT* goL = reinterpret_cast<GT*>(ent + (size_t)a.Q * a.P * 4);            // [Q][32]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int slab = blockIdx.x, b = blockIdx.y / a.M, h = blockIdx.y - b * a.M;
@@ -449,7 +455,7 @@ extern "C" int fx_msda_train_bwd(const void* value, int value_bf16, int ldv, con
 // L (H, W) pairs on the host (the slab grid is sized from them).  FX_ERR_UNSUPPORTED when a level is wider than MS_PIX pixels or the
 // taps of Q*P points do not fit the LDS (fx_msda_bwd_slab_supported tells beforehand).
 static int msda_slab_smem(int P, int Q, int go_bf16) {
-  return (MS_PIX + 8 + 2 + 512 + (Q * P * 4 / MS_HOT + 2) / 2 * 2) * 4 + Q * P * 4 * 8 + Q * 32 * (go_bf16 ? 2 : 4);
+  return (MS_PIX + 8 + 2 + 512 + msda_hot_ints(Q, P)) * 4 + Q * P * 4 * 8 + Q * 32 * (go_bf16 ? 2 : 4);
 }
 
 extern "C" int fx_msda_bwd_slab_supported(const int32_t* shapes_host, int L, int P, int Q, int M, int grad_out_bf16) {

@@ -34,21 +34,23 @@ def _fx_version_key(module) -> tuple:
         tuple(p.data_ptr() for p in module.parameters())
 
 
-def _engine_can_run(images) -> bool:
-    """The engine's plans need H and W to be multiples of 32 (five stride-2 stages + the 2x2 ceil-mode shortcut pools).  Other sizes -
-    which stock focoos accepts for the mask families, whose processors never resize - run the reference's own (GPU) graph with a
-    warning, so user code that works with stock focoos keeps working.  A CPU tensor is NOT a reason to fall back: the engine
-    raises FocoosAmdError for it (no silent CPU path)."""
-    if images.dim() != 4:
-        return True    # let the engine raise on the malformed input
-    h, w = (images.shape[2], images.shape[3]) if (images.shape[1] == 3 and images.shape[-1] != 3) else (images.shape[1], images.shape[2])
-    ok = h % 32 == 0 and w % 32 == 0
-    if not ok and images.device.type == "cuda":
-        import warnings
+def _require_engine_input(images) -> None:
+    """The adapters NEVER run the reference's stock PyTorch graph (a result produced that way says nothing about the engine):
+    inputs the engine has no plan for are refused loudly.  That is (i) H or W not a multiple of 32 - stock focoos accepts such sizes for
+    the mask families, whose processors never resize; reference-equal support needs ceil-size semantics in the stride-2 / pool / resize /
+    mask-plane kernels, not pad-and-crop - and (ii) a gradient with respect to the input images.  CPU tensors
+    are refused by the engine itself (FocoosAmdError: no CPU path)."""
+    from ._lib import FocoosAmdError
 
-        warnings.warn(f"focoos_amd: input {h}x{w} is not a multiple of 32 - this call runs the reference's stock PyTorch graph, not the HIP engine")
-        return False
-    return True
+    if images.dim() != 4:
+        return    # let the engine raise on the malformed input
+    h, w = (images.shape[2], images.shape[3]) if (images.shape[1] == 3 and images.shape[-1] != 3) else (images.shape[1], images.shape[2])
+    if h % 32 or w % 32:
+        raise FocoosAmdError(f"focoos_amd: input {h}x{w} is not a multiple of 32; the HIP engine has no plan for it and does not fall back to the "
+                             "reference's stock graph (resize or pad the image in the processor, or unregister the engine for this model)")
+    if torch.is_grad_enabled() and images.requires_grad:
+        raise FocoosAmdError("focoos_amd: gradients with respect to the input images are not implemented by the HIP training graph "
+                             "(and the adapter does not fall back to the reference's stock graph)")
 
 
 def share_parameters(engine_graph, reference_module) -> int:
@@ -116,8 +118,7 @@ def make_engine_class():
             return g[0]
 
         def forward(self, images, targets=[]):
-            if not _engine_can_run(images):
-                return super().forward(images, targets)   # shapes / devices the engine has no plan for: the reference's own graph
+            _require_engine_input(images)   # raises: no fallback to the reference's own graph
             x = images
             if x.dim() == 4 and x.shape[1] == 3 and x.shape[-1] != 3:
                 x = x.permute(0, 2, 3, 1)
@@ -178,8 +179,7 @@ def make_mf_engine_class():
             return g[0]
 
         def forward(self, images, targets=[]):
-            if (torch.is_grad_enabled() and images.requires_grad) or not _engine_can_run(images):
-                return super().forward(images, targets)  # shapes / devices the engine has no plan for: the reference's own graph
+            _require_engine_input(images)   # raises: no fallback to the reference's own graph
             x = images
             if x.dim() == 4 and x.shape[1] == 3 and x.shape[-1] != 3:
                 x = x.permute(0, 2, 3, 1)
@@ -244,8 +244,7 @@ def make_bf_engine_class():
             return g[0]
 
         def forward(self, images, targets=[]):
-            if (torch.is_grad_enabled() and images.requires_grad) or not _engine_can_run(images):
-                return super().forward(images, targets)  # shapes / devices the engine has no plan for: the reference's own graph
+            _require_engine_input(images)   # raises: no fallback to the reference's own graph
             x = images
             if x.dim() == 4 and x.shape[1] == 3 and x.shape[-1] != 3:
                 x = x.permute(0, 2, 3, 1)

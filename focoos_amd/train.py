@@ -60,7 +60,7 @@ class ValueGradSink:
     per-layer fp32 buffers, zero-fills, casts or G-1 memory-sized gradient additions."""
 
     def __init__(self, G: int):
-        self.G, self.count, self.buf = G, 0, None
+        self.G, self.count, self.buf, self.slab = G, 0, None, None   # slab: the backward form (binning / atomics) this pass's buffer was allocated for
 
 
 class _MSDAGroupFunction(torch.autograd.Function):
@@ -98,6 +98,18 @@ def _msda_group_backward(value_all, shapes_t, starts_t, lc, aw, grad_out, sink, 
     go_bf16 = grad_out.dtype == torch.bfloat16
     slab = (sh is not None and os.environ.get("FX_MSDA_BWD_SLAB", "1") != "0"
             and lib.fx_msda_bwd_slab_supported(sh.ctypes.data, L, P, Q, M, int(go_bf16)) == 1)
+    # The path is decided ONCE per sink (by the first layer of a backward pass to arrive): the shared buffer is bf16 [B,S,Nt] for the
+    # binning form and fp32 for the atomic form, and a layer taking the other path would write fp32 rows into a bf16 buffer of half
+    # the size.  A later layer that cannot follow the sink's choice fails loudly instead.
+    if sink.buf is None:
+        sink.slab = slab
+    elif sink.slab != slab:
+        if sink.slab and not go_bf16:   # the binning form was chosen for bf16 gradients; an fp32 grad_out of a later layer is cast, not re-routed
+            grad_out, go_bf16, slab = grad_out.to(torch.bfloat16), True, True
+        else:
+            raise _lib.FocoosAmdError("grouped deformable-attention backward: the layers of one value group must all take the same "
+                                      f"path (sink holds a {'bf16 slab' if sink.slab else 'fp32 atomic'} buffer, this layer asked for the other)")
+    assert sink.buf is None or sink.buf.dtype == (torch.bfloat16 if slab else torch.float32)
     gl, ga = torch.empty_like(lc), torch.empty_like(aw)
     if slab:
         go = grad_out.contiguous() if go_bf16 else grad_out.float().contiguous()

@@ -374,11 +374,12 @@ class TrainStep:
 
     def __init__(self, model: FAIDetrTrainable, lr: float = 1e-4, backbone_multiplier: float = 0.1, weight_decay: float = 1e-4,
                  weight_decay_norm: float = 0.0, weight_decay_embed: float = 0.0, max_grad_norm: float = 0.1, ema_decay: Optional[float] = None, ema_warmups: int = 2000, scheduler: Optional[str] = None,
-                 max_iters: int = 0, scheduler_extra: Optional[Dict] = None):
+                 max_iters: int = 0, scheduler_extra: Optional[Dict] = None, check_every: int = 16):
         from . import train_nn
         from .train import BucketedGradAllReduce, FlatAdamW
 
         self.model, self._nn = model, train_nn
+        self.check_every = int(check_every)   # Hungarian status word polled every N steps (0 = only through check()): see check()
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         dev = named[0][1].device
         from .state_spec import state_spec
@@ -485,4 +486,17 @@ class TrainStep:
         nn_.WEIGHTS_EPOCH[0] += 1
         if self.ema is not None:
             self.ema.update()
+        if self.check_every > 0 and self.iteration % self.check_every == 0:
+            self.check()
         return losses
+
+    def check(self) -> None:
+        """Poll and clear the Hungarian solver's device status word (criterion.raise_if_infeasible): a step whose matching costs were
+        NaN / inf - where the reference raises from SciPy inside the matcher (fai_detr/modelling.py:749-750) - raises the same ValueError
+        here, on EVERY rank (the word is MAX-all-reduced first: a rank raising alone would leave the others blocked in the next gradient
+        all-reduce).  One 4-byte D2H read = one host synchronisation, so step() calls it every `check_every` steps (default 16: at most
+        15 optimizer steps run on identity assignments before the run ends) instead of every step; direct users of TrainStep that want the
+        reference's per-step behaviour pass check_every=1 or call check() themselves."""
+        from .criterion import raise_if_infeasible
+
+        raise_if_infeasible(self.opt.dev, all_ranks=True)

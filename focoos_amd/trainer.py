@@ -79,7 +79,6 @@ def run_train(args: TrainerArgs, data_train, data_val, model, processor, model_i
     Ignored TrainerArgs fields (trainer-side features outside SURVEY §8): ckpt_dir, checkpointer_period / _max_to_keep, eval_period,
     samples, early_stop, patience, workers, ddp_*, gather_metric_period, zero_grad_before_forward, sync_to_hub, size_divisibility."""
     check_supported(args)
-    from .criterion import raise_if_infeasible
     from .train_data import TrainingSampler, per_rank_batch_size, rank_seed
     from .train_detr import FAIDetrTrainable, TrainStep
 
@@ -118,12 +117,12 @@ def run_train(args: TrainerArgs, data_train, data_val, model, processor, model_i
         images, targets = processor.preprocess(entries, device=dev)
         losses = stepper.step(images, targets)
         if args.log_period and (it + 1) % args.log_period == 0:
-            raise_if_infeasible(dev)    # every rank: a diverged step (NaN / inf matching costs) ends the run as SciPy's error does in the reference
+            stepper.check()    # every rank (MAX-all-reduced status): a diverged step (NaN / inf matching costs) ends the run as SciPy's error does in the reference
         if rank == 0 and args.log_period and (it + 1) % args.log_period == 0:
             tot = float(sum(v.detach().float() for v in losses.values()))
             print(f"[focoos_amd.train] iter {it + 1}/{args.max_iters} total_loss {tot:.4f} {(time.perf_counter() - t0) / (it + 1) * 1e3:.1f} ms/iter", flush=True)
     torch.cuda.synchronize(dev)
-    raise_if_infeasible(dev)
+    stepper.check()
     out = {k: float(v.detach().float()) for k, v in losses.items()}
     if rank == 0:
         folder = os.path.join(args.output_dir, args.run_name.strip())

@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define FX_ABI_VERSION 1
+/* Bumped whenever a descriptor struct's layout OR the semantics the host relies on change (version 2: fx_conv_desc grew mask / ldm /
+ * reserved0 and the library applies the ReLU mask the previous bottleneck skips); focoos_amd/_lib.py refuses a library of another version. */
+#define FX_ABI_VERSION 2
 
 enum { FX_OK = 0, FX_ERR_INVALID_ARGUMENT = -1, FX_ERR_LAUNCH = -2, FX_ERR_UNSUPPORTED = -3, FX_ERR_RUNTIME = -4 };
 enum { FX_ACT_NONE = 0, FX_ACT_RELU = 1, FX_ACT_SILU = 2, FX_ACT_GELU = 3 };

@@ -1,0 +1,213 @@
+"""Oracle parity of the BASELINE.json configurations THEMSELVES, run exactly as bench.py runs them (VERDICT r3 "weak #1"):
+full batch, production kernel routing (no `flat_small_shapes`: a layer's kernel is chosen by M = B*H*W, so bs=2 tests do not
+exercise the `conv3x3_kplane<256>` / `pw_kplane` instances that carry the benchmark), two concurrent batch parts, hipGraph
+replay, bench.py's own weights (seed 0) and images (`synth_image(i)`).
+
+What is compared: a sample of images (first / last image of each batch part) against the CPU fp32 oracle with the
+discontinuous selections teacher-forced FROM the engine (RT-DETR: the engine's own top-300 query set is handed to the oracle;
+mask families: the engine's own attention bitmaps), so every stage and the final outputs are checked with the same gates as the
+small-batch tests (tests/test_gpu_e2e.py::test_stage_parity_teacher_forced, test_gpu_mf.py, test_gpu_bf.py); the free-running
+selection itself is checked through the encoder scores (RT-DETR) within TOL_SCORE.  Each test prints the kernel variants the
+library routed to (`fx_conv2d_variant`, recorded in plan.meta) so that the log shows which instances ran under the oracle.
+
+Reference: FAIDetr.forward fai_detr/modelling.py:1344-1358, DETRProcessor.postprocess fai_detr/processor.py:146-217,
+FAIMaskFormer.forward fai_mf/modelling.py:712-725, BisenetFormer.forward bisenetformer/modelling.py:594-609.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from focoos_amd.registry import ModelRegistry  # noqa: E402
+from focoos_amd.synth import synth_image, synth_state_dict  # noqa: E402
+from oracle import bf_oracle as BFO  # noqa: E402
+from oracle import detr_oracle as O  # noqa: E402
+from oracle import mf_oracle as M  # noqa: E402
+from tests.helpers import rel_l2  # noqa: E402
+from tests.test_gpu_e2e import TOL_BOX, TOL_PROB, TOL_SCORE  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _bench_step(eng, pl, imgs, thr, replays=2):
+    """bench.py's step (infer_measure.step): device->device copy into the plan's input, graph replay on the engine's stream."""
+    st = eng.stream
+    sizes = torch.tensor([[imgs.shape[1], imgs.shape[2]]] * imgs.shape[0], dtype=torch.int32, device=DEV)
+    for _ in range(replays):   # the first call captures (after its eager warm-up), the later ones are pure replays
+        with torch.cuda.stream(st):
+            pl.input.copy_(imgs, non_blocking=True)
+            if hasattr(pl, "sizes"):
+                pl.sizes.copy_(sizes, non_blocking=True)
+            pl.run(st.cuda_stream, thr, None, True)
+    st.synchronize()
+
+
+def _img_nchw(pl, name, b):
+    """Image b's [1,C,H,W] fp32 view of activation buffer `name` (the buffer lives in the batch part that computed the image)."""
+    bp = pl.parts[0].B
+    nt = pl.parts[b // bp].bufs[name]
+    return nt.torch_view()[b % bp:b % bp + 1].float().cpu().permute(0, 3, 1, 2)
+
+
+def _img_rows(pl, name, b, rows_per_image):
+    bp = pl.parts[0].B
+    nt = pl.parts[b // bp].bufs[name]
+    v = nt.torch_view().reshape(bp, rows_per_image, -1)
+    return v[b % bp:b % bp + 1].float().cpu()
+
+
+def _variants(pl):
+    out = {}
+    for m in pl.meta.values():
+        out[m["variant"]] = out.get(m["variant"], 0) + 1
+    return out
+
+
+def test_config1_detr_bs32_production_path_vs_oracle():
+    """BASELINE configs[1]: fai-detr-l-obj365, bs=32, 640x640 - the step the driver times."""
+    from focoos_amd.model import FAIDetr
+
+    cfg = ModelRegistry.get_model_info("fai-detr-l-obj365")["config"]
+    sd = synth_state_dict(cfg, 0)
+    model = FAIDetr(cfg, device=DEV, seed=0)
+    eng = model.engine
+    B = 32
+    images = [synth_image(i, 640, 640) for i in range(B)]
+    x = torch.from_numpy(np.stack(images)).to(DEV)
+    pl = eng.plan(B, 640, 640, False)
+    assert getattr(pl, "n", 1) == 2 and pl.parts[0].B == 16, "bench.py's default step = two concurrent 16-image parts"
+    _bench_step(eng, pl, x, 0.5)
+    assert isinstance(pl.graph, list) and len(pl.graph) == 2, "the parts must have been replayed as hipGraphs"
+    var = _variants(pl)
+    print("kernel variants under the oracle (launches per step):", dict(sorted(var.items(), key=lambda kv: -kv[1])))
+    assert var.get("conv3x3_kplane<256>", 0) >= 30 and any(k.startswith("pw_kplane") for k in var) and any(k.startswith("pw_chain") for k in var)
+
+    sample = [0, 15, 16, 31]
+    topk = pl.enc_topk.cpu().long()
+    col = {}
+    with torch.no_grad():
+        xo = O.get_torch_batch([images[i] for i in sample], (640, 640))
+        probs_o, boxes_o = O.detr_forward(sd, cfg, xo, forced_topk=topk[sample], collect=col)
+    worst = {}
+    for j, b in enumerate(sample):
+        for k in ("res3", "res4", "res5", "enc_s32", "enc_s16", "enc_s8"):
+            e = rel_l2(_img_nchw(pl, k, b), col[k][j:j + 1])
+            worst[k] = max(worst.get(k, 0.0), e)
+            assert e < 2e-2, (b, k, e)
+        e = rel_l2(_img_rows(pl, "memory", b, pl.S), col["memory"][j:j + 1])
+        worst["memory"] = max(worst.get("memory", 0.0), e)
+        assert e < 2e-2, (b, "memory", e)
+        ds = (pl.enc_scores[b].cpu() - col["enc_scores"][j]).abs().max().item()
+        worst["enc_scores"] = max(worst.get("enc_scores", 0.0), ds)
+        assert ds <= TOL_SCORE, (b, ds)
+        e = rel_l2(_img_rows(pl, "target", b, 300), col["target"][j:j + 1])
+        assert e < 3e-2, (b, "target", e)
+        for i in range(6):
+            e = rel_l2(_img_rows(pl, f"dec{i}.out", b, 300), col[f"dec{i}_out"][j:j + 1])
+            worst[f"dec{i}"] = max(worst.get(f"dec{i}", 0.0), e)
+            assert e < 4e-2, (b, i, e)
+        dp = (pl.probs[b].cpu() - probs_o[j]).abs().max().item()
+        db = (pl.boxes[b].cpu() - boxes_o[j]).abs().max().item()
+        worst["dprob"], worst["dbox"] = max(worst.get("dprob", 0.0), dp), max(worst.get("dbox", 0.0), db)
+        assert dp <= TOL_PROB and db <= TOL_BOX, (b, dp, db)
+        # device post-process of the production step vs the oracle's post-process on the same query set: every detection the
+        # oracle puts clearly above the threshold is present with the same (query, class), nothing clearly below it is reported
+        K = probs_o.shape[-1]
+        n = int(pl.det_count[b])
+        pairs = set(zip(pl.det_queries[b, :n].cpu().tolist(), pl.det_labels[b, :n].cpu().tolist()))
+        flat = probs_o[j].flatten()
+        for f in torch.nonzero(flat > 0.5 + 2 * TOL_PROB).flatten().tolist():
+            assert divmod(f, K) in pairs, (b, divmod(f, K))
+        never = set(torch.nonzero(flat < 0.5 - 2 * TOL_PROB).flatten().tolist())
+        assert not any((q * K + c) in never for q, c in pairs)
+    print("bs=32 production path vs oracle, worst over images", sample, ":", {k: round(v, 5) for k, v in worst.items()})
+
+
+def _attn_from_bits(part, b_local, Q, levels, nl):
+    """The engine's own boolean attention masks of image b_local, one [1,Q,Lk] tensor per decoder layer (bit set = masked)."""
+    out = []
+    nlev = len(levels)
+    for i in range(nl):
+        Lk = levels[i % nlev]
+        words = part.attn_bits[i][b_local * Q:(b_local + 1) * Q].cpu().numpy().view(np.uint8)
+        m = np.unpackbits(words, axis=-1, bitorder="little")[:, :Lk].astype(bool)
+        out.append(torch.from_numpy(m).reshape(1, Q, Lk))
+    return out
+
+
+def _mask_family_check(pl, b, j, cfg, col, probs_o, stages, nl, worst):
+    bp = pl.parts[0].B
+    Q = int(cfg.get("num_queries", 100))
+    for name in stages:
+        e = rel_l2(_img_nchw(pl, name, b), col[name])
+        worst[name] = max(worst.get(name, 0.0), e)
+        assert e <= 2.5e-2, (b, name, e)
+    for i in range(nl):
+        e = rel_l2(_img_rows(pl, f"dec{i}.out", b, Q), col[f"dec{i}_out"])
+        worst[f"dec{i}"] = max(worst.get(f"dec{i}", 0.0), e)
+        assert e <= 3e-2, (b, i, e)
+    dp = (pl.probs[b].cpu() - probs_o[0]).abs().max().item()
+    lo_o = torch.sigmoid(col["mask_logits"])[0]
+    mine = pl.mask_probs[b].cpu()
+    dm = (mine - lo_o).abs().mean().item()
+    agree = ((mine >= 0.5) == (lo_o >= 0.5)).float().mean().item()
+    worst["dprob"], worst["dmask_mean"] = max(worst.get("dprob", 0.0), dp), max(worst.get("dmask_mean", 0.0), dm)
+    worst["binary_agreement_min"] = min(worst.get("binary_agreement_min", 1.0), agree)
+    assert dp <= 3e-2 and dm <= 1e-2 and agree >= 0.99, (b, dp, dm, agree)
+
+
+def test_config2_maskformer_bs16_800_production_path_vs_oracle():
+    """BASELINE configs[2]: fai-mf-l-coco-ins, bs=16, 800x800 (bench.py --model fai-mf-l-coco-ins / the default line's other_configs leg)."""
+    from focoos_amd.model import FAIMaskFormer
+
+    cfg = ModelRegistry.get_model_info("fai-mf-l-coco-ins")["config"]
+    sd = synth_state_dict(cfg, 0, family="fai_mf")
+    model = FAIMaskFormer(cfg, device=DEV, seed=0)
+    eng = model.engine
+    B, S = 16, 800
+    images = [synth_image(i, S, S) for i in range(B)]
+    x = torch.from_numpy(np.stack(images)).to(DEV)
+    pl = eng.plan(B, S, S, False, False, None)
+    assert getattr(pl, "n", 1) == 2 and pl.parts[0].B == 8
+    _bench_step(eng, pl, x, 0.5)
+    assert isinstance(pl.graph, list) and len(pl.graph) == 2
+    print("kernel variants under the oracle (launches per step):", dict(sorted(_variants(pl).items(), key=lambda kv: -kv[1])))
+    worst = {}
+    sample = [0, 15]
+    for j, b in enumerate(sample):
+        part = pl.parts[b // 8]
+        forced = _attn_from_bits(part, b % 8, eng.nq, part.levels, eng.nl)
+        col = {}
+        with torch.no_grad():
+            probs_o, _ = M.mf_forward(sd, cfg, O.get_torch_batch([images[b]], None), forced_attn=forced, collect=col, upsample=False)
+        _mask_family_check(pl, b, j, cfg, col, probs_o, ("res2", "res5", "msf0", "msf1", "msf2", "fpn_s4", "mask_features"), eng.nl, worst)
+    print("MaskFormer bs=16 800^2 production path vs oracle, worst over images", sample, ":", {k: round(v, 5) for k, v in worst.items()})
+
+
+def test_config5_bisenetformer_bs8_1024_production_path_vs_oracle():
+    """The model and size of BASELINE configs[4] (bisenetformer-l-ade, 1024x1024, bs=8), inference path of the production engine."""
+    from focoos_amd.model import BisenetFormer
+
+    cfg = ModelRegistry.get_model_info("bisenetformer-l-ade")["config"]
+    sd = synth_state_dict(cfg, 0, family="bisenetformer")
+    model = BisenetFormer(cfg, device=DEV, seed=0)
+    eng = model.engine
+    B, S = 8, 1024
+    images = [synth_image(i, S, S) for i in range(B)]
+    x = torch.from_numpy(np.stack(images)).to(DEV)
+    pl = eng.plan(B, S, S, False, False, None)
+    assert getattr(pl, "n", 1) == 2 and pl.parts[0].B == 4
+    _bench_step(eng, pl, x, 0.5)
+    assert isinstance(pl.graph, list) and len(pl.graph) == 2
+    print("kernel variants under the oracle (launches per step):", dict(sorted(_variants(pl).items(), key=lambda kv: -kv[1])))
+    worst = {}
+    sample = [0, 7]
+    for j, b in enumerate(sample):
+        part = pl.parts[b // 4]
+        forced = _attn_from_bits(part, b % 4, eng.nq, part.levels, eng.nl)
+        col = {}
+        with torch.no_grad():
+            probs_o, _ = BFO.bf_forward(sd, cfg, O.get_torch_batch([images[b]], None), forced_attn=forced, collect=col, upsample=False)
+        _mask_family_check(pl, b, j, cfg, col, probs_o, ("res2", "res3", "res4", "res5", "cp32", "cp16", "cp8", "ffm", "mask_features"), eng.nl, worst)
+    print("BiSeNetFormer bs=8 1024^2 production path vs oracle, worst over images", sample, ":", {k: round(v, 5) for k, v in worst.items()})

@@ -41,7 +41,8 @@ def test_library_exports_every_declared_symbol(lib_path):
 
     assert sorted(list(_lib.SIGNATURES) + ["fx_error_string"]) == names, "ctypes binding and header drifted apart"
     lib.fx_abi_version.restype = ctypes.c_int
-    assert lib.fx_abi_version() == 1
+    hdr = int(re.search(r"#define FX_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "focoos_amd.h")).read()).group(1))
+    assert lib.fx_abi_version() == hdr == _lib.FX_ABI_VERSION   # header, library and ctypes binding agree (a stale .so fails in _lib.load)
     lib.fx_error_string.restype = ctypes.c_char_p
     assert b"invalid argument" in lib.fx_error_string(-1)
 
@@ -323,3 +324,19 @@ def test_msda_slab_backward_support_predicate():
     assert ok([[100, 100], [50, 50], [25, 25]], 4, 13125) == 0      # the mask families' pixel-decoder encoder: every pixel is a query
     assert ok([[2, 4000]], 4, 10) == 0
     assert ok([[8, 8]], 4, 10, M=4) == 0
+
+
+def test_adapter_refuses_inputs_without_a_plan_instead_of_running_the_stock_graph():
+    """VERDICT r3 / DESIGN §7.1: the integration adapters never execute the reference's own PyTorch graph - sizes that are not multiples
+    of 32 and gradients w.r.t. the images raise."""
+    from focoos_amd import _lib
+    from focoos_amd.integration import _require_engine_input
+
+    _require_engine_input(torch.zeros(1, 3, 64, 96))
+    _require_engine_input(torch.zeros(2, 64, 96, 3, dtype=torch.uint8))
+    with pytest.raises(_lib.FocoosAmdError, match="multiple of 32"):
+        _require_engine_input(torch.zeros(1, 3, 600, 800))
+    with pytest.raises(_lib.FocoosAmdError, match="multiple of 32"):
+        _require_engine_input(torch.zeros(1, 750, 512, 3))
+    with pytest.raises(_lib.FocoosAmdError, match="input images"):
+        _require_engine_input(torch.zeros(1, 3, 64, 64, requires_grad=True))
