@@ -99,7 +99,7 @@ def test_grouped_msda_fp32_grad_out(Q):
     """The fp32-grad_out instantiation of the binning backward (msda_bwd_value_kernel<float>: 16-byte LDS stores of the staged gradient
     rows - ADVICE r3: their base was only 8-byte aligned for Q*P = 1200 and no test passed fp32 gradients).  Autograd always hands the
     node a bf16 grad_out (its output is bf16), so the backward core is called directly: the same gradient values as fp32 and as bf16 must
-    give identical point gradients and an identical value gradient."""
+    give identical point gradients and the same value gradient (up to the summation order)."""
     from focoos_amd.train import ValueGradSink, _msda_group_backward, _shape_host, _shape_tensors
 
     shapes = [[80, 80], [40, 40], [20, 20]]
@@ -118,8 +118,12 @@ def test_grouped_msda_fp32_grad_out(Q):
         torch.cuda.synchronize()
         assert sink.slab is True and gv.dtype == torch.bfloat16 and torch.isfinite(gv.float()).all()
         res.append((gv, gl, ga))
-    for a, b in zip(*res):
-        assert torch.equal(a, b)
+    (gv_a, gl_a, ga_a), (gv_b, gl_b, ga_b) = res
+    assert torch.equal(gl_a, gl_b) and torch.equal(ga_a, ga_b)     # point gradients: same arithmetic on the same values
+    # value gradient: a pixel's taps are filed in the order the LDS atomics of a launch happen to retire, so the fp32 summation order (and
+    # the bf16 rounding of the result) may differ between ANY two launches - same tolerance as the grouped test above
+    a, b = gv_a.float(), gv_b.float()
+    assert ((a - b).abs() <= 8e-3 * b.abs() + 2e-5 * b.abs().max()).all(), float((a - b).abs().max())
 
 
 def _grouped_msda_case(shapes, Q, crowd, slab, monkeypatch):
