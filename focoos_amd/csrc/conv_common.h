@@ -58,6 +58,9 @@ int fx_launch_conv3x3_flat(const ConvArgs& c, const bf16_t* w_frag, hipStream_t 
 // conv3x3_kplane.hip: the round-3 form of the same layer class (k-plane LDS layout, immediate-offset fragment reads, direct stores)
 extern "C" int fx_conv3x3_kplane_supported(int C, int N, int W);
 int fx_launch_conv3x3_kplane(const ConvArgs& c, const bf16_t* w_frag, hipStream_t stream);
+// conv3x3s2_kplane.hip: 3x3 / stride 2 / pad 1 as a stride-1 correlation over the four parity planes of the input (round 4)
+bool fx_conv3x3s2_kplane_supported(int C, int N, int Wo, int M);
+int fx_launch_conv3x3s2_kplane(const ConvArgs& c, const bf16_t* w_frag, hipStream_t stream);
 // conv_pw_kplane.hip: pointwise layers with the whole reduction resident in LDS (K = 256 / 512), one workgroup per pixel tile over all N
 bool fx_pw_kplane_supported(int C, int N, int mode);
 int fx_launch_pw_kplane(const ConvArgs& c, const bf16_t* w_frag, hipStream_t stream);

@@ -326,7 +326,7 @@ static int conv_prepare(const fx_conv_desc* d, ConvArgs& a) {
 }
 
 // Which kernel runs a layer - ONE routing function for the launch and for the label bench.py reports (fx_conv2d_variant).
-enum ConvRoute { R_C3_FLAT, R_PW_FLAT, R_SMALL_M, R_DMA, R_POOL, R_K64_N128, R_K64_N64, R_K64_N32, R_K32_N128, R_K32_N64, R_K32_N32, R_UNSUPPORTED };
+enum ConvRoute { R_C3_FLAT, R_C3_S2, R_PW_FLAT, R_SMALL_M, R_DMA, R_POOL, R_K64_N128, R_K64_N64, R_K64_N32, R_K32_N128, R_K32_N64, R_K32_N32, R_UNSUPPORTED };
 
 static ConvRoute conv_route(const fx_conv_desc* d, const ConvArgs& a) {
   // Layers with a fragment-ordered weight copy: 3x3 / stride 1 -> halo kernel (pixels fetched once for all nine taps);
@@ -352,6 +352,14 @@ static ConvRoute conv_route(const fx_conv_desc* d, const ConvArgs& a) {
         (a.M >= 20000 || (int64_t)((a.M + 127) / 128) * (d->N / 256) >= fx_tune("FX_PW_SMALL_TILES", 0)) && (mode == 0 || mode == 1 || (mode >= 3 && mode <= 6)))
       return R_PW_FLAT;
   }
+  // 3x3 / stride 2 (branch2b of the first block of res3 / res4 / res5): k-plane kernel over the parity planes of the input
+  // (conv3x3s2_kplane.hip; FX_C3S2_KPLANE=0: the implicit-GEMM tiles of rounds 1-3)
+  static const int s2_on = fx_tune("FX_C3S2_KPLANE", 1);
+  if (s2_on && !d->mask && d->w_frag && ((uintptr_t)d->w_frag % 16) == 0 && d->stride == 2 && d->KH == 3 && d->KW == 3 && d->pad == 1 && !d->pool2 &&
+      !d->out_f32 && !d->residual && d->H == 2 * d->Ho && d->W == 2 * d->Wo && a.M >= c3_min_m) {
+    const int mode = fx_c3_epilogue_mode(d->act, false, 0);
+    if ((mode == 0 || mode == 1 || mode == 3) && fx_conv3x3s2_kplane_supported(d->C, d->N, d->Wo, a.M)) return R_C3_S2;
+  }
   // BK=64 (2 workgroups/CU, 64 KiB LDS) for deep-K compute-bound layers; BK=32 (4 workgroups/CU, 34 KiB LDS: more
   // tiles and bytes in flight per CU) for the short-K layers, which are HBM/latency-bound.
   static const int k64_min = fx_tune("FX_K64_MIN_KTOT", FX_K64_MIN_KTOT);
@@ -373,6 +381,7 @@ extern "C" int fx_conv2d_nhwc_bf16(const fx_conv_desc* d, fx_stream_t stream_) {
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   switch (conv_route(d, a)) {
     case R_C3_FLAT: return fx_launch_conv3x3_flat(a, reinterpret_cast<const bf16_t*>(d->w_frag), stream);
+    case R_C3_S2: return fx_launch_conv3x3s2_kplane(a, reinterpret_cast<const bf16_t*>(d->w_frag), stream);
     case R_PW_FLAT: return fx_launch_pw_flat(a, reinterpret_cast<const bf16_t*>(d->w_frag), stream);
     case R_SMALL_M: return launch_conv<64, 64, 256, 2, 2, false, 1>(a, stream);
     case R_DMA: return fx_launch_conv_dma(a, stream);
@@ -409,6 +418,7 @@ extern "C" int fx_conv2d_variant(const fx_conv_desc* d, char* out, int cap) {
       snprintf(out, cap, kp ? "pw_kplane<K%d>" : "pw_flat<K%d>", d->C);
       break;
     }
+    case R_C3_S2: snprintf(out, cap, "conv3x3s2_kplane<%d>", d->N); break;
     case R_SMALL_M: snprintf(out, cap, "conv_igemm<64,64,256,1stage>"); break;
     case R_DMA: snprintf(out, cap, "conv_igemm_dma<256,%d>", d->N % 256 == 0 ? 256 : 128); break;
     case R_POOL: snprintf(out, cap, "conv_igemm<128,128,64,pool>"); break;

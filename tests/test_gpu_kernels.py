@@ -661,6 +661,59 @@ def test_conv3x3_flat_halo_kernel(lib, case, flat_small_shapes):
     assert (got - igemm).abs().max() / ref.abs().max() < 1.2e-2
 
 
+# 3x3 / STRIDE 2 layers on the parity-plane k-plane kernel (conv3x3s2_kplane.hip): B,H,W,C,N,act,ldx pad
+S2_CASES = [
+    (2, 16, 16, 128, 128, "relu", 0),      # res3 branch2b class: 256 x 128 tile, two channel chunks x 4 planes, M = 128 < one tile
+    (1, 48, 40, 128, 128, "relu", 8),      # several tiles (M = 480), strided input rows
+    (2, 80, 80, 256, 256, "relu", 0),      # res4 block 0 at the benchmark's width (Wo = 40): 128 x 256 tiles, image boundary inside a tile
+    (3, 40, 40, 512, 512, "relu", 0),      # res5 block 0 (Wo = 20): the 64-pixel small-M tile, two 256-channel output tiles, 32 chunks
+    (5, 6, 10, 64, 256, None, 0),          # several tiny images per tile: top / left border masks everywhere, no activation, one chunk per plane
+    (1, 12, 200, 128, 128, "silu", 16),    # Wo = 100 (MaskFormer res3 at 800 x 800): the widest plane instance
+    (1, 34, 26, 256, 256, "relu", 0),      # Wo = 13: odd output width, M tail
+]
+
+
+@pytest.mark.parametrize("case", S2_CASES)
+def test_conv3x3_stride2_kplane_kernel(lib, case, flat_small_shapes):
+    """Stride-2 3x3 layers as a stride-1 correlation over the four parity planes of the input vs fp32 torch and vs the implicit-GEMM
+    kernel; position-dependent inputs so that a wrong plane / tap offset / border mask is an O(1) error."""
+    B, H, W, Cc, N, act, pad = case
+    g = torch.Generator().manual_seed(700 + S2_CASES.index(case))
+    x = torch.randn(B, H, W, Cc, generator=g) + torch.linspace(-1, 1, W)[None, None, :, None] + torch.linspace(-0.5, 0.5, H)[None, :, None, None]
+    W4 = torch.randn(N, Cc, 3, 3, generator=g) / math.sqrt(Cc * 9) + torch.linspace(-0.03, 0.03, 9).view(1, 1, 3, 3)
+    bias = torch.randn(N, generator=g) * 0.5
+    ref = ref_conv(x, W4, bias, 2, act, None, False, False)
+    d = FxConvDesc()
+    got = run_conv(lib, x, W4, bias, 2, act, None, False, ldx=Cc + pad, frag=True)[..., :N]
+    assert got.shape == ref.shape and not torch.isnan(got).any()
+    err = (got - ref).abs().max() / ref.abs().max()
+    assert err < 1.2e-2, f"rel err {err}"
+    igemm = run_conv(lib, x, W4, bias, 2, act, None, False, ldx=Cc + pad, frag=False)[..., :N]
+    assert (got - igemm).abs().max() / ref.abs().max() < 1.2e-2
+
+
+def test_conv3x3_stride2_routing(lib, flat_small_shapes):
+    """The library's own routing label: stride-2 3x3 layers with a fragment-ordered weight copy and even input sizes run on the
+    parity-plane kernel; odd input sizes (no parity-plane view) and layers without the copy stay on the implicit-GEMM tiles."""
+    def label(H, W, Cc, N, frag):
+        d = FxConvDesc()
+        buf = torch.zeros(16, dtype=torch.bfloat16, device=DEV)
+        d.x = d.w = d.y = buf.data_ptr()
+        d.B, d.H, d.W, d.C, d.ldx = 2, H, W, Cc, Cc
+        d.Ho, d.Wo, d.N, d.ldy = (H + 1) // 2, (W + 1) // 2, N, N
+        d.KH, d.KW, d.stride, d.pad, d.act = 3, 3, 2, 1, FX_ACT["relu"]
+        if frag:
+            d.w_frag = buf.data_ptr()
+        out = C.create_string_buffer(64)
+        check(lib.fx_conv2d_variant(C.byref(d), out, 64), "variant")
+        return out.value.decode()
+
+    assert label(80, 80, 256, 256, True) == "conv3x3s2_kplane<256>"
+    assert label(160, 160, 128, 128, True) == "conv3x3s2_kplane<128>"
+    assert label(80, 80, 256, 256, False).startswith("conv_igemm")
+    assert label(81, 80, 256, 256, True).startswith("conv_igemm")
+
+
 # 1x1 layers with C, N multiples of 256 on the pointwise variant of the same kernel: B,H,W,C,N,act,residual(before act)
 PW_FLAT_CASES = [
     (1, 1, 300, 256, 256, None, False),
