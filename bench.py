@@ -432,9 +432,21 @@ def run(args):
         barrier(world, True)
         dt = max_over_ranks(time.perf_counter() - t0, world, True)
         if rank == 0:
-            print(json.dumps({"metric": "dry-run", "value": world * args.batch * args.steps / dt, "unit": "images/s", "n_gpus": world,
-                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-                              "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none", "config": {"workload": "dry-run"}}))
+            line = {"metric": "dry-run", "value": world * args.batch * args.steps / dt, "unit": "images/s", "n_gpus": world,
+                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+                    "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none", "config": {"workload": "dry-run"}}
+            if args.train:
+                # the per-rank plan of the data-parallel training step this command line would run: batch split, gradient segments and
+                # buckets, bytes all-reduced per step - from the state spec alone (focoos_amd.train.dp_plan; no GPU, no model)
+                from focoos_amd.registry import ModelRegistry
+                from focoos_amd.train import dp_plan
+
+                cfg = ModelRegistry.get_model_info(args.model)["config"]
+                norm = "SyncBN" if (args.norm == "BN" and world > 1 and args.family == "bisenetformer") else args.norm
+                line["dp_plan"] = dp_plan(cfg, args.family, norm, world, args.batch, grad_bytes=2 if os.environ.get("FX_DP_BF16", "0") == "1" else 4)
+                line["dp_plan"]["ranks"] = [{"rank": r, "images": [r * args.batch, (r + 1) * args.batch], "target_seed": f"{r} * 1000 + iteration"}
+                                            for r in range(world)]
+            print(json.dumps(line))
         return
 
     if args.train:

@@ -296,6 +296,43 @@ def notify_when_all_grads(tensors, callback, name):
         t.register_hook(hook)
 
 
+def dp_segment_of(name: str) -> int:
+    """Segment of a parameter in the flat gradient buffer: 0 backbone, 1 pixel decoder, 2 head - forward order, so backward finalises
+    them 2 -> 1 -> 0 (the three families share the prefixes ``pixel_decoder.backbone.`` / ``pixel_decoder.``)."""
+    return 0 if name.startswith("pixel_decoder.backbone.") else (1 if name.startswith("pixel_decoder.") else 2)
+
+
+def dp_plan(config: Dict, family: str, norm: str, world: int, per_rank_batch: int, bucket_bytes: int = 64 << 20, grad_bytes: int = 4) -> Dict:
+    """What a data-parallel training step moves, computed from the state spec alone (no GPU, no model): trainable parameters per segment,
+    the buckets ``BucketedGradAllReduce`` cuts (never across a segment), bytes all-reduced per step and per rank, the batch split of
+    ``TrainerArgs.batch_size`` (loaders.py:61-65).  ``bench.py --train --dry-run`` prints it; tests/test_dp_trainstep_cpu.py checks it against
+    the layout the real ``TrainStep`` builds.  ``grad_bytes`` = 2 describes the bf16 bucket option (FX_DP_BF16)."""
+    import math
+
+    from .state_spec import state_spec
+
+    kinds = ("conv_w", "lin_w", "lin_b", "ln_w", "ln_b", "emb") + (() if norm == "FrozenBN" else ("bn_w", "bn_b"))
+    seg_numel = [0, 0, 0]
+    for name, (shape, kind) in state_spec(config, family).items():
+        if kind in kinds and not (family == "fai_detr" and ".mask_features." in name):   # RT-DETR's dead mask_features conv is frozen (train_nn.HybridEncoder)
+            seg_numel[dp_segment_of(name)] += math.prod(shape) if shape else 1
+    per = max(1, bucket_bytes // 4)     # bucket boundaries are cut on the fp32 flat buffer
+    buckets, lo = [], 0
+    for n in seg_numel:
+        buckets += [min(per, lo + n - s) for s in range(lo, lo + n, per)]
+        lo += n
+    total = sum(seg_numel)
+    # ring all-reduce moves 2 (N-1)/N of the buffer per rank and direction; xGMI is point-to-point (7 links x ~153 GB/s per GPU)
+    ring = 2.0 * (world - 1) / max(world, 1) * total * grad_bytes
+    return {"world_size": world, "per_rank_batch": per_rank_batch, "global_batch": per_rank_batch * world, "trainable_parameters": total,
+            "segment_parameters": {"backbone": seg_numel[0], "pixel_decoder": seg_numel[1], "head": seg_numel[2]},
+            "launch_order": ["head", "pixel_decoder", "backbone"], "bucket_elements": buckets, "n_buckets": len(buckets),
+            "allreduce_bytes_per_step": total * grad_bytes, "ring_bytes_sent_per_rank": int(ring),
+            "other_collectives": ["num_boxes / num_masks: one 4-byte all-reduce per step"] + (
+                ["SyncBN: two [2, C] fp32 all-reduces per BatchNorm layer (forward statistics, backward sums)"] if norm == "SyncBN" else []),
+            "gradient_dtype": "fp32" if grad_bytes == 4 else "bf16"}
+
+
 class BucketedGradAllReduce:
     """Average a flat gradient buffer across data-parallel ranks in buckets with asynchronous all-reduce, OVERLAPPED with the rest
     of backward - what DistributedDataParallel's reducer does for the reference (utils/distributed/dist.py:138-157).
@@ -309,7 +346,12 @@ class BucketedGradAllReduce:
     segment i from the layers before it - starts that segment's collectives while backward continues into the earlier layers.
     ``launch()`` starts whatever has not been started (end of backward), ``wait()`` completes the step."""
 
-    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 64 << 20, group=None, segments: Optional[Sequence[Tuple[int, int]]] = None):
+    def __init__(self, flat_grad: torch.Tensor, bucket_bytes: int = 64 << 20, group=None, segments: Optional[Sequence[Tuple[int, int]]] = None,
+                 bf16: Optional[bool] = None):
+        """``bf16`` (default: FX_DP_BF16=1 in the environment, else off): the buckets travel as bfloat16 - half the bytes on the xGMI
+        links (86.7 instead of 173.4 MB per step for RT-DETR-L) at the price of rounding every rank's gradient to 8 mantissa bits
+        before the sum (the sum itself is accumulated by the collective in bf16 as well).  Each bucket is cast into a staging tensor
+        when its segment is launched and written back, averaged, in wait().  Off by default: the reference's DDP reduces fp32 buckets."""
         import torch.distributed as dist
 
         self.dist, self.group = dist, group
@@ -325,6 +367,8 @@ class BucketedGradAllReduce:
         self.log: List[Tuple[str, int]] = []      # ("segment", i) / ("backward_end", -1) in launch order: what the overlap test reads
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.before_collective = None   # optional callable: orders the current stream after gradient producers on other streams
+        self.bf16 = bool(int(os.environ.get("FX_DP_BF16", "0"))) if bf16 is None else bool(bf16)
+        self._staged: List[Tuple[int, int, torch.Tensor]] = []   # (start, numel, bf16 staging tensor) of the buckets in flight
 
     def launch_segment(self, i: int):
         """Start the all-reduce of segment i's buckets (idempotent within a step): its gradients are final."""
@@ -337,7 +381,11 @@ class BucketedGradAllReduce:
         if self.before_collective is not None:
             self.before_collective()
         for s, n in self.seg_buckets[i]:
-            self.handles.append(self.dist.all_reduce(self.flat[s:s + n], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+            buf = self.flat[s:s + n]
+            if self.bf16:
+                buf = buf.to(torch.bfloat16)
+                self._staged.append((s, n, buf))
+            self.handles.append(self.dist.all_reduce(buf, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def launch(self, first: int = 0, last: Optional[int] = None):
         """End of backward: start every segment that no hook has started yet."""
@@ -351,4 +399,8 @@ class BucketedGradAllReduce:
         self.handles.clear()
         self.launched = [False] * len(self.segments)
         if self.world > 1:
+            if self.bf16:
+                for s, n, buf in self._staged:
+                    self.flat[s:s + n].copy_(buf)
+                self._staged.clear()
             self.flat.div_(self.world)

@@ -380,7 +380,15 @@ class TrainStep:
 
         self.model, self._nn = model, train_nn
         self.check_every = int(check_every)   # Hungarian status word polled every N steps (0 = only through check()): see check()
-        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+
+        from .train import dp_segment_of as seg_of
+
+        # Flat layout = FORWARD order [backbone | pixel decoder | head], whatever order the modules were registered in (the backbone is
+        # assigned to pixel_decoder after pixel_decoder's own layers exist, so named_parameters() lists it LAST among them - round 4: with
+        # the registration order the three-segment layout below was never recognised and the overlapped all-reduce silently fell back to
+        # one segment launched after backward; tests/test_dp_trainstep_cpu.py now drives this constructor on two gloo ranks).  The sort is
+        # stable, so parameters keep their module order inside a segment; state_dict() / checkpoints are unaffected (they follow the modules).
+        named = sorted(((n, p) for n, p in model.named_parameters() if p.requires_grad), key=lambda np_: seg_of(np_[0]))
         dev = named[0][1].device
         from .state_spec import state_spec
         from .train_data import optimizer_hyperparams
@@ -400,9 +408,6 @@ class TrainStep:
         self.named = named
         # gradient all-reduce overlapped with backward: the flat buffer is [backbone | hybrid encoder | predictor] in parameter order;
         # backward finalises the predictor's gradients first (hook on the encoder outputs), then the encoder's (hook on res3..5)
-        def seg_of(n):
-            return 0 if n.startswith("pixel_decoder.backbone.") else (1 if n.startswith("pixel_decoder.") else 2)
-
         base = self.opt.flat_p.data_ptr()
         segs = [seg_of(n) for n, _ in named]
         offs = [(self.opt.params[n].data_ptr() - base) // 4 for n, _ in named]

@@ -24,6 +24,40 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _bf16_worker(rank, world, port, q):
+    """FX_DP_BF16 / bf16=True: buckets travel as bfloat16 (half the xGMI bytes); the averaged gradient equals the fp32 average to bf16
+    rounding of the two summands and of their sum (VERDICT r3 next #9c)."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from focoos_amd.train import BucketedGradAllReduce
+
+    flat = torch.randn(10_000, generator=torch.Generator().manual_seed(200 + rank)) * 3.0
+    mine = flat.clone()
+    red = BucketedGradAllReduce(flat, bucket_bytes=4096 * 4, segments=[(0, 6000), (6000, 10_000)], bf16=True)
+    red.launch_segment(1)
+    staged_dtype = red._staged[0][2].dtype
+    red.launch()
+    red.wait()
+    other = torch.randn(10_000, generator=torch.Generator().manual_seed(200 + (1 - rank))) * 3.0
+    want = (mine + other) / 2
+    exact = (mine.bfloat16().float() + other.bfloat16().float()).bfloat16().float() / 2     # what a bf16 collective computes
+    err = float((flat - want).abs().max() / want.abs().max())
+    q.put((rank, staged_dtype == torch.bfloat16, bool(torch.equal(flat, exact)), err < 8e-3, not red._staged))
+    dist.destroy_process_group()
+
+
+def test_bf16_buckets_two_ranks_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bf16_worker, args=(r, 2, 29715, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert res == [(0, True, True, True, True), (1, True, True, True, True)], res
+
+
 def test_bucketed_allreduce_two_ranks_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -138,6 +138,20 @@ def test_bench_spawns_its_own_ranks():
         assert len(lines) == 1, r.stdout
         j = json.loads(lines[0])
         assert j["n_gpus"] == 2 and j["steps"] == 4 and j["value"] > 0
+        if extra:   # --train --dry-run: the per-rank plan of the data-parallel step (VERDICT r3 next #9b)
+            plan = j["dp_plan"]
+            assert plan["world_size"] == 2 and plan["per_rank_batch"] == 16 and plan["global_batch"] == 32
+            assert plan["trainable_parameters"] == 43_361_847 and plan["allreduce_bytes_per_step"] == 4 * 43_361_847   # 173.4 MB fp32 (SURVEY: 173.7)
+            assert sum(plan["segment_parameters"].values()) == plan["trainable_parameters"] == sum(plan["bucket_elements"])
+            assert max(plan["bucket_elements"]) * 4 <= 64 << 20 and plan["n_buckets"] == 4 and plan["launch_order"][0] == "head"
+            assert plan["ring_bytes_sent_per_rank"] == plan["allreduce_bytes_per_step"]          # 2 (N-1)/N = 1 at N = 2
+            assert [r["images"] for r in plan["ranks"]] == [[0, 16], [16, 32]]
+    r8 = subprocess.run([sys.executable, "-c", "import json; from focoos_amd.train import dp_plan; from focoos_amd.registry import ModelRegistry as R; "
+                         "print(json.dumps(dp_plan(R.get_model_info('bisenetformer-l-ade')['config'], 'bisenetformer', 'SyncBN', 8, 8, grad_bytes=2)))"],
+                        capture_output=True, text=True, timeout=120, cwd=ROOT, env=env)
+    p8 = json.loads(r8.stdout.strip().splitlines()[-1])
+    assert p8["global_batch"] == 64 and p8["gradient_dtype"] == "bf16" and 30e6 < p8["allreduce_bytes_per_step"] < 40e6 and len(p8["other_collectives"]) == 2
+    assert abs(p8["ring_bytes_sent_per_rank"] - 1.75 * p8["allreduce_bytes_per_step"]) < 8
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--dry-run"], capture_output=True, text=True, timeout=120,
                          cwd=ROOT, env=dict(env, WORLD_SIZE="2", RANK="0"))
     assert bad.returncode != 0 and "WORLD_SIZE=2 but --gpus 1" in (bad.stderr + bad.stdout)
