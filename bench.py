@@ -257,11 +257,13 @@ def _wgrad_roofline(nn_, stepper, imgs, targets, family="fai_detr"):
 
     nn_._conv_param_grads = timed
     side, stepper.wgrad_stream = stepper.wgrad_stream, None   # this one step keeps the weight gradients on the main stream, where the events are
+    graphs, stepper.use_graphs = stepper.use_graphs, False     # ... and runs eagerly (a graph replay never enters the Python hook)
     try:
         stepper.step(imgs, targets)
     finally:
         nn_._conv_param_grads = orig
         stepper.wgrad_stream = side
+        stepper.use_graphs = graphs
     torch.cuda.synchronize()
     ms = sum(a.elapsed_time(b) for a, b, _, _ in rec)
     fl, by = sum(r[2] for r in rec), sum(r[3] for r in rec)
@@ -367,6 +369,8 @@ def train_measure(args, world, rank, local, with_roofline=True):
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
         dp_check = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "master_weights_identical_across_ranks": bool((lo == hi).item()),
                     "checksum": float(chk.item())}
+    class stepper_graphs:   # noqa: N801  (tiny record read by the JSON line below)
+        on = stepper._graph_state is not None
     roof = _wgrad_roofline(train_nn, stepper, imgs, all_targets[0], args.family) if (rank == 0 and with_roofline) else None
     barrier(world, False)
     out = None
@@ -377,9 +381,11 @@ def train_measure(args, world, rank, local, with_roofline=True):
             "metric": f"images/sec @ {S}^2 (train bs={B}/GPU" + ("; bf16 variant of BASELINE configs[4], which names fp16" if bf else "") + ")", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.model} training step: forward (train mode, norm={args.norm}) + {crit} "
+            "config": {"steps_are": "hipGraph replays (forward graph, backward graph) around an eager criterion + optimizer" if stepper_graphs.on else "eager launches",
+                       "workload": f"{args.model} training step: forward (train mode, norm={args.norm}) + {crit} "
                                    f"+ backward + gradient all-reduce + fused AdamW/clip, bs={B}/GPU, {S}x{S}, bf16 activations and gradients, "
-                                   "fp32 master weights; HIP autograd nodes (eager launches, no graph)"
+                                   "fp32 master weights; HIP autograd nodes; "
+                                   + ("forward and backward replayed as two hipGraphs around an eager criterion" if getattr(stepper_graphs, "on", False) else "eager launches, no graph")
                                    + ("; DEVIATION from BASELINE configs[4] ('fp16'): the engine computes in bf16 without a GradScaler - on the real "
                                       "reference the training losses under fp16 autocast deviate 0.66 % from fp32, under bf16 autocast 1.7 % "
                                       "(tests/test_oracle_vs_reference.py::test_reference_fp16_amp_losses_vs_fp32_and_bf16_autocast)" if bf else ""),
@@ -487,9 +493,9 @@ def other_configs(args, world, rank, local, out):
     # inference legs first (replicas, no collective), the data-parallel training legs last
     plan = [("infer_fai-mf-l-coco-ins_bs16_800", dict(train=False, model="fai-mf-l-coco-ins", family="fai_mf", batch=16, size=800, steps=10, warmup=3)),
             ("infer_bisenetformer-l-ade_bs32_640", dict(train=False, model="bisenetformer-l-ade", family="bisenetformer", batch=32, size=640, steps=10, warmup=3)),
-            ("train_fai-detr-l-obj365_bs16_640_frozenbn", dict(train=True, model="fai-detr-l-obj365", family="fai_detr", batch=16, size=640, norm="FrozenBN", steps=6, warmup=2)),
+            ("train_fai-detr-l-obj365_bs16_640_frozenbn", dict(train=True, model="fai-detr-l-obj365", family="fai_detr", batch=16, size=640, norm="FrozenBN", steps=6, warmup=4)),
             ("train_bisenetformer-l-ade_bs8_1024_bn", dict(train=True, model="bisenetformer-l-ade", family="bisenetformer", batch=8, size=1024,
-                                                          norm="SyncBN" if world > 1 else "BN", steps=4, warmup=2))]
+                                                          norm="SyncBN" if world > 1 else "BN", steps=4, warmup=4))]
     for name, over in plan:
         a = copy.copy(args)
         for k, v in over.items():

@@ -351,7 +351,8 @@ class FAIDetrTrainable(nn.Module):
 
             notify_when_all_grads(tensors, self.grad_ready, name)
 
-    def forward(self, images: torch.Tensor, targets: Sequence, forced_topk=None, fixed_matches=None):
+    def forward_outputs(self, images: torch.Tensor, forced_topk=None):
+        """Everything before the criterion: the prediction sets (static shapes - what a captured training step replays, TrainStep graphs)."""
         f = self.pixel_decoder.backbone(images)
         feats = [f["res3"], f["res4"], f["res5"]]
         self._notify_when_all_grads(feats, "encoder")
@@ -359,7 +360,10 @@ class FAIDetrTrainable(nn.Module):
         self._notify_when_all_grads(list(enc), "head")
         out = self.head.predictor(enc, forced_topk)
         self.last_outputs = out
-        return self.head.criterion(out, targets, fixed_matches)
+        return out
+
+    def forward(self, images: torch.Tensor, targets: Sequence, forced_topk=None, fixed_matches=None):
+        return self.head.criterion(self.forward_outputs(images, forced_topk), targets, fixed_matches)
 
 
 class TrainStep:
@@ -374,12 +378,20 @@ class TrainStep:
 
     def __init__(self, model: FAIDetrTrainable, lr: float = 1e-4, backbone_multiplier: float = 0.1, weight_decay: float = 1e-4,
                  weight_decay_norm: float = 0.0, weight_decay_embed: float = 0.0, max_grad_norm: float = 0.1, ema_decay: Optional[float] = None, ema_warmups: int = 2000, scheduler: Optional[str] = None,
-                 max_iters: int = 0, scheduler_extra: Optional[Dict] = None, check_every: int = 16):
+                 max_iters: int = 0, scheduler_extra: Optional[Dict] = None, check_every: int = 16, graphs: Optional[bool] = None):
         from . import train_nn
         from .train import BucketedGradAllReduce, FlatAdamW
 
         self.model, self._nn = model, train_nn
         self.check_every = int(check_every)   # Hungarian status word polled every N steps (0 = only through check()): see check()
+        # hipGraph replay of the step (see _step_graphed); default from FX_TRAIN_GRAPH.  OFF by default: measured on one MI355X the
+        # replayed step is 8 % SLOWER than the eager one (RT-DETR 26.6 vs 24.5 ms, BiSeNetFormer 32.3 vs 29.5, MaskFormer 90.6 vs 83.8;
+        # profiles/r04_train_graph.txt) - the step is GPU-bound, not host-bound: on ONE stream eager and replay take the same 27.9 ms, and
+        # the weight-gradient side stream buys the eager step 3.5 ms of overlap but the replayed graph only 1.2 ms (the runtime runs the
+        # forked branches of one graph with less concurrency than two live queues).  The capture removes ~20 ms of host work per step,
+        # which matters only where the host is the bottleneck (many ranks per host, slow cores).
+        self.use_graphs = bool(int(os.environ.get("FX_TRAIN_GRAPH", "0"))) if graphs is None else bool(graphs)
+        self._graph_state, self._eager_steps = None, 0
 
         from .train import dp_segment_of as seg_of
 
@@ -424,6 +436,15 @@ class TrainStep:
             from .engine import _device_stream
 
             self.wgrad_stream = _device_stream(torch.device(self.opt.dev), 1)
+        # The step runs on a stream of its own, never on the legacy default stream: autograd ties every parameter's AccumulateGrad node to
+        # the stream of its first use, and a backward CAPTURE that has to synchronise with the legacy default stream crashes in
+        # hipStreamEndCapture (ROCm 7.2; PyTorch's CUDA-graph notes demand the same: warm-up on a side stream).  Stream 0 of the per-device
+        # pool = the engines' main stream (training and inference of one process do not overlap).
+        self.stream = None
+        if torch.device(self.opt.dev).type == "cuda":
+            from .engine import _device_stream
+
+            self.stream = _device_stream(torch.device(self.opt.dev), 0)
         self.packer = self._nn.WeightPacker(model)
         self.reducer.before_collective = self._join_wgrads   # a segment's gradients are final only once its queued wgrads have run
         import os as _os
@@ -456,8 +477,140 @@ class TrainStep:
     def _join_wgrads(self):
         self._nn.wgrad_join(self.opt.dev)
 
-    def step(self, images: torch.Tensor, targets: Sequence) -> Dict[str, torch.Tensor]:
+    # ------------------------------------------------------------------------------------------------ captured step
+    # TrainerLoop.run_step (trainer/trainer.py:723-773) as TWO hipGraph replays around an eager criterion (the eager
+    # step issued ~1 700 launches from Python, 20-22 ms of host time in a 24 ms step; BiSeNetFormer's 1 956 launches were host-bound
+    # outright).  What is static is captured: graph 1 = zero the flat gradients + weight re-packing + the model up to its prediction sets
+    # (`forward_outputs`), graph 2 = the backward of exactly that part from the prediction sets' gradients (weight gradients on the side
+    # stream, forked and joined inside the capture).  What depends on the step's TARGETS - Hungarian matching, pair counts, num_boxes,
+    # the losses and their gradient w.r.t. the prediction sets - runs eagerly in between on detached leaves (tens of launches instead
+    # of ~1 700): no target-dependent host scalar is frozen into a graph.  The optimizer (its bias-correction step count is a host scalar)
+    # and the data-parallel all-reduce stay eager as well: with graphs the all-reduce starts after the backward graph (no overlap with
+    # it; the overlapped hooks are the eager path's).  The mechanism is torch.cuda.make_graphed_callables' (static input / output /
+    # gradient buffers in one private pool), written out because the step owns state that must sit inside the captures (gradient
+    # zero-fill, arena, weight packing, stream pinning, side-stream join).  Falls back to the eager step for SyncBN (collectives inside
+    # the forward) and on CPU tensors (the gloo tests).
+    def _graphs_applicable(self, images) -> bool:
+        if not self.use_graphs or not images.is_cuda:
+            return False
+        return not any(getattr(m, "norm_mode", None) == "SyncBN" for m in self.model.modules())
+
+    @staticmethod
+    def _flatten(obj, out: List):
+        if isinstance(obj, torch.Tensor):
+            out.append(obj)
+            return ("t", len(out) - 1)
+        if isinstance(obj, dict):
+            return ("d", {k: TrainStep._flatten(v, out) for k, v in obj.items()})
+        if isinstance(obj, (list, tuple)):
+            return ("l" if isinstance(obj, list) else "u", [TrainStep._flatten(v, out) for v in obj])
+        return ("c", obj)
+
+    @staticmethod
+    def _rebuild(spec, tensors):
+        kind, v = spec
+        if kind == "t":
+            return tensors[v]
+        if kind == "d":
+            return {k: TrainStep._rebuild(x, tensors) for k, x in v.items()}
+        if kind in ("l", "u"):
+            r = [TrainStep._rebuild(x, tensors) for x in v]
+            return r if kind == "l" else tuple(r)
+        return v
+
+    def _capture(self, images: torch.Tensor):
         nn_ = self._nn
+        dev = torch.device(self.opt.dev)
+        st = {"key": (tuple(images.shape), images.dtype), "images": images.clone()}
+        for n, p in self.named:
+            p.grad = self.opt.grads[n]
+        hooks, self.model.grad_ready = self.model.grad_ready, None     # the reducer's hooks belong to the eager path (collectives are not captured)
+        torch.cuda.synchronize(dev)
+        pool = torch.cuda.graph_pool_handle()
+        g_fwd, g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        nn_.DIRECT_GRAD[0] = True
+        if self.wgrad_stream is not None:
+            nn_.WGRAD_STREAM[dev] = self.wgrad_stream
+        try:
+            with torch.cuda.graph(g_fwd, pool=pool, stream=self.stream):
+                nn_.pin_stream(dev, True)          # the capture stream (pinned inside the context: launches must land on it)
+                self.opt.zero_grad()
+                nn_.ARENA.arm(self.opt.numel + (8 << 20), dev)
+                self.packer.pack(dev)
+                out = self.model.forward_outputs(st["images"])
+                nn_.pin_stream(dev, False)
+            tensors: List[torch.Tensor] = []
+            st["spec"] = self._flatten(out, tensors)
+            st["outs"] = tensors
+            req = [t for t in tensors if t.requires_grad]
+            st["gouts"] = [torch.zeros_like(t) for t in req]
+            # (the backward is captured on THIS thread - no launches from the autograd engine's worker thread into a capture)
+            with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(g_bwd, pool=pool, stream=self.stream):
+                nn_.pin_stream(dev, True)
+                torch.autograd.backward(req, st["gouts"])
+                self._join_wgrads()
+                nn_.pin_stream(dev, False)
+        finally:
+            nn_.DIRECT_GRAD[0] = False
+            nn_.pin_stream(dev, False)
+            nn_.WGRAD_STREAM.pop(dev, None)
+            self.model.grad_ready = hooks
+        st["fwd"], st["bwd"] = g_fwd, g_bwd
+        self._graph_state = st
+
+    def _step_graphed(self, images: torch.Tensor, targets: Sequence) -> Dict[str, torch.Tensor]:
+        st = self._graph_state
+        if st is None or st["key"] != (tuple(images.shape), images.dtype):
+            self._capture(images)
+            st = self._graph_state
+        st["images"].copy_(images, non_blocking=True)
+        st["fwd"].replay()
+        leaves = [t.detach().requires_grad_(True) if t.requires_grad else t for t in st["outs"]]
+        out = self._rebuild(st["spec"], leaves)
+        self.model.last_outputs = out
+        losses = self.model.head.criterion(out, targets)
+        total = torch.stack(list(losses.values())).sum()
+        total.backward()
+        for g, l in zip(st["gouts"], [l for l in leaves if l.requires_grad]):
+            if l.grad is None:
+                g.zero_()
+            else:
+                g.copy_(l.grad)
+        st["bwd"].replay()
+        return losses
+
+    def step(self, images: torch.Tensor, targets: Sequence) -> Dict[str, torch.Tensor]:
+        if self.stream is None or not images.is_cuda:
+            return self._step(images, targets)
+        cur = torch.cuda.current_stream(images.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            losses = self._step(images, targets)
+        cur.wait_stream(self.stream)
+        return losses
+
+    def _step(self, images: torch.Tensor, targets: Sequence) -> Dict[str, torch.Tensor]:
+        nn_ = self._nn
+        if self._graphs_applicable(images) and self._eager_steps >= 2:   # two eager steps first: lazy packing + first-use kernel attributes, then the packer's device table
+            if self.scheduler is not None:
+                from .train_data import lr_factor
+
+                f = lr_factor(self.scheduler, self.iteration, self.max_iters, **self.scheduler_extra)
+                if f != self._lr_factor:
+                    self.opt.set_lr_scale(f, self._base_lrs)
+                    self._lr_factor = f
+            self.iteration += 1
+            losses = self._step_graphed(images, targets)
+            self.reducer.launch()
+            self.reducer.wait()
+            self.opt.step()
+            nn_.WEIGHTS_EPOCH[0] += 1
+            if self.ema is not None:
+                self.ema.update()
+            if self.check_every > 0 and self.iteration % self.check_every == 0:
+                self.check()
+            return losses
+        self._eager_steps += 1
         if self.scheduler is not None:
             from .train_data import lr_factor
 

@@ -242,7 +242,8 @@ class FAIMaskFormerTrainable(nn.Module):
 
     grad_ready = None   # callable(segment_name) set by TrainStep (overlapped gradient all-reduce)
 
-    def forward(self, images: torch.Tensor, targets: Sequence, forced_attn=None, fixed_matches=None):
+    def forward_outputs(self, images: torch.Tensor, forced_attn=None):
+        """Everything before the criterion: the prediction sets (static shapes - what a captured training step replays, TrainStep graphs)."""
         f = self.pixel_decoder.backbone(images)
         if self.grad_ready is not None:
             from .train import notify_when_all_grads
@@ -253,4 +254,7 @@ class FAIMaskFormerTrainable(nn.Module):
             notify_when_all_grads([mask_features] + list(msf), self.grad_ready, "head")
         out = self.head.predictor(msf, mask_features, forced_attn)
         self.last_outputs = out
-        return self.head.criterion(out, targets, fixed_matches)
+        return out
+
+    def forward(self, images: torch.Tensor, targets: Sequence, forced_attn=None, fixed_matches=None):
+        return self.head.criterion(self.forward_outputs(images, forced_attn), targets, fixed_matches)
