@@ -501,7 +501,7 @@ class _PlanBase:
         # algorithmic (compulsory) HBM bytes of this launch: input read once, output written once, residual, weights
         alg_bytes = 2.0 * x.B * x.H * x.W * pc.C + (4.0 if out_f32 else 2.0) * M * pc.N + (2.0 * M * pc.N if residual is not None else 0.0) \
             + 2.0 * pc.N * pc.KH * pc.KW * pc.C
-        self.meta[len(self.ops)] = {"kind": "conv", "variant": variant, "flops": flops, "bytes": alg_bytes,
+        self.meta[len(self.ops)] = {"kind": "conv", "variant": variant, "flops": flops, "flops_executed": flops - extra_flops_per_pixel * M, "bytes": alg_bytes,
                                     "name": name or "slice", "M": M, "N": pc.N, "K": pc.KH * pc.KW * pc.C}
         self._op(self.lib.fx_conv2d_nhwc_bf16, C.byref(d))
         return out

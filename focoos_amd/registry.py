@@ -73,6 +73,11 @@ _BF_L_ADE_CONFIG = {
 }
 
 
+# focoos/model_registry/bisenetformer-s-ade.json: the same head on STDC-1 (two blocks per stage)
+_BF_S_ADE_CONFIG = copy.deepcopy(_BF_L_ADE_CONFIG)
+_BF_S_ADE_CONFIG["backbone_config"]["layers"] = [2, 2, 2]
+
+
 def _bf_entry(name: str, cfg: Dict, description: str) -> Dict:
     cfg = copy.deepcopy(cfg)
     return {
@@ -93,6 +98,7 @@ def _mf_entry(name: str, cfg: Dict, description: str) -> Dict:
 
 _REGISTRY = {
     "bisenetformer-l-ade": _bf_entry("bisenetformer-l-ade", _BF_L_ADE_CONFIG, "BiSeNetFormer large (STDC-2), ADE20K semantic segmentation"),
+    "bisenetformer-s-ade": _bf_entry("bisenetformer-s-ade", _BF_S_ADE_CONFIG, "BiSeNetFormer small (STDC-1), ADE20K semantic segmentation"),
     "fai-mf-l-coco-ins": _mf_entry("fai-mf-l-coco-ins", _MF_L_COCO_INS_CONFIG, "MaskFormer large (R101-vd), COCO instance segmentation"),
     "fai-detr-l-obj365": _entry("fai-detr-l-obj365", 365, "RT-DETR large (R50-vd), Objects365 head"),
     "fai-detr-l-coco": _entry("fai-detr-l-coco", 80, "RT-DETR large (R50-vd), COCO head"),

@@ -364,3 +364,31 @@ def test_bf_full_size_batch_properties(setup):
         assert M.masks_to_xyxy(m).tolist() == boxes[b, :n].cpu().tolist()
         assert m.sum(0).max() <= 1
         assert sorted(dq[b, :n].cpu().tolist()) == dq[b, :n].cpu().tolist()
+
+
+def test_bf_small_variant_stage_parity():
+    """bisenetformer-s-ade (STDC-1, layers [2, 2, 2]; focoos/model_registry/bisenetformer-s-ade.json) through the same engine: stage and
+    output parity against the oracle (pinned live to the reference built from that registry file: tests/test_oracle_vs_reference.py),
+    attention masks teacher-forced to the oracle's, plus the training graph's state-dict keys."""
+    cfg = ModelRegistry.get_model_info("bisenetformer-s-ade")["config"]
+    assert cfg["backbone_config"]["layers"] == [2, 2, 2]
+    sd = synth_state_dict(cfg, 11, family="bisenetformer")
+    eng = BfEngine(cfg, sd, device=DEV, full_masks=False)
+    images = [synth_image_structured(40 + i, 192, 256) for i in range(2)]
+    col = {}
+    with torch.no_grad():
+        probs_o, masks_o = BF.bf_forward(sd, cfg, get_torch_batch(images, None), collect=col, upsample=False)
+    pl = eng.forward(torch.from_numpy(np.stack(images)).to(DEV), forced_attn=col["attn_masks"])
+    torch.cuda.synchronize()
+    for name in ("res2", "res3", "res4", "res5", "cp32", "cp16", "cp8", "ffm", "mask_features"):
+        assert rel_l2(nchw(pl.bufs[name]), col[name]) <= 2.5e-2, name
+    for i in range(6):
+        assert rel_l2(pl.bufs[f"dec{i}.out"].torch_view().float().cpu().reshape(2, -1, 256), col[f"dec{i}_out"]) <= 3e-2, i
+    assert (pl.probs.cpu() - probs_o).abs().max() <= 3e-2
+    assert (pl.mask_probs.cpu() - masks_o).abs().mean() <= 1e-2
+    assert ((pl.mask_probs.cpu() >= 0.5) == (masks_o >= 0.5)).float().mean() >= 0.99
+    from focoos_amd.train_bf import BisenetFormerTrainable
+
+    net = BisenetFormerTrainable(cfg, norm="FrozenBN").to(DEV)
+    assert sorted(net.state_dict().keys()) == sorted(sd.keys())
+    net.load_state_dict(sd, strict=True)

@@ -84,6 +84,15 @@ def test_mf_oracle_matches_reference_live():
 def test_bf_oracle_matches_reference_live():
     """BiSeNetFormer (A13): forward + batch-1 postprocess (predict_all_pixels) of the restatement vs the real reference, another
     seed and size than the committed golden; the registry config equals the reference's own registry file."""
+    _bf_forward_vs_reference("bisenetformer-l-ade")
+
+
+def test_bf_small_variant_forward_matches_reference():
+    """bisenetformer-s-ade (STDC-1: two blocks per stage): the same restatement against the reference built from ITS registry file."""
+    _bf_forward_vs_reference("bisenetformer-s-ade")
+
+
+def _bf_forward_vs_reference(name):
     import json
     import os
 
@@ -94,8 +103,8 @@ def test_bf_oracle_matches_reference_live():
     ref_import.install()
     import focoos.models.bisenetformer.processor as bp
 
-    cfg = ModelRegistry.get_model_info("bisenetformer-l-ade")["config"]
-    ref_cfg = json.load(open(os.path.join(ref_import.REFERENCE_ROOT, "focoos/model_registry/bisenetformer-l-ade.json")))["config"]
+    cfg = ModelRegistry.get_model_info(name)["config"]
+    ref_cfg = json.load(open(os.path.join(ref_import.REFERENCE_ROOT, f"focoos/model_registry/{name}.json")))["config"]
     assert {k: v for k, v in cfg.items() if k != "resolution"} == ref_cfg
     model, proc, _ = ref_import.build_reference_bf(ref_cfg)
     bp.binary_mask_to_base64 = lambda m: ""  # cv2/PNG tail is not installed and outside the path
