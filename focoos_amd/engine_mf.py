@@ -45,14 +45,19 @@ class MfEngine(_EngineBase):
         self.nl = int(config.get("transformer_predictor_dec_layers", 6))
         self.n_enc = int(config.get("pixel_decoder_transformer_layers", 0))
         self.nlev = min(3, self.nl)
-        dims = [self.hd, int(config.get("pixel_decoder_feat_dim", 256)), int(config.get("pixel_decoder_out_dim", 256)),
-                int(config.get("transformer_predictor_out_dim", 256))]
-        if any(d != 256 for d in dims) or int(config.get("pixel_decoder_transformer_nheads", 8)) != 8:
-            raise _lib.FocoosAmdError("engine kernels are specialised for 256 channels / 8 heads (fai-mf-l)")
+        # pixel-decoder width fd = mask-feature / mask-embedding width md: 256 (fai-mf-l-coco-ins) or 128 (fai-mf-l-ade); the decoder's
+        # hidden width is 256 in every registry model.  The pixel decoder's own transformer encoder runs at fd channels with 8 heads:
+        # only fd = 256 (head dim 32) has an attention kernel, so fd = 128 needs pixel_decoder_transformer_layers = 0 (fai-mf-l-ade).
+        self.fd = int(config.get("pixel_decoder_feat_dim", 256))
+        self.md = int(config.get("transformer_predictor_out_dim", 256))
+        if (self.hd != 256 or self.fd not in (128, 256) or self.md != self.fd or int(config.get("pixel_decoder_out_dim", 256)) != self.fd
+                or int(config.get("pixel_decoder_transformer_nheads", 8)) != 8 or (self.n_enc > 0 and self.fd != 256)):
+            raise _lib.FocoosAmdError("engine kernels cover hidden 256 / 8 heads with pixel-decoder = mask width 256, or 128 without a "
+                                      "pixel-decoder transformer (fai-mf-l-coco-ins, fai-mf-l-ade)")
         if self.nq > 128 or self.nc + 1 > 256:
             raise _lib.FocoosAmdError("engine kernels cover num_queries <= 128 and num_classes <= 255")
-        if config.get("postprocessing_type", "instance") != "instance" or config.get("predict_all_pixels", False):
-            raise _lib.FocoosAmdError("engine covers the instance post-processing branch (predict_all_pixels=False)")
+        # post-processing: threshold branch (instance, fx_mf_postprocess) or per-pixel argmax (predict_all_pixels, fx_seg_postprocess)
+        self.predict_all_pixels = bool(config.get("predict_all_pixels", False))
         self.mask_threshold = float(config.get("mask_threshold", 0.5))
         self.threshold = float(config.get("threshold", 0.5))
         self.use_mask_score = bool(config.get("use_mask_score", False))
@@ -179,13 +184,13 @@ class _MfPlan(MaskDecoderPlanMixin, _PlanBase):
         msf = [y]
         for idx, f in ((3, feats[4]), (2, feats[3]), (1, feats[2])):
             cur = self.conv(f, P[f"{pd}.adapter_{idx}"], name=f"fpn.lat{idx}")
-            ysum = self._new(f"fpn.sum{idx}", B, f.H, f.W, 256)
-            self._op(lib.fx_upsample_nearest_add_nhwc_bf16, cur.ptr, cur.ld, y.ptr, y.ld, ysum.ptr, ysum.ld, B, f.H, f.W, y.H, y.W, 256)
+            ysum = self._new(f"fpn.sum{idx}", B, f.H, f.W, e.fd)
+            self._op(lib.fx_upsample_nearest_add_nhwc_bf16, cur.ptr, cur.ld, y.ptr, y.ld, ysum.ptr, ysum.ld, B, f.H, f.W, y.H, y.W, e.fd)
             y = self.conv(ysum, P[f"{pd}.layer_{idx}"], name=f"msf{4 - idx}" if len(msf) < 3 else "fpn_s4", act="relu")
             if len(msf) < 3:
                 msf.append(y)
         mf = self.conv(y, P[f"{pd}.mask_features"], name="mask_features")
         # ---- masked-attention decoder, heads, outputs and post-process (engine_maskdec.py)
-        dn, emb = self.build_masked_decoder(msf, mf, 256)
-        self.build_mask_outputs(dn, emb, mf, 256, self.full_masks, predict_all_pixels=False)
+        dn, emb = self.build_masked_decoder(msf, mf, e.md)
+        self.build_mask_outputs(dn, emb, mf, e.md, self.full_masks, predict_all_pixels=e.predict_all_pixels)
 

@@ -269,13 +269,13 @@ def binary_mask_to_base64(binary_mask: np.ndarray) -> str:
 
 
 class MaskFormerProcessor(DETRProcessor):
-    """Mirror of focoos/models/fai_mf/processor.py:34-306 (instance branch).  ``preprocess`` does not resize
+    """Mirror of focoos/models/fai_mf/processor.py:34-306 (threshold branch and the predict_all_pixels branch).  ``preprocess`` does not resize
     (processor.py:96: "we are not using image_size input"); ``postprocess`` runs the reference's mask thresholding,
     empty-mask filter, mask score and score filter on the GPU (``fx_mf_postprocess``) and only the PNG/base64 packaging on
     the host.  The reference's gather-based filtering only works for batch 1 (index tensors are [1, n]); here every image
     of the batch gets the batch-1 behaviour."""
 
-    _postprocessing_types = ("instance",)
+    _postprocessing_types = ("instance", "semantic")   # fai-mf-l-coco-ins / fai-mf-l-ade (predict_all_pixels): one post-process, two branches
     _export_output_names = ("masks", "logits")
 
     def __init__(self, config: dict, image_size=None):

@@ -78,6 +78,18 @@ _BF_S_ADE_CONFIG = copy.deepcopy(_BF_L_ADE_CONFIG)
 _BF_S_ADE_CONFIG["backbone_config"]["layers"] = [2, 2, 2]
 
 
+# focoos/model_registry/fai-mf-l-ade.json: R101-vd, 128-channel FPN without a transformer encoder, 6 decoder layers, semantic post-processing
+_MF_L_ADE_CONFIG = copy.deepcopy(_MF_L_COCO_INS_CONFIG)
+_MF_L_ADE_CONFIG.update({
+    "num_classes": 150, "resolution": 640, "pixel_decoder_out_dim": 128, "pixel_decoder_feat_dim": 128, "pixel_decoder_transformer_layers": 0,
+    "transformer_predictor_out_dim": 128, "transformer_predictor_dec_layers": 6, "transformer_predictor_dim_feedforward": 1024, "head_out_dim": 128,
+    "postprocessing_type": "semantic", "predict_all_pixels": True, "use_mask_score": False,
+    "criterion_deep_supervision": True, "criterion_eos_coef": 0.1, "criterion_num_points": 12544,
+    "weight_dict_loss_dice": 5, "weight_dict_loss_mask": 5, "weight_dict_loss_ce": 2,
+    "matcher_cost_class": 2, "matcher_cost_mask": 5, "matcher_cost_dice": 5,
+})
+
+
 def _bf_entry(name: str, cfg: Dict, description: str) -> Dict:
     cfg = copy.deepcopy(cfg)
     return {
@@ -100,6 +112,7 @@ _REGISTRY = {
     "bisenetformer-l-ade": _bf_entry("bisenetformer-l-ade", _BF_L_ADE_CONFIG, "BiSeNetFormer large (STDC-2), ADE20K semantic segmentation"),
     "bisenetformer-s-ade": _bf_entry("bisenetformer-s-ade", _BF_S_ADE_CONFIG, "BiSeNetFormer small (STDC-1), ADE20K semantic segmentation"),
     "fai-mf-l-coco-ins": _mf_entry("fai-mf-l-coco-ins", _MF_L_COCO_INS_CONFIG, "MaskFormer large (R101-vd), COCO instance segmentation"),
+    "fai-mf-l-ade": dict(_mf_entry("fai-mf-l-ade", _MF_L_ADE_CONFIG, "MaskFormer large (R101-vd), ADE20K semantic segmentation"), task="semseg"),
     "fai-detr-l-obj365": _entry("fai-detr-l-obj365", 365, "RT-DETR large (R50-vd), Objects365 head"),
     "fai-detr-l-coco": _entry("fai-detr-l-coco", 80, "RT-DETR large (R50-vd), COCO head"),
 }

@@ -176,8 +176,9 @@ class TransformerFPN(nn.Module):
         fd = int(config.get("pixel_decoder_feat_dim", 256))
         od = int(config.get("pixel_decoder_out_dim", 256))
         n_enc = int(config.get("pixel_decoder_transformer_layers", 0))
-        if fd != 256:
-            raise _lib.FocoosAmdError("trainable graph is built for pixel_decoder_feat_dim 256 (LayerNorm / attention kernels)")
+        if fd != 256 and n_enc > 0:
+            raise _lib.FocoosAmdError("the pixel decoder's transformer encoder needs pixel_decoder_feat_dim 256 (LayerNorm / attention kernels, head dim 32); "
+                                      "narrower pixel decoders are covered without it (fai-mf-l-ade: pixel_decoder_transformer_layers = 0)")
         if int(config.get("pixel_decoder_transformer_nheads", 8)) != 8:
             raise _lib.FocoosAmdError("attention kernels: 8 heads of 32 channels")
         self.fd, self.n_enc = fd, n_enc

@@ -81,6 +81,44 @@ def test_mf_oracle_matches_reference_live():
     assert [list(d.bbox) for d in dets] == boxes.tolist()
 
 
+def test_mf_ade_variant_oracle_matches_reference_live():
+    """fai-mf-l-ade (focoos/model_registry/fai-mf-l-ade.json: R101-vd, 128-channel FPN without a transformer encoder, 6 decoder layers,
+    semantic post-processing with predict_all_pixels): registry config = the reference's file, state-dict keys = the reference model's,
+    forward and the per-pixel-argmax post-process of the restatement vs the real reference."""
+    import json
+    import os
+
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.synth import synth_image_structured, synth_state_dict
+    from oracle import mf_oracle as M
+
+    ref_import.install()
+    import focoos.models.fai_mf.processor as fp
+
+    cfg = ModelRegistry.get_model_info("fai-mf-l-ade")["config"]
+    ref_cfg = json.load(open(os.path.join(ref_import.REFERENCE_ROOT, "focoos/model_registry/fai-mf-l-ade.json")))["config"]
+    assert {k: v for k, v in cfg.items() if k in ref_cfg} == ref_cfg
+    model, proc, _ = ref_import.build_reference_mf(ref_cfg)
+    fp.binary_mask_to_base64 = lambda m: ""
+    sd = synth_state_dict(cfg, seed=17, family="fai_mf")
+    model.load_state_dict(sd, strict=True)
+    assert list(model.state_dict()) == list(sd)
+    imgs = [synth_image_structured(27, 96, 128)]
+    x, _ = proc.preprocess(imgs, device=torch.device("cpu"), dtype=torch.float32)
+    with torch.no_grad():
+        out = model(x)
+        probs, masks = M.mf_forward(sd, cfg, x)
+    np.testing.assert_allclose(probs.numpy(), out.logits.numpy(), atol=1e-4)
+    assert (masks - out.masks).abs().max().item() < 5e-3
+    dets = proc.postprocess(out, imgs)[0].detections
+    s, l, q, boxes, bm = M.postprocess(out.logits, out.masks, [(96, 128)], cfg["mask_threshold"], cfg["threshold"], cfg["use_mask_score"],
+                                       predict_all_pixels=True)[0]
+    assert len(dets) == len(s) and len(s) >= 1
+    np.testing.assert_allclose([d.conf for d in dets], s.numpy(), atol=1e-6)
+    assert [d.cls_id for d in dets] == l.tolist()
+    assert [list(d.bbox) for d in dets] == boxes.tolist()
+
+
 def test_bf_oracle_matches_reference_live():
     """BiSeNetFormer (A13): forward + batch-1 postprocess (predict_all_pixels) of the restatement vs the real reference, another
     seed and size than the committed golden; the registry config equals the reference's own registry file."""
