@@ -45,6 +45,7 @@ class FxPwChainDesc(C.Structure):
         ("M", C.c_int32), ("K1a", C.c_int32), ("K1b", C.c_int32), ("N1", C.c_int32), ("N2", C.c_int32),
         ("ldx1", C.c_int32), ("ldx2", C.c_int32), ("ldr", C.c_int32), ("ldy1", C.c_int32), ("ldy2", C.c_int32),
         ("act1", C.c_int32), ("act2", C.c_int32),
+        ("pool", C.c_void_p), ("ldp", C.c_int32), ("img_h", C.c_int32), ("img_w", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 
@@ -67,6 +68,7 @@ SIGNATURES = {
     "fx_conv2d_nhwc_bf16": [C.POINTER(FxConvDesc), _vp],
     "fx_conv2d_variant": [_vp, C.c_char_p, _i],
     "fx_pw_chain_supported": [_i, _i, _i, _i],
+    "fx_pw_chain_pool_supported": [_i, _i, _i, _i],
     "fx_conv3x3_flat_supported": [_i, _i, _i],
     "fx_pw_chain_bf16": [C.POINTER(FxPwChainDesc), _vp],
     "fx_stem_conv3x3s2": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -185,7 +187,7 @@ def lib_path() -> str:
     return os.environ.get("FOCOOS_AMD_LIB", LIB_PATH)
 
 
-FX_ABI_VERSION = 2   # = include/focoos_amd.h (tests/test_host_cpu.py compares the two)
+FX_ABI_VERSION = 3   # = include/focoos_amd.h (tests/test_host_cpu.py compares the two)
 
 
 def load() -> C.CDLL:

@@ -38,9 +38,29 @@ struct PwChainArgs {
   int ldx1, ldx2, ldr, ldy1, ldy2;
   int M, N1, act1, act2;
   unsigned x1_bytes, x2_bytes, r_bytes;
+  // QUAD form (round 4): the tile is 16 consecutive 2x2 pixel quads instead of 64 consecutive pixels, and pool = AvgPool2d(2,2) of y1
+  bf16_t* pool;
+  int ldp, H, W;     // image height / width (even) of every operand of this launch
 };
 
-template <int K1A, int K1B, int N2, int BM>
+// DMA `nrows` tile rows of RL 16-byte chunks whose pixel index comes from `pix(row)` (-1: beyond the tensor): pw_dma_rows with a pixel map
+template <int RL, typename F>
+__device__ __forceinline__ void pw_dma_rows_map(__amdgpu_buffer_rsrc_t r, unsigned char* tile, int nrows, int ld, int col0, int wave, int lane, F&& pix) {
+  const int ninstr = nrows * RL / 64;
+  for (int i = wave; i < ninstr; i += 4) {
+    const int q = i * 64 + lane;
+    const int row = q / RL, pc = q % RL;
+    const int lc = pw_swz<RL>(row, pc);
+    const int m = pix(row);
+    const unsigned off = (m >= 0) ? (unsigned)(m * ld + col0 + lc * 8) * 2u : FX_OOB;
+    pw_dma16(r, tile + i * 1024, off);
+  }
+}
+
+// QUAD: tile row r = pixel (sub-position r & 3 of quad blockIdx.x * 16 + (r >> 2)): any 64 pixels do for a pointwise layer, and with whole 2x2
+// quads in the tile the variant-d shortcut's AvgPool2d(2, 2) of the block output (resnet.py:46,95) is the average of four rows of the y1 tile
+// that sits in LDS anyway - written as a quarter-size second output, the stand-alone pooling pass over y1 (122 MB read per launch) is gone.
+template <int K1A, int K1B, int N2, int BM, bool QUAD = false>
 __global__ __launch_bounds__(256, ((N2 <= 64 && K1B == 0) ? 4 : ((N2 <= 128 && (K1B == 0 || N2 <= 64)) ? 3 : 2))) void pw_chain_kernel(const PwChainArgs p) {
   constexpr int K1 = K1A + K1B, KS1 = K1 / 16, KS1A = K1A / 16;
   constexpr int RLA = K1A / 8, RLB = (K1B > 0 ? K1B : 64) / 8;
@@ -67,11 +87,25 @@ __global__ __launch_bounds__(256, ((N2 <= 64 && K1B == 0) ? 4 : ((N2 <= 128 && (
   const int NG = p.N1 >> 8;
   const int KS2 = p.N1 >> 4;  // k-steps of GEMM2 over all of N1
 
+  // pixel of tile row `row` (-1: beyond the tensor)
+  const int W2 = p.W >> 1, QI = (p.H >> 1) * W2;
+  auto pix = [&](int row) -> int {
+    if constexpr (!QUAD) {
+      const int m = m0 + row;
+      return m < p.M ? m : -1;
+    } else {
+      const int q = blockIdx.x * (BM / 4) + (row >> 2), sub = row & 3;
+      if (q * 4 >= p.M) return -1;
+      const int b = q / QI, rem = q - b * QI;
+      const int y2 = rem / W2, x2 = rem - y2 * W2;
+      return (b * p.H + 2 * y2 + (sub >> 1)) * p.W + 2 * x2 + (sub & 1);
+    }
+  };
   const __amdgpu_buffer_rsrc_t x1r = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.x1_bytes, 0x00020000);
-  pw_dma_rows<RLA>(x1r, XA, BM, m0, p.M, p.ldx1, 0, wave, lane);
+  pw_dma_rows_map<RLA>(x1r, XA, BM, p.ldx1, 0, wave, lane, pix);
   if constexpr (K1B > 0) {
     const __amdgpu_buffer_rsrc_t x2r = __builtin_amdgcn_make_buffer_rsrc((void*)p.x2, 0, p.x2_bytes, 0x00020000);
-    pw_dma_rows<RLB>(x2r, XB, BM, m0, p.M, p.ldx2, 0, wave, lane);
+    pw_dma_rows_map<RLB>(x2r, XB, BM, p.ldx2, 0, wave, lane, pix);
   }
   const __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc((void*)(p.res ? p.res : p.x1), 0, p.res ? p.r_bytes : 0u, 0x00020000);
 
@@ -89,7 +123,7 @@ __global__ __launch_bounds__(256, ((N2 <= 64 && K1B == 0) ? 4 : ((N2 <= 128 && (
     // position from being hoisted out of the group loop into long-lived registers
     int l32g = l32, halfg = half, tidg = tid;
     asm volatile("" : "+v"(l32g), "+v"(halfg), "+v"(tidg));
-    if (p.res) pw_dma_rows<32>(rr, T, BM, m0, p.M, p.ldr, g * 256, wave, lane);
+    if (p.res) pw_dma_rows_map<32>(rr, T, BM, p.ldr, g * 256, wave, lane, pix);
     // ---- first weight fragments of GEMM2's K-slice [g*256, +256): requested now, consumed after the y1 store
     bf16x8 a2[PF2][TN2];
     const bf16_t* w2 = p.w2p + (size_t)((wn2 * TN2) * KS2 + g * 16) * 512 + lane * 8;
@@ -177,8 +211,30 @@ __global__ __launch_bounds__(256, ((N2 <= 64 && K1B == 0) ? 4 : ((N2 <= 128 && (
       const int q = tidg + i * 256;
       const int row = q >> 5, lc = q & 31;
       const uint4 v = *reinterpret_cast<const uint4*>(T + row * 512 + ((lc ^ (row & 15)) << 4));
-      const int m = m0 + row;
-      if (m < p.M) *reinterpret_cast<uint4*>(p.y1 + (size_t)m * p.ldy1 + g * 256 + lc * 8) = v;
+      const int m = pix(row);
+      if (m >= 0) *reinterpret_cast<uint4*>(p.y1 + (size_t)m * p.ldy1 + g * 256 + lc * 8) = v;
+    }
+    if constexpr (QUAD) {
+      // AvgPool2d(2, 2) of the y1 tile: quad j = rows 4j .. 4j+3 in the order (dy, dx) = (0,0), (0,1), (1,0), (1,1) - the summation order of
+      // avgpool2_kernel (pixel_ops.hip), so the pooled tensor is bit-identical to the stand-alone pass over the stored bf16 y1
+#pragma unroll
+      for (int i = 0; i < (BM / 4) * 32 / 256; ++i) {
+        const int idx = tidg + i * 256;
+        const int j = idx >> 5, lc = idx & 31;
+        float s8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * j + r;
+          float f[8];
+          unpack_bf16x8(*reinterpret_cast<const uint4*>(T + row * 512 + ((lc ^ (row & 15)) << 4)), f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) s8[e] += f[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s8[e] *= 0.25f;
+        const int q = blockIdx.x * (BM / 4) + j;
+        if (q * 4 < p.M) *reinterpret_cast<uint4*>(p.pool + (size_t)q * p.ldp + g * 256 + lc * 8) = pack_bf16x8(s8);
+      }
     }
     // ---- GEMM2, K-slice of this group (B operand = T)
     if constexpr (HAS2) {
@@ -231,18 +287,18 @@ __global__ __launch_bounds__(256, ((N2 <= 64 && K1B == 0) ? 4 : ((N2 <= 128 && (
       const int q = tid + i * 256;
       const int row = q / RL2, lc = q % RL2;
       const uint4 v = *reinterpret_cast<const uint4*>(T + row * (N2 * 2) + (pw_swz<RL2>(row, lc) << 4));
-      const int m = m0 + row;
-      if (m < p.M) *reinterpret_cast<uint4*>(p.y2 + (size_t)m * p.ldy2 + lc * 8) = v;
+      const int m = pix(row);
+      if (m >= 0) *reinterpret_cast<uint4*>(p.y2 + (size_t)m * p.ldy2 + lc * 8) = v;
     }
   }
 }
 
-template <int K1A, int K1B, int N2>
+template <int K1A, int K1B, int N2, bool QUAD = false>
 static int launch_pw_chain(const PwChainArgs& a, hipStream_t stream) {
   constexpr int BM = 64;
   constexpr int SMEM = BM * (K1A + K1B) * 2 + BM * 512;
   static bool attr_set = false;
-  auto kern = pw_chain_kernel<K1A, K1B, N2, BM>;
+  auto kern = pw_chain_kernel<K1A, K1B, N2, BM, QUAD>;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, SMEM) != hipSuccess)
       return FX_ERR_RUNTIME;
@@ -263,6 +319,18 @@ extern "C" int fx_pw_chain_supported(int K1a, int K1b, int N1, int N2) {
 #define FX_PW_CASE(KA, KB, NN2) \
   if (K1a == KA && K1b == KB && N2 == NN2) return 1;
   FX_PW_INSTANCES(FX_PW_CASE)
+#undef FX_PW_CASE
+  return 0;
+}
+
+// (K1a, K1b, N2) instances of the QUAD form: the seams in front of a stride-2 block (res2 -> res3, res3 -> res4)
+#define FX_PW_POOL_INSTANCES(X) X(64, 0, 128) X(128, 0, 256)
+
+extern "C" int fx_pw_chain_pool_supported(int K1a, int K1b, int N1, int N2) {
+  if (N1 <= 0 || N1 % 256 != 0) return 0;
+#define FX_PW_CASE(KA, KB, NN2) \
+  if (K1a == KA && K1b == KB && N2 == NN2) return 1;
+  FX_PW_POOL_INSTANCES(FX_PW_CASE)
 #undef FX_PW_CASE
   return 0;
 }
@@ -297,7 +365,18 @@ extern "C" int fx_pw_chain_bf16(const fx_pw_chain_desc* d, fx_stream_t stream_) 
   a.ldx1 = d->ldx1; a.ldx2 = d->ldx2; a.ldr = d->ldr; a.ldy1 = d->ldy1; a.ldy2 = d->ldy2;
   a.M = d->M; a.N1 = d->N1; a.act1 = d->act1; a.act2 = d->act2;
   a.x1_bytes = (unsigned)x1_bytes; a.x2_bytes = (unsigned)x2_bytes; a.r_bytes = (unsigned)r_bytes;
+  a.pool = reinterpret_cast<bf16_t*>(d->pool); a.ldp = d->ldp; a.H = d->img_h; a.W = d->img_w;
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  if (d->pool) {
+    FX_CHECK_ARG(d->img_h > 0 && d->img_w > 0 && d->img_h % 2 == 0 && d->img_w % 2 == 0 && d->M % (d->img_h * d->img_w) == 0);
+    FX_CHECK_ARG(d->ldp >= d->N1 && d->ldp % 8 == 0 && ((uintptr_t)d->pool % 16) == 0);
+    if (!fx_pw_chain_pool_supported(d->K1a, d->K1b, d->N1, d->N2)) return FX_ERR_UNSUPPORTED;
+#define FX_PW_CASE(KA, KB, NN2) \
+  if (d->K1a == KA && d->K1b == KB && d->N2 == NN2) return launch_pw_chain<KA, KB, NN2, true>(a, stream);
+    FX_PW_POOL_INSTANCES(FX_PW_CASE)
+#undef FX_PW_CASE
+    return FX_ERR_UNSUPPORTED;
+  }
 #define FX_PW_CASE(KA, KB, NN2) \
   if (d->K1a == KA && d->K1b == KB && d->N2 == NN2) return launch_pw_chain<KA, KB, NN2>(a, stream);
   FX_PW_INSTANCES(FX_PW_CASE)

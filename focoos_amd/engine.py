@@ -506,7 +506,8 @@ class _PlanBase:
         self._op(self.lib.fx_conv2d_nhwc_bf16, C.byref(d))
         return out
 
-    def pw_chain(self, x1: NT, x2: Optional[NT], residual: Optional[NT], cc: Tuple, ca: Optional[Tuple], name1: str, name2: Optional[str]):
+    def pw_chain(self, x1: NT, x2: Optional[NT], residual: Optional[NT], cc: Tuple, ca: Optional[Tuple], name1: str, name2: Optional[str],
+                 pool_name: Optional[str] = None):
         """y1 = relu([x1 | x2] W1^T + b1 (+ residual)), y2 = relu(y1 W2^T + b2) in one launch (include/focoos_amd.h, fx_pw_chain_desc):
         BottleNeck branch2c (+ shortcut conv) + add + ReLU and the next block's branch2a + ReLU (resnet.py:107-121)."""
         w1, b1, k1a, k1b, n1 = cc
@@ -525,11 +526,17 @@ class _PlanBase:
             y2 = self._new(name2, x1.B, x1.H, x1.W, n2)
             d.w2, d.bias2, d.y2, d.ldy2 = w2.data_ptr(), b2.data_ptr(), y2.ptr, y2.ld
         d.N2 = n2
+        pooled = None
+        if pool_name is not None:   # AvgPool2d(2, 2) of y1 as a third output (the next stage's variant-d shortcut input): quad-ordered tiles
+            pooled = self._new(pool_name, x1.B, x1.H // 2, x1.W // 2, n1)
+            d.pool, d.ldp, d.img_h, d.img_w = pooled.ptr, pooled.ld, x1.H, x1.W
         self.keep.append(d)
-        self.meta[len(self.ops)] = {"kind": "conv", "variant": f"pw_chain<{k1a},{k1b},{n2}>", "flops": 2.0 * M * n1 * (k1a + k1b + n2),
+        self.meta[len(self.ops)] = {"kind": "conv", "variant": f"pw_chain<{k1a},{k1b},{n2}>" + ("+pool" if pooled is not None else ""), "flops": 2.0 * M * n1 * (k1a + k1b + n2),
                                     "name": name1 + ("+" + name2.rsplit("res_layers.", 1)[-1] if name2 else ""), "M": M, "N": n1, "K": k1a + k1b,
-                                    "bytes": 2.0 * M * (k1a + k1b + (n1 if residual is not None else 0) + n1 + n2)}
+                                    "bytes": 2.0 * M * (k1a + k1b + (n1 if residual is not None else 0) + n1 + n2 + (n1 / 4 if pooled is not None else 0))}
         self._op(self.lib.fx_pw_chain_bf16, C.byref(d))
+        if pool_name is not None:
+            return y1, y2, pooled
         return y1, y2
 
     def linear(self, x: NT, pc: PackedConv, **kw) -> NT:
@@ -582,6 +589,8 @@ class _PlanBase:
         x = mp
         seq = [(si, bi) for si in range(4) for bi in range(blocks[si])]
         a_next: Optional[NT] = None
+        pooled_next: Optional[NT] = None   # AvgPool2d(2,2) of the previous stage's output, written by its last pw_chain launch (FX_PW_CHAIN_POOL=0: the stand-alone pass)
+        use_pool = int(os.environ.get("FX_PW_CHAIN_POOL", "1")) != 0
         for idx, (si, bi) in enumerate(seq):
             p = f"{bb}.res_layers.{si}.blocks.{bi}"
             stride = 2 if (bi == 0 and si != 0) else 1
@@ -591,7 +600,9 @@ class _PlanBase:
             short_in = None
             if bi == 0:
                 short_in = x
-                if stride == 2:
+                if stride == 2 and pooled_next is not None:
+                    short_in, pooled_next = pooled_next, None
+                elif stride == 2:
                     short_in = self._new(f"{p}.pool", x.B, (x.H + 1) // 2, (x.W + 1) // 2, x.C)
                     self._op(lib.fx_avgpool2x2_nhwc_bf16, x.ptr, x.ld, short_in.ptr, short_in.ld, x.B, x.H, x.W, x.C)
             nxt = seq[idx + 1] if idx + 1 < len(seq) else None
@@ -605,7 +616,14 @@ class _PlanBase:
                     cc = None
             if cc is not None:
                 nxt_name = f"{bb}.res_layers.{nxt[0]}.blocks.{nxt[1]}.a" if n2 else None
-                x, a_next = self.pw_chain(bmid, short_in, None if bi == 0 else x, cc, e.chain_a[nxt] if n2 else None, f"{p}.c", nxt_name)
+                # last block of a stage whose successor starts with a stride-2 block: the pooled shortcut input comes out of this launch
+                want_pool = (use_pool and nxt is not None and nxt[0] == si + 1 and bi != 0 and bmid.H % 2 == 0 and bmid.W % 2 == 0
+                             and lib.fx_pw_chain_pool_supported(cc[2], cc[3], cc[4], n2) == 1)
+                if want_pool:
+                    x, a_next, pooled_next = self.pw_chain(bmid, short_in, x, cc, e.chain_a[nxt] if n2 else None, f"{p}.c", nxt_name,
+                                                           pool_name=f"{bb}.res_layers.{nxt[0]}.blocks.0.pool")
+                else:
+                    x, a_next = self.pw_chain(bmid, short_in, None if bi == 0 else x, cc, e.chain_a[nxt] if n2 else None, f"{p}.c", nxt_name)
             else:
                 short = x if bi != 0 else self.conv(short_in, P[f"{p}.short" if si == 0 else f"{p}.short.conv"], name=f"{p}.s")
                 x = self.conv(bmid, P[f"{p}.branch2c"], name=f"{p}.c", residual=short, act="relu")

@@ -27,8 +27,9 @@ extern "C" {
 #endif
 
 /* Bumped whenever a descriptor struct's layout OR the semantics the host relies on change (version 2: fx_conv_desc grew mask / ldm /
- * reserved0 and the library applies the ReLU mask the previous bottleneck skips); focoos_amd/_lib.py refuses a library of another version. */
-#define FX_ABI_VERSION 2
+ * reserved0 and the library applies the ReLU mask the previous bottleneck skips; version 3: fx_pw_chain_desc grew pool / ldp / img_h / img_w);
+ * focoos_amd/_lib.py refuses a library of another version. */
+#define FX_ABI_VERSION 3
 
 enum { FX_OK = 0, FX_ERR_INVALID_ARGUMENT = -1, FX_ERR_LAUNCH = -2, FX_ERR_UNSUPPORTED = -3, FX_ERR_RUNTIME = -4 };
 enum { FX_ACT_NONE = 0, FX_ACT_RELU = 1, FX_ACT_SILU = 2, FX_ACT_GELU = 3 };
@@ -115,8 +116,14 @@ typedef struct fx_pw_chain_desc {
   int32_t M, K1a, K1b, N1, N2;
   int32_t ldx1, ldx2, ldr, ldy1, ldy2;
   int32_t act1, act2;   /* FX_ACT_* */
+  /* optional third output (ABI 3): pool = AvgPool2d(2, 2) of y1, bf16 [M/4, ldp] - the input of the NEXT stage's variant-d shortcut conv
+   * (focoos/nn/backbone/resnet.py:46,95).  Needs the image size of the operands (even img_h, img_w; M = B * img_h * img_w): the kernel then
+   * tiles the pixels by 2x2 quads.  NULL: no pooled output (img_h / img_w ignored).  Supported shapes: fx_pw_chain_pool_supported(). */
+  void* pool;
+  int32_t ldp, img_h, img_w, reserved0;
 } fx_pw_chain_desc;
 int fx_pw_chain_supported(int K1a, int K1b, int N1, int N2); /* 1 / 0 (not an error code) */
+int fx_pw_chain_pool_supported(int K1a, int K1b, int N1, int N2); /* 1 / 0: the form with the pooled third output */
 int fx_pw_chain_bf16(const fx_pw_chain_desc* d, fx_stream_t stream);
 
 /* Stem: pixel normalisation (x-mean)/std (fai_detr/modelling.py:1349) fused with conv1_1 3x3/s2 +

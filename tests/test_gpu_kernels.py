@@ -573,6 +573,52 @@ def test_pw_chain_matches_two_convs(lib, case):
         assert (got2 - r2).abs().max().item() <= tol2, ((got2 - r2).abs().max().item(), tol2)
 
 
+@pytest.mark.parametrize("case", [(2, 12, 20, 64, 256, 128), (1, 8, 8, 128, 512, 256), (3, 6, 10, 64, 512, 128)])
+def test_pw_chain_quad_tiles_with_pooled_output(lib, case):
+    """The QUAD form of fx_pw_chain_bf16 (tiles of 16 2x2 pixel quads, AvgPool2d(2,2) of y1 as a third output - the variant-d shortcut input of
+    the next stage, resnet.py:46,95): y1 and y2 are bit-identical to the flat-tile launch (same arithmetic per pixel, another pixel -> tile map),
+    and the pooled tensor is bit-identical to fx_avgpool2x2_nhwc_bf16 of the stored y1 (same summation order)."""
+    from focoos_amd._lib import FxPwChainDesc
+
+    B, H, W, K1a, N1, N2 = case
+    assert lib.fx_pw_chain_pool_supported(K1a, 0, N1, N2) == 1 and lib.fx_pw_chain_pool_supported(K1a, 64, N1, N2) == 0
+    M = B * H * W
+    g = torch.Generator().manual_seed(M + N1)
+    x1 = to_dev(bf(torch.randn(M, K1a, generator=g) + torch.linspace(-1, 1, M)[:, None]))
+    res = to_dev(bf(torch.randn(M, N1, generator=g)))
+    W1 = torch.randn(N1, K1a, generator=g) / math.sqrt(K1a) + torch.linspace(-0.05, 0.05, N1)[:, None]
+    W2 = torch.randn(N2, N1, generator=g) / math.sqrt(N1)
+    w1d, b1d, w2d, b2d = frag_pack(W1), to_dev(torch.randn(N1, generator=g) * 0.3), frag_pack(W2), to_dev(torch.randn(N2, generator=g) * 0.3)
+    outs = []
+    for quad in (False, True):
+        y1 = torch.full((M + 3, N1), float("nan"), dtype=torch.bfloat16, device=DEV)
+        y2 = torch.full((M + 3, N2), float("nan"), dtype=torch.bfloat16, device=DEV)
+        pool = torch.full((M // 4 + 2, N1), float("nan"), dtype=torch.bfloat16, device=DEV)
+        d = FxPwChainDesc()
+        d.x1, d.ldx1, d.K1a, d.residual, d.ldr = x1.data_ptr(), K1a, K1a, res.data_ptr(), N1
+        d.w1, d.bias1, d.y1, d.ldy1, d.N1, d.M = w1d.data_ptr(), b1d.data_ptr(), y1.data_ptr(), N1, N1, M
+        d.w2, d.bias2, d.y2, d.ldy2, d.N2 = w2d.data_ptr(), b2d.data_ptr(), y2.data_ptr(), N2, N2
+        d.act1 = d.act2 = FX_ACT["relu"]
+        if quad:
+            d.pool, d.ldp, d.img_h, d.img_w = pool.data_ptr(), N1, H, W
+        check(lib.fx_pw_chain_bf16(C.byref(d), stream()), "pw_chain")
+        torch.cuda.synchronize()
+        outs.append((y1, y2, pool))
+    (y1a, y2a, _), (y1b, y2b, pool) = outs
+    assert not torch.isnan(y1a[:M].float()).any() and torch.isnan(y1b[M:].float()).all() and torch.isnan(y2b[M:].float()).all()
+    assert torch.equal(y1a[:M], y1b[:M]) and torch.equal(y2a[:M], y2b[:M])
+    ref = torch.full((B, H // 2, W // 2, N1), float("nan"), dtype=torch.bfloat16, device=DEV)
+    check(lib.fx_avgpool2x2_nhwc_bf16(y1b.data_ptr(), N1, ref.data_ptr(), N1, B, H, W, N1, stream()), "avgpool")
+    torch.cuda.synchronize()
+    assert torch.isnan(pool[M // 4:].float()).all()
+    assert torch.equal(pool[: M // 4], ref.reshape(M // 4, N1))
+    # and against torch on the stored bf16 y1
+    want = F.avg_pool2d(y1b[:M].float().reshape(B, H, W, N1).permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).reshape(M // 4, N1)
+    assert (pool[: M // 4].float() - want).abs().max().item() <= 8e-3 * want.abs().max().item()
+    d.img_h = H + 1   # odd height: refused
+    assert lib.fx_pw_chain_bf16(C.byref(d), stream()) == -1
+
+
 def test_pw_chain_rejects_bad_arguments(lib):
     from focoos_amd._lib import FxPwChainDesc
 

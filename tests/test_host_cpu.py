@@ -61,6 +61,20 @@ def test_conv_desc_layout_matches_header(tmp_path):
     assert FxConvDesc.y_batch_stride.offset == off_ybs and FxConvDesc.B.offset == off_b and FxConvDesc.residual_after_act.offset == off_raa
 
 
+def test_pw_chain_desc_layout_matches_header(tmp_path):
+    """ctypes mirror of fx_pw_chain_desc (grown in ABI 3 by pool / ldp / img_h / img_w) vs the C compiler's layout of the header's struct."""
+    from focoos_amd._lib import FxPwChainDesc
+
+    src = tmp_path / "layout2.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "focoos_amd.h"\nint main(void){printf("%zu %zu %zu %zu\\n", sizeof(fx_pw_chain_desc), '
+                   'offsetof(fx_pw_chain_desc, act2), offsetof(fx_pw_chain_desc, pool), offsetof(fx_pw_chain_desc, img_w));return 0;}\n')
+    exe = tmp_path / "layout2"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    size, off_act2, off_pool, off_w = map(int, subprocess.check_output([str(exe)]).split())
+    assert ctypes.sizeof(FxPwChainDesc) == size
+    assert FxPwChainDesc.act2.offset == off_act2 and FxPwChainDesc.pool.offset == off_pool and FxPwChainDesc.img_w.offset == off_w
+
+
 def test_missing_library_is_loud(monkeypatch):
     from focoos_amd import _lib
 
