@@ -33,12 +33,17 @@ import torch
 from . import _lib
 from ._lib import check
 from .engine import DEFAULT_STREAMS, MIN_PART_BATCH, NT, PackedConv, _EngineBase, _MultiPlan, _PlanBase, _fold_bn
+from .engine_stdc import StdcEngineMixin, StdcPlanMixin
 from .engine_maskdec import MaskDecoderPlanMixin, pack_mask_bits, pack_masked_decoder, pos_embed_sine_normalized  # noqa: F401  (pack_mask_bits re-exported)
 
 
-class MfEngine(_EngineBase):
+class MfEngine(StdcEngineMixin, _EngineBase):
     def __init__(self, config: Dict, state_dict: Dict[str, torch.Tensor], device: str = "cuda:0", full_masks: bool = False):
         super().__init__(config, device)
+        # backbone: ResNet-vd (fai-mf-l-*) or STDC (fai-mf-m-ade; engine_stdc.py)
+        self.stdc = config["backbone_config"].get("model_type") == "stdc"
+        if self.stdc:
+            self._init_stdc(config["backbone_config"])
         self.nc = int(config["num_classes"])
         self.nq = int(config.get("num_queries", 100))
         self.hd = int(config.get("transformer_predictor_hidden_dim", 256))
@@ -70,7 +75,10 @@ class MfEngine(_EngineBase):
         sd = {k: v.detach().cpu() for k, v in sd.items()}
         P: Dict[str, PackedConv] = {}
         self.ln = {}
-        self._pack_backbone(sd, P)
+        if self.stdc:
+            self._pack_stdc(sd, P)
+        else:
+            self._pack_backbone(sd, P)
         pd = "pixel_decoder"
 
         def lin(key, wkey, rows=None):
@@ -144,7 +152,7 @@ class MfEngine(_EngineBase):
         return pl
 
 
-class _MfPlan(MaskDecoderPlanMixin, _PlanBase):
+class _MfPlan(StdcPlanMixin, MaskDecoderPlanMixin, _PlanBase):
     """MaskFormer launch sequence for one (batch, height, width)."""
 
     def __init__(self, eng: "MfEngine", B: int, H: int, W: int, f32_input: bool, full_masks: bool = False, parent=None, index: int = 0):
@@ -155,7 +163,7 @@ class _MfPlan(MaskDecoderPlanMixin, _PlanBase):
         e, P, B, lib = self.eng, self.eng.P, self.B, self.lib
         H, W = self.H, self.W
         Q, K = e.nq, e.nc
-        feats = self.build_backbone()
+        feats = self.build_stdc() if e.stdc else self.build_backbone()
         pd = "pixel_decoder"
         h32, w32 = H // 32, W // 32
         # ---- pixel decoder (fai_mf/modelling.py:347-369)

@@ -89,6 +89,14 @@ _MF_L_ADE_CONFIG.update({
     "matcher_cost_class": 2, "matcher_cost_mask": 5, "matcher_cost_dice": 5,
 })
 
+# focoos/model_registry/fai-mf-m-ade.json: STDC-2 backbone (the BiSeNetFormer-L one), 128-channel FPN, 3 decoder layers with a 512-wide FFN
+_MF_M_ADE_CONFIG = copy.deepcopy(_MF_L_ADE_CONFIG)
+_MF_M_ADE_CONFIG.update({
+    "backbone_config": copy.deepcopy(_BF_L_ADE_CONFIG["backbone_config"]),
+    "transformer_predictor_dec_layers": 3, "transformer_predictor_dim_feedforward": 512,
+})
+_MF_M_ADE_CONFIG["backbone_config"]["out_features"] = ["res2", "res3", "res4", "res5"]
+
 
 def _bf_entry(name: str, cfg: Dict, description: str) -> Dict:
     cfg = copy.deepcopy(cfg)
@@ -113,6 +121,7 @@ _REGISTRY = {
     "bisenetformer-s-ade": _bf_entry("bisenetformer-s-ade", _BF_S_ADE_CONFIG, "BiSeNetFormer small (STDC-1), ADE20K semantic segmentation"),
     "fai-mf-l-coco-ins": _mf_entry("fai-mf-l-coco-ins", _MF_L_COCO_INS_CONFIG, "MaskFormer large (R101-vd), COCO instance segmentation"),
     "fai-mf-l-ade": dict(_mf_entry("fai-mf-l-ade", _MF_L_ADE_CONFIG, "MaskFormer large (R101-vd), ADE20K semantic segmentation"), task="semseg"),
+    "fai-mf-m-ade": dict(_mf_entry("fai-mf-m-ade", _MF_M_ADE_CONFIG, "MaskFormer medium (STDC-2), ADE20K semantic segmentation"), task="semseg"),
     "fai-detr-l-obj365": _entry("fai-detr-l-obj365", 365, "RT-DETR large (R50-vd), Objects365 head"),
     "fai-detr-l-coco": _entry("fai-detr-l-coco", 80, "RT-DETR large (R50-vd), COCO head"),
 }

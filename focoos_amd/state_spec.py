@@ -157,8 +157,8 @@ def mf_state_spec(config: Dict) -> "OrderedDict[str, Tuple[Tuple[int, ...], str]
     (focoos/models/fai_mf/modelling.py:633-710: TransformerFPN :201-338, MultiScaleMaskedTransformerDecoder :372-499,
     PredictionHeads :28-60); pinned against the reference's own key dump in tests/golden/mf_l_state_keys.json."""
     bb = config["backbone_config"]
-    if bb.get("model_type", "resnet") != "resnet":
-        raise ValueError("engine state spec covers resnet backbones (fai-mf-l-*)")
+    if bb.get("model_type", "resnet") not in ("resnet", "stdc"):
+        raise ValueError("engine state spec covers resnet (fai-mf-l-*) and stdc (fai-mf-m-ade) backbones")
     nc = int(config["num_classes"])
     fd = int(config.get("pixel_decoder_feat_dim", 256))
     od = int(config.get("pixel_decoder_out_dim", 256))
@@ -171,7 +171,11 @@ def mf_state_spec(config: Dict) -> "OrderedDict[str, Tuple[Tuple[int, ...], str]
     nq = int(config.get("num_queries", 100))
 
     spec: "OrderedDict[str, Tuple[Tuple[int, ...], str]]" = OrderedDict()
-    chans = resnet_vd_spec(spec, "pixel_decoder.backbone", int(bb.get("depth", 50)), int(bb.get("in_chans", 3)))
+    if bb.get("model_type", "resnet") == "stdc":
+        chans = stdc_spec(spec, "pixel_decoder.backbone", int(bb.get("base", 64)), tuple(bb.get("layers", (4, 5, 3))), int(bb.get("block_num", 4)),
+                          int(bb.get("in_chans", 3)))
+    else:
+        chans = resnet_vd_spec(spec, "pixel_decoder.backbone", int(bb.get("depth", 50)), int(bb.get("in_chans", 3)))
     P = "pixel_decoder"
     if n_enc > 0:
         spec[f"{P}.input_proj.weight"] = ((fd, chans[-1], 1, 1), "conv_w")

@@ -1,5 +1,5 @@
 """MaskFormer (``fai-mf-*``) as a trainable HIP autograd graph: what ``FAIMaskFormer.forward(images,
-targets)`` computes under ``model.train()`` (focoos/models/fai_mf/modelling.py:712-725) - ResNet-vd backbone (train_nn.ResNetVd), the
+targets)`` computes under ``model.train()`` (focoos/models/fai_mf/modelling.py:712-725) - ResNet-vd (train_nn.ResNetVd) or STDC (train_bf.STDC) backbone, the
 ``TransformerFPN`` pixel decoder (:201-369: 1x1 input projection, pre-norm transformer encoder on res5 with the normalised sine position
 embedding :143-198, lateral 1x1 / output 3x3 convs with BatchNorm, nearest-neighbour top-down additions, biased 3x3 ``mask_features``), the
 ``MultiScaleMaskedTransformerDecoder`` over three levels with every prediction head supervised (:453-549; the decoder modules are
@@ -19,7 +19,7 @@ from torch import nn
 from . import _lib
 from ._lib import check
 from .engine_maskdec import pos_embed_sine_normalized
-from .train_bf import Conv1x1, TransformerDecoder, _CriterionHolder
+from .train_bf import STDC, Conv1x1, TransformerDecoder, _CriterionHolder
 from .train_nn import (ARENA, DIRECT_GRAD, WEIGHTS_EPOCH, ConvNormLayer, LayerNorm, Linear, MultiheadAttention, ResNetVd, _AddFn, _conv_call,
                        _conv_input_grad, _conv_param_grads, _frag_eligible, _ptr, _stream, set_norm_mode)
 
@@ -182,9 +182,15 @@ class TransformerFPN(nn.Module):
         if int(config.get("pixel_decoder_transformer_nheads", 8)) != 8:
             raise _lib.FocoosAmdError("attention kernels: 8 heads of 32 channels")
         self.fd, self.n_enc = fd, n_enc
-        self.backbone = ResNetVd(int(config["backbone_config"].get("depth", 50)), config.get("pixel_mean", (123.675, 116.28, 103.53)),
-                                 config.get("pixel_std", (58.395, 57.12, 57.375)))
-        chans = [256, 512, 1024, 2048]
+        bb = config["backbone_config"]
+        mean, std = config.get("pixel_mean", (123.675, 116.28, 103.53)), config.get("pixel_std", (58.395, 57.12, 57.375))
+        if bb.get("model_type") == "stdc":      # fai-mf-m-ade: the BiSeNetFormer backbone under the MaskFormer FPN
+            base = int(bb.get("base", 64))
+            self.backbone = STDC(lib, base, tuple(bb.get("layers", (4, 5, 3))), mean, std)
+            chans = [base, base * 4, base * 8, base * 16]
+        else:
+            self.backbone = ResNetVd(int(bb.get("depth", 50)), mean, std)
+            chans = [256, 512, 1024, 2048]
         if n_enc > 0:
             self.input_proj = Conv1x1(lib, chans[-1], fd, bias=True)
             self.transformer = _TransformerEncoderOnly(lib, fd, int(config.get("pixel_decoder_transformer_dim_feedforward", 1024)), n_enc)

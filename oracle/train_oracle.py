@@ -129,7 +129,7 @@ def mf_train_outputs(sd: SD, cfg: Dict, images: torch.Tensor, forced_attn: Optio
     mean = torch.tensor(cfg.get("pixel_mean", [123.675, 116.28, 103.53]), dtype=torch.float32).view(-1, 1, 1)
     std = torch.tensor(cfg.get("pixel_std", [58.395, 57.12, 57.375]), dtype=torch.float32).view(-1, 1, 1)
     x = (images - mean) / std
-    feats = O.resnet_vd(sd, "pixel_decoder.backbone", x, O.RESNET_BLOCKS[int(cfg["backbone_config"].get("depth", 50))])
+    feats = M.backbone_features(sd, cfg, x)
     if collect is not None:
         collect.update(feats)
     mask_features, msf = M.transformer_fpn(sd, feats, cfg, collect)

@@ -366,18 +366,22 @@ def test_mf_full_size_batch_properties(setup):
         assert M.masks_to_xyxy(m).tolist() == a["det_boxes"][i, :ni].cpu().tolist()
 
 
-def test_mf_ade_variant_stage_parity_and_semantic_postprocess():
+@pytest.mark.parametrize("variant", ["fai-mf-l-ade", "fai-mf-m-ade"])
+def test_mf_ade_variant_stage_parity_and_semantic_postprocess(variant):
     """fai-mf-l-ade (focoos/model_registry/fai-mf-l-ade.json: 128-channel FPN without the transformer encoder, 128-wide mask embedding, six
-    decoder layers, semantic / predict_all_pixels post-processing) through the same engine: stage and output parity against the oracle
+    decoder layers, semantic / predict_all_pixels post-processing) and fai-mf-m-ade (fai-mf-m-ade.json: the same head with three decoder
+    layers and a 512-wide FFN on the STDC-2 backbone, engine_stdc.py) through the same engine: stage and output parity against the oracle
     (pinned live to the reference built from that registry file), attention masks teacher-forced; the device post-process (per-pixel
     argmax over the queries, fx_seg_postprocess) against the oracle's restatement on the engine's own outputs; the training graph's keys."""
     from focoos_amd.model import ModelManager
     from focoos_amd.processor import MaskFormerProcessor
 
-    cfg = ModelRegistry.get_model_info("fai-mf-l-ade")["config"]
+    cfg = ModelRegistry.get_model_info(variant)["config"]
     sd = synth_state_dict(cfg, 13, family="fai_mf")
     eng = MfEngine(cfg, sd, device=DEV, full_masks=False)
-    assert eng.fd == 128 and eng.n_enc == 0 and eng.predict_all_pixels
+    assert eng.fd == 128 and eng.n_enc == 0 and eng.predict_all_pixels and eng.stdc == (variant == "fai-mf-m-ade")
+    nl = int(cfg["transformer_predictor_dec_layers"])
+    assert nl == (3 if eng.stdc else 6)
     h, w = 192, 256
     images = [synth_image_structured(60 + i, h, w) for i in range(2)]
     col = {}
@@ -395,7 +399,7 @@ def test_mf_ade_variant_stage_parity_and_semantic_postprocess():
     colb = {}
     with torch.no_grad():
         probs_w, masks_w = M.mf_forward(sdb, cfg, get_torch_batch(images, None), forced_attn=col["attn_masks"], collect=colb, upsample=False)
-    for i in range(6):
+    for i in range(nl):
         e_w = rel_l2(colb[f"dec{i}_out"], col[f"dec{i}_out"])
         e = rel_l2(pl.bufs[f"dec{i}.out"].torch_view().float().cpu().reshape(2, -1, 256), col[f"dec{i}_out"])
         assert e <= max(3e-2, 2.5 * e_w), (i, e, e_w)
@@ -403,7 +407,7 @@ def test_mf_ade_variant_stage_parity_and_semantic_postprocess():
     dm, dm_w = float((pl.mask_probs.cpu() - masks_o).abs().mean()), float((masks_w - masks_o).abs().mean())
     ag = float(((pl.mask_probs.cpu() >= 0.5) == (masks_o >= 0.5)).float().mean())
     ag_w = float(((masks_w >= 0.5) == (masks_o >= 0.5)).float().mean())
-    print(f"fai-mf-l-ade: engine dprob {dp:.3f} mean|dmask| {dm:.4f} agreement {ag:.4f}; bf16-weights-only oracle: {dp_w:.3f} {dm_w:.4f} {ag_w:.4f}")
+    print(f"{variant}: engine dprob {dp:.3f} mean|dmask| {dm:.4f} agreement {ag:.4f}; bf16-weights-only oracle: {dp_w:.3f} {dm_w:.4f} {ag_w:.4f}")
     assert dp <= max(3e-2, 2.5 * dp_w) and dm <= max(1e-2, 2.5 * dm_w) and ag >= min(0.99, 1.0 - 2.5 * (1.0 - ag_w))
     # device post-process vs the oracle's restatement, both fed the ENGINE's class probabilities and (upsampled) mask probabilities
     up = torch.nn.functional.interpolate(pl.mask_probs.cpu(), size=(h, w), mode="bilinear", align_corners=False)
@@ -415,7 +419,7 @@ def test_mf_ade_variant_stage_parity_and_semantic_postprocess():
         if n == len(s):
             assert pl.det_labels[b, :n].cpu().tolist() == l.tolist()
             np.testing.assert_allclose(pl.det_scores[b, :n].cpu().numpy(), s.numpy(), atol=2e-5)
-    fm = ModelManager.get("fai-mf-l-ade", seed=13)
+    fm = ModelManager.get(variant, seed=13)
     assert isinstance(fm.processor, MaskFormerProcessor) and fm.processor.predict_all_pixels
     dets = fm.infer_batch(images)
     assert len(dets) == 2 and len(dets[0]) >= 1

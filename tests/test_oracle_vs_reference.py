@@ -81,10 +81,12 @@ def test_mf_oracle_matches_reference_live():
     assert [list(d.bbox) for d in dets] == boxes.tolist()
 
 
-def test_mf_ade_variant_oracle_matches_reference_live():
+@pytest.mark.parametrize("name", ["fai-mf-l-ade", "fai-mf-m-ade"])
+def test_mf_ade_variant_oracle_matches_reference_live(name):
     """fai-mf-l-ade (focoos/model_registry/fai-mf-l-ade.json: R101-vd, 128-channel FPN without a transformer encoder, 6 decoder layers,
-    semantic post-processing with predict_all_pixels): registry config = the reference's file, state-dict keys = the reference model's,
-    forward and the per-pixel-argmax post-process of the restatement vs the real reference."""
+    semantic post-processing with predict_all_pixels) and fai-mf-m-ade (fai-mf-m-ade.json: the same head, 3 decoder layers with a 512-wide
+    FFN, on the STDC-2 backbone): registry config = the reference's file, state-dict keys = the reference model's, forward and the
+    per-pixel-argmax post-process of the restatement vs the real reference."""
     import json
     import os
 
@@ -95,8 +97,8 @@ def test_mf_ade_variant_oracle_matches_reference_live():
     ref_import.install()
     import focoos.models.fai_mf.processor as fp
 
-    cfg = ModelRegistry.get_model_info("fai-mf-l-ade")["config"]
-    ref_cfg = json.load(open(os.path.join(ref_import.REFERENCE_ROOT, "focoos/model_registry/fai-mf-l-ade.json")))["config"]
+    cfg = ModelRegistry.get_model_info(name)["config"]
+    ref_cfg = json.load(open(os.path.join(ref_import.REFERENCE_ROOT, f"focoos/model_registry/{name}.json")))["config"]
     assert {k: v for k, v in cfg.items() if k in ref_cfg} == ref_cfg
     model, proc, _ = ref_import.build_reference_mf(ref_cfg)
     fp.binary_mask_to_base64 = lambda m: ""
