@@ -82,6 +82,7 @@ SIGNATURES = {
     "fx_mha_workspace_bytes": [_i, _i, _i, _i, _i],
     "fx_mha_masked_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _i, _vp, C.c_size_t, _vp],
     "fx_upsample_nearest_add_nhwc_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "fx_upsample_nearest_bwd_nhwc_bf16": [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "fx_query_pixel_logits_bf16": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "fx_mf_class_head": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "fx_mf_upsample_probs_f32": [_vp, _i, _i, _vp, _i, _i, _i, _vp],
@@ -187,7 +188,7 @@ def lib_path() -> str:
     return os.environ.get("FOCOOS_AMD_LIB", LIB_PATH)
 
 
-FX_ABI_VERSION = 3   # = include/focoos_amd.h (tests/test_host_cpu.py compares the two)
+FX_ABI_VERSION = 4   # = include/focoos_amd.h (tests/test_host_cpu.py compares the two)
 
 
 def load() -> C.CDLL:

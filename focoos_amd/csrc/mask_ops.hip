@@ -7,6 +7,15 @@
 // ------------------------------------------------------------------------------------------------
 // y = lateral + nearest_upsample(top)   (TransformerFPN.forward_features, fai_mf/modelling.py:364;
 // F.interpolate(mode="nearest"): src = floor(dst * in/out)).  8 channels (16 B) per thread.
+// ATen's nearest_idx (UpSample.h): identity / exact x2 by shift, otherwise floorf(dst * (float)in / out) clamped - in float, which is
+// NOT floor(dst * in / out) for every ratio (in 14, out 20, dst 10: 6, not 7).
+__device__ __forceinline__ int nearest_src(int dst, int in_size, int out_size) {
+  if (out_size == in_size) return dst;
+  if (out_size == 2 * in_size) return dst >> 1;
+  const float scale = (float)in_size / (float)out_size;
+  return min((int)floorf((float)dst * scale), in_size - 1);
+}
+
 __global__ __launch_bounds__(256) void upsample_nearest_add_kernel(const bf16_t* __restrict__ lat, int ldl, const bf16_t* __restrict__ top,
                                                                    int ldt, bf16_t* __restrict__ out, int ldo, int B, int H, int W, int Hs,
                                                                    int Ws, int C8) {
@@ -18,7 +27,7 @@ __global__ __launch_bounds__(256) void upsample_nearest_add_kernel(const bf16_t*
     p /= W;
     const int y = (int)(p % H);
     const int b = (int)(p / H);
-    const int ys = (int)(((int64_t)y * Hs) / H), xs = (int)(((int64_t)x * Ws) / W);
+    const int ys = nearest_src(y, Hs, H), xs = nearest_src(x, Ws, W);
     float a[8], t[8];
     unpack_bf16x8(*reinterpret_cast<const uint4*>(lat + (((int64_t)b * H + y) * W + x) * ldl + c8 * 8), a);
     unpack_bf16x8(*reinterpret_cast<const uint4*>(top + (((int64_t)b * Hs + ys) * Ws + xs) * ldt + c8 * 8), t);
@@ -37,6 +46,48 @@ extern "C" int fx_upsample_nearest_add_nhwc_bf16(const void* lateral, int ldl, c
   if (grid > 256 * 32) grid = 256 * 32;
   hipLaunchKernelGGL(upsample_nearest_add_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_),
                      (const bf16_t*)lateral, ldl, (const bf16_t*)top, ldt, (bf16_t*)out, ldo, B, H, W, Hs, Ws, C / 8);
+  return fx_launch_status();
+}
+
+// Adjoint of the up-sampling half of the kernel above, in gather form (deterministic): dtop[b,ys,xs,:] = sum of dy over the output
+// pixels whose nearest source is (ys, xs).  The map dst -> src is monotone, so a source's pre-image is a short contiguous run per axis
+// (2 for the x2 case, 1-2 for ceil sizes); it is found by testing the candidates around src * out / in with the forward's own formula.
+__global__ __launch_bounds__(256) void upsample_nearest_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, bf16_t* __restrict__ dtop, int lddt, int B,
+                                                                   int H, int W, int Hs, int Ws, int C8) {
+  const int64_t total = (int64_t)B * Hs * Ws * C8;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c8 = (int)(i % C8);
+    int64_t p = i / C8;
+    const int xs = (int)(p % Ws);
+    p /= Ws;
+    const int ys = (int)(p % Hs);
+    const int b = (int)(p / Hs);
+    const int y_lo = max(0, (int)(((int64_t)ys * H) / Hs) - 1), y_hi = min(H - 1, (int)(((int64_t)(ys + 1) * H + Hs - 1) / Hs) + 1);
+    const int x_lo = max(0, (int)(((int64_t)xs * W) / Ws) - 1), x_hi = min(W - 1, (int)(((int64_t)(xs + 1) * W + Ws - 1) / Ws) + 1);
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int y = y_lo; y <= y_hi; ++y) {
+      if (nearest_src(y, Hs, H) != ys) continue;
+      for (int x = x_lo; x <= x_hi; ++x) {
+        if (nearest_src(x, Ws, W) != xs) continue;
+        float f[8];
+        unpack_bf16x8(*reinterpret_cast<const uint4*>(dy + (((int64_t)b * H + y) * W + x) * lddy + c8 * 8), f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += f[j];
+      }
+    }
+    *reinterpret_cast<uint4*>(dtop + (((int64_t)b * Hs + ys) * Ws + xs) * lddt + c8 * 8) = pack_bf16x8(acc);
+  }
+}
+
+extern "C" int fx_upsample_nearest_bwd_nhwc_bf16(const void* dy, int lddy, void* dtop, int lddt, int B, int H, int W, int Hs, int Ws, int C,
+                                                 fx_stream_t stream_) {
+  FX_CHECK_ARG(dy && dtop && B > 0 && H > 0 && W > 0 && Hs > 0 && Ws > 0 && C > 0 && C % 8 == 0);
+  FX_CHECK_ARG(lddy >= C && lddt >= C && lddy % 8 == 0 && lddt % 8 == 0);
+  int64_t total = (int64_t)B * Hs * Ws * (C / 8);
+  int64_t grid = (total + 255) / 256;
+  if (grid > 256 * 32) grid = 256 * 32;
+  hipLaunchKernelGGL(upsample_nearest_bwd_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)dy, lddy,
+                     (bf16_t*)dtop, lddt, B, H, W, Hs, Ws, C / 8);
   return fx_launch_status();
 }
 
@@ -420,7 +471,7 @@ __global__ __launch_bounds__(128) void mf_select_kernel(const MfPartial* __restr
   if (threadIdx.x == 0) det_count[b] = wcount[0] + wcount[1];
 }
 
-// Bit-packed binary masks of the kept detections: words[((b*Q + slot)*H + y)*(W/32) + x/32], bit x&31.
+// Bit-packed binary masks of the kept detections: words[((b*Q + slot)*H + y)*ceil(W/32) + x/32], bit x&31 (bits >= W are 0).
 __global__ __launch_bounds__(256) void mf_pack_masks_kernel(const float* __restrict__ lo, int h, int w, int H, int W, float sy, float sx,
                                                             float thr, const int32_t* __restrict__ det_count,
                                                             const int32_t* __restrict__ det_query, int Q, uint32_t* __restrict__ words) {
@@ -428,7 +479,7 @@ __global__ __launch_bounds__(256) void mf_pack_masks_kernel(const float* __restr
   if (slot >= det_count[b]) return;
   const int q = det_query[b * Q + slot];
   const float* p = lo + ((int64_t)b * Q + q) * h * w;
-  const int W32 = W >> 5;
+  const int W32 = (W + 31) >> 5;
   uint32_t* wo = words + ((int64_t)b * Q + slot) * H * W32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ya = blockIdx.x * FX_MF_BAND, yb = min(H, ya + FX_MF_BAND);
@@ -470,7 +521,6 @@ extern "C" int fx_mf_postprocess(const float* mask_probs_lowres, int h, int w, i
   FX_CHECK_ARG(mask_probs_lowres && score && label && workspace && det_count && det_query && det_score && det_label && det_box && det_area);
   FX_CHECK_ARG(B > 0 && Q > 0 && h > 0 && w > 0 && H > 0 && W > 0);
   if (Q > 128) return FX_ERR_UNSUPPORTED;
-  FX_CHECK_ARG(!mask_words || W % 32 == 0);
   FX_CHECK_ARG(workspace_bytes >= (size_t)fx_mf_postprocess_workspace_bytes(B, Q, H));
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const int nband = (H + FX_MF_BAND - 1) / FX_MF_BAND;

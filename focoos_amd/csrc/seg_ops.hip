@@ -433,16 +433,27 @@ __global__ __launch_bounds__(128) void seg_select_kernel(const SegPartial* __res
   if (threadIdx.x == 0) det_count[b] = wcount[0] + wcount[1];
 }
 
-// Bit-packed binary masks of the kept detections from the winner map: bit x&31 of words[((b*Q + slot)*H + y)*(W/32) + x/32].
+// Bit-packed binary masks of the kept detections from the winner map: bit x&31 of words[((b*Q + slot)*H + y)*ceil(W/32) + x/32].
 __global__ __launch_bounds__(256) void seg_pack_masks_kernel(const uint8_t* __restrict__ winner, int H, int W, const int32_t* __restrict__ det_count,
                                                              const int32_t* __restrict__ det_query, int Q, uint32_t* __restrict__ words) {
   const int slot = blockIdx.y, b = blockIdx.z;
   if (slot >= det_count[b]) return;
   const int q = det_query[b * Q + slot];
-  const int W32 = W >> 5;
+  const int W32 = (W + 31) >> 5;
   const uint8_t* wb = winner + (int64_t)b * H * W;
   uint32_t* wo = words + ((int64_t)b * Q + slot) * H * W32;
   const int64_t nwords = (int64_t)H * W32;
+  if (W & 31) {   // rows are not whole words: byte-wise, bits >= W stay 0 (odd image widths; the aligned form below is the hot one)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * 256) {
+      const int y = (int)(i / W32), x0 = (int)(i % W32) * 32;
+      const uint8_t* row = wb + (int64_t)y * W + x0;
+      const int n = min(32, W - x0);
+      uint32_t bits = 0;
+      for (int t = 0; t < n; ++t) bits |= (uint32_t)(row[t] == (uint8_t)q) << t;
+      wo[i] = bits;
+    }
+    return;
+  }
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * 256) {
     const uint4 a = *reinterpret_cast<const uint4*>(wb + i * 32), c = *reinterpret_cast<const uint4*>(wb + i * 32 + 16);
     const uint32_t v[8] = {a.x, a.y, a.z, a.w, c.x, c.y, c.z, c.w};
@@ -473,7 +484,6 @@ extern "C" int fx_seg_postprocess(const float* mask_probs_lowres, int h, int w, 
   FX_CHECK_ARG(mask_probs_lowres && score && label && workspace && det_count && det_query && det_score && det_label && det_box && det_area);
   FX_CHECK_ARG(B > 0 && Q > 0 && h > 0 && w > 0 && H > 0 && W > 0);
   if (Q > SEG_QMAX) return FX_ERR_UNSUPPORTED;
-  FX_CHECK_ARG(!mask_words || W % 32 == 0);
   FX_CHECK_ARG(workspace_bytes >= fx_seg_postprocess_workspace_bytes(B, Q, h, w, H, W) && ((uintptr_t)workspace % 16) == 0);
   hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
   const size_t win_bytes = ((size_t)B * H * W + 255) / 256 * 256;
@@ -501,7 +511,7 @@ extern "C" int fx_seg_postprocess(const float* mask_probs_lowres, int h, int w, 
   hipLaunchKernelGGL(seg_select_kernel, dim3(B), dim3(128), 0, stream, part, nblk, score, label, Q, threshold, use_mask_score, det_count,
                      det_query, det_score, det_label, det_box, det_area);
   if (mask_words) {
-    const int64_t nwords = (int64_t)H * (W / 32);
+    const int64_t nwords = (int64_t)H * ((W + 31) / 32);
     int gx = (int)((nwords + 255) / 256);
     if (gx > 64) gx = 64;
     hipLaunchKernelGGL(seg_pack_masks_kernel, dim3(gx, Q, B), dim3(256), 0, stream, winner, H, W, det_count, det_query, Q, mask_words);

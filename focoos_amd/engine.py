@@ -400,9 +400,13 @@ class DetrEngine(_EngineBase):
 class _PlanBase:
     """Buffers + the static launch sequence for one (batch, height, width); helpers shared by the model families."""
 
+    size_multiple = 32
+
     def __init__(self, eng: _EngineBase, B: int, H: int, W: int, f32_input: bool, parent: Optional["_MultiPlan"] = None, index: int = 0):
-        if H % 32 or W % 32:
-            raise _lib.FocoosAmdError("input height/width must be multiples of 32")
+        # RT-DETR runs at its configured square resolution (DETRProcessor.preprocess resizes, fai_detr/processor.py:66-119): multiples of 32.
+        # The mask families run at the image's own size (size_divisibility 0) with ceil(H/2) at every stride-2 layer: size_multiple = 1.
+        if H % self.size_multiple or W % self.size_multiple or H < 32 or W < 32:
+            raise _lib.FocoosAmdError(f"input height/width must be multiples of {self.size_multiple} (and at least 32)")
         self.eng, self.B, self.H, self.W, self.f32_input = eng, B, H, W, f32_input
         self.parent, self.index = parent, index
         self.lib = eng.lib
@@ -579,12 +583,12 @@ class _PlanBase:
         # and consumed from LDS; FX_PW_CHAIN=0 restores one launch per layer, FX_PW_CHAIN_MAX_STAGE limits the stages covered.
         use_chain = int(os.environ.get("FX_PW_CHAIN", "1")) != 0
         max_stage = int(os.environ.get("FX_PW_CHAIN_MAX_STAGE", "1"))  # res2 + res3: HBM-bound seams; res4 measured neutral (profiles/r02a)
-        c1 = self._new("conv1_1", B, H // 2, W // 2, 32)
+        c1 = self._new("conv1_1", B, (H + 1) // 2, (W + 1) // 2, 32)   # 3x3 / s2 / p1: ceil(H/2)
         self._op(lib.fx_stem_conv3x3s2, self.input.data_ptr(), int(self.f32_input), e.stem_w.data_ptr(), e.stem_b.data_ptr(),
                  e.px_mean.data_ptr(), e.px_inv_std.data_ptr(), c1.ptr, B, H, W, 32)
         x = self.conv(c1, P[f"{bb}.conv1.conv1_2"], name="conv1_2", act="relu")
         x = self.conv(x, P[f"{bb}.conv1.conv1_3"], name="conv1_3", act="relu")
-        mp = self._new("maxpool", B, H // 4, W // 4, 64)
+        mp = self._new("maxpool", B, (x.H + 1) // 2, (x.W + 1) // 2, 64)
         self._op(lib.fx_maxpool3x3s2_nhwc_bf16, x.ptr, x.ld, mp.ptr, mp.ld, B, x.H, x.W, 64)
         x = mp
         seq = [(si, bi) for si in range(4) for bi in range(blocks[si])]

@@ -129,6 +129,8 @@ class BfEngine(StdcEngineMixin, _EngineBase):
 class _BfPlan(StdcPlanMixin, MaskDecoderPlanMixin, _PlanBase):
     """BiSeNetFormer launch sequence for one (batch, height, width)."""
 
+    size_multiple = 1   # the processor hands the image over at its own size (bisenetformer/processor.py:96)
+
     def __init__(self, eng: "BfEngine", B: int, H: int, W: int, f32_input: bool, full_masks: bool = False, parent=None, index: int = 0):
         self.full_masks = bool(full_masks)
         super().__init__(eng, B, H, W, f32_input, parent, index)

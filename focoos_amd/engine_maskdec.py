@@ -198,7 +198,8 @@ class MaskDecoderPlanMixin:
         self.det_labels = self._io("det_labels", (B, Q), torch.int32).zero_()
         self.det_boxes = self._io("det_boxes", (B, Q, 4), torch.int32).zero_()
         self.det_area = self._io("det_area", (B, Q), torch.int32).zero_()
-        self.mask_words = self._io("mask_words", (B, Q, H, W // 32), torch.int32).zero_()
+        self.mask_width = W
+        self.mask_words = self._io("mask_words", (B, Q, H, (W + 31) // 32), torch.int32).zero_()   # rows padded to whole words (bits >= W are 0)
         self.winner = None
         self.post_index = len(self.ops)
         if predict_all_pixels:

@@ -155,6 +155,8 @@ class MfEngine(StdcEngineMixin, _EngineBase):
 class _MfPlan(StdcPlanMixin, MaskDecoderPlanMixin, _PlanBase):
     """MaskFormer launch sequence for one (batch, height, width)."""
 
+    size_multiple = 1   # MaskFormerProcessor.preprocess hands the image over at its own size (fai_mf/processor.py:96)
+
     def __init__(self, eng: "MfEngine", B: int, H: int, W: int, f32_input: bool, full_masks: bool = False, parent=None, index: int = 0):
         self.full_masks = bool(full_masks)
         super().__init__(eng, B, H, W, f32_input, parent, index)
@@ -165,7 +167,7 @@ class _MfPlan(StdcPlanMixin, MaskDecoderPlanMixin, _PlanBase):
         Q, K = e.nq, e.nc
         feats = self.build_stdc() if e.stdc else self.build_backbone()
         pd = "pixel_decoder"
-        h32, w32 = H // 32, W // 32
+        h32, w32 = feats[5].H, feats[5].W
         # ---- pixel decoder (fai_mf/modelling.py:347-369)
         x5 = feats[5]
         if e.n_enc > 0:

@@ -76,7 +76,7 @@ class StdcPlanMixin:
         bb = "pixel_decoder.backbone"
         self.input = self._io("input", (B, H, W, 3), torch.float32 if self.f32_input else torch.uint8)
         self.sizes = self._io("sizes", (B, 2), torch.int32)
-        c1 = self._new("features.0", B, H // 2, W // 2, 32)
+        c1 = self._new("features.0", B, (H + 1) // 2, (W + 1) // 2, 32)
         self._op(lib.fx_stem_conv3x3s2, self.input.data_ptr(), int(self.f32_input), e.stem_w.data_ptr(), e.stem_b.data_ptr(), e.px_mean.data_ptr(),
                  e.px_inv_std.data_ptr(), c1.ptr, B, H, W, 32)
         x = self.conv(c1, P[f"{bb}.features.1"], name="features.1", stride=2, act="relu")

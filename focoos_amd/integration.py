@@ -34,20 +34,22 @@ def _fx_version_key(module) -> tuple:
         tuple(p.data_ptr() for p in module.parameters())
 
 
-def _require_engine_input(images) -> None:
+def _require_engine_input(images, size_multiple: int = 32) -> None:
     """The adapters NEVER run the reference's stock PyTorch graph (a result produced that way says nothing about the engine):
-    inputs the engine has no plan for are refused loudly.  That is (i) H or W not a multiple of 32 - stock focoos accepts such sizes for
-    the mask families, whose processors never resize; reference-equal support needs ceil-size semantics in the stride-2 / pool / resize /
-    mask-plane kernels, not pad-and-crop - and (ii) a gradient with respect to the input images.  CPU tensors
-    are refused by the engine itself (FocoosAmdError: no CPU path)."""
+    inputs the engine has no plan for are refused loudly.  That is (i) for RT-DETR, H or W not a multiple of 32 (``size_multiple``): its
+    processor resizes every image to the configured square resolution (fai_detr/processor.py:66-119), the engine has no plan for anything
+    else; the mask families run at the image's own size with the reference's ceil(H/2) arithmetic at every level (``size_multiple`` 1,
+    tests/test_gpu_odd_sizes.py) - and (ii) a gradient with respect to the input images.  CPU tensors are refused by the engine itself
+    (FocoosAmdError: no CPU path)."""
     from ._lib import FocoosAmdError
 
     if images.dim() != 4:
         return    # let the engine raise on the malformed input
     h, w = (images.shape[2], images.shape[3]) if (images.shape[1] == 3 and images.shape[-1] != 3) else (images.shape[1], images.shape[2])
-    if h % 32 or w % 32:
-        raise FocoosAmdError(f"focoos_amd: input {h}x{w} is not a multiple of 32; the HIP engine has no plan for it and does not fall back to the "
-                             "reference's stock graph (resize or pad the image in the processor, or unregister the engine for this model)")
+    if h % size_multiple or w % size_multiple or h < 32 or w < 32:
+        raise FocoosAmdError(f"focoos_amd: input {h}x{w} is not a multiple of {size_multiple} (or smaller than 32); the HIP engine has no plan for it "
+                             "and does not fall back to the reference's stock graph (resize or pad the image in the processor, or unregister "
+                             "the engine for this model)")
     if torch.is_grad_enabled() and images.requires_grad:
         raise FocoosAmdError("focoos_amd: gradients with respect to the input images are not implemented by the HIP training graph "
                              "(and the adapter does not fall back to the reference's stock graph)")
@@ -179,7 +181,7 @@ def make_mf_engine_class():
             return g[0]
 
         def forward(self, images, targets=[]):
-            _require_engine_input(images)   # raises: no fallback to the reference's own graph
+            _require_engine_input(images, 1)   # any size >= 32 (ceil-size arithmetic); raises otherwise: no fallback to the reference's own graph
             x = images
             if x.dim() == 4 and x.shape[1] == 3 and x.shape[-1] != 3:
                 x = x.permute(0, 2, 3, 1)
@@ -244,7 +246,7 @@ def make_bf_engine_class():
             return g[0]
 
         def forward(self, images, targets=[]):
-            _require_engine_input(images)   # raises: no fallback to the reference's own graph
+            _require_engine_input(images, 1)   # any size >= 32 (ceil-size arithmetic); raises otherwise: no fallback to the reference's own graph
             x = images
             if x.dim() == 4 and x.shape[1] == 3 and x.shape[-1] != 3:
                 x = x.permute(0, 2, 3, 1)

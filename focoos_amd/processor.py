@@ -427,16 +427,16 @@ class MaskFormerProcessor(DETRProcessor):
 
     @staticmethod
     def unpack_masks(words: torch.Tensor, H: int, W: int) -> np.ndarray:
-        """int32 [n, H, W/32] bit-packed -> bool [n, H, W]."""
+        """int32 [n, H, ceil(W/32)] bit-packed -> bool [n, H, W]."""
         w = words.cpu().numpy().view(np.uint8)
-        return np.unpackbits(w, axis=-1, bitorder="little").reshape(words.shape[0], H, W).astype(bool)
+        return np.unpackbits(w, axis=-1, bitorder="little").reshape(words.shape[0], H, -1)[..., :W].astype(bool)
 
     def pack_detections(self, res, class_names: Sequence[str] = (), encode_masks: bool = True) -> List[FocoosDetections]:
         """D2H of the packed device results (counts, scores, labels, boxes, bit-packed masks of the kept detections only),
         then the host tail of processor.py:270-303: trim to the box, PNG + base64."""
         n = res.det_count.cpu().tolist()
         s, l, b = res.det_scores.cpu().tolist(), res.det_labels.cpu().tolist(), res.det_boxes.cpu().tolist()
-        H, W = res.mask_words.shape[2], res.mask_words.shape[3] * 32
+        H, W = res.mask_words.shape[2], int(getattr(res, "mask_width", res.mask_words.shape[3] * 32))
         out = []
         for i, ni in enumerate(n):
             if ni == 0:
@@ -464,12 +464,11 @@ class _MfDeviceResults:
     """Output buffers of fx_mf_postprocess (same attribute names as the engine plan)."""
 
     def __init__(self, B: int, Q: int, H: int, W: int, dev):
-        if W % 32:
-            raise ValueError("mask width must be a multiple of 32 for the bit-packed mask output")
+        self.mask_width = W
         self.det_count = torch.zeros(B, dtype=torch.int32, device=dev)
         self.det_query = torch.zeros(B, Q, dtype=torch.int32, device=dev)
         self.det_scores = torch.zeros(B, Q, dtype=torch.float32, device=dev)
         self.det_labels = torch.zeros(B, Q, dtype=torch.int32, device=dev)
         self.det_boxes = torch.zeros(B, Q, 4, dtype=torch.int32, device=dev)
         self.det_area = torch.zeros(B, Q, dtype=torch.int32, device=dev)
-        self.mask_words = torch.zeros(B, Q, H, W // 32, dtype=torch.int32, device=dev)
+        self.mask_words = torch.zeros(B, Q, H, (W + 31) // 32, dtype=torch.int32, device=dev)   # rows padded to whole words

@@ -7,8 +7,8 @@ train_bf's, the reference's two decoder files differ only in the number of level
 ``SetCriterion`` (fai_mf/loss.py:345-607, 626-723 = mask_criterion.py).  Parameter names are the reference's.
 
 New nodes here: ``ConvNormFlat`` (detectron-style ``Conv2d`` whose weight lives on the module itself next to ``norm.*``), ``ConvBias``
-(biased convolution without normalisation), ``_UpAddFn`` (nearest x2 upsample + add; backward = 2x2 block sums), the pre-norm encoder layer.
-Glue on small tensors as listed in train_bf.py; additionally the x4 of the 2x2 block means in ``_UpAddFn.backward``."""
+(biased convolution without normalisation), ``_UpAddFn`` (nearest upsample + add; backward = sums over each source's pre-image), the pre-norm
+encoder layer.  Glue on small tensors as listed in train_bf.py."""
 from __future__ import annotations
 
 from typing import Dict, Optional, Sequence
@@ -104,28 +104,31 @@ class ConvBias(nn.Module):
 
 
 class _UpAddFn(torch.autograd.Function):
-    """cur + interpolate(y, size=cur.shape, mode="nearest") for an exact x2 (TransformerFPN top-down path, modelling.py:361):
-    fx_upsample_nearest_add_nhwc_bf16; backward: d cur = d, d y = the 2x2 block sums of d."""
+    """cur + interpolate(y, size=cur.shape, mode="nearest") (TransformerFPN top-down path, modelling.py:361-364): fx_upsample_nearest_add_nhwc_bf16;
+    backward: d cur = d, d y = the sums of d over each source pixel's pre-image (fx_upsample_nearest_bwd_nhwc_bf16; 2x2 blocks for the exact
+    x2 of inputs that are multiples of 32, 1-2 pixels per axis at the ceil(H/2) levels of other sizes)."""
 
     @staticmethod
     def forward(ctx, cur, y, lib):
         B, H, W_, Cc = cur.shape
-        if tuple(y.shape) != (B, H // 2, W_ // 2, Cc) or H % 2 or W_ % 2:
-            raise _lib.FocoosAmdError(f"nearest top-down addition needs an exact x2 ({tuple(y.shape)} -> {tuple(cur.shape)})")
+        if y.shape[0] != B or y.shape[3] != Cc:
+            raise _lib.FocoosAmdError(f"nearest top-down addition: batch / channel mismatch ({tuple(y.shape)} -> {tuple(cur.shape)})")
         cur, y = cur.contiguous(), y.contiguous()
         out = torch.empty_like(cur)
-        check(lib.fx_upsample_nearest_add_nhwc_bf16(cur.data_ptr(), Cc, y.data_ptr(), Cc, out.data_ptr(), Cc, B, H, W_, H // 2, W_ // 2, Cc,
+        check(lib.fx_upsample_nearest_add_nhwc_bf16(cur.data_ptr(), Cc, y.data_ptr(), Cc, out.data_ptr(), Cc, B, H, W_, y.shape[1], y.shape[2], Cc,
                                                     _stream(cur.device)), "fx_upsample_nearest_add_nhwc_bf16")
-        ctx.lib = lib
+        ctx.lib, ctx.src_hw = lib, (y.shape[1], y.shape[2])
         return out
 
     @staticmethod
     def backward(ctx, d):
         d = d.contiguous()
         B, H, W_, Cc = d.shape
-        dy = torch.empty(B, H // 2, W_ // 2, Cc, dtype=torch.bfloat16, device=d.device)
-        check(ctx.lib.fx_avgpool2x2_nhwc_bf16(d.data_ptr(), Cc, dy.data_ptr(), Cc, B, H, W_, Cc, _stream(d.device)), "fx_avgpool2x2_nhwc_bf16")
-        return d, dy * 4, None
+        hs, ws = ctx.src_hw
+        dy = torch.empty(B, hs, ws, Cc, dtype=torch.bfloat16, device=d.device)
+        check(ctx.lib.fx_upsample_nearest_bwd_nhwc_bf16(d.data_ptr(), Cc, dy.data_ptr(), Cc, B, H, W_, hs, ws, Cc, _stream(d.device)),
+              "fx_upsample_nearest_bwd_nhwc_bf16")
+        return d, dy, None
 
 
 class PreNormEncoderLayer(nn.Module):

@@ -29,7 +29,7 @@ extern "C" {
 /* Bumped whenever a descriptor struct's layout OR the semantics the host relies on change (version 2: fx_conv_desc grew mask / ldm /
  * reserved0 and the library applies the ReLU mask the previous bottleneck skips; version 3: fx_pw_chain_desc grew pool / ldp / img_h / img_w);
  * focoos_amd/_lib.py refuses a library of another version. */
-#define FX_ABI_VERSION 3
+#define FX_ABI_VERSION 4
 
 enum { FX_OK = 0, FX_ERR_INVALID_ARGUMENT = -1, FX_ERR_LAUNCH = -2, FX_ERR_UNSUPPORTED = -3, FX_ERR_RUNTIME = -4 };
 enum { FX_ACT_NONE = 0, FX_ACT_RELU = 1, FX_ACT_SILU = 2, FX_ACT_GELU = 3 };
@@ -278,9 +278,14 @@ int fx_mha_masked_bf16(const void* q, int ldq, const void* k, int ldk, const voi
                        int heads, const uint32_t* mask_bits, int ld_mask_words, void* workspace, size_t workspace_bytes, fx_stream_t stream);
 
 /* TransformerFPN top-down step (fai_mf/modelling.py:364): out = lateral + F.interpolate(top, size=(H,W), mode="nearest").
- * lateral/out bf16 NHWC [B,H,W,C], top bf16 NHWC [B,Hs,Ws,C]; C % 8 == 0. */
+ * lateral/out bf16 NHWC [B,H,W,C], top bf16 NHWC [B,Hs,Ws,C]; C % 8 == 0.  Any (H, W) / (Hs, Ws): the source index follows ATen's
+ * nearest_idx (float arithmetic), e.g. the ceil(H/2) levels of inputs that are not multiples of 32. */
 int fx_upsample_nearest_add_nhwc_bf16(const void* lateral, int ldl, const void* top, int ldt, void* out, int ldo, int B, int H, int W,
                                       int Hs, int Ws, int C, fx_stream_t stream);
+/* Adjoint of its up-sampling half (training): dtop bf16 [B,Hs,Ws,C] = sum of dy bf16 [B,H,W,C] over the pixels whose nearest source
+ * (ATen's float rule: identity, exact x2, else floorf(dst * (float)in / out)) it is; gather form, deterministic.  d lateral = dy. */
+int fx_upsample_nearest_bwd_nhwc_bf16(const void* dy, int lddy, void* dtop, int lddt, int B, int H, int W, int Hs, int Ws, int C,
+                                      fx_stream_t stream);
 
 /* PredictionHeads mask einsum (fai_mf/modelling.py:88): logit[b,q,p] = sum_c embed[b,q,c] * feat[b,p,c]; embed bf16
  * [B*Q, C] (row stride lde), feat bf16 [B*P, C] (row stride ldf), C == 256 (fai-mf) or 128 (bisenetformer), Q <= 128.
@@ -303,7 +308,7 @@ int fx_mf_upsample_probs_f32(const float* lowres, int h, int w, float* out, int 
  * mask_threshold; keep masks with > 1 pixel; score = class score * (1e-3*sum_in_mask p)/(1e-3*area + 1e-5) when
  * use_mask_score; keep score > threshold (threshold <= 0 keeps all).  Survivors compacted in query order per image:
  * det_count i32 [B]; det_query/det_label/det_area i32 [B][Q]; det_score f32 [B][Q]; det_box i32 [B][Q][4] =
- * (x_min, y_min, x_max, y_max) inclusive; mask_words (optional, W % 32 == 0) u32 [B][Q][H][W/32], bit x&31 — slot j holds the
+ * (x_min, y_min, x_max, y_max) inclusive; mask_words (optional) u32 [B][Q][H][ceil(W/32)], bit x&31 (bits >= W are 0) — slot j holds the
  * binary mask of detection j.  workspace: fx_mf_postprocess_workspace_bytes(B,Q,H) bytes.  Deterministic. */
 int fx_mf_postprocess_workspace_bytes(int B, int Q, int H);
 int fx_mf_postprocess(const float* mask_probs_lowres, int h, int w, int H, int W, const float* score, const int32_t* label, int B, int Q,

@@ -131,6 +131,34 @@ def test_upsample_nearest_add_and_class_head(lib):
         assert label.cpu().tolist() == l.tolist()
 
 
+@pytest.mark.parametrize("sizes", [((10, 12), (5, 6)), ((19, 25), (10, 13)), ((20, 30), (14, 20)), ((7, 9), (7, 9)), ((13, 47), (4, 11))])
+def test_upsample_nearest_any_size_and_adjoint(lib, sizes):
+    """F.interpolate(mode="nearest") for any size pair - the ceil(H/2) levels of inputs that are not multiples of 32 - with ATen's float index
+    rule ((20, 30) <- (14, 20) holds a pixel where floor(dst*in/out) in exact arithmetic differs from it), bit-exact; and the adjoint (training)
+    against autograd's, to bf16 rounding of the sums."""
+    (H, W), (Hs, Ws) = sizes
+    g = torch.Generator().manual_seed(1)
+    lat = torch.randn(2, H, W, 64, generator=g).bfloat16()
+    top = torch.randn(2, Hs, Ws, 64, generator=g).bfloat16()
+    out = torch.empty(2, H, W, 64, dtype=torch.bfloat16, device=DEV)
+    ld, td = dev(lat), dev(top)
+    check(lib.fx_upsample_nearest_add_nhwc_bf16(ld.data_ptr(), 64, td.data_ptr(), 64, out.data_ptr(), 64, 2, H, W, Hs, Ws, 64, stream()))
+    t32 = top.float().permute(0, 3, 1, 2).requires_grad_(True)
+    up = F.interpolate(t32, size=(H, W), mode="nearest")
+    ref = lat.float() + up.permute(0, 2, 3, 1)
+    torch.cuda.synchronize()
+    assert (out.float().cpu() - ref.detach().bfloat16().float()).abs().max() == 0
+    dy = torch.randn(2, H, W, 64, generator=g).bfloat16()
+    up.backward(dy.float().permute(0, 3, 1, 2))
+    dtop = torch.empty(2, Hs, Ws, 64, dtype=torch.bfloat16, device=DEV)
+    dyd = dev(dy)
+    check(lib.fx_upsample_nearest_bwd_nhwc_bf16(dyd.data_ptr(), 64, dtop.data_ptr(), 64, 2, H, W, Hs, Ws, 64, stream()))
+    torch.cuda.synchronize()
+    want = t32.grad.permute(0, 2, 3, 1)
+    got, wb = dtop.float().cpu(), want.bfloat16().float()     # fp32 sums of <= 20 bf16 values rounded once: equal up to the summation order
+    assert float((got == wb).float().mean()) >= 0.995 and (got - wb).abs().max() <= 2 ** -6 * want.abs().max()
+
+
 @pytest.mark.parametrize("cfg", [(2, 100, 40, 48), (1, 17, 25, 33)])
 def test_mf_postprocess_vs_oracle(lib, cfg):
     """fx_mf_postprocess + fx_mf_upsample_probs_f32 vs F.interpolate + the oracle's restatement of
@@ -280,7 +308,7 @@ def test_mf_free_running_and_graph(setup):
 def test_mf_loud_failures(setup):
     g, cfg, sd, eng, *_ = setup
     with pytest.raises(_lib.FocoosAmdError):
-        eng.plan(1, 100, 128)  # not a multiple of 32
+        eng.plan(1, 20, 128)   # smaller than 32 (any size >= 32 has a plan: tests/test_gpu_odd_sizes.py)
     bad = dict(cfg, num_queries=200)
     with pytest.raises(_lib.FocoosAmdError):
         MfEngine(bad, sd, device=DEV)

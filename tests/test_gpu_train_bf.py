@@ -52,8 +52,10 @@ def _cfg(num_points=2048):
     return dict(cfg, criterion_num_points=num_points)   # 12544 in the registry: minutes on the CPU oracle, same code path
 
 
-@pytest.mark.parametrize("norm", ["FrozenBN", "BN"])
-def test_bf_train_step_losses_and_gradients(norm):
+@pytest.mark.parametrize("norm,size", [("FrozenBN", (192, 256)), ("BN", (192, 256)), ("FrozenBN", (150, 200))])
+def test_bf_train_step_losses_and_gradients(norm, size):
+    """size (150, 200): not a multiple of 32 - ceil(H/2) at every stride-2 layer of the forward AND of its adjoints (tests/test_gpu_odd_sizes.py
+    covers the inference engine)."""
     from focoos_amd.train_bf import BisenetFormerTrainable
 
     cfg = _cfg()
@@ -65,7 +67,7 @@ def test_bf_train_step_losses_and_gradients(norm):
         # therefore compared on the 3-block STDC (layers 1-1-1: the same modules, a composition shallow enough to be well conditioned).
         cfg = dict(cfg, backbone_config=dict(cfg["backbone_config"], layers=[1, 1, 1]))
     sd = synth_state_dict(cfg, 31, family="bisenetformer")
-    nimg, (ih, iw) = (4, (192, 256)) if norm == "BN" else (2, (192, 256))
+    nimg, (ih, iw) = (4 if norm == "BN" else 2), size
     imgs = [synth_image_structured(60 + i, ih, iw) for i in range(nimg)]
     labels, masks = T.synth_mask_targets(5, nimg, int(cfg["num_classes"]), (ih, iw), counts=(3, 5, 2, 4))
 

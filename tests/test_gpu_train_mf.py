@@ -26,8 +26,11 @@ def _cfg(depth, num_points=2048):
     return cfg
 
 
-@pytest.mark.parametrize("norm,variant", [("FrozenBN", "r50"), ("BN", "r50"), ("FrozenBN", "fai-mf-m-ade")])
-def test_mf_train_step_losses_and_gradients(norm, variant):
+@pytest.mark.parametrize("norm,variant,size", [("FrozenBN", "r50", (192, 256)), ("BN", "r50", (192, 256)), ("FrozenBN", "fai-mf-m-ade", (192, 256)),
+                                               ("FrozenBN", "r50", (150, 200))])
+def test_mf_train_step_losses_and_gradients(norm, variant, size):
+    """size (150, 200): not a multiple of 32 (ceil-size forward and adjoints: partial AvgPool2d(2,2,ceil_mode) windows, nearest up-sampling with
+    non-integer ratios, 5 x 7 encoder tokens)."""
     from focoos_amd.train_mf import FAIMaskFormerTrainable
 
     if variant == "r50":
@@ -45,7 +48,7 @@ def test_mf_train_step_losses_and_gradients(norm, variant):
             if k.startswith("head.predictor.") and k.endswith("in_proj_weight"):
                 sd[k] = sd[k].clone()
                 sd[k][:512] *= 0.25
-    nimg, (ih, iw) = (4, (192, 256)) if norm == "BN" else (2, (192, 256))
+    nimg, (ih, iw) = (4 if norm == "BN" else 2), size
     imgs = [synth_image_structured(160 + i, ih, iw) for i in range(nimg)]
     labels, masks = T.synth_mask_targets(7, nimg, int(cfg["num_classes"]), (ih, iw), counts=(3, 5, 2, 4))
 

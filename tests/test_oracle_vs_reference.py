@@ -121,6 +121,45 @@ def test_mf_ade_variant_oracle_matches_reference_live(name):
     assert [list(d.bbox) for d in dets] == boxes.tolist()
 
 
+@pytest.mark.parametrize("name", ["fai-mf-l-coco-ins", "fai-mf-m-ade", "bisenetformer-l-ade"])
+def test_odd_sizes_oracle_matches_reference_live(name):
+    """Inputs that are not multiples of 32 (the mask families' processors do not resize or pad: size_divisibility 0): the restatements
+    against the real reference at 100x150, 75x94 and 130x97 - ceil(H/2) at every stride-2 layer, partial AvgPool2d(ceil_mode) windows,
+    F.interpolate(size=...) with non-integer ratios.  What tests/test_gpu_odd_sizes.py compares the engine with."""
+    import json
+    import os
+
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.synth import synth_image_structured, synth_state_dict
+
+    ref_import.install()
+    info = ModelRegistry.get_model_info(name)
+    cfg, family = info["config"], info["model_family"]
+    ref_cfg = json.load(open(os.path.join(ref_import.REFERENCE_ROOT, f"focoos/model_registry/{name}.json")))["config"]
+    if family == "fai_mf":
+        from oracle import mf_oracle as M
+
+        model, proc, _ = ref_import.build_reference_mf(ref_cfg)
+        fwd = lambda sd, x: M.mf_forward(sd, cfg, x)   # noqa: E731
+    else:
+        from oracle import bf_oracle as BF
+
+        model, proc, _ = ref_import.build_reference_bf(ref_cfg)
+        fwd = lambda sd, x: BF.bf_forward(sd, cfg, x)   # noqa: E731
+    sd = synth_state_dict(cfg, seed=17, family=family)
+    model.load_state_dict(sd, strict=True)
+    for h, w in ((100, 150), (75, 94), (130, 97)):
+        imgs = [synth_image_structured(27, h, w)]
+        x, _ = proc.preprocess(imgs, device=torch.device("cpu"), dtype=torch.float32)
+        assert tuple(x.shape) == (1, 3, h, w)
+        with torch.no_grad():
+            out = model(x)
+            probs, masks = fwd(sd, x)
+        assert tuple(out.masks.shape[-2:]) == (h, w)
+        np.testing.assert_allclose(probs.numpy(), out.logits.numpy(), atol=1e-4)
+        assert (masks - out.masks).abs().max().item() < 5e-3
+
+
 def test_bf_oracle_matches_reference_live():
     """BiSeNetFormer (A13): forward + batch-1 postprocess (predict_all_pixels) of the restatement vs the real reference, another
     seed and size than the committed golden; the registry config equals the reference's own registry file."""
