@@ -252,7 +252,7 @@ def _wgrad_roofline(nn_, stepper, imgs, targets, family="fai_detr"):
         B, H, W_, Cc = x.shape
         _, Ho, Wo, N = dz.shape
         k = layer.k
-        rec.append((e0, e1, 2.0 * B * Ho * Wo * N * Cc * k * k, 2.0 * (x.numel() + dz.numel()) + 4.0 * N * Cc * k * k))
+        rec.append((e0, e1, 2.0 * B * Ho * Wo * N * Cc * k * k, 2.0 * (x.numel() + dz.numel()) + 4.0 * N * Cc * k * k, (B * Ho * Wo, N, Cc, k, layer.stride)))
         return out
 
     nn_._conv_param_grads = timed
@@ -265,7 +265,18 @@ def _wgrad_roofline(nn_, stepper, imgs, targets, family="fai_detr"):
         stepper.wgrad_stream = side
         stepper.use_graphs = graphs
     torch.cuda.synchronize()
-    ms = sum(a.elapsed_time(b) for a, b, _, _ in rec)
+    ms = sum(r[0].elapsed_time(r[1]) for r in rec)
+    if os.environ.get("FX_WGRAD_TABLE"):   # per-shape table of the weight-gradient launches (+ slab sum): M N C k stride launches ms TFLOP/s
+        by_shape = {}
+        for r in rec:
+            d = by_shape.setdefault(r[4], [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += r[0].elapsed_time(r[1])
+            d[2] += r[2]
+        with open(os.environ["FX_WGRAD_TABLE"], "w") as f:
+            f.write("# M N C k stride launches ms TFLOP/s   (weight-gradient kernel + slab sum per conv layer shape, serial on the main stream)\n")
+            for sh, (n, t, fl_) in sorted(by_shape.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"{sh[0]:8d} {sh[1]:5d} {sh[2]:5d} {sh[3]} {sh[4]} {n:3d} {t:8.3f} {fl_ / (t * 1e-3) / 1e12:8.1f}\n")
     fl, by = sum(r[2] for r in rec), sum(r[3] for r in rec)
     tf, gbs = fl / (ms * 1e-3) / 1e12, by / (ms * 1e-3) / 1e9
     ai = fl / by

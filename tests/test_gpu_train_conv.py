@@ -37,6 +37,13 @@ WGRAD_CASES = [
     (1, 28, 28, 512, 2048, 1, 1),   # many tiles
     (4, 64, 64, 64, 256, 1, 1),     # M = 16384: several pixel chunks accumulate atomically
     (2, 12, 12, 3 * 8, 40, 3, 1),   # C = 24, N = 40: both below a tile, C not a power of two
+    # wide layers (N % 256 == 0, C % 256 == 0): the partial-slab call runs conv_wgrad_dma_kernel (256 x 256 tiles, LDS-DMA ring)
+    (2, 40, 40, 256, 256, 3, 1),    # res4-level 3x3: nine taps = nine K tiles, image borders inside a pixel range
+    (3, 17, 23, 256, 256, 3, 1),    # ragged: rows wrap inside a 32-pixel step, W < 32, pixel tail (M = 1173)
+    (1, 20, 20, 512, 512, 3, 1),    # res5 3x3: two K tiles per tap, 2 x 18 tiles
+    (2, 25, 31, 256, 512, 1, 1),    # pointwise, M = 1550 (tail), N = 512
+    (1, 40, 40, 1024, 256, 1, 1),   # pointwise, K = 1024
+    (2, 20, 20, 256, 256, 3, 2),    # same shape class at stride 2: the 128 x 128 kernel with the wide class's split plan
 ]
 
 
