@@ -29,6 +29,7 @@ import torch
 
 from . import _lib
 from ._lib import FX_ACT, FxConvDesc, FxPwChainDesc, FxRcStage, check
+from .engine_stdc import StdcEngineMixin, StdcPlanMixin
 from .state_spec import RESNET_BLOCKS
 
 BN_EPS = 1e-5
@@ -184,17 +185,26 @@ class _EngineBase:
                     self.chain_a[(si, bi)] = (self._pack_frag(wa[:, :, 0, 0]), self._dev(ba), wa.shape[0])
 
 
-class DetrEngine(_EngineBase):
+class DetrEngine(StdcEngineMixin, _EngineBase):
     def __init__(self, config: Dict, state_dict: Dict[str, torch.Tensor], device: str = "cuda:0"):
         super().__init__(config, device)
+        # backbone: ResNet-vd (fai-detr-l-*) or STDC (fai-detr-m-coco; engine_stdc.py)
+        self.stdc = config["backbone_config"].get("model_type") == "stdc"
+        if self.stdc:
+            self._init_stdc(config["backbone_config"])
         self.nc = int(config["num_classes"])
         self.nq = int(config.get("num_queries", 300))
         self.hd = int(config.get("transformer_predictor_hidden_dim", 256))
         self.nl = int(config.get("transformer_predictor_dec_layers", 6))
         self.nhead = int(config.get("transformer_predictor_nhead", 8))
         self.n_enc = int(config.get("pixel_decoder_num_encoder_layers", 1))
-        if self.hd != 256 or int(config.get("pixel_decoder_feat_dim", 256)) != 256 or self.nhead != 8:
-            raise _lib.FocoosAmdError("engine kernels are specialised for hidden_dim 256 / 8 heads (fai-detr-l)")
+        # hybrid-encoder width: 256 (fai-detr-l-*) or 128 (fai-detr-m-coco); the AIFI layer's attention / LayerNorm kernels exist at 256 only
+        # (8 heads of 32 channels), so the narrow encoder needs pixel_decoder_num_encoder_layers = 0 - as fai-detr-m-coco has
+        self.fd = int(config.get("pixel_decoder_feat_dim", 256))
+        if (self.hd != 256 or self.fd not in (128, 256) or int(config.get("pixel_decoder_out_dim", self.fd)) != self.fd or self.nhead != 8
+                or (self.n_enc > 0 and self.fd != 256)):
+            raise _lib.FocoosAmdError("engine kernels cover decoder width 256 / 8 heads with a 256-channel hybrid encoder, or a 128-channel one "
+                                      "without the AIFI layer (fai-detr-l-*, fai-detr-m-coco)")
         self.top_k = int(config.get("top_k", 300))
         self.threshold = float(config.get("threshold", 0.5))
         self.load_state_dict(state_dict)
@@ -207,7 +217,10 @@ class DetrEngine(_EngineBase):
         def cbn(name, conv="conv", norm="norm"):
             P[name] = self._pack(*_fold_bn(sd, f"{name}.{conv}.weight", f"{name}.{norm}"))
 
-        self._pack_backbone(sd, P)
+        if self.stdc:
+            self._pack_stdc(sd, P)
+        else:
+            self._pack_backbone(sd, P)
         pd = "pixel_decoder"
         for i in range(3):
             P[f"{pd}.input_proj.{i}"] = self._pack(*_fold_bn(sd, f"{pd}.input_proj.{i}.0.weight", f"{pd}.input_proj.{i}.1"))
@@ -676,23 +689,24 @@ class _PlanBase:
             pass
 
 
-class _Plan(_PlanBase):
+class _Plan(StdcPlanMixin, _PlanBase):
     """RT-DETR launch sequence."""
 
     # -------------------------------------------------------------- the network
     def _build(self):
         e, P, B, lib = self.eng, self.eng.P, self.B, self.lib
         H, W = self.H, self.W
-        feats = self.build_backbone()
+        feats = self.build_stdc() if e.stdc else self.build_backbone()
+        fd = e.fd
         # ---- hybrid encoder (modelling.py:297-347)
         pd = "pixel_decoder"
         h8, w8, h16, w16, h32, w32 = H // 8, W // 8, H // 16, W // 16, H // 32, W // 32
-        cat80 = self._new("cat80", B, h8, w8, 512)     # [up(lat1) | proj(res3)]
-        cat40a = self._new("cat40a", B, h16, w16, 512)  # [up(lat0) | proj(res4)]
-        cat40b = self._new("cat40b", B, h16, w16, 512)  # [downconv0 | lat1]
-        cat20 = self._new("cat20", B, h32, w32, 512)    # [downconv1 | lat0]
-        self.conv(feats[3], P[f"{pd}.input_proj.0"], out=cat80.slice(256, 256))
-        self.conv(feats[4], P[f"{pd}.input_proj.1"], out=cat40a.slice(256, 256))
+        cat80 = self._new("cat80", B, h8, w8, 2 * fd)     # [up(lat1) | proj(res3)]
+        cat40a = self._new("cat40a", B, h16, w16, 2 * fd)  # [up(lat0) | proj(res4)]
+        cat40b = self._new("cat40b", B, h16, w16, 2 * fd)  # [downconv0 | lat1]
+        cat20 = self._new("cat20", B, h32, w32, 2 * fd)    # [downconv1 | lat0]
+        self.conv(feats[3], P[f"{pd}.input_proj.0"], out=cat80.slice(fd, fd))
+        self.conv(feats[4], P[f"{pd}.input_proj.1"], out=cat40a.slice(fd, fd))
         src = self.conv(feats[5], P[f"{pd}.input_proj.2"], name="proj5")
         L = h32 * w32
         if e.n_enc > 0:
@@ -716,27 +730,27 @@ class _Plan(_PlanBase):
 
         def csp(xin: NT, p: str, out_name: str) -> NT:
             c12 = self.conv(xin, P[f"{p}.conv12"], name=f"{p}.c12", act="silu")  # [x_1 | x_2]
-            x1 = c12.slice(0, 256)
+            x1 = c12.slice(0, fd)
             for j in range(3):
                 last = j == 2
                 x1 = self.conv(x1, P[f"{p}.bottlenecks.{j}.rep"], name=out_name if last else f"{p}.rep{j}", act="silu",
-                               residual=c12.slice(256, 256) if last else None, res_after=True,
-                               extra_flops_per_pixel=2.0 * 256 * 256)  # the reference's separate 1x1 RepVGG branch
+                               residual=c12.slice(fd, fd) if last else None, res_after=True,
+                               extra_flops_per_pixel=2.0 * fd * fd)  # the reference's separate 1x1 RepVGG branch
             return x1
 
-        lat0 = self.conv(src, P[f"{pd}.lateral_convs.0"], out=cat20.slice(256, 256), act="silu")
-        self.resize(lat0, cat40a.slice(0, 256))
+        lat0 = self.conv(src, P[f"{pd}.lateral_convs.0"], out=cat20.slice(fd, fd), act="silu")
+        self.resize(lat0, cat40a.slice(0, fd))
         fpn0 = csp(cat40a, f"{pd}.fpn_blocks.0", "fpn0")
-        lat1 = self.conv(fpn0, P[f"{pd}.lateral_convs.1"], out=cat40b.slice(256, 256), act="silu")
-        self.resize(lat1, cat80.slice(0, 256))
+        lat1 = self.conv(fpn0, P[f"{pd}.lateral_convs.1"], out=cat40b.slice(fd, fd), act="silu")
+        self.resize(lat1, cat80.slice(0, fd))
         out80 = csp(cat80, f"{pd}.fpn_blocks.1", "enc_s8")
-        d0 = self._new("down0", B, h16, w16, 256)
+        d0 = self._new("down0", B, h16, w16, fd)
         self.resize(out80, d0)
-        self.conv(d0, P[f"{pd}.downsample_convs.0"], out=cat40b.slice(0, 256), act="silu")
+        self.conv(d0, P[f"{pd}.downsample_convs.0"], out=cat40b.slice(0, fd), act="silu")
         out40 = csp(cat40b, f"{pd}.pan_blocks.0", "enc_s16")
-        d1 = self._new("down1", B, h32, w32, 256)
+        d1 = self._new("down1", B, h32, w32, fd)
         self.resize(out40, d1)
-        self.conv(d1, P[f"{pd}.downsample_convs.1"], out=cat20.slice(0, 256), act="silu")
+        self.conv(d1, P[f"{pd}.downsample_convs.1"], out=cat20.slice(0, fd), act="silu")
         out20 = csp(cat20, f"{pd}.pan_blocks.1", "enc_s32")
         # ---- predictor (modelling.py:1145-1263); memory rows in the reference order [s32 | s16 | s8]
         hp = "head.predictor"

@@ -11,7 +11,8 @@ from typing import Dict
 import torch
 
 from . import _lib
-from .engine import NT, PackedConv, _fold_bn
+
+# (engine.py imports this module - the RT-DETR engine takes the STDC backbone too (fai-detr-m-coco) - so its helpers are imported at call time)
 
 BN_EPS = 1e-5
 
@@ -37,6 +38,8 @@ class StdcEngineMixin:
             self.vec: Dict[str, torch.Tensor] = {}
 
     def _pack_stdc(self, sd, P: Dict[str, PackedConv]) -> None:
+        from .engine import _fold_bn
+
         bb = "pixel_decoder.backbone"
         if not hasattr(self, "vec"):
             self.vec = {}

@@ -6,7 +6,7 @@ or a local ``model_final.pth`` given by ``weights_uri``."""
 from __future__ import annotations
 
 import copy
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 _DETR_L_CONFIG = {
     "num_classes": 365,
@@ -22,11 +22,24 @@ _DETR_L_CONFIG = {
     "transformer_predictor_dec_layers": 6, "transformer_predictor_dim_feedforward": 1024,
     "head_out_dim": 256, "pixel_decoder_dropout": 0.0, "pixel_decoder_nhead": 8, "transformer_predictor_nhead": 8,
     "threshold": 0.5, "top_k": 300,
+    "criterion_deep_supervision": True, "criterion_eos_coef": 0.1, "criterion_losses": ["vfl", "boxes"], "criterion_num_points": 0,
+    "criterion_focal_alpha": 0.75, "criterion_focal_gamma": 2.0, "weight_dict_loss_vfl": 1, "weight_dict_loss_bbox": 5, "weight_dict_loss_giou": 2,
+    "matcher_cost_class": 2, "matcher_cost_bbox": 5, "matcher_cost_giou": 2, "matcher_use_focal_loss": True, "matcher_alpha": 0.25, "matcher_gamma": 2.0,
 }
 
+# focoos/model_registry/fai-detr-m-coco.json: STDC-2 backbone, 128-channel hybrid encoder WITHOUT the AIFI layer, 3 decoder layers
+_DETR_M_COCO_CONFIG = copy.deepcopy(_DETR_L_CONFIG)
+_DETR_M_COCO_CONFIG.update({
+    "num_classes": 80,
+    "backbone_config": {"use_pretrained": False, "backbone_url": None, "model_type": "stdc", "in_chans": 3, "base": 64, "layers": [4, 5, 3],
+                        "out_features": ["res2", "res3", "res4", "res5"], "block_num": 4, "block_type": "cat", "use_conv_last": False},
+    "pixel_decoder_out_dim": 128, "pixel_decoder_feat_dim": 128, "pixel_decoder_num_encoder_layers": 0,
+    "transformer_predictor_out_dim": 128, "transformer_predictor_dec_layers": 3, "head_out_dim": 128,
+})
 
-def _entry(name: str, num_classes: int, description: str) -> Dict:
-    cfg = copy.deepcopy(_DETR_L_CONFIG)
+
+def _entry(name: str, num_classes: int, description: str, base: Optional[Dict] = None) -> Dict:
+    cfg = copy.deepcopy(base if base is not None else _DETR_L_CONFIG)
     cfg["num_classes"] = num_classes
     return {
         "name": name, "model_family": "fai_detr", "task": "detection", "im_size": 640,
@@ -124,6 +137,7 @@ _REGISTRY = {
     "fai-mf-m-ade": dict(_mf_entry("fai-mf-m-ade", _MF_M_ADE_CONFIG, "MaskFormer medium (STDC-2), ADE20K semantic segmentation"), task="semseg"),
     "fai-detr-l-obj365": _entry("fai-detr-l-obj365", 365, "RT-DETR large (R50-vd), Objects365 head"),
     "fai-detr-l-coco": _entry("fai-detr-l-coco", 80, "RT-DETR large (R50-vd), COCO head"),
+    "fai-detr-m-coco": _entry("fai-detr-m-coco", 80, "RT-DETR medium (STDC-2, 128-channel encoder, 3 decoder layers), COCO head", _DETR_M_COCO_CONFIG),
 }
 
 

@@ -76,8 +76,8 @@ def resnet_vd_spec(spec, prefix: str, depth: int, in_chans: int = 3):
 def detr_state_spec(config: Dict) -> "OrderedDict[str, Tuple[Tuple[int, ...], str]]":
     """Ordered ``name -> (shape, kind)`` for a registry-style DETR config dict."""
     bb = config["backbone_config"]
-    if bb.get("model_type", "resnet") != "resnet":
-        raise ValueError("engine state spec covers resnet backbones (fai-detr-l-*)")
+    if bb.get("model_type", "resnet") not in ("resnet", "stdc"):
+        raise ValueError("engine state spec covers resnet (fai-detr-l-*) and stdc (fai-detr-m-coco) backbones")
     nc = int(config["num_classes"])
     fd = int(config.get("pixel_decoder_feat_dim", 256))
     od = int(config.get("pixel_decoder_out_dim", 256))
@@ -90,7 +90,11 @@ def detr_state_spec(config: Dict) -> "OrderedDict[str, Tuple[Tuple[int, ...], st
     n_levels, n_points = 3, 4
 
     spec: "OrderedDict[str, Tuple[Tuple[int, ...], str]]" = OrderedDict()
-    chans = resnet_vd_spec(spec, "pixel_decoder.backbone", int(bb.get("depth", 50)), int(bb.get("in_chans", 3)))
+    if bb.get("model_type", "resnet") == "stdc":
+        chans = stdc_spec(spec, "pixel_decoder.backbone", int(bb.get("base", 64)), tuple(bb.get("layers", (4, 5, 3))), int(bb.get("block_num", 4)),
+                          int(bb.get("in_chans", 3)))
+    else:
+        chans = resnet_vd_spec(spec, "pixel_decoder.backbone", int(bb.get("depth", 50)), int(bb.get("in_chans", 3)))
     # Encoder (modelling.py:195-291)
     for i, c in enumerate(chans[1:]):
         spec[f"pixel_decoder.input_proj.{i}.0.weight"] = ((fd, c, 1, 1), "conv_w")

@@ -143,10 +143,11 @@ class _Seq2(nn.Module):
 class TransformerPredictor(nn.Module):
     """fai_detr/modelling.py:1023-1263, training branch (all decoder layers + the encoder top-k set are supervised)."""
 
-    def __init__(self, lib, nc: int, c=256, nq=300, nl=6, ffn=1024):
+    def __init__(self, lib, nc: int, c=256, nq=300, nl=6, ffn=1024, in_dim=None):
         super().__init__()
         self.lib, self.nc, self.c, self.nq, self.nl = lib, nc, c, nq, nl
-        self.input_proj = nn.ModuleList([ConvNormLayer(lib, c, c, 1, 1, None) for _ in range(3)])
+        # in_dim: channels of the encoder's maps (pixel_decoder_out_dim: 256, or 128 for fai-detr-m-coco) projected to the decoder width
+        self.input_proj = nn.ModuleList([ConvNormLayer(lib, in_dim or c, c, 1, 1, None) for _ in range(3)])
         self.decoder = _Layers([TransformerDecoderLayer(lib, c, ffn) for _ in range(nl)])
         self.query_pos_head = MLP(lib, 4, 2 * c, c, 2)
         self.enc_output = _Seq2(Linear(lib, c, c), LayerNorm(lib, c))
@@ -332,14 +333,26 @@ class FAIDetrTrainable(nn.Module):
         lib = _lib.load()
         self.config = dict(config)
         nc = int(config["num_classes"])
-        self.pixel_decoder = HybridEncoder(lib, ffn=int(config.get("pixel_decoder_dim_feedforward", 1024)),
-                                           n_enc=int(config.get("pixel_decoder_num_encoder_layers", 1)))
-        self.pixel_decoder.backbone = ResNetVd(int(config["backbone_config"].get("depth", 50)), config.get("pixel_mean", (123.675, 116.28, 103.53)),
-                                               config.get("pixel_std", (58.395, 57.12, 57.375)))
+        bb = config["backbone_config"]
+        mean, std = config.get("pixel_mean", (123.675, 116.28, 103.53)), config.get("pixel_std", (58.395, 57.12, 57.375))
+        fd, n_enc = int(config.get("pixel_decoder_feat_dim", 256)), int(config.get("pixel_decoder_num_encoder_layers", 1))
+        if fd not in (128, 256) or int(config.get("pixel_decoder_out_dim", fd)) != fd or (n_enc > 0 and fd != 256):
+            raise _lib.FocoosAmdError("hybrid encoder: 256 channels, or 128 without the AIFI layer (attention / LayerNorm kernels: 8 heads of 32 channels)")
+        if bb.get("model_type") == "stdc":      # fai-detr-m-coco: the BiSeNetFormer backbone under the hybrid encoder
+            from .train_bf import STDC
+
+            base = int(bb.get("base", 64))
+            backbone = STDC(lib, base, tuple(bb.get("layers", (4, 5, 3))), mean, std)
+            in_channels = (base * 4, base * 8, base * 16)
+        else:
+            backbone = ResNetVd(int(bb.get("depth", 50)), mean, std)
+            in_channels = (512, 1024, 2048)
+        self.pixel_decoder = HybridEncoder(lib, in_channels=in_channels, c=fd, ffn=int(config.get("pixel_decoder_dim_feedforward", 1024)), n_enc=n_enc)
+        self.pixel_decoder.backbone = backbone
         self.head = nn.Module()
         self.head.criterion = SetCriterionTrain(nc)
         self.head.predictor = TransformerPredictor(lib, nc, nq=int(config.get("num_queries", 300)), nl=int(config.get("transformer_predictor_dec_layers", 6)),
-                                                   ffn=int(config.get("transformer_predictor_dim_feedforward", 1024)))
+                                                   ffn=int(config.get("transformer_predictor_dim_feedforward", 1024)), in_dim=fd)
         from .train_nn import set_norm_mode
         set_norm_mode(self, norm)
 

@@ -322,6 +322,17 @@ def box_cxcywh_to_xyxy(x: torch.Tensor) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------- whole model
+def backbone_features(sd: SD, cfg: Dict, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+    """res2..res5 of the configured backbone: ResNet-vd (fai-detr-l-*, focoos/nn/backbone/resnet.py:252-266) or STDC (fai-detr-m-coco,
+    focoos/nn/backbone/stdc.py:313-320) - load_backbone dispatches on backbone_config.model_type (focoos/nn/backbone/build.py:4-8)."""
+    bb = cfg["backbone_config"]
+    if bb.get("model_type", "resnet") == "stdc":
+        from . import bf_oracle as BF
+
+        return BF.stdc(sd, "pixel_decoder.backbone", x, tuple(bb.get("layers", (4, 5, 3))))
+    return resnet_vd(sd, "pixel_decoder.backbone", x, RESNET_BLOCKS[int(bb.get("depth", 50))])
+
+
 def detr_forward(sd: SD, cfg: Dict, images: torch.Tensor, forced_topk: Optional[torch.Tensor] = None,
                  collect: Optional[dict] = None) -> Tuple[torch.Tensor, torch.Tensor]:
     """FAIDetr.forward (eval) — modelling.py:1344-1358 + DETRHead.forward :386-401.
@@ -330,8 +341,7 @@ def detr_forward(sd: SD, cfg: Dict, images: torch.Tensor, forced_topk: Optional[
     mean = torch.tensor(cfg.get("pixel_mean", [123.675, 116.28, 103.53]), dtype=torch.float32).view(-1, 1, 1)
     std = torch.tensor(cfg.get("pixel_std", [58.395, 57.12, 57.375]), dtype=torch.float32).view(-1, 1, 1)
     x = (images - mean) / std
-    depth = int(cfg["backbone_config"].get("depth", 50))
-    feats = resnet_vd(sd, "pixel_decoder.backbone", x, RESNET_BLOCKS[depth])
+    feats = backbone_features(sd, cfg, x)
     if collect is not None:
         collect.update({k: v for k, v in feats.items()})
     enc = hybrid_encoder(sd, [feats["res3"], feats["res4"], feats["res5"]], cfg, collect)

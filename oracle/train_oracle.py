@@ -64,8 +64,7 @@ def detr_train_outputs(sd: SD, cfg: Dict, images: torch.Tensor, forced_topk: Opt
     mean = torch.tensor(cfg.get("pixel_mean", [123.675, 116.28, 103.53]), dtype=torch.float32).view(-1, 1, 1)
     std = torch.tensor(cfg.get("pixel_std", [58.395, 57.12, 57.375]), dtype=torch.float32).view(-1, 1, 1)
     x = (images - mean) / std
-    depth = int(cfg["backbone_config"].get("depth", 50))
-    feats = O.resnet_vd(sd, "pixel_decoder.backbone", x, O.RESNET_BLOCKS[depth])
+    feats = O.backbone_features(sd, cfg, x)
     enc = O.hybrid_encoder(sd, [feats["res3"], feats["res4"], feats["res5"]], cfg)
     return predictor_train(sd, enc, cfg, forced_topk)
 

@@ -1,0 +1,141 @@
+"""fai-detr-m-coco (focoos/model_registry/fai-detr-m-coco.json) on a real MI355X: the STDC-2 backbone (engine_stdc.py) under a 128-channel
+hybrid encoder without the AIFI layer, three decoder layers fed through 128 -> 256 input projections - the same engine / training graph as
+fai-detr-l-*, parametrised.  The oracle is pinned live to the reference built from that registry file
+(tests/test_oracle_vs_reference.py::test_oracle_matches_reference_small_input[fai-detr-m-coco]).  Gates as in tests/test_gpu_e2e.py /
+tests/test_gpu_train_detr.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from focoos_amd.model import FAIDetr, ModelManager  # noqa: E402
+from focoos_amd.ports import DETRTargets  # noqa: E402
+from focoos_amd.registry import ModelRegistry  # noqa: E402
+from focoos_amd.synth import synth_image_structured, synth_state_dict  # noqa: E402
+from oracle import detr_oracle as O  # noqa: E402
+from oracle import train_oracle as T  # noqa: E402
+from tests.helpers import rel_l2  # noqa: E402
+from tests.test_gpu_e2e import TOL_BOX, TOL_PROB, TOL_SCORE  # noqa: E402
+
+DEV = "cuda:0"
+NAME = "fai-detr-m-coco"
+
+
+def nchw(nt):
+    return nt.torch_view().float().cpu().permute(0, 3, 1, 2)
+
+
+def test_detr_m_stage_parity_teacher_forced():
+    cfg = ModelRegistry.get_model_info(NAME)["config"]
+    assert cfg["backbone_config"]["model_type"] == "stdc" and cfg["pixel_decoder_feat_dim"] == 128 and cfg["transformer_predictor_dec_layers"] == 3
+    seed = 7
+    sd = synth_state_dict(cfg, seed)
+    model = FAIDetr(cfg, device=DEV, seed=seed)
+    eng = model.engine
+    assert eng.stdc and eng.fd == 128 and eng.n_enc == 0 and eng.nl == 3
+    images = [synth_image_structured(30 + i, 640, 640) for i in range(2)]
+    x_u8 = torch.from_numpy(np.stack(images)).to(DEV)
+    col = {}
+    with torch.no_grad():
+        xo = O.get_torch_batch(images, (640, 640))
+        probs_free, _ = O.detr_forward(sd, cfg, xo, collect=col)
+    # free-running first: the encoder scores that drive the top-300 selection, then the oracle again with the ENGINE's selection forced
+    out = model.forward(x_u8, use_graph=False)
+    torch.cuda.synchronize()
+    pl = model.last_plan
+    for k in ("res3", "res4", "res5", "enc_s32", "enc_s16", "enc_s8"):
+        assert tuple(nchw(pl.bufs[k]).shape) == tuple(col[k].shape), k
+        e = rel_l2(nchw(pl.bufs[k]), col[k])
+        assert e < 2e-2, (k, e)
+    assert rel_l2(pl.bufs["memory"].t.float().cpu().view(2, -1, 256), col["memory"]) < 2e-2
+    ds = (pl.enc_scores.cpu() - col["enc_scores"].view(2, -1)).abs().max().item() if "enc_scores" in col else None
+    forced = pl.enc_topk.cpu().long()
+    col2 = {}
+    with torch.no_grad():
+        probs_o, boxes_o = O.detr_forward(sd, cfg, xo, forced_topk=forced, collect=col2)
+    assert rel_l2(pl.bufs["target"].t.float().cpu().view(2, 300, 256), col2["target"]) < 3e-2
+    for i in range(3):
+        e = rel_l2(pl.bufs[f"dec{i}.out"].t.float().cpu().view(2, 300, 256), col2[f"dec{i}_out"])
+        assert e < 4e-2, (i, e)
+        assert (pl.refs[i + 1].cpu().view(2, 300, 4) - col2[f"dec{i}_ref"]).abs().max() < 1e-2, i
+    dp = (out.logits.cpu() - probs_o).abs().max().item()
+    db = (out.boxes.cpu() - boxes_o).abs().max().item()
+    print(f"{NAME}: |dprob| {dp:.4f} |dbox| {db:.4f} encoder-score max |d| {ds}")
+    assert dp <= TOL_PROB and db <= TOL_BOX, (dp, db)
+    if ds is not None:   # measured 0.085 (fai-detr-l: 0.066-0.069; the STDC backbone arrives at the score head with 0.9 % instead of 0.6 %)
+        assert ds <= 1.3 * TOL_SCORE
+    # graph replay (two parts only from bs 32 on; here one plan) equals the eager launch
+    out2 = model.forward(x_u8, use_graph=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out2.logits, out.logits) and torch.equal(out2.boxes, out.boxes)
+    # the standalone surface
+    fm = ModelManager.get(NAME, seed=seed)
+    dets = fm.infer_batch(images, threshold=0.05)
+    assert len(dets) == 2
+
+
+def test_detr_m_train_step_losses_and_gradients():
+    from focoos_amd.train_detr import FAIDetrTrainable
+
+    cfg = ModelRegistry.get_model_info(NAME)["config"]
+    sd = synth_state_dict(cfg, 21)
+    imgs = [synth_image_structured(80 + i, 128, 160) for i in range(2)]
+    labels, boxes = T.synth_targets(2, 2, 80, counts=(4, 6))
+
+    def trainable(k, v):
+        if not (v.dtype == torch.float32 and v.dim() > 0) or any(t in k for t in ("running_", "empty_weight", "mask_features")):
+            return False
+        is_bn = (k.endswith((".norm.weight", ".norm.bias", ".bn.weight", ".bn.bias", ".avd_layer.1.weight", ".avd_layer.1.bias"))
+                 or ".input_proj." in k and k.split(".")[-2] == "1")
+        return not is_bn
+
+    sdg = {k: (v.clone().requires_grad_(True) if trainable(k, v) else v.clone()) for k, v in sd.items()}
+    x = O.get_torch_batch(imgs, None)
+    outs = T.detr_train_outputs(sdg, cfg, x)
+    losses_o, matches = T.criterion(outs, labels, boxes)
+    sum(losses_o.values()).backward()
+    # conditioning of THIS configuration at random-init weights: the fp32 oracle again with nothing but the weights rounded to bf16 (same
+    # top-k selection and matches) - the early STDC blocks move by 30-50 % (no residual connections, 12 blocks deep; the same backbone
+    # under MaskFormer: tests/test_gpu_train_mf.py), so each tensor is gated against ITS measured sensitivity as well as the absolute gate
+    sdb = {k: ((v.detach().bfloat16().float() if v.dim() >= 2 else v.detach().clone()).requires_grad_(v.requires_grad)) if v.dtype == torch.float32
+           else v.clone() for k, v in sdg.items()}
+    outs_w = T.detr_train_outputs(sdb, cfg, x, forced_topk=outs["topk_ind"])
+    lw, _ = T.criterion(outs_w, labels, boxes, fixed_matches=matches)
+    sum(lw.values()).backward()
+    sens = {k: rel_l2(sdb[k].grad, sdg[k].grad) for k in sdg if isinstance(sdg[k], torch.Tensor) and sdg[k].requires_grad and sdb[k].grad is not None}
+    model = FAIDetrTrainable(cfg, norm="FrozenBN").to(DEV)
+    model.load_state_dict(sd, strict=True)
+    assert sorted(model.state_dict().keys()) == sorted(sd.keys())
+    targets = [DETRTargets(labels=l.to(DEV), boxes=b.to(DEV)) for l, b in zip(labels, boxes)]
+    fixed = []
+    for m in matches:
+        pi = torch.tensor(np.concatenate([i for i, _ in m]), dtype=torch.int32, device=DEV)
+        ti = torch.tensor(np.concatenate([j for _, j in m]), dtype=torch.int32, device=DEV)
+        fixed.append((pi, ti))
+    x_u8 = torch.from_numpy(np.stack(imgs)).to(DEV)
+    losses = model(x_u8, targets, forced_topk=outs["topk_ind"].to(DEV), fixed_matches=fixed)
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    assert sorted(losses) == sorted(losses_o) and len(losses) == 3 * (3 + 1)     # three decoder layers + the encoder set
+    for k in losses_o:
+        a, b = float(losses[k]), float(losses_o[k])
+        assert abs(a - b) <= 3e-2 * abs(b) + 1e-3, (k, a, b)
+    errs = []
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        r = sdg[name]
+        if not (isinstance(r, torch.Tensor) and r.requires_grad):
+            continue
+        assert p.grad is not None and r.grad is not None, name
+        errs.append((rel_l2(p.grad.cpu(), r.grad), name, float(r.grad.norm())))
+    floor = 1e-3 * sorted(n for _, _, n in errs)[len(errs) // 2]
+    errs = sorted(((e, n) for e, n, g in errs if g >= floor), reverse=True)
+    print(f"{len(errs)} parameter tensors; worst 5: {[(round(e, 4), n) for e, n in errs[:5]]}; median {errs[len(errs) // 2][0]:.4f}")
+    sw = sorted(sens.values(), reverse=True)
+    print(f"bf16-weights-only oracle: worst {sw[0]:.4f}, median {sw[len(sw) // 2]:.4f}")
+    assert len(errs) > 150
+    assert errs[len(errs) // 2][0] <= 0.08
+    bad = [(round(e, 4), round(sens.get(n, 0.0), 4), n) for e, n in errs if e > max(0.25, 3.0 * sens.get(n, 0.0))]
+    assert not bad, bad
