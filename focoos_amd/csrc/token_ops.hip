@@ -69,13 +69,39 @@ __global__ __launch_bounds__(256) void layernorm256_kernel(const bf16_t* __restr
   *reinterpret_cast<uint2*>(out + (int64_t)row * ldo + lane * 4) = o;
 }
 
+// The same over 128 channels (2 per lane): the 128-channel pixel-decoder encoders of fai-mf-{m,s}-coco-ins.
+__global__ __launch_bounds__(256) void layernorm128_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ res, int ldr,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            bf16_t* __restrict__ out, int ldo, int rows) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const unsigned xv = *reinterpret_cast<const unsigned*>(x + (int64_t)row * ldx + lane * 2);
+  float v0 = __uint_as_float(xv << 16), v1 = __uint_as_float(xv & 0xffff0000u);
+  if (res) {
+    const unsigned rv = *reinterpret_cast<const unsigned*>(res + (int64_t)row * ldr + lane * 2);
+    v0 += __uint_as_float(rv << 16);
+    v1 += __uint_as_float(rv & 0xffff0000u);
+  }
+  const float mean = wave_sum(v0 + v1) * (1.0f / 128.0f);
+  const float d0 = v0 - mean, d1 = v1 - mean;
+  const float var = wave_sum(d0 * d0 + d1 * d1) * (1.0f / 128.0f);
+  const float rstd = rsqrtf(var + 1e-5f);
+  const float2 g = *reinterpret_cast<const float2*>(gamma + lane * 2), bt = *reinterpret_cast<const float2*>(beta + lane * 2);
+  *reinterpret_cast<unsigned*>(out + (int64_t)row * ldo + lane * 2) = pack_bf16x2(d0 * rstd * g.x + bt.x, d1 * rstd * g.y + bt.y);
+}
+
 extern "C" int fx_layernorm_bf16(const void* x, int ldx, const void* residual, int ldr, const float* gamma, const float* beta, void* out,
                                  int ldo, int rows, int cols, fx_stream_t stream_) {
   FX_CHECK_ARG(x && gamma && beta && out && rows > 0);
-  if (cols != 256) return FX_ERR_UNSUPPORTED;
+  if (cols != 256 && cols != 128) return FX_ERR_UNSUPPORTED;
   FX_CHECK_ARG(ldx >= cols && ldo >= cols && ldx % 4 == 0 && ldo % 4 == 0 && (!residual || (ldr >= cols && ldr % 4 == 0)));
-  hipLaunchKernelGGL(layernorm256_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)x,
-                     ldx, (const bf16_t*)residual, ldr, gamma, beta, (bf16_t*)out, ldo, rows);
+  if (cols == 128)
+    hipLaunchKernelGGL(layernorm128_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)x,
+                       ldx, (const bf16_t*)residual, ldr, gamma, beta, (bf16_t*)out, ldo, rows);
+  else
+    hipLaunchKernelGGL(layernorm256_kernel, dim3((rows + 3) / 4), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)x,
+                       ldx, (const bf16_t*)residual, ldr, gamma, beta, (bf16_t*)out, ldo, rows);
   return fx_launch_status();
 }
 

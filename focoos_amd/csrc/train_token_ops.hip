@@ -120,43 +120,58 @@ extern "C" int fx_colsum_bf16(const void* x, int ldx, float* out, int64_t rows, 
 }
 
 // ------------------------------------------------------------------------------------------------ LayerNorm backward
-// y = (x - mu) * rstd * gamma + beta over 256 channels, one wave per row (4 channels per lane):
+// y = (x - mu) * rstd * gamma + beta over 256 (or 128) channels, one wave per row (4 or 2 channels per lane):
 //   g = dy * gamma;  dx = rstd * (g - mean(g) - xhat * mean(g * xhat));  dgamma += dy * xhat;  dbeta += dy.
-__global__ __launch_bounds__(256) void layernorm256_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
-                                                               const float* __restrict__ gamma, bf16_t* __restrict__ dx, int lddx,
-                                                               float* __restrict__ dgamma, float* __restrict__ dbeta, int rows) {
-  __shared__ float pg[4][256], pb[4][256];
+template <int CPL>   // channels per lane: 4 (256 columns) or 2 (128 columns: the narrow pixel-decoder encoders of fai-mf-{m,s}-coco-ins)
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
+                                                            const float* __restrict__ gamma, bf16_t* __restrict__ dx, int lddx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int rows) {
+  constexpr int COLS = 64 * CPL;
+  constexpr float INV = 1.0f / (float)COLS;
+  __shared__ float pg[4][COLS], pb[4][COLS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float ag[4] = {0, 0, 0, 0}, ab[4] = {0, 0, 0, 0};
-  const float4 gm = *reinterpret_cast<const float4*>(gamma + lane * 4);
-  const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
+  float ag[CPL], ab[CPL], gmv[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) ag[j] = 0.0f, ab[j] = 0.0f, gmv[j] = gamma[lane * CPL + j];
+  auto load = [&](const bf16_t* p, float* v) {   // CPL consecutive bf16 of this lane
+    if constexpr (CPL == 4) {
+      const uint2 w = *reinterpret_cast<const uint2*>(p);
+      v[0] = __uint_as_float(w.x << 16), v[1] = __uint_as_float(w.x & 0xffff0000u), v[2] = __uint_as_float(w.y << 16), v[3] = __uint_as_float(w.y & 0xffff0000u);
+    } else {
+      const unsigned w = *reinterpret_cast<const unsigned*>(p);
+      v[0] = __uint_as_float(w << 16), v[1] = __uint_as_float(w & 0xffff0000u);
+    }
+  };
   // a wave walks ~16 rows: the next row's loads are issued before this row's four wave reductions (the loop was one memory round
   // trip per row: 24 us for the decoder's 4800-row LayerNorms, 21 of them on the critical path of a training step)
   const int step = gridDim.x * 4;
   int row = blockIdx.x * 4 + wave;
-  uint2 xn = make_uint2(0, 0), dn = make_uint2(0, 0);
+  float xn[CPL], dn[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) xn[j] = dn[j] = 0.0f;
   if (row < rows) {
-    xn = *reinterpret_cast<const uint2*>(x + (int64_t)row * ldx + lane * 4);
-    dn = *reinterpret_cast<const uint2*>(dy + (int64_t)row * lddy + lane * 4);
+    load(x + (int64_t)row * ldx + lane * CPL, xn);
+    load(dy + (int64_t)row * lddy + lane * CPL, dn);
   }
   for (; row < rows; row += step) {
-    const uint2 xv = xn, dv = dn;
+    float v[CPL], d[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) v[j] = xn[j], d[j] = dn[j];
     if (row + step < rows) {
-      xn = *reinterpret_cast<const uint2*>(x + (int64_t)(row + step) * ldx + lane * 4);
-      dn = *reinterpret_cast<const uint2*>(dy + (int64_t)(row + step) * lddy + lane * 4);
+      load(x + (int64_t)(row + step) * ldx + lane * CPL, xn);
+      load(dy + (int64_t)(row + step) * lddy + lane * CPL, dn);
     }
-    const float v[4] = {__uint_as_float(xv.x << 16), __uint_as_float(xv.x & 0xffff0000u), __uint_as_float(xv.y << 16),
-                        __uint_as_float(xv.y & 0xffff0000u)};
-    const float d[4] = {__uint_as_float(dv.x << 16), __uint_as_float(dv.x & 0xffff0000u), __uint_as_float(dv.y << 16),
-                        __uint_as_float(dv.y & 0xffff0000u)};
-    const float mean = wsum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
-    float c[4], var = 0.0f;
+    float sum = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) c[j] = v[j] - mean, var += c[j] * c[j];
-    const float rstd = rsqrtf(wsum(var) * (1.0f / 256.0f) + 1e-5f);
-    float xh[4], g[4], sg = 0.0f, sgx = 0.0f;
+    for (int j = 0; j < CPL; ++j) sum += v[j];
+    const float mean = wsum(sum) * INV;
+    float c[CPL], var = 0.0f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < CPL; ++j) c[j] = v[j] - mean, var += c[j] * c[j];
+    const float rstd = rsqrtf(wsum(var) * INV + 1e-5f);
+    float xh[CPL], g[CPL], sg = 0.0f, sgx = 0.0f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
       xh[j] = c[j] * rstd;
       g[j] = d[j] * gmv[j];
       sg += g[j];
@@ -164,33 +179,43 @@ __global__ __launch_bounds__(256) void layernorm256_bwd_kernel(const bf16_t* __r
       ag[j] += d[j] * xh[j];
       ab[j] += d[j];
     }
-    sg = wsum(sg) * (1.0f / 256.0f);
-    sgx = wsum(sgx) * (1.0f / 256.0f);
-    uint2 o;
-    o.x = pack_bf16x2(rstd * (g[0] - sg - xh[0] * sgx), rstd * (g[1] - sg - xh[1] * sgx));
-    o.y = pack_bf16x2(rstd * (g[2] - sg - xh[2] * sgx), rstd * (g[3] - sg - xh[3] * sgx));
-    *reinterpret_cast<uint2*>(dx + (int64_t)row * lddx + lane * 4) = o;
+    sg = wsum(sg) * INV;
+    sgx = wsum(sgx) * INV;
+    if constexpr (CPL == 4) {
+      uint2 o;
+      o.x = pack_bf16x2(rstd * (g[0] - sg - xh[0] * sgx), rstd * (g[1] - sg - xh[1] * sgx));
+      o.y = pack_bf16x2(rstd * (g[2] - sg - xh[2] * sgx), rstd * (g[3] - sg - xh[3] * sgx));
+      *reinterpret_cast<uint2*>(dx + (int64_t)row * lddx + lane * 4) = o;
+    } else {
+      *reinterpret_cast<unsigned*>(dx + (int64_t)row * lddx + lane * 2) = pack_bf16x2(rstd * (g[0] - sg - xh[0] * sgx), rstd * (g[1] - sg - xh[1] * sgx));
+    }
   }
 #pragma unroll
-  for (int j = 0; j < 4; ++j) pg[wave][lane * 4 + j] = ag[j], pb[wave][lane * 4 + j] = ab[j];
+  for (int j = 0; j < CPL; ++j) pg[wave][lane * CPL + j] = ag[j], pb[wave][lane * CPL + j] = ab[j];
   __syncthreads();
   const int c = threadIdx.x;
-  if (dgamma) unsafeAtomicAdd(dgamma + c, pg[0][c] + pg[1][c] + pg[2][c] + pg[3][c]);
-  if (dbeta) unsafeAtomicAdd(dbeta + c, pb[0][c] + pb[1][c] + pb[2][c] + pb[3][c]);
+  if (c < COLS) {
+    if (dgamma) unsafeAtomicAdd(dgamma + c, pg[0][c] + pg[1][c] + pg[2][c] + pg[3][c]);
+    if (dbeta) unsafeAtomicAdd(dbeta + c, pb[0][c] + pb[1][c] + pb[2][c] + pb[3][c]);
+  }
 }
 
 extern "C" int fx_layernorm_bwd_bf16(const void* dy, int lddy, const void* x, int ldx, const float* gamma, void* dx, int lddx, float* dgamma,
                                      float* dbeta, int rows, int cols, fx_stream_t stream_) {
   FX_CHECK_ARG(dy && x && gamma && dx && rows > 0);
-  if (cols != 256) return FX_ERR_UNSUPPORTED;
+  if (cols != 256 && cols != 128) return FX_ERR_UNSUPPORTED;
   FX_CHECK_ARG(lddy >= cols && ldx >= cols && lddx >= cols && lddy % 4 == 0 && ldx % 4 == 0 && lddx % 4 == 0);
   // every workgroup ends with 512 fp32 atomics onto the same dgamma / dbeta addresses: ~64 rows per workgroup keep that tail short
   // (one workgroup per 4 rows made the 4800-row decoder LayerNorms 36 us each - 1024-deep contention per address)
   int grid = (rows + 63) / 64;
   if (grid < 64) grid = (rows + 3) / 4 < 64 ? (rows + 3) / 4 : 64;
   if (grid > 1024) grid = 1024;
-  hipLaunchKernelGGL(layernorm256_bwd_kernel, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)dy, lddy,
-                     (const bf16_t*)x, ldx, gamma, (bf16_t*)dx, lddx, dgamma, dbeta, rows);
+  if (cols == 128)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)dy, lddy,
+                       (const bf16_t*)x, ldx, gamma, (bf16_t*)dx, lddx, dgamma, dbeta, rows);
+  else
+    hipLaunchKernelGGL(layernorm_bwd_kernel<4>, dim3(grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)dy, lddy,
+                       (const bf16_t*)x, ldx, gamma, (bf16_t*)dx, lddx, dgamma, dbeta, rows);
   return fx_launch_status();
 }
 

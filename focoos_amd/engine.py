@@ -561,9 +561,10 @@ class _PlanBase:
 
     def layernorm(self, x: NT, name_ln: str, out_name: str, residual: Optional[NT] = None) -> NT:
         g, b = self.eng.ln[name_ln]
-        out = self._new(out_name, x.rows, 1, 1, 256)
+        cols = int(g.numel())     # 256, or 128 (the narrow pixel-decoder encoders of fai-mf-{m,s}-coco-ins)
+        out = self._new(out_name, x.rows, 1, 1, cols)
         self._op(self.lib.fx_layernorm_bf16, x.ptr, x.ld, residual.ptr if residual is not None else None,
-                 residual.ld if residual is not None else 0, g.data_ptr(), b.data_ptr(), out.ptr, out.ld, x.rows, 256)
+                 residual.ld if residual is not None else 0, g.data_ptr(), b.data_ptr(), out.ptr, out.ld, x.rows, cols)
         return out
 
     def add_rows(self, x: NT, y: NT, y_rows: int, out_name: str) -> NT:

@@ -43,8 +43,11 @@ class BfEngine(StdcEngineMixin, _EngineBase):
         self.nlev = min(2, self.nl)
         self.fd = int(config.get("pixel_decoder_feat_dim", 128))
         self.md = int(config.get("transformer_predictor_out_dim", 128))
-        if self.hd != 256 or self.md not in (128, 256) or int(config.get("pixel_decoder_out_dim", 128)) != self.md or self.fd % 32:
-            raise _lib.FocoosAmdError("engine kernels are specialised for hidden 256 / mask dim 128 or 256 / 8 heads (bisenetformer-l)")
+        if self.hd != 256 or self.md not in (96, 128, 256) or int(config.get("pixel_decoder_out_dim", 128)) != self.md or self.fd % 32:
+            raise _lib.FocoosAmdError("engine kernels are specialised for hidden 256 / mask dim 96, 128 or 256 / 8 heads (bisenetformer-*)")
+        # the mask einsum kernel (fx_query_pixel_logits_bf16) takes 128 or 256 channels: a 96-wide mask dimension (bisenetformer-m-ade) runs
+        # zero-padded to 128 - mask features and mask embeddings live in 128-wide buffers whose upper 32 channels are written once with zeros
+        self.md_eff = 128 if self.md < 128 else self.md
         if self.nq > 128 or self.nc + 1 > 256:
             raise _lib.FocoosAmdError("engine kernels cover num_queries <= 128 and num_classes <= 255")
         self.predict_all_pixels = bool(config.get("predict_all_pixels", False))
@@ -195,7 +198,13 @@ class _BfPlan(StdcPlanMixin, MaskDecoderPlanMixin, _PlanBase):
         a1 = self.pooled_linear(self.global_mean(feat, "ffm.mean"), e.vec["ffm.conv1.w"], None, 1, "ffm.a1")
         a2 = self.pooled_linear(a1, e.vec["ffm.conv2.w"], None, 4, "ffm.a2")
         fuse = self.gate(feat, a2, "ffm", self_add=True)
-        mf = self.conv(fuse, P[f"{pd}.conv_out"], name="mask_features", act="relu")
+        if e.md_eff == e.md:
+            mf = self.conv(fuse, P[f"{pd}.conv_out"], name="mask_features", act="relu")
+        else:
+            mf = self._new("mask_features.padded", B, fuse.H, fuse.W, e.md_eff)
+            mf.t.zero_()
+            self.conv(fuse, P[f"{pd}.conv_out"], out=mf.slice(0, e.md), act="relu")
+            self.bufs["mask_features"] = mf.slice(0, e.md)
         # ---- masked-attention decoder over (cp32, cp16), heads, outputs and post-process (engine_maskdec.py)
-        dn, emb = self.build_masked_decoder([cp32, cp16], mf, e.md)
-        self.build_mask_outputs(dn, emb, mf, e.md, self.full_masks, predict_all_pixels=e.predict_all_pixels)
+        dn, emb = self.build_masked_decoder([cp32, cp16], mf, e.md_eff)
+        self.build_mask_outputs(dn, emb, mf, e.md_eff, self.full_masks, predict_all_pixels=e.predict_all_pixels)

@@ -94,8 +94,8 @@ class MaskDecoderPlanMixin:
     """Launch-sequence builders for plans (subclasses of engine._PlanBase) whose engine has nq, nc, nl, nlev, P, ln, query_*."""
 
     def build_masked_decoder(self, msf: Sequence[NT], mf: NT, md: int):
-        """``msf``: the nlev memory levels (coarsest first), ``mf``: mask features [B,h,w,md].  Returns (decoder_norm output of
-        the last layer [B*Q,256], its mask embedding [B*Q,md])."""
+        """``msf``: the nlev memory levels (coarsest first), ``mf``: mask features [B,h,w,md] (md = 128 or 256: a narrower mask dimension
+        arrives zero-padded, see _BfPlan._build).  Returns (decoder_norm output of the last layer [B*Q,256], its mask embedding [B*Q,md])."""
         e, P, B, lib = self.eng, self.eng.P, self.B, self.lib
         Q = e.nq
         nlev = e.nlev
@@ -128,7 +128,13 @@ class MaskDecoderPlanMixin:
             dn = self.layernorm(x, f"{PH}.decoder_norm", f"ph{idx}.dn")
             m1 = self.linear(dn, P[f"{PH}.mask_classifier.0"], name=f"ph{idx}.m1", act="relu")
             m2 = self.linear(m1, P[f"{PH}.mask_classifier.1"], name=f"ph{idx}.m2", act="relu")
-            emb = self.linear(m2, P[f"{PH}.mask_classifier.2"], name=f"ph{idx}.emb")
+            pcm = P[f"{PH}.mask_classifier.2"]
+            if pcm.N == md:
+                emb = self.linear(m2, pcm, name=f"ph{idx}.emb")
+            else:   # mask dimension below the einsum kernel's 128 channels (bisenetformer-m-ade: 96): zero channels up to md, written once here
+                emb = self._new(f"ph{idx}.emb", R, 1, 1, md)
+                emb.t.zero_()
+                self.linear(m2, pcm, out=emb.slice(0, pcm.N))
             if level is not None:
                 bits = torch.zeros(R, W32[level], dtype=torch.int32, device=self.dev)
                 self._op(lib.fx_query_pixel_logits_bf16, emb.ptr, emb.ld, mfp[level].ptr, mfp[level].ld, 2, None, 0, bits.data_ptr(),

@@ -50,15 +50,15 @@ class MfEngine(StdcEngineMixin, _EngineBase):
         self.nl = int(config.get("transformer_predictor_dec_layers", 6))
         self.n_enc = int(config.get("pixel_decoder_transformer_layers", 0))
         self.nlev = min(3, self.nl)
-        # pixel-decoder width fd = mask-feature / mask-embedding width md: 256 (fai-mf-l-coco-ins) or 128 (fai-mf-l-ade); the decoder's
-        # hidden width is 256 in every registry model.  The pixel decoder's own transformer encoder runs at fd channels with 8 heads:
-        # only fd = 256 (head dim 32) has an attention kernel, so fd = 128 needs pixel_decoder_transformer_layers = 0 (fai-mf-l-ade).
+        # pixel-decoder width fd = mask-feature / mask-embedding width md: 256 (fai-mf-l-coco-ins) or 128 (fai-mf-{l,m}-ade,
+        # fai-mf-{m,s}-coco-ins); the decoder's hidden width is 256 in every registry model.  The pixel decoder's own transformer encoder
+        # runs at fd channels with 8 heads: head dim 32 at fd = 256; at fd = 128 (head dim 16) the heads are ZERO-PADDED to 32 channels
+        # in the packed projection weights (load_state_dict) and run on the same attention kernel.
         self.fd = int(config.get("pixel_decoder_feat_dim", 256))
         self.md = int(config.get("transformer_predictor_out_dim", 256))
         if (self.hd != 256 or self.fd not in (128, 256) or self.md != self.fd or int(config.get("pixel_decoder_out_dim", 256)) != self.fd
-                or int(config.get("pixel_decoder_transformer_nheads", 8)) != 8 or (self.n_enc > 0 and self.fd != 256)):
-            raise _lib.FocoosAmdError("engine kernels cover hidden 256 / 8 heads with pixel-decoder = mask width 256, or 128 without a "
-                                      "pixel-decoder transformer (fai-mf-l-coco-ins, fai-mf-l-ade)")
+                or int(config.get("pixel_decoder_transformer_nheads", 8)) != 8):
+            raise _lib.FocoosAmdError("engine kernels cover hidden 256 / 8 heads with pixel-decoder = mask width 256 or 128 (fai-mf-*)")
         if self.nq > 128 or self.nc + 1 > 256:
             raise _lib.FocoosAmdError("engine kernels cover num_queries <= 128 and num_classes <= 255")
         # post-processing: threshold branch (instance, fx_mf_postprocess) or per-pixel argmax (predict_all_pixels, fx_seg_postprocess)
@@ -87,6 +87,31 @@ class MfEngine(StdcEngineMixin, _EngineBase):
                 W, b = W[rows], b[rows]
             P[key] = self._pack_linear(W, b)
 
+        def attn_padded_heads(prefix, name):
+            """nn.MultiheadAttention at 128 channels / 8 heads (head dim 16) on the head-dim-32 attention kernel: every head's q / k / v get 16
+            zero channels (zero weight rows, zero bias) - scores and outputs are unchanged, the extra output channels are zero and meet
+            zero columns of out_proj.  The kernel scales by 1/sqrt(32); the reference by 1/sqrt(16): the q rows carry the sqrt(2)."""
+            Wi, bi = sd[f"{prefix}.{name}.in_proj_weight"].float(), sd[f"{prefix}.{name}.in_proj_bias"].float()
+            c = Wi.shape[1]
+
+            def pad_rows(W, b, scale=1.0):
+                Wp, bp = torch.zeros(256, c), torch.zeros(256)
+                for h in range(8):
+                    Wp[32 * h:32 * h + 16] = W[16 * h:16 * h + 16] * scale
+                    bp[32 * h:32 * h + 16] = b[16 * h:16 * h + 16] * scale
+                return Wp, bp
+
+            wq, bq = pad_rows(Wi[:c], bi[:c], math.sqrt(2.0))
+            wk, bk = pad_rows(Wi[c:2 * c], bi[c:2 * c])
+            wv, bv = pad_rows(Wi[2 * c:], bi[2 * c:])
+            P[f"{prefix}.qk"] = self._pack_linear(torch.cat([wq, wk], 0), torch.cat([bq, bk], 0))
+            P[f"{prefix}.v"] = self._pack_linear(wv, bv)
+            Wo, bo = sd[f"{prefix}.{name}.out_proj.weight"].float(), sd[f"{prefix}.{name}.out_proj.bias"].float()
+            Wop = torch.zeros(c, 256)
+            for h in range(8):
+                Wop[:, 32 * h:32 * h + 16] = Wo[:, 16 * h:16 * h + 16]
+            P[f"{prefix}.out_proj"] = self._pack_linear(Wop, bo)
+
         def attn(prefix, name, split_q: bool):
             Wi, bi = sd[f"{prefix}.{name}.in_proj_weight"], sd[f"{prefix}.{name}.in_proj_bias"]
             if split_q:
@@ -101,7 +126,10 @@ class MfEngine(StdcEngineMixin, _EngineBase):
             P[f"{pd}.input_proj"] = self._pack(sd[f"{pd}.input_proj.weight"].float(), sd[f"{pd}.input_proj.bias"].float())
             for li in range(self.n_enc):
                 p = f"{pd}.transformer.encoder.layers.{li}"
-                attn(p, "self_attn", False)
+                if self.fd == 256:
+                    attn(p, "self_attn", False)
+                else:
+                    attn_padded_heads(p, "self_attn")
                 lin(f"{p}.linear1", f"{p}.linear1")
                 lin(f"{p}.linear2", f"{p}.linear2")
                 self._pack_ln(sd, f"{p}.norm1")
@@ -173,8 +201,8 @@ class _MfPlan(StdcPlanMixin, MaskDecoderPlanMixin, _PlanBase):
         if e.n_enc > 0:
             src = self.conv(feats[5], P[f"{pd}.input_proj"], name="pd.proj5")
             L5 = h32 * w32
-            pos = e._pos_embed_sine_normalized(h32, w32, 128).to(device=self.dev, dtype=torch.bfloat16).contiguous()
-            self.pos5 = NT(pos, L5, 1, 1, 256, 256)
+            pos = e._pos_embed_sine_normalized(h32, w32, e.fd // 2).to(device=self.dev, dtype=torch.bfloat16).contiguous()
+            self.pos5 = NT(pos, L5, 1, 1, e.fd, e.fd)
             s = src.as_rows()
             for li in range(e.n_enc):
                 p = f"{pd}.transformer.encoder.layers.{li}"
@@ -189,7 +217,7 @@ class _MfPlan(StdcPlanMixin, MaskDecoderPlanMixin, _PlanBase):
                 f1 = self.linear(s2, P[f"{p}.linear1"], name=f"enc{li}.f1", act="relu")
                 s = self.linear(f1, P[f"{p}.linear2"], name=f"enc{li}.f2", residual=o)
             s = self.layernorm(s, f"{pd}.transformer.encoder.norm", "enc_tokens")
-            x5 = NT(s.t, B, h32, w32, 256, 256, s.off)
+            x5 = NT(s.t, B, h32, w32, e.fd, e.fd, s.off)
         y = self.conv(x5, P[f"{pd}.layer_4"], name="msf0", act="relu")
         msf = [y]
         for idx, f in ((3, feats[4]), (2, feats[3]), (1, feats[2])):

@@ -63,6 +63,9 @@ _MF_L_COCO_INS_CONFIG = {
     "transformer_predictor_dec_layers": 9, "transformer_predictor_dim_feedforward": 2048,
     "head_out_dim": 256, "cls_sigmoid": False, "postprocessing_type": "instance", "mask_threshold": 0.5,
     "predict_all_pixels": False, "use_mask_score": True, "threshold": 0.5, "top_k": 100,
+    "criterion_deep_supervision": True, "criterion_eos_coef": 0.1, "criterion_num_points": 12544,
+    "weight_dict_loss_dice": 5, "weight_dict_loss_mask": 5, "weight_dict_loss_ce": 2,
+    "matcher_cost_class": 2, "matcher_cost_mask": 5, "matcher_cost_dice": 5,
 }
 
 
@@ -86,6 +89,12 @@ _BF_L_ADE_CONFIG = {
 }
 
 
+# focoos/model_registry/bisenetformer-m-ade.json: STDC-2, 96-channel pixel decoder / mask dimension, 4 decoder layers, 512-wide FFN
+_BF_M_ADE_CONFIG = copy.deepcopy(_BF_L_ADE_CONFIG)
+_BF_M_ADE_CONFIG.update({"pixel_decoder_out_dim": 96, "pixel_decoder_feat_dim": 96, "transformer_predictor_out_dim": 96, "head_out_dim": 96,
+                         "transformer_predictor_dec_layers": 4, "transformer_predictor_dim_feedforward": 512})
+
+
 # focoos/model_registry/bisenetformer-s-ade.json: the same head on STDC-1 (two blocks per stage)
 _BF_S_ADE_CONFIG = copy.deepcopy(_BF_L_ADE_CONFIG)
 _BF_S_ADE_CONFIG["backbone_config"]["layers"] = [2, 2, 2]
@@ -101,6 +110,19 @@ _MF_L_ADE_CONFIG.update({
     "weight_dict_loss_dice": 5, "weight_dict_loss_mask": 5, "weight_dict_loss_ce": 2,
     "matcher_cost_class": 2, "matcher_cost_mask": 5, "matcher_cost_dice": 5,
 })
+
+# focoos/model_registry/fai-mf-{m,s}-coco-ins.json: R101-vd / R50-vd, 128-channel pixel decoder WITH a 3-layer transformer encoder (8 heads of 16
+# channels), 6 decoder layers, instance post-processing
+_MF_M_COCO_INS_CONFIG = copy.deepcopy(_MF_L_COCO_INS_CONFIG)
+_MF_M_COCO_INS_CONFIG.update({
+    "pixel_decoder_out_dim": 128, "pixel_decoder_feat_dim": 128, "pixel_decoder_transformer_layers": 3,
+    "transformer_predictor_out_dim": 128, "transformer_predictor_dec_layers": 6, "transformer_predictor_dim_feedforward": 1024, "head_out_dim": 128,
+    "criterion_deep_supervision": True, "criterion_eos_coef": 0.1, "criterion_num_points": 12544,
+    "weight_dict_loss_dice": 5, "weight_dict_loss_mask": 5, "weight_dict_loss_ce": 2,
+    "matcher_cost_class": 2, "matcher_cost_mask": 5, "matcher_cost_dice": 5,
+})
+_MF_S_COCO_INS_CONFIG = copy.deepcopy(_MF_M_COCO_INS_CONFIG)
+_MF_S_COCO_INS_CONFIG["backbone_config"] = dict(_MF_S_COCO_INS_CONFIG["backbone_config"], depth=50)
 
 # focoos/model_registry/fai-mf-m-ade.json: STDC-2 backbone (the BiSeNetFormer-L one), 128-channel FPN, 3 decoder layers with a 512-wide FFN
 _MF_M_ADE_CONFIG = copy.deepcopy(_MF_L_ADE_CONFIG)
@@ -131,8 +153,11 @@ def _mf_entry(name: str, cfg: Dict, description: str) -> Dict:
 
 _REGISTRY = {
     "bisenetformer-l-ade": _bf_entry("bisenetformer-l-ade", _BF_L_ADE_CONFIG, "BiSeNetFormer large (STDC-2), ADE20K semantic segmentation"),
+    "bisenetformer-m-ade": _bf_entry("bisenetformer-m-ade", _BF_M_ADE_CONFIG, "BiSeNetFormer medium (STDC-2, 96-channel pixel decoder), ADE20K semantic segmentation"),
     "bisenetformer-s-ade": _bf_entry("bisenetformer-s-ade", _BF_S_ADE_CONFIG, "BiSeNetFormer small (STDC-1), ADE20K semantic segmentation"),
     "fai-mf-l-coco-ins": _mf_entry("fai-mf-l-coco-ins", _MF_L_COCO_INS_CONFIG, "MaskFormer large (R101-vd), COCO instance segmentation"),
+    "fai-mf-m-coco-ins": _mf_entry("fai-mf-m-coco-ins", _MF_M_COCO_INS_CONFIG, "MaskFormer medium (R101-vd, 128-channel pixel decoder), COCO instance segmentation"),
+    "fai-mf-s-coco-ins": _mf_entry("fai-mf-s-coco-ins", _MF_S_COCO_INS_CONFIG, "MaskFormer small (R50-vd, 128-channel pixel decoder), COCO instance segmentation"),
     "fai-mf-l-ade": dict(_mf_entry("fai-mf-l-ade", _MF_L_ADE_CONFIG, "MaskFormer large (R101-vd), ADE20K semantic segmentation"), task="semseg"),
     "fai-mf-m-ade": dict(_mf_entry("fai-mf-m-ade", _MF_M_ADE_CONFIG, "MaskFormer medium (STDC-2), ADE20K semantic segmentation"), task="semseg"),
     "fai-detr-l-obj365": _entry("fai-detr-l-obj365", 365, "RT-DETR large (R50-vd), Objects365 head"),

@@ -443,6 +443,17 @@ class BiseNet(nn.Module):
 
 
 # ================================================================================================ masked-attention decoder
+def _einsum_operands(emb, feat):
+    """The mask einsum kernel takes 128 or 256 channels; a narrower mask dimension (bisenetformer-m-ade: 96) runs on zero-padded copies
+    of its two operands (glue: one pad of the mask embeddings and of the stride-8 mask features per prediction head)."""
+    Cc = emb.shape[-1]
+    if Cc in (128, 256):
+        return emb.contiguous(), feat.contiguous(), Cc
+    if Cc > 128:
+        raise _lib.FocoosAmdError(f"mask dimension {Cc}: the einsum kernel covers up to 128 (zero-padded) or exactly 256 channels")
+    return F.pad(emb, (0, 128 - Cc)).contiguous(), F.pad(feat, (0, 128 - Cc)).contiguous(), 128
+
+
 class _MaskEinsumFn(torch.autograd.Function):
     """masks[b, q, p] = sum_c embed[b, q, c] * feat[b, p, c] (einsum "bqc,bchw->bqhw", modelling.py:84) -> f32 [B, Q, h, w]:
     fx_query_pixel_logits_bf16 mode 0.  Backward: the f32 gradient planes (the criterion scatters into them) are transposed to
@@ -455,7 +466,8 @@ class _MaskEinsumFn(torch.autograd.Function):
         _, h, w, _ = feat.shape
         emb, feat = emb.contiguous(), feat.contiguous()
         out = torch.empty(B, Q, h, w, dtype=torch.float32, device=emb.device)
-        check(lib.fx_query_pixel_logits_bf16(emb.data_ptr(), Cc, feat.data_ptr(), Cc, 0, out.data_ptr(), h * w, None, 0, B, Q, h * w, Cc, _stream(emb.device)),
+        ep, fp, cp = _einsum_operands(emb, feat)
+        check(lib.fx_query_pixel_logits_bf16(ep.data_ptr(), cp, fp.data_ptr(), cp, 0, out.data_ptr(), h * w, None, 0, B, Q, h * w, cp, _stream(emb.device)),
               "fx_query_pixel_logits_bf16")
         ctx.lib = lib
         ctx.save_for_backward(emb, feat)
@@ -551,8 +563,8 @@ class PredictionHeads(nn.Module):
             L = mf_level.shape[1] * mf_level.shape[2]
             words = (L + 31) // 32
             bits = torch.zeros(B * Q, words, dtype=torch.int32, device=emb.device)
-            e = emb.detach().contiguous()
-            check(lib.fx_query_pixel_logits_bf16(e.data_ptr(), Cc, mf_level.data_ptr(), Cc, 2, None, 0, bits.data_ptr(), words, B, Q, L, Cc, _stream(e.device)),
+            e, ml, cp = _einsum_operands(emb.detach(), mf_level)
+            check(lib.fx_query_pixel_logits_bf16(e.data_ptr(), cp, ml.data_ptr(), cp, 2, None, 0, bits.data_ptr(), words, B, Q, L, cp, _stream(e.device)),
                   "fx_query_pixel_logits_bf16")
         return cls, masks, bits
 

@@ -179,9 +179,9 @@ class TransformerFPN(nn.Module):
         fd = int(config.get("pixel_decoder_feat_dim", 256))
         od = int(config.get("pixel_decoder_out_dim", 256))
         n_enc = int(config.get("pixel_decoder_transformer_layers", 0))
-        if fd != 256 and n_enc > 0:
-            raise _lib.FocoosAmdError("the pixel decoder's transformer encoder needs pixel_decoder_feat_dim 256 (LayerNorm / attention kernels, head dim 32); "
-                                      "narrower pixel decoders are covered without it (fai-mf-l-ade: pixel_decoder_transformer_layers = 0)")
+        if fd not in (128, 256):
+            raise _lib.FocoosAmdError("pixel_decoder_feat_dim 256, or 128 (fai-mf-{l,m}-ade; fai-mf-{m,s}-coco-ins: the encoder's 8 heads of 16 channels run "
+                                      "zero-padded on the head-dim-32 attention kernels, train_nn.MultiheadAttention)")
         if int(config.get("pixel_decoder_transformer_nheads", 8)) != 8:
             raise _lib.FocoosAmdError("attention kernels: 8 heads of 32 channels")
         self.fd, self.n_enc = fd, n_enc

@@ -17,6 +17,7 @@ order; every FLOP and every byte moved inside a node is a HIP kernel of this rep
 from __future__ import annotations
 
 import ctypes as C
+import math
 import weakref
 import os
 from typing import Dict, List, Optional
@@ -1184,9 +1185,9 @@ class Linear(nn.Module):
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, lib):
-        R = _rows(x)
+        R, c = _rows(x), x.shape[-1]     # c = 256, or 128 (the narrow pixel-decoder encoders of fai-mf-{m,s}-coco-ins)
         y = torch.empty_like(x)
-        check(lib.fx_layernorm_bf16(x.data_ptr(), 256, None, 0, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), 256, R, 256, _stream(x.device)),
+        check(lib.fx_layernorm_bf16(x.data_ptr(), c, None, 0, gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), c, R, c, _stream(x.device)),
               "fx_layernorm_bf16")
         ctx.lib = lib
         ctx.gparam, ctx.bparam = gamma, beta
@@ -1200,17 +1201,18 @@ class _LayerNormFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         direct = DIRECT_GRAD[0] and ctx.gparam.grad is not None and ctx.bparam.grad is not None
-        dg = ctx.gparam.grad if direct else ARENA.zeros((256,), x.device)
-        db = ctx.bparam.grad if direct else ARENA.zeros((256,), x.device)
-        check(lib.fx_layernorm_bwd_bf16(dy.data_ptr(), 256, x.data_ptr(), 256, gamma.data_ptr(), dx.data_ptr(), 256, dg.data_ptr(), db.data_ptr(),
-                                        _rows(x), 256, _stream(x.device)), "fx_layernorm_bwd_bf16")
+        c = x.shape[-1]
+        dg = ctx.gparam.grad if direct else ARENA.zeros((c,), x.device)
+        db = ctx.bparam.grad if direct else ARENA.zeros((c,), x.device)
+        check(lib.fx_layernorm_bwd_bf16(dy.data_ptr(), c, x.data_ptr(), c, gamma.data_ptr(), dx.data_ptr(), c, dg.data_ptr(), db.data_ptr(),
+                                        _rows(x), c, _stream(x.device)), "fx_layernorm_bwd_bf16")
         return dx, (None if direct else dg), (None if direct else db), None
 
 
 class LayerNorm(nn.Module):
     def __init__(self, lib, c=256):
         super().__init__()
-        assert c == 256
+        assert c in (128, 256)
         self.lib = lib
         self.weight = nn.Parameter(torch.ones(c))
         self.bias = nn.Parameter(torch.zeros(c))
@@ -1259,8 +1261,8 @@ class _MHACoreFn(torch.autograd.Function):
 
 
 class MultiheadAttention(nn.Module):
-    """nn.MultiheadAttention(256, 8, batch_first=True) with the reference's parameter names (in_proj_weight, in_proj_bias,
-    out_proj.weight/bias); q = k inputs share one projection GEMM."""
+    """nn.MultiheadAttention(c, 8, batch_first=True), c = 256 (or 128, see forward) with the reference's parameter names (in_proj_weight,
+    in_proj_bias, out_proj.weight/bias); q = k inputs share one projection GEMM."""
 
     def __init__(self, lib, c=256):
         super().__init__()
@@ -1279,7 +1281,20 @@ class MultiheadAttention(nn.Module):
             q = _LinearFn.apply(q_in, W, b, None, self._pq, lib, 0, c, None)
             k = _LinearFn.apply(k_in, W, b, None, self._pk, lib, c, 2 * c, None)
         v = _LinearFn.apply(v_in, W, b, None, self._pv, lib, 2 * c, 3 * c, None)
-        o = _MHACoreFn.apply(q, k, v, lib, mask_bits)
+        if c == 128:
+            # 8 heads of 16 channels on the head-dim-32 attention kernels: every head zero-padded to 32 channels (scores and outputs
+            # unchanged), sqrt(2) on q because the kernels scale by 1/sqrt(32) where the reference scales by 1/sqrt(16).  Glue on
+            # [B, L, 256] tensors at the stride-32 level (<= 1024 tokens per image).
+            def pad(t, scale=None):
+                t = t.reshape(*t.shape[:-1], 8, 16)
+                if scale is not None:
+                    t = t * scale
+                return torch.nn.functional.pad(t, (0, 16)).reshape(*t.shape[:-2], 256)
+
+            o = _MHACoreFn.apply(pad(q, math.sqrt(2.0)), pad(k), pad(v), lib, mask_bits)
+            o = o.reshape(*o.shape[:-1], 8, 32)[..., :16].reshape(*o.shape[:-1], 128)
+        else:
+            o = _MHACoreFn.apply(q, k, v, lib, mask_bits)
         return self.out_proj(o, residual=residual)
 
 

@@ -155,7 +155,7 @@ int fx_resize_bilinear_nhwc_bf16(const void* x, int ldx, void* y, int ldy, int B
 int fx_add_rows_bf16(const void* x, int ldx, const void* y, int ldy_, int y_rows, void* out, int ldo, int rows, int cols,
                      fx_stream_t stream);
 
-/* out = LayerNorm(x + residual) * gamma + beta, eps 1e-5, cols == 256 (nn.LayerNorm uses:
+/* out = LayerNorm(x + residual) * gamma + beta, eps 1e-5, cols == 256 or 128 (nn.LayerNorm uses:
  * modelling.py:940,951,956,1089; transformer.py:592,600).  residual may be NULL. */
 int fx_layernorm_bf16(const void* x, int ldx, const void* residual, int ldr, const float* gamma, const float* beta, void* out,
                       int ldo, int rows, int cols, fx_stream_t stream);

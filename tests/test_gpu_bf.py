@@ -366,12 +366,15 @@ def test_bf_full_size_batch_properties(setup):
         assert sorted(dq[b, :n].cpu().tolist()) == dq[b, :n].cpu().tolist()
 
 
-def test_bf_small_variant_stage_parity():
-    """bisenetformer-s-ade (STDC-1, layers [2, 2, 2]; focoos/model_registry/bisenetformer-s-ade.json) through the same engine: stage and
-    output parity against the oracle (pinned live to the reference built from that registry file: tests/test_oracle_vs_reference.py),
-    attention masks teacher-forced to the oracle's, plus the training graph's state-dict keys."""
-    cfg = ModelRegistry.get_model_info("bisenetformer-s-ade")["config"]
-    assert cfg["backbone_config"]["layers"] == [2, 2, 2]
+@pytest.mark.parametrize("variant", ["bisenetformer-s-ade", "bisenetformer-m-ade"])
+def test_bf_small_variant_stage_parity(variant):
+    """bisenetformer-s-ade (STDC-1, layers [2, 2, 2]; focoos/model_registry/bisenetformer-s-ade.json) and bisenetformer-m-ade (96-channel
+    pixel decoder and mask dimension - the mask einsum runs zero-padded to its kernel's 128 channels -, four decoder layers, 512-wide FFN)
+    through the same engine: stage and output parity against the oracle (pinned live to the reference built from that registry file:
+    tests/test_oracle_vs_reference.py), attention masks teacher-forced to the oracle's, plus the training graph's state-dict keys."""
+    cfg = ModelRegistry.get_model_info(variant)["config"]
+    assert cfg["backbone_config"]["layers"] == ([2, 2, 2] if variant.endswith("-s-ade") else [4, 5, 3])
+    nl = int(cfg["transformer_predictor_dec_layers"])
     sd = synth_state_dict(cfg, 11, family="bisenetformer")
     eng = BfEngine(cfg, sd, device=DEV, full_masks=False)
     images = [synth_image_structured(40 + i, 192, 256) for i in range(2)]
@@ -382,7 +385,7 @@ def test_bf_small_variant_stage_parity():
     torch.cuda.synchronize()
     for name in ("res2", "res3", "res4", "res5", "cp32", "cp16", "cp8", "ffm", "mask_features"):
         assert rel_l2(nchw(pl.bufs[name]), col[name]) <= 2.5e-2, name
-    for i in range(6):
+    for i in range(nl):
         assert rel_l2(pl.bufs[f"dec{i}.out"].torch_view().float().cpu().reshape(2, -1, 256), col[f"dec{i}_out"]) <= 3e-2, i
     assert (pl.probs.cpu() - probs_o).abs().max() <= 3e-2
     assert (pl.mask_probs.cpu() - masks_o).abs().mean() <= 1e-2

@@ -456,3 +456,57 @@ def test_mf_ade_variant_stage_parity_and_semantic_postprocess(variant):
     net = FAIMaskFormerTrainable(cfg, norm="FrozenBN").to(DEV)
     assert sorted(net.state_dict().keys()) == sorted(sd.keys())
     net.load_state_dict(sd, strict=True)
+
+
+@pytest.mark.parametrize("variant", ["fai-mf-m-coco-ins", "fai-mf-s-coco-ins"])
+def test_mf_narrow_encoder_variants(variant):
+    """fai-mf-{m,s}-coco-ins (R101-vd / R50-vd; focoos/model_registry/*.json): the pixel decoder's three-layer transformer encoder runs at 128
+    channels with 8 heads of SIXTEEN channels - on the head-dim-32 attention kernel through zero-padded heads in the packed projection
+    weights (MfEngine.load_state_dict: scores and outputs unchanged, sqrt(2) folded into the q rows), LayerNorm over 128 columns; six decoder
+    layers, 128-wide mask embedding, instance post-processing.  Stage / decoder / output parity against the oracle (pinned live to the
+    reference built from the registry file), attention masks teacher-forced; the training graph's state-dict keys."""
+    cfg = ModelRegistry.get_model_info(variant)["config"]
+    assert cfg["pixel_decoder_feat_dim"] == 128 and cfg["pixel_decoder_transformer_layers"] == 3
+    sd = synth_state_dict(cfg, 5, family="fai_mf")
+    eng = MfEngine(cfg, sd, device=DEV, full_masks=False)
+    assert eng.fd == 128 and eng.n_enc == 3
+    h, w = 192, 256
+    images = [synth_image_structured(20 + i, h, w) for i in range(2)]
+    col = {}
+    with torch.no_grad():
+        probs_o, masks_o = M.mf_forward(sd, cfg, get_torch_batch(images, None), collect=col, upsample=False)
+    pl = eng.forward(torch.from_numpy(np.stack(images)).to(DEV), forced_attn=col["attn_masks"])
+    torch.cuda.synchronize()
+    B, L, Cc = col["enc_tokens"].shape
+    assert Cc == 128
+    assert rel_l2(pl.bufs["enc_tokens"].torch_view().float().cpu().reshape(B, L, Cc), col["enc_tokens"]) <= 2.5e-2
+    for name in ("res2", "res5", "msf0", "msf1", "msf2", "fpn_s4", "mask_features"):
+        assert rel_l2(nchw(pl.bufs[name]), col[name]) <= 2.5e-2, name
+    # decoder / outputs: the absolute gates of the 256-channel model, or 2.5x this configuration's bf16-weights-only sensitivity
+    sdb = {k: (v.bfloat16().float() if v.dtype == torch.float32 and v.dim() >= 2 else v) for k, v in sd.items()}
+    colb = {}
+    with torch.no_grad():
+        probs_w, masks_w = M.mf_forward(sdb, cfg, get_torch_batch(images, None), forced_attn=col["attn_masks"], collect=colb, upsample=False)
+    for i in range(6):
+        e_w = rel_l2(colb[f"dec{i}_out"], col[f"dec{i}_out"])
+        e = rel_l2(pl.bufs[f"dec{i}.out"].torch_view().float().cpu().reshape(2, -1, 256), col[f"dec{i}_out"])
+        assert e <= max(3e-2, 2.5 * e_w), (i, e, e_w)
+    dp, dp_w = float((pl.probs.cpu() - probs_o).abs().max()), float((probs_w - probs_o).abs().max())
+    dm, dm_w = float((pl.mask_probs.cpu() - masks_o).abs().mean()), float((masks_w - masks_o).abs().mean())
+    ag = float(((pl.mask_probs.cpu() >= 0.5) == (masks_o >= 0.5)).float().mean())
+    ag_w = float(((masks_w >= 0.5) == (masks_o >= 0.5)).float().mean())
+    print(f"{variant}: engine dprob {dp:.3f} mean|dmask| {dm:.4f} agreement {ag:.4f}; bf16-weights-only oracle: {dp_w:.3f} {dm_w:.4f} {ag_w:.4f}")
+    assert dp <= max(3e-2, 2.5 * dp_w) and dm <= max(1e-2, 2.5 * dm_w) and ag >= min(0.99, 1.0 - 2.5 * (1.0 - ag_w))
+    up = torch.nn.functional.interpolate(pl.mask_probs.cpu(), size=(h, w), mode="bilinear", align_corners=False)
+    for b in range(2):
+        s, l, q, boxes, bm = M.postprocess(pl.probs[b:b + 1].cpu(), up[b:b + 1], [(h, w)], cfg["mask_threshold"], cfg["threshold"], cfg["use_mask_score"])[0]
+        n = int(pl.det_count[b])
+        assert abs(n - len(s)) <= 1
+        if n == len(s) and n > 0:
+            assert pl.det_labels[b, :n].cpu().tolist() == l.tolist()
+            np.testing.assert_allclose(pl.det_scores[b, :n].cpu().numpy(), s.numpy(), atol=2e-4)
+    from focoos_amd.train_mf import FAIMaskFormerTrainable
+
+    net = FAIMaskFormerTrainable(cfg, norm="FrozenBN").to(DEV)       # losses / gradients: tests/test_gpu_train_mf.py (fai-mf-s-coco-ins)
+    assert sorted(net.state_dict().keys()) == sorted(sd.keys())
+    net.load_state_dict(sd, strict=True)

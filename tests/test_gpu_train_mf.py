@@ -27,10 +27,11 @@ def _cfg(depth, num_points=2048):
 
 
 @pytest.mark.parametrize("norm,variant,size", [("FrozenBN", "r50", (192, 256)), ("BN", "r50", (192, 256)), ("FrozenBN", "fai-mf-m-ade", (192, 256)),
-                                               ("FrozenBN", "r50", (150, 200))])
+                                               ("FrozenBN", "r50", (150, 200)), ("FrozenBN", "fai-mf-s-coco-ins", (192, 256))])
 def test_mf_train_step_losses_and_gradients(norm, variant, size):
     """size (150, 200): not a multiple of 32 (ceil-size forward and adjoints: partial AvgPool2d(2,2,ceil_mode) windows, nearest up-sampling with
-    non-integer ratios, 5 x 7 encoder tokens)."""
+    non-integer ratios, 5 x 7 encoder tokens).  fai-mf-s-coco-ins: the 128-channel pixel decoder WITH its three-layer transformer encoder
+    (8 heads of 16 channels zero-padded onto the head-dim-32 attention kernels, LayerNorm over 128 columns) and six decoder layers."""
     from focoos_amd.train_mf import FAIMaskFormerTrainable
 
     if variant == "r50":
@@ -42,7 +43,7 @@ def test_mf_train_step_losses_and_gradients(norm, variant, size):
     for k in sd:     # keep the six pre-norm encoder layers' attention logits O(1) (see tests/test_gpu_train_conv.py on AIFI)
         if ".transformer.encoder.layers." in k and k.endswith("self_attn.in_proj_weight"):
             sd[k] = sd[k].clone()
-            sd[k][:512] *= 0.05
+            sd[k][: 2 * sd[k].shape[1]] *= 0.05      # the q and k rows (512 at 256 channels, 256 at the 128 channels of fai-mf-{m,s}-coco-ins)
     if variant != "r50":   # no pixel-decoder encoder (and no LayerNorm) in front of the decoder: keep ITS attention logits O(1) as well
         for k in sd:
             if k.startswith("head.predictor.") and k.endswith("in_proj_weight"):

@@ -90,12 +90,13 @@ def test_mf_oracle_matches_reference_live():
     assert [list(d.bbox) for d in dets] == boxes.tolist()
 
 
-@pytest.mark.parametrize("name", ["fai-mf-l-ade", "fai-mf-m-ade"])
+@pytest.mark.parametrize("name", ["fai-mf-l-ade", "fai-mf-m-ade", "fai-mf-m-coco-ins", "fai-mf-s-coco-ins", "fai-mf-l-coco-ins"])
 def test_mf_ade_variant_oracle_matches_reference_live(name):
     """fai-mf-l-ade (focoos/model_registry/fai-mf-l-ade.json: R101-vd, 128-channel FPN without a transformer encoder, 6 decoder layers,
     semantic post-processing with predict_all_pixels) and fai-mf-m-ade (fai-mf-m-ade.json: the same head, 3 decoder layers with a 512-wide
     FFN, on the STDC-2 backbone): registry config = the reference's file, state-dict keys = the reference model's, forward and the
-    per-pixel-argmax post-process of the restatement vs the real reference."""
+    per-pixel-argmax post-process of the restatement vs the real reference.  fai-mf-{m,s}-coco-ins (R101-vd / R50-vd, 128-channel pixel
+    decoder WITH a three-layer transformer encoder of 8 heads x 16 channels, instance post-processing) through the same check."""
     import json
     import os
 
@@ -123,7 +124,7 @@ def test_mf_ade_variant_oracle_matches_reference_live(name):
     assert (masks - out.masks).abs().max().item() < 5e-3
     dets = proc.postprocess(out, imgs)[0].detections
     s, l, q, boxes, bm = M.postprocess(out.logits, out.masks, [(96, 128)], cfg["mask_threshold"], cfg["threshold"], cfg["use_mask_score"],
-                                       predict_all_pixels=True)[0]
+                                       predict_all_pixels=bool(cfg["predict_all_pixels"]))[0]
     assert len(dets) == len(s) and len(s) >= 1
     np.testing.assert_allclose([d.conf for d in dets], s.numpy(), atol=1e-6)
     assert [d.cls_id for d in dets] == l.tolist()
@@ -175,9 +176,11 @@ def test_bf_oracle_matches_reference_live():
     _bf_forward_vs_reference("bisenetformer-l-ade")
 
 
-def test_bf_small_variant_forward_matches_reference():
-    """bisenetformer-s-ade (STDC-1: two blocks per stage): the same restatement against the reference built from ITS registry file."""
-    _bf_forward_vs_reference("bisenetformer-s-ade")
+@pytest.mark.parametrize("name", ["bisenetformer-s-ade", "bisenetformer-m-ade"])
+def test_bf_small_variant_forward_matches_reference(name):
+    """bisenetformer-s-ade (STDC-1: two blocks per stage) and bisenetformer-m-ade (96-channel pixel decoder / mask dimension, four decoder
+    layers): the same restatement against the reference built from ITS registry file."""
+    _bf_forward_vs_reference(name)
 
 
 def _bf_forward_vs_reference(name):
