@@ -139,3 +139,43 @@ def test_detr_m_train_step_losses_and_gradients():
     assert errs[len(errs) // 2][0] <= 0.08
     bad = [(round(e, 4), round(sens.get(n, 0.0), 4), n) for e, n in errs if e > max(0.25, 3.0 * sens.get(n, 0.0))]
     assert not bad, bad
+
+
+@pytest.mark.parametrize("counts", [(0, 0), (0, 3)])
+def test_detr_train_step_with_empty_targets(counts):
+    """Images without a single ground-truth box - a whole batch of them, or one of two (the reference: SetCriterion.forward clamps num_boxes to
+    1, the matcher returns empty index pairs, the box losses sum over nothing; fai_detr/modelling.py:553-612, 693-758): losses against the
+    fp32 training oracle, free-running matcher (nothing to match on an empty image), finite gradients everywhere."""
+    from focoos_amd.train_detr import FAIDetrTrainable
+
+    cfg = ModelRegistry.get_model_info(NAME)["config"]
+    sd = synth_state_dict(cfg, 33)
+    imgs = [synth_image_structured(90 + i, 128, 160) for i in range(2)]
+    g = torch.Generator().manual_seed(4)
+    labels = [torch.randint(0, 80, (n,), generator=g) for n in counts]
+    boxes = [torch.cat([torch.rand(n, 2, generator=g) * 0.5 + 0.25, torch.rand(n, 2, generator=g) * 0.3 + 0.1], 1) for n in counts]
+    x = O.get_torch_batch(imgs, None)
+    with torch.no_grad():
+        outs = T.detr_train_outputs(sd, cfg, x)
+        losses_o, matches = T.criterion(outs, labels, boxes)
+    model = FAIDetrTrainable(cfg, norm="FrozenBN").to(DEV)
+    model.load_state_dict(sd, strict=True)
+    targets = [DETRTargets(labels=l.to(DEV), boxes=b.to(DEV)) for l, b in zip(labels, boxes)]
+    fixed = None
+    if sum(counts) > 0:     # force the oracle's matches where there is something to match (bf16 cost ties aside, they agree anyway)
+        fixed = []
+        for m in matches:
+            pi = torch.tensor(np.concatenate([np.asarray(i, dtype=np.int64) for i, _ in m]), dtype=torch.int32, device=DEV)
+            ti = torch.tensor(np.concatenate([np.asarray(j, dtype=np.int64) for _, j in m]), dtype=torch.int32, device=DEV)
+            fixed.append((pi, ti))
+    losses = model(torch.from_numpy(np.stack(imgs)).to(DEV), targets, forced_topk=outs["topk_ind"].to(DEV), fixed_matches=fixed)
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    assert sorted(losses) == sorted(losses_o)
+    for k in losses_o:
+        a, b = float(losses[k]), float(losses_o[k])
+        assert np.isfinite(a) and abs(a - b) <= 3e-2 * abs(b) + 1e-3, (k, a, b)
+        if sum(counts) == 0 and ("bbox" in k or "giou" in k):
+            assert a == 0.0, (k, a)
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.requires_grad and p.grad is not None)
+    assert sum(p.grad is not None for p in model.parameters() if p.requires_grad) > 150

@@ -190,3 +190,45 @@ def test_bf_train_step_free_running_and_optimizer():
     dead = [n for n, _ in ts.named if float(ts.opt.grads[n].abs().max()) == 0.0]   # the flat gradient views still hold step 2's gradients
     assert not dead, dead[:10]
     assert int(model.state_dict()["pixel_decoder.backbone.features.0.bn.num_batches_tracked"]) == 2
+
+
+@pytest.mark.parametrize("counts", [(0, 0), (0, 4)])
+def test_mask_train_step_with_empty_targets(counts):
+    """Images without a single ground-truth mask - both images, or one of two (mask SetCriterion: num_masks clamped to 1, empty matches, the
+    mask / dice losses sum over nothing; bisenetformer/loss.py = fai_mf/loss.py:345-607, 661-723): losses of the BiSeNetFormer training
+    graph against the fp32 training oracle (attention masks and point draws teacher-forced), finite gradients everywhere."""
+    from focoos_amd.train_bf import BisenetFormerTrainable
+
+    cfg = _cfg(variant="bisenetformer-m-ade")
+    sd = synth_state_dict(cfg, 35, family="bisenetformer")
+    ih, iw = 128, 160
+    imgs = [synth_image_structured(70 + i, ih, iw) for i in range(2)]
+    labels, masks = T.synth_mask_targets(9, 2, int(cfg["num_classes"]), (ih, iw), counts=counts)
+    x = O.get_torch_batch(imgs, None)
+    col = {}
+    with torch.no_grad():
+        outs = T.bf_train_outputs(sd, cfg, x, collect=col)
+        rs = _DrawAndRecord(79)
+        losses_o, matches = T.bf_criterion(outs, labels, masks, rs, cfg)
+    # (the reference's torch.rand of a (0, n, 2) tensor for a set without masks draws nothing from the generator; the engine skips the call)
+    model = BisenetFormerTrainable(cfg, norm="FrozenBN", rand=_Replay([t for t in rs.rec if t.numel() > 0])).to(DEV)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    targets = [MaskFormerTargets(labels=l.to(DEV), masks=m.to(DEV)) for l, m in zip(labels, masks)]
+    fixed = None
+    if sum(counts) > 0:
+        fixed = []
+        for m in matches:
+            pi = torch.tensor(np.concatenate([np.asarray(i, dtype=np.int64) for i, _ in m]), dtype=torch.int32, device=DEV)
+            ti = torch.tensor(np.concatenate([np.asarray(j, dtype=np.int64) for _, j in m]), dtype=torch.int32, device=DEV)
+            fixed.append((pi, ti))
+    losses = model(torch.from_numpy(np.stack(imgs)).to(DEV), targets, forced_attn=col["attn_masks"], fixed_matches=fixed)
+    sum(losses.values()).backward()
+    torch.cuda.synchronize()
+    assert sorted(losses) == sorted(losses_o)
+    for k in losses_o:
+        a, b = float(losses[k]), float(losses_o[k])
+        assert np.isfinite(a) and abs(a - b) <= 3e-2 * abs(b) + 1e-3, (k, a, b)
+        if sum(counts) == 0 and ("mask" in k or "dice" in k):
+            assert a == 0.0, (k, a)
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.requires_grad and p.grad is not None)
