@@ -91,7 +91,7 @@ def test_bf_train_step_losses_and_gradients(norm, size, variant):
     losses_o, matches = T.bf_criterion(outs, labels, masks, rs, cfg)
     sum(losses_o.values()).backward()
     sens = None
-    if variant != "bisenetformer-l-ade":
+    if variant != "bisenetformer-l-ade" or size != (192, 256):   # (the odd-size case measured 0.248 against the absolute 0.25: gate it per tensor too)
         # this configuration's own conditioning: the fp32 oracle again with nothing but the weights rounded to bf16 (same attention masks,
         # matches and draws); each tensor is then gated against ITS sensitivity as well as the absolute gate (tests/test_gpu_detr_variants.py)
         from oracle.mask_criterion_oracle import RandStream
