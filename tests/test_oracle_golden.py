@@ -90,3 +90,45 @@ def test_msda_core_golden():
     value, loc, w = (torch.from_numpy(a) for a in msda_case_inputs())
     out = O.ms_deform_attn_core(value, MSDA_SHAPES, loc, w)
     np.testing.assert_allclose(out.numpy(), g["out"], atol=1e-5)
+
+
+REGISTRY_VARIANTS = ["fai-detr-m-coco", "fai-mf-m-coco-ins", "fai-mf-s-coco-ins", "fai-mf-l-ade", "fai-mf-m-ade", "bisenetformer-m-ade", "bisenetformer-s-ade"]
+
+
+@pytest.mark.parametrize("name", REGISTRY_VARIANTS)
+def test_oracle_reproduces_registry_variant_golden(name):
+    """tests/golden/registry_variants.npz (scripts/make_golden.py::variants_case: the REAL reference on the round-4 registry variants): the
+    restatements, teacher-forced with the reference's top-k / attention masks, reproduce its class probabilities, boxes and mask logits
+    to the fixture's fp16 storage - the link that lets the GPU box (no /root/reference there) trust the oracle on these models."""
+    g = load_golden("registry_variants.npz")
+    key = name.replace("-", "_")
+    h, w = (int(v) for v in g["hw"])
+    images = [synth_image_structured(40 + i, h, w) for i in range(2)]
+    info = ModelRegistry.get_model_info(name)
+    cfg, fam = info["config"], info["model_family"]
+    sd = synth_state_dict(cfg, int(g["seed"]), family=fam)
+    torch.set_num_threads(8)
+    if fam == "fai_detr":
+        x = O.get_torch_batch([np.ascontiguousarray(im[:h, :h]) for im in images], None)
+        with torch.no_grad():
+            probs, boxes = O.detr_forward(sd, dict(cfg, resolution=h), x, forced_topk=torch.from_numpy(g[f"{key}.enc_topk"]).long())
+        np.testing.assert_allclose(probs.numpy(), g[f"{key}.probs"].astype(np.float32), atol=1e-3)
+        np.testing.assert_allclose(boxes.numpy(), g[f"{key}.boxes"], atol=1e-4)
+        return
+    n = int(g[f"{key}.n_masks"])
+    forced = [torch.from_numpy(np.unpackbits(g[f"{key}.attn_mask{i}"], axis=-1)[..., : int(g[f"{key}.attn_mask{i}_len"])].astype(bool)) for i in range(n)]
+    x = O.get_torch_batch(images, None)
+    col = {}
+    with torch.no_grad():
+        if fam == "fai_mf":
+            from oracle import mf_oracle as M
+
+            probs, _ = M.mf_forward(sd, cfg, x, forced_attn=forced, collect=col, upsample=False)
+        else:
+            from oracle import bf_oracle as BF
+
+            probs, _ = BF.bf_forward(sd, cfg, x, forced_attn=forced, collect=col, upsample=False)
+    np.testing.assert_allclose(probs.numpy(), g[f"{key}.probs"].astype(np.float32), atol=1e-3)
+    ml = col["mask_logits"][..., ::2, ::2].numpy()
+    ref = g[f"{key}.mask_logits"].astype(np.float32)
+    assert np.abs(ml - ref).max() <= 2e-3 * max(1.0, np.abs(ref).max())       # fp16 storage of the fixture
