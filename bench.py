@@ -286,14 +286,14 @@ def _wgrad_roofline(nn_, stepper, imgs, targets, family="fai_detr"):
     try:
         if family == "fai_detr":
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_train_hbm_latest.json")))
-            hits = [v for k, v in pmc.items() if k.startswith("conv_wgrad_kernel")]   # the pointwise and the im2col instantiation
+            hits = [v for k, v in pmc.items() if k.startswith(("conv_wgrad_kernel", "conv_wgrad_dma_kernel"))]   # 128x128 tiles (pointwise / im2col) + the wide-layer form
             n_ = sum(v["launches"] for v in hits)
             traffic = round(sum((v["fetch_bytes_per_launch"] + v["write_bytes_per_launch"]) * v["launches"] for v in hits) / n_)
             traffic_src = ("profiles/pmc_train_hbm_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py --train`, calibrated counter "
-                           "units; launch-weighted average over ALL conv_wgrad_kernel launches of a step, both instantiations - the 96 conv layers the event bracket covers plus the ~100 smaller Linear layers - partial-slab stores included)")
+                           "units; launch-weighted average over ALL conv_wgrad_kernel / conv_wgrad_dma_kernel launches of a step - the 96 conv layers the event bracket covers plus the ~100 smaller Linear layers - partial-slab stores included)")
     except Exception:
         pass
-    return {"bound": "mfma" if ai >= PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm", "kernel": "conv_wgrad_kernel (+ slab sum / unpack)",
+    return {"bound": "mfma" if ai >= PEAK_BF16_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9) else "hbm", "kernel": "conv_wgrad_kernel / conv_wgrad_dma_kernel (+ slab sum / unpack)",
             "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
             "traffic_source": traffic_src, "alg_bytes_per_launch": round(by / max(len(rec), 1)),
             "launches_per_step": len(rec), "ms_per_step": round(ms, 3), "arithmetic_intensity_flop_per_byte": round(ai, 1),
