@@ -87,6 +87,7 @@ SIGNATURES = {
     "fx_mf_class_head": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "fx_mf_upsample_probs_f32": [_vp, _i, _i, _vp, _i, _i, _i, _vp],
     "fx_mf_postprocess_workspace_bytes": [_i, _i, _i],
+    "fx_mf_postprocess_workspace_bytes_fused": [_i, _i, _i, _i, _i, _i],
     "fx_mf_postprocess": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _i, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "fx_msda_bf16": [_vp, _i, _vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "fx_rowmax_f32": [_vp, _i, _vp, _i, _i, _vp],
@@ -188,7 +189,7 @@ def lib_path() -> str:
     return os.environ.get("FOCOOS_AMD_LIB", LIB_PATH)
 
 
-FX_ABI_VERSION = 4   # = include/focoos_amd.h (tests/test_host_cpu.py compares the two)
+FX_ABI_VERSION = 5   # = include/focoos_amd.h (tests/test_host_cpu.py compares the two)
 
 
 def load() -> C.CDLL:
@@ -210,6 +211,7 @@ def load() -> C.CDLL:
         fn.restype = C.c_int
     lib.fx_mha_bwd_workspace_bytes.restype = C.c_size_t
     lib.fx_seg_postprocess_workspace_bytes.restype = C.c_size_t
+    lib.fx_mf_postprocess_workspace_bytes_fused.restype = C.c_size_t
     lib.fx_mask_set_loss_workspace_bytes.restype = C.c_size_t
     lib.fx_topk_rows_workspace_bytes.restype = C.c_size_t
     lib.fx_error_string.argtypes = [C.c_int]

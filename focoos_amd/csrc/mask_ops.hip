@@ -335,10 +335,14 @@ struct MfPartial {
 // X4: exact x4 upsample (H = 4h, W = 4w, the MaskFormer case): one thread per quarter-resolution cell produces its 4x4
 // output pixels from the 3x3 neighbourhood (9 loads per 16 pixels) with the same tap arithmetic as the generic path.
 // NOTE the summation order over pixels differs between the two paths (sum is a float reduction).
-template <bool X4>
+// BITS (X4 with w % 8 == 0 only): the pass also writes the binary mask of every EVALUATED query bit-packed (allbits[(b*Q + q)][y][W/32],
+// bit x & 31) - the 16 flags of a cell are 4 bits of 4 output rows, eight neighbouring lanes make a word (three xor-shuffles) - so that the
+// masks of the kept detections are a plane copy afterwards (mf_compact_masks_kernel) instead of a second interpolation pass over
+// H x W pixels per detection (mf_pack_masks_kernel: 465 us against the 282 us of this kernel at 8 x 100 x 800^2).
+template <bool X4, bool BITS = false>
 __global__ __launch_bounds__(256) void mf_mask_stats_kernel(const float* __restrict__ lo, int h, int w, int H, int W, float sy, float sx,
                                                             float thr, const float* __restrict__ score, float score_thr,
-                                                            MfPartial* __restrict__ part, int nband) {
+                                                            MfPartial* __restrict__ part, int nband, uint32_t* __restrict__ allbits = nullptr) {
   const int bq = blockIdx.y, band = blockIdx.x;
   if (score_thr > 0.0f && !(score[bq] > score_thr)) {
     if (threadIdx.x == 0) part[(int64_t)bq * nband + band] = MfPartial{0, 0.0f, 0x7fffffff, -1, 0x7fffffff, -1};
@@ -351,9 +355,12 @@ __global__ __launch_bounds__(256) void mf_mask_stats_kernel(const float* __restr
   if (X4) {
     const int ia = ya >> 2, ib = yb >> 2;  // FX_MF_BAND % 4 == 0
     const int ncell = (ib - ia) * w;
-    for (int c = threadIdx.x; c < ncell; c += 256) {
+    for (int c0 = 0; c0 < ncell; c0 += 256) {      // uniform trip count: the BITS form exchanges flags between lanes
+      const int c = c0 + (int)threadIdx.x;
+      unsigned flags = 0;                          // bit 4 r + q: output pixel (4 i + r, 4 j + q) is inside the mask
       const int i = ia + c / w, j = c % w;
-      if (i >= 1 && i <= h - 2 && j >= 1 && j <= w - 2) {
+      if (c >= ncell) {
+      } else if (i >= 1 && i <= h - 2 && j >= 1 && j <= w - 2) {
         float v[3][3];
 #pragma unroll
         for (int a = 0; a < 3; ++a)
@@ -372,6 +379,7 @@ __global__ __launch_bounds__(256) void mf_mask_stats_kernel(const float* __restr
             const float val = lerp_taps(v[a0][b0], v[a0][b0 + 1], v[a0 + 1][b0], v[a0 + 1][b0 + 1], 1.0f - lam[r], lam[r], 1.0f - lam[q], lam[q]);
             if (val >= thr) {
               const int x = 4 * j + q, y = 4 * i + r;
+              if (BITS) flags |= 1u << (4 * r + q);
               ++cnt;
               sum += val;
               x0 = min(x0, x); x1 = max(x1, x);
@@ -387,12 +395,25 @@ __global__ __launch_bounds__(256) void mf_mask_stats_kernel(const float* __restr
             const int x = 4 * j + q;
             const float val = lerp2(p, w, ay, lerp_axis(x, sx, w));
             if (val >= thr) {
+              if (BITS) flags |= 1u << (4 * r + q);
               ++cnt;
               sum += val;
               x0 = min(x0, x); x1 = max(x1, x);
               y0 = min(y0, y); y1 = max(y1, y);
             }
           }
+        }
+      }
+      if constexpr (BITS) {   // w % 8 == 0: the eight lanes 8g .. 8g+7 hold cells j0 .. j0+7 (j0 % 8 == 0) of one cell row = one 32-bit word per output row
+        const int l8 = threadIdx.x & 7;
+        uint32_t* wo = allbits + ((int64_t)bq * H + 4 * i) * (W >> 5) + (j >> 3);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          unsigned word = ((flags >> (4 * r)) & 0xFu) << (4 * l8);
+          word |= __shfl_xor(word, 1, 64);
+          word |= __shfl_xor(word, 2, 64);
+          word |= __shfl_xor(word, 4, 64);
+          if (l8 == 0 && c < ncell) wo[(int64_t)r * (W >> 5)] = word;
         }
       }
     }
@@ -509,6 +530,27 @@ __global__ __launch_bounds__(256) void mf_pack_masks_kernel(const float* __restr
   }
 }
 
+// Masks of the kept detections from the planes mf_mask_stats_kernel<true, true> wrote for every evaluated query: slot j <- query det_query[j].
+__global__ __launch_bounds__(256) void mf_compact_masks_kernel(const uint32_t* __restrict__ allbits, int64_t plane_words, const int32_t* __restrict__ det_count,
+                                                               const int32_t* __restrict__ det_query, int Q, uint32_t* __restrict__ words) {
+  const int slot = blockIdx.y, b = blockIdx.z;
+  if (slot >= det_count[b]) return;
+  const int q = det_query[b * Q + slot];
+  const uint4* src = reinterpret_cast<const uint4*>(allbits + ((int64_t)b * Q + q) * plane_words);
+  uint4* dst = reinterpret_cast<uint4*>(words + ((int64_t)b * Q + slot) * plane_words);
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < plane_words / 4; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
+// Workspace that also holds the bit planes of the fused form (x4 upsample with w % 8 == 0 and H * W/32 a multiple of 4): pass this many
+// bytes to fx_mf_postprocess and the masks of the kept detections are compacted from them; with the smaller
+// fx_mf_postprocess_workspace_bytes() buffer (or any other size ratio) they are interpolated a second time (mf_pack_masks_kernel).
+extern "C" size_t fx_mf_postprocess_workspace_bytes_fused(int B, int Q, int h, int w, int H, int W) {
+  if (B <= 0 || Q <= 0 || H <= 0 || W <= 0) return 0;
+  const size_t base = ((size_t)B * Q * ((H + FX_MF_BAND - 1) / FX_MF_BAND) * sizeof(MfPartial) + 15) / 16 * 16;
+  if (H != 4 * h || W != 4 * w || w % 8 != 0 || ((int64_t)H * (W / 32)) % 4 != 0) return base;
+  return base + (size_t)B * Q * H * (W / 32) * 4;
+}
+
 extern "C" int fx_mf_postprocess_workspace_bytes(int B, int Q, int H) {
   if (B <= 0 || Q <= 0 || H <= 0) return 0;
   return (int)((size_t)B * Q * ((H + FX_MF_BAND - 1) / FX_MF_BAND) * sizeof(MfPartial));
@@ -526,7 +568,14 @@ extern "C" int fx_mf_postprocess(const float* mask_probs_lowres, int h, int w, i
   const int nband = (H + FX_MF_BAND - 1) / FX_MF_BAND;
   const float sy = (float)h / (float)H, sx = (float)w / (float)W;
   MfPartial* part = reinterpret_cast<MfPartial*>(workspace);
-  if (H == 4 * h && W == 4 * w)
+  const size_t base = ((size_t)fx_mf_postprocess_workspace_bytes(B, Q, H) + 15) / 16 * 16;
+  const bool fused = mask_words && H == 4 * h && W == 4 * w && w % 8 == 0 && ((int64_t)H * (W / 32)) % 4 == 0 && ((uintptr_t)workspace % 16) == 0 &&
+                     ((uintptr_t)mask_words % 16) == 0 && workspace_bytes >= base + (size_t)B * Q * H * (W / 32) * 4;
+  uint32_t* allbits = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(workspace) + base);
+  if (fused)
+    hipLaunchKernelGGL((mf_mask_stats_kernel<true, true>), dim3(nband, B * Q), dim3(256), 0, stream, mask_probs_lowres, h, w, H, W, sy, sx,
+                       mask_threshold, score, threshold, part, nband, allbits);
+  else if (H == 4 * h && W == 4 * w)
     hipLaunchKernelGGL(mf_mask_stats_kernel<true>, dim3(nband, B * Q), dim3(256), 0, stream, mask_probs_lowres, h, w, H, W, sy, sx,
                        mask_threshold, score, threshold, part, nband);
   else
@@ -534,8 +583,14 @@ extern "C" int fx_mf_postprocess(const float* mask_probs_lowres, int h, int w, i
                        mask_threshold, score, threshold, part, nband);
   hipLaunchKernelGGL(mf_select_kernel, dim3(B), dim3(128), 0, stream, part, nband, score, label, Q, threshold, use_mask_score, det_count,
                      det_query, det_score, det_label, det_box, det_area);
-  if (mask_words)
+  if (fused) {
+    const int64_t plane_words = (int64_t)H * (W / 32);
+    int gx = (int)((plane_words / 4 + 255) / 256);
+    if (gx > 16) gx = 16;
+    hipLaunchKernelGGL(mf_compact_masks_kernel, dim3(gx, Q, B), dim3(256), 0, stream, allbits, plane_words, det_count, det_query, Q, mask_words);
+  } else if (mask_words) {
     hipLaunchKernelGGL(mf_pack_masks_kernel, dim3(nband, Q, B), dim3(256), 0, stream, mask_probs_lowres, h, w, H, W, sy, sx, mask_threshold,
                        det_count, det_query, Q, mask_words);
+  }
   return fx_launch_status();
 }

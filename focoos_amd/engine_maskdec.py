@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -217,8 +218,9 @@ class MaskDecoderPlanMixin:
                      self.det_query.data_ptr(), self.det_scores.data_ptr(), self.det_labels.data_ptr(), self.det_boxes.data_ptr(),
                      self.det_area.data_ptr(), self.mask_words.data_ptr(), self.winner.data_ptr())
         else:
-            ws_bytes = lib.fx_mf_postprocess_workspace_bytes(B, Q, H)
-            self.post_ws = torch.empty(max(ws_bytes, 8), dtype=torch.uint8, device=self.dev)
+            # (the larger workspace: the statistics pass also leaves one bit plane per evaluated query, the kept detections' masks are plane copies)
+            ws_bytes = lib.fx_mf_postprocess_workspace_bytes_fused(B, Q, hl, wl, H, W) if int(os.environ.get("FX_MF_POST_FUSED", "1")) else lib.fx_mf_postprocess_workspace_bytes(B, Q, H)
+            self.post_ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=self.dev)
             self._op(lib.fx_mf_postprocess, self.mask_probs.data_ptr(), hl, wl, H, W, self.cls_score.data_ptr(), self.cls_label.data_ptr(), B, Q,
                      C.c_float(e.mask_threshold), None, int(e.use_mask_score), self.post_ws.data_ptr(), C.c_size_t(self.post_ws.numel()),
                      self.det_count.data_ptr(), self.det_query.data_ptr(), self.det_scores.data_ptr(), self.det_labels.data_ptr(),

@@ -29,7 +29,7 @@ extern "C" {
 /* Bumped whenever a descriptor struct's layout OR the semantics the host relies on change (version 2: fx_conv_desc grew mask / ldm /
  * reserved0 and the library applies the ReLU mask the previous bottleneck skips; version 3: fx_pw_chain_desc grew pool / ldp / img_h / img_w);
  * focoos_amd/_lib.py refuses a library of another version. */
-#define FX_ABI_VERSION 4
+#define FX_ABI_VERSION 5
 
 enum { FX_OK = 0, FX_ERR_INVALID_ARGUMENT = -1, FX_ERR_LAUNCH = -2, FX_ERR_UNSUPPORTED = -3, FX_ERR_RUNTIME = -4 };
 enum { FX_ACT_NONE = 0, FX_ACT_RELU = 1, FX_ACT_SILU = 2, FX_ACT_GELU = 3 };
@@ -311,6 +311,10 @@ int fx_mf_upsample_probs_f32(const float* lowres, int h, int w, float* out, int 
  * (x_min, y_min, x_max, y_max) inclusive; mask_words (optional) u32 [B][Q][H][ceil(W/32)], bit x&31 (bits >= W are 0) — slot j holds the
  * binary mask of detection j.  workspace: fx_mf_postprocess_workspace_bytes(B,Q,H) bytes.  Deterministic. */
 int fx_mf_postprocess_workspace_bytes(int B, int Q, int H);
+/* The larger workspace (16-byte aligned) that also holds one bit plane per evaluated query: for the x4 up-sample (H = 4h, W = 4w, w % 8 == 0)
+ * the masks of the kept detections are then compacted from the planes the statistics pass writes anyway, instead of being
+ * interpolated a second time.  Same results; fx_mf_postprocess picks the form from workspace_bytes. */
+size_t fx_mf_postprocess_workspace_bytes_fused(int B, int Q, int h, int w, int H, int W);
 int fx_mf_postprocess(const float* mask_probs_lowres, int h, int w, int H, int W, const float* score, const int32_t* label, int B, int Q,
                       float mask_threshold, float threshold, int use_mask_score, void* workspace, size_t workspace_bytes,
                       int32_t* det_count, int32_t* det_query, float* det_score, int32_t* det_label, int32_t* det_box, int32_t* det_area,

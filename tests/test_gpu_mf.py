@@ -159,11 +159,13 @@ def test_upsample_nearest_any_size_and_adjoint(lib, sizes):
     assert float((got == wb).float().mean()) >= 0.995 and (got - wb).abs().max() <= 2 ** -6 * want.abs().max()
 
 
-@pytest.mark.parametrize("cfg", [(2, 100, 40, 48), (1, 17, 25, 33)])
+@pytest.mark.parametrize("cfg", [(2, 100, 40, 48, 0), (1, 17, 25, 33, 0), (2, 100, 40, 48, 1), (3, 37, 33, 56, 1), (1, 17, 25, 33, 1)])
 def test_mf_postprocess_vs_oracle(lib, cfg):
     """fx_mf_postprocess + fx_mf_upsample_probs_f32 vs F.interpolate + the oracle's restatement of
-    MaskFormerProcessor.postprocess on identical fp32 inputs."""
-    B, Q, h, w = cfg
+    MaskFormerProcessor.postprocess on identical fp32 inputs.  Last field 1: the larger workspace of
+    fx_mf_postprocess_workspace_bytes_fused - for x4 shapes with w % 8 == 0 the statistics pass then also writes the bit planes and the
+    kept masks are compacted from them (same results, bit for bit); other shapes fall back to the second interpolation pass."""
+    B, Q, h, w, fused_ws = cfg
     H, W = (4 * h, 4 * w) if w % 8 == 0 else (4 * h, 128)
     rs = np.random.RandomState(7)
     # smooth blobs so masks have structure; a few queries empty / one-pixel
@@ -186,8 +188,10 @@ def test_mf_postprocess_vs_oracle(lib, cfg):
     ref_full = F.interpolate(lo_t, size=(H, W), mode="bilinear", align_corners=False)
     assert (full.cpu() - ref_full).abs().max() < 2e-6
     sd, ld_ = dev(score), dev(label.int())
-    nb = lib.fx_mf_postprocess_workspace_bytes(B, Q, H)
-    ws = torch.empty(nb, dtype=torch.uint8, device=DEV)
+    nb = lib.fx_mf_postprocess_workspace_bytes_fused(B, Q, h, w, H, W) if fused_ws else lib.fx_mf_postprocess_workspace_bytes(B, Q, H)
+    if fused_ws and H == 4 * h and W == 4 * w and w % 8 == 0:
+        assert nb >= lib.fx_mf_postprocess_workspace_bytes(B, Q, H) + B * Q * H * (W // 32) * 4
+    ws = torch.full((max(nb, 16),), 0x5A, dtype=torch.uint8, device=DEV)      # stale planes must never leak into a kept mask
     cnt = torch.zeros(B, dtype=torch.int32, device=DEV)
     dq, dl, da = (torch.zeros(B, Q, dtype=torch.int32, device=DEV) for _ in range(3))
     ds = torch.zeros(B, Q, dtype=torch.float32, device=DEV)
