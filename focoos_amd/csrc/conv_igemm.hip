@@ -366,7 +366,9 @@ static ConvRoute conv_route(const fx_conv_desc* d, const ConvArgs& a) {
   static const int small_m = fx_tune("FX_SMALL_M", 16384);
   // Small-M GEMMs (decoder / 20x20 level: a few hundred tiles, latency-bound): 64x64 tiles with a 256-deep K slab per
   // step - for K = 256 the whole reduction is ONE load phase (all 16 loads per lane in flight at once), no K loop.
-  if (!d->pool2 && a.M <= small_m && d->C % 256 == 0 && a.Ktot <= 1024) return R_SMALL_M;
+  // (Ktot <= 2048 since round 4: MaskFormer-L's FFN linear2 - 800 rows, K = 2048 - took 45 us on 14 workgroups of the 128 x 128 tiles)
+  static const int small_k = fx_tune("FX_SMALL_M_KTOT", 2048);
+  if (!d->pool2 && a.M <= small_m && d->C % 256 == 0 && a.Ktot <= small_k) return R_SMALL_M;
   const bool k64 = (d->C % 64 == 0) && (a.Ktot >= k64_min);
   if (!d->pool2 && !d->mask && fx_conv_dma_eligible(a)) return R_DMA;
   if (d->pool2) return d->C % 64 != 0 ? R_UNSUPPORTED : R_POOL;

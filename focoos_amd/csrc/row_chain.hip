@@ -12,6 +12,7 @@
 //   RC_ADD      Y = X1 + X2
 //   RC_K4       Y = relu(ref[.,4] . W^T + b)            (query_pos_head layer 0, modelling.py:996)
 //   RC_BBOX     ref' = sigmoid(X . W4^T + b + inverse_sigmoid(ref))   (bbox head tail + refinement, modelling.py:1000-1003)
+//   RC_LN       Y = LayerNorm_256(X) * gamma + beta               (the pre-norm layers of the masked-attention decoders, round 4)
 // GEMMs: 8 waves, a wave owns 32 output channels per pass (one 32x32 accumulator block over the 32 rows), weights = MFMA A
 // operand in fragment order straight from L2 through an 8-deep register ring (loads hidden from hipcc's waitcnt bookkeeping, see
 // pw_common.h), rows = B operand from LDS.  With 32 rows a fragment is used by one MFMA only: the chain is bound by the
@@ -21,7 +22,7 @@
 
 #include "pw_common.h"
 
-enum { RC_LOAD = 0, RC_GEMM = 1, RC_GEMM_LN = 2, RC_ADD = 3, RC_K4 = 4, RC_BBOX = 5 };
+enum { RC_LOAD = 0, RC_GEMM = 1, RC_GEMM_LN = 2, RC_ADD = 3, RC_K4 = 4, RC_BBOX = 5, RC_LN = 6 };
 
 __device__ __forceinline__ float rc_inv_sigmoid(float x) {
   x = fminf(fmaxf(x, 0.0f), 1.0f);
@@ -72,7 +73,46 @@ __global__ __launch_bounds__(512, 1) void row_chain_kernel(const fx_rc_stage* __
         unpack_bf16x8(b, fb);
 #pragma unroll
         for (int i = 0; i < 8; ++i) fa[i] += fb[i];
-        *reinterpret_cast<uint4*>(smem + st.dst + o) = pack_bf16x8(fa);
+        const uint4 pk = pack_bf16x8(fa);
+        *reinterpret_cast<uint4*>(smem + st.dst + o) = pk;
+        if (st.g0) {   // also to global (bf16 rows of stride ld): undo the swizzle of the physical chunk index
+          const int row = q / cpr, pc = q - row * cpr;
+          const int c = (pc & ~15) | ((pc ^ (row & 15)) & 15);
+          const int m = m0 + row;
+          if (m < M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(st.g0) + (size_t)m * st.ld + c * 8) = pk;
+        }
+      }
+    } else if (st.type == RC_LN) {
+      // 16 threads per row, 16 channels each (two 16-byte chunks); fp32 statistics, two passes, the row's partial sums meet by xor-shuffles
+      const int row = tid >> 4, t16 = tid & 15;
+      float v[16];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) unpack_bf16x8(*reinterpret_cast<const uint4*>(smem + st.src + rc_off(row, 2 * t16 + c, 512)), v + 8 * c);
+      float sum = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sum += v[i];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+      const float mean = sum * (1.0f / 256.0f);
+      float var = 0.0f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        v[i] -= mean;
+        var += v[i] * v[i];
+      }
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) var += __shfl_xor(var, o, 64);
+      const float rstd = rsqrtf(var * (1.0f / 256.0f) + 1e-5f);
+      const int m = m0 + row;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int n = (2 * t16 + c) * 8;
+        float o[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = v[8 * c + i] * rstd * st.gamma[n + i] + st.beta[n + i];
+        const uint4 pk = pack_bf16x8(o);
+        if (st.dst >= 0) *reinterpret_cast<uint4*>(smem + st.dst + rc_off(row, 2 * t16 + c, 512)) = pk;
+        if (st.g0 && m < M) *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(st.g0) + (size_t)m * st.ld + n) = pk;
       }
     } else if (st.type == RC_K4) {
       // Y[row][n] = relu(b[n] + sum_k ref[row][k] * W[n][k]); ref from the LDS hand-over area (aux >= 0) or from global.  N <= 512.

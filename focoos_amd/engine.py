@@ -572,6 +572,18 @@ class _PlanBase:
         self._op(self.lib.fx_add_rows_bf16, x.ptr, x.ld, y.ptr, y.ld, y_rows, out.ptr, out.ld, x.rows, x.C)
         return out
 
+    # LDS map of the decoder's row chains (bytes): four [32][256] slots, one [32][1024] slot, the refined-box hand-over, LN scratch
+    RC_S0, RC_S1, RC_S2, RC_S3, RC_BIG, RC_REF, RC_RED, RC_LDS = 0, 16384, 32768, 49152, 65536, 131072, 131584, 132608
+
+    def _rc_program(self, stages: List[FxRcStage], rows: int, label: str, flops: float):
+        """Upload a stage list and append the fx_row_chain launch."""
+        arr = (FxRcStage * len(stages))(*stages)
+        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+        dev = host.to(self.dev)
+        self.keep.append(dev)
+        self.meta[len(self.ops)] = {"kind": "conv", "variant": "row_chain", "flops": flops, "name": label, "M": rows, "N": 0, "K": 0}
+        self._op(self.lib.fx_row_chain, dev.data_ptr(), len(stages), rows, self.RC_LDS)
+
     def resize(self, x: NT, out: NT):
         self._op(self.lib.fx_resize_bilinear_nhwc_bf16, x.ptr, x.ld, out.ptr, out.ld, x.B, x.H, x.W, x.C, out.H, out.W)
 
@@ -865,18 +877,6 @@ class _Plan(StdcPlanMixin, _PlanBase):
                      None, R, 256)
         logits = self.linear(tgt, P[f"{hp}.dec_score"], name="logits", out_f32=True)
         return logits
-
-    # LDS map of the decoder's row chains (bytes): four [32][256] slots, one [32][1024] slot, the refined-box hand-over, LN scratch
-    RC_S0, RC_S1, RC_S2, RC_S3, RC_BIG, RC_REF, RC_RED, RC_LDS = 0, 16384, 32768, 49152, 65536, 131072, 131584, 132608
-
-    def _rc_program(self, stages: List[FxRcStage], rows: int, label: str, flops: float):
-        """Upload a stage list and append the fx_row_chain launch."""
-        arr = (FxRcStage * len(stages))(*stages)
-        host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-        dev = host.to(self.dev)
-        self.keep.append(dev)
-        self.meta[len(self.ops)] = {"kind": "conv", "variant": "row_chain", "flops": flops, "name": label, "M": rows, "N": 0, "K": 0}
-        self._op(self.lib.fx_row_chain, dev.data_ptr(), len(stages), rows, self.RC_LDS)
 
     def _build_decoder_row_chain(self, tgt: NT, refs, value: NT, R: int, B: int, Q: int, S: int) -> NT:
         """TransformerDecoder.forward (modelling.py:969-1020) as row chains: per layer  [self-attention core]  [out_proj + LN1 + offsets]

@@ -16,11 +16,12 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
 
+from ._lib import FX_ACT, FxRcStage
 from .engine import NT, PackedConv
 
 HP = "head.predictor"
@@ -83,6 +84,39 @@ def pack_masked_decoder(eng, sd: Dict[str, torch.Tensor], P: Dict[str, PackedCon
         P[f"{HP}.k_all.{lvl}"] = eng._pack_linear(torch.cat(kw[lvl], 0), torch.cat(kb[lvl], 0))
         P[f"{HP}.v_all.{lvl}"] = eng._pack_linear(torch.cat(vw[lvl], 0), torch.cat(vb[lvl], 0))
         P[f"{HP}.input_proj.{lvl}"] = eng._pack(sd[f"{HP}.input_proj.{lvl}.weight"].float(), sd[f"{HP}.input_proj.{lvl}.bias"].float())
+    # fragment-ordered copies of the row-local linears for fx_row_chain (two launches per decoder layer instead of ~17; build_masked_decoder)
+    RC: Dict[str, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+    def rc(key, W, b, pad_n=None):
+        W, b = W.float(), (b.float() if b is not None else torch.zeros(W.shape[0]))
+        if pad_n is not None and W.shape[0] < pad_n:
+            W = torch.cat([W, torch.zeros(pad_n - W.shape[0], W.shape[1])], 0)
+            b = torch.cat([b, torch.zeros(pad_n - b.shape[0])], 0)
+        RC[key] = (eng._pack_frag(W), eng._dev(b))
+
+    for li in range(eng.nl):
+        p = f"{HP}.transformer_cross_attention_layers.{li}"
+        Wi, bi = sd[f"{p}.multihead_attn.in_proj_weight"], sd[f"{p}.multihead_attn.in_proj_bias"]
+        rc(f"{li}.cq", Wi[:256], bi[:256])
+        rc(f"{li}.co", sd[f"{p}.multihead_attn.out_proj.weight"], sd[f"{p}.multihead_attn.out_proj.bias"])
+        p = f"{HP}.transformer_self_attention_layers.{li}"
+        Wi, bi = sd[f"{p}.self_attn.in_proj_weight"], sd[f"{p}.self_attn.in_proj_bias"]
+        rc(f"{li}.sqk", Wi[:512], bi[:512])
+        rc(f"{li}.sv", Wi[512:], bi[512:])
+        rc(f"{li}.so", sd[f"{p}.self_attn.out_proj.weight"], sd[f"{p}.self_attn.out_proj.bias"])
+        p = f"{HP}.transformer_ffn_layers.{li}"
+        W1, b1, W2, b2 = sd[f"{p}.linear1.weight"], sd[f"{p}.linear1.bias"], sd[f"{p}.linear2.weight"], sd[f"{p}.linear2.bias"]
+        ffn = W1.shape[0]
+        for h0 in range(0, ffn, 1024):      # the [32][1024] LDS slot holds 1024 hidden channels at a time: wider FFNs run as halves whose outputs add
+            h1 = min(ffn, h0 + 1024)
+            rc(f"{li}.f1.{h0 // 1024}", W1[h0:h1], b1[h0:h1])
+            rc(f"{li}.f2.{h0 // 1024}", W2[:, h0:h1], b2 if h0 == 0 else None)
+    eng.rc_ffn_parts = [(h0 // 1024, min(1024, ffn - h0)) for h0 in range(0, ffn, 1024)]
+    for j in range(2):
+        rc(f"mc{j}", sd[f"{PH}.mask_classifier.layers.{j}.weight"], sd[f"{PH}.mask_classifier.layers.{j}.bias"])
+    md_w = sd[f"{PH}.mask_classifier.layers.2.weight"]
+    rc("mc2", md_w, sd[f"{PH}.mask_classifier.layers.2.bias"], pad_n=(128 if md_w.shape[0] < 128 else None))
+    eng.RCM = RC
     eng.query_feat = eng._dev(sd[f"{HP}.query_feat.weight"].float(), torch.bfloat16)
     eng.query_embed = eng._dev(sd[f"{HP}.query_embed.weight"].float(), torch.bfloat16)
     eng._pack_ln(sd, f"{PH}.decoder_norm")
@@ -144,6 +178,15 @@ class MaskDecoderPlanMixin:
                 self.force_points.append(len(self.ops))
             return dn, emb
 
+        # row chains from 1 000 rows on (FX_MASKDEC_ROW_CHAIN_MIN_ROWS; 0 = never): a 32-row workgroup walks its ~10 GEMM stages serially, each
+        # streaming the stage's whole weight matrix - 25 workgroups (MaskFormer bs=16: two parts of 8 x 100 rows) are no faster than the
+        # 50-workgroup launches per layer they replace (1441 vs 1448 img/s), 50+ are (BiSeNetFormer bs=32: 7 406 -> 7 767-8 373 img/s)
+        min_rows = int(os.environ.get("FX_MASKDEC_ROW_CHAIN_MIN_ROWS", "1000"))
+        if min_rows > 0 and R >= min_rows and hasattr(e, "RCM"):
+            dn, emb = self._masked_decoder_row_chains(out, qe, k_all, v_all, mfp, Ls, W32, md, R, B, Q)
+            self.levels = Ls
+            self.W32 = W32
+            return dn, emb
         heads(out, 0, 0)
         dn = emb = None
         # one workspace for the key-sliced cross attention (launches are serial on one stream)
@@ -175,6 +218,116 @@ class MaskDecoderPlanMixin:
             dn, emb = heads(out, i + 1, (i + 1) % nlev if i < e.nl - 1 else None)
         self.levels = Ls
         self.W32 = W32
+        return dn, emb
+
+    def _masked_decoder_row_chains(self, out: NT, qe: NT, k_all, v_all, mfp, Ls, W32, md: int, R: int, B: int, Q: int):
+        """The decoder layers of build_masked_decoder with every row-local run of layers as ONE fx_row_chain launch (round 4): per layer
+        [masked cross-attention core] [out_proj + residual, LayerNorm, + query embedding, q = k and v projections of the self-attention]
+        [self-attention core] [out_proj + residual, LayerNorm, FFN + residual, decoder_norm + the 3-layer mask-embedding MLP, the NEXT layer's
+        LayerNorm + query embedding + q projection] [attention-mask bits] - 5 launches instead of ~22 (the pre-norm form of
+        fai_mf/modelling.py:453-549: norm -> attention / FFN -> residual add)."""
+        e, lib = self.eng, self.lib
+        RC = e.RCM
+        S0, S1, S2, S3, BIG = self.RC_S0, self.RC_S1, self.RC_S2, self.RC_S3, self.RC_BIG
+        relu = FX_ACT["relu"]
+        nlev = e.nlev
+
+        def st(type_, K=0, N=0, act=0, src=-1, dst=-1, aux=-1, ld=0, ld2=0, flags=0, w=None, bias=None, gamma=None, beta=None, g0=None, g1=None):
+            s_ = FxRcStage()
+            s_.type, s_.K, s_.N, s_.act, s_.src, s_.dst, s_.aux, s_.ld, s_.ld2, s_.flags = type_, K, N, act, src, dst, aux, ld, ld2, flags
+            s_.w, s_.bias, s_.gamma, s_.beta, s_.g0, s_.g1 = w, bias, gamma, beta, g0, g1
+            return s_
+
+        def load(nt: NT, dst):
+            return st(0, K=nt.C, dst=dst, g0=nt.ptr, ld=nt.ld)
+
+        def gemm(key, src, K, N, dst=-1, act=0, out: Optional[NT] = None):
+            w, b = RC[key]
+            return st(1, K=K, N=N, act=act, src=src, dst=dst, w=w.data_ptr(), bias=b.data_ptr(), g0=out.ptr if out is not None else None,
+                      ld=out.ld if out is not None else 0)
+
+        def ln(name, src, dst, out: Optional[NT] = None):
+            g_, b_ = e.ln[name]
+            return st(6, K=256, src=src, dst=dst, gamma=g_.data_ptr(), beta=b_.data_ptr(), g0=out.ptr if out is not None else None,
+                      ld=out.ld if out is not None else 0)
+
+        def add(a, b_, dst, out: Optional[NT] = None):
+            return st(3, K=256, src=a, aux=b_, dst=dst, g0=out.ptr if out is not None else None, ld=out.ld if out is not None else 0)
+
+        qe_rep = e.query_embed.repeat(B, 1).contiguous()     # [R, 256]: a LOAD stage reads row m of a global matrix
+        self.keep.append(qe_rep)
+        qe_r = NT(qe_rep, R, 1, 1, 256, 256)
+        mdn = RC["mc2"][0].shape[0] * 32                      # mask-embedding width as packed (zero-padded to 128 below that)
+        assert mdn == md, (mdn, md)
+        n_ffn = sum(n for _, n in e.rc_ffn_parts)
+        fl_heads = 2.0 * R * 256 * (256 + 256 + md)
+        fl_cq = 2.0 * R * 256 * 256
+
+        def heads_stages(src_out, idx):
+            """decoder_norm + mask MLP on the LDS slot `src_out` (kept intact); emb -> global.  Uses S0, S2, S3."""
+            dn = self._new(f"ph{idx}.dn", R, 1, 1, 256)
+            emb = self._new(f"ph{idx}.emb", R, 1, 1, md)
+            return [ln(f"{PH}.decoder_norm", src_out, S2, out=dn), gemm("mc0", S2, 256, 256, dst=S0, act=relu), gemm("mc1", S0, 256, 256, dst=S2, act=relu),
+                    gemm("mc2", S2, 256, md, out=emb)], dn, emb
+
+        def cross_pre_stages(src_out, li, qc: NT):
+            """LayerNorm + query embedding + q projection of layer li's cross attention from the LDS slot `src_out`.  Uses S0, S2, S3."""
+            p = f"{HP}.transformer_cross_attention_layers.{li}"
+            return [ln(f"{p}.norm", src_out, S2), load(qe_r, S3), add(S2, S3, S0), gemm(f"{li}.cq", S0, 256, 256, out=qc)]
+
+        def bits_op(emb: NT, level: int):
+            bits = torch.zeros(R, W32[level], dtype=torch.int32, device=self.dev)
+            self._op(lib.fx_query_pixel_logits_bf16, emb.ptr, emb.ld, mfp[level].ptr, mfp[level].ld, 2, None, 0, bits.data_ptr(), W32[level], B, Q,
+                     Ls[level], md)
+            self.attn_bits.append(bits)
+            self.force_points.append(len(self.ops))
+
+        qc = self._new("dec0.c_q", R, 1, 1, 256)
+        hs, dn, emb = heads_stages(S1, 0)
+        self._rc_program([load(out, S1)] + hs + cross_pre_stages(S1, 0, qc), R, "maskdec.pre", fl_heads + fl_cq)
+        bits_op(emb, 0)
+        mha_ws = torch.empty(max(8, max(lib.fx_mha_workspace_bytes(B, Q, L, 8, 1) for L in Ls)), dtype=torch.uint8, device=self.dev)
+        self.keep.append(mha_ws)
+        for i in range(e.nl):
+            lvl, j = i % nlev, i // nlev
+            last = i == e.nl - 1
+            att = self._new(f"dec{i}.c_att", R, 1, 1, 256)
+            ks, vs = k_all[lvl].slice(j * 256, 256), v_all[lvl].slice(j * 256, 256)
+            self._op(lib.fx_mha_masked_bf16, qc.ptr, qc.ld, ks.ptr, ks.ld, vs.ptr, vs.ld, att.ptr, att.ld, B, Q, Ls[lvl], 8,
+                     self.attn_bits[i].data_ptr(), W32[lvl], mha_ws.data_ptr(), C.c_size_t(mha_ws.numel()))
+            # ---- after the cross attention: residual, self-attention projections
+            p = f"{HP}.transformer_self_attention_layers.{i}"
+            out1 = self._new(f"dec{i}.c_o", R, 1, 1, 256)
+            qkv = self._new(f"dec{i}.s_qkv", R, 1, 1, 768)
+            prog = [load(att, S0), load(out, S1), gemm(f"{i}.co", S0, 256, 256, dst=S2), add(S2, S1, S1, out=out1),
+                    ln(f"{p}.norm", S1, S2), load(qe_r, S3), add(S2, S3, S0),
+                    gemm(f"{i}.sqk", S0, 256, 512, out=qkv.slice(0, 512)), gemm(f"{i}.sv", S2, 256, 256, out=qkv.slice(512, 256))]
+            self._rc_program(prog, R, f"dec{i}.post_cross", 2.0 * R * 256 * (256 + 768))
+            att = self.mha(qkv, B, Q, f"dec{i}.s_att")
+            # ---- after the self attention: residual, FFN, heads, the next layer's query projection
+            p = f"{HP}.transformer_ffn_layers.{i}"
+            out3 = self._new(f"dec{i}.out", R, 1, 1, 256)
+            prog = [load(att, S0), load(out1, S1), gemm(f"{i}.so", S0, 256, 256, dst=S2), add(S2, S1, S1), ln(f"{p}.norm", S1, S2)]
+            acc_slot = None
+            for part, n in e.rc_ffn_parts:       # hidden channels in blocks of <= 1024 (the [32][1024] slot); partial outputs add
+                dst = S0 if acc_slot is None else S3
+                prog += [gemm(f"{i}.f1.{part}", S2, 256, n, dst=BIG, act=relu), gemm(f"{i}.f2.{part}", BIG, n, 256, dst=dst)]
+                if acc_slot is None:
+                    acc_slot = S0
+                else:
+                    prog.append(add(S0, S3, S0))
+            prog.append(add(S0, S1, S1, out=out3))
+            hs, dn, emb = heads_stages(S1, i + 1)
+            prog += hs
+            fl = 2.0 * R * (256 * 256 + 2 * 256 * n_ffn) + fl_heads
+            if not last:
+                qc = self._new(f"dec{i + 1}.c_q", R, 1, 1, 256)
+                prog += cross_pre_stages(S1, i + 1, qc)
+                fl += fl_cq
+            self._rc_program(prog, R, f"dec{i}.post_self", fl)
+            out = out3
+            if not last:
+                bits_op(emb, (i + 1) % nlev)
         return dn, emb
 
     def build_mask_outputs(self, dn: NT, emb: NT, mf: NT, md: int, full_masks: bool, predict_all_pixels: bool):

@@ -207,11 +207,13 @@ int fx_enc_score_head_bf16(const void* memory, int ldm, const uint8_t* valid, in
  *              f32 if flags&1 else bf16); N % 32 == 0, K % 128 == 0 (the weight stream moves in groups of eight 16-channel fragments)
  *   2 GEMM_LN  LayerNorm_256(src . w^T + bias + aux) * gamma + beta -> dst and optionally g0 (bf16); eps 1e-5; ld2 = LDS byte
  *              offset of a 512-byte reduction scratch
- *   3 ADD      dst <- src + aux  (K columns)
+ *   3 ADD      dst <- src + aux  (K columns); if g0: also to g0[row, 0:K] (bf16, row stride ld)
  *   4 K4       dst[32,N] <- relu(ref[row,0:4] . w^T + bias), w f32 [N][4]; ref = f32 at LDS offset aux (16 B per row) if aux >= 0,
  *              else g0 (f32 [rows][4])
  *   5 BBOX     ref' = sigmoid(src[32,256] . w^T + bias + inverse_sigmoid(g0[row,0:4])), w f32 [4][256]; ref' -> g1 (f32 [rows][4])
- *              and, if aux >= 0, to LDS offset aux (for a following K4 stage) */
+ *              and, if aux >= 0, to LDS offset aux (for a following K4 stage)
+ *   6 LN       dst and / or g0[row, 0:256] (bf16, row stride ld) <- LayerNorm_256(src) * gamma + beta (the pre-norm layers of the
+ *              masked-attention decoders, fai_mf/modelling.py:453-549); src == dst allowed */
 typedef struct fx_rc_stage {
   int32_t type, K, N, act;
   int32_t src, dst, aux;

@@ -211,3 +211,34 @@ def test_config5_bisenetformer_bs8_1024_production_path_vs_oracle():
             probs_o, _ = BFO.bf_forward(sd, cfg, O.get_torch_batch([images[b]], None), forced_attn=forced, collect=col, upsample=False)
         _mask_family_check(pl, b, j, cfg, col, probs_o, ("res2", "res3", "res4", "res5", "cp32", "cp16", "cp8", "ffm", "mask_features"), eng.nl, worst)
     print("BiSeNetFormer bs=8 1024^2 production path vs oracle, worst over images", sample, ":", {k: round(v, 5) for k, v in worst.items()})
+
+
+def test_bisenetformer_bs32_640_production_path_vs_oracle():
+    """BiSeNetFormer-L inference exactly as `bench.py --model bisenetformer-l-ade` (and the `other_configs` leg of the default run) times it:
+    bs=32 at 640x640, two concurrent 16-image parts, hipGraph replay - the shape at which the masked decoder runs as fx_row_chain programs
+    (1 600 rows per part; engine_maskdec._masked_decoder_row_chains).  Images 0 and 31 against the oracle, attention masks from the engine."""
+    from focoos_amd.model import BisenetFormer
+
+    cfg = ModelRegistry.get_model_info("bisenetformer-l-ade")["config"]
+    sd = synth_state_dict(cfg, 0, family="bisenetformer")
+    model = BisenetFormer(cfg, device=DEV, seed=0)
+    eng = model.engine
+    B, S = 32, 640
+    images = [synth_image(i, S, S) for i in range(B)]
+    x = torch.from_numpy(np.stack(images)).to(DEV)
+    pl = eng.plan(B, S, S, False, False, None)
+    assert getattr(pl, "n", 1) == 2 and pl.parts[0].B == 16
+    _bench_step(eng, pl, x, 0.5)
+    var = _variants(pl)
+    print("kernel variants under the oracle (launches per step):", dict(sorted(var.items(), key=lambda kv: -kv[1])))
+    assert var.get("row_chain", 0) == 2 * (2 * eng.nl + 1)
+    worst = {}
+    sample = [0, 31]
+    for j, b in enumerate(sample):
+        part = pl.parts[b // 16]
+        forced = _attn_from_bits(part, b % 16, eng.nq, part.levels, eng.nl)
+        col = {}
+        with torch.no_grad():
+            probs_o, _ = BFO.bf_forward(sd, cfg, O.get_torch_batch([images[b]], None), forced_attn=forced, collect=col, upsample=False)
+        _mask_family_check(pl, b, j, cfg, col, probs_o, ("res2", "res3", "res4", "res5", "cp32", "cp16", "cp8", "ffm", "mask_features"), eng.nl, worst)
+    print("BiSeNetFormer bs=32 640^2 production path vs oracle, worst over images", sample, ":", {k: round(v, 5) for k, v in worst.items()})

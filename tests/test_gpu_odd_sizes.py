@@ -223,3 +223,40 @@ def test_detr_still_needs_multiples_of_32():
     eng = DetrEngine(cfg, synth_state_dict(cfg, 3), device=DEV)
     with pytest.raises(_lib.FocoosAmdError):
         eng.forward(torch.zeros(1, 150, 200, 3, dtype=torch.uint8, device=DEV))
+
+
+@pytest.mark.parametrize("name", ["fai-mf-l-coco-ins", "bisenetformer-l-ade", "bisenetformer-m-ade", "fai-mf-m-ade"])
+def test_masked_decoder_row_chains_match_per_op_launches(monkeypatch, name):
+    """The decoder's row-local layers as fx_row_chain programs (engine_maskdec._masked_decoder_row_chains: from 1 000 rows on in production, i.e.
+    BiSeNetFormer bs >= 20 per part) against the one-launch-per-layer form AND the oracle at the test's small batch: MaskFormer-L (FFN of 2 048
+    hidden channels = two 1 024-channel halves), BiSeNetFormer-L, BiSeNetFormer-M (96-wide mask embedding padded to 128), fai-mf-m-ade (512-wide
+    FFN, three layers).  Attention masks teacher-forced, so both forms see the same discrete inputs."""
+    info = ModelRegistry.get_model_info(name)
+    cfg, fam = info["config"], info["model_family"]
+    sd = synth_state_dict(cfg, 9, family=fam)
+    h, w = 160, 192
+    images = [synth_image_structured(30 + i, h, w) for i in range(2)]
+    col = {}
+    with torch.no_grad():
+        if fam == "fai_mf":
+            probs_o, masks_o = M.mf_forward(sd, cfg, get_torch_batch(images, None), collect=col, upsample=False)
+        else:
+            probs_o, masks_o = BF.bf_forward(sd, cfg, get_torch_batch(images, None), collect=col, upsample=False)
+    x = torch.from_numpy(np.stack(images)).to(DEV)
+    outs = {}
+    for mode, min_rows in (("chains", "1"), ("per_op", "0")):
+        monkeypatch.setenv("FX_MASKDEC_ROW_CHAIN_MIN_ROWS", min_rows)
+        eng = (MfEngine if fam == "fai_mf" else BfEngine)(cfg, sd, device=DEV, full_masks=False)
+        pl = eng.forward(x, forced_attn=col["attn_masks"])
+        torch.cuda.synchronize()
+        n_chain = sum(1 for m in pl.meta.values() if m.get("variant") == "row_chain")
+        assert (n_chain == 2 * eng.nl + 1) if mode == "chains" else (n_chain == 0), (mode, n_chain)
+        outs[mode] = (pl.probs.cpu().clone(), pl.mask_probs.cpu().clone(),
+                      [pl.bufs[f"dec{i}.out"].torch_view().float().cpu().reshape(2, -1, 256).clone() for i in range(eng.nl)], int(pl.det_count.sum()))
+    (pc, mc, dc, nc_), (pp, mp, dp_, np_) = outs["chains"], outs["per_op"]
+    for i, (a, b) in enumerate(zip(dc, dp_)):
+        assert rel_l2(a, b) <= 1e-2, (i, rel_l2(a, b))                      # same arithmetic up to the order of fp32 sums and one bf16 rounding
+        assert rel_l2(a, col[f"dec{i}_out"]) <= max(3e-2, 1.5 * rel_l2(b, col[f"dec{i}_out"])), i
+    assert (pc - pp).abs().max() <= 2e-2 and (mc - mp).abs().mean() <= 2e-3
+    assert (mc - masks_o).abs().mean() <= max(1e-2, 1.5 * float((mp - masks_o).abs().mean()))
+    assert abs(nc_ - np_) <= 2
