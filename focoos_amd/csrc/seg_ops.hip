@@ -7,6 +7,7 @@
 //     pixel is assigned to the query maximising class score x upsampled mask probability - fused with the x8 bilinear
 //     upsample, so neither the [B,Q,H,W] probability tensor nor the [B,Q,H,W] boolean tensor is materialised.
 #include "common.h"
+int fx_tune(const char* env_name, int default_value);   // runtime.hip
 
 // ------------------------------------------------------------------------------------------------
 // y[b,ho,wo,c] = bias[c] + sum_{kh,kw} w[kh*3+kw][c] * x[b, 2ho-1+kh, 2wo-1+kw, c]   (zero padding; AvgPool2d's default
@@ -251,7 +252,7 @@ __device__ __forceinline__ void seg_stats_add(int32_t* cnt, int32_t* bx, float* 
 // to the generic kernel.
 template <int S, bool USE_SUM>
 __global__ __launch_bounds__(256) void seg_winner_cell_kernel(const float* __restrict__ lo, int h, int w, const float* __restrict__ score, int Q,
-                                                              uint8_t* __restrict__ winner, SegPartial* __restrict__ part, int nblk) {
+                                                              uint8_t* __restrict__ winner, SegPartial* __restrict__ part, int nblk, int skip) {
   __shared__ int32_t s_cnt[SEG_QMAX];
   __shared__ int32_t s_bx[SEG_QMAX * 4];
   __shared__ float s_sum[SEG_QMAX];
@@ -288,6 +289,11 @@ __global__ __launch_bounds__(256) void seg_winner_cell_kernel(const float* __res
     nx[0][0] = pb[o00]; nx[0][1] = pb[o01]; nx[0][2] = pb[o02];
     nx[1][0] = pb[o10]; nx[1][1] = pb[o11]; nx[1][2] = pb[o12];
     nx[2][0] = pb[o20]; nx[2][1] = pb[o21]; nx[2][2] = pb[o22];
+    // A query whose score x the largest of its nine window values cannot exceed the smallest running maximum of the cell is skipped: every
+    // output pixel is a convex combination of window values (weights w0 + w1 = 1 exactly, all dyadic), so its product with the score is at
+    // most sc * max9 up to two roundings - the 1e-6 margin covers them - and an update needs a STRICTLY larger value.  Same winner map, bit
+    // for bit; with trained weights most of the Q queries (low class score) leave after nine loads and ten VALU operations.
+    float bmin = -INFINITY;
 #pragma unroll 1
     for (int q = 0; q < Q; ++q) {
       const float sc = s_score[q];
@@ -302,6 +308,11 @@ __global__ __launch_bounds__(256) void seg_winner_cell_kernel(const float* __res
         nx[1][0] = p[o10]; nx[1][1] = p[o11]; nx[1][2] = p[o12];
         nx[2][0] = p[o20]; nx[2][1] = p[o21]; nx[2][2] = p[o22];
       }
+      {
+        const float m9 = fmaxf(fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[0][2], v[1][0])), fmaxf(fmaxf(fmaxf(v[1][1], v[1][2]), fmaxf(v[2][0], v[2][1])), v[2][2]));
+        if (skip && sc * m9 * 1.000001f <= bmin) continue;
+      }
+      bool touched = false;
       float rowi[3][S];   // x-interpolated window rows (ATen interpolates along x first; same operation order as lerp_taps)
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
@@ -321,8 +332,15 @@ __global__ __launch_bounds__(256) void seg_winner_cell_kernel(const float* __res
             best[r * S + c] = val;
             bidx[r * S + c] = (uint8_t)q;
             if (USE_SUM) bprob[r * S + c] = pr;
+            touched = true;
           }
         }
+      }
+      if (touched) {
+        float m = best[0];
+#pragma unroll
+        for (int k = 1; k < S * S; ++k) m = fminf(m, best[k]);
+        bmin = m;
       }
     }
     // winner map + statistics
@@ -490,14 +508,15 @@ extern "C" int fx_seg_postprocess(const float* mask_probs_lowres, int h, int w, 
   uint8_t* winner = winner_out ? winner_out : reinterpret_cast<uint8_t*>(workspace);
   SegPartial* part = reinterpret_cast<SegPartial*>(reinterpret_cast<uint8_t*>(workspace) + win_bytes);
   const int nblk = seg_blocks(h, w, H, W);
+  static const int skip = fx_tune("FX_SEG_SKIP", 1);   // A/B knob of the hopeless-query test in seg_winner_cell_kernel
 #define SEG_CELL(S)                                                                                                                        \
   do {                                                                                                                                     \
     if (use_mask_score)                                                                                                                    \
       hipLaunchKernelGGL((seg_winner_cell_kernel<S, true>), dim3(nblk, B), dim3(256), 0, stream, mask_probs_lowres, h, w, score, Q, winner, \
-                         part, nblk);                                                                                                      \
+                         part, nblk, skip);                                                                                                \
     else                                                                                                                                   \
       hipLaunchKernelGGL((seg_winner_cell_kernel<S, false>), dim3(nblk, B), dim3(256), 0, stream, mask_probs_lowres, h, w, score, Q,       \
-                         winner, part, nblk);                                                                                              \
+                         winner, part, nblk, skip);                                                                                        \
   } while (0)
   if (H == 8 * h && W == 8 * w && W % 4 == 0) SEG_CELL(8);
   else if (H == 4 * h && W == 4 * w) SEG_CELL(4);
