@@ -123,6 +123,8 @@ SIGNATURES = {
     "fx_conv2d_wgrad_bias_nhwc_bf16": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "fx_point_sample_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "fx_mask_match_cost_f32": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, C.c_float, C.c_float, _i, _vp, _vp],
+    "fx_mask_match_cost_workspace_bytes": [_i, _i, _i],
+    "fx_mask_match_cost_ws_f32": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, C.c_float, C.c_float, C.c_float, _i, _vp, _vp, C.c_size_t, _vp],
     "fx_mask_set_loss_workspace_bytes": [_i, _i, _i, _i],
     "fx_mask_set_loss_f32": [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, C.c_float, C.c_float,
                              C.c_float, C.c_float, C.c_float, _vp, C.c_size_t, _vp, _vp],
@@ -189,7 +191,7 @@ def lib_path() -> str:
     return os.environ.get("FOCOOS_AMD_LIB", LIB_PATH)
 
 
-FX_ABI_VERSION = 5   # = include/focoos_amd.h (tests/test_host_cpu.py compares the two)
+FX_ABI_VERSION = 6   # = include/focoos_amd.h (tests/test_host_cpu.py compares the two)
 
 
 def load() -> C.CDLL:
@@ -211,6 +213,7 @@ def load() -> C.CDLL:
         fn.restype = C.c_int
     lib.fx_mha_bwd_workspace_bytes.restype = C.c_size_t
     lib.fx_seg_postprocess_workspace_bytes.restype = C.c_size_t
+    lib.fx_mask_match_cost_workspace_bytes.restype = C.c_size_t
     lib.fx_mf_postprocess_workspace_bytes_fused.restype = C.c_size_t
     lib.fx_mask_set_loss_workspace_bytes.restype = C.c_size_t
     lib.fx_topk_rows_workspace_bytes.restype = C.c_size_t

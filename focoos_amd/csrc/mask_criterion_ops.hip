@@ -6,6 +6,7 @@
 // wrapper generates them on the device), so results are a pure function of the arguments.  fp32 arithmetic like the reference
 // (autocast is disabled there, loss.py:702), float64 for the final reductions, fixed summation order -> deterministic.
 #include "common.h"
+int fx_tune(const char* env_name, int default_value);   // runtime.hip
 
 // ATen's grid_sampler_compute_source_index (align_corners=False) applied to the wrapper's `2 * c - 1`: ((g + 1) * size - 1) / 2.
 __device__ __forceinline__ float ps_unnormalize(float c, int size) {
@@ -133,6 +134,158 @@ extern "C" int fx_mask_match_cost_f32(const float* logits, int ldl, const float*
   if ((size_t)P * sizeof(float) > 150 * 1024) return FX_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(mask_match_cost_kernel, dim3(Q, B), dim3(256), (size_t)P * sizeof(float), reinterpret_cast<hipStream_t>(stream_), logits, ldl,
                      pred_pts, tgt_pts, tgt_labels, tgt_offsets, Q, K, P, Tmax, w_class, w_mask, w_dice, cls_sigmoid, cost);
+  return fx_launch_status();
+}
+
+// The same cost blocks as two small fp32 GEMMs (round 4): per image  A[q][t] = sum_p x[q][p] tgt[t][p],  S[q][t] = sum_p sigmoid(x[q][p]) tgt[t][p]
+// over the shared points.  The kernel above is one workgroup per (image, query) that streams every target's P points for ITS query - 800
+// workgroups x T x 50 KB = 600 MB of L2 reads per prediction set, a sigmoid per (point, target), 245 us.  Here a workgroup owns 16 queries x
+// 16 targets x one slice of the points: 64-point tiles of x (+ sigmoid, softplus: computed once per point) and of the targets go through
+// LDS, thread (q, t) accumulates its three sums; slices are reduced in a fixed order by the finishing kernel (deterministic).
+#define MMC_QB 16
+#define MMC_TB 16
+#define MMC_PC 64
+#define MMC_NTB 4          // target blocks held in registers: Tmax <= 64 (above: the kernel above)
+__global__ __launch_bounds__(256) void mask_match_partial_kernel(const float* __restrict__ pred_pts, const float* __restrict__ tgt_pts,
+                                                                 const int32_t* __restrict__ tgt_offsets, int Q, int P, int Tmax, int nsplit,
+                                                                 float* __restrict__ part /*[B][nsplit][Q][3*Tmax + 2]*/) {
+  __shared__ float xsT[MMC_QB][MMC_PC + 1], sgT[MMC_QB][MMC_PC + 1], spT[MMC_QB][MMC_PC + 1], tgT[MMC_TB][MMC_PC + 1];
+  const int b = blockIdx.y, qb = blockIdx.x, sp_i = blockIdx.z;
+  const int t0 = tgt_offsets[b], T = tgt_offsets[b + 1] - t0;
+  const int tid = threadIdx.x, qi = tid >> 4, ti = tid & 15;
+  const int q = qb * MMC_QB + qi;
+  const int row = 3 * Tmax + 2;
+  float* out = part + (((int64_t)b * nsplit + sp_i) * Q + q) * row;
+  if (T == 0) return;
+  const int per = ((P + nsplit - 1) / nsplit + MMC_PC - 1) / MMC_PC * MMC_PC;
+  const int p_lo = sp_i * per, p_hi = min(P, p_lo + per);
+  float a[MMC_NTB], bs[MMC_NTB], st[MMC_NTB], SP = 0.0f, SG = 0.0f;
+#pragma unroll
+  for (int k = 0; k < MMC_NTB; ++k) a[k] = bs[k] = st[k] = 0.0f;
+  const int ntb = (T + MMC_TB - 1) / MMC_TB;
+  for (int p0 = p_lo; p0 < p_hi; p0 += MMC_PC) {
+    __syncthreads();
+    for (int e = tid; e < MMC_QB * MMC_PC; e += 256) {          // the 16 queries' points of this tile: logit, sigmoid, softplus
+      const int r = e / MMC_PC, c = e - r * MMC_PC;
+      const int qq = qb * MMC_QB + r, p = p0 + c;
+      float x = 0.0f, sx = 0.0f, px = 0.0f;
+      if (qq < Q && p < p_hi) {
+        x = pred_pts[((int64_t)b * Q + qq) * P + p];
+        sx = fx_sigmoid(x);
+        px = softplus_f(x);
+      }
+      xsT[r][c] = x; sgT[r][c] = sx; spT[r][c] = px;
+    }
+#pragma unroll
+    for (int k = 0; k < MMC_NTB; ++k) {
+      if (k >= ntb) break;
+      if (k > 0) __syncthreads();
+      for (int e = tid; e < MMC_TB * MMC_PC; e += 256) {
+        const int r = e / MMC_PC, c = e - r * MMC_PC;
+        const int t = k * MMC_TB + r, p = p0 + c;
+        tgT[r][c] = (t < T && p < p_hi) ? tgt_pts[(int64_t)(t0 + t) * P + p] : 0.0f;
+      }
+      __syncthreads();
+      float aa = a[k], bb = bs[k], ss = st[k];
+#pragma unroll 8
+      for (int c = 0; c < MMC_PC; ++c) {
+        const float tv = tgT[ti][c];
+        aa = fmaf(xsT[qi][c], tv, aa);
+        bb = fmaf(sgT[qi][c], tv, bb);
+        ss += tv;
+      }
+      a[k] = aa; bs[k] = bb; st[k] = ss;
+      if (k == 0 && ti == 0) {
+#pragma unroll 8
+        for (int c = 0; c < MMC_PC; ++c) SP += spT[qi][c], SG += sgT[qi][c];
+      }
+    }
+  }
+  if (q < Q) {
+#pragma unroll
+    for (int k = 0; k < MMC_NTB; ++k) {
+      const int t = k * MMC_TB + ti;
+      if (t < T) out[3 * t] = a[k], out[3 * t + 1] = bs[k], out[3 * t + 2] = st[k];
+    }
+    if (ti == 0) out[3 * Tmax] = SP, out[3 * Tmax + 1] = SG;
+  }
+}
+
+__global__ __launch_bounds__(256) void mask_match_finish_kernel(const float* __restrict__ logits, int ldl, const float* __restrict__ part, int nsplit,
+                                                                const int32_t* __restrict__ tgt_labels, const int32_t* __restrict__ tgt_offsets, int Q,
+                                                                int K, int P, int Tmax, float w_class, float w_mask, float w_dice, int cls_sigmoid,
+                                                                float* __restrict__ cost) {
+  // one wave per (image, query): class probabilities, then lane t finishes target t
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, q = blockIdx.x * 4 + wave;
+  if (q >= Q) return;
+  const int t0 = tgt_offsets[b], T = tgt_offsets[b + 1] - t0;
+  float* crow = cost + ((int64_t)b * Q + q) * Tmax;
+  for (int t = T + lane; t < Tmax; t += 64) crow[t] = 0.0f;
+  if (T == 0) return;
+  const float* lp = logits + ((int64_t)b * Q + q) * ldl;
+  float mx = 0.0f, inv = 1.0f;
+  if (!cls_sigmoid) {
+    mx = -INFINITY;
+    for (int c = lane; c <= K; c += 64) mx = fmaxf(mx, lp[c]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float se = 0.0f;
+    for (int c = lane; c <= K; c += 64) se += __expf(lp[c] - mx);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) se += __shfl_xor(se, o, 64);
+    inv = 1.0f / se;
+  }
+  const int row = 3 * Tmax + 2;
+  float SP = 0.0f, SG = 0.0f;
+  for (int s = 0; s < nsplit; ++s) {
+    const float* pr = part + (((int64_t)b * nsplit + s) * Q + q) * row;
+    SP += pr[3 * Tmax];
+    SG += pr[3 * Tmax + 1];
+  }
+  for (int t = lane; t < T; t += 64) {
+    float a = 0.0f, bs = 0.0f, st = 0.0f;
+    for (int s = 0; s < nsplit; ++s) {
+      const float* pr = part + (((int64_t)b * nsplit + s) * Q + q) * row;
+      a += pr[3 * t]; bs += pr[3 * t + 1]; st += pr[3 * t + 2];
+    }
+    const int lab = tgt_labels[t0 + t];
+    const float prob = cls_sigmoid ? fx_sigmoid(lp[lab]) : __expf(lp[lab] - mx) * inv;
+    const float c_mask = (SP - a) / (float)P;
+    const float c_dice = 1.0f - (2.0f * bs + 1.0f) / (SG + st + 1.0f);
+    crow[t] = w_mask * c_mask + w_class * (-prob) + w_dice * c_dice;
+  }
+}
+
+static int mmc_splits(int B, int Q) {
+  const int wgs = B * ((Q + MMC_QB - 1) / MMC_QB);
+  int s = (512 + wgs - 1) / wgs;     // ~2 workgroups per CU
+  return s < 1 ? 1 : (s > 16 ? 16 : s);
+}
+
+extern "C" size_t fx_mask_match_cost_workspace_bytes(int B, int Q, int Tmax) {
+  if (B <= 0 || Q <= 0 || Tmax <= 0 || Tmax > MMC_NTB * MMC_TB) return 0;
+  return (size_t)B * mmc_splits(B, Q) * Q * (3 * (size_t)Tmax + 2) * sizeof(float);
+}
+
+extern "C" int fx_mask_match_cost_f32(const float* logits, int ldl, const float* pred_pts, const float* tgt_pts, const int32_t* tgt_labels,
+                                      const int32_t* tgt_offsets, int B, int Q, int K, int P, int Tmax, float w_class, float w_mask, float w_dice,
+                                      int cls_sigmoid, float* cost, fx_stream_t stream_);
+
+extern "C" int fx_mask_match_cost_ws_f32(const float* logits, int ldl, const float* pred_pts, const float* tgt_pts, const int32_t* tgt_labels,
+                                         const int32_t* tgt_offsets, int B, int Q, int K, int P, int Tmax, float w_class, float w_mask, float w_dice,
+                                         int cls_sigmoid, float* cost, void* workspace, size_t workspace_bytes, fx_stream_t stream_) {
+  const size_t need = fx_mask_match_cost_workspace_bytes(B, Q, Tmax);
+  static const int tiled = fx_tune("FX_MASK_COST_TILED", 1);
+  if (!tiled || !workspace || need == 0 || workspace_bytes < need || ((uintptr_t)workspace % 16) != 0)
+    return fx_mask_match_cost_f32(logits, ldl, pred_pts, tgt_pts, tgt_labels, tgt_offsets, B, Q, K, P, Tmax, w_class, w_mask, w_dice, cls_sigmoid, cost, stream_);
+  FX_CHECK_ARG(logits && pred_pts && tgt_pts && tgt_labels && tgt_offsets && cost && B > 0 && Q > 0 && K > 0 && P > 0 && Tmax > 0 && ldl >= K + 1);
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  const int ns = mmc_splits(B, Q);
+  hipLaunchKernelGGL(mask_match_partial_kernel, dim3((Q + MMC_QB - 1) / MMC_QB, B, ns), dim3(256), 0, stream, pred_pts, tgt_pts, tgt_offsets, Q, P, Tmax, ns,
+                     reinterpret_cast<float*>(workspace));
+  hipLaunchKernelGGL(mask_match_finish_kernel, dim3((Q + 3) / 4, B), dim3(256), 0, stream, logits, ldl, reinterpret_cast<const float*>(workspace), ns, tgt_labels,
+                     tgt_offsets, Q, K, P, Tmax, w_class, w_mask, w_dice, cls_sigmoid, cost);
   return fx_launch_status();
 }
 

@@ -84,9 +84,11 @@ class MaskHungarianMatcher:
             check(lib.fx_point_sample_f32(tg.masks.data_ptr(), tg.is_u8, tg.H, tg.W, None, coords.data_ptr(), img_of_tgt.data_ptr(), tp.data_ptr(), tg.n, P,
                                           st), "fx_point_sample_f32")
             cost = torch.empty(B, Q, tg.tmax, dtype=torch.float32, device=dev)
-            check(lib.fx_mask_match_cost_f32(logits.data_ptr(), K1, pp.data_ptr(), tp.data_ptr(), tg.labels.data_ptr(), tg.offsets.data_ptr(), B, Q, K1 - 1,
-                                             P, tg.tmax, float(self.cost_class), float(self.cost_mask), float(self.cost_dice), int(self.cls_sigmoid),
-                                             cost.data_ptr(), st), "fx_mask_match_cost_f32")
+            nws = int(lib.fx_mask_match_cost_workspace_bytes(B, Q, tg.tmax))      # 0: more than 64 targets in one image - the untiled kernel
+            ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=dev)
+            check(lib.fx_mask_match_cost_ws_f32(logits.data_ptr(), K1, pp.data_ptr(), tp.data_ptr(), tg.labels.data_ptr(), tg.offsets.data_ptr(), B, Q, K1 - 1,
+                                                P, tg.tmax, float(self.cost_class), float(self.cost_mask), float(self.cost_dice), int(self.cls_sigmoid),
+                                                cost.data_ptr(), ws.data_ptr(), nws, st), "fx_mask_match_cost_ws_f32")
             from .criterion import lsa_status
 
             check(lib.fx_lsa_status_f32(cost.data_ptr(), B, Q, tg.tmax, tg.offsets.data_ptr(), pi.data_ptr(), ti.data_ptr(), lsa_status(dev).data_ptr(), st),

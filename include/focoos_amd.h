@@ -29,7 +29,7 @@ extern "C" {
 /* Bumped whenever a descriptor struct's layout OR the semantics the host relies on change (version 2: fx_conv_desc grew mask / ldm /
  * reserved0 and the library applies the ReLU mask the previous bottleneck skips; version 3: fx_pw_chain_desc grew pool / ldp / img_h / img_w);
  * focoos_amd/_lib.py refuses a library of another version. */
-#define FX_ABI_VERSION 5
+#define FX_ABI_VERSION 6
 
 enum { FX_OK = 0, FX_ERR_INVALID_ARGUMENT = -1, FX_ERR_LAUNCH = -2, FX_ERR_UNSUPPORTED = -3, FX_ERR_RUNTIME = -4 };
 enum { FX_ACT_NONE = 0, FX_ACT_RELU = 1, FX_ACT_SILU = 2, FX_ACT_GELU = 3 };
@@ -336,6 +336,13 @@ int fx_point_sample_f32(const void* src, int src_is_u8, int H, int W, const int3
 int fx_mask_match_cost_f32(const float* logits, int ldl, const float* pred_pts, const float* tgt_pts, const int32_t* tgt_labels,
                            const int32_t* tgt_offsets, int B, int Q, int K, int P, int Tmax, float w_class, float w_mask, float w_dice,
                            int cls_sigmoid, float* cost, fx_stream_t stream);
+/* The same cost blocks computed as tiled fp32 GEMMs over the points (16 queries x 16 targets x a slice of the points per workgroup; slices reduced
+ * in a fixed order: deterministic) when given fx_mask_match_cost_workspace_bytes() bytes of 16-byte aligned scratch and Tmax <= 64; otherwise
+ * identical to fx_mask_match_cost_f32.  Sums are accumulated in a different order than there (agreement ~1e-6 relative). */
+size_t fx_mask_match_cost_workspace_bytes(int B, int Q, int Tmax);
+int fx_mask_match_cost_ws_f32(const float* logits, int ldl, const float* pred_pts, const float* tgt_pts, const int32_t* tgt_labels,
+                              const int32_t* tgt_offsets, int B, int Q, int K, int P, int Tmax, float w_class, float w_mask, float w_dice,
+                              int cls_sigmoid, float* cost, void* workspace, size_t workspace_bytes, fx_stream_t stream);
 
 /* SetCriterion.loss_labels (ce_loss branch, :411-431) + loss_masks (:463-523) of one prediction set: out3 = {w_ce * loss_ce,
  * w_mask * loss_mask, w_dice * loss_dice}.  pred_masks f32 [B,Q,h,w] (logits), tgt_masks f32 or u8 [sumT,H,W], matches as written

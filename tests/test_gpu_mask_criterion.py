@@ -150,3 +150,35 @@ def test_default_random_points_and_determinism():
     ref, _ = MC.criterion(out, labels, masks, MC.RandStream(draws), 80, P)
     for k in ref:
         assert abs(a[k] - float(ref[k])) <= 0.05 * abs(float(ref[k])) + 1e-3, (k, a[k], float(ref[k]))
+
+
+@pytest.mark.parametrize("shape", [(2, 100, 1000, (3, 5)), (3, 37, 777, (0, 21, 40)), (1, 100, 12544, (64,)), (2, 20, 500, (70, 2))])
+def test_match_cost_tiled_equals_untiled(shape):
+    """fx_mask_match_cost_ws_f32 (16 queries x 16 targets x point slices per workgroup, slices reduced in a fixed order) against
+    fx_mask_match_cost_f32 (one workgroup per query) on ragged shapes: an image without targets, more than 16 and more than 32 targets (several
+    target blocks in registers), point counts that are not multiples of the 64-point tile, and more than 64 targets in one image (the ws
+    variant then reports a zero workspace and runs the untiled kernel).  Agreement to the order of fp32 sums."""
+    lib = _lib.load()
+    B, Q, P, counts = shape
+    K = 20
+    g = torch.Generator().manual_seed(B * 1000 + Q)
+    logits = torch.randn(B, Q, K + 1, generator=g).to(DEV)
+    pp = (torch.randn(B * Q, P, generator=g) * 3).to(DEV)
+    n = sum(counts)
+    tp = (torch.rand(n, P, generator=g) > 0.6).float().to(DEV)
+    labels = torch.randint(0, K, (n,), generator=g, dtype=torch.int32).to(DEV)
+    off = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int32, device=DEV)
+    tmax = max(max(counts), 1)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    c0 = torch.full((B, Q, tmax), float("nan"), device=DEV)
+    c1 = torch.full((B, Q, tmax), float("nan"), device=DEV)
+    check(lib.fx_mask_match_cost_f32(logits.data_ptr(), K + 1, pp.data_ptr(), tp.data_ptr(), labels.data_ptr(), off.data_ptr(), B, Q, K, P, tmax, 2.0, 5.0, 5.0, 0,
+                                     c0.data_ptr(), st))
+    nws = int(lib.fx_mask_match_cost_workspace_bytes(B, Q, tmax))
+    assert (nws == 0) == (tmax > 64)
+    ws = torch.full((max(nws, 16),), 0x7F, dtype=torch.uint8, device=DEV)
+    check(lib.fx_mask_match_cost_ws_f32(logits.data_ptr(), K + 1, pp.data_ptr(), tp.data_ptr(), labels.data_ptr(), off.data_ptr(), B, Q, K, P, tmax, 2.0, 5.0, 5.0,
+                                        0, c1.data_ptr(), ws.data_ptr(), nws, st))
+    torch.cuda.synchronize()
+    assert torch.isfinite(c1).all()
+    np.testing.assert_allclose(c1.cpu().numpy(), c0.cpu().numpy(), rtol=2e-5, atol=2e-5)
