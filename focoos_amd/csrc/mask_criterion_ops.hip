@@ -493,6 +493,67 @@ __global__ __launch_bounds__(256) void mask_point_loss_bwd_kernel(const float* _
   }
 }
 
+// The same gradient with the plane accumulated in LDS (round 4): the kernel above spends its time in four scattered fp32 atomics per point on
+// L2 (BiSeNetFormer 8 x ~10 pairs x 12 544 points: 200 us; caching the target values changed nothing).  Here a workgroup owns a band of rows
+// of ONE pair's [h, w] plane (<= 64 KiB of fp32: the whole 128 x 128 plane of BiSeNetFormer at 1024^2, two or three bands of MaskFormer's
+// 200 x 200), walks all the pair's points, adds the taps that fall into its band with LDS atomics and stores the band once (a prediction
+// is matched to at most one target, so its plane has ONE writer: plain stores over the caller's zeros).
+#define MPB_THREADS 1024
+#define MPB_LDS_FLOATS 16384
+__global__ __launch_bounds__(MPB_THREADS) void mask_point_loss_bwd_lds_kernel(const float* __restrict__ pred_masks, int h, int w, const void* __restrict__ tgt_masks,
+                                                                              int tgt_is_u8, int H, int W, const int32_t* __restrict__ tgt_offsets, int B, int Q,
+                                                                              const int32_t* __restrict__ pred_idx, const int32_t* __restrict__ tgt_idx,
+                                                                              const float* __restrict__ rand_over, int n_over, const float* __restrict__ rand_extra,
+                                                                              int n_extra, int k_imp, const double* __restrict__ rows,
+                                                                              const float* __restrict__ xs_all, const uint8_t* __restrict__ sel_all, float c_bce,
+                                                                              float c_dice, const float* __restrict__ g3, float* __restrict__ dmasks, int band_rows) {
+  extern __shared__ float plane[];   // [band_rows][w]
+  const int n = blockIdx.x, r0 = blockIdx.y * band_rows, r1 = min(h, r0 + band_rows), tid = threadIdx.x;
+  int b = 0;
+  while (b + 1 < B && tgt_offsets[b + 1] <= n) ++b;
+  const int q = pred_idx[n];
+  const float* pm = pred_masks + ((int64_t)b * Q + q) * h * w;
+  const int64_t toff = (int64_t)(tgt_offsets[b] + tgt_idx[n]) * H * W;
+  const uint8_t* tm8 = reinterpret_cast<const uint8_t*>(tgt_masks) + toff;
+  const float* tmf = reinterpret_cast<const float*>(tgt_masks) + toff;
+  const int nband = (r1 - r0) * w;
+  for (int i = tid; i < nband; i += MPB_THREADS) plane[i] = 0.0f;
+  __syncthreads();
+  const double ST = rows[(int64_t)n * 4 + 1], D = rows[(int64_t)n * 4 + 2] + rows[(int64_t)n * 4 + 3] + 1.0;
+  const float dice_a = (float)(-2.0 / D), dice_b = (float)((2.0 * ST + 1.0) / (D * D));
+  const float g_bce = g3[1] * c_bce, g_dice = g3[2] * c_dice;
+  auto point = [&](bool have_x, float x_in, float cx, float cy) {
+    // taps of the point in the prediction plane (ps_scatter's arithmetic); nothing to do if none lies in this band
+    const float ix = ps_unnormalize(cx, w), iy = ps_unnormalize(cy, h);
+    const float fx = floorf(ix), fy = floorf(iy);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const bool ya = y0 >= r0 && y0 < r1, yb = y0 + 1 >= r0 && y0 + 1 < r1;
+    if (!ya && !yb) return;
+    const float x = have_x ? x_in : ps_sample(pm, h, w, cx, cy);
+    const float t = tgt_is_u8 ? ps_sample(tm8, H, W, cx, cy) : ps_sample(tmf, H, W, cx, cy);
+    const float s = 1.0f / (1.0f + expf(-x));
+    const float v = g_bce * (s - t) + g_dice * (s * (1.0f - s)) * (dice_a * t + dice_b);
+    const float wx = ix - fx, ex = 1.0f - wx, ny = iy - fy, sy = 1.0f - ny;
+    const bool xa = x0 >= 0 && x0 < w, xb = x0 + 1 >= 0 && x0 + 1 < w;
+    if (ya && xa) atomicAdd(&plane[(y0 - r0) * w + x0], v * (ex * sy));
+    if (ya && xb) atomicAdd(&plane[(y0 - r0) * w + x0 + 1], v * (wx * sy));
+    if (yb && xa) atomicAdd(&plane[(y0 + 1 - r0) * w + x0], v * (ex * ny));
+    if (yb && xb) atomicAdd(&plane[(y0 + 1 - r0) * w + x0 + 1], v * (wx * ny));
+  };
+  if (k_imp > 0) {
+    const float* ro = rand_over + (int64_t)n * n_over * 2;
+    const float* xs = xs_all + (int64_t)n * n_over;
+    const uint8_t* sel = sel_all + (int64_t)n * n_over;
+    for (int i = tid; i < n_over; i += MPB_THREADS)
+      if (sel[i]) point(true, xs[i], ro[2 * i], ro[2 * i + 1]);
+  }
+  const float* re = rand_extra + (int64_t)n * n_extra * 2;
+  for (int i = tid; i < n_extra; i += MPB_THREADS) point(false, 0.0f, re[2 * i], re[2 * i + 1]);
+  __syncthreads();
+  float* gband = dmasks + ((int64_t)b * Q + q) * h * w + (int64_t)r0 * w;
+  for (int i = tid; i < nband; i += MPB_THREADS) gband[i] = plane[i];
+}
+
 __global__ __launch_bounds__(256) void mask_loss_final_kernel(const double* __restrict__ ce_partial, int n_rows, const double* __restrict__ rows, int N,
                                                               int num_points, float num_masks, float w_ce, float w_mask, float w_dice,
                                                               float* __restrict__ out3, double* __restrict__ wsum_out) {
@@ -607,6 +668,22 @@ extern "C" int fx_mask_set_loss_bwd_f32(const float* logits, int ldl, const floa
     const float c_bce = w_mask / (num_masks * (float)num_points), c_dice = w_dice / num_masks;
     const float* xs = reinterpret_cast<const float*>(rows + (size_t)sum_T * 4 + 1);
     const uint8_t* sel = reinterpret_cast<const uint8_t*>(xs + (size_t)sum_T * n_over);
+    static const int lds_on = fx_tune("FX_MPL_BWD_LDS", 1);
+    if (lds_on && w <= MPB_LDS_FLOATS) {
+      const int band_rows = min(h, MPB_LDS_FLOATS / w);
+      const int nbands = (h + band_rows - 1) / band_rows;
+      const size_t smem = (size_t)band_rows * w * sizeof(float);
+      static size_t attr_smem = 0;
+      if (smem > attr_smem) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(mask_point_loss_bwd_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
+          return FX_ERR_RUNTIME;
+        attr_smem = smem;
+      }
+      hipLaunchKernelGGL(mask_point_loss_bwd_lds_kernel, dim3(sum_T, nbands), dim3(MPB_THREADS), smem, stream, pred_masks, h, w, tgt_masks, tgt_is_u8, H, W,
+                         tgt_offsets, B, Q, pred_idx, tgt_idx, rand_over, n_over, rand_extra, n_extra, num_points - n_extra, rows, xs, sel, c_bce, c_dice, grad3,
+                         dmasks, band_rows);
+      return fx_launch_status();
+    }
     const int split = sum_T >= 256 ? 2 : (sum_T >= 64 ? 8 : 16);   // >= 512 workgroups
     hipLaunchKernelGGL(mask_point_loss_bwd_kernel, dim3(sum_T, split), dim3(256), 0, stream, pred_masks, h, w, tgt_masks, tgt_is_u8, H, W, tgt_offsets, B, Q,
                        pred_idx, tgt_idx, rand_over, n_over, rand_extra, n_extra, num_points - n_extra, rows, xs, sel, c_bce, c_dice, grad3, dmasks);

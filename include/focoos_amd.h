@@ -676,7 +676,8 @@ int fx_graph_time(void* graph_exec, fx_stream_t stream, int iters, float* ms_avg
  * 463-523 == bisenetformer/loss.py): same arguments plus the forward's workspace (pair sums and CE weight sum are read from it),
  * grad3 f32 [3] ON THE DEVICE = upstream gradients of (loss_ce, loss_mask, loss_dice); writes dlogits f32 [B,Q,lddl] (all K+1
  * columns of every row) and ACCUMULATES into dmasks f32 [B,Q,h,w] (zero-initialised by the caller; only the planes of matched
- * queries are touched).  The point selection is recomputed (deterministic); sample coordinates carry no gradient. */
+ * queries are touched).  The point selection is recomputed (deterministic); sample coordinates carry no gradient.  pred_idx must not repeat within an image (a Hungarian matching never does): each matched
+ * plane has one writer (the gradient is accumulated in LDS per plane band and stored, not added). */
 int fx_mask_set_loss_bwd_f32(const float* logits, int ldl, const float* pred_masks, int h, int w, const void* tgt_masks, int tgt_is_u8, int H, int W,
                              const int32_t* tgt_labels, const int32_t* tgt_offsets, int sum_T, const int32_t* pred_idx, const int32_t* tgt_idx,
                              const float* rand_over, int n_over, const float* rand_extra, int n_extra, int num_points, int B, int Q, int K,
