@@ -250,9 +250,9 @@ __device__ __forceinline__ void seg_stats_add(int32_t* cnt, int32_t* bx, float* 
 // (cell, cell+1) with lambda (r+.5)/S - .5 otherwise; at the first cell the source clamps to 0 (weights 1, 0) and at the
 // last the right tap clamps onto the cell - exactly seg_lerp_axis, all values exact in fp32, so the result is bit-identical
 // to the generic kernel.
-template <int S, bool USE_SUM>
+template <int S, bool USE_SUM, bool SKIP>
 __global__ __launch_bounds__(256) void seg_winner_cell_kernel(const float* __restrict__ lo, int h, int w, const float* __restrict__ score, int Q,
-                                                              uint8_t* __restrict__ winner, SegPartial* __restrict__ part, int nblk, int skip) {
+                                                              uint8_t* __restrict__ winner, SegPartial* __restrict__ part, int nblk) {
   __shared__ int32_t s_cnt[SEG_QMAX];
   __shared__ int32_t s_bx[SEG_QMAX * 4];
   __shared__ float s_sum[SEG_QMAX];
@@ -294,7 +294,9 @@ __global__ __launch_bounds__(256) void seg_winner_cell_kernel(const float* __res
     // most sc * max9 up to two roundings - the 1e-6 margin covers them - and an update needs a STRICTLY larger value.  Same winner map, bit
     // for bit; with trained weights most of the Q queries (low class score) leave after nine loads and ten VALU operations.
     // bmin is refreshed only every eighth query (63 fmin per refresh): the running maxima only grow, so a stale bmin is a valid - merely
-    // weaker - bound (a refresh after every touched query cost more than the test saved on random-weight inputs: 0.26 -> 0.40 ms per part).
+    // weaker - bound.  SKIP is a template parameter, not a kernel argument: with the test compiled in, the loop costs 0.40 instead of
+    // 0.26 ms per part on inputs where nothing can be skipped (random weights - every query competitive), whatever the runtime flag says
+    // (register allocation / loop shape; measured with the pre-test kernel linked in, profiles/r04_wgrad_table_after.txt).
     float bmin = -INFINITY;
     bool touched = false;
 #pragma unroll 1
@@ -311,9 +313,9 @@ __global__ __launch_bounds__(256) void seg_winner_cell_kernel(const float* __res
         nx[1][0] = p[o10]; nx[1][1] = p[o11]; nx[1][2] = p[o12];
         nx[2][0] = p[o20]; nx[2][1] = p[o21]; nx[2][2] = p[o22];
       }
-      {
+      if constexpr (SKIP) {
         const float m9 = fmaxf(fmaxf(fmaxf(v[0][0], v[0][1]), fmaxf(v[0][2], v[1][0])), fmaxf(fmaxf(fmaxf(v[1][1], v[1][2]), fmaxf(v[2][0], v[2][1])), v[2][2]));
-        if (skip && sc * m9 * 1.000001f <= bmin) continue;
+        if (sc * m9 * 1.000001f <= bmin) continue;
       }
       float rowi[3][S];   // x-interpolated window rows (ATen interpolates along x first; same operation order as lerp_taps)
 #pragma unroll
@@ -334,11 +336,11 @@ __global__ __launch_bounds__(256) void seg_winner_cell_kernel(const float* __res
             best[r * S + c] = val;
             bidx[r * S + c] = (uint8_t)q;
             if (USE_SUM) bprob[r * S + c] = pr;
-            touched = true;
+            if constexpr (SKIP) touched = true;
           }
         }
       }
-      if (skip && touched && (q & 7) == 7) {
+      if constexpr (SKIP) if (touched && (q & 7) == 7) {
         float m = best[0];
 #pragma unroll
         for (int k = 1; k < S * S; ++k) m = fminf(m, best[k]);
@@ -511,15 +513,16 @@ extern "C" int fx_seg_postprocess(const float* mask_probs_lowres, int h, int w, 
   uint8_t* winner = winner_out ? winner_out : reinterpret_cast<uint8_t*>(workspace);
   SegPartial* part = reinterpret_cast<SegPartial*>(reinterpret_cast<uint8_t*>(workspace) + win_bytes);
   const int nblk = seg_blocks(h, w, H, W);
-  static const int skip = fx_tune("FX_SEG_SKIP", 1);   // A/B knob of the hopeless-query test in seg_winner_cell_kernel
+  // the hopeless-query test of seg_winner_cell_kernel: pays when most queries carry a small class score (trained weights), costs 0.14 ms
+  // per 16-image part when none does (the random-weight bench) - default from the measurement, see scripts/dev/seg_skip_bench.py
+  const int skip = fx_tune("FX_SEG_SKIP", 0);   // read per call (capture time under a graph): tests flip it in-process
+#define SEG_LAUNCH(S, SUM, SK)                                                                                                             \
+  hipLaunchKernelGGL((seg_winner_cell_kernel<S, SUM, SK>), dim3(nblk, B), dim3(256), 0, stream, mask_probs_lowres, h, w, score, Q, winner, \
+                     part, nblk)
 #define SEG_CELL(S)                                                                                                                        \
   do {                                                                                                                                     \
-    if (use_mask_score)                                                                                                                    \
-      hipLaunchKernelGGL((seg_winner_cell_kernel<S, true>), dim3(nblk, B), dim3(256), 0, stream, mask_probs_lowres, h, w, score, Q, winner, \
-                         part, nblk, skip);                                                                                                \
-    else                                                                                                                                   \
-      hipLaunchKernelGGL((seg_winner_cell_kernel<S, false>), dim3(nblk, B), dim3(256), 0, stream, mask_probs_lowres, h, w, score, Q,       \
-                         winner, part, nblk, skip);                                                                                        \
+    if (use_mask_score) { if (skip) SEG_LAUNCH(S, true, true); else SEG_LAUNCH(S, true, false); }                                          \
+    else { if (skip) SEG_LAUNCH(S, false, true); else SEG_LAUNCH(S, false, false); }                                                       \
   } while (0)
   if (H == 8 * h && W == 8 * w && W % 4 == 0) SEG_CELL(8);
   else if (H == 4 * h && W == 4 * w) SEG_CELL(4);
@@ -530,6 +533,7 @@ extern "C" int fx_seg_postprocess(const float* mask_probs_lowres, int h, int w, 
     hipLaunchKernelGGL(seg_winner_generic_kernel<false>, dim3(nblk, B), dim3(256), 0, stream, mask_probs_lowres, h, w, H, W, (float)h / (float)H,
                        (float)w / (float)W, score, Q, winner, part, nblk);
 #undef SEG_CELL
+#undef SEG_LAUNCH
   hipLaunchKernelGGL(seg_select_kernel, dim3(B), dim3(128), 0, stream, part, nblk, score, label, Q, threshold, use_mask_score, det_count,
                      det_query, det_score, det_label, det_box, det_area);
   if (mask_words) {

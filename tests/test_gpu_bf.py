@@ -142,9 +142,12 @@ def _blob_probs(B, Q, h, w, seed):
 
 @pytest.mark.parametrize("cfg", [(2, 100, 20, 24, 8), (1, 37, 9, 12, 8), (2, 50, 16, 16, 4), (1, 100, 20, 32, 1), (1, 30, 11, 13, 0)])
 @pytest.mark.parametrize("use_mask_score", [False, True])
-def test_seg_postprocess_vs_oracle(lib, cfg, use_mask_score):
+@pytest.mark.parametrize("skip", [0, 1])
+def test_seg_postprocess_vs_oracle(lib, cfg, use_mask_score, skip, monkeypatch):
     """fx_seg_postprocess (x8 / x4 cell kernels, scale 1 and a non-integer scale through the generic kernel) vs the oracle's
-    restatement of BisenetFormerProcessor.postprocess (predict_all_pixels=True) on the kernel-independent F.interpolate output."""
+    restatement of BisenetFormerProcessor.postprocess (predict_all_pixels=True) on the kernel-independent F.interpolate output.  Both
+    instantiations of the cell kernel: without and with the hopeless-query test (FX_SEG_SKIP, read per call) - same winner map bit for bit."""
+    monkeypatch.setenv("FX_SEG_SKIP", str(skip))
     B, Q, h, w, S = cfg
     H, W = (S * h, S * w) if S else (96, 128)
     lo, probs = _blob_probs(B, Q, h, w, 7 + S)
