@@ -42,6 +42,8 @@ class MLP(nn.Module):
 
 
 INV_SIGMOID_EPS = 1e-5   # focoos/nn/layers/functional.py:4
+# encoder score / box heads of the training graph on the selected rows only (TransformerPredictor.forward); 0: over all tokens, then gather
+SELECT_ROWS = [os.environ.get("FX_ENC_SELECT_ROWS", "1") != "0"]
 RAW_MSDA = [os.environ.get("FX_MSDA_RAW", "1") != "0"]   # decoder cross-attention from the raw projections (train._MSDAGroupRawFunction); 0: the torch-op form
 
 
@@ -158,6 +160,7 @@ class TransformerPredictor(nn.Module):
         self._anchor_cache = {}
         self._value_group = _PackedLinearGroup()   # the six value projections as one GEMM (what the inference plan calls value_all)
         self._sink = None
+        self._sel_state = None
 
     def _anchors(self, shapes, dev, grid_size=0.05, eps=1e-2):
         key = (tuple(shapes), dev)
@@ -174,22 +177,73 @@ class TransformerPredictor(nn.Module):
             self._anchor_cache[key] = (a.to(dev), valid.to(dev))
         return self._anchor_cache[key]
 
+    def _selection_scores(self, memory: torch.Tensor, valid: torch.Tensor) -> torch.Tensor:
+        """max over the classes of enc_score_classifier(enc_output(valid * memory)) for every token, f32 [B, S] (no gradient).  The fused
+        launch needs 256 channels and <= 384 classes; other shapes take the layers one by one."""
+        B, S, c = memory.shape
+        lin, norm, cls = self.enc_output._a, self.enc_output._b, self.enc_score_classifier
+        ncp = (self.nc + 127) // 128 * 128
+        if c != 256 or ncp > 384:
+            om = norm(lin(memory * valid.to(memory.dtype)))
+            return cls(om).float().max(-1).values
+        lib, dev = self.lib, memory.device
+        lin._pack.sync(lib, lin.weight, lin.bias, 0, c)
+        cls._pack.sync(lib, cls.weight, cls.bias, 0, self.nc)
+        st = self._sel_state
+        ver = (lin._pack.ver, cls._pack.ver)
+        if st is None or st["dev"] != dev:
+            st = self._sel_state = {"dev": dev, "ver": None, "w2_frag": torch.empty(ncp * c, dtype=torch.bfloat16, device=dev),
+                                    "b2": torch.full((ncp,), -3e38, dtype=torch.float32, device=dev),
+                                    "valid": valid.view(-1).to(torch.uint8).contiguous()}
+        # once per optimizer step: the class weights in fragment order, the bias with -3e38 in the padding (inside a capture always - the
+        # launches must be part of the graph that replays the step)
+        if st["ver"] != ver or torch.cuda.is_current_stream_capturing():
+            assert cls._pack.w_fwd.numel() == ncp * c   # the bf16 image is already [ncp, 256] with zero padding rows
+            check(lib.fx_pack_frag_bf16(cls._pack.w_fwd.data_ptr(), st["w2_frag"].data_ptr(), ncp, c, _stream(dev)), "fx_pack_frag_bf16")
+            st["b2"][: self.nc].copy_(cls.bias.detach())
+            st["ver"] = ver
+        if st["valid"].numel() != S:
+            st["valid"] = valid.view(-1).to(torch.uint8).contiguous()
+        mem = memory.contiguous()
+        om = torch.empty(B * S, c, dtype=torch.bfloat16, device=dev)
+        scores = torch.empty(B, S, dtype=torch.float32, device=dev)
+        check(lib.fx_enc_score_head_bf16(mem.data_ptr(), c, st["valid"].data_ptr(), S, lin._pack.w_fwd_frag.data_ptr(), lin.bias.data_ptr(),
+                                         norm.weight.data_ptr(), norm.bias.data_ptr(), C.c_float(1e-5), st["w2_frag"].data_ptr(), st["b2"].data_ptr(),
+                                         ncp, om.data_ptr(), c, scores.data_ptr(), B * S, _stream(dev)), "fx_enc_score_head_bf16")
+        return scores
+
     def forward(self, feats: List[torch.Tensor], forced_topk: Optional[torch.Tensor] = None):
         B = feats[0].shape[0]
         proj = [p(f) for p, f in zip(self.input_proj, feats)]
         shapes = [(t.shape[1], t.shape[2]) for t in proj]
         memory = torch.cat([t.reshape(B, -1, self.c) for t in proj], 1)  # [B, S, 256]
         anchors, valid = self._anchors(shapes, memory.device)
-        mem_v = memory * valid.to(memory.dtype)
-        output_memory = self.enc_output(mem_v)
-        enc_class = self.enc_score_classifier(output_memory)                    # [B, S, nc] bf16
-        enc_coord_unact = self.enc_bbox_classifier(output_memory).float() + anchors
-        with torch.no_grad():
-            topk_ind = torch.topk(enc_class.float().max(-1).values, self.nq, dim=1).indices if forced_topk is None else forced_topk
-        ref_unact = enc_coord_unact.gather(1, topk_ind.unsqueeze(-1).expand(-1, -1, 4))
+        if not SELECT_ROWS[0]:
+            # the reference's literal order (modelling.py:1202-1232): both heads over all S tokens, then the gathers - kept switchable as the
+            # A/B form of the row-selected path below (tests/test_gpu_train_detr.py::test_encoder_heads_on_selected_rows_equal_all_rows)
+            mem_v = memory * valid.to(memory.dtype)
+            output_memory = self.enc_output(mem_v)
+            enc_class = self.enc_score_classifier(output_memory)                    # [B, S, nc] bf16
+            enc_coord_unact = self.enc_bbox_classifier(output_memory).float() + anchors
+            with torch.no_grad():
+                topk_ind = torch.topk(enc_class.float().max(-1).values, self.nq, dim=1).indices if forced_topk is None else forced_topk
+            ref_unact = enc_coord_unact.gather(1, topk_ind.unsqueeze(-1).expand(-1, -1, 4))
+            enc_topk_logits = enc_class.gather(1, topk_ind.unsqueeze(-1).expand(-1, -1, self.nc))
+            target = output_memory.gather(1, topk_ind.unsqueeze(-1).expand(-1, -1, self.c)).detach()
+        else:
+            # Every operation between `memory` and the three gathers is ROW-LOCAL (mask, Linear, LayerNorm, Linear / MLP) and only the nq selected
+            # rows of an image reach a loss, so the gathers commute with them: the selection scores of all S tokens come from the inference
+            # plan's fused launch (fx_enc_score_head_bf16: enc_output -> enc_score -> max, no [B,S,nc] tensor, nothing saved), and the
+            # differentiable heads run on the [B, nq] selected rows - same values, same gradients (rows that are not selected have zero
+            # gradient in the reference's graph too), 1/28 of the rows in the forward and the backward of four layers.
+            with torch.no_grad():
+                topk_ind = torch.topk(self._selection_scores(memory, valid), self.nq, dim=1).indices if forced_topk is None else forced_topk
+            sel = memory.gather(1, topk_ind.unsqueeze(-1).expand(-1, -1, self.c)) * valid.view(-1)[topk_ind].unsqueeze(-1).to(memory.dtype)
+            output_sel = self.enc_output(sel)                                       # [B, nq, 256]
+            enc_topk_logits = self.enc_score_classifier(output_sel)
+            ref_unact = self.enc_bbox_classifier(output_sel).float() + anchors[topk_ind]
+            target = output_sel.detach()
         enc_topk_bboxes = torch.sigmoid(ref_unact)
-        enc_topk_logits = enc_class.gather(1, topk_ind.unsqueeze(-1).expand(-1, -1, self.nc))
-        target = output_memory.gather(1, topk_ind.unsqueeze(-1).expand(-1, -1, self.c)).detach()
         out = target
         ref_detach = torch.sigmoid(ref_unact.detach())
         ref = ref_detach

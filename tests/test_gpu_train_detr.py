@@ -281,3 +281,51 @@ def test_train_step_graph_equals_eager(norm):
         assert torch.allclose(l_graph, l_eager, rtol=2e-4, atol=1e-5), (l_graph, l_eager)
     else:
         assert abs(float(l_graph.sum() - l_eager.sum())) <= 3e-2 * float(l_eager.sum()), (l_graph, l_eager)
+
+
+def test_encoder_heads_on_selected_rows_equal_all_rows():
+    """TransformerPredictor runs the encoder's score / box heads (and enc_output) on the 300 selected rows of an image, with the selection
+    scores of all tokens from the inference plan's fused launch; the reference computes both heads over all tokens and gathers
+    (fai_detr/modelling.py:1202-1232).  The operations are row-local, so the two orders must agree: the same selection when free-running
+    (the fused launch feeds its LayerNorm and class scores from fp32 accumulators, the layer-by-layer form rounds to bf16 in between - a
+    few borderline tokens may swap), and with the selection fixed the same losses and the same gradients - including the gradient that
+    reaches `memory` and, through it, the encoder and the backbone."""
+    from focoos_amd import train_detr as TD
+
+    cfg = ModelRegistry.get_model_info("fai-detr-l-coco")["config"]
+    sd = synth_state_dict(cfg, 5)
+    imgs = [synth_image_structured(40 + i, 256, 320) for i in range(2)]
+    labels, boxes = T.synth_targets(3, 2, 80, counts=(5, 3))
+    targets = [DETRTargets(labels=l.to(DEV), boxes=b.to(DEV)) for l, b in zip(labels, boxes)]
+    x_u8 = torch.from_numpy(np.stack(imgs)).to(DEV)
+    res = {}
+    prev = TD.SELECT_ROWS[0]
+    try:
+        for mode in (False, True):
+            TD.SELECT_ROWS[0] = mode
+            model = TD.FAIDetrTrainable(cfg, norm="FrozenBN").to(DEV)
+            model.load_state_dict(sd, strict=True)
+            with torch.no_grad():
+                free = model.forward_outputs(x_u8)["topk_ind"]
+            forced = res[False]["free"] if mode else free
+            out = model.forward_outputs(x_u8, forced)
+            losses = model.head.criterion(out, targets, res[False]["matches"] if mode else None)
+            matches = model.head.criterion.last_matches if hasattr(model.head.criterion, "last_matches") else None
+            sum(losses.values()).backward()
+            torch.cuda.synchronize()
+            res[mode] = {"free": free, "losses": {k: float(v) for k, v in losses.items()}, "matches": matches,
+                         "grads": {n: p.grad.float().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}}
+    finally:
+        TD.SELECT_ROWS[0] = prev
+    a, b = res[False], res[True]
+    same = [len(set(a["free"][i].tolist()) & set(b["free"][i].tolist())) for i in range(2)]
+    print("free-running selection overlap:", same)
+    assert min(same) >= 285, same
+    if a["matches"] is not None:
+        for k in a["losses"]:
+            assert abs(a["losses"][k] - b["losses"][k]) <= 5e-3 * abs(a["losses"][k]) + 1e-4, (k, a["losses"][k], b["losses"][k])
+    assert sorted(a["grads"]) == sorted(b["grads"])
+    errs = sorted(((rel_l2(b["grads"][n], a["grads"][n]), n) for n in a["grads"] if float(a["grads"][n].norm()) > 0), reverse=True)
+    print("worst 5:", [(round(e, 4), n) for e, n in errs[:5]], "median", round(errs[len(errs) // 2][0], 5))
+    if a["matches"] is not None:
+        assert errs[0][0] <= 0.05 and errs[len(errs) // 2][0] <= 0.01, errs[:5]
