@@ -194,7 +194,7 @@ class TransformerPredictor(nn.Module):
         if st is None or st["dev"] != dev:
             st = self._sel_state = {"dev": dev, "ver": None, "w2_frag": torch.empty(ncp * c, dtype=torch.bfloat16, device=dev),
                                     "b2": torch.full((ncp,), -3e38, dtype=torch.float32, device=dev),
-                                    "valid": valid.view(-1).to(torch.uint8).contiguous()}
+                                    "valid": None, "valid_src": None}
         # once per optimizer step: the class weights in fragment order, the bias with -3e38 in the padding (inside a capture always - the
         # launches must be part of the graph that replays the step)
         if st["ver"] != ver or torch.cuda.is_current_stream_capturing():
@@ -202,8 +202,8 @@ class TransformerPredictor(nn.Module):
             check(lib.fx_pack_frag_bf16(cls._pack.w_fwd.data_ptr(), st["w2_frag"].data_ptr(), ncp, c, _stream(dev)), "fx_pack_frag_bf16")
             st["b2"][: self.nc].copy_(cls.bias.detach())
             st["ver"] = ver
-        if st["valid"].numel() != S:
-            st["valid"] = valid.view(-1).to(torch.uint8).contiguous()
+        if st["valid_src"] is not valid:   # the anchors' validity mask of THIS set of level shapes (cached per shapes in _anchors: identity is enough)
+            st["valid"], st["valid_src"] = valid.view(-1).to(torch.uint8).contiguous(), valid
         mem = memory.contiguous()
         om = torch.empty(B * S, c, dtype=torch.bfloat16, device=dev)
         scores = torch.empty(B, S, dtype=torch.float32, device=dev)
