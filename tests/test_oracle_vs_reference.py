@@ -494,3 +494,98 @@ def test_mf_train_oracle_matches_reference_losses_and_gradients():
     for k in ("pixel_decoder.adapter_3.norm.running_mean", "pixel_decoder.layer_2.norm.running_var"):
         np.testing.assert_allclose(sdg[k].numpy(), ref_sd[k].numpy(), rtol=1e-4, atol=1e-5, err_msg=k)
         assert not torch.equal(sdg[k], sd[k]), k
+
+
+@pytest.mark.parametrize("counts", [(0, 0), (0, 3)])
+def test_train_oracle_matches_reference_with_empty_targets(counts):
+    """Images without a single ground-truth box (a whole batch of them, or one of two): the training oracle against the REAL reference -
+    `num_boxes` clamped to 1, empty index pairs from the matcher, box losses that sum over nothing (fai_detr/modelling.py:553-612,
+    693-758).  This is what tests/test_gpu_detr_variants.py::test_detr_train_step_with_empty_targets holds the engine against."""
+    ref_import.install()
+    from focoos.models.fai_detr.ports import DETRTargets
+
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.synth import synth_image_structured, synth_state_dict
+    from oracle import detr_oracle as O
+    from oracle import train_oracle as T
+
+    cfg = ModelRegistry.get_model_info("fai-detr-m-coco")["config"]
+    model, proc, _ = ref_import.build_reference_detr(cfg)
+    sd = synth_state_dict(cfg, seed=33)
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    for m in model.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.eval()
+    imgs = [synth_image_structured(90 + i, 128, 160) for i in range(2)]
+    x = O.get_torch_batch(imgs, None)
+    g = torch.Generator().manual_seed(4)
+    labels = [torch.randint(0, 80, (n,), generator=g) for n in counts]
+    boxes = [torch.cat([torch.rand(n, 2, generator=g) * 0.5 + 0.25, torch.rand(n, 2, generator=g) * 0.3 + 0.1], 1) for n in counts]
+    with torch.no_grad():
+        ref_losses = model(x, [DETRTargets(labels=l, boxes=b) for l, b in zip(labels, boxes)]).loss
+        outs = T.detr_train_outputs(sd, cfg, x)
+        losses, matches = T.criterion(outs, labels, boxes)
+    assert sorted(losses) == sorted(ref_losses) and len(losses) == 3 * (3 + 1)
+    for k in ref_losses:
+        a, b = float(losses[k]), float(ref_losses[k])
+        assert np.isfinite(b)
+        np.testing.assert_allclose(a, b, rtol=2e-4, atol=1e-5, err_msg=k)
+        if sum(counts) == 0 and ("bbox" in k or "giou" in k):
+            assert b == 0.0, (k, b)
+    for per_set in matches:
+        assert [len(i) for i, _ in per_set] == list(counts)
+
+
+def test_mask_train_oracle_matches_reference_with_an_empty_image():
+    """One of two images without a ground-truth mask: the mask-family training oracle (BiSeNetFormer-S, 1 024 sample points) against the
+    REAL reference - `num_masks` counts the other image only, the empty image contributes its no-object class loss and nothing to the
+    mask / dice sums (fai_mf/loss.py:345-607, 661-723).  tests/test_gpu_train_bf.py::test_mask_train_step_with_empty_targets holds the
+    engine against the oracle on the same kind of input."""
+    ref_import.install()
+    import json
+    import os
+
+    from focoos.models.bisenetformer.ports import BisenetFormerTargets
+
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.synth import synth_image_structured, synth_state_dict
+    from oracle import detr_oracle as O
+    from oracle import mask_criterion_oracle as MC
+    from oracle import train_oracle as T
+
+    name = "bisenetformer-s-ade"
+    cfg = dict(ModelRegistry.get_model_info(name)["config"], criterion_num_points=1024)
+    ref_cfg = dict(json.load(open(os.path.join(ref_import.REFERENCE_ROOT, f"focoos/model_registry/{name}.json")))["config"], criterion_num_points=1024)
+    model, proc, _ = ref_import.build_reference_bf(ref_cfg)
+    sd = synth_state_dict(cfg, seed=17, family="bisenetformer")
+    model.load_state_dict(sd, strict=True)
+    model.train()
+    imgs = [synth_image_structured(60 + i, 128, 160) for i in range(2)]
+    x = O.get_torch_batch(imgs, None)
+    labels, masks = T.synth_mask_targets(5, 2, int(cfg["num_classes"]), (128, 160), counts=(0, 4))
+    assert labels[0].numel() == 0 and masks[0].shape[0] == 0
+    rec, orig_rand = [], torch.rand
+
+    def spy_rand(*a, **k):
+        t = orig_rand(*a, **k)
+        rec.append(t.clone())
+        return t
+
+    torch.rand = spy_rand
+    try:
+        with torch.no_grad():
+            ref_losses = model(x, [BisenetFormerTargets(labels=l, masks=m) for l, m in zip(labels, masks)]).loss
+    finally:
+        torch.rand = orig_rand
+    O.BN_TRAINING[0] = True
+    try:
+        with torch.no_grad():
+            outs = T.bf_train_outputs({k: v.clone() for k, v in sd.items()}, cfg, x)
+    finally:
+        O.BN_TRAINING[0] = False
+    losses, _ = T.bf_criterion(outs, labels, masks, MC.RandStream([r for r in rec if r.numel() > 0]), cfg)
+    assert sorted(losses) == sorted(ref_losses)
+    for k in ref_losses:
+        assert np.isfinite(float(ref_losses[k]))
+        np.testing.assert_allclose(float(losses[k]), float(ref_losses[k]), rtol=5e-4, atol=1e-5, err_msg=k)
