@@ -4,10 +4,58 @@ focoos/models/fai_detr/ports.py:9-19 DETRModelOutput / DETRTargets).  When the r
 installed next to this one, ``focoos_amd.integration`` uses the reference's own classes instead."""
 from __future__ import annotations
 
-from dataclasses import dataclass, field
+from collections import OrderedDict
+from dataclasses import dataclass, field, fields
 from typing import Any, List, Optional, Tuple, Union
 
 import torch
+
+
+class DictClass(OrderedDict):
+    """The reference's container base (focoos/ports.py:875-922): a dataclass that is ALSO an ordered mapping of its fields - what
+    ``BaseModelNN.forward`` returns (``ModelOutput``) and what the data pipeline hands over (``DatasetEntry``).  Same observable
+    behaviour: ``obj["field"]`` and ``obj.field`` are one value, an integer (or slice) index addresses ``to_tuple()`` - the fields that
+    are not None, in declaration order (what the export path traces) -, attribute assignment of a non-None value and item assignment
+    keep both views in step, and the object pickles by its fields.  (One addition: ``__setstate__`` restores the mapping view too; the
+    reference's unpickled objects come back with attributes only.)"""
+
+    def __post_init__(self):
+        names = [f.name for f in fields(self)]
+        if not names:
+            raise ValueError(f"{type(self).__name__} has no fields.")
+        for n in names:
+            OrderedDict.__setitem__(self, n, getattr(self, n))
+
+    def to_tuple(self) -> tuple:
+        return tuple(v for v in OrderedDict.values(self) if v is not None)
+
+    def __getitem__(self, k):
+        if isinstance(k, str):
+            return OrderedDict.__getitem__(self, k)
+        return self.to_tuple()[k]
+
+    def __setattr__(self, name, value):
+        if value is not None and OrderedDict.__contains__(self, name):
+            OrderedDict.__setitem__(self, name, value)
+        object.__setattr__(self, name, value)
+
+    def __setitem__(self, key, value):
+        OrderedDict.__setitem__(self, key, value)
+        object.__setattr__(self, key, value)
+
+    def __reduce__(self):
+        return (type(self).__new__, (type(self),), {f.name: getattr(self, f.name) for f in fields(self)})
+
+    def __setstate__(self, state):
+        for k, v in state.items():
+            object.__setattr__(self, k, v)
+            OrderedDict.__setitem__(self, k, v)
+
+
+@dataclass
+class ModelOutput(DictClass):
+    """focoos/ports.py:930-934 - model output base container."""
+    loss: Optional[dict]
 
 
 @dataclass
@@ -40,26 +88,27 @@ class FocoosDetections:
 
 
 @dataclass
-class DETRModelOutput:
+class DETRModelOutput(ModelOutput):
+    """focoos/models/fai_detr/ports.py:9-13."""
     boxes: torch.Tensor   # [N, num_queries, 4] XYXY normalised to [0,1]
     logits: torch.Tensor  # [N, num_queries, num_classes] (probabilities, like the reference)
-    loss: Optional[dict] = None
+    loss: Optional[dict]   # (declared in ModelOutput: stays the FIRST field, like in the reference - construct by keyword)
 
 
 @dataclass
-class MaskFormerModelOutput:
+class MaskFormerModelOutput(ModelOutput):
     """focoos/models/fai_mf/ports.py:9-13."""
     masks: torch.Tensor   # [N, num_queries, H, W] mask probabilities (sigmoid, bilinearly upsampled to the input size)
     logits: torch.Tensor  # [N, num_queries, num_classes] class probabilities (softmax, no-object column dropped)
-    loss: Optional[dict] = None
+    loss: Optional[dict]   # (declared in ModelOutput: stays the FIRST field, like in the reference - construct by keyword)
 
 
 @dataclass
-class BisenetFormerOutput:
+class BisenetFormerOutput(ModelOutput):
     """focoos/models/bisenetformer/ports.py (same fields as MaskFormerModelOutput)."""
     masks: torch.Tensor   # [N, num_queries, H, W] mask probabilities (sigmoid at 1/8 resolution, bilinearly upsampled to the input size)
     logits: torch.Tensor  # [N, num_queries, num_classes] class probabilities (softmax, no-object column dropped)
-    loss: Optional[dict] = None
+    loss: Optional[dict]   # (declared in ModelOutput: stays the FIRST field, like in the reference - construct by keyword)
 
 
 @dataclass
@@ -219,7 +268,7 @@ class Instances:
 
 # ---- training-side ports (focoos/ports.py: DatasetEntry :938-944, TrainerArgs :970-1065)
 @dataclass
-class DatasetEntry:
+class DatasetEntry(DictClass):
     """One training / evaluation sample: ``image`` CHW uint8 (or float) tensor, ``instances`` with ``boxes`` (Boxes, absolute xyxy) and
     ``classes`` (int64 tensor), ``height`` / ``width`` of the original image."""
     image: Optional[object] = None
