@@ -22,7 +22,7 @@ import torch
 from .engine import DetrEngine
 from .engine_bf import BfEngine
 from .engine_mf import MfEngine
-from .ports import BisenetFormerOutput, DETRModelOutput, FocoosDetections, InferLatency, MaskFormerModelOutput, ModelInfo
+from .ports import MODELS_DIR, BisenetFormerOutput, DETRModelOutput, FocoosDetections, InferLatency, MaskFormerModelOutput, ModelInfo
 from .processor import BisenetFormerProcessor, DETRProcessor, MaskFormerProcessor
 from .registry import ModelRegistry
 from .state_spec import state_spec
@@ -276,13 +276,34 @@ class ModelManager:
         cls._MODEL_MAPPING[getattr(model_family, "value", model_family)] = model_loader
 
     @classmethod
+    def _from_local_dir(cls, name: str) -> ModelInfo:
+        """model_manager.py:158-188: a run directory (as given, or under the models directory) holding ``model_info.json``; a bare
+        ``model_final.pth`` in it is resolved against the directory."""
+        run_dir = name
+        if not os.path.exists(run_dir):
+            run_dir = os.path.join(MODELS_DIR, name)
+            if not os.path.exists(run_dir):
+                raise ValueError(f"Run {run_dir} not exists.")
+        info_path = os.path.join(run_dir, "model_info.json")
+        if not os.path.exists(info_path):
+            raise ValueError(f"Model info not found in {run_dir}")
+        info = ModelInfo.from_json(info_path)
+        if info.weights_uri == "model_final.pth":
+            info.weights_uri = os.path.join(run_dir, info.weights_uri)
+        return info
+
+    @classmethod
     def get(cls, name: str, model_info: Optional[ModelInfo] = None, config: Optional[dict] = None, device: str = "cuda:0", seed: int = 0,
             **kwargs) -> FocoosModel:
         if model_info is None:
-            if not ModelRegistry.exists(name):
-                raise ValueError(f"⚠️ Model {name} not found")
-            d = ModelRegistry.get_model_info(name)
-            model_info = ModelInfo(**{k: d[k] for k in ("name", "model_family", "classes", "im_size", "task", "config", "weights_uri", "description")})
+            # model_manager.py:74-91: hub reference / registry name / local run directory, in this order
+            name = os.fspath(name)
+            if name.startswith("hub://"):
+                raise NotImplementedError("hub:// references need the Focoos Hub client (network; outside this engine): download the run and pass its folder")
+            if ModelRegistry.exists(name):
+                model_info = ModelInfo.from_json(ModelRegistry.get_model_info(name))
+            else:
+                model_info = cls._from_local_dir(name)
         fam = getattr(model_info.model_family, "value", model_info.model_family)
         if fam not in cls._MODEL_MAPPING:
             raise ValueError(f"Model {fam} not supported")

@@ -4,11 +4,17 @@ focoos/models/fai_detr/ports.py:9-19 DETRModelOutput / DETRTargets).  When the r
 installed next to this one, ``focoos_amd.integration`` uses the reference's own classes instead."""
 from __future__ import annotations
 
+import json
+import os
 from collections import OrderedDict
 from dataclasses import dataclass, field, fields
 from typing import Any, List, Optional, Tuple, Union
 
 import torch
+
+
+# focoos/ports.py:22-24: where runs live when a model is named by its run folder (ModelManager._from_local_dir)
+MODELS_DIR = os.path.join(os.path.expanduser("~"), "FocoosAI", "models")
 
 
 class DictClass(OrderedDict):
@@ -145,6 +151,19 @@ class ModelInfo:
     config: dict
     weights_uri: Optional[str] = None
     description: Optional[str] = None
+
+    @classmethod
+    def from_json(cls, data) -> "ModelInfo":
+        """focoos/ports.py:32-38 (PydanticBase.from_json): a path to a ``model_info.json`` - what the reference's trainer and this one write
+        next to ``model_final.pth`` - or the parsed dict.  The fields the engine does not use (ref, status, train_args, metrics, latency ...)
+        are accepted and dropped; enum-valued fields arrive as their string values."""
+        if isinstance(data, (str, os.PathLike)):
+            with open(data, encoding="utf-8") as f:
+                data = json.load(f)
+        missing = [k for k in ("name", "model_family", "classes", "im_size", "task", "config") if k not in data]
+        if missing:
+            raise ValueError(f"model info without the required field(s) {missing}")
+        return cls(**{f.name: data[f.name] for f in fields(cls) if f.name in data})
 
 
 # ---- evaluation-side structures (focoos/structures.py: Boxes :18-170, Instances :430-560), the subset eval_postprocess needs

@@ -6,6 +6,8 @@ or a local ``model_final.pth`` given by ``weights_uri``."""
 from __future__ import annotations
 
 import copy
+import json
+import os
 from typing import Dict, List, Optional
 
 _DETR_L_CONFIG = {
@@ -179,6 +181,16 @@ class ModelRegistry:
 
     @classmethod
     def get_model_info(cls, name: str) -> Dict:
-        if name not in _REGISTRY:
+        """model_registry.py:50-71: a registry name, or the path of a ``model_info.json`` (a fine-tuned model's own description)."""
+        if name in _REGISTRY:
+            return copy.deepcopy(_REGISTRY[name])
+        if not os.path.exists(name):
             raise ValueError(f"⚠️ Model {name} not found. Available models: {cls.list_models()}")
-        return copy.deepcopy(_REGISTRY[name])
+        with open(name, encoding="utf-8") as f:
+            d = json.load(f)
+        missing = [k for k in ("name", "model_family", "classes", "im_size", "task", "config") if k not in d]
+        if missing:
+            raise ValueError(f"⚠️ Model {name}: model info without the required field(s) {missing}")
+        d.setdefault("weights_uri", None)
+        d.setdefault("description", None)
+        return d

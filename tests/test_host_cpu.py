@@ -372,3 +372,78 @@ def test_adapter_refuses_inputs_without_a_plan_instead_of_running_the_stock_grap
         _require_engine_input(torch.zeros(1, 3, 20, 800), 1)
     with pytest.raises(_lib.FocoosAmdError, match="input images"):
         _require_engine_input(torch.zeros(1, 3, 64, 64, requires_grad=True))
+
+
+def test_model_manager_resolution_order_and_local_run_directories(tmp_path, monkeypatch):
+    """ModelManager.get resolves like the reference (model_manager.py:74-91, 158-188; the cases of its tests/test_model_manager.py): an
+    explicit ModelInfo, a registry name, else a local run directory holding model_info.json - as given or under MODELS_DIR - whose bare
+    ``model_final.pth`` is resolved against the directory; ModelRegistry.get_model_info also takes the path of such a JSON
+    (model_registry.py:50-71).  A stub family stands in for the engine classes: no GPU in this test."""
+    import json
+
+    from focoos_amd import model as Mo
+    from focoos_amd.model import ModelManager
+    from focoos_amd.ports import ModelInfo
+    from focoos_amd.registry import ModelRegistry
+
+    built = []
+
+    class StubNN:
+        family, device, dtype = "fai_detr", torch.device("cpu"), torch.float32
+
+        def __init__(self, cfg, device="cpu", seed=0):
+            self.cfg, self.loaded = cfg, None
+            built.append(self)
+
+        def eval(self):
+            return self
+
+        def load_state_dict(self, state, strict=False):
+            self.loaded = state
+
+    monkeypatch.setitem(ModelManager._MODEL_MAPPING, "fai_detr", lambda: StubNN)
+    base = ModelRegistry.get_model_info("fai-detr-l-coco")
+    run = tmp_path / "my_run"
+    run.mkdir()
+    info = {k: base[k] for k in ("model_family", "classes", "im_size", "task", "config")}
+    info.update(name="my_run", weights_uri="model_final.pth", status="TRAINING_COMPLETED", train_args={"max_iters": 10}, focoos_version="0.25.0")
+    (run / "model_info.json").write_text(json.dumps(info))
+    w = {"model": {"a": torch.ones(2)}, "iteration": 10}
+    torch.save(w, run / "model_final.pth")
+    # a run directory given by path; fields the engine does not know are dropped, the bare weights name is resolved
+    import warnings as W
+
+    with W.catch_warnings(record=True) as rec:
+        W.simplefilter("always")
+        fm = ModelManager.get(str(run))
+    assert not [r for r in rec if "no pretrained weights" in str(r.message)]
+    assert fm.model_info.name == "my_run" and fm.model_info.weights_uri == str(run / "model_final.pth")
+    assert torch.equal(built[-1].loaded["a"], torch.ones(2))                     # the "model" entry of the checkpoint
+    # ... by name under MODELS_DIR, with config overrides (dict and kwargs) on top of the run's own config
+    monkeypatch.setattr(Mo, "MODELS_DIR", str(tmp_path))
+    fm = ModelManager.get("my_run", config={"threshold": 0.25}, top_k=100)
+    assert built[-1].cfg["threshold"] == 0.25 and built[-1].cfg["top_k"] == 100 and built[-1].cfg["num_classes"] == 80
+    # a pathlib.Path works like a string
+    assert ModelManager.get(run).model_info.name == "my_run"
+    # the registry by JSON path
+    d = ModelRegistry.get_model_info(str(run / "model_info.json"))
+    assert d["name"] == "my_run" and d["config"] == base["config"] and d["description"] is None
+    assert ModelInfo.from_json(str(run / "model_info.json")).im_size == base["im_size"]
+    # error cases, with the reference's messages
+    with pytest.raises(ValueError, match="not exists"):
+        ModelManager.get("no_such_run")
+    (tmp_path / "empty_run").mkdir()
+    with pytest.raises(ValueError, match="Model info not found"):
+        ModelManager.get("empty_run")
+    with pytest.raises(ValueError, match="⚠️ Model /nonexistent/model.json not found"):
+        ModelRegistry.get_model_info("/nonexistent/model.json")
+    (tmp_path / "bad.json").write_text(json.dumps({"name": "x"}))
+    with pytest.raises(ValueError, match="required field"):
+        ModelRegistry.get_model_info(str(tmp_path / "bad.json"))
+    with pytest.raises(NotImplementedError, match="hub://"):
+        ModelManager.get("hub://user/ref")
+    missing = dict(info, weights_uri=str(run / "gone.pth"))
+    with pytest.raises(FileNotFoundError):
+        ModelManager.get("x", model_info=ModelInfo.from_json(missing))
+    with pytest.raises(ValueError, match="not supported"):
+        ModelManager.get("x", model_info=ModelInfo.from_json(dict(info, model_family="rtmo")))
