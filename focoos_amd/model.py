@@ -66,6 +66,10 @@ class _EngineModel:
     def dtype(self) -> torch.dtype:
         return torch.float32  # pixel_mean.dtype in the reference (modelling.py:1340-1342)
 
+    def __call__(self, *args, **kwargs):
+        """nn.Module semantics of the reference's BaseModelNN: ``model(images, targets)`` is ``model.forward(images, targets)``."""
+        return self.forward(*args, **kwargs)
+
     def eval(self):
         self.training = False
         return self
