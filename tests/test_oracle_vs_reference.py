@@ -589,3 +589,48 @@ def test_mask_train_oracle_matches_reference_with_an_empty_image():
     for k in ref_losses:
         assert np.isfinite(float(ref_losses[k]))
         np.testing.assert_allclose(float(losses[k]), float(ref_losses[k]), rtol=5e-4, atol=1e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("case", ["default", "none_above_threshold", "top_k_10", "threshold_zero_means_default", "ragged_sizes"])
+def test_detr_postprocess_oracle_equals_reference_on_random_outputs(case):
+    """oracle.detr_oracle.postprocess against the REAL DETRProcessor.postprocess (fai_detr/processor.py:146-217) on the same random model
+    outputs - no model in the loop, so exact: scores, class ids and the rounded integer boxes detection by detection, for the edge cases
+    the GPU post-process tests hold fx_detr_postprocess to: nothing above the threshold (empty detection lists), a small top_k,
+    `threshold=0.0` (the reference's `threshold or self.threshold`: 0.0 selects the configured default), a batch of differently sized
+    non-square originals."""
+    ref_import.install()
+    from focoos.models.fai_detr.ports import DETRModelOutput as RefOut
+    from focoos.models.fai_detr.processor import DETRProcessor as RefProc
+    from focoos.model_manager import ConfigManager
+    from focoos.ports import ModelFamily
+
+    from focoos_amd.registry import ModelRegistry
+    from oracle import detr_oracle as O
+
+    g = torch.Generator().manual_seed({"default": 1, "none_above_threshold": 2, "top_k_10": 3, "threshold_zero_means_default": 4, "ragged_sizes": 5}[case])
+    B, Q, K = 3, 300, 80
+    probs = torch.rand(B, Q, K, generator=g) ** 6            # a few confident entries per image, most near zero
+    cxcy, wh = torch.rand(B, Q, 2, generator=g) * 0.6 + 0.2, torch.rand(B, Q, 2, generator=g) * 0.3 + 0.02
+    boxes = torch.cat([cxcy - wh / 2, cxcy + wh / 2], -1)
+    sizes = [(480, 640), (333, 517), (1080, 1920)] if case == "ragged_sizes" else [(480, 640)] * B
+    imgs = [np.zeros((h, w, 3), np.uint8) for h, w in sizes]
+    cfg = ConfigManager.from_dict(ModelFamily.DETR, dict(ModelRegistry.get_model_info("fai-detr-l-coco")["config"], top_k=10 if case == "top_k_10" else 300,
+                                                         threshold=0.5))
+    proc = RefProc(cfg, image_size=640).eval()
+    if case == "none_above_threshold":
+        probs = probs * 0.4
+    thr_arg = {"default": 0.5, "none_above_threshold": 0.5, "top_k_10": 0.3, "threshold_zero_means_default": 0.0, "ragged_sizes": 0.25}[case]
+    thr_eff = thr_arg or cfg.threshold
+    dets = proc.postprocess(RefOut(boxes=boxes, logits=probs, loss=None), imgs, threshold=thr_arg)
+    res = O.postprocess(probs, boxes, sizes, cfg.top_k, thr_eff)
+    assert len(dets) == B
+    total = 0
+    for d, (s, l, q, bx) in zip(dets, res):
+        assert len(d.detections) == len(s)
+        total += len(s)
+        assert [x.cls_id for x in d.detections] == l.tolist()
+        assert [list(x.bbox) for x in d.detections] == bx.tolist()
+        np.testing.assert_allclose([x.conf for x in d.detections], s.numpy(), rtol=0, atol=1e-7)
+    assert (total == 0) == (case == "none_above_threshold")
+    if case == "top_k_10":
+        assert all(len(d.detections) <= 10 for d in dets)
