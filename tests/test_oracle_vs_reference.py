@@ -634,3 +634,67 @@ def test_detr_postprocess_oracle_equals_reference_on_random_outputs(case):
     assert (total == 0) == (case == "none_above_threshold")
     if case == "top_k_10":
         assert all(len(d.detections) <= 10 for d in dets)
+
+
+@pytest.mark.parametrize("family", ["fai_mf", "bisenetformer"])
+@pytest.mark.parametrize("case", ["instances", "instances_no_mask_score", "nothing_kept", "tiny_masks_dropped", "all_pixels", "resized_original"])
+def test_mask_postprocess_oracle_equals_reference_on_random_outputs(family, case):
+    """oracle.mf_oracle.postprocess against the REAL MaskFormerProcessor / BisenetFormerProcessor.postprocess (fai_mf/processor.py:168-306,
+    bisenetformer/processor.py:176-300) on the same random model outputs, batch 1 (what the reference's gather indexing supports) - no
+    model in the loop: scores, class ids and integer boxes detection by detection, the decoded masks through their areas.  Cases: the
+    threshold branch with and without the mask score (the x1e-3 scaling quirk :247-255), scores all below the threshold (empty list),
+    masks of 0 / 1 pixels (dropped: strictly more than one pixel), the predict_all_pixels branch, an original size other than the mask's."""
+    ref_import.install()
+    import base64
+    import json
+    import os
+
+    from oracle import mf_oracle as M
+
+    if family == "fai_mf":
+        import focoos.models.fai_mf.processor as mod
+        from focoos.models.fai_mf.ports import MaskFormerModelOutput as RefOut
+
+        name, build = "fai-mf-l-coco-ins", ref_import.build_reference_mf
+    else:
+        import focoos.models.bisenetformer.processor as mod
+        from focoos.models.bisenetformer.ports import BisenetFormerOutput as RefOut
+
+        name, build = "bisenetformer-l-ade", ref_import.build_reference_bf
+    ref_cfg = json.load(open(os.path.join(ref_import.REFERENCE_ROOT, f"focoos/model_registry/{name}.json")))["config"]
+    ref_cfg = dict(ref_cfg, predict_all_pixels=(case == "all_pixels"), use_mask_score=(case != "instances_no_mask_score"), threshold=0.3, mask_threshold=0.5)
+    ref_cfg["backbone_config"] = dict(ref_cfg["backbone_config"], **({"depth": 50} if family == "fai_mf" else {}))
+    _, proc, cfg = build(ref_cfg)
+    areas = []
+    mod.binary_mask_to_base64 = lambda m: areas.append(int(np.asarray(m).sum())) or base64.b64encode(b"x").decode()   # cv2 tail: not installed
+    g = torch.Generator().manual_seed(sum(map(ord, case)))
+    Q, K, h, w = 12, int(ref_cfg["num_classes"]), 48, 64
+    probs = torch.softmax(torch.randn(1, Q, K + 1, generator=g) * 3.0, -1)[..., :K]
+    yy, xx = torch.meshgrid(torch.arange(h).float(), torch.arange(w).float(), indexing="ij")
+    masks = torch.zeros(1, Q, h, w)
+    for q in range(Q):
+        cy, cx, r = float(torch.rand(1, generator=g)) * h, float(torch.rand(1, generator=g)) * w, 4.0 + 8.0 * float(torch.rand(1, generator=g))
+        masks[0, q] = torch.sigmoid((r - ((yy - cy) ** 2 + (xx - cx) ** 2).sqrt()) * 0.8)
+    if case == "nothing_kept":
+        probs = probs * 0.2
+    if case == "tiny_masks_dropped":
+        masks[0, :6] = 0.01
+        masks[0, 0, 5, 5] = 0.9                      # one pixel: dropped
+        masks[0, 1, 7, 7:9] = 0.9                    # two pixels: kept (if its score passes)
+        probs[0, 1] = 0.0
+        probs[0, 1, 3] = 0.95
+    size = (96, 120) if case == "resized_original" else (h, w)
+    img = np.zeros(size + (3,), np.uint8)
+    dets = proc.postprocess(RefOut(masks=masks, logits=probs, loss=None), [img])[0].detections
+    s, l, q, boxes, bm = M.postprocess(probs, masks, [size], 0.5, 0.3, case != "instances_no_mask_score", predict_all_pixels=(case == "all_pixels"))[0]
+    assert len(dets) == len(s), (len(dets), len(s))
+    assert (len(s) == 0) == (case == "nothing_kept")
+    print(f"{family} {case}: {len(s)} detections, areas {areas}")
+    np.testing.assert_allclose([d.conf for d in dets], s.numpy(), rtol=0, atol=1e-6)
+    assert [d.cls_id for d in dets] == l.tolist()
+    assert [list(d.bbox) for d in dets] == np.asarray(boxes).tolist()
+    # the reference encodes the mask cropped to its box with an exclusive slice end (utils/vision.py:264-267): the same crop of the oracle's mask
+    want = [int(m[b[1]:min(b[3], m.shape[0]), b[0]:min(b[2], m.shape[1])].sum()) for m, b in zip(bm, np.asarray(boxes).tolist())]
+    assert areas == want
+    if case == "tiny_masks_dropped":
+        assert 0 not in q.tolist() and 1 in q.tolist()
