@@ -289,7 +289,8 @@ def test_encoder_heads_on_selected_rows_equal_all_rows():
     (fai_detr/modelling.py:1202-1232).  The operations are row-local, so the two orders must agree: the same selection when free-running
     (the fused launch feeds its LayerNorm and class scores from fp32 accumulators, the layer-by-layer form rounds to bf16 in between - a
     few borderline tokens may swap), and with the selection fixed the same losses and the same gradients - including the gradient that
-    reaches `memory` and, through it, the encoder and the backbone."""
+    reaches `memory` and, through it, the encoder and the backbone.  Measured: selection 300 / 300 and 300 / 300 identical, worst gradient
+    tensor 0.8 % apart (res5, the other GEMM tile for 4 800 instead of 134 400 rows), median 0 (most tensors bit-identical)."""
     from focoos_amd import train_detr as TD
 
     cfg = ModelRegistry.get_model_info("fai-detr-l-coco")["config"]
