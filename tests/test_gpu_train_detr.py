@@ -330,3 +330,31 @@ def test_encoder_heads_on_selected_rows_equal_all_rows():
     print("worst 5:", [(round(e, 4), n) for e, n in errs[:5]], "median", round(errs[len(errs) // 2][0], 5))
     if a["matches"] is not None:
         assert errs[0][0] <= 0.05 and errs[len(errs) // 2][0] <= 0.01, errs[:5]
+
+
+def test_selection_scores_layer_by_layer_form_for_many_classes():
+    """More than 384 classes do not fit the fused score-head launch: TransformerPredictor._selection_scores then runs enc_output and the class
+    head layer by layer (no gradient) - the same selection as the all-token order, and a complete step."""
+    from focoos_amd import train_detr as TD
+
+    cfg = dict(ModelRegistry.get_model_info("fai-detr-l-coco")["config"], num_classes=400)
+    sd = synth_state_dict(cfg, 2)
+    x_u8 = torch.from_numpy(np.stack([synth_image_structured(50 + i, 128, 160) for i in range(2)])).to(DEV)
+    labels, boxes = T.synth_targets(5, 2, 400, counts=(2, 3))
+    targets = [DETRTargets(labels=l.to(DEV), boxes=b.to(DEV)) for l, b in zip(labels, boxes)]
+    sel = {}
+    prev = TD.SELECT_ROWS[0]
+    try:
+        for mode in (False, True):
+            TD.SELECT_ROWS[0] = mode
+            model = TD.FAIDetrTrainable(cfg, norm="FrozenBN").to(DEV)
+            model.load_state_dict(sd, strict=True)
+            losses = model(x_u8, targets)
+            sum(losses.values()).backward()
+            torch.cuda.synchronize()
+            assert all(torch.isfinite(v) for v in losses.values())
+            sel[mode] = model.last_outputs["topk_ind"]
+    finally:
+        TD.SELECT_ROWS[0] = prev
+    same = [len(set(sel[False][i].tolist()) & set(sel[True][i].tolist())) for i in range(2)]
+    assert min(same) >= 285, same
