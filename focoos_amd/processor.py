@@ -112,22 +112,12 @@ class DETRProcessor:
         return out, []
 
     def _preprocess_entries(self, entries, device: torch.device):
-        """fai_detr/processor.py:81-101: a list of DatasetEntry -> (uint8 NHWC batch, [DETRTargets]): images stacked (equal sizes: the
-        training augmentations produce fixed-resolution crops; ImageList padding is not mirrored), ground-truth boxes absolute xyxy ->
-        normalised cxcywh, classes as they are.  Targets only in training mode."""
+        """fai_detr/processor.py:81-101: a list of DatasetEntry -> (uint8 NHWC batch, [DETRTargets]): images of different sizes zero-padded to the
+        batch's largest height / width like ImageList.from_tensors (_stack_entry_images), ground-truth boxes absolute xyxy -> cxcywh normalised
+        by the PADDED size (:91-96), classes as they are.  Targets only in training mode."""
         from .ports import DETRTargets
 
-        imgs = []
-        for e in entries:
-            im = e.image
-            if isinstance(im, np.ndarray):
-                im = torch.from_numpy(np.ascontiguousarray(im))
-            if im.dim() == 3 and im.shape[0] == 3 and im.shape[-1] != 3:
-                im = im.permute(1, 2, 0)
-            imgs.append(im.contiguous())
-        if any(tuple(i.shape) != tuple(imgs[0].shape) for i in imgs):
-            raise ValueError("training batches need equally sized images (resolution-fixing augmentations)")
-        batch = torch.stack(imgs, 0).to(device, non_blocking=True)
+        batch = _stack_entry_images(entries).to(device, non_blocking=True)
         if batch.dtype != torch.uint8:
             batch = batch.to(torch.float32)
         targets = []
@@ -241,6 +231,31 @@ class DETRProcessor:
 
 
 # ------------------------------------------------------------------------------------------------ MaskFormer
+def _stack_entry_images(entries) -> torch.Tensor:
+    """The images of a DatasetEntry batch as ONE channels-last tensor [B, Hmax, Wmax, 3]: every image in the top-left corner of a zero
+    canvas of the batch's largest height and width - ImageList.from_tensors with its defaults (focoos/structures.py:730-803: pad_value 0,
+    no size divisibility), which is what both families' processors call for entry lists (fai_detr/processor.py:82-86,
+    fai_mf/processor.py:66-70).  The pad is applied to the raw 0..255 pixels (normalisation happens inside the model), so a zero is a
+    black pixel here as there.  Accepts CHW / HWC tensors and HWC ndarrays; equal sizes stack without a copy of the canvas."""
+    imgs = []
+    for e in entries:
+        im = e.image
+        if isinstance(im, np.ndarray):
+            im = torch.from_numpy(np.ascontiguousarray(im))
+        if im.dim() == 3 and im.shape[0] == 3 and im.shape[-1] != 3:
+            im = im.permute(1, 2, 0)
+        imgs.append(im.contiguous())
+    if any(i.dtype != imgs[0].dtype or i.shape[-1] != imgs[0].shape[-1] for i in imgs):
+        raise ValueError("the images of a batch must share dtype and channel count")
+    if all(tuple(i.shape) == tuple(imgs[0].shape) for i in imgs):
+        return torch.stack(imgs, 0)
+    H, W = max(i.shape[0] for i in imgs), max(i.shape[1] for i in imgs)
+    batch = imgs[0].new_zeros((len(imgs), H, W, imgs[0].shape[-1]))
+    for k, im in enumerate(imgs):
+        batch[k, : im.shape[0], : im.shape[1]] = im
+    return batch
+
+
 def trim_mask(mask: np.ndarray, bbox) -> np.ndarray:
     """focoos/utils/vision.py:264-267 (note: the inclusive box is used as an exclusive slice end, as in the reference)."""
     x1, y1, x2, y2 = map(int, bbox)
@@ -341,20 +356,11 @@ class MaskFormerProcessor(DETRProcessor):
     def _preprocess_mask_entries(self, entries, device: torch.device):
         """fai_mf/processor.py:60-90 == bisenetformer/processor.py:60-86: a list of DatasetEntry -> (uint8 NHWC batch, [MaskFormerTargets]):
         per image the classes and the ground-truth masks (``instances.masks``: a [T,h,w] tensor or an object with ``.tensor``) padded to
-        the batch's (h, w).  Targets only in training mode; images must share one size (ImageList padding is not mirrored)."""
+        the batch's (h, w) - images of different sizes are zero-padded to the largest height / width like ImageList.from_tensors
+        (_stack_entry_images).  Targets only in training mode."""
         from .ports import MaskFormerTargets
 
-        imgs = []
-        for e in entries:
-            im = e.image
-            if isinstance(im, np.ndarray):
-                im = torch.from_numpy(np.ascontiguousarray(im))
-            if im.dim() == 3 and im.shape[0] == 3 and im.shape[-1] != 3:
-                im = im.permute(1, 2, 0)
-            imgs.append(im.contiguous())
-        if any(tuple(i.shape) != tuple(imgs[0].shape) for i in imgs):
-            raise ValueError("training batches need equally sized images (resolution-fixing augmentations)")
-        batch = torch.stack(imgs, 0).to(device, non_blocking=True)
+        batch = _stack_entry_images(entries).to(device, non_blocking=True)
         if batch.dtype != torch.uint8:
             batch = batch.to(torch.float32)
         targets = []
