@@ -289,3 +289,33 @@ def test_entry_batches_are_padded_like_imagelist(family, sizes):
     # evaluation mode: the same padded batch, no targets
     xe, te = mine.eval().preprocess(ents_m, device=cpu)
     assert torch.equal(xe, xm) and te == []
+
+
+def test_get_image_sizes_equals_reference_for_every_input_kind():
+    """Processor.get_image_sizes (base_processor.py:176-221) - the original sizes every post-process scales its boxes / masks to - ours against
+    the REAL one for each accepted input kind: ndarray HWC and BHWC (the reference reports ONE size for a 4-D array), tensor CHW and BCHW,
+    a PIL image, lists of each and a mixed list; an unsupported type raises ValueError in both."""
+    ref_import.install()
+    import numpy as np
+    import torch
+    from PIL import Image
+
+    from focoos_amd.processor import DETRProcessor
+    from focoos_amd.registry import ModelRegistry
+
+    cfg = ModelRegistry.get_model_info("fai-detr-l-coco")["config"]
+    _, ref, _ = ref_import.build_reference_detr(dict(cfg))
+    mine = DETRProcessor(cfg, 640)
+    pil = Image.fromarray(np.zeros((30, 50, 3), np.uint8))
+    cases = [np.zeros((48, 60, 3), np.uint8), np.zeros((2, 64, 32, 3), np.uint8), torch.zeros(3, 100, 50), torch.zeros(2, 3, 40, 70), pil,
+             [np.zeros((48, 60, 3), np.uint8), np.zeros((10, 20, 3), np.uint8)], [torch.zeros(3, 100, 50), torch.zeros(3, 7, 9)], [pil, pil],
+             [pil, np.zeros((48, 60, 3), np.uint8), torch.zeros(3, 11, 13)]]
+    for c in cases:
+        want = [tuple(int(v) for v in s) for s in ref.get_image_sizes(c)]
+        got = [tuple(int(v) for v in s) for s in mine.get_image_sizes(c)]
+        assert got == want, (type(c), got, want)
+    for bad in ("x", [1, 2]):
+        with pytest.raises(ValueError):
+            ref.get_image_sizes(bad)
+        with pytest.raises(ValueError):
+            mine.get_image_sizes(bad)
