@@ -301,6 +301,32 @@ def _wgrad_roofline(nn_, stepper, imgs, targets, family="fai_detr"):
             "note": "events bracket the wgrad launch + its slab-sum/unpack pass of every conv layer in one extra step run with the weight gradients on the main stream (in the timed steps they run on a side stream, concurrently with the input-gradient chain)"}
 
 
+def synth_train_targets(family, rank, it, B, S, K, dev):
+    """The synthetic targets of training step ``it`` on ``rank`` (seed = rank*1000 + it): RT-DETR - T_i ~ U{1..20} boxes per image, centres in
+    [0.2, 0.8], sizes in [0.05, 0.35], labels U{0..K-1}; mask families - 5-15 random rectangular masks per image.  Module-level so that the
+    parity tests at the BASELINE shapes (tests/test_gpu_train_baseline_configs.py) run on EXACTLY the step the bench times."""
+    import numpy as np
+    import torch
+
+    from focoos_amd.ports import DETRTargets, MaskFormerTargets
+
+    rs = np.random.RandomState(rank * 1000 + it)
+    out = []
+    for _ in range(B):
+        if family in ("bisenetformer", "fai_mf"):
+            t = rs.randint(5, 16)
+            m = np.zeros((t, S, S), bool)
+            for i in range(t):
+                y0, x0 = rs.randint(0, S - 32), rs.randint(0, S - 32)
+                m[i, y0:y0 + rs.randint(32, S // 2), x0:x0 + rs.randint(32, S // 2)] = True
+            out.append(MaskFormerTargets(labels=torch.from_numpy(rs.randint(0, K, (t,))).to(dev), masks=torch.from_numpy(m).to(dev)))
+        else:
+            t = rs.randint(1, 21)
+            bx = np.concatenate([rs.uniform(0.2, 0.8, (t, 2)), rs.uniform(0.05, 0.35, (t, 2))], -1).astype(np.float32)
+            out.append(DETRTargets(labels=torch.from_numpy(rs.randint(0, K, (t,))).to(dev), boxes=torch.from_numpy(bx).to(dev)))
+    return out
+
+
 def train_measure(args, world, rank, local, with_roofline=True):
     """BASELINE config 4 per GPU: 16 synthetic 640^2 images + COCO-shaped targets (T_i ~ U{1..20}, seed = rank*1000 + iter);
     config 5 (--model bisenetformer-l-ade): 8 synthetic 1024^2 images + 5-15 random rectangular masks per image, labels U{0..149}.
@@ -309,7 +335,6 @@ def train_measure(args, world, rank, local, with_roofline=True):
     import torch
 
     from focoos_amd import train_nn
-    from focoos_amd.ports import DETRTargets, MaskFormerTargets
     from focoos_amd.registry import ModelRegistry
     from focoos_amd.synth import synth_image, synth_state_dict
     from focoos_amd.train_detr import FAIDetrTrainable, TrainStep
@@ -335,21 +360,7 @@ def train_measure(args, world, rank, local, with_roofline=True):
     imgs = torch.stack([torch.from_numpy(synth_image(rank * B + i, S, S)) for i in range(B)]).to(dev)
 
     def targets(it):
-        rs = np.random.RandomState(rank * 1000 + it)
-        out = []
-        for _ in range(B):
-            if bf or args.family == "fai_mf":
-                t = rs.randint(5, 16)
-                m = np.zeros((t, S, S), bool)
-                for i in range(t):
-                    y0, x0 = rs.randint(0, S - 32), rs.randint(0, S - 32)
-                    m[i, y0:y0 + rs.randint(32, S // 2), x0:x0 + rs.randint(32, S // 2)] = True
-                out.append(MaskFormerTargets(labels=torch.from_numpy(rs.randint(0, K, (t,))).to(dev), masks=torch.from_numpy(m).to(dev)))
-            else:
-                t = rs.randint(1, 21)
-                bx = np.concatenate([rs.uniform(0.2, 0.8, (t, 2)), rs.uniform(0.05, 0.35, (t, 2))], -1).astype(np.float32)
-                out.append(DETRTargets(labels=torch.from_numpy(rs.randint(0, K, (t,))).to(dev), boxes=torch.from_numpy(bx).to(dev)))
-        return out
+        return synth_train_targets(args.family, rank, it, B, S, K, dev)
 
     # targets of every step are created (and moved to HBM) BEFORE the timed region, like the images: a data loader hands them over
     # asynchronously, and a pageable host->device copy inside the loop would stall the launch queue once per copy

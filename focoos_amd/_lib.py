@@ -139,6 +139,7 @@ SIGNATURES = {
     "fx_unpack_conv_wgrad_f32": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "fx_linear_wgrad_bias_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "fx_conv2d_wgrad_splits": [_i, _i, _i, _i, _i, _i, _i],
+    "fx_conv2d_wgrad_variant": [_i, _i, _i, _i, _i, _i, _i, _i, _i, C.c_char_p, _i],
     "fx_conv2d_wgrad_partial_nhwc_bf16": [_vp, _i, _vp, _i, _vp, C.c_int64, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "fx_unpack_conv_wgrad_sum_f32": [_vp, C.c_int64, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "fx_relu_bwd_bf16": [_vp, _i, _vp, _i, _vp, _i, _vp, _i, C.c_int64, _i, _i, _vp],
@@ -191,7 +192,7 @@ def lib_path() -> str:
     return os.environ.get("FOCOOS_AMD_LIB", LIB_PATH)
 
 
-FX_ABI_VERSION = 6   # = include/focoos_amd.h (tests/test_host_cpu.py compares the two)
+FX_ABI_VERSION = 7   # = include/focoos_amd.h (tests/test_host_cpu.py compares the two)
 
 
 def load() -> C.CDLL:

@@ -20,6 +20,7 @@ ARCH = "gfx950"
 # 60 with it off; single-queue execution is unaffected).  FX_PK_F32=1 re-enables them (the reproducer).
 NO_PK_FLAGS = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 STAMP_PATH = os.path.join(LIB_DIR, "build_stamp.txt")
+EXTRA_FLAGS: list = []
 
 
 def _pk_units():
@@ -73,17 +74,42 @@ def build(force: bool = False, verbose: bool = True, out_path: str = None) -> st
     objs = []
     hipcc = _hipcc()
     pk = _pk_units()
+    # per-unit incremental build: a unit is recompiled when its object is missing or older than its source / any header, or when the
+    # flag stamp changed; stale units compile in parallel (hipcc takes 5-60 s per unit)
+    headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(PKG, "..", "include", "*.h"))
+    hdr_t = max(os.path.getmtime(h) for h in headers)
+    stamp_ok = False
+    if out_path is None and os.path.exists(STAMP_PATH):
+        with open(STAMP_PATH) as f:
+            stamp_ok = f.read().strip() == _stamp()
+    jobs = []
     for src in sources():
         base = os.path.basename(src)
         obj = os.path.join(objdir, base.replace(".hip", ".o"))
+        objs.append(obj)
+        fresh = (not force and stamp_ok and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t))
+        if fresh:
+            continue
         flags = [] if base in pk else NO_PK_FLAGS
         if base == "runtime.hip":
             flags = flags + [f"-DFX_BUILD_FLAGS={1 if pk else 0}"]
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + flags + ["-c", src, "-o", obj]
-        if verbose:
-            print(" ".join(cmd), file=sys.stderr)
-        subprocess.check_call(cmd)
-        objs.append(obj)
+        jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + flags + EXTRA_FLAGS + ["-c", src, "-o", obj])
+    running = []
+    nproc = max(1, min(int(os.environ.get("FX_BUILD_JOBS", os.cpu_count() or 4)), 16))
+    failed = None
+    while (jobs or running) and failed is None:
+        while jobs and len(running) < nproc:
+            cmd = jobs.pop(0)
+            if verbose:
+                print(" ".join(cmd), file=sys.stderr)
+            running.append((cmd, subprocess.Popen(cmd)))
+        cmd, pr = running.pop(0)
+        if pr.wait() != 0:
+            failed = cmd
+    for _, pr in running:
+        pr.wait()
+    if failed is not None:
+        raise subprocess.CalledProcessError(1, failed)
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", target] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)

@@ -36,6 +36,10 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(uint32_t, v);
 }
 
+// the two storage elements of a 32-bit word (low half = even element) as floats
+__device__ __forceinline__ float bf16lo_to_f32(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16hi_to_f32(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
 __device__ __forceinline__ void unpack_bf16x8(const uint4& v, float* f) {
   f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
   f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);

@@ -268,7 +268,7 @@ typedef __attribute__((address_space(3))) unsigned char wd_lds_u8;
 // (s_waitcnt vmcnt(16) in the step body).  M0 = LDS byte address of lane 0's piece; one wait state between the M0 write and its use.
 typedef __attribute__((ext_vector_type(4))) int wd_v4i;
 __device__ __forceinline__ void wd_dma16(wd_v4i rsrc, unsigned lds_addr, unsigned voff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");   // (m0 is not used by anything else in this kernel: checked in the ISA)
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory", "m0");   // m0 declared clobbered: the compiler may not keep a value of its own in it across the DMA
 }
 
 template <int IMM>
@@ -572,6 +572,16 @@ extern "C" int fx_linear_wgrad_bias_bf16(const void* x, int ldx, const void* dz,
                                          int k_store, int n_store, fx_stream_t stream_) {
   FX_CHECK_ARG(k_store > 0 && n_store > 0 && k_store <= Kp && n_store <= Np && ld_dw >= k_store);
   return wgrad_launch(x, ldx, dz, lddz, dw, 0, 0, dbias, 1, 1, R, Kp, 1, R, Np, 1, 1, 1, 0, stream_, n_store, k_store, ld_dw);
+}
+
+// Label of the kernel the partial-slab weight gradient of this layer shape runs on (the routing predicate of wgrad_launch itself, for the
+// kernel census of tests / profiles): "conv_wgrad_dma<pw|3x3>" or "conv_wgrad<pw|im2col>".
+extern "C" int fx_conv2d_wgrad_variant(int B, int Ho, int Wo, int C, int N, int KH, int KW, int stride, int pad, char* out, int cap) {
+  FX_CHECK_ARG(out && cap >= 32 && B > 0 && Ho > 0 && Wo > 0 && C > 0 && N > 0);
+  const bool pw = KH == 1 && KW == 1 && stride == 1 && pad == 0;
+  const bool dma = wgrad_dma_shape(B * Ho * Wo, N, C, KH, KW) && (pw || (KH == 3 && stride == 1 && pad == 1));
+  snprintf(out, cap, "%s<%s>", dma ? "conv_wgrad_dma" : "conv_wgrad", pw ? "pw" : (dma ? "3x3" : "im2col"));
+  return FX_OK;
 }
 
 extern "C" int fx_conv2d_wgrad_splits(int B, int Ho, int Wo, int C, int N, int KH, int KW) {

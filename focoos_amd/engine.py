@@ -337,6 +337,9 @@ class DetrEngine(StdcEngineMixin, _EngineBase):
             rc(f"{li}.o2", sd[f"{ca}.output_proj.weight"], sd[f"{ca}.output_proj.bias"])
             rc(f"{li}.f1", sd[f"{p}.linear1.weight"], sd[f"{p}.linear1.bias"])
             rc(f"{li}.f2", sd[f"{p}.linear2.weight"], sd[f"{p}.linear2.bias"])
+            # RC_FFN_LN (round 5): both matrices in fragment order + the two bias vectors as one [b1 | b2] array
+            RC[f"{li}.ffn_b"] = (None, self._dev(torch.cat([sd[f"{p}.linear1.bias"].float(), sd[f"{p}.linear2.bias"].float()])))
+            self.dec_ffn = int(sd[f"{p}.linear1.weight"].shape[0])
             bb = f"{hp}.dec_bbox_classifier.{li}"
             rc(f"{li}.bb0", sd[f"{bb}.layers.0.weight"], sd[f"{bb}.layers.0.bias"])
             rc(f"{li}.bb1", sd[f"{bb}.layers.1.weight"], sd[f"{bb}.layers.1.bias"])
@@ -574,15 +577,19 @@ class _PlanBase:
 
     # LDS map of the decoder's row chains (bytes): four [32][256] slots, one [32][1024] slot, the refined-box hand-over, LN scratch
     RC_S0, RC_S1, RC_S2, RC_S3, RC_BIG, RC_REF, RC_RED, RC_LDS = 0, 16384, 32768, 49152, 65536, 131072, 131584, 132608
+    # Round 5 ("lean" programs, FX_RC_LEAN=1): no wide slot - the FFN is ONE stage whose hidden layer lives in two ping-pong [32][256] slots
+    # (RC_FFN_LN), the query-position MLP's 512-wide hidden in two slots (flags bit 2) - 65 536 + 1 536 bytes + the kernel's 12 KiB scratch
+    # = 79 360 <= 80 KiB: TWO workgroups per CU (the kernel is compiled for 128 registers per wave)
+    RC2_REF, RC2_RED, RC2_LDS = 65536, 66048, 67072
 
-    def _rc_program(self, stages: List[FxRcStage], rows: int, label: str, flops: float):
+    def _rc_program(self, stages: List[FxRcStage], rows: int, label: str, flops: float, lds: Optional[int] = None):
         """Upload a stage list and append the fx_row_chain launch."""
         arr = (FxRcStage * len(stages))(*stages)
         host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
         dev = host.to(self.dev)
         self.keep.append(dev)
         self.meta[len(self.ops)] = {"kind": "conv", "variant": "row_chain", "flops": flops, "name": label, "M": rows, "N": 0, "K": 0}
-        self._op(self.lib.fx_row_chain, dev.data_ptr(), len(stages), rows, self.RC_LDS)
+        self._op(self.lib.fx_row_chain, dev.data_ptr(), len(stages), rows, self.RC_LDS if lds is None else lds)
 
     def resize(self, x: NT, out: NT):
         self._op(self.lib.fx_resize_bilinear_nhwc_bf16, x.ptr, x.ld, out.ptr, out.ld, x.B, x.H, x.W, x.C, out.H, out.W)
@@ -915,20 +922,48 @@ class _Plan(StdcPlanMixin, _PlanBase):
         logits = self._new("logits", R, 1, 1, ncp, torch.float32)
         logits.C = e.nc
 
+        hidden = int(e.dec_ffn)
+        lean = os.environ.get("FX_RC_LEAN", "1") != "0" and hidden % 256 == 0 and hidden <= 2048
+        if lean:
+            REF, RED = self.RC2_REF, self.RC2_RED
+        lds = self.RC2_LDS if lean else None
+
+        def gemm_ln(key, src, K, aux, ln_name, dst, out: Optional[NT] = None):   # (re-defined: RED depends on the LDS map)
+            w, b = RC[key]
+            g_, b_ = e.ln[ln_name]
+            return st(2, K=K, N=256, src=src, dst=dst, aux=aux, w=w.data_ptr(), bias=b.data_ptr(), gamma=g_.data_ptr(), beta=b_.data_ptr(),
+                      g0=out.ptr if out is not None else None, ld=out.ld if out is not None else 0, ld2=RED)
+
+        def ffn_ln(li, src, res, slot_a, slot_b, ln_name, dst, out: Optional[NT] = None):
+            """RC_FFN_LN: LayerNorm(linear2(relu(linear1(x))) + residual) in one stage, hidden layer in two ping-pong [32][256] slots."""
+            g_, b_ = e.ln[ln_name]
+            return st(7, K=256, N=hidden, act=slot_a, flags=slot_b, src=src, aux=res, dst=dst, w=RC[f"{li}.f1"][0].data_ptr(), g1=RC[f"{li}.f2"][0].data_ptr(),
+                      bias=RC[f"{li}.ffn_b"][1].data_ptr(), gamma=g_.data_ptr(), beta=b_.data_ptr(), g0=out.ptr if out is not None else None,
+                      ld=out.ld if out is not None else 0, ld2=RED)
+
         def pre_attention(li, tgt_slot, ref_global=None):
             """query_pos_head(ref) -> qpos; q = k = (tgt + qpos) W_qk, v = tgt W_v  (modelling.py:996, transformer MHA in_proj)."""
+            if lean:   # tgt in S3; the 512-wide hidden of the query-position MLP in (S0, S1), qpos -> S2, tgt + qpos -> S0
+                assert tgt_slot == S3
+                k4 = st(4, N=512, dst=S0, ld2=S1, flags=4, aux=(-1 if ref_global is not None else REF), w=e.qpos0[0].data_ptr(), bias=e.qpos0[1].data_ptr(),
+                        g0=ref_global)
+                w, b = RC["qpos1"]
+                q1 = st(1, K=512, N=256, src=S0, aux=S1, dst=S2, flags=4, w=w.data_ptr(), bias=b.data_ptr(), g0=qpos.ptr, ld=qpos.ld)
+                return [k4, q1, st(3, K=256, src=S3, aux=S2, dst=S0), gemm(f"{li}.qk", S0, 256, 512, out=qkv.slice(0, 512)),
+                        gemm(f"{li}.v", S3, 256, 256, out=qkv.slice(512, 256))]
             k4 = st(4, N=512, dst=BIG, aux=(-1 if ref_global is not None else REF), w=e.qpos0[0].data_ptr(), bias=e.qpos0[1].data_ptr(), g0=ref_global)
             return [k4, gemm("qpos1", BIG, 512, 256, dst=S1, out=qpos), st(3, K=256, src=tgt_slot, aux=S1, dst=S2),
                     gemm(f"{li}.qk", S2, 256, 512, out=qkv.slice(0, 512)), gemm(f"{li}.v", tgt_slot, 256, 256, out=qkv.slice(512, 256))]
 
         fl_pre = 2.0 * R * (512 * 256 + 256 * 768)
-        self._rc_program([load(tgt, S0)] + pre_attention(0, S0, refs[0].data_ptr()), R, "dec0.pre", fl_pre)
+        first_slot = S3 if lean else S0
+        self._rc_program([load(tgt, first_slot)] + pre_attention(0, first_slot, refs[0].data_ptr()), R, "dec0.pre", fl_pre, lds)
         for li in range(e.nl):
             p = f"{hp}.decoder.layers.{li}"
             att = self.mha(qkv, B, Q, f"dec{li}.att")
             prog = [load(att, S0), load(tgt, S1), load(qpos, S2), gemm_ln(f"{li}.o", S0, 256, S1, f"{p}.norm1", S3, out=t1),
                     st(3, K=256, src=S3, aux=S2, dst=S0), gemm(f"{li}.offaw", S0, 256, 288, out=offaw, f32=True)]
-            self._rc_program(prog, R, f"dec{li}.post_attn", 2.0 * R * 256 * (256 + 288))
+            self._rc_program(prog, R, f"dec{li}.post_attn", 2.0 * R * 256 * (256 + 288), lds)
             ms = self._new(f"dec{li}.msda", R, 1, 1, 256)
             vsl = value.slice(li * 256, 256)
             self._op(lib.fx_msda_bf16, vsl.ptr, vsl.ld, self.shapes_t.data_ptr(), self.starts_t.data_ptr(), 3, 4, offaw.ptr, offaw.ld,
@@ -936,8 +971,11 @@ class _Plan(StdcPlanMixin, _PlanBase):
             out = self._new(f"dec{li}.out", R, 1, 1, 256)
             wl, bl = e.bbox_last[f"dec{li}"]
             last = li == e.nl - 1
-            prog = [load(ms, S0), load(t1, S1), gemm_ln(f"{li}.o2", S0, 256, S1, f"{p}.norm2", S2),
-                    gemm(f"{li}.f1", S2, 256, 1024, dst=BIG, act=relu), gemm_ln(f"{li}.f2", BIG, 1024, S2, f"{p}.norm3", S3, out=out),
+            if lean:   # ms S0, t1 S1 -> LN2 S2 -> FFN (chunks in S0 / S1) -> LN3 S3 (+ global) -> bbox MLP through S0, S1
+                ffn = [ffn_ln(li, S2, S2, S0, S1, f"{p}.norm3", S3, out=out)]
+            else:
+                ffn = [gemm(f"{li}.f1", S2, 256, 1024, dst=BIG, act=relu), gemm_ln(f"{li}.f2", BIG, 1024, S2, f"{p}.norm3", S3, out=out)]
+            prog = [load(ms, S0), load(t1, S1), gemm_ln(f"{li}.o2", S0, 256, S1, f"{p}.norm2", S2)] + ffn + [
                     gemm(f"{li}.bb0", S3, 256, 256, dst=S0, act=relu), gemm(f"{li}.bb1", S0, 256, 256, dst=S1, act=relu),
                     st(5, K=256, src=S1, aux=(-1 if last else REF), w=wl.data_ptr(), bias=bl.data_ptr(), g0=refs[li].data_ptr(), g1=refs[li + 1].data_ptr())]
             fl = 2.0 * R * (256 * 256 * 3 + 2 * 256 * 1024)
@@ -947,7 +985,7 @@ class _Plan(StdcPlanMixin, _PlanBase):
             else:
                 prog += pre_attention(li + 1, S3)
                 fl += fl_pre
-            self._rc_program(prog, R, f"dec{li}.post_msda", fl)
+            self._rc_program(prog, R, f"dec{li}.post_msda", fl, lds)
             tgt = out
         return logits
 

@@ -79,14 +79,89 @@ def share_parameters(engine_graph, reference_module) -> int:
     return n
 
 
+class _FxAdapterState:
+    """What the adapters add to the reference module lives in ``__dict__`` and is NOT state: the engine (``_fx_engine``: a ctypes.CDLL, plans with
+    function pointers and hipGraph handles), the parameter-version key it was packed from and the HIP training graph that shares this module's
+    parameters (``_fx_train``).  ``copy.deepcopy`` (FocoosModel.export models/focoos_model.py:465, EMAState trainer/solver/ema.py:49) and pickling
+    into spawned ranks (utils/distributed/dist.py:78-91) therefore drop them; the copy re-builds each lazily on its first forward, from ITS parameters."""
+
+    _FX_TRANSIENT = ("_fx_engine", "_fx_version", "_fx_train")
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        st["_fx_engine"] = None
+        st["_fx_version"] = None
+        st.pop("_fx_train", None)
+        return st
+
+
+_CLASSES: dict = {}
+
+
+def _publish(cls):
+    """Adapter classes are created against the installed reference at run time; pickle finds a class by ``module.qualname``, so each is given
+    this module as its home and served by the module-level ``__getattr__`` below (also in a freshly spawned rank)."""
+    cls.__module__ = __name__
+    cls.__qualname__ = cls.__name__
+    _CLASSES[cls.__name__] = cls
+    return cls
+
+
+_FACTORIES = {"EngineFAIDetr": "make_engine_class", "EngineFAIMaskFormer": "make_mf_engine_class", "EngineBisenetFormer": "make_bf_engine_class"}
+
+
+def __getattr__(name):
+    if name in _FACTORIES:
+        return globals()[_FACTORIES[name]]()
+    if name in ("EngineDETRProcessor", "EngineMaskFormerProcessor", "EngineBisenetFormerProcessor"):
+        make_processor_classes()
+        return _CLASSES[name]
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
+
+def _mask_family_forward(self, images, targets, OutputCls):
+    """Shared forward of the two mask-family adapters - every branch of FAIMaskFormer.forward (fai_mf/modelling.py:712-725) /
+    BisenetFormer.forward (bisenetformer/modelling.py:594-621) on the engine, none on the reference's stock graph:
+    train + targets -> losses of the HIP training graph + the last head's probabilities (not upsampled); train without targets -> the same
+    forward, loss None; eval -> the inference engine (masks at input resolution); eval + targets -> the engine's outputs AND the losses
+    of the training graph in eval mode (frozen statistics; MaskFormerHead.forward computes them whenever targets are given, :603-609)."""
+    _require_engine_input(images, 1)   # any size >= 32 (ceil-size arithmetic); raises otherwise
+    x = images
+    if x.dim() == 4 and x.shape[1] == 3 and x.shape[-1] != 3:
+        x = x.permute(0, 2, 3, 1)
+    x = (x if x.dtype == torch.uint8 else x.float()).contiguous()
+    has_targets = targets is not None and len(targets) > 0
+    losses = None
+    if self.training or has_targets:
+        from . import train_nn
+
+        train_nn.WEIGHTS_EPOCH[0] += 1     # an external optimizer may have stepped the parameters since the last forward
+        net = self._fx_train_graph()
+        if has_targets:
+            losses = net(x, targets)
+        else:
+            net.forward_outputs(x)
+        if self.training:
+            with torch.no_grad():
+                o = net.last_outputs
+                logits = torch.softmax(o["pred_logits"].float(), -1)[..., :-1]
+                masks = torch.sigmoid(o["pred_masks"])
+            return OutputCls(masks=masks, logits=logits, loss=losses)
+    self._fx_sync()
+    pl = self._fx_engine.forward(x, full_masks=True)
+    return OutputCls(masks=pl.masks.clone(), logits=pl.probs.clone(), loss=losses)
+
+
 def make_engine_class():
     """Build the adapter class against the installed reference (import deferred: focoos is optional)."""
+    if "EngineFAIDetr" in _CLASSES:
+        return _CLASSES["EngineFAIDetr"]
     from focoos.models.fai_detr.modelling import FAIDetr as RefFAIDetr
     from focoos.models.fai_detr.ports import DETRModelOutput
 
     from .engine import DetrEngine
 
-    class EngineFAIDetr(RefFAIDetr):
+    class EngineFAIDetr(_FxAdapterState, RefFAIDetr):
         """Reference FAIDetr with its eval forward replaced by the gfx950 engine."""
 
         def __init__(self, config):
@@ -134,23 +209,25 @@ def make_engine_class():
                 losses = self._fx_train_graph()(x, targets)
                 z = torch.zeros(0, 0, 0, device=images.device)
                 return DETRModelOutput(boxes=z, logits=z, loss=losses)
-            if targets is not None and len(targets) > 0:
-                return super().forward(images, targets)
+            # eval mode: FAIDetr.forward returns loss=None whether or not targets were passed (modelling.py:1352-1358: the head's losses
+            # are dropped), so the outputs are the engine's either way
             self._fx_sync()
             pl = self._fx_engine.forward(x)
             return DETRModelOutput(logits=pl.probs.clone(), boxes=pl.boxes.clone(), loss=None)
 
-    return EngineFAIDetr
+    return _publish(EngineFAIDetr)
 
 
 def make_mf_engine_class():
     """Adapter for the MaskFormer family: reference FAIMaskFormer whose eval forward is the gfx950 engine."""
+    if "EngineFAIMaskFormer" in _CLASSES:
+        return _CLASSES["EngineFAIMaskFormer"]
     from focoos.models.fai_mf.modelling import FAIMaskFormer as RefFAIMaskFormer
     from focoos.models.fai_mf.ports import MaskFormerModelOutput
 
     from .engine_mf import MfEngine
 
-    class EngineFAIMaskFormer(RefFAIMaskFormer):
+    class EngineFAIMaskFormer(_FxAdapterState, RefFAIMaskFormer):
         def __init__(self, config):
             super().__init__(config)
             self._fx_engine: Optional[MfEngine] = None
@@ -181,40 +258,21 @@ def make_mf_engine_class():
             return g[0]
 
         def forward(self, images, targets=[]):
-            _require_engine_input(images, 1)   # any size >= 32 (ceil-size arithmetic); raises otherwise: no fallback to the reference's own graph
-            x = images
-            if x.dim() == 4 and x.shape[1] == 3 and x.shape[-1] != 3:
-                x = x.permute(0, 2, 3, 1)
-            x = (x if x.dtype == torch.uint8 else x.float()).contiguous()
-            if self.training and targets is not None and len(targets) > 0:
-                # FAIMaskFormer.forward in train mode (modelling.py:712-725): losses from the HIP training graph over this module's parameters
-                from . import train_nn
+            return _mask_family_forward(self, images, targets, MaskFormerModelOutput)
 
-                train_nn.WEIGHTS_EPOCH[0] += 1
-                net = self._fx_train_graph()
-                losses = net(x, targets)
-                with torch.no_grad():
-                    o = net.last_outputs
-                    logits = torch.softmax(o["pred_logits"].float(), -1)[..., :-1]
-                    masks = torch.sigmoid(o["pred_masks"])
-                return MaskFormerModelOutput(masks=masks, logits=logits, loss=losses)
-            if self.training or (targets is not None and len(targets) > 0):
-                return super().forward(images, targets)
-            self._fx_sync()
-            pl = self._fx_engine.forward(x, full_masks=True)
-            return MaskFormerModelOutput(masks=pl.masks.clone(), logits=pl.probs.clone(), loss=None)
-
-    return EngineFAIMaskFormer
+    return _publish(EngineFAIMaskFormer)
 
 
 def make_bf_engine_class():
     """Adapter for the BiSeNetFormer family: reference BisenetFormer whose eval forward is the gfx950 engine."""
+    if "EngineBisenetFormer" in _CLASSES:
+        return _CLASSES["EngineBisenetFormer"]
     from focoos.models.bisenetformer.modelling import BisenetFormer as RefBisenetFormer
     from focoos.models.bisenetformer.ports import BisenetFormerOutput
 
     from .engine_bf import BfEngine
 
-    class EngineBisenetFormer(RefBisenetFormer):
+    class EngineBisenetFormer(_FxAdapterState, RefBisenetFormer):
         def __init__(self, config):
             super().__init__(config)
             self._fx_engine: Optional[BfEngine] = None
@@ -246,31 +304,9 @@ def make_bf_engine_class():
             return g[0]
 
         def forward(self, images, targets=[]):
-            _require_engine_input(images, 1)   # any size >= 32 (ceil-size arithmetic); raises otherwise: no fallback to the reference's own graph
-            x = images
-            if x.dim() == 4 and x.shape[1] == 3 and x.shape[-1] != 3:
-                x = x.permute(0, 2, 3, 1)
-            x = (x if x.dtype == torch.uint8 else x.float()).contiguous()
-            if self.training and targets is not None and len(targets) > 0:
-                # BisenetFormer.forward in train mode (modelling.py:594-609): the dict of weighted losses from the HIP training graph on this
-                # module's own parameters (TrainerLoop.run_step sums it and calls backward) + the last head's probabilities (not upsampled)
-                from . import train_nn
+            return _mask_family_forward(self, images, targets, BisenetFormerOutput)
 
-                train_nn.WEIGHTS_EPOCH[0] += 1     # an external optimizer may have stepped the parameters since the last forward
-                net = self._fx_train_graph()
-                losses = net(x, targets)
-                with torch.no_grad():
-                    o = net.last_outputs
-                    logits = torch.softmax(o["pred_logits"].float(), -1)[..., :-1]
-                    masks = torch.sigmoid(o["pred_masks"])
-                return BisenetFormerOutput(masks=masks, logits=logits, loss=losses)
-            if self.training or (targets is not None and len(targets) > 0):
-                return super().forward(images, targets)
-            self._fx_sync()
-            pl = self._fx_engine.forward(x, full_masks=True)
-            return BisenetFormerOutput(masks=pl.masks.clone(), logits=pl.probs.clone(), loss=None)
-
-    return EngineBisenetFormer
+    return _publish(EngineBisenetFormer)
 
 
 def make_processor_classes():
@@ -278,6 +314,8 @@ def make_processor_classes():
     the reference processors (pre-process, training targets, export paths untouched) whose ``postprocess`` on GPU tensors runs the
     device kernels (fx_topk_rows_f32 + fx_detr_postprocess; fx_mf_postprocess / fx_seg_postprocess) and builds the reference's own
     ``FocoosDetections`` objects from ONE packed device->host copy."""
+    if "EngineDETRProcessor" in _CLASSES:
+        return _CLASSES["EngineDETRProcessor"], _CLASSES["EngineMaskFormerProcessor"], _CLASSES["EngineBisenetFormerProcessor"]
     from focoos.models.bisenetformer.processor import BisenetFormerProcessor as RefBF
     from focoos.models.fai_detr.processor import DETRProcessor as RefDETR
     from focoos.models.fai_mf.processor import MaskFormerProcessor as RefMF
@@ -313,7 +351,7 @@ def make_processor_classes():
             mirror = fxp.BisenetFormerProcessor(cfg_dict(self), self.image_size)
             return convert(mirror.postprocess(output, inputs, class_names, threshold=threshold))
 
-    return EngineDETRProcessor, EngineMaskFormerProcessor, EngineBisenetFormerProcessor
+    return _publish(EngineDETRProcessor), _publish(EngineMaskFormerProcessor), _publish(EngineBisenetFormerProcessor)
 
 
 def register() -> None:

@@ -686,6 +686,22 @@ class TrainStep:
                 self.opt.set_lr_scale(f, self._base_lrs)
                 self._lr_factor = f
         self.iteration += 1
+        losses = self._forward_backward(images, targets)
+        self.reducer.launch()
+        self.reducer.wait()
+        self.opt.step()
+        nn_.WEIGHTS_EPOCH[0] += 1
+        if self.ema is not None:
+            self.ema.update()
+        if self.check_every > 0 and self.iteration % self.check_every == 0:
+            self.check()
+        return losses
+
+    def _forward_backward(self, images: torch.Tensor, targets: Sequence, **forced) -> Dict[str, torch.Tensor]:
+        """The eager step up to the gradients: zeroed flat gradient buffer, weight images re-packed in one launch, forward + criterion +
+        backward with the gradient kernels accumulating straight into the flat views and the weight gradients on the side stream (joined
+        before returning).  ``forced``: teacher-forcing arguments of the model's forward (forced_topk / forced_attn / fixed_matches)."""
+        nn_ = self._nn
         self.opt.zero_grad()
         for n, p in self.named:  # gradient kernels / autograd accumulate in place into these views
             p.grad = self.opt.grads[n]
@@ -697,7 +713,7 @@ class TrainStep:
         if self.wgrad_stream is not None:
             nn_.WGRAD_STREAM[dev] = self.wgrad_stream   # weight gradients overlap the input-gradient chain (train_nn._wgrad_fork)
         try:
-            losses = self.model(images, targets)
+            losses = self.model(images, targets, **forced)
             total = torch.stack(list(losses.values())).sum()   # 2 launches instead of one add per loss term
             total.backward()
         finally:
@@ -705,14 +721,19 @@ class TrainStep:
             nn_.pin_stream(self.opt.dev, False)
             self._join_wgrads()
             nn_.WGRAD_STREAM.pop(dev, None)
-        self.reducer.launch()
-        self.reducer.wait()
-        self.opt.step()
-        nn_.WEIGHTS_EPOCH[0] += 1
-        if self.ema is not None:
-            self.ema.update()
-        if self.check_every > 0 and self.iteration % self.check_every == 0:
-            self.check()
+        return losses
+
+    def forward_backward(self, images: torch.Tensor, targets: Sequence, **forced) -> Dict[str, torch.Tensor]:
+        """``step()`` WITHOUT the all-reduce / optimizer / EMA: the production forward + backward (same routing, streams and buffers) leaving
+        the gradients in ``self.opt.grads`` - what the parity tests at the BASELINE shapes compare with the oracle's gradients
+        (tests/test_gpu_train_baseline_configs.py)."""
+        if self.stream is None or not images.is_cuda:
+            return self._forward_backward(images, targets, **forced)
+        cur = torch.cuda.current_stream(images.device)
+        self.stream.wait_stream(cur)
+        with torch.cuda.stream(self.stream):
+            losses = self._forward_backward(images, targets, **forced)
+        cur.wait_stream(self.stream)
         return losses
 
     def check(self) -> None:

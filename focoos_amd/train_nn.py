@@ -186,6 +186,17 @@ class WeightPacker:
 
 _DESC_CACHE: Dict[tuple, tuple] = {}
 
+# Kernel census of a training step (tests / profiles): set to a dict and every convolution launch of the autograd graph - forward, input
+# gradient, weight gradient - is counted under the label of the kernel the library routes it to (fx_conv2d_variant /
+# fx_conv2d_wgrad_variant: the launch's own routing function).  None (default): no bookkeeping on the hot path.
+VARIANT_CENSUS: List[Optional[Dict[str, int]]] = [None]
+
+
+def _census(label: str) -> None:
+    c = VARIANT_CENSUS[0]
+    c[label] = c.get(label, 0) + 1
+
+
 
 def _conv_call(lib, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], N: int, KH: int, KW: int, stride: int, pad: int,
                act: Optional[str], residual: Optional[torch.Tensor], res_mode: int = 0, out_f32: bool = False,
@@ -217,6 +228,10 @@ def _conv_call(lib, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tenso
     d.residual = residual.data_ptr() if residual is not None else None
     d.mask, d.ldm = (mask.data_ptr(), N) if mask is not None else (None, 0)   # result *= (mask > 0): [B,Ho,Wo,N] bf16 (fx_conv_desc.mask)
     check(lib.fx_conv2d_nhwc_bf16(ref, _stream(x.device)), "fx_conv2d_nhwc_bf16")
+    if VARIANT_CENSUS[0] is not None:
+        buf = C.create_string_buffer(64)
+        check(lib.fx_conv2d_variant(ref, buf, 64), "fx_conv2d_variant")
+        _census("conv:" + buf.value.decode())
     return y
 
 
@@ -389,6 +404,10 @@ def _conv_param_grads(layer, x: torch.Tensor, dz: torch.Tensor, scale: Optional[
     ws = _wgrad_workspace(S * slab, dev)
     check(lib.fx_conv2d_wgrad_partial_nhwc_bf16(x.data_ptr(), Cc, dz.data_ptr(), N, ws.data_ptr(), slab, S, B, H, W_, Cc, Ho, Wo, N, k, k,
                                                 layer.stride, layer.pad, st), "fx_conv2d_wgrad_partial_nhwc_bf16")
+    if VARIANT_CENSUS[0] is not None:
+        buf = C.create_string_buffer(64)
+        check(lib.fx_conv2d_wgrad_variant(B, Ho, Wo, Cc, N, k, k, layer.stride, layer.pad, buf, 64), "fx_conv2d_wgrad_variant")
+        _census("wgrad:" + buf.value.decode())
     dw = wparam.grad if direct else torch.empty(N, Cc, k, k, dtype=torch.float32, device=dev)
     check(lib.fx_unpack_conv_wgrad_sum_f32(ws.data_ptr(), slab, S, scale.data_ptr() if scale is not None else None, dw.data_ptr(), N, Cc, k, k, Cc,
                                            int(direct), st), "fx_unpack_conv_wgrad_sum_f32")

@@ -29,7 +29,7 @@ extern "C" {
 /* Bumped whenever a descriptor struct's layout OR the semantics the host relies on change (version 2: fx_conv_desc grew mask / ldm /
  * reserved0 and the library applies the ReLU mask the previous bottleneck skips; version 3: fx_pw_chain_desc grew pool / ldp / img_h / img_w);
  * focoos_amd/_lib.py refuses a library of another version. */
-#define FX_ABI_VERSION 6
+#define FX_ABI_VERSION 7
 
 enum { FX_OK = 0, FX_ERR_INVALID_ARGUMENT = -1, FX_ERR_LAUNCH = -2, FX_ERR_UNSUPPORTED = -3, FX_ERR_RUNTIME = -4 };
 enum { FX_ACT_NONE = 0, FX_ACT_RELU = 1, FX_ACT_SILU = 2, FX_ACT_GELU = 3 };
@@ -553,6 +553,9 @@ int fx_linear_wgrad_bias_bf16(const void* x, int ldx, const void* dz, int lddz, 
  * fx_unpack_conv_wgrad_sum_f32 adds the slabs while it re-lays the gradient out for the master weight.  The L2 atomic units sustain
  * ~0.6 TB/s of fp32 adds, plain stores the HBM rate, so this is the path for the 3x3 / wide layers whose dW is megabytes. */
 int fx_conv2d_wgrad_splits(int B, int Ho, int Wo, int C, int N, int KH, int KW);
+/* Label of the kernel fx_conv2d_wgrad_partial_nhwc_bf16 runs for this layer shape ("conv_wgrad_dma<3x3>", "conv_wgrad_dma<pw>",
+ * "conv_wgrad<pw>", "conv_wgrad<im2col>"): the launch's own routing predicate, for kernel censuses (ABI 7).  out: at least 32 bytes. */
+int fx_conv2d_wgrad_variant(int B, int Ho, int Wo, int C, int N, int KH, int KW, int stride, int pad, char* out, int cap);
 int fx_conv2d_wgrad_partial_nhwc_bf16(const void* x, int ldx, const void* dz, int lddz, float* partials, int64_t split_stride, int splits, int B,
                                       int H, int W, int C, int Ho, int Wo, int N, int KH, int KW, int stride, int pad, fx_stream_t stream);
 int fx_unpack_conv_wgrad_sum_f32(const float* partials, int64_t split_stride, int splits, const float* scale, float* dw_master, int N, int C, int KH,

