@@ -43,6 +43,10 @@ def parse():
                          "all-reduce + fused AdamW, bs=16/GPU (BASELINE config 4 with BatchNorm frozen)")
     ap.add_argument("--norm", default="FrozenBN", choices=["FrozenBN", "BN", "SyncBN"],
                     help="--train: BatchNorm mode (FrozenBN = reference freeze_bn; BN / SyncBN = batch statistics, SyncBN all-reduces them)")
+    ap.add_argument("--dtype", default=None, choices=["bf16", "fp16"],
+                    help="--train: 16-bit element type of activations / gradients / weight images (default bf16; bisenetformer-* training: fp16 = "
+                         "BASELINE configs[4], the reference's fp16 autocast + GradScaler: fp16 MFMA, fp32 masters, dynamic loss scale with "
+                         "skip-on-overflow inside the fused AdamW launch)")
     ap.add_argument("--streams", type=int, default=None, help="concurrent batch parts per step (default: engine default / FX_STREAMS)")
     ap.add_argument("--mf-full-masks", action="store_true", help="fai-mf-*: also write the reference's [B,Q,H,W] fp32 `masks` tensor")
     ap.add_argument("--mf-masks-d2h", action="store_true", help="fai-mf-*: include the D2H copy of the bit-packed mask buffer in the step")
@@ -62,6 +66,7 @@ def parse():
     mf = a.model.startswith("fai-mf")
     a.family = "fai_mf" if mf else ("bisenetformer" if a.model.startswith("bisenetformer") else "fai_detr")
     bf_train = a.train and a.family == "bisenetformer"   # BASELINE config 5: 1024 x 1024, 8 images per GPU
+    a.dtype = a.dtype or ("fp16" if bf_train else "bf16")   # BASELINE configs[4] names fp16
     a.batch = a.batch or (8 if bf_train else (16 if (mf or a.train) else 32))
     a.size = a.size or (1024 if bf_train else (800 if mf else 640))
     return a
@@ -344,6 +349,10 @@ def train_measure(args, world, rank, local, with_roofline=True):
     cfg = ModelRegistry.get_model_info(args.model)["config"]
     K, B, S = int(cfg["num_classes"]), args.batch, args.size
     bf = args.family == "bisenetformer"
+    from focoos_amd import _lib as fxlib
+
+    dtype = getattr(args, "dtype", None) or "bf16"
+    prev_dtype = fxlib.set_compute_dtype(dtype)   # the element type of everything built below (restored before returning)
     if bf:
         from focoos_amd.train_bf import BisenetFormerTrainable
 
@@ -400,23 +409,27 @@ def train_measure(args, world, rank, local, with_roofline=True):
         crit = ("point-sampled mask Hungarian set criterion over 7 prediction sets" if bf else
                 ("point-sampled mask Hungarian set criterion over 10 prediction sets" if args.family == "fai_mf" else "Hungarian set criterion over 7 prediction sets"))
         out = ({
-            "metric": f"images/sec @ {S}^2 (train bs={B}/GPU" + ("; bf16 variant of BASELINE configs[4], which names fp16" if bf else "") + ")", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "metric": f"images/sec @ {S}^2 (train bs={B}/GPU" + ("; bf16 variant of BASELINE configs[4], which names fp16" if (bf and dtype != "fp16") else "") + ")", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": dtype, "data": "synthetic",
             "config": {"steps_are": "hipGraph replays (forward graph, backward graph) around an eager criterion + optimizer" if stepper_graphs.on else "eager launches",
                        "workload": f"{args.model} training step: forward (train mode, norm={args.norm}) + {crit} "
-                                   f"+ backward + gradient all-reduce + fused AdamW/clip, bs={B}/GPU, {S}x{S}, bf16 activations and gradients, "
-                                   "fp32 master weights; HIP autograd nodes; "
+                                   f"+ backward + gradient all-reduce + fused AdamW/clip, bs={B}/GPU, {S}x{S}, {dtype} activations and gradients"
+                                   + (" (fp16 MFMA; dynamic loss scale as torch.amp.GradScaler: init 2**10, unscale / skip-on-inf / scale update "
+                                      "inside the fused AdamW launch), " if dtype == "fp16" else ", ")
+                                   + "fp32 master weights; HIP autograd nodes; "
                                    + ("forward and backward replayed as two hipGraphs around an eager criterion" if getattr(stepper_graphs, "on", False) else "eager launches, no graph")
-                                   + ("; DEVIATION from BASELINE configs[4] ('fp16'): the engine computes in bf16 without a GradScaler - on the real "
+                                   + ("; DEVIATION from BASELINE configs[4] ('fp16'): this run computes in bf16 without a GradScaler (--dtype bf16) - on the real "
                                       "reference the training losses under fp16 autocast deviate 0.66 % from fp32, under bf16 autocast 1.7 % "
-                                      "(tests/test_oracle_vs_reference.py::test_reference_fp16_amp_losses_vs_fp32_and_bf16_autocast)" if bf else ""),
+                                      "(tests/test_oracle_vs_reference.py::test_reference_fp16_amp_losses_vs_fp32_and_bf16_autocast)" if (bf and dtype != "fp16") else ""),
                        "global_batch": B * world, "parallelism": f"dp{world} (RCCL all-reduce of one flat fp32 gradient buffer, 64 MiB buckets, "
                                                                  "segments launched from backward hooks)"},
             "alg_gflop_per_image": round(alg, 1), "frac_of_bf16_mfma_roofline_whole_path": round(value / world * alg * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
-            "roofline": roof, "final_total_loss": round(total, 4), "dp_check": dp_check})
+            "roofline": roof, "final_total_loss": round(total, 4), "dp_check": dp_check,
+            "loss_scale": stepper.opt.scaler_state() if stepper.opt.scaler is not None else None})
     del stepper, model
     torch.cuda.empty_cache()
+    fxlib.set_compute_dtype(prev_dtype)
     return out
 
 
@@ -516,8 +529,8 @@ def other_configs(args, world, rank, local, out):
     plan = [("infer_fai-mf-l-coco-ins_bs16_800", dict(train=False, model="fai-mf-l-coco-ins", family="fai_mf", batch=16, size=800, steps=10, warmup=3)),
             ("infer_bisenetformer-l-ade_bs32_640", dict(train=False, model="bisenetformer-l-ade", family="bisenetformer", batch=32, size=640, steps=10, warmup=3)),
             ("train_fai-detr-l-obj365_bs16_640_frozenbn", dict(train=True, model="fai-detr-l-obj365", family="fai_detr", batch=16, size=640, norm="FrozenBN", steps=6, warmup=4)),
-            ("train_bisenetformer-l-ade_bs8_1024_bn", dict(train=True, model="bisenetformer-l-ade", family="bisenetformer", batch=8, size=1024,
-                                                          norm="SyncBN" if world > 1 else "BN", steps=4, warmup=4))]
+            ("train_bisenetformer-l-ade_bs8_1024_bn_fp16", dict(train=True, model="bisenetformer-l-ade", family="bisenetformer", batch=8, size=1024,
+                                                               norm="SyncBN" if world > 1 else "BN", steps=4, warmup=4, dtype="fp16"))]
     for name, over in plan:
         a = copy.copy(args)
         for k, v in over.items():
@@ -525,11 +538,14 @@ def other_configs(args, world, rank, local, out):
         try:
             r = train_measure(a, world, rank, local, with_roofline=False) if a.train else infer_measure(a, world, rank, local, light=True)
             if rank == 0:
-                legs[name] = {k: r[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "config", "alg_gflop_per_image",
-                                                "frac_of_bf16_mfma_roofline_whole_path") if k in r}
+                legs[name] = {k: r[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "alg_gflop_per_image",
+                                                "frac_of_bf16_mfma_roofline_whole_path", "loss_scale", "final_total_loss") if k in r}
         except Exception as e:   # a failed leg must not take the headline with it
             if rank == 0:
                 legs[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            from focoos_amd import _lib as fxlib
+
+            fxlib.set_compute_dtype("bf16")
     timer.cancel()
 
 

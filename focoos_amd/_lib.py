@@ -8,7 +8,7 @@ import ctypes as C
 import os
 from typing import Optional
 
-from .build import LIB_PATH
+from .build import LIB_PATH, LIB_PATH_FP16
 
 FX_ACT = {None: 0, "none": 0, "relu": 1, "silu": 2, "gelu": 3}
 
@@ -119,6 +119,7 @@ SIGNATURES = {
     "fx_msda_train_bwd_slab": [_vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "fx_adamw_workspace_bytes": [],
     "fx_adamw_step_f32": [_vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp],
+    "fx_adamw_step_scaled_f32": [_vp, _vp, _vp, _vp, C.c_int64, _vp, _vp, _vp, _vp, _i, _f, _f, _f, _f, _vp, _vp, _vp, _f, _f, _i, _vp],
     "fx_conv2d_wgrad_nhwc_bf16": [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "fx_conv2d_wgrad_bias_nhwc_bf16": [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "fx_point_sample_f32": [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],
@@ -185,10 +186,36 @@ SIGNATURES = {
     "fx_graph_time": [_vp, _vp, _i, C.POINTER(C.c_float)],
 }
 
-_lib: Optional[C.CDLL] = None
+# One library per 16-bit storage element: "bf16" = libfocoos_amd.so (the product: inference engines and the default training step),
+# "fp16" = libfocoos_amd_fp16.so (same sources, -DFX_FP16=1: the training step under a loss scale - BASELINE configs[4], the reference's
+# fp16 autocast + GradScaler).  The CURRENT element type is process state: everything that allocates activations / weight images asks
+# act_dtype(), everything that launches asks load(); a TrainStep pins its own type at the top of every step.  Inference engines are bf16.
+_libs: dict = {}
+_DTYPE = [os.environ.get("FX_DTYPE", "bf16")]
+
+
+def compute_dtype() -> str:
+    return _DTYPE[0]
+
+
+def set_compute_dtype(name: str) -> str:
+    """Select the library / element type used by objects created and steps run from now on; returns the previous one."""
+    if name not in ("bf16", "fp16"):
+        raise FocoosAmdError(f"compute dtype {name!r}: the engine has a bfloat16 and an fp16 (+ loss scale) build")
+    prev, _DTYPE[0] = _DTYPE[0], name
+    return prev
+
+
+def act_dtype():
+    """torch dtype of activations, packed weight images and activation gradients under the current element type."""
+    import torch
+
+    return torch.float16 if _DTYPE[0] == "fp16" else torch.bfloat16
 
 
 def lib_path() -> str:
+    if _DTYPE[0] == "fp16":
+        return os.environ.get("FOCOOS_AMD_LIB_FP16", LIB_PATH_FP16)
     return os.environ.get("FOCOOS_AMD_LIB", LIB_PATH)
 
 
@@ -196,10 +223,10 @@ FX_ABI_VERSION = 7   # = include/focoos_amd.h (tests/test_host_cpu.py compares t
 
 
 def load() -> C.CDLL:
-    """Load the HIP library; raise loudly when it is absent (no fallback)."""
-    global _lib
-    if _lib is not None:
-        return _lib
+    """Load the HIP library of the current element type; raise loudly when it is absent (no fallback)."""
+    name = _DTYPE[0]
+    if name in _libs:
+        return _libs[name]
     import torch  # noqa: F401  -- must be imported first: it loads the HIP runtime (its bundled libamdhip64) our .so binds to
     path = lib_path()
     if not os.path.exists(path):
@@ -208,8 +235,8 @@ def load() -> C.CDLL:
             "(or `python -m focoos_amd.build`). focoos_amd has no CPU/PyTorch fallback by design."
         )
     lib = C.CDLL(path)
-    for name, argtypes in SIGNATURES.items():
-        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+    for sym, argtypes in SIGNATURES.items():
+        fn = getattr(lib, sym)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = C.c_int
     lib.fx_mha_bwd_workspace_bytes.restype = C.c_size_t
@@ -221,8 +248,10 @@ def load() -> C.CDLL:
     lib.fx_error_string.argtypes = [C.c_int]
     lib.fx_error_string.restype = C.c_char_p
     if lib.fx_abi_version() != FX_ABI_VERSION:
-        raise FocoosAmdError(f"ABI version mismatch: library {lib.fx_abi_version()} != binding {FX_ABI_VERSION} (stale libfocoos_amd.so: rebuild)")
-    _lib = lib
+        raise FocoosAmdError(f"ABI version mismatch: library {lib.fx_abi_version()} != binding {FX_ABI_VERSION} (stale {os.path.basename(path)}: rebuild)")
+    if bool(lib.fx_build_flags() & 2) != (name == "fp16"):
+        raise FocoosAmdError(f"{path} was built for the other 16-bit element type (fx_build_flags = {lib.fx_build_flags()}) than {name!r}")
+    _libs[name] = lib
     return lib
 
 

@@ -13,6 +13,8 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB_DIR = os.path.join(PKG, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libfocoos_amd.so")
+# the same sources with the 16-bit storage element = IEEE fp16 (csrc/common.h FX_FP16): the training library of the fp16 + loss-scale step
+LIB_PATH_FP16 = os.path.join(LIB_DIR, "libfocoos_amd_fp16.so")
 ARCH = "gfx950"
 # The kernels are compiled WITHOUT packed-fp32 VALU instructions (v_pk_mul/add/fma_f32, v_pk_mov_b32): on MI355X / ROCm 7.2 a wave that
 # executes them while waves of a second hardware queue are resident on its CU computes wrong values in lanes 48-63 of one operand
@@ -62,9 +64,11 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True, out_path: str = None) -> str:
+def build(force: bool = False, verbose: bool = True, out_path: str = None, fp16: bool = False) -> str:
     """Compile every csrc/*.hip for gfx950 and link the shared library (`out_path`: a variant library next to the product one, used by
-    the packed-fp32 bisection; the product path keeps its stamp file)."""
+    the packed-fp32 bisection; the product path keeps its stamp file).  ``fp16``: the fp16-element library (objects under lib/fp16/)."""
+    if fp16 and out_path is None:
+        return _build_fp16(force, verbose)
     if out_path is None and not force and not needs_build():
         return LIB_PATH
     target = out_path or LIB_PATH
@@ -94,6 +98,54 @@ def build(force: bool = False, verbose: bool = True, out_path: str = None) -> st
         if base == "runtime.hip":
             flags = flags + [f"-DFX_BUILD_FLAGS={1 if pk else 0}"]
         jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + flags + EXTRA_FLAGS + ["-c", src, "-o", obj])
+    _run_jobs(jobs, verbose)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", target] + objs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    if out_path is None:
+        with open(STAMP_PATH, "w") as f:
+            f.write(_stamp() + "\n")
+    else:
+        shutil.rmtree(objdir, ignore_errors=True)
+    return target
+
+
+def _build_fp16(force: bool, verbose: bool) -> str:
+    """libfocoos_amd_fp16.so: same recipe with -DFX_FP16=1, own object directory and stamp; rebuilt when a source / header is newer."""
+    objdir = os.path.join(LIB_DIR, "fp16")
+    os.makedirs(objdir, exist_ok=True)
+    stamp = os.path.join(objdir, "build_stamp.txt")
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(PKG, "..", "include", "*.h"))
+    fresh = (not force and os.path.exists(LIB_PATH_FP16) and os.path.exists(stamp) and open(stamp).read().strip() == _stamp() + " fp16"
+             and all(os.path.getmtime(d) <= os.path.getmtime(LIB_PATH_FP16) for d in deps))
+    if fresh:
+        return LIB_PATH_FP16
+    hipcc, pk = _hipcc(), _pk_units()
+    hdr_t = max(os.path.getmtime(h) for h in deps if h.endswith(".h"))
+    stamp_ok = os.path.exists(stamp) and open(stamp).read().strip() == _stamp() + " fp16"
+    jobs, objs = [], []
+    for src in sources():
+        base = os.path.basename(src)
+        obj = os.path.join(objdir, base.replace(".hip", ".o"))
+        objs.append(obj)
+        if not force and stamp_ok and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t):
+            continue
+        flags = ([] if base in pk else NO_PK_FLAGS) + ["-DFX_FP16=1"]
+        if base == "runtime.hip":
+            flags = flags + [f"-DFX_BUILD_FLAGS={1 if pk else 0}"]
+        jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + flags + EXTRA_FLAGS + ["-c", src, "-o", obj])
+    _run_jobs(jobs, verbose)
+    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH_FP16] + objs
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    with open(stamp, "w") as f:
+        f.write(_stamp() + " fp16\n")
+    return LIB_PATH_FP16
+
+
+def _run_jobs(jobs, verbose):
     running = []
     nproc = max(1, min(int(os.environ.get("FX_BUILD_JOBS", os.cpu_count() or 4)), 16))
     failed = None
@@ -110,16 +162,6 @@ def build(force: bool = False, verbose: bool = True, out_path: str = None) -> st
         pr.wait()
     if failed is not None:
         raise subprocess.CalledProcessError(1, failed)
-    cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", target] + objs
-    if verbose:
-        print(" ".join(cmd), file=sys.stderr)
-    subprocess.check_call(cmd)
-    if out_path is None:
-        with open(STAMP_PATH, "w") as f:
-            f.write(_stamp() + "\n")
-    else:
-        shutil.rmtree(objdir, ignore_errors=True)
-    return target
 
 
 if __name__ == "__main__":
@@ -128,3 +170,5 @@ if __name__ == "__main__":
         if a.startswith("--out="):
             out = os.path.abspath(a[len("--out="):])
     print(build(force="--force" in sys.argv, out_path=out))
+    if out is None:
+        print(build(force="--force" in sys.argv, fp16=True))

@@ -121,10 +121,10 @@ __global__ __launch_bounds__(256) void mha32_bwd_dq_kernel(const bf16_t* __restr
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) s[r] = 0.0f, dp[r] = 0.0f;
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf0, s, 0, 0, 0);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf1, s, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, df0, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, df1, dp, 0, 0, 0);
+        s = FX_MFMA_32x32x16(kf0, qf0, s);
+        s = FX_MFMA_32x32x16(kf1, qf1, s);
+        dp = FX_MFMA_32x32x16(vf0, df0, dp);
+        dp = FX_MFMA_32x32x16(vf1, df1, dp);
         uint32_t mw = 0;
         if (MASKED) mw = mrow[c0 + t];
         if (sweep == 0) {
@@ -183,8 +183,8 @@ __global__ __launch_bounds__(256) void mha32_bwd_dq_kernel(const bf16_t* __restr
           bf16x8 kt0, kt1;
           ab_frag_tr(kt + t * 2048, j, h, kt0, kt1);
           const uint4 p0 = pack_bf16x8(ds), p1 = pack_bf16x8(ds + 8);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt0, __builtin_bit_cast(bf16x8, p0), acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt1, __builtin_bit_cast(bf16x8, p1), acc, 0, 0, 0);
+          acc = FX_MFMA_32x32x16(kt0, __builtin_bit_cast(bf16x8, p0), acc);
+          acc = FX_MFMA_32x32x16(kt1, __builtin_bit_cast(bf16x8, p1), acc);
         }
       }
     }
@@ -279,10 +279,10 @@ __global__ __launch_bounds__(256) void mha32_bwd_dkv_kernel(const bf16_t* __rest
       f32x16 s, dp;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.0f, dp[r] = 0.0f;
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf0, kf0, s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qf1, kf1, s, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df0, vf0, dp, 0, 0, 0);
-      dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(df1, vf1, dp, 0, 0, 0);
+      s = FX_MFMA_32x32x16(qf0, kf0, s);
+      s = FX_MFMA_32x32x16(qf1, kf1, s);
+      dp = FX_MFMA_32x32x16(df0, vf0, dp);
+      dp = FX_MFMA_32x32x16(df1, vf1, dp);
       float pf[16], ds[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -297,12 +297,12 @@ __global__ __launch_bounds__(256) void mha32_bwd_dkv_kernel(const bf16_t* __rest
       bf16x8 t0, t1;
       ab_frag_tr(dot + t * 2048, j, h, t0, t1);
       uint4 p0 = pack_bf16x8(pf), p1 = pack_bf16x8(pf + 8);
-      av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t0, __builtin_bit_cast(bf16x8, p0), av, 0, 0, 0);
-      av = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t1, __builtin_bit_cast(bf16x8, p1), av, 0, 0, 0);
+      av = FX_MFMA_32x32x16(t0, __builtin_bit_cast(bf16x8, p0), av);
+      av = FX_MFMA_32x32x16(t1, __builtin_bit_cast(bf16x8, p1), av);
       ab_frag_tr(qt + t * 2048, j, h, t0, t1);
       p0 = pack_bf16x8(ds), p1 = pack_bf16x8(ds + 8);
-      ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t0, __builtin_bit_cast(bf16x8, p0), ak, 0, 0, 0);
-      ak = __builtin_amdgcn_mfma_f32_32x32x16_bf16(t1, __builtin_bit_cast(bf16x8, p1), ak, 0, 0, 0);
+      ak = FX_MFMA_32x32x16(t0, __builtin_bit_cast(bf16x8, p0), ak);
+      ak = FX_MFMA_32x32x16(t1, __builtin_bit_cast(bf16x8, p1), ak);
     }
   }
   if (!active || kj >= Lk) return;

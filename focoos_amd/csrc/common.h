@@ -5,11 +5,6 @@
 
 #include "../../include/focoos_amd.h"
 
-typedef uint16_t bf16_t;  // raw bfloat16 bits; storage type of activations / packed weights
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) float f32x4;
-
 #define FX_CHECK_ARG(cond) \
   do {                     \
     if (!(cond)) return FX_ERR_INVALID_ARGUMENT; \
@@ -19,6 +14,42 @@ static inline int fx_launch_status() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? FX_OK : FX_ERR_LAUNCH;
 }
+
+// ---- the 16-bit storage element of activations / packed weights / activation gradients -----------------------------------------
+// Default build: bfloat16.  -DFX_FP16=1 (the second library, libfocoos_amd_fp16.so: BASELINE configs[4] names fp16 - the reference trains
+// under torch.autocast(float16) + GradScaler, trainer/trainer.py:645,735-773): IEEE half, 11 significand bits instead of 8, exponent range
+// 6e-8 .. 65504 - which is why that build's training step carries a dynamic loss scale (fx_adamw_step_scaled_f32).  Every kernel takes its
+// element type from the helpers below (no kernel touches the bit layout itself), the MFMA instruction from FX_MFMA_*; the names keep the
+// historical "bf16" (`bf16_t` = raw 16-bit storage word, `bf16x8` = an MFMA operand fragment of eight elements).
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+#ifndef FX_FP16
+#define FX_FP16 0
+#endif
+
+#if FX_FP16
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 bf16x2_t;
+#define FX_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define FX_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {   // round-to-nearest-even; |f| > 65504 -> +-inf (what the loss scaler watches for)
+  _Float16 h = (_Float16)f;
+  return __builtin_bit_cast(bf16_t, h);
+}
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  bf16x2_t v = {(_Float16)lo, (_Float16)hi};
+  return __builtin_bit_cast(uint32_t, v);
+}
+// the two storage elements of a 32-bit word (low half = even element) as floats
+__device__ __forceinline__ float bf16lo_to_f32(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(u & 0xffffu)); }
+__device__ __forceinline__ float bf16hi_to_f32(uint32_t u) { return (float)__builtin_bit_cast(_Float16, (uint16_t)(u >> 16)); }
+#else
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+#define FX_MFMA_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#define FX_MFMA_16x16x32(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
 
@@ -39,12 +70,13 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 // the two storage elements of a 32-bit word (low half = even element) as floats
 __device__ __forceinline__ float bf16lo_to_f32(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16hi_to_f32(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+#endif
 
 __device__ __forceinline__ void unpack_bf16x8(const uint4& v, float* f) {
-  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
-  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
-  f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
-  f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+  f[0] = bf16lo_to_f32(v.x); f[1] = bf16hi_to_f32(v.x);
+  f[2] = bf16lo_to_f32(v.y); f[3] = bf16hi_to_f32(v.y);
+  f[4] = bf16lo_to_f32(v.z); f[5] = bf16hi_to_f32(v.z);
+  f[6] = bf16lo_to_f32(v.w); f[7] = bf16hi_to_f32(v.w);
 }
 
 __device__ __forceinline__ uint4 pack_bf16x8(const float* f) {

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c32_kernel(const C32Args p) {
       for (int a = 0; a < TN; ++a) {
 #pragma unroll
         for (int b = 0; b < TM; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[s][a], xb[s & 1][b], acc[a][b], 0, 0, 0);
+          acc[a][b] = FX_MFMA_32x32x16(ar[s][a], xb[s & 1][b], acc[a][b]);
           if (a == 0) {   // fragment b of the next k-step
             if constexpr (s + 1 < PF) xb[(s + 1) & 1][b] = c32_lds_read<((s + 1) % KJ) * PLANE>(addr[(s + 1) / KJ][b]);
             else xb[0][b] = c32_lds_read<0>(addrn[0][b]);

@@ -218,7 +218,7 @@ __global__ __launch_bounds__((WN* WM + LOADER) * 64, 1) void conv3x3_flat_kernel
           for (int a = 0; a < TN; ++a) {
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j][a], xb[j & 1][b], acc[a][b], 0, 0, 0);
+              acc[a][b] = FX_MFMA_32x32x16(ar[j][a], xb[j & 1][b], acc[a][b]);
               if (a == 0) {
                 if constexpr (!tap_end) {
                   xb[(j + 1) & 1][b] = *reinterpret_cast<const bf16x8*>(smem + (((co + hc[tap_end ? 0 : j + 1]) ^ sw[b]) + ra[b]));
@@ -263,8 +263,8 @@ __global__ __launch_bounds__((WN* WM + LOADER) * 64, 1) void conv3x3_flat_kernel
             float r0 = 0.0f, r1 = 0.0f, r2 = 0.0f, r3 = 0.0f;
             if constexpr (RESMODE != 0) {
               const uint2 rv = *reinterpret_cast<const uint2*>(tp);
-              r0 = __uint_as_float(rv.x << 16); r1 = __uint_as_float(rv.x & 0xffff0000u);
-              r2 = __uint_as_float(rv.y << 16); r3 = __uint_as_float(rv.y & 0xffff0000u);
+              r0 = bf16lo_to_f32(rv.x); r1 = bf16hi_to_f32(rv.x);
+              r2 = bf16lo_to_f32(rv.y); r3 = bf16hi_to_f32(rv.y);
             }
             if constexpr (RESMODE == 1) { v0 += r0; v1 += r1; v2 += r2; v3 += r3; }       // act(conv + residual)
             if constexpr (ACT == FX_ACT_RELU) {

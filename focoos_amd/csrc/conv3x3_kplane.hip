@@ -256,7 +256,7 @@ __global__ __launch_bounds__((WN* WM + LD) * 64, LD ? 1 : 2) void conv3x3_kplane
           for (int a = 0; a < TN; ++a) {
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j][a], xb[j & 1][b], acc[a][b], 0, 0, 0);
+              acc[a][b] = FX_MFMA_32x32x16(ar[j][a], xb[j & 1][b], acc[a][b]);
               if constexpr (!(ABL & 2)) {
                 if (a == 0) {   // fragment b of the next k-step (k-step 0 of the next tap behind the last one)
                   if constexpr (j + 1 < KJ) xb[(j + 1) & 1][b] = c3k_lds_read<(j + 1) * PLANE>(addr[b]);
@@ -344,8 +344,8 @@ __global__ __launch_bounds__((WN* WM + LD) * 64, LD ? 1 : 2) void conv3x3_kplane
           float r[4] = {0.f, 0.f, 0.f, 0.f};
           if constexpr (RESMODE != 0) {
             const uint2 rv = *reinterpret_cast<const uint2*>(tp);
-            r[0] = __uint_as_float(rv.x << 16); r[1] = __uint_as_float(rv.x & 0xffff0000u);
-            r[2] = __uint_as_float(rv.y << 16); r[3] = __uint_as_float(rv.y & 0xffff0000u);
+            r[0] = bf16lo_to_f32(rv.x); r[1] = bf16hi_to_f32(rv.x);
+            r[2] = bf16lo_to_f32(rv.y); r[3] = bf16hi_to_f32(rv.y);
           }
 #pragma unroll
           for (int e = 0; e < 4; ++e) {

@@ -235,7 +235,7 @@ __global__ __launch_bounds__((WN* WM + NLD) * 64, 1) void conv3x3s2_kplane_kerne
           for (int a = 0; a < TN; ++a) {
 #pragma unroll
             for (int b = 0; b < TM; ++b) {
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j][a], xb[j & 1][b], acc[a][b], 0, 0, 0);
+              acc[a][b] = FX_MFMA_32x32x16(ar[j][a], xb[j & 1][b], acc[a][b]);
               if (a == 0) {   // fragment b of the next k-step (k-step 0 of the next tap behind the last one)
                 if constexpr (j + 1 < KJ) xb[(j + 1) & 1][b] = s2k_lds_read<(j + 1) * PLANE>(addr[b]);
                 else xb[0][b] = s2k_lds_read<0>(addrn[b]);

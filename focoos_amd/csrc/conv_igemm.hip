@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, (BK == 32 ? 4 : 2)) void conv_igemm_kernel(con
       _Pragma("unroll") for (int i = 0; i < TN; ++i) wb[i] =                                                         \
           *reinterpret_cast<const bf16x8*>(B_ + lds_off<BK>(wn * WTN + i * 32 + lrow, chunk));                       \
       _Pragma("unroll") for (int a = 0; a < TN; ++a) _Pragma("unroll") for (int b = 0; b < TM; ++b) acc[a][b] =      \
-          __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[a], xa[b], acc[a][b], 0, 0, 0);                                 \
+          FX_MFMA_32x32x16(wb[a], xa[b], acc[a][b]);                                 \
     }                                                                                                                \
   }
 

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(WM* WN * 64, 1) void conv_igemm_dma_kernel(const Co
       for (int a = 0; a < TN; ++a)
 #pragma unroll
         for (int b = 0; b < TM; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb[kk & 1][a], xa[kk & 1][b], acc[a][b], 0, 0, 0);
+          acc[a][b] = FX_MFMA_32x32x16(wb[kk & 1][a], xa[kk & 1][b], acc[a][b]);
     }
   }
   __syncthreads();

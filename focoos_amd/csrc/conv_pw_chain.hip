@@ -164,7 +164,7 @@ __global__ __launch_bounds__(256, ((N2 <= 64 && K1B == 0) ? 4 : ((N2 <= 128 && (
       const int row = b * 32 + l32k;                                                                                         \
       xb[b] = *reinterpret_cast<const bf16x8*>((XT_) + row * ((KROW_)*2) + (pw_swz<RL_>(row, ((KL0_) + i) * 2 + halfg) << 4)); \
     }                                                                                                                       \
-    _Pragma("unroll") for (int b = 0; b < TM; ++b) acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i], xb[b], acc[b], 0, 0, 0); \
+    _Pragma("unroll") for (int b = 0; b < TM; ++b) acc[b] = FX_MFMA_32x32x16(a1[i], xb[b], acc[b]); \
     const int kn = ks0 + i + PF1;                                                                                           \
     a1[i] = pw_ldg_frag(w1 + (kn < KS1 ? kn : KS1 - 1) * 512); /* clamped: the last block re-requests a fragment it never uses */ \
   }
@@ -190,10 +190,10 @@ __global__ __launch_bounds__(256, ((N2 <= 64 && K1B == 0) ? 4 : ((N2 <= 128 && (
           float v0 = acc[b][4 * gq], v1 = acc[b][4 * gq + 1], v2 = acc[b][4 * gq + 2], v3 = acc[b][4 * gq + 3];
           if (p.res) {
             const uint2 r2 = *reinterpret_cast<const uint2*>(tp);
-            v0 += __uint_as_float(r2.x << 16);
-            v1 += __uint_as_float(r2.x & 0xffff0000u);
-            v2 += __uint_as_float(r2.y << 16);
-            v3 += __uint_as_float(r2.y & 0xffff0000u);
+            v0 += bf16lo_to_f32(r2.x);
+            v1 += bf16hi_to_f32(r2.x);
+            v2 += bf16lo_to_f32(r2.y);
+            v3 += bf16hi_to_f32(r2.y);
           }
           if (p.act1 == FX_ACT_RELU) {  // ResNet bottlenecks: ReLU or nothing (keeps erff / expf out of the epilogue)
             v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f);
@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256, ((N2 <= 64 && K1B == 0) ? 4 : ((N2 <= 128 && (
 #pragma unroll
         for (int a = 0; a < TN2; ++a)
 #pragma unroll
-          for (int b = 0; b < TM2; ++b) acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[ks % PF2][a], tb[b], acc2[a][b], 0, 0, 0);
+          for (int b = 0; b < TM2; ++b) acc2[a][b] = FX_MFMA_32x32x16(a2[ks % PF2][a], tb[b], acc2[a][b]);
         if (ks + PF2 < 16) {
 #pragma unroll
           for (int a = 0; a < TN2; ++a) a2[ks % PF2][a] = pw_ldg_frag(w2 + (size_t)(a * KS2 + ks + PF2) * 512);

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kplane_kernel(const PWKArgs p)
         for (int a = 0; a < TN; ++a) {
 #pragma unroll
           for (int b = 0; b < TM; ++b) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[j][a], xb[j & 1][b], acc[a][b], 0, 0, 0);
+            acc[a][b] = FX_MFMA_32x32x16(ar[j][a], xb[j & 1][b], acc[a][b]);
             if (a == 0) {   // fragment b of the next k-step (behind the last one of the n-tile: k-step 0 again, unused)
               if constexpr (j + 1 < PF) xb[(j + 1) & 1][b] = pwk_lds_read<(j + 1) * PLANE>(addr[b] + aoff);
               else xb[0][b] = pwk_lds_read<PF * PLANE>(addr[b] + (last ? -PF * PLANE : aoff));
@@ -193,8 +193,8 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kplane_kernel(const PWKArgs p)
           for (int q = 0; q < 2; ++q) {
             const int gq = 2 * g2 + q;
             float v[4];
-            const float r[4] = {__uint_as_float(rq[q][0] << 16), __uint_as_float(rq[q][0] & 0xffff0000u), __uint_as_float(rq[q][1] << 16),
-                                __uint_as_float(rq[q][1] & 0xffff0000u)};
+            const float r[4] = {bf16lo_to_f32(rq[q][0]), bf16hi_to_f32(rq[q][0]), bf16lo_to_f32(rq[q][1]),
+                                bf16hi_to_f32(rq[q][1])};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               v[e] = acc[a][b][4 * gq + e];

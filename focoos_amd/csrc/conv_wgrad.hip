@@ -182,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const WgradArgs p) {
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < 2; ++b) acc[a][b] = FX_MFMA_32x32x16(af[a], bfr[b], acc[a][b]);
     }
   };
 
@@ -268,7 +268,7 @@ typedef __attribute__((address_space(3))) unsigned char wd_lds_u8;
 // (s_waitcnt vmcnt(16) in the step body).  M0 = LDS byte address of lane 0's piece; one wait state between the M0 write and its use.
 typedef __attribute__((ext_vector_type(4))) int wd_v4i;
 __device__ __forceinline__ void wd_dma16(wd_v4i rsrc, unsigned lds_addr, unsigned voff) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory", "m0");   // m0 declared clobbered: the compiler may not keep a value of its own in it across the DMA
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" : : "s"(lds_addr), "v"(voff), "s"(rsrc) : "memory");   // m0 is a RESERVED register for hipcc (listing it as a clobber is rejected with "clobber list contains reserved registers: m0"): the compiler never keeps a value of its own in it across statements - it writes m0 immediately in front of each of its own uses
 }
 
 template <int IMM>
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(256, 1) void conv_wgrad_dma_kernel(const WgradArgs 
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[a], b_[b], acc[a][b], 0, 0, 0);
+      for (int b = 0; b < 4; ++b) acc[a][b] = FX_MFMA_32x32x16(a_[a], b_[b], acc[a][b]);
   };
   auto interleave = [&]() {
 #pragma unroll

@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void query_pixel_logits_kernel(const bf16_t* _
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) {
         bf16x8 a = *reinterpret_cast<const bf16x8*>(er + (((kk * 2 + h) ^ (row & (NCH - 1))) << 4));
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, kf[kk], acc, 0, 0, 0);
+        acc = FX_MFMA_32x32x16(a, kf[kk], acc);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {

@@ -186,8 +186,8 @@ __global__ __launch_bounds__(256) void stem_mfma_kernel(const TIn* __restrict__ 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = bs[r];
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc, 0, 0, 0);
+    acc = FX_MFMA_32x32x16(a1, b1, acc);
+    acc = FX_MFMA_32x32x16(a2, b2, acc);
     if (act) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -295,7 +295,11 @@ extern "C" int fx_resize_bilinear_u8(const uint8_t* x, int H, int W, float* y, i
 __global__ __launch_bounds__(256) void resize_nhwc_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int B,
                                                            int H, int W, int C8, int Ho, int Wo, float sh, float sw) {
   int64_t total = (int64_t)B * Ho * Wo * C8;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+  // XCD-aware block order (round 5): consecutive blocks are dealt round-robin to the 8 XCDs, each with its own L2, and vertically adjacent
+  // output rows share an input row - in launch order every XCD fetched its own copy of it (PMC: 318 MB read for a 210 MB tensor).  With the
+  // remap an XCD owns a contiguous band of output rows and the shared rows are re-fetched only at the eight band seams.
+  const int bid = fx_xcd_remap(blockIdx.x, gridDim.x);
+  for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     int c8 = (int)(i % C8);
     int64_t p = i / C8;
     int wo = (int)(p % Wo);
@@ -333,7 +337,11 @@ extern "C" int fx_resize_bilinear_nhwc_bf16(const void* x, int ldx, void* y, int
 __global__ __launch_bounds__(256) void maxpool_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int B, int H,
                                                        int W, int C8, int Ho, int Wo) {
   int64_t total = (int64_t)B * Ho * Wo * C8;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+  // XCD-aware block order (round 5): consecutive blocks are dealt round-robin to the 8 XCDs, each with its own L2, and vertically adjacent
+  // output rows share an input row - in launch order every XCD fetched its own copy of it (PMC: 318 MB read for a 210 MB tensor).  With the
+  // remap an XCD owns a contiguous band of output rows and the shared rows are re-fetched only at the eight band seams.
+  const int bid = fx_xcd_remap(blockIdx.x, gridDim.x);
+  for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     int c8 = (int)(i % C8);
     int64_t p = i / C8;
     int wo = (int)(p % Wo);
@@ -365,7 +373,7 @@ extern "C" int fx_maxpool3x3s2_nhwc_bf16(const void* x, int ldx, void* y, int ld
   int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
   int64_t total = (int64_t)B * Ho * Wo * (C / 8);
   int64_t grid = (total + 255) / 256;
-  if (grid > 256 * 32) grid = 256 * 32;
+  if (grid > 256 * 256) grid = 256 * 256;   // one pass for every registry shape (the band order of the remap needs it)
   hipLaunchKernelGGL(maxpool_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)x, ldx,
                      (bf16_t*)y, ldy, B, H, W, C / 8, Ho, Wo);
   return fx_launch_status();
@@ -378,7 +386,11 @@ extern "C" int fx_maxpool3x3s2_nhwc_bf16(const void* x, int ldx, void* y, int ld
 __global__ __launch_bounds__(256) void avgpool2_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int B, int H,
                                                         int W, int C8, int Ho, int Wo) {
   int64_t total = (int64_t)B * Ho * Wo * C8;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+  // XCD-aware block order (round 5): consecutive blocks are dealt round-robin to the 8 XCDs, each with its own L2, and vertically adjacent
+  // output rows share an input row - in launch order every XCD fetched its own copy of it (PMC: 318 MB read for a 210 MB tensor).  With the
+  // remap an XCD owns a contiguous band of output rows and the shared rows are re-fetched only at the eight band seams.
+  const int bid = fx_xcd_remap(blockIdx.x, gridDim.x);
+  for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     int c8 = (int)(i % C8);
     int64_t p = i / C8;
     int wo = (int)(p % Wo);

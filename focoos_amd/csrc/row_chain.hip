@@ -335,7 +335,7 @@ __global__ __launch_bounds__(512, 4) void row_chain_kernel(const fx_rc_stage* __
               constexpr int i = decltype(ic)::value;
               xb[(i + 1) & 1] = xfrag(ks0 + i + 1);   // next k-step's rows (wraps to k-step 0 for the next pass), one MFMA ahead of its use
               c3_wait<RC_RING - 1>(ar[i]);
-              acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[i], xb[i & 1], acc, 0, 0, 0);
+              acc = FX_MFMA_32x32x16(ar[i], xb[i & 1], acc);
               rc_ldg_next(ar[i], st.w, voff);
             };
             c3_static_for<RC_RING>(step);
@@ -347,7 +347,7 @@ __global__ __launch_bounds__(512, 4) void row_chain_kernel(const fx_rc_stage* __
             constexpr int i = decltype(ic)::value;
             if constexpr (i + 1 < RC_RING) xb[(i + 1) & 1] = xfrag(KS - RC_RING + i + 1);
             c3_wait<RC_RING - 1 - i>(ar[i]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[i], xb[i & 1], acc, 0, 0, 0);
+            acc = FX_MFMA_32x32x16(ar[i], xb[i & 1], acc);
           };
           c3_static_for<RC_RING>(step_tail);
           epilogue(wv + (npass - 1) * 8);
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(512, 4) void row_chain_kernel(const fx_rc_stage* __
           constexpr int i = decltype(ic)::value;
           xb[(i + 1) & 1] = xfrag(ks0 + i + 1);
           c3_wait<RC_RING - 1>(ar[i]);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[i], xb[i & 1], acc, 0, 0, 0);
+          acc = FX_MFMA_32x32x16(ar[i], xb[i & 1], acc);
           rc_ldg_next(ar[i], st.w, voff);
         };
         c3_static_for<RC_RING>(step);
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(512, 4) void row_chain_kernel(const fx_rc_stage* __
           constexpr int i = decltype(ic)::value;
           if constexpr (i + 1 < RC_RING) xb[(i + 1) & 1] = xfrag(KS - RC_RING + i + 1);
           c3_wait<RC_RING - 1 - i>(ar[i]);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[i], xb[i & 1], acc, 0, 0, 0);
+          acc = FX_MFMA_32x32x16(ar[i], xb[i & 1], acc);
         };
         c3_static_for<RC_RING>(step_tail);
       }
@@ -435,7 +435,7 @@ __global__ __launch_bounds__(512, 4) void row_chain_kernel(const fx_rc_stage* __
           xb[(i + 1) & 1] = rc_xread(smem, pre, (ks0 + i + 1) & 15);
           if constexpr (NEXT == 0) c3_wait<RC_RING - 1 - i>(ar[i]);
           else c3_wait<RC_RING - 1>(ar[i]);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ar[i], xb[i & 1], acc, 0, 0, 0);
+          acc = FX_MFMA_32x32x16(ar[i], xb[i & 1], acc);
           if constexpr (NEXT == 1 || NEXT == 4) rc_ldg_next(ar[i], st.w, voff1);
           if constexpr (NEXT == 2 || NEXT == 3) rc_ldg_next(ar[i], st.g1, voff2);
         };

@@ -16,7 +16,7 @@ extern "C" int fx_abi_version(void) { return FX_ABI_VERSION; }
 #ifndef FX_BUILD_FLAGS
 #define FX_BUILD_FLAGS 0
 #endif
-extern "C" int fx_build_flags(void) { return FX_BUILD_FLAGS; }
+extern "C" int fx_build_flags(void) { return FX_BUILD_FLAGS | (FX_FP16 ? 2 : 0); }
 
 extern "C" const char* fx_error_string(int code) {
   switch (code) {

@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256, 2) void score_head_kernel(const ScoreHeadArgs 
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int b = 0; b < TM; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[i][a], xb[b], acc[a][b], 0, 0, 0);
+        for (int b = 0; b < TM; ++b) acc[a][b] = FX_MFMA_32x32x16(a1[i][a], xb[b], acc[a][b]);
       const int kn = ks0 + i + PF;
       const int kc = kn < KS ? kn : KS - 1;
       a1[i][0] = pw_ldg_frag(w1 + kc * 512);
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void score_head_kernel(const ScoreHeadArgs 
 #pragma unroll
       for (int a = 0; a < TN2; ++a)
 #pragma unroll
-        for (int b = 0; b < TM; ++b) acc2[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2[i][a], tb[b], acc2[a][b], 0, 0, 0);
+        for (int b = 0; b < TM; ++b) acc2[a][b] = FX_MFMA_32x32x16(a2[i][a], tb[b], acc2[a][b]);
       const int kn = ks0 + i + PF;
       const int kc = kn < KS ? kn : KS - 1;
 #pragma unroll

@@ -379,8 +379,8 @@ __global__ FX_SEL_PK(5) __launch_bounds__(256) void bbox_head_kernel(const bf16_
   float acc[4] = {0.f, 0.f, 0.f, 0.f};
   for (int c = lane * 4; c < K; c += 256) {
     uint2 hv = *reinterpret_cast<const uint2*>(h + (int64_t)row * ldh + c);
-    float x[4] = {__uint_as_float(hv.x << 16), __uint_as_float(hv.x & 0xffff0000u), __uint_as_float(hv.y << 16),
-                  __uint_as_float(hv.y & 0xffff0000u)};
+    float x[4] = {bf16lo_to_f32(hv.x), bf16hi_to_f32(hv.x), bf16lo_to_f32(hv.y),
+                  bf16hi_to_f32(hv.y)};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       float4 wv = *reinterpret_cast<const float4*>(w + (int64_t)j * K + c);

@@ -49,14 +49,14 @@ __global__ __launch_bounds__(256) void layernorm256_kernel(const bf16_t* __restr
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   uint2 xv = *reinterpret_cast<const uint2*>(x + (int64_t)row * ldx + lane * 4);
-  float v[4] = {__uint_as_float(xv.x << 16), __uint_as_float(xv.x & 0xffff0000u), __uint_as_float(xv.y << 16),
-                __uint_as_float(xv.y & 0xffff0000u)};
+  float v[4] = {bf16lo_to_f32(xv.x), bf16hi_to_f32(xv.x), bf16lo_to_f32(xv.y),
+                bf16hi_to_f32(xv.y)};
   if (res) {
     uint2 rv = *reinterpret_cast<const uint2*>(res + (int64_t)row * ldr + lane * 4);
-    v[0] += __uint_as_float(rv.x << 16);
-    v[1] += __uint_as_float(rv.x & 0xffff0000u);
-    v[2] += __uint_as_float(rv.y << 16);
-    v[3] += __uint_as_float(rv.y & 0xffff0000u);
+    v[0] += bf16lo_to_f32(rv.x);
+    v[1] += bf16hi_to_f32(rv.x);
+    v[2] += bf16lo_to_f32(rv.y);
+    v[3] += bf16hi_to_f32(rv.y);
   }
   float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
   float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
@@ -77,11 +77,11 @@ __global__ __launch_bounds__(256) void layernorm128_kernel(const bf16_t* __restr
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const unsigned xv = *reinterpret_cast<const unsigned*>(x + (int64_t)row * ldx + lane * 2);
-  float v0 = __uint_as_float(xv << 16), v1 = __uint_as_float(xv & 0xffff0000u);
+  float v0 = bf16lo_to_f32(xv), v1 = bf16hi_to_f32(xv);
   if (res) {
     const unsigned rv = *reinterpret_cast<const unsigned*>(res + (int64_t)row * ldr + lane * 2);
-    v0 += __uint_as_float(rv << 16);
-    v1 += __uint_as_float(rv & 0xffff0000u);
+    v0 += bf16lo_to_f32(rv);
+    v1 += bf16hi_to_f32(rv);
   }
   const float mean = wave_sum(v0 + v1) * (1.0f / 128.0f);
   const float d0 = v0 - mean, d1 = v1 - mean;
@@ -190,8 +190,8 @@ __global__ __launch_bounds__(256) void mha32_mfma_kernel(const bf16_t* __restric
       f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.0f;
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf0, qf0, s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf1, qf1, s, 0, 0, 0);
+      s = FX_MFMA_32x32x16(kf0, qf0, s);
+      s = FX_MFMA_32x32x16(kf1, qf1, s);
       uint32_t mw = 0;
       if (MASKED) mw = mrow[c0 + t];
       float mx = -INFINITY, mx2 = -INFINITY;
@@ -230,8 +230,8 @@ __global__ __launch_bounds__(256) void mha32_mfma_kernel(const bf16_t* __restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] *= alpha;
         uint4 p0 = pack_bf16x8(pf), p1 = pack_bf16x8(pf + 8);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, __builtin_bit_cast(bf16x8, p0), o, 0, 0, 0);
-        o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, __builtin_bit_cast(bf16x8, p1), o, 0, 0, 0);
+        o = FX_MFMA_32x32x16(vf0, __builtin_bit_cast(bf16x8, p0), o);
+        o = FX_MFMA_32x32x16(vf1, __builtin_bit_cast(bf16x8, p1), o);
       }
       if (MASKED) {
         mx2 = fmaxf(mx2, __shfl_xor(mx2, 32, 64));
@@ -250,8 +250,8 @@ __global__ __launch_bounds__(256) void mha32_mfma_kernel(const bf16_t* __restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) o2[r] *= alpha;
         uint4 p0 = pack_bf16x8(pf), p1 = pack_bf16x8(pf + 8);
-        o2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf0, __builtin_bit_cast(bf16x8, p0), o2, 0, 0, 0);
-        o2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf1, __builtin_bit_cast(bf16x8, p1), o2, 0, 0, 0);
+        o2 = FX_MFMA_32x32x16(vf0, __builtin_bit_cast(bf16x8, p0), o2);
+        o2 = FX_MFMA_32x32x16(vf1, __builtin_bit_cast(bf16x8, p1), o2);
       }
     }
   }
@@ -444,10 +444,10 @@ __global__ __launch_bounds__(256) void msda_kernel(const bf16_t* __restrict__ va
       auto tap = [&](bool ok, int yy, int xx, float w) {
         if (ok) {
           uint2 t = *reinterpret_cast<const uint2*>(vl + (int64_t)(yy * Wl + xx) * ldv);
-          s[0] += w * __uint_as_float(t.x << 16);
-          s[1] += w * __uint_as_float(t.x & 0xffff0000u);
-          s[2] += w * __uint_as_float(t.y << 16);
-          s[3] += w * __uint_as_float(t.y & 0xffff0000u);
+          s[0] += w * bf16lo_to_f32(t.x);
+          s[1] += w * bf16hi_to_f32(t.x);
+          s[2] += w * bf16lo_to_f32(t.y);
+          s[3] += w * bf16hi_to_f32(t.y);
         }
       };
       tap(yin0 && xin0, y0, x0, w00);
@@ -546,10 +546,10 @@ __global__ __launch_bounds__(256) void msda_l3p4_kernel(const bf16_t* __restrict
     for (int pt = 0; pt < P; ++pt) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        acc[0] += w[pt][k] * __uint_as_float(t[pt][k].x << 16);
-        acc[1] += w[pt][k] * __uint_as_float(t[pt][k].x & 0xffff0000u);
-        acc[2] += w[pt][k] * __uint_as_float(t[pt][k].y << 16);
-        acc[3] += w[pt][k] * __uint_as_float(t[pt][k].y & 0xffff0000u);
+        acc[0] += w[pt][k] * bf16lo_to_f32(t[pt][k].x);
+        acc[1] += w[pt][k] * bf16hi_to_f32(t[pt][k].x);
+        acc[2] += w[pt][k] * bf16lo_to_f32(t[pt][k].y);
+        acc[3] += w[pt][k] * bf16hi_to_f32(t[pt][k].y);
       }
     }
   }

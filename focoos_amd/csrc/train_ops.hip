@@ -46,8 +46,8 @@ __device__ __forceinline__ void msda_ld4(const float* p, float* v) {
 }
 __device__ __forceinline__ void msda_ld4(const bf16_t* p, float* v) {
   const uint2 x = *reinterpret_cast<const uint2*>(p);
-  v[0] = __uint_as_float(x.x << 16); v[1] = __uint_as_float(x.x & 0xffff0000u);
-  v[2] = __uint_as_float(x.y << 16); v[3] = __uint_as_float(x.y & 0xffff0000u);
+  v[0] = bf16lo_to_f32(x.x); v[1] = bf16hi_to_f32(x.x);
+  v[2] = bf16lo_to_f32(x.y); v[3] = bf16hi_to_f32(x.y);
 }
 __device__ __forceinline__ float msda_ld1(const float* p) { return *p; }
 __device__ __forceinline__ float msda_ld1(const bf16_t* p) { return bf16_to_f32(*p); }
@@ -662,5 +662,90 @@ extern "C" int fx_adamw_step_f32(float* params, const float* grads, float* exp_a
   const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, chunk_start, chunk_len, chunk_lr, chunk_wd,
                      partial, NORM_BLOCKS, max_grad_norm, beta1, beta2, eps, bc1, bc2s, total_norm_out);
+  return fx_launch_status();
+}
+
+// ---- the same step under a dynamic loss scale (fp16 build; torch.amp.GradScaler semantics, trainer/trainer.py:645,735-773) ----------------
+// The loss was multiplied by state->scale before backward, so `grads` hold scale * g.  Everything GradScaler does around optimizer.step()
+// happens on the device, in the launches of the step itself, with no host synchronisation:
+//   unscale_()   : g * (1 / scale) folded into the update; the clip norm is ||g|| / scale
+//   step()       : SKIPPED (parameters, moments and the step count untouched) when the gradients hold an inf / NaN - the fixed-order fp64
+//                  sum of squares the clip needs anyway is non-finite exactly then
+//   update()     : scale *= backoff on a skipped step, scale *= growth after `growth_interval` consecutive good ones
+// Adam's bias correction uses the number of steps actually TAKEN (state->good_steps), as torch.optim.AdamW's own step counter would.
+__global__ __launch_bounds__(256) void adamw_scaled_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                            const int64_t* __restrict__ chunk_start, const int32_t* __restrict__ chunk_len,
+                                                            const float* __restrict__ chunk_lr, const float* __restrict__ chunk_wd,
+                                                            const double* __restrict__ partial, int npartial, float max_norm, float beta1, float beta2,
+                                                            float eps, const fx_loss_scale_state* __restrict__ state, float* __restrict__ total_norm_out) {
+  __shared__ float s_mul, s_bc1, s_bc2s;
+  __shared__ int s_skip;
+  if (threadIdx.x == 0) {
+    double tot = 0.0;
+    for (int i = 0; i < npartial; ++i) tot += partial[i];
+    const float inv = 1.0f / state->scale;
+    const bool finite = tot == tot && tot < 1.7976931348623157e308;   // not NaN, not +inf
+    const float norm = finite ? (float)sqrt(tot) * inv : __builtin_inff();
+    float c = 1.0f;
+    if (max_norm > 0.0f) c = fminf(max_norm / (norm + 1e-6f), 1.0f);
+    s_mul = c * inv;
+    s_skip = finite ? 0 : 1;
+    const double t = (double)(state->good_steps + 1);
+    s_bc1 = (float)(1.0 - pow((double)beta1, t));
+    s_bc2s = (float)sqrt(1.0 - pow((double)beta2, t));
+    if (blockIdx.x == 0 && total_norm_out) *total_norm_out = norm;
+  }
+  __syncthreads();
+  if (s_skip) return;
+  const float mul = s_mul, bias_c1 = s_bc1, bias_c2_sqrt = s_bc2s;
+  const int64_t start = chunk_start[blockIdx.x];
+  const int len = chunk_len[blockIdx.x];
+  const float lr = chunk_lr[blockIdx.x], wd = chunk_wd[blockIdx.x];
+  const float step = lr / bias_c1;
+  for (int i = threadIdx.x; i < len; i += 256) {
+    const int64_t j = start + i;
+    const float gg = g[j] * mul;
+    float pp = p[j] * (1.0f - lr * wd);
+    const float mm = beta1 * m[j] + (1.0f - beta1) * gg;
+    const float vv = beta2 * v[j] + (1.0f - beta2) * gg * gg;
+    const float denom = sqrtf(vv) / bias_c2_sqrt + eps;
+    pp -= step * (mm / denom);
+    p[j] = pp;
+    m[j] = mm;
+    v[j] = vv;
+  }
+}
+
+// GradScaler.update(): one thread, launched behind the step (every block of the step has read the OLD scale by then)
+__global__ void loss_scale_update_kernel(const double* __restrict__ partial, int npartial, fx_loss_scale_state* __restrict__ state, float growth,
+                                         float backoff, int growth_interval) {
+  double tot = 0.0;
+  for (int i = 0; i < npartial; ++i) tot += partial[i];
+  const bool finite = tot == tot && tot < 1.7976931348623157e308;
+  if (!finite) {
+    state->scale *= backoff;
+    state->growth_tracker = 0;
+    state->skipped_steps += 1;
+  } else {
+    state->good_steps += 1;
+    if (++state->growth_tracker >= growth_interval) {
+      state->scale *= growth;
+      state->growth_tracker = 0;
+    }
+  }
+}
+
+extern "C" int fx_adamw_step_scaled_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t numel, const int64_t* chunk_start,
+                                        const int32_t* chunk_len, const float* chunk_lr, const float* chunk_wd, int nchunks, float beta1, float beta2,
+                                        float eps, float max_grad_norm, void* workspace, float* total_norm_out, fx_loss_scale_state* state,
+                                        float growth_factor, float backoff_factor, int growth_interval, fx_stream_t stream_) {
+  FX_CHECK_ARG(params && grads && exp_avg && exp_avg_sq && numel > 0 && chunk_start && chunk_len && chunk_lr && chunk_wd && nchunks > 0 && state);
+  FX_CHECK_ARG(workspace && ((uintptr_t)workspace % 8) == 0 && growth_factor >= 1.0f && backoff_factor > 0.0f && backoff_factor <= 1.0f && growth_interval > 0);
+  hipStream_t stream = reinterpret_cast<hipStream_t>(stream_);
+  double* partial = reinterpret_cast<double*>(workspace);
+  hipLaunchKernelGGL(sqnorm_kernel, dim3(NORM_BLOCKS), dim3(256), 0, stream, grads, numel, partial);
+  hipLaunchKernelGGL(adamw_scaled_kernel, dim3(nchunks), dim3(256), 0, stream, params, grads, exp_avg, exp_avg_sq, chunk_start, chunk_len, chunk_lr, chunk_wd,
+                     partial, NORM_BLOCKS, max_grad_norm, beta1, beta2, eps, state, total_norm_out);
+  hipLaunchKernelGGL(loss_scale_update_kernel, dim3(1), dim3(1), 0, stream, partial, NORM_BLOCKS, state, growth_factor, backoff_factor, growth_interval);
   return fx_launch_status();
 }

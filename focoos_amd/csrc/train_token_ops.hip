@@ -136,10 +136,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
   auto load = [&](const bf16_t* p, float* v) {   // CPL consecutive bf16 of this lane
     if constexpr (CPL == 4) {
       const uint2 w = *reinterpret_cast<const uint2*>(p);
-      v[0] = __uint_as_float(w.x << 16), v[1] = __uint_as_float(w.x & 0xffff0000u), v[2] = __uint_as_float(w.y << 16), v[3] = __uint_as_float(w.y & 0xffff0000u);
+      v[0] = bf16lo_to_f32(w.x), v[1] = bf16hi_to_f32(w.x), v[2] = bf16lo_to_f32(w.y), v[3] = bf16hi_to_f32(w.y);
     } else {
       const unsigned w = *reinterpret_cast<const unsigned*>(p);
-      v[0] = __uint_as_float(w << 16), v[1] = __uint_as_float(w & 0xffff0000u);
+      v[0] = bf16lo_to_f32(w), v[1] = bf16hi_to_f32(w);
     }
   };
   // a wave walks ~16 rows: the next row's loads are issued before this row's four wave reductions (the loop was one memory round

@@ -102,6 +102,9 @@ class _EngineBase:
     def __init__(self, config: Dict, device: str = "cuda:0"):
         if not torch.cuda.is_available():
             raise _lib.FocoosAmdError("focoos_amd needs a ROCm GPU (gfx950); no CPU fallback exists")
+        if _lib.compute_dtype() != "bf16":
+            raise _lib.FocoosAmdError("the inference engines compute in bfloat16 (north_star: bf16 MFMA); the fp16 element type "
+                                      "(_lib.set_compute_dtype('fp16')) is the training step's - build the engine under 'bf16'")
         self.lib = _lib.load()
         self.cfg = dict(config)
         self.dev = torch.device(device)

@@ -72,7 +72,7 @@ class _MSDAGroupFunction(torch.autograd.Function):
         B, S, Nt = value_all.shape
         M, D = 8, 32
         Q, L, P = loc.shape[1], loc.shape[3], loc.shape[4]
-        assert value_all.dtype == torch.bfloat16 and value_all.is_contiguous() and Nt == sink.G * M * D
+        assert value_all.dtype == _lib.act_dtype() and value_all.is_contiguous() and Nt == sink.G * M * D
         lc, aw = loc.float().contiguous(), attn.float().contiguous()
         out = torch.empty(B, Q, M * D, dtype=torch.float32, device=value_all.device)
         check(lib.fx_msda_train_fwd(value_all.data_ptr() + g * M * D * 2, 1, Nt, shapes_t.data_ptr(), starts_t.data_ptr(), L, P, lc.data_ptr(),
@@ -81,7 +81,7 @@ class _MSDAGroupFunction(torch.autograd.Function):
         ctx.sink, ctx.g, ctx.dims = sink, g, (B, S, Q, M, D, L, P, Nt)
         ctx.shapes_host = shapes_host
         ctx.in_dtypes = (loc.dtype, attn.dtype)
-        return out.to(torch.bfloat16)
+        return out.to(_lib.act_dtype())
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -95,7 +95,7 @@ def _msda_group_backward(value_all, shapes_t, starts_t, lc, aw, grad_out, sink, 
     """Backward core of the grouped deformable attention: (value gradient or None, grad_loc f32, grad_attn f32)."""
     lib = _lib.load()
     B, S, Q, M, D, L, P, Nt = dims
-    go_bf16 = grad_out.dtype == torch.bfloat16
+    go_bf16 = grad_out.dtype == _lib.act_dtype()
     slab = (sh is not None and os.environ.get("FX_MSDA_BWD_SLAB", "1") != "0"
             and lib.fx_msda_bwd_slab_supported(sh.ctypes.data, L, P, Q, M, int(go_bf16)) == 1)
     # The path is decided ONCE per sink (by the first layer of a backward pass to arrive): the shared buffer is bf16 [B,S,Nt] for the
@@ -105,16 +105,16 @@ def _msda_group_backward(value_all, shapes_t, starts_t, lc, aw, grad_out, sink, 
         sink.slab = slab
     elif sink.slab != slab:
         if sink.slab and not go_bf16:   # the binning form was chosen for bf16 gradients; an fp32 grad_out of a later layer is cast, not re-routed
-            grad_out, go_bf16, slab = grad_out.to(torch.bfloat16), True, True
+            grad_out, go_bf16, slab = grad_out.to(_lib.act_dtype()), True, True
         else:
             raise _lib.FocoosAmdError("grouped deformable-attention backward: the layers of one value group must all take the same "
                                       f"path (sink holds a {'bf16 slab' if sink.slab else 'fp32 atomic'} buffer, this layer asked for the other)")
-    assert sink.buf is None or sink.buf.dtype == (torch.bfloat16 if slab else torch.float32)
+    assert sink.buf is None or sink.buf.dtype == (_lib.act_dtype() if slab else torch.float32)
     gl, ga = torch.empty_like(lc), torch.empty_like(aw)
     if slab:
         go = grad_out.contiguous() if go_bf16 else grad_out.float().contiguous()
         if sink.buf is None:   # every layer overwrites its 256 columns: no zero-fill, no fp32 image, no cast
-            sink.buf = torch.empty(B, S, Nt, dtype=torch.bfloat16, device=value_all.device)
+            sink.buf = torch.empty(B, S, Nt, dtype=_lib.act_dtype(), device=value_all.device)
         check(lib.fx_msda_train_bwd_slab(value_all.data_ptr() + g * M * D * 2, 1, Nt, shapes_t.data_ptr(), starts_t.data_ptr(), sh.ctypes.data, L, P,
                                          lc.data_ptr(), aw.data_ptr(), go.data_ptr(), int(go_bf16), sink.buf.data_ptr() + g * M * D * 2, Nt,
                                          gl.data_ptr(), ga.data_ptr(), B, S, Q, M, _stream(value_all.device)), "fx_msda_train_bwd_slab")
@@ -128,7 +128,7 @@ def _msda_group_backward(value_all, shapes_t, starts_t, lc, aw, grad_out, sink, 
     sink.count += 1
     gv = None
     if sink.count == sink.G:   # every layer has delivered its slice
-        gv = sink.buf if sink.buf.dtype == torch.bfloat16 else sink.buf.to(torch.bfloat16)
+        gv = sink.buf if sink.buf.dtype == _lib.act_dtype() else sink.buf.to(_lib.act_dtype())
         sink.buf, sink.count = None, 0
     return gv, gl, ga
 
@@ -145,9 +145,9 @@ class _MSDAGroupRawFunction(torch.autograd.Function):
         D = 32
         Q = off.shape[1]
         dev = value_all.device
-        assert value_all.dtype == torch.bfloat16 and value_all.is_contiguous() and Nt == sink.G * M * D
+        assert value_all.dtype == _lib.act_dtype() and value_all.is_contiguous() and Nt == sink.G * M * D
         off, logit, ref = off.contiguous(), logit.contiguous(), ref.float().contiguous()
-        assert off.dtype == torch.bfloat16 and logit.dtype == torch.bfloat16 and off.shape[-1] == M * L * P * 2 and logit.shape[-1] == M * L * P
+        assert off.dtype == _lib.act_dtype() and logit.dtype == _lib.act_dtype() and off.shape[-1] == M * L * P * 2 and logit.shape[-1] == M * L * P
         lc = torch.empty(B, Q, M, L, P, 2, dtype=torch.float32, device=dev)
         aw = torch.empty(B, Q, M, L, P, dtype=torch.float32, device=dev)
         st = _stream(dev)
@@ -158,7 +158,7 @@ class _MSDAGroupRawFunction(torch.autograd.Function):
                                     aw.data_ptr(), out.data_ptr(), B, S, Q, M, st), "fx_msda_train_fwd")
         ctx.save_for_backward(value_all, shapes_t, starts_t, lc, aw, ref)
         ctx.sink, ctx.g, ctx.dims, ctx.shapes_host = sink, g, (B, S, Q, M, D, L, P, Nt), shapes_host
-        return out.to(torch.bfloat16)
+        return out.to(_lib.act_dtype())
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -166,8 +166,8 @@ class _MSDAGroupRawFunction(torch.autograd.Function):
         value_all, shapes_t, starts_t, lc, aw, ref = ctx.saved_tensors
         B, S, Q, M, D, L, P, Nt = ctx.dims
         gv, gl, ga = _msda_group_backward(value_all, shapes_t, starts_t, lc, aw, grad_out, ctx.sink, ctx.g, ctx.dims, ctx.shapes_host)
-        g_off = torch.empty(B, Q, M * L * P * 2, dtype=torch.bfloat16, device=value_all.device)
-        g_logit = torch.empty(B, Q, M * L * P, dtype=torch.bfloat16, device=value_all.device)
+        g_off = torch.empty(B, Q, M * L * P * 2, dtype=_lib.act_dtype(), device=value_all.device)
+        g_logit = torch.empty(B, Q, M * L * P, dtype=_lib.act_dtype(), device=value_all.device)
         check(lib.fx_msda_prep_bwd_bf16(gl.data_ptr(), ga.data_ptr(), aw.data_ptr(), ref.data_ptr(), g_off.data_ptr(), M * L * P * 2, g_logit.data_ptr(),
                                         M * L * P, B * Q, M, L, P, _stream(value_all.device)), "fx_msda_prep_bwd_bf16")
         return gv, None, None, None, None, g_off, g_logit, None, None, None, None, None
@@ -230,7 +230,12 @@ class FlatAdamW:
     CHUNK = 65536
 
     def __init__(self, named_shapes: Sequence[Tuple[str, Sequence[int], float, float]], device, betas=(0.9, 0.999), eps: float = 1e-8,
-                 max_grad_norm: float = 0.1):
+                 max_grad_norm: float = 0.1, loss_scale: Optional[float] = None, growth_factor: float = 2.0, backoff_factor: float = 0.5,
+                 growth_interval: int = 2000):
+        """``loss_scale`` (fp16 element type): initial value of a DYNAMIC loss scale kept on the device - torch.amp.GradScaler's state
+        and arithmetic (the reference: GradScaler(init_scale=2**10), trainer/trainer.py:645; growth 2.0 / backoff 0.5 / interval 2000 are
+        GradScaler's defaults): ``scale`` is the tensor the loss is multiplied by, ``step()`` unscales, skips on inf / NaN and updates the
+        scale inside the optimizer launches (fx_adamw_step_scaled_f32)."""
         self.lib = _lib.load()
         self.dev = torch.device(device)
         self.betas, self.eps, self.max_grad_norm = betas, eps, max_grad_norm
@@ -265,12 +270,31 @@ class FlatAdamW:
         self.ws = torch.empty(self.lib.fx_adamw_workspace_bytes() // 8, dtype=torch.float64, device=self.dev)
         self.total_norm = torch.zeros(1, dtype=torch.float32, device=self.dev)
         self.step_count = 0
+        self.scaler = None
+        if loss_scale is not None:
+            # fx_loss_scale_state {float scale; int32 growth_tracker, good_steps, skipped_steps}: one 16-byte device record, two typed views
+            self._scale_state = torch.zeros(4, dtype=torch.int32, device=self.dev)
+            self.scale = self._scale_state.view(torch.float32)[0:1]
+            self.scale.fill_(float(loss_scale))
+            self.scaler = (float(growth_factor), float(backoff_factor), int(growth_interval))
+
+    def scaler_state(self) -> Dict[str, float]:
+        """(host synchronisation) the loss-scale record: scale, growth_tracker, good_steps, skipped_steps."""
+        st = self._scale_state.cpu()
+        return {"scale": float(st.view(torch.float32)[0]), "growth_tracker": int(st[1]), "good_steps": int(st[2]), "skipped_steps": int(st[3])}
 
     def set_lr_scale(self, scale: float, base_lrs: torch.Tensor):
         self.chunk_lr.copy_(base_lrs * scale)
 
     def step(self):
         self.step_count += 1
+        if self.scaler is not None:
+            check(self.lib.fx_adamw_step_scaled_f32(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(), self.numel,
+                                                    self.chunk_start.data_ptr(), self.chunk_len.data_ptr(), self.chunk_lr.data_ptr(), self.chunk_wd.data_ptr(),
+                                                    self.nchunks, float(self.betas[0]), float(self.betas[1]), float(self.eps), float(self.max_grad_norm),
+                                                    self.ws.data_ptr(), self.total_norm.data_ptr(), self._scale_state.data_ptr(), self.scaler[0],
+                                                    self.scaler[1], self.scaler[2], _stream(self.dev)), "fx_adamw_step_scaled_f32")
+            return
         check(self.lib.fx_adamw_step_f32(self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.flat_m.data_ptr(), self.flat_v.data_ptr(), self.numel,
                                          self.chunk_start.data_ptr(), self.chunk_len.data_ptr(), self.chunk_lr.data_ptr(), self.chunk_wd.data_ptr(),
                                          self.nchunks, self.step_count, float(self.betas[0]), float(self.betas[1]), float(self.eps),

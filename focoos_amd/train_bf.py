@@ -43,7 +43,7 @@ class _DwConvFn(torch.autograd.Function):
         Ho, Wo = (H - 1) // 2 + 1, (W_ - 1) // 2 + 1
         live = layer.batch_stats
         w9, shift = layer.taps(live)
-        z = torch.empty(B, Ho, Wo, Cc, dtype=torch.float32 if live else torch.bfloat16, device=dev)
+        z = torch.empty(B, Ho, Wo, Cc, dtype=torch.float32 if live else _lib.act_dtype(), device=dev)
         fn = lib.fx_dwconv3x3s2_nhwc_f32out if live else lib.fx_dwconv3x3s2_nhwc_bf16   # fp32 in front of a batch-statistics BatchNorm
         check(fn(x.data_ptr(), Cc, w9.data_ptr(), None if live else shift.data_ptr(), z.data_ptr(), Cc, B, H, W_, Cc, _stream(dev)), fn.__name__)
         ctx.layer, ctx.live = layer, live
@@ -137,7 +137,7 @@ class _AvgPool3x3s2Fn(torch.autograd.Function):
         B, H, W_, Cc = x.shape
         x = x.contiguous()
         w = _const_ninth(Cc, x.device)
-        y = torch.empty(B, (H - 1) // 2 + 1, (W_ - 1) // 2 + 1, Cc, dtype=torch.bfloat16, device=x.device)
+        y = torch.empty(B, (H - 1) // 2 + 1, (W_ - 1) // 2 + 1, Cc, dtype=_lib.act_dtype(), device=x.device)
         check(lib.fx_dwconv3x3s2_nhwc_bf16(x.data_ptr(), Cc, w.data_ptr(), None, y.data_ptr(), Cc, B, H, W_, Cc, _stream(x.device)), "fx_dwconv3x3s2_nhwc_bf16")
         ctx.lib, ctx.shape = lib, tuple(x.shape)
         return y
@@ -146,7 +146,7 @@ class _AvgPool3x3s2Fn(torch.autograd.Function):
     def backward(ctx, dy):
         B, H, W_, Cc = ctx.shape
         dy = dy.contiguous()
-        dx = torch.empty(B, H, W_, Cc, dtype=torch.bfloat16, device=dy.device)
+        dx = torch.empty(B, H, W_, Cc, dtype=_lib.act_dtype(), device=dy.device)
         w = _const_ninth(Cc, dy.device)
         check(ctx.lib.fx_dwconv3x3s2_bwd_nhwc_bf16(dy.data_ptr(), Cc, None, 0, w.data_ptr(), dx.data_ptr(), Cc, None, B, H, W_, Cc, _stream(dy.device)),
               "fx_dwconv3x3s2_bwd_nhwc_bf16")
@@ -238,7 +238,7 @@ class _GlobalMeanFn(torch.autograd.Function):
     def backward(ctx, d):
         B, H, W_, Cc = ctx.shape
         d = d.float().contiguous()
-        dx = torch.empty(B, H, W_, Cc, dtype=torch.bfloat16, device=d.device)
+        dx = torch.empty(B, H, W_, Cc, dtype=_lib.act_dtype(), device=d.device)
         check(ctx.lib.fx_bcast_vec_nhwc_bf16(d.data_ptr(), Cc, 1.0 / (H * W_), dx.data_ptr(), Cc, B, H * W_, Cc, _stream(d.device)), "fx_bcast_vec_nhwc_bf16")
         return dx, None
 
@@ -483,11 +483,11 @@ class _MaskEinsumFn(torch.autograd.Function):
         Qp = _rup(Q, 32)
         st = _stream(dev)
         dm = dm.float().contiguous()
-        rows = torch.empty(B, 1, P, Qp, dtype=torch.bfloat16, device=dev)
+        rows = torch.empty(B, 1, P, Qp, dtype=_lib.act_dtype(), device=dev)
         check(lib.fx_planes_to_rows_bf16(dm.data_ptr(), Q, P, rows.data_ptr(), Qp, Qp, B, st), "fx_planes_to_rows_bf16")
         dfeat = demb = None
         if ctx.needs_input_grad[1]:
-            et = torch.zeros(B, _rup(Cc, 128), 1, 1, Qp, dtype=torch.bfloat16, device=dev)   # per-image [N = C][K = Qp] weight images
+            et = torch.zeros(B, _rup(Cc, 128), 1, 1, Qp, dtype=_lib.act_dtype(), device=dev)   # per-image [N = C][K = Qp] weight images
             et[:, :Cc, 0, 0, :Q] = emb.transpose(1, 2)
             dfeat = torch.cat([_conv_call(lib, rows[b:b + 1], et[b], None, Cc, 1, 1, 1, 0, None, None) for b in range(B)], 0).view(B, h, w, Cc)
         if ctx.needs_input_grad[0]:
@@ -495,7 +495,7 @@ class _MaskEinsumFn(torch.autograd.Function):
             for b in range(B):
                 check(lib.fx_conv2d_wgrad_bias_nhwc_bf16(feat[b].data_ptr(), Cc, rows[b].data_ptr(), Qp, dw[b].data_ptr(), None, 1, 1, P, Cc, 1, P, Qp, 1, 1,
                                                          1, 0, st), "fx_conv2d_wgrad_bias_nhwc_bf16")
-            demb = dw[:, :Q].to(torch.bfloat16)
+            demb = dw[:, :Q].to(_lib.act_dtype())
         return demb, dfeat, None
 
 
@@ -589,7 +589,7 @@ class TransformerDecoder(nn.Module):
     def _pos_for(self, h, w, dev):
         key = (h, w, dev)
         if key not in self._pos:
-            self._pos[key] = pos_embed_sine_normalized(h, w, self.c // 2).to(device=dev, dtype=torch.bfloat16).contiguous()
+            self._pos[key] = pos_embed_sine_normalized(h, w, self.c // 2).to(device=dev, dtype=_lib.act_dtype()).contiguous()
         return self._pos[key]
 
     def forward(self, msf: Sequence[torch.Tensor], mask_features: torch.Tensor, forced_attn: Optional[Sequence[torch.Tensor]] = None):
@@ -605,8 +605,8 @@ class TransformerDecoder(nn.Module):
             mem_k.append(_AddFn.apply(src, self._pos_for(h, w, dev), lib))
             with torch.no_grad():
                 mf_lvl.append(_ResizeFn.apply(mask_features.detach(), h, w, lib))
-        qe = self.query_embed.weight.to(torch.bfloat16)
-        out = self.query_feat.weight.to(torch.bfloat16).unsqueeze(0).expand(B, -1, -1).contiguous()
+        qe = self.query_embed.weight.to(_lib.act_dtype())
+        out = self.query_feat.weight.to(_lib.act_dtype()).unsqueeze(0).expand(B, -1, -1).contiguous()
         heads = self.forward_prediction_heads
         pc, pm = [], []
         cls, masks, bits = heads(out, mask_features, mf_lvl[0])

@@ -67,7 +67,7 @@ class _BoxRefineFn(torch.autograd.Function):
         lib = _lib.load()
         box, ref = ctx.saved_tensors
         g = g.contiguous()
-        d_delta = torch.empty(box.shape, dtype=torch.bfloat16, device=box.device)
+        d_delta = torch.empty(box.shape, dtype=_lib.act_dtype(), device=box.device)
         d_ref = torch.empty_like(box) if ctx.needs_input_grad[1] else None
         check(lib.fx_box_refine_bwd_f32(g.data_ptr(), box.data_ptr(), ref.data_ptr(), d_delta.data_ptr(), d_ref.data_ptr() if d_ref is not None else None,
                                         box.numel(), INV_SIGMOID_EPS, _stream(box.device)), "fx_box_refine_bwd_f32")
@@ -91,7 +91,7 @@ class MSDeformableAttention(nn.Module):
         B, Q, _ = query.shape
         S = memory.shape[1]
         if (value_all is not None and RAW_MSDA[0] and ref_points.shape[-1] == 4 and ref_points.shape[2] == 1 and not ref_points.requires_grad
-                and query.dtype == torch.bfloat16):
+                and query.dtype == _lib.act_dtype()):
             # softmax + location arithmetic inside the sampling node (fx_msda_prep_bf16): ~15 elementwise launches per layer less
             out = ms_deform_attn_grouped_raw(value_all, sink, g, shapes, self.sampling_offsets(query), self.attention_weights(query),
                                              ref_points.reshape(B, Q, 4), self.h, self.l, self.p)
@@ -103,7 +103,7 @@ class MSDeformableAttention(nn.Module):
             out = ms_deform_attn_grouped(value_all, sink, g, shapes, loc, aw)
         else:
             value = self.value_proj(memory).view(B, S, self.h, self.c // self.h)
-            out = ms_deform_attn_core(value, shapes, loc, aw).to(torch.bfloat16)
+            out = ms_deform_attn_core(value, shapes, loc, aw).to(_lib.act_dtype())
         return self.output_proj(out, residual=residual)
 
 
@@ -192,7 +192,7 @@ class TransformerPredictor(nn.Module):
         st = self._sel_state
         ver = (lin._pack.ver, cls._pack.ver)
         if st is None or st["dev"] != dev:
-            st = self._sel_state = {"dev": dev, "ver": None, "w2_frag": torch.empty(ncp * c, dtype=torch.bfloat16, device=dev),
+            st = self._sel_state = {"dev": dev, "ver": None, "w2_frag": torch.empty(ncp * c, dtype=_lib.act_dtype(), device=dev),
                                     "b2": torch.full((ncp,), -3e38, dtype=torch.float32, device=dev),
                                     "valid": None, "valid_src": None}
         # once per optimizer step: the class weights in fragment order, the bias with -3e38 in the padding (inside a capture always - the
@@ -205,7 +205,7 @@ class TransformerPredictor(nn.Module):
         if st["valid_src"] is not valid:   # the anchors' validity mask of THIS set of level shapes (cached per shapes in _anchors: identity is enough)
             st["valid"], st["valid_src"] = valid.view(-1).to(torch.uint8).contiguous(), valid
         mem = memory.contiguous()
-        om = torch.empty(B * S, c, dtype=torch.bfloat16, device=dev)
+        om = torch.empty(B * S, c, dtype=_lib.act_dtype(), device=dev)
         scores = torch.empty(B, S, dtype=torch.float32, device=dev)
         check(lib.fx_enc_score_head_bf16(mem.data_ptr(), c, st["valid"].data_ptr(), S, lin._pack.w_fwd_frag.data_ptr(), lin.bias.data_ptr(),
                                          norm.weight.data_ptr(), norm.bias.data_ptr(), C.c_float(1e-5), st["w2_frag"].data_ptr(), st["b2"].data_ptr(),
@@ -256,7 +256,7 @@ class TransformerPredictor(nn.Module):
         value_all = _LinearGroupFn.apply(memory, self._value_group, self.lib, *[v.weight for v in vps], *[v.bias for v in vps])
         sink = self._sink = ValueGradSink(len(vps))
         for i, layer in enumerate(self.decoder.layers):
-            qpos = self.query_pos_head(ref_detach.to(torch.bfloat16))
+            qpos = self.query_pos_head(ref_detach.to(_lib.act_dtype()))
             out = layer(out, ref_detach.unsqueeze(2), memory, shapes, qpos, value_all=value_all, sink=sink, g=i)
             delta = self.dec_bbox_classifier[i](out)
             inter = _BoxRefineFn.apply(delta, ref_detach)
@@ -445,11 +445,19 @@ class TrainStep:
 
     def __init__(self, model: FAIDetrTrainable, lr: float = 1e-4, backbone_multiplier: float = 0.1, weight_decay: float = 1e-4,
                  weight_decay_norm: float = 0.0, weight_decay_embed: float = 0.0, max_grad_norm: float = 0.1, ema_decay: Optional[float] = None, ema_warmups: int = 2000, scheduler: Optional[str] = None,
-                 max_iters: int = 0, scheduler_extra: Optional[Dict] = None, check_every: int = 16, graphs: Optional[bool] = None):
+                 max_iters: int = 0, scheduler_extra: Optional[Dict] = None, check_every: int = 16, graphs: Optional[bool] = None,
+                 loss_scale: Optional[float] = None):
+        """The step computes in the 16-bit element type that is current when it is built (_lib.compute_dtype(): "bf16", or "fp16" =
+        the reference's amp training, trainer/trainer.py:645,735-773) and pins it at the top of every step.  Under fp16 the loss is
+        multiplied by a dynamic scale before backward (default initial value 2**10 like the reference's GradScaler; ``loss_scale`` overrides),
+        the optimizer launch unscales, skips the update on inf / NaN gradients and adapts the scale - all on the device."""
         from . import train_nn
         from .train import BucketedGradAllReduce, FlatAdamW
 
         self.model, self._nn = model, train_nn
+        self.dtype_name = _lib.compute_dtype()
+        if loss_scale is None and self.dtype_name == "fp16":
+            loss_scale = 1024.0
         self.check_every = int(check_every)   # Hungarian status word polled every N steps (0 = only through check()): see check()
         # hipGraph replay of the step (see _step_graphed); default from FX_TRAIN_GRAPH.  OFF by default: measured on one MI355X the
         # replayed step is 8 % SLOWER than the eager one (RT-DETR 26.6 vs 24.5 ms, BiSeNetFormer 32.3 vs 29.5, MaskFormer 90.6 vs 83.8;
@@ -478,7 +486,7 @@ class TrainStep:
             plr, pwd = optimizer_hyperparams(n, kinds[n][1], lr, weight_decay, weight_decay_norm, weight_decay_embed, backbone_multiplier)
             spec.append((n, tuple(p.shape), plr, pwd))
         self.spec = spec
-        self.opt = FlatAdamW(spec, dev, max_grad_norm=max_grad_norm)
+        self.opt = FlatAdamW(spec, dev, max_grad_norm=max_grad_norm, loss_scale=loss_scale)
         with torch.no_grad():
             for n, p in named:
                 self.opt.params[n].copy_(p.data)
@@ -637,6 +645,8 @@ class TrainStep:
         self.model.last_outputs = out
         losses = self.model.head.criterion(out, targets)
         total = torch.stack(list(losses.values())).sum()
+        if self.opt.scaler is not None:
+            total = total * self.opt.scale.detach()
         total.backward()
         for g, l in zip(st["gouts"], [l for l in leaves if l.requires_grad]):
             if l.grad is None:
@@ -647,6 +657,7 @@ class TrainStep:
         return losses
 
     def step(self, images: torch.Tensor, targets: Sequence) -> Dict[str, torch.Tensor]:
+        _lib.set_compute_dtype(self.dtype_name)
         if self.stream is None or not images.is_cuda:
             return self._step(images, targets)
         cur = torch.cuda.current_stream(images.device)
@@ -702,6 +713,7 @@ class TrainStep:
         backward with the gradient kernels accumulating straight into the flat views and the weight gradients on the side stream (joined
         before returning).  ``forced``: teacher-forcing arguments of the model's forward (forced_topk / forced_attn / fixed_matches)."""
         nn_ = self._nn
+        _lib.set_compute_dtype(self.dtype_name)
         self.opt.zero_grad()
         for n, p in self.named:  # gradient kernels / autograd accumulate in place into these views
             p.grad = self.opt.grads[n]
@@ -715,6 +727,8 @@ class TrainStep:
         try:
             losses = self.model(images, targets, **forced)
             total = torch.stack(list(losses.values())).sum()   # 2 launches instead of one add per loss term
+            if self.opt.scaler is not None:
+                total = total * self.opt.scale.detach()        # GradScaler.scale(loss): the gradients carry the factor until the optimizer launch
             total.backward()
         finally:
             nn_.DIRECT_GRAD[0] = False

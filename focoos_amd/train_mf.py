@@ -89,11 +89,11 @@ class ConvBias(nn.Module):
         with torch.no_grad():
             Np, Cp = (N + 127) // 128 * 128, (Cc + 127) // 128 * 128
             if self.w_fwd is None or self.w_fwd.device != dev:
-                self.w_fwd = torch.zeros(Np, k, k, Cc, dtype=torch.bfloat16, device=dev)
-                self.w_dgrad = torch.zeros(Cp, k, k, N, dtype=torch.bfloat16, device=dev)
+                self.w_fwd = torch.zeros(Np, k, k, Cc, dtype=_lib.act_dtype(), device=dev)
+                self.w_dgrad = torch.zeros(Cp, k, k, N, dtype=_lib.act_dtype(), device=dev)
                 self.shift = torch.zeros(Np, dtype=torch.float32, device=dev)
-                self.w_fwd_frag = torch.empty(N * k * k * Cc, dtype=torch.bfloat16, device=dev) if _frag_eligible(N, Cc, k) else None
-                self.w_dgrad_frag = torch.empty(N * k * k * Cc, dtype=torch.bfloat16, device=dev) if _frag_eligible(Cc, N, k) else None
+                self.w_fwd_frag = torch.empty(N * k * k * Cc, dtype=_lib.act_dtype(), device=dev) if _frag_eligible(N, Cc, k) else None
+                self.w_dgrad_frag = torch.empty(N * k * k * Cc, dtype=_lib.act_dtype(), device=dev) if _frag_eligible(Cc, N, k) else None
             self.shift[:N] = b
             check(self.lib.fx_pack_conv_weights_f32(w.data_ptr(), None, self.w_fwd.data_ptr(), self.w_dgrad.data_ptr(), _ptr(self.w_fwd_frag),
                                                     _ptr(self.w_dgrad_frag), N, Cc, k, k, _stream(dev)), "fx_pack_conv_weights_f32")
@@ -125,7 +125,7 @@ class _UpAddFn(torch.autograd.Function):
         d = d.contiguous()
         B, H, W_, Cc = d.shape
         hs, ws = ctx.src_hw
-        dy = torch.empty(B, hs, ws, Cc, dtype=torch.bfloat16, device=d.device)
+        dy = torch.empty(B, hs, ws, Cc, dtype=_lib.act_dtype(), device=d.device)
         check(ctx.lib.fx_upsample_nearest_bwd_nhwc_bf16(d.data_ptr(), Cc, dy.data_ptr(), Cc, B, H, W_, hs, ws, Cc, _stream(d.device)),
               "fx_upsample_nearest_bwd_nhwc_bf16")
         return d, dy, None
@@ -212,7 +212,7 @@ class TransformerFPN(nn.Module):
             B, h, w, c = x.shape
             key = (h, w, x.device)
             if key not in self._pos:
-                self._pos[key] = pos_embed_sine_normalized(h, w, c // 2).to(device=x.device, dtype=torch.bfloat16).contiguous()
+                self._pos[key] = pos_embed_sine_normalized(h, w, c // 2).to(device=x.device, dtype=_lib.act_dtype()).contiguous()
             x = self.transformer(x.reshape(B, h * w, c), self._pos[key]).reshape(B, h, w, c)
         y = self.layer_4(x)
         msf = [y]

@@ -223,7 +223,7 @@ def _conv_call(lib, x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tenso
             _DESC_CACHE.clear()
         _DESC_CACHE[key] = ent
     d, ref, oshape = ent
-    y = torch.empty(oshape, dtype=torch.float32 if out_f32 else torch.bfloat16, device=x.device)
+    y = torch.empty(oshape, dtype=torch.float32 if out_f32 else _lib.act_dtype(), device=x.device)
     d.x, d.y = x.data_ptr(), y.data_ptr()
     d.residual = residual.data_ptr() if residual is not None else None
     d.mask, d.ldm = (mask.data_ptr(), N) if mask is not None else (None, 0)   # result *= (mask > 0): [B,Ho,Wo,N] bf16 (fx_conv_desc.mask)
@@ -318,7 +318,7 @@ def _bn_forward(layer, z: torch.Tensor, residual: Optional[torch.Tensor]):
                                  norm.running_mean.data_ptr(), norm.running_var.data_ptr(), norm.num_batches_tracked.data_ptr(),
                                  stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), N, st), "fx_bn_finalize_f32")
     layer._stats_epoch = getattr(layer, "_stats_epoch", 0) + 1   # the kernel moved the running statistics behind autograd's back
-    y = torch.empty(z.shape, dtype=torch.bfloat16, device=dev)
+    y = torch.empty(z.shape, dtype=_lib.act_dtype(), device=dev)
     check(lib.fx_bn_apply_bf16(z.data_ptr(), N, zf, stats[2].data_ptr(), stats[3].data_ptr(), residual.data_ptr() if residual is not None else None, N,
                                FX_ACT[layer.act], y.data_ptr(), N, rows, N, st), "fx_bn_apply_bf16")
     return y, stats, n
@@ -342,8 +342,8 @@ def _bn_backward(layer, dy: torch.Tensor, z: torch.Tensor, residual: Optional[to
         import torch.distributed as dist
         local = sums.clone()
         dist.all_reduce(sums)
-    dz = torch.empty(z.shape, dtype=torch.bfloat16, device=dev)
-    da = torch.empty(z.shape, dtype=torch.bfloat16, device=dev) if residual is not None else None
+    dz = torch.empty(z.shape, dtype=_lib.act_dtype(), device=dev)
+    da = torch.empty(z.shape, dtype=_lib.act_dtype(), device=dev) if residual is not None else None
     norm = layer._norm_h
     direct = want_affine and DIRECT_GRAD[0] and norm.weight.grad is not None and norm.bias.grad is not None
     fused = direct and local is sums    # the kernel adds the (local) sums to the parameter gradients itself
@@ -421,7 +421,7 @@ def _conv_input_grad(layer, dz: torch.Tensor, x_shape) -> torch.Tensor:
     if layer.stride == 1:
         src = dz
     else:  # stride 2: zero-insert, then the stride-1 transposed filter
-        src = torch.empty(B, H, W_, N, dtype=torch.bfloat16, device=dev)
+        src = torch.empty(B, H, W_, N, dtype=_lib.act_dtype(), device=dev)
         check(lib.fx_zero_insert2_nhwc_bf16(dz.data_ptr(), N, src.data_ptr(), N, B, Ho, Wo, H, W_, N, _stream(dev)), "fx_zero_insert2_nhwc_bf16")
     return _conv_call(lib, src, layer.w_dgrad, None, Cc, layer.k, layer.k, 1, layer.pad, None, None, w_frag=layer.w_dgrad_frag)
 
@@ -519,11 +519,11 @@ class ConvNormLayer(nn.Module):
                     self.shift = torch.zeros(Np, dtype=torch.float32, device=dev)
                     self.shift[:N] = self._shift_n
             if self.w_fwd is None or self.w_fwd.device != dev:
-                self.w_fwd = torch.zeros(Np, k, k, Cc, dtype=torch.bfloat16, device=dev)
-                self.w_dgrad = torch.zeros(Cp, k, k, N, dtype=torch.bfloat16, device=dev)
-                self.w_fwd_frag = (torch.empty(N * k * k * Cc, dtype=torch.bfloat16, device=dev)
+                self.w_fwd = torch.zeros(Np, k, k, Cc, dtype=_lib.act_dtype(), device=dev)
+                self.w_dgrad = torch.zeros(Cp, k, k, N, dtype=_lib.act_dtype(), device=dev)
+                self.w_fwd_frag = (torch.empty(N * k * k * Cc, dtype=_lib.act_dtype(), device=dev)
                                    if self.stride == 1 and _frag_eligible(N, Cc, k) else None)
-                self.w_dgrad_frag = torch.empty(N * k * k * Cc, dtype=torch.bfloat16, device=dev) if _frag_eligible(Cc, N, k) else None
+                self.w_dgrad_frag = torch.empty(N * k * k * Cc, dtype=_lib.act_dtype(), device=dev) if _frag_eligible(Cc, N, k) else None
         return (w.data_ptr(), None if live else self.scale.data_ptr(), None, self.w_fwd.data_ptr(), self.w_dgrad.data_ptr(),
                 _ptr(self.w_fwd_frag), _ptr(self.w_dgrad_frag), None, N, Cc, k, k, k * k * Cc, k * k * N)
 
@@ -577,7 +577,7 @@ class _StemFn(torch.autograd.Function):
         lib = layer.lib
         layer.sync_packed()
         B, H, W_, _ = images.shape
-        y = torch.empty(B, H // 2, W_ // 2, 32, dtype=torch.bfloat16, device=images.device)
+        y = torch.empty(B, H // 2, W_ // 2, 32, dtype=_lib.act_dtype(), device=images.device)
         check(lib.fx_stem_conv3x3s2(images.data_ptr(), int(images.dtype == torch.float32), layer.stem_w.data_ptr(), layer.stem_b.data_ptr(),
                                     layer.px_mean.data_ptr(), layer.px_inv_std.data_ptr(), y.data_ptr(), B, H, W_, 32, _stream(images.device)),
               "fx_stem_conv3x3s2")
@@ -608,7 +608,7 @@ class _StemTrainFn(torch.autograd.Function):
         lib = layer.lib
         layer.sync_packed()
         B, H, W_, _ = images.shape
-        z = torch.empty(B, H // 2, W_ // 2, 32, dtype=torch.bfloat16, device=images.device)
+        z = torch.empty(B, H // 2, W_ // 2, 32, dtype=_lib.act_dtype(), device=images.device)
         check(lib.fx_stem_conv3x3s2_linear(images.data_ptr(), int(images.dtype == torch.float32), layer.stem_w.data_ptr(), layer.stem_b.data_ptr(),
                                            layer.px_mean.data_ptr(), layer.px_inv_std.data_ptr(), z.data_ptr(), B, H, W_, 32,
                                            _stream(images.device)), "fx_stem_conv3x3s2_linear")
@@ -629,7 +629,7 @@ def _stem_wgrad(layer, images, dz, scale):
     lib, dev = layer.lib, images.device
     B, H, W_, _ = images.shape
     st = _stream(dev)
-    xn = torch.empty(B, H, W_, 8, dtype=torch.bfloat16, device=dev)
+    xn = torch.empty(B, H, W_, 8, dtype=_lib.act_dtype(), device=dev)
     check(lib.fx_normalize_pad8(images.data_ptr(), int(images.dtype == torch.float32), layer.px_mean.data_ptr(), layer.px_inv_std.data_ptr(),
                                 xn.data_ptr(), B * H * W_, st), "fx_normalize_pad8")
     dw_eff = ARENA.zeros((32, 3, 3, 8), dev)
@@ -679,7 +679,7 @@ class _PoolFn(torch.autograd.Function):
     def forward(ctx, x, lib, kind: str):
         B, H, W_, Cc = x.shape
         Ho, Wo = ((H + 2 - 3) // 2 + 1, (W_ + 2 - 3) // 2 + 1) if kind == "max" else ((H + 1) // 2, (W_ + 1) // 2)
-        y = torch.empty(B, Ho, Wo, Cc, dtype=torch.bfloat16, device=x.device)
+        y = torch.empty(B, Ho, Wo, Cc, dtype=_lib.act_dtype(), device=x.device)
         fn = lib.fx_maxpool3x3s2_nhwc_bf16 if kind == "max" else lib.fx_avgpool2x2_nhwc_bf16
         check(fn(x.data_ptr(), Cc, y.data_ptr(), Cc, B, H, W_, Cc, _stream(x.device)), fn.__name__)
         ctx.lib, ctx.kind = lib, kind
@@ -738,7 +738,7 @@ class _BottleneckFn(torch.autograd.Function):
             sx = x
             if isinstance(blk.short, _Short):
                 B, H, W_, Cc = x.shape
-                pooled = torch.empty(B, (H + 1) // 2, (W_ + 1) // 2, Cc, dtype=torch.bfloat16, device=x.device)
+                pooled = torch.empty(B, (H + 1) // 2, (W_ + 1) // 2, Cc, dtype=_lib.act_dtype(), device=x.device)
                 check(lib.fx_avgpool2x2_nhwc_bf16(x.data_ptr(), Cc, pooled.data_ptr(), Cc, B, H, W_, Cc, _stream(x.device)), "fx_avgpool2x2_nhwc_bf16")
                 sx = pooled
             short = _conv_call(lib, sx, s_l.w_fwd, s_l.shift, s_l.cout, 1, 1, 1, 0, None, None, w_frag=s_l.w_fwd_frag)
@@ -775,7 +775,7 @@ class _BottleneckFn(torch.autograd.Function):
             src = dz_b
         else:
             Ba, Ha, Wa, Ca = a.shape
-            src = torch.empty(Ba, Ha, Wa, b_l.cout, dtype=torch.bfloat16, device=dev)
+            src = torch.empty(Ba, Ha, Wa, b_l.cout, dtype=_lib.act_dtype(), device=dev)
             check(lib.fx_zero_insert2_nhwc_bf16(dz_b.data_ptr(), b_l.cout, src.data_ptr(), b_l.cout, Ba, dz_b.shape[1], dz_b.shape[2], Ha, Wa, b_l.cout, st),
                   "fx_zero_insert2_nhwc_bf16")
         dz_a = _conv_call(lib, src, b_l.w_dgrad, None, b_l.cin, 3, 3, 1, 1, None, a, res_mode=2, w_frag=b_l.w_dgrad_frag)       # dgrad_b * relu'(a)
@@ -937,11 +937,11 @@ class _PackedLinear:
             w = weight[r0:r1]   # rows of a contiguous [N_total, K(, 1, 1)] master ([N, K, 1, 1] conv weights of train_bf.Conv1x1 are GEMM weights too)
             assert w.is_contiguous()
             if self.w_fwd is None or self.w_fwd.device != dev:
-                self.w_fwd = torch.zeros(_rup(Np, 128), 1, 1, Kp, dtype=torch.bfloat16, device=dev)
-                self.w_t = torch.zeros(_rup(Kp, 128), 1, 1, Np, dtype=torch.bfloat16, device=dev)
+                self.w_fwd = torch.zeros(_rup(Np, 128), 1, 1, Kp, dtype=_lib.act_dtype(), device=dev)
+                self.w_t = torch.zeros(_rup(Kp, 128), 1, 1, Np, dtype=_lib.act_dtype(), device=dev)
                 ok = _frag_eligible(Np, Kp, 1) and Np == N and Kp == K   # 256-multiples both ways: the flat pointwise kernel, forward and input gradient
-                self.w_fwd_frag = torch.empty(Np * Kp, dtype=torch.bfloat16, device=dev) if ok else None
-                self.w_t_frag = torch.empty(Np * Kp, dtype=torch.bfloat16, device=dev) if ok else None
+                self.w_fwd_frag = torch.empty(Np * Kp, dtype=_lib.act_dtype(), device=dev) if ok else None
+                self.w_t_frag = torch.empty(Np * Kp, dtype=_lib.act_dtype(), device=dev) if ok else None
             if self.bias is None or self.bias.device != dev or self.bias.numel() != _rup(Np, 128):
                 self.bias = torch.zeros(_rup(Np, 128), dtype=torch.float32, device=dev)   # allocated (and its padding zeroed) once
             bsrc = bias[r0:r1] if bias is not None else None
@@ -994,12 +994,12 @@ class _PackedLinearGroup:
         self.G, self.N, self.K = G, N, K
         Nt = G * N
         if self.w_fwd is None or self.w_fwd.device != dev:
-            self.w_fwd = torch.zeros(_rup(Nt, 128), 1, 1, K, dtype=torch.bfloat16, device=dev)
-            self.w_t = torch.zeros(_rup(K, 128), 1, 1, Nt, dtype=torch.bfloat16, device=dev)
+            self.w_fwd = torch.zeros(_rup(Nt, 128), 1, 1, K, dtype=_lib.act_dtype(), device=dev)
+            self.w_t = torch.zeros(_rup(K, 128), 1, 1, Nt, dtype=_lib.act_dtype(), device=dev)
             self.bias = torch.zeros(_rup(Nt, 128), dtype=torch.float32, device=dev)
             ok = _frag_eligible(Nt, K, 1)
-            self.w_fwd_frag = torch.empty(Nt * K, dtype=torch.bfloat16, device=dev) if ok else None
-            self.w_t_frag = torch.empty(Nt * K, dtype=torch.bfloat16, device=dev) if ok else None
+            self.w_fwd_frag = torch.empty(Nt * K, dtype=_lib.act_dtype(), device=dev) if ok else None
+            self.w_t_frag = torch.empty(Nt * K, dtype=_lib.act_dtype(), device=dev) if ok else None
         return tuple((w.data_ptr(), None, b.data_ptr(), self.w_fwd.data_ptr(), self.w_t.data_ptr(), _ptr(self.w_fwd_frag), _ptr(self.w_t_frag),
                       self.bias.data_ptr(), N, K, 1, 1, K, Nt, g * N, Nt) for g, (w, b) in enumerate(zip(weights, biases)))
 
@@ -1322,7 +1322,7 @@ class _ResizeFn(torch.autograd.Function):
     def forward(ctx, x, Ho, Wo, lib):
         B, H, W_, Cc = x.shape
         x = x.contiguous()
-        y = torch.empty(B, Ho, Wo, Cc, dtype=torch.bfloat16, device=x.device)
+        y = torch.empty(B, Ho, Wo, Cc, dtype=_lib.act_dtype(), device=x.device)
         check(lib.fx_resize_bilinear_nhwc_bf16(x.data_ptr(), Cc, y.data_ptr(), Cc, B, H, W_, Cc, Ho, Wo, _stream(x.device)), "fx_resize_bilinear_nhwc_bf16")
         ctx.lib, ctx.shape = lib, (B, H, W_, Cc)
         return y
@@ -1332,7 +1332,7 @@ class _ResizeFn(torch.autograd.Function):
         lib = ctx.lib
         B, H, W_, Cc = ctx.shape
         dy = dy.contiguous()
-        dx = torch.empty(B, H, W_, Cc, dtype=torch.bfloat16, device=dy.device)
+        dx = torch.empty(B, H, W_, Cc, dtype=_lib.act_dtype(), device=dy.device)
         check(lib.fx_resize_bilinear_bwd_nhwc_bf16(dy.data_ptr(), Cc, dx.data_ptr(), Cc, B, H, W_, Cc, dy.shape[1], dy.shape[2], _stream(dy.device)),
               "fx_resize_bilinear_bwd_nhwc_bf16")
         return dx, None, None, None
@@ -1437,7 +1437,7 @@ class HybridEncoder(nn.Module):
     def _pos_for(self, h, w, dev):
         key = (h, w, dev)
         if key not in self._pos:
-            self._pos[key] = _pos_embed_sine(h, w, self.c // 2).to(device=dev, dtype=torch.bfloat16).contiguous()
+            self._pos[key] = _pos_embed_sine(h, w, self.c // 2).to(device=dev, dtype=_lib.act_dtype()).contiguous()
         return self._pos[key]
 
     def forward(self, feats: List[torch.Tensor]) -> List[torch.Tensor]:

@@ -97,6 +97,12 @@ def run_train(args: TrainerArgs, data_train, data_val, model, processor, model_i
     torch.cuda.set_device(dev)
     torch.manual_seed(rank_seed(args.seed, rank))
     norm = "FrozenBN" if args.freeze_bn else ("SyncBN" if world > 1 else "BN")
+    # 16-bit element type of the step: bf16 by default; FX_TRAIN_DTYPE=fp16 with amp_enabled = the reference's own mixed precision (fp16
+    # autocast + GradScaler(init_scale=2**10), trainer/trainer.py:645,735-773): fp16 library + dynamic loss scale inside the optimizer launch
+    from . import _lib
+
+    dtype = os.environ.get("FX_TRAIN_DTYPE", "bf16") if args.amp_enabled else "bf16"
+    prev_dtype = _lib.set_compute_dtype(dtype)
     net = trainable(model.config, norm=norm).to(dev)
     net.load_state_dict(model.state_dict(), strict=True)
     if args.init_checkpoint:
@@ -123,6 +129,7 @@ def run_train(args: TrainerArgs, data_train, data_val, model, processor, model_i
             print(f"[focoos_amd.train] iter {it + 1}/{args.max_iters} total_loss {tot:.4f} {(time.perf_counter() - t0) / (it + 1) * 1e3:.1f} ms/iter", flush=True)
     torch.cuda.synchronize(dev)
     stepper.check()
+    _lib.set_compute_dtype(prev_dtype)
     out = {k: float(v.detach().float()) for k, v in losses.items()}
     if rank == 0:
         folder = os.path.join(args.output_dir, args.run_name.strip())

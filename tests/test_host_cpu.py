@@ -47,6 +47,39 @@ def test_library_exports_every_declared_symbol(lib_path):
     assert b"invalid argument" in lib.fx_error_string(-1)
 
 
+def test_fp16_library_exports_the_same_abi_and_reports_its_element_type(lib_path):
+    """libfocoos_amd_fp16.so (the same sources, -DFX_FP16=1: training under a loss scale) exports every declared symbol, the same ABI
+    version, and fx_build_flags bit 1 tells the two element types apart (the loader checks it: _lib.load)."""
+    import torch  # noqa: F401
+
+    from focoos_amd import _lib, build
+
+    p16 = build.build(force=False, verbose=False, fp16=True)
+    lib16, lib = ctypes.CDLL(p16), ctypes.CDLL(lib_path)
+    for n in header_functions():
+        assert getattr(lib16, n) is not None, n
+    assert lib16.fx_abi_version() == lib.fx_abi_version() == _lib.FX_ABI_VERSION
+    assert (lib16.fx_build_flags() & 2) and not (lib.fx_build_flags() & 2)
+    prev = _lib.set_compute_dtype("fp16")
+    try:
+        assert _lib.lib_path() == p16 and _lib.act_dtype() == torch.float16 and _lib.load().fx_build_flags() & 2
+    finally:
+        _lib.set_compute_dtype(prev)
+    assert _lib.act_dtype() == torch.bfloat16 and not (_lib.load().fx_build_flags() & 2)
+
+
+def test_loss_scale_state_layout_matches_header(tmp_path):
+    """fx_loss_scale_state = {float scale; int32 growth_tracker, good_steps, skipped_steps}: the 16-byte device record FlatAdamW views as
+    int32[4] / float32[0]."""
+    src = tmp_path / "ls.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "focoos_amd.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(fx_loss_scale_state), '
+                   'offsetof(fx_loss_scale_state, scale), offsetof(fx_loss_scale_state, growth_tracker), offsetof(fx_loss_scale_state, good_steps), '
+                   'offsetof(fx_loss_scale_state, skipped_steps));return 0;}\n')
+    exe = tmp_path / "ls"
+    subprocess.check_call(["gcc", "-std=c99", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    assert list(map(int, subprocess.check_output([str(exe)]).split())) == [16, 0, 4, 8, 12]
+
+
 def test_conv_desc_layout_matches_header(tmp_path):
     """The ctypes mirror of fx_conv_desc has the layout a C compiler gives the header's struct (plain C, gcc)."""
     from focoos_amd._lib import FxConvDesc
@@ -78,7 +111,7 @@ def test_pw_chain_desc_layout_matches_header(tmp_path):
 def test_missing_library_is_loud(monkeypatch):
     from focoos_amd import _lib
 
-    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_libs", {})
     monkeypatch.setenv("FOCOOS_AMD_LIB", "/nonexistent/libfocoos_amd.so")
     with pytest.raises(_lib.FocoosAmdError, match="no CPU/PyTorch fallback"):
         _lib.load()
