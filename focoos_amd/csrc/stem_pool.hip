@@ -1,0 +1,191 @@
+// conv1_3 (3x3 / s1 / p1, 32 -> 64 channels, folded BatchNorm + ReLU) FUSED with the stem's max-pool (3x3 / s2 / p1) - round 5 (gfx950).
+// Reference: ResNet.forward  x = self.conv1(x); x = F.max_pool2d(x, 3, 2, 1)  (focoos/nn/backbone/resnet.py:184-196, 252-256).
+//
+// Why: unfused, the [B,320,320,64] conv1_3 activation is written once (210 MB per 16-image part) and read back 1.0-1.5 times by the pool
+// (318 MB measured) to produce a tensor a quarter of its size - 0.53 of the stem chain's 1.0 GB per part, on a stage that runs AT its byte
+// bound on both queues.  Fused, the layer reads its 105 MB input ~1.35 times and writes 52 MB.
+//
+// Tiling.  The pool needs conv rows 2p-1 .. 2p+1 for pooled row p, so the tile is 2-D: a workgroup (4 waves) owns one image, a band of 8
+// pooled rows and a strip of 15 pooled columns; wave w owns pooled rows 2w, 2w+1 of the band = 5 conv rows x 32 conv columns (columns
+// 2 i0 - 1 .. 2 i0 + 30 for the strip's first pooled column i0): five 32-pixel MFMA blocks whose lanes are 32 CONSECUTIVE COLUMNS of one
+// conv row, so
+//   * the vertical 3-maximum of a pooled row is elementwise over three of the wave's own accumulators (no data movement),
+//   * the horizontal 3-maximum (conv columns 2k-1+.., i.e. lanes 2k, 2k+1, 2k+2) is two ds_bpermute per packed register, valid at the even lanes
+//     0..28 = 15 pooled columns per 32 conv columns (6.7 % recompute), and a conv row shared by two pooled rows of different waves /
+//     bands is recomputed (5 rows per 4: 25 %).  Executed flops = 1.37 x the layer's: MFMA work of ~35 us per 16-image part at peak against the
+//     conv (94 us) + pool (59 us) launches it replaces.
+// The input tile (19 rows x 34 columns of 32 channels, zero outside the image: OOB buffer loads) sits in LDS in the k-plane layout of
+// conv3x3_c32.hip ([plane = half * 2 + j][position][8 channels]), fetched by buffer_load ... lds (each 64-byte pixel is four 16-byte pieces, one per
+// plane); a conv output at tile position t reads tap (dy, dx) at t + dy * 34 + dx - no border masks in the K loop (the padding IS zeros in the
+// tile).  Weights: the SAME fragment-order image conv3x3_c32 uses ([2 blocks][18 k-steps][64 lanes][8]), one 18 KiB block at a time in LDS
+// (an A fragment feeds five MFMAs, so reading it from LDS costs 0.2 LDS reads per MFMA on top of the B operand's 1.0) - no register ring, no
+// asm: two workgroups per CU (63.5 KiB each) cover each other's fetch / reload / store phases.
+// Exactness: per output the accumulation order is bias, then k-steps 0..17 - conv3x3_c32's order - and max commutes with the monotonic
+// bf16 rounding, so the result is bit-identical to the two launches it replaces.  Conv positions outside the image are forced to 0 before the
+// maximum: every value is >= 0 after the ReLU and every window holds at least one real pixel, so 0 stands in for max_pool2d's -inf padding.
+#include "pw_common.h"
+
+struct StemPoolArgs {
+  const bf16_t* x;
+  const bf16_t* wp;
+  const float* bias;
+  bf16_t* y;
+  int H, W, Ho, Wo, ldx, ldy;
+  int nbands, nstrips;
+  unsigned x_bytes;
+};
+
+#define SP_TW 34                      // tile columns: 32 conv columns + 1 halo column each side
+#define SP_TH 19                      // tile rows: 17 conv rows (8 pooled rows) + 1 halo row each side
+#define SP_POS 704                    // SP_TW * SP_TH = 646 positions, padded to whole 64-position DMA blocks
+#define SP_PLANE (SP_POS * 16)
+#define SP_WOFF (4 * SP_PLANE)        // weight block behind the four planes
+#define SP_SMEM (SP_WOFF + 18 * 1024)
+
+typedef __attribute__((ext_vector_type(2))) unsigned short sp_u16x2;
+
+__device__ __forceinline__ unsigned sp_max_u16x2(unsigned a, unsigned b) {   // packed maximum of two NON-NEGATIVE 16-bit floats (order = integer order)
+  const sp_u16x2 va = __builtin_bit_cast(sp_u16x2, a), vb = __builtin_bit_cast(sp_u16x2, b);
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(va, vb));
+}
+
+__global__ __launch_bounds__(256, 2) void stem_c3_pool_kernel(const StemPoolArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l32 = lane & 31, half = lane >> 5;
+  // XCD-aware order: an XCD (own L2) takes a contiguous run of (image, band, strip) tiles - neighbours share halo rows / columns
+  int bid = fx_xcd_remap(blockIdx.x, gridDim.x);
+  const int strip = bid % p.nstrips;
+  bid /= p.nstrips;
+  const int band = bid % p.nbands, b = bid / p.nbands;
+  const int Y0 = 16 * band - 2, X0 = 30 * strip - 2;       // image coordinates of tile position (0, 0)
+
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 2 * 18 * 1024, 0x00020000);
+  // ---- weights of channel block 0, then the input tile (44 DMA instructions: 11 position blocks x 4 pieces; lane = position)
+  for (int i = wave; i < 18; i += 4) pw_dma16(wr, smem + SP_WOFF + i * 1024, (unsigned)(i * 1024 + lane * 16));
+  for (int i = wave; i < (SP_POS / 64) * 4; i += 4) {
+    const int blk = i >> 2, c = i & 3;
+    const int t = blk * 64 + lane;
+    const int ty = t / SP_TW, tx = t - ty * SP_TW;
+    const int gy = Y0 + ty, gx = X0 + tx;
+    const bool ok = t < SP_TW * SP_TH && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    const unsigned off = ok ? (unsigned)(((b * p.H + gy) * p.W + gx) * p.ldx + c * 8) * 2u : FX_OOB;
+    pw_dma16(xr, smem + ((c & 1) * 2 + (c >> 1)) * SP_PLANE + blk * 1024, off);
+  }
+  // ---- per-lane constants
+  const int lds0 = (int)(unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+  int row0[5];      // LDS address of (conv row bb of this wave, conv column l32) in plane half * 2
+#pragma unroll
+  for (int bb = 0; bb < 5; ++bb) row0[bb] = lds0 + half * 2 * SP_PLANE + ((4 * wave + 1 + bb) * SP_TW + (l32 + 1)) * 16;
+  const int cx = 30 * strip - 1 + l32;                      // conv column of this lane
+  const bool col_ok = (unsigned)cx < (unsigned)p.W;
+  const int cy0 = 16 * band + 4 * wave - 1;                  // conv row of block 0
+  const int prow0 = 8 * band + 2 * wave;                     // first pooled row of this wave
+  const int pcol = 15 * strip + (l32 >> 1);                  // pooled column held by an even lane after the horizontal maximum
+  const bool store_lane = (l32 & 1) == 0 && l32 <= 28 && pcol < p.Wo;
+  const int waddr = lds0 + SP_WOFF + lane * 16;
+
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+#pragma unroll 1
+  for (int a = 0; a < 2; ++a) {
+    if (a == 1) {   // channel block 1 over block 0 (every wave is past its reads of it)
+      __syncthreads();
+      for (int i = wave; i < 18; i += 4) pw_dma16(wr, smem + SP_WOFF + i * 1024, (unsigned)(18 * 1024 + i * 1024 + lane * 16));
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    f32x16 acc[5];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const float4 bb4 = *reinterpret_cast<const float4*>(p.bias + a * 32 + 8 * gq + 4 * half);
+#pragma unroll
+      for (int bb = 0; bb < 5; ++bb) {
+        acc[bb][4 * gq] = bb4.x; acc[bb][4 * gq + 1] = bb4.y; acc[bb][4 * gq + 2] = bb4.z; acc[bb][4 * gq + 3] = bb4.w;
+      }
+    }
+    typedef __attribute__((address_space(3))) const bf16x8 lds_frag_t;
+#pragma unroll
+    for (int s = 0; s < 18; ++s) {   // k-step s = tap * 2 + j: channels 16 j .. 16 j + 15 of tap (dy, dx)
+      const int tap = s >> 1, j = s & 1;
+      const int toff = ((tap / 3 - 1) * SP_TW + (tap % 3 - 1)) * 16 + j * SP_PLANE;
+      const bf16x8 af = *reinterpret_cast<lds_frag_t*>((size_t)(unsigned)(waddr + s * 1024));
+#pragma unroll
+      for (int bb = 0; bb < 5; ++bb) {
+        const bf16x8 xf = *reinterpret_cast<lds_frag_t*>((size_t)(unsigned)(row0[bb] + toff));
+        acc[bb] = FX_MFMA_32x32x16(af, xf, acc[bb]);
+      }
+    }
+    // ---- ReLU, zero outside the image, vertical maximum, pack, horizontal maximum, 16-byte stores
+#pragma unroll
+    for (int bb = 0; bb < 5; ++bb) {
+      const bool ok = col_ok && (unsigned)(cy0 + bb) < (unsigned)p.H;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[bb][e] = (ok && acc[bb][e] > 0.0f) ? acc[bb][e] : 0.0f;   // (never -0.0: the packed maximum below orders BIT PATTERNS)
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      unsigned pk[4][2];   // [accumulator quad gq][register pair]: channels a*32 + 8 gq + 4 half + (0,1) / (2,3)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2) {
+          const int e = 4 * gq + 2 * w2;
+          const float v0 = fmaxf(fmaxf(acc[2 * r][e], acc[2 * r + 1][e]), acc[2 * r + 2][e]);
+          const float v1 = fmaxf(fmaxf(acc[2 * r][e + 1], acc[2 * r + 1][e + 1]), acc[2 * r + 2][e + 1]);
+          unsigned d = pack_bf16x2(v0, v1);
+          const unsigned d1 = (unsigned)__builtin_amdgcn_ds_bpermute(((lane + 1) & 63) << 2, (int)d);
+          const unsigned d2 = (unsigned)__builtin_amdgcn_ds_bpermute(((lane + 2) & 63) << 2, (int)d);
+          pk[gq][w2] = sp_max_u16x2(sp_max_u16x2(d, d1), d2);
+        }
+      const int prow = prow0 + r;
+      bf16_t* yrow = p.y + ((size_t)(b * p.Ho + prow) * p.Wo + pcol) * p.ldy + a * 32 + half * 8;
+      const bool live = store_lane && prow < p.Ho;
+#pragma unroll
+      for (int g2 = 0; g2 < 2; ++g2) {
+        unsigned q0[2] = {pk[2 * g2][0], pk[2 * g2][1]}, q1[2] = {pk[2 * g2 + 1][0], pk[2 * g2 + 1][1]};
+#pragma unroll
+        for (int w2 = 0; w2 < 2; ++w2) {   // half 0 keeps quad 2 g2 of both halves (8 consecutive channels), half 1 quad 2 g2 + 1
+          const auto sw = __builtin_amdgcn_permlane32_swap(q0[w2], q1[w2], false, false);
+          q0[w2] = sw[0];
+          q1[w2] = sw[1];
+        }
+        if (live) *reinterpret_cast<uint4*>(yrow + g2 * 16) = make_uint4(q0[0], q0[1], q1[0], q1[1]);
+      }
+    }
+  }
+}
+
+// 1 iff the fused launch covers the layer pair: conv 3x3 / s1 / p1 with 32 input and 64 output channels + ReLU, then max-pool 3x3 / s2 / p1
+extern "C" int fx_stem_conv_pool_supported(int C, int N, int H, int W) { return C == 32 && N == 64 && H >= 2 && W >= 2; }
+
+extern "C" int fx_stem_conv3x3_relu_maxpool_bf16(const void* x, int ldx, const void* w_frag, const float* bias, void* y, int ldy, int B, int H, int W,
+                                                 fx_stream_t stream_) {
+  FX_CHECK_ARG(x && w_frag && bias && y && B > 0 && H >= 2 && W >= 2 && ldx >= 32 && ldx % 8 == 0 && ldy >= 64 && ldy % 8 == 0);
+  FX_CHECK_ARG(((uintptr_t)x % 16) == 0 && ((uintptr_t)w_frag % 16) == 0 && ((uintptr_t)y % 16) == 0 && ((uintptr_t)bias % 16) == 0);
+  const int64_t x_bytes = ((int64_t)B * H * W - 1) * ldx * 2 + 64;
+  if (x_bytes >= 0xFFFFFFF0ll) return FX_ERR_UNSUPPORTED;
+  StemPoolArgs a{};
+  a.x = reinterpret_cast<const bf16_t*>(x);
+  a.wp = reinterpret_cast<const bf16_t*>(w_frag);
+  a.bias = bias;
+  a.y = reinterpret_cast<bf16_t*>(y);
+  a.H = H; a.W = W; a.ldx = ldx; a.ldy = ldy;
+  a.Ho = (H - 1) / 2 + 1; a.Wo = (W - 1) / 2 + 1;
+  a.nbands = (a.Ho + 7) / 8;
+  a.nstrips = (a.Wo + 14) / 15;
+  a.x_bytes = (unsigned)x_bytes;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_c3_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SP_SMEM) != hipSuccess)
+      return FX_ERR_RUNTIME;
+    attr_set = true;
+  }
+  const int64_t grid = (int64_t)B * a.nbands * a.nstrips;
+  if (grid >= (1ll << 31)) return FX_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(stem_c3_pool_kernel, dim3((int)grid), dim3(256), SP_SMEM, reinterpret_cast<hipStream_t>(stream_), a);
+  return fx_launch_status();
+}

@@ -623,9 +623,18 @@ class _PlanBase:
         self._op(lib.fx_stem_conv3x3s2, self.input.data_ptr(), int(self.f32_input), e.stem_w.data_ptr(), e.stem_b.data_ptr(),
                  e.px_mean.data_ptr(), e.px_inv_std.data_ptr(), c1.ptr, B, H, W, 32)
         x = self.conv(c1, P[f"{bb}.conv1.conv1_2"], name="conv1_2", act="relu")
-        x = self.conv(x, P[f"{bb}.conv1.conv1_3"], name="conv1_3", act="relu")
-        mp = self._new("maxpool", B, (x.H + 1) // 2, (x.W + 1) // 2, 64)
-        self._op(lib.fx_maxpool3x3s2_nhwc_bf16, x.ptr, x.ld, mp.ptr, mp.ld, B, x.H, x.W, 64)
+        pc3 = P[f"{bb}.conv1.conv1_3"]
+        if os.environ.get("FX_STEM_FUSE", "1") != "0" and pc3.wf is not None and lib.fx_stem_conv_pool_supported(x.C, pc3.N, x.H, x.W) == 1:
+            # conv1_3 + ReLU + max-pool in one launch (csrc/stem_pool.hip, round 5): the [B,H/2,W/2,64] conv1_3 activation is never written
+            mp = self._new("maxpool", B, (x.H + 1) // 2, (x.W + 1) // 2, 64)
+            M3 = B * x.H * x.W
+            self.meta[len(self.ops)] = {"kind": "conv", "variant": "stem_c3+pool", "flops": 2.0 * M3 * 64 * 288, "flops_executed": 2.0 * M3 * 64 * 288 * 1.37,
+                                        "bytes": 2.0 * M3 * 32 + 2.0 * mp.rows * 64 + 2.0 * 64 * 288, "name": "conv1_3+maxpool", "M": M3, "N": 64, "K": 288}
+            self._op(lib.fx_stem_conv3x3_relu_maxpool_bf16, x.ptr, x.ld, pc3.wf.data_ptr(), pc3.b.data_ptr(), mp.ptr, mp.ld, B, x.H, x.W)
+        else:
+            x = self.conv(x, pc3, name="conv1_3", act="relu")
+            mp = self._new("maxpool", B, (x.H + 1) // 2, (x.W + 1) // 2, 64)
+            self._op(lib.fx_maxpool3x3s2_nhwc_bf16, x.ptr, x.ld, mp.ptr, mp.ld, B, x.H, x.W, 64)
         x = mp
         seq = [(si, bi) for si in range(4) for bi in range(blocks[si])]
         a_next: Optional[NT] = None

@@ -346,6 +346,28 @@ def dp_plan(config: Dict, family: str, norm: str, world: int, per_rank_batch: in
         buckets += [min(per, lo + n - s) for s in range(lo, lo + n, per)]
         lo += n
     total = sum(seg_numel)
+    # SyncBN (the reference's multi-GPU conversion, trainer/trainer.py:333-334): every BatchNorm layer issues one small all-reduce in the
+    # forward ([2, C] sums) and one in the backward ([sum da, sum da xhat]) - serialised, latency-bound collectives.  A layer's
+    # statistics are a data dependency of its own output, so only SIBLINGS can share a collective: layers that read the same input (forward)
+    # / receive the same output gradient (backward) - a bottleneck's shortcut conv with branch2a (forward) / branch2c (backward), the
+    # conv1 | conv2 halves of a CSP layer and the 3x3 | 1x1 branches of a RepVGG block, the level projections whose inputs exist together.
+    spec = state_spec(config, family)
+    bn_layers = [n[: -len(".weight")] for n, (_, kind) in spec.items() if kind == "bn_w"]
+    pairs = 0
+    if family == "fai_detr":
+        parents = {}
+        for n in bn_layers:
+            parts = n.split(".")
+            if "conv1" in parts or "conv2" in parts:    # CSPRepLayer.conv1 | conv2, RepVggBlock.conv1 | conv2
+                i = parts.index("conv1") if "conv1" in parts else parts.index("conv2")
+                if parts[i - 1] != "backbone":
+                    parents.setdefault(".".join(parts[:i]), set()).add(parts[i])
+        pairs = sum(1 for v in parents.values() if v == {"conv1", "conv2"}) + sum(1 for n in bn_layers if ".short." in n)
+    syncbn = {"batchnorm_layers": len(bn_layers), "collectives_per_step": 2 * len(bn_layers),
+              "sibling_pairs_that_could_share_a_collective": pairs,
+              "collectives_per_step_with_siblings_coalesced": 2 * (len(bn_layers) - pairs),
+              "note": "one all-reduce per layer and direction today (what nn.SyncBatchNorm issues); siblings = same input (forward) / same output "
+                      "gradient (backward); everything else is a chain of data dependencies and cannot be batched without changing the arithmetic"}
     # ring all-reduce moves 2 (N-1)/N of the buffer per rank and direction; xGMI is point-to-point (7 links x ~153 GB/s per GPU)
     ring = 2.0 * (world - 1) / max(world, 1) * total * grad_bytes
     return {"world_size": world, "per_rank_batch": per_rank_batch, "global_batch": per_rank_batch * world, "trainable_parameters": total,
@@ -354,6 +376,7 @@ def dp_plan(config: Dict, family: str, norm: str, world: int, per_rank_batch: in
             "allreduce_bytes_per_step": total * grad_bytes, "ring_bytes_sent_per_rank": int(ring),
             "other_collectives": ["num_boxes / num_masks: one 4-byte all-reduce per step"] + (
                 ["SyncBN: two [2, C] fp32 all-reduces per BatchNorm layer (forward statistics, backward sums)"] if norm == "SyncBN" else []),
+            "syncbn": syncbn if norm == "SyncBN" else None,
             "gradient_dtype": "fp32" if grad_bytes == 4 else "bf16"}
 
 

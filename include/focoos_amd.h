@@ -142,6 +142,14 @@ int fx_resize_bilinear_u8(const uint8_t* x, int H, int W, float* y, int Ho, int 
 
 /* F.max_pool2d(k=3,s=2,p=1) (resnet.py:254) on NHWC bf16. */
 int fx_maxpool3x3s2_nhwc_bf16(const void* x, int ldx, void* y, int ldy, int B, int H, int W, int C, fx_stream_t stream);
+/* The last stem layer and the pool in ONE launch (ABI 7; csrc/stem_pool.hip): y = max_pool2d(relu(conv3x3_s1_p1(x) + bias), 3, 2, 1) for the
+ * ResNet-vd stem's conv1_3 (32 -> 64 channels, BatchNorm folded; focoos/nn/backbone/resnet.py:184-196 `conv1`, :252-256 forward) - the
+ * [B,H,W,64] activation between them is never written.  x bf16 NHWC [B,H,W,32] (pixel stride ldx), w_frag = the layer's weights in MFMA
+ * fragment order (fx_conv_desc.w_frag: [2][18][64][8], k = (kh*3 + kw)*32 + c), bias f32 [64], y bf16 [B,(H-1)/2+1,(W-1)/2+1,64] (pixel
+ * stride ldy).  Bit-identical to fx_conv2d_nhwc_bf16 (act = ReLU) followed by fx_maxpool3x3s2_nhwc_bf16. */
+int fx_stem_conv_pool_supported(int C, int N, int H, int W);
+int fx_stem_conv3x3_relu_maxpool_bf16(const void* x, int ldx, const void* w_frag, const float* bias, void* y, int ldy, int B, int H, int W,
+                                      fx_stream_t stream);
 
 /* nn.AvgPool2d(2, 2, 0, ceil_mode=True) of the "d"-variant shortcut (resnet.py:89-100) on NHWC bf16 -> [B,ceil(H/2),ceil(W/2),C].
  * (fx_conv2d_nhwc_bf16's pool2 flag fuses the same pooling into the conv's A-load; this standalone form pools once

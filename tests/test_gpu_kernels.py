@@ -933,3 +933,41 @@ def test_row_chain_lean_stages(lib, hidden):
         ]
         run(old, LDS3)
         assert torch.equal(y_old[:M], y_lean[:M]) and torch.equal(q_old[:M], q_lean[:M])
+
+
+@pytest.mark.parametrize("case", [(2, 64, 96, 0), (1, 320, 320, 0), (3, 33, 47, 8), (1, 400, 400, 0), (2, 17, 30, 0), (1, 2, 2, 0)])
+def test_stem_conv_relu_maxpool_fused(lib, case, flat_small_shapes):
+    """fx_stem_conv3x3_relu_maxpool_bf16 (csrc/stem_pool.hip, round 5): conv1_3 + ReLU + max_pool2d(3, 2, 1) in one launch - BIT-identical to the
+    two launches it replaces (fx_conv2d_nhwc_bf16 on the c32 kernel, then fx_maxpool3x3s2_nhwc_bf16) and equal to fp32 torch within one bf16
+    rounding; odd sizes (partial bands / strips, odd H and W), the benchmark's 320 x 320 and MaskFormer's 400 x 400, strided input rows.
+    Position-dependent inputs: a wrong tap offset / tile coordinate is an O(1) error."""
+    B, H, W, pad = case
+    Cc, N = 32, 64
+    assert lib.fx_stem_conv_pool_supported(Cc, N, H, W) == 1
+    g = torch.Generator().manual_seed(900 + H + W)
+    x = torch.randn(B, H, W, Cc, generator=g) + torch.linspace(-1, 1, W)[None, None, :, None] + torch.linspace(-0.5, 0.5, H)[None, :, None, None]
+    W4 = torch.randn(N, Cc, 3, 3, generator=g) / math.sqrt(Cc * 9) + torch.linspace(-0.03, 0.03, 9).view(1, 1, 3, 3)
+    bias = torch.randn(N, generator=g) * 0.5 - 0.3     # a good share of negative pre-activations: the ReLU / zero-padding rule matters
+    ldx = Cc + pad
+    xb = torch.zeros(B, H, W, ldx, dtype=torch.bfloat16)
+    xb[..., :Cc] = bf(x)
+    xd = to_dev(xb)
+    wf = frag_pack(W4.permute(0, 2, 3, 1).reshape(N, 9 * Cc))
+    bd = to_dev(bias)
+    Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    y = torch.full((B, Ho, Wo, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    check(lib.fx_stem_conv3x3_relu_maxpool_bf16(xd.data_ptr(), ldx, wf.data_ptr(), bd.data_ptr(), y.data_ptr(), N, B, H, W, stream()), "stem_conv_pool")
+    torch.cuda.synchronize()
+    got = y.float().cpu()
+    assert not torch.isnan(got).any()
+    # (1) fp32 torch on the bf16-rounded operands
+    ref = F.max_pool2d(F.relu(F.conv2d(bf(x).float().permute(0, 3, 1, 2), bf(W4).float(), bias, padding=1)), 3, 2, 1).permute(0, 2, 3, 1)
+    assert tuple(ref.shape) == (B, Ho, Wo, N)
+    assert (got - ref).abs().max() <= 1.0e-2 * ref.abs().max(), (got - ref).abs().max()
+    # (2) the two launches it replaces: identical bits
+    conv = run_conv(lib, x, W4, bias, 1, "relu", ldx=ldx, frag=True)     # [B,H,W,64] through fx_conv2d_nhwc_bf16 (c32 kernel where W allows)
+    cd = to_dev(bf(conv))
+    y2 = torch.full((B, Ho, Wo, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    check(lib.fx_maxpool3x3s2_nhwc_bf16(cd.data_ptr(), N, y2.data_ptr(), N, B, H, W, N, stream()), "maxpool")
+    torch.cuda.synchronize()
+    assert torch.equal(y2, y), (y2.float() - y.float()).abs().max()

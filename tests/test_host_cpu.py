@@ -480,3 +480,28 @@ def test_model_manager_resolution_order_and_local_run_directories(tmp_path, monk
         ModelManager.get("x", model_info=ModelInfo.from_json(missing))
     with pytest.raises(ValueError, match="not supported"):
         ModelManager.get("x", model_info=ModelInfo.from_json(dict(info, model_family="rtmo")))
+
+
+def test_dp_plan_counts_the_syncbn_collectives_of_the_real_module_tree():
+    """the per-step SyncBN collective count stated by dp_plan (RT-DETR-L: 97 BatchNorm layers -> 194 small all-reduces,
+    154 if the 20 sibling pairs shared theirs) equals what the REAL trainable module tree would issue: one statistics all-reduce in the
+    forward and one in the backward per batch-statistics layer (train_nn._bn_forward / _bn_backward)."""
+    from unittest import mock
+
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.train import dp_plan
+
+    cfg = ModelRegistry.get_model_info("fai-detr-l-obj365")["config"]
+    plan = dp_plan(cfg, "fai_detr", "SyncBN", 8, 16)
+    sb = plan["syncbn"]
+    assert sb["batchnorm_layers"] == 97 and sb["collectives_per_step"] == 194
+    assert sb["sibling_pairs_that_could_share_a_collective"] == 20 and sb["collectives_per_step_with_siblings_coalesced"] == 154
+    assert dp_plan(cfg, "fai_detr", "FrozenBN", 8, 16)["syncbn"] is None
+    with mock.patch("torch.cuda.is_available", return_value=True), mock.patch("focoos_amd._lib.load", return_value=None):
+        from focoos_amd.train_detr import FAIDetrTrainable
+
+        net = FAIDetrTrainable(cfg, norm="SyncBN")
+    layers = [m for m in net.modules() if getattr(m, "norm_mode", None) == "SyncBN" and hasattr(m, "_norm_h")]
+    live = [m for m in layers if m._norm_h.weight.requires_grad]
+    # the dead mask_features conv of RT-DETR is frozen out of the training graph (train_nn.HybridEncoder): every other BatchNorm is live
+    assert len(layers) >= 97 and len(live) in (97, 96), (len(layers), len(live))
