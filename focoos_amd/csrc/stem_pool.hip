@@ -17,9 +17,11 @@
 // The input tile (19 rows x 34 columns of 32 channels, zero outside the image: OOB buffer loads) sits in LDS in the k-plane layout of
 // conv3x3_c32.hip ([plane = half * 2 + j][position][8 channels]), fetched by buffer_load ... lds (each 64-byte pixel is four 16-byte pieces, one per
 // plane); a conv output at tile position t reads tap (dy, dx) at t + dy * 34 + dx - no border masks in the K loop (the padding IS zeros in the
-// tile).  Weights: the SAME fragment-order image conv3x3_c32 uses ([2 blocks][18 k-steps][64 lanes][8]), one 18 KiB block at a time in LDS
-// (an A fragment feeds five MFMAs, so reading it from LDS costs 0.2 LDS reads per MFMA on top of the B operand's 1.0) - no register ring, no
-// asm: two workgroups per CU (63.5 KiB each) cover each other's fetch / reload / store phases.
+// tile).  Weights: the SAME fragment-order image conv3x3_c32 uses ([2 blocks][18 k-steps][64 lanes][8]), all 36 KiB of it in LDS (an A
+// fragment feeds five MFMAs, a B fragment both channel blocks: 126 LDS reads per 180 MFMAs of a wave) - no register ring, no asm: two
+// workgroups per CU (77 KiB each) cover each other's fetch / store phases.  (First form: one 18 KiB weight block at a time, two passes over
+// the tile with a reload + two barriers in between and every B fragment read twice - 116 us per part, LDS-bound; the four planes are packed
+// at their exact 646-position pitch, filled by 41 DMA instructions over the concatenated slot space, to make room for both blocks.)
 // Exactness: per output the accumulation order is bias, then k-steps 0..17 - conv3x3_c32's order - and max commutes with the monotonic
 // bf16 rounding, so the result is bit-identical to the two launches it replaces.  Conv positions outside the image are forced to 0 before the
 // maximum: every value is >= 0 after the ReLU and every window holds at least one real pixel, so 0 stands in for max_pool2d's -inf padding.
@@ -37,10 +39,11 @@ struct StemPoolArgs {
 
 #define SP_TW 34                      // tile columns: 32 conv columns + 1 halo column each side
 #define SP_TH 19                      // tile rows: 17 conv rows (8 pooled rows) + 1 halo row each side
-#define SP_POS 704                    // SP_TW * SP_TH = 646 positions, padded to whole 64-position DMA blocks
+#define SP_POS (SP_TW * SP_TH)        // 646 positions per plane, planes packed back to back
 #define SP_PLANE (SP_POS * 16)
-#define SP_WOFF (4 * SP_PLANE)        // weight block behind the four planes
-#define SP_SMEM (SP_WOFF + 18 * 1024)
+#define SP_NDMA ((4 * SP_POS + 63) / 64)   // 41 DMA instructions over the 2584 (plane, position) slots; the last one's 40 spare lanes land in the pad
+#define SP_WOFF (SP_NDMA * 1024)      // both weight blocks behind the planes (+ pad)
+#define SP_SMEM (SP_WOFF + 36 * 1024)
 
 typedef __attribute__((ext_vector_type(2))) unsigned short sp_u16x2;
 
@@ -63,16 +66,18 @@ __global__ __launch_bounds__(256, 2) void stem_c3_pool_kernel(const StemPoolArgs
 
   const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 2 * 18 * 1024, 0x00020000);
-  // ---- weights of channel block 0, then the input tile (44 DMA instructions: 11 position blocks x 4 pieces; lane = position)
-  for (int i = wave; i < 18; i += 4) pw_dma16(wr, smem + SP_WOFF + i * 1024, (unsigned)(i * 1024 + lane * 16));
-  for (int i = wave; i < (SP_POS / 64) * 4; i += 4) {
-    const int blk = i >> 2, c = i & 3;
-    const int t = blk * 64 + lane;
+  // ---- weights (36 DMA instructions), then the input tile: slot S = plane * 646 + position, 64 slots per instruction, lane = slot; plane pl
+  // holds piece c = (pl & 1) * 2 + (pl >> 1) of a pixel's 64 bytes (plane = half * 2 + j <-> channels 16 j + 8 half .. + 7)
+  for (int i = wave; i < 36; i += 4) pw_dma16(wr, smem + SP_WOFF + i * 1024, (unsigned)(i * 1024 + lane * 16));
+  for (int i = wave; i < SP_NDMA; i += 4) {
+    const int S = i * 64 + lane;
+    const int pl = S / SP_POS, t = S - pl * SP_POS;
+    const int c = (pl & 1) * 2 + (pl >> 1);
     const int ty = t / SP_TW, tx = t - ty * SP_TW;
     const int gy = Y0 + ty, gx = X0 + tx;
-    const bool ok = t < SP_TW * SP_TH && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+    const bool ok = pl < 4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
     const unsigned off = ok ? (unsigned)(((b * p.H + gy) * p.W + gx) * p.ldx + c * 8) * 2u : FX_OOB;
-    pw_dma16(xr, smem + ((c & 1) * 2 + (c >> 1)) * SP_PLANE + blk * 1024, off);
+    pw_dma16(xr, smem + i * 1024, off);
   }
   // ---- per-lane constants
   const int lds0 = (int)(unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
@@ -90,41 +95,39 @@ __global__ __launch_bounds__(256, 2) void stem_c3_pool_kernel(const StemPoolArgs
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-#pragma unroll 1
-  for (int a = 0; a < 2; ++a) {
-    if (a == 1) {   // channel block 1 over block 0 (every wave is past its reads of it)
-      __syncthreads();
-      for (int i = wave; i < 18; i += 4) pw_dma16(wr, smem + SP_WOFF + i * 1024, (unsigned)(18 * 1024 + i * 1024 + lane * 16));
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-    f32x16 acc[5];
+  f32x16 acc[2][5];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
       const float4 bb4 = *reinterpret_cast<const float4*>(p.bias + a * 32 + 8 * gq + 4 * half);
 #pragma unroll
       for (int bb = 0; bb < 5; ++bb) {
-        acc[bb][4 * gq] = bb4.x; acc[bb][4 * gq + 1] = bb4.y; acc[bb][4 * gq + 2] = bb4.z; acc[bb][4 * gq + 3] = bb4.w;
+        acc[a][bb][4 * gq] = bb4.x; acc[a][bb][4 * gq + 1] = bb4.y; acc[a][bb][4 * gq + 2] = bb4.z; acc[a][bb][4 * gq + 3] = bb4.w;
       }
     }
-    typedef __attribute__((address_space(3))) const bf16x8 lds_frag_t;
+  typedef __attribute__((address_space(3))) const bf16x8 lds_frag_t;
 #pragma unroll
-    for (int s = 0; s < 18; ++s) {   // k-step s = tap * 2 + j: channels 16 j .. 16 j + 15 of tap (dy, dx)
-      const int tap = s >> 1, j = s & 1;
-      const int toff = ((tap / 3 - 1) * SP_TW + (tap % 3 - 1)) * 16 + j * SP_PLANE;
-      const bf16x8 af = *reinterpret_cast<lds_frag_t*>((size_t)(unsigned)(waddr + s * 1024));
+  for (int s = 0; s < 18; ++s) {   // k-step s = tap * 2 + j: channels 16 j .. 16 j + 15 of tap (dy, dx)
+    const int tap = s >> 1, j = s & 1;
+    const int toff = ((tap / 3 - 1) * SP_TW + (tap % 3 - 1)) * 16 + j * SP_PLANE;
+    const bf16x8 af0 = *reinterpret_cast<lds_frag_t*>((size_t)(unsigned)(waddr + s * 1024));
+    const bf16x8 af1 = *reinterpret_cast<lds_frag_t*>((size_t)(unsigned)(waddr + (18 + s) * 1024));
 #pragma unroll
-      for (int bb = 0; bb < 5; ++bb) {
-        const bf16x8 xf = *reinterpret_cast<lds_frag_t*>((size_t)(unsigned)(row0[bb] + toff));
-        acc[bb] = FX_MFMA_32x32x16(af, xf, acc[bb]);
-      }
+    for (int bb = 0; bb < 5; ++bb) {
+      const bf16x8 xf = *reinterpret_cast<lds_frag_t*>((size_t)(unsigned)(row0[bb] + toff));
+      acc[0][bb] = FX_MFMA_32x32x16(af0, xf, acc[0][bb]);
+      acc[1][bb] = FX_MFMA_32x32x16(af1, xf, acc[1][bb]);
     }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a) {
     // ---- ReLU, zero outside the image, vertical maximum, pack, horizontal maximum, 16-byte stores
 #pragma unroll
     for (int bb = 0; bb < 5; ++bb) {
       const bool ok = col_ok && (unsigned)(cy0 + bb) < (unsigned)p.H;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) acc[bb][e] = (ok && acc[bb][e] > 0.0f) ? acc[bb][e] : 0.0f;   // (never -0.0: the packed maximum below orders BIT PATTERNS)
+      for (int e = 0; e < 16; ++e) acc[a][bb][e] = (ok && acc[a][bb][e] > 0.0f) ? acc[a][bb][e] : 0.0f;   // (never -0.0: the packed maximum below orders BIT PATTERNS)
     }
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -134,8 +137,8 @@ __global__ __launch_bounds__(256, 2) void stem_c3_pool_kernel(const StemPoolArgs
 #pragma unroll
         for (int w2 = 0; w2 < 2; ++w2) {
           const int e = 4 * gq + 2 * w2;
-          const float v0 = fmaxf(fmaxf(acc[2 * r][e], acc[2 * r + 1][e]), acc[2 * r + 2][e]);
-          const float v1 = fmaxf(fmaxf(acc[2 * r][e + 1], acc[2 * r + 1][e + 1]), acc[2 * r + 2][e + 1]);
+          const float v0 = fmaxf(fmaxf(acc[a][2 * r][e], acc[a][2 * r + 1][e]), acc[a][2 * r + 2][e]);
+          const float v1 = fmaxf(fmaxf(acc[a][2 * r][e + 1], acc[a][2 * r + 1][e + 1]), acc[a][2 * r + 2][e + 1]);
           unsigned d = pack_bf16x2(v0, v1);
           const unsigned d1 = (unsigned)__builtin_amdgcn_ds_bpermute(((lane + 1) & 63) << 2, (int)d);
           const unsigned d2 = (unsigned)__builtin_amdgcn_ds_bpermute(((lane + 2) & 63) << 2, (int)d);
