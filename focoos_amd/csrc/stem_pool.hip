@@ -107,18 +107,32 @@ __global__ __launch_bounds__(256, 2) void stem_c3_pool_kernel(const StemPoolArgs
       }
     }
   typedef __attribute__((address_space(3))) const bf16x8 lds_frag_t;
+  // k-step s = tap * 2 + j: channels 16 j .. 16 j + 15 of tap (dy, dx).  Software pipeline: the seven fragments of step s + 1 (five pixel
+  // blocks, two weight blocks) are requested BEFORE the ten MFMAs of step s, into the other half of a register double buffer - an LDS read
+  // takes ~130 cycles, ten MFMAs 320; left to itself hipcc issued each read right in front of the MFMA pair that needs it (first form:
+  // `ds_read; s_waitcnt lgkmcnt(0); 2 x v_mfma`, 104 us per part).  sched_barrier keeps the steps from being interleaved again.
+  auto toff = [&](int s) { return (((s >> 1) / 3 - 1) * SP_TW + ((s >> 1) % 3 - 1)) * 16 + (s & 1) * SP_PLANE; };
+  bf16x8 xb[2][5], af[2][2];
 #pragma unroll
-  for (int s = 0; s < 18; ++s) {   // k-step s = tap * 2 + j: channels 16 j .. 16 j + 15 of tap (dy, dx)
-    const int tap = s >> 1, j = s & 1;
-    const int toff = ((tap / 3 - 1) * SP_TW + (tap % 3 - 1)) * 16 + j * SP_PLANE;
-    const bf16x8 af0 = *reinterpret_cast<lds_frag_t*>((size_t)(unsigned)(waddr + s * 1024));
-    const bf16x8 af1 = *reinterpret_cast<lds_frag_t*>((size_t)(unsigned)(waddr + (18 + s) * 1024));
+  for (int bb = 0; bb < 5; ++bb) xb[0][bb] = *reinterpret_cast<lds_frag_t*>((size_t)(unsigned)(row0[bb] + toff(0)));
+  af[0][0] = *reinterpret_cast<lds_frag_t*>((size_t)(unsigned)(waddr));
+  af[0][1] = *reinterpret_cast<lds_frag_t*>((size_t)(unsigned)(waddr + 18 * 1024));
+#pragma unroll
+  for (int s = 0; s < 18; ++s) {
+    const int cur = s & 1, nxt = cur ^ 1;
+    if (s + 1 < 18) {
+#pragma unroll
+      for (int bb = 0; bb < 5; ++bb) xb[nxt][bb] = *reinterpret_cast<lds_frag_t*>((size_t)(unsigned)(row0[bb] + toff(s + 1)));
+      af[nxt][0] = *reinterpret_cast<lds_frag_t*>((size_t)(unsigned)(waddr + (s + 1) * 1024));
+      af[nxt][1] = *reinterpret_cast<lds_frag_t*>((size_t)(unsigned)(waddr + (18 + s + 1) * 1024));
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int bb = 0; bb < 5; ++bb) {
-      const bf16x8 xf = *reinterpret_cast<lds_frag_t*>((size_t)(unsigned)(row0[bb] + toff));
-      acc[0][bb] = FX_MFMA_32x32x16(af0, xf, acc[0][bb]);
-      acc[1][bb] = FX_MFMA_32x32x16(af1, xf, acc[1][bb]);
+      acc[0][bb] = FX_MFMA_32x32x16(af[cur][0], xb[cur][bb], acc[0][bb]);
+      acc[1][bb] = FX_MFMA_32x32x16(af[cur][1], xb[cur][bb], acc[1][bb]);
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int a = 0; a < 2; ++a) {

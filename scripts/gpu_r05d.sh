@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5, call D: single-pass form of the fused conv1_3 + max-pool kernel (both weight blocks resident, B fragments shared): parity + A/B
-TAG=r05d
+TAG=r05e
 out=$PWD/gpurun_out/$TAG; mkdir -p $out
 export TMPDIR=/tmp
 timeout 300 python -m pytest tests/test_gpu_kernels.py -q -k "stem_conv_relu_maxpool" > $out/stem_tests.txt 2>&1; echo "fused stem kernel tests rc=$?"; tail -4 $out/stem_tests.txt | cut -c1-400
