@@ -52,24 +52,13 @@ __device__ __forceinline__ unsigned sp_max_u16x2(unsigned a, unsigned b) {   // 
   return __builtin_bit_cast(unsigned, __builtin_elementwise_max(va, vb));
 }
 
-__global__ __launch_bounds__(256, 2) void stem_c3_pool_kernel(const StemPoolArgs p) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l32 = lane & 31, half = lane >> 5;
-  // XCD-aware order: an XCD (own L2) takes a contiguous run of (image, band, strip) tiles - neighbours share halo rows / columns
-  int bid = fx_xcd_remap(blockIdx.x, gridDim.x);
-  const int strip = bid % p.nstrips;
-  bid /= p.nstrips;
-  const int band = bid % p.nbands, b = bid / p.nbands;
+// DMA of one input tile (plane-packed, 41 instructions) by the calling wave(s): instruction i = first, first + step, ...
+__device__ __forceinline__ void sp_dma_tile(const StemPoolArgs& p, __amdgpu_buffer_rsrc_t xr, unsigned char* tile, int b, int band, int strip, int lane,
+                                            int first, int step) {
   const int Y0 = 16 * band - 2, X0 = 30 * strip - 2;       // image coordinates of tile position (0, 0)
-
-  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 2 * 18 * 1024, 0x00020000);
-  // ---- weights (36 DMA instructions), then the input tile: slot S = plane * 646 + position, 64 slots per instruction, lane = slot; plane pl
-  // holds piece c = (pl & 1) * 2 + (pl >> 1) of a pixel's 64 bytes (plane = half * 2 + j <-> channels 16 j + 8 half .. + 7)
-  for (int i = wave; i < 36; i += 4) pw_dma16(wr, smem + SP_WOFF + i * 1024, (unsigned)(i * 1024 + lane * 16));
-  for (int i = wave; i < SP_NDMA; i += 4) {
+  // slot S = plane * 646 + position, 64 slots per instruction, lane = slot; plane pl holds piece c = (pl & 1) * 2 + (pl >> 1) of a pixel's
+  // 64 bytes (plane = half * 2 + j <-> channels 16 j + 8 half .. + 7)
+  for (int i = first; i < SP_NDMA; i += step) {
     const int S = i * 64 + lane;
     const int pl = S / SP_POS, t = S - pl * SP_POS;
     const int c = (pl & 1) * 2 + (pl >> 1);
@@ -77,24 +66,23 @@ __global__ __launch_bounds__(256, 2) void stem_c3_pool_kernel(const StemPoolArgs
     const int gy = Y0 + ty, gx = X0 + tx;
     const bool ok = pl < 4 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
     const unsigned off = ok ? (unsigned)(((b * p.H + gy) * p.W + gx) * p.ldx + c * 8) * 2u : FX_OOB;
-    pw_dma16(xr, smem + i * 1024, off);
+    pw_dma16(xr, tile + i * 1024, off);
   }
-  // ---- per-lane constants
-  const int lds0 = (int)(unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+}
+
+// One tile by the four compute waves: `tile_lds` / `w_lds` = LDS byte addresses of the input tile and of the weights
+__device__ __forceinline__ void sp_compute_tile(const StemPoolArgs& p, int tile_lds, int w_lds, int b, int band, int strip, int wave, int lane) {
+  const int l32 = lane & 31, half = lane >> 5;
   int row0[5];      // LDS address of (conv row bb of this wave, conv column l32) in plane half * 2
 #pragma unroll
-  for (int bb = 0; bb < 5; ++bb) row0[bb] = lds0 + half * 2 * SP_PLANE + ((4 * wave + 1 + bb) * SP_TW + (l32 + 1)) * 16;
+  for (int bb = 0; bb < 5; ++bb) row0[bb] = tile_lds + half * 2 * SP_PLANE + ((4 * wave + 1 + bb) * SP_TW + (l32 + 1)) * 16;
   const int cx = 30 * strip - 1 + l32;                      // conv column of this lane
   const bool col_ok = (unsigned)cx < (unsigned)p.W;
   const int cy0 = 16 * band + 4 * wave - 1;                  // conv row of block 0
   const int prow0 = 8 * band + 2 * wave;                     // first pooled row of this wave
   const int pcol = 15 * strip + (l32 >> 1);                  // pooled column held by an even lane after the horizontal maximum
   const bool store_lane = (l32 & 1) == 0 && l32 <= 28 && pcol < p.Wo;
-  const int waddr = lds0 + SP_WOFF + lane * 16;
-
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
+  const int waddr = w_lds + lane * 16;
   f32x16 acc[2][5];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -176,6 +164,76 @@ __global__ __launch_bounds__(256, 2) void stem_c3_pool_kernel(const StemPoolArgs
   }
 }
 
+// Form 1: one workgroup (4 waves) per tile, two workgroups per CU (77 KiB each) covering each other's fetch / store phases.
+__global__ __launch_bounds__(256, 2) void stem_c3_pool_kernel(const StemPoolArgs p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware order: an XCD (own L2) takes a contiguous run of (image, band, strip) tiles - neighbours share halo rows / columns
+  int bid = fx_xcd_remap(blockIdx.x, gridDim.x);
+  const int strip = bid % p.nstrips;
+  bid /= p.nstrips;
+  const int band = bid % p.nbands, b = bid / p.nbands;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 2 * 18 * 1024, 0x00020000);
+  for (int i = wave; i < 36; i += 4) pw_dma16(wr, smem + SP_WOFF + i * 1024, (unsigned)(i * 1024 + lane * 16));
+  sp_dma_tile(p, xr, smem, b, band, strip, lane, wave, 4);
+  const int lds0 = (int)(unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  sp_compute_tile(p, lds0, lds0 + SP_WOFF, b, band, strip, wave, lane);
+}
+
+// Form 2 (FX_STEM_POOL_PERSIST=1): persistent workgroups, one per CU, of four compute waves + a LOADER wave.  Form 1's workgroups live ~10 us
+// of which the first ~4 are the fetch of 77 KiB (weights again for every tile) before the first MFMA - two per CU overlap that only in part
+// (104 us per 16-image part for 35 us of MFMA work).  Here a workgroup walks a contiguous run of tiles; the weights are fetched once, the
+// loader wave DMAs tile i + 1 into the other of two tile buffers while the compute waves are on tile i; one barrier per tile.
+#define SP2_TILE (SP_NDMA * 1024)
+#define SP2_WOFF (2 * SP2_TILE)
+#define SP2_SMEM (SP2_WOFF + 36 * 1024)
+__global__ __launch_bounds__(320, 1) void stem_c3_pool_persist_kernel(const StemPoolArgs p, int ntiles) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool is_loader = wave == 4;
+  // contiguous run of tiles per workgroup (strip fastest: consecutive tiles share halo columns / rows in this XCD's L2)
+  const int wg = fx_xcd_remap(blockIdx.x, gridDim.x);
+  const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int t0 = wg * per, t1 = min(ntiles, t0 + per);
+  const int lds0 = (int)(unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+  auto coords = [&](int t, int& b, int& band, int& strip) {
+    strip = t % p.nstrips;
+    t /= p.nstrips;
+    band = t % p.nbands;
+    b = t / p.nbands;
+  };
+  if (is_loader) {
+    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 2 * 18 * 1024, 0x00020000);
+    for (int i = 0; i < 36; ++i) pw_dma16(wr, smem + SP2_WOFF + i * 1024, (unsigned)(i * 1024 + lane * 16));
+    int b, band, strip;
+    if (t0 < t1) {
+      coords(t0, b, band, strip);
+      sp_dma_tile(p, xr, smem, b, band, strip, lane, 0, 1);
+    }
+    for (int t = t0; t < t1; ++t) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();   // tile t has landed; the compute waves are done with tile t - 1 (the other buffer)
+      if (t + 1 < t1) {
+        coords(t + 1, b, band, strip);
+        sp_dma_tile(p, xr, smem + ((t + 1 - t0) & 1) * SP2_TILE, b, band, strip, lane, 0, 1);
+      }
+    }
+  } else {
+    for (int t = t0; t < t1; ++t) {
+      __syncthreads();
+      int b, band, strip;
+      coords(t, b, band, strip);
+      sp_compute_tile(p, lds0 + ((t - t0) & 1) * SP2_TILE, lds0 + SP2_WOFF, b, band, strip, wave, lane);
+    }
+  }
+}
+
 // 1 iff the fused launch covers the layer pair: conv 3x3 / s1 / p1 with 32 input and 64 output channels + ReLU, then max-pool 3x3 / s2 / p1
 extern "C" int fx_stem_conv_pool_supported(int C, int N, int H, int W) { return C == 32 && N == 64 && H >= 2 && W >= 2; }
 
@@ -197,12 +255,18 @@ extern "C" int fx_stem_conv3x3_relu_maxpool_bf16(const void* x, int ldx, const v
   a.x_bytes = (unsigned)x_bytes;
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_c3_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SP_SMEM) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_c3_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SP_SMEM) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(stem_c3_pool_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SP2_SMEM) != hipSuccess)
       return FX_ERR_RUNTIME;
     attr_set = true;
   }
   const int64_t grid = (int64_t)B * a.nbands * a.nstrips;
   if (grid >= (1ll << 31)) return FX_ERR_UNSUPPORTED;
+  static const int persist = fx_tune("FX_STEM_POOL_PERSIST", 1), wgs = fx_tune("FX_STEM_POOL_WGS", 256);
+  if (persist && grid > wgs) {
+    hipLaunchKernelGGL(stem_c3_pool_persist_kernel, dim3(wgs), dim3(320), SP2_SMEM, reinterpret_cast<hipStream_t>(stream_), a, (int)grid);
+    return fx_launch_status();
+  }
   hipLaunchKernelGGL(stem_c3_pool_kernel, dim3((int)grid), dim3(256), SP_SMEM, reinterpret_cast<hipStream_t>(stream_), a);
   return fx_launch_status();
 }
