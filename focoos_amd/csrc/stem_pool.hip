@@ -184,54 +184,101 @@ __global__ __launch_bounds__(256, 2) void stem_c3_pool_kernel(const StemPoolArgs
   sp_compute_tile(p, lds0, lds0 + SP_WOFF, b, band, strip, wave, lane);
 }
 
-// Form 2 (FX_STEM_POOL_PERSIST=1): persistent workgroups, one per CU, of four compute waves + a LOADER wave.  Form 1's workgroups live ~10 us
-// of which the first ~4 are the fetch of 77 KiB (weights again for every tile) before the first MFMA - two per CU overlap that only in part
-// (104 us per 16-image part for 35 us of MFMA work).  Here a workgroup walks a contiguous run of tiles; the weights are fetched once, the
-// loader wave DMAs tile i + 1 into the other of two tile buffers while the compute waves are on tile i; one barrier per tile.
-#define SP2_TILE (SP_NDMA * 1024)
-#define SP2_WOFF (2 * SP2_TILE)
-#define SP2_SMEM (SP2_WOFF + 36 * 1024)
-__global__ __launch_bounds__(320, 1) void stem_c3_pool_persist_kernel(const StemPoolArgs p, int ntiles) {
+// Form 2 (round 5, measured and REMOVED: profiles/r05_stem_pool_persistent_ab.txt): persistent workgroups, one per CU, four compute waves + a
+// loader wave double-buffering the tiles, weights fetched once per workgroup - 155 us per part against form 1's 101: with ONE wave per SIMD
+// nothing covers a wave's LDS / epilogue latencies; the kernel is bound by how many waves share a SIMD, not by the fetch at its start.
+//
+// Form 3: eight waves per workgroup - waves 0-3 compute channel block 0 of the tile, waves 4-7 block 1, from the same input tile - each with
+// ONE accumulator set (80 registers instead of 160): 128 registers per wave, so that two 77 KiB workgroups per CU are FOUR waves per SIMD.
+__device__ __forceinline__ void sp_compute_tile_half(const StemPoolArgs& p, int tile_lds, int w_lds, int a, int b, int band, int strip, int wave,
+                                                     int lane) {
+  const int l32 = lane & 31, half = lane >> 5;
+  int row0[5];
+#pragma unroll
+  for (int bb = 0; bb < 5; ++bb) row0[bb] = tile_lds + half * 2 * SP_PLANE + ((4 * wave + 1 + bb) * SP_TW + (l32 + 1)) * 16;
+  const int cx = 30 * strip - 1 + l32;
+  const bool col_ok = (unsigned)cx < (unsigned)p.W;
+  const int cy0 = 16 * band + 4 * wave - 1;
+  const int prow0 = 8 * band + 2 * wave;
+  const int pcol = 15 * strip + (l32 >> 1);
+  const bool store_lane = (l32 & 1) == 0 && l32 <= 28 && pcol < p.Wo;
+  const int waddr = w_lds + a * 18 * 1024 + lane * 16;
+  f32x16 acc[5];
+#pragma unroll
+  for (int gq = 0; gq < 4; ++gq) {
+    const float4 bb4 = *reinterpret_cast<const float4*>(p.bias + a * 32 + 8 * gq + 4 * half);
+#pragma unroll
+    for (int bb = 0; bb < 5; ++bb) {
+      acc[bb][4 * gq] = bb4.x; acc[bb][4 * gq + 1] = bb4.y; acc[bb][4 * gq + 2] = bb4.z; acc[bb][4 * gq + 3] = bb4.w;
+    }
+  }
+  typedef __attribute__((address_space(3))) const bf16x8 lds_frag_t;
+#pragma unroll
+  for (int s = 0; s < 18; ++s) {
+    const int toff = (((s >> 1) / 3 - 1) * SP_TW + ((s >> 1) % 3 - 1)) * 16 + (s & 1) * SP_PLANE;
+    const bf16x8 af = *reinterpret_cast<lds_frag_t*>((size_t)(unsigned)(waddr + s * 1024));
+    bf16x8 xf[5];
+#pragma unroll
+    for (int bb = 0; bb < 5; ++bb) xf[bb] = *reinterpret_cast<lds_frag_t*>((size_t)(unsigned)(row0[bb] + toff));
+#pragma unroll
+    for (int bb = 0; bb < 5; ++bb) acc[bb] = FX_MFMA_32x32x16(af, xf[bb], acc[bb]);
+    __builtin_amdgcn_sched_barrier(0);   // one k-step's six reads and five MFMAs at a time: four waves per SIMD cover the latency, not a deep
+                                         // per-wave prefetch (left free, the scheduler hoisted reads until 194 registers spilled at the 128 cap)
+  }
+#pragma unroll
+  for (int bb = 0; bb < 5; ++bb) {
+    const bool ok = col_ok && (unsigned)(cy0 + bb) < (unsigned)p.H;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[bb][e] = (ok && acc[bb][e] > 0.0f) ? acc[bb][e] : 0.0f;
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    unsigned pk[4][2];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq)
+#pragma unroll
+      for (int w2 = 0; w2 < 2; ++w2) {
+        const int e = 4 * gq + 2 * w2;
+        const float v0 = fmaxf(fmaxf(acc[2 * r][e], acc[2 * r + 1][e]), acc[2 * r + 2][e]);
+        const float v1 = fmaxf(fmaxf(acc[2 * r][e + 1], acc[2 * r + 1][e + 1]), acc[2 * r + 2][e + 1]);
+        unsigned d = pack_bf16x2(v0, v1);
+        const unsigned d1 = (unsigned)__builtin_amdgcn_ds_bpermute(((lane + 1) & 63) << 2, (int)d);
+        const unsigned d2 = (unsigned)__builtin_amdgcn_ds_bpermute(((lane + 2) & 63) << 2, (int)d);
+        pk[gq][w2] = sp_max_u16x2(sp_max_u16x2(d, d1), d2);
+      }
+    const int prow = prow0 + r;
+    bf16_t* yrow = p.y + ((size_t)(b * p.Ho + prow) * p.Wo + pcol) * p.ldy + a * 32 + half * 8;
+    const bool live = store_lane && prow < p.Ho;
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+      unsigned q0[2] = {pk[2 * g2][0], pk[2 * g2][1]}, q1[2] = {pk[2 * g2 + 1][0], pk[2 * g2 + 1][1]};
+#pragma unroll
+      for (int w2 = 0; w2 < 2; ++w2) {
+        const auto sw = __builtin_amdgcn_permlane32_swap(q0[w2], q1[w2], false, false);
+        q0[w2] = sw[0];
+        q1[w2] = sw[1];
+      }
+      if (live) *reinterpret_cast<uint4*>(yrow + g2 * 16) = make_uint4(q0[0], q0[1], q1[0], q1[1]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(512, 4) void stem_c3_pool8_kernel(const StemPoolArgs p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool is_loader = wave == 4;
-  // contiguous run of tiles per workgroup (strip fastest: consecutive tiles share halo columns / rows in this XCD's L2)
-  const int wg = fx_xcd_remap(blockIdx.x, gridDim.x);
-  const int per = (ntiles + (int)gridDim.x - 1) / (int)gridDim.x;
-  const int t0 = wg * per, t1 = min(ntiles, t0 + per);
+  int bid = fx_xcd_remap(blockIdx.x, gridDim.x);
+  const int strip = bid % p.nstrips;
+  bid /= p.nstrips;
+  const int band = bid % p.nbands, b = bid / p.nbands;
+  const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 2 * 18 * 1024, 0x00020000);
+  for (int i = wave; i < 36; i += 8) pw_dma16(wr, smem + SP_WOFF + i * 1024, (unsigned)(i * 1024 + lane * 16));
+  sp_dma_tile(p, xr, smem, b, band, strip, lane, wave, 8);
   const int lds0 = (int)(unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
-  auto coords = [&](int t, int& b, int& band, int& strip) {
-    strip = t % p.nstrips;
-    t /= p.nstrips;
-    band = t % p.nbands;
-    b = t / p.nbands;
-  };
-  if (is_loader) {
-    const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, 2 * 18 * 1024, 0x00020000);
-    for (int i = 0; i < 36; ++i) pw_dma16(wr, smem + SP2_WOFF + i * 1024, (unsigned)(i * 1024 + lane * 16));
-    int b, band, strip;
-    if (t0 < t1) {
-      coords(t0, b, band, strip);
-      sp_dma_tile(p, xr, smem, b, band, strip, lane, 0, 1);
-    }
-    for (int t = t0; t < t1; ++t) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();   // tile t has landed; the compute waves are done with tile t - 1 (the other buffer)
-      if (t + 1 < t1) {
-        coords(t + 1, b, band, strip);
-        sp_dma_tile(p, xr, smem + ((t + 1 - t0) & 1) * SP2_TILE, b, band, strip, lane, 0, 1);
-      }
-    }
-  } else {
-    for (int t = t0; t < t1; ++t) {
-      __syncthreads();
-      int b, band, strip;
-      coords(t, b, band, strip);
-      sp_compute_tile(p, lds0 + ((t - t0) & 1) * SP2_TILE, lds0 + SP2_WOFF, b, band, strip, wave, lane);
-    }
-  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  sp_compute_tile_half(p, lds0, lds0 + SP_WOFF, wave >> 2, b, band, strip, wave & 3, lane);
 }
 
 // 1 iff the fused launch covers the layer pair: conv 3x3 / s1 / p1 with 32 input and 64 output channels + ReLU, then max-pool 3x3 / s2 / p1
@@ -256,15 +303,15 @@ extern "C" int fx_stem_conv3x3_relu_maxpool_bf16(const void* x, int ldx, const v
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem_c3_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SP_SMEM) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(stem_c3_pool_persist_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SP2_SMEM) != hipSuccess)
+        hipFuncSetAttribute(reinterpret_cast<const void*>(stem_c3_pool8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SP_SMEM) != hipSuccess)
       return FX_ERR_RUNTIME;
     attr_set = true;
   }
   const int64_t grid = (int64_t)B * a.nbands * a.nstrips;
   if (grid >= (1ll << 31)) return FX_ERR_UNSUPPORTED;
-  static const int persist = fx_tune("FX_STEM_POOL_PERSIST", 1), wgs = fx_tune("FX_STEM_POOL_WGS", 256);
-  if (persist && grid > wgs) {
-    hipLaunchKernelGGL(stem_c3_pool_persist_kernel, dim3(wgs), dim3(320), SP2_SMEM, reinterpret_cast<hipStream_t>(stream_), a, (int)grid);
+  static const int eight = fx_tune("FX_STEM_POOL_8WAVE", 1);
+  if (eight) {
+    hipLaunchKernelGGL(stem_c3_pool8_kernel, dim3((int)grid), dim3(512), SP_SMEM, reinterpret_cast<hipStream_t>(stream_), a);
     return fx_launch_status();
   }
   hipLaunchKernelGGL(stem_c3_pool_kernel, dim3((int)grid), dim3(256), SP_SMEM, reinterpret_cast<hipStream_t>(stream_), a);
