@@ -971,3 +971,16 @@ def test_stem_conv_relu_maxpool_fused(lib, case, flat_small_shapes):
     check(lib.fx_maxpool3x3s2_nhwc_bf16(cd.data_ptr(), N, y2.data_ptr(), N, B, H, W, N, stream()), "maxpool")
     torch.cuda.synchronize()
     assert torch.equal(y2, y), (y2.float() - y.float()).abs().max()
+
+
+def test_stem_conv_relu_maxpool_fused_four_wave_form():
+    """The 4-wave form of the fused stem kernel (both channel blocks per wave, software-pipelined K loop; FX_STEM_POOL_8WAVE=0 - the routing
+    knob is read once per process, hence the subprocess): the same bit-exact parity cases as the default 8-wave form."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-q", "-x", "-k", "test_stem_conv_relu_maxpool_fused and not four_wave"],
+                       cwd=root, env=dict(os.environ, FX_STEM_POOL_8WAVE="0"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "6 passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
