@@ -209,7 +209,7 @@ def pmc_kernel_prefix(variant: str) -> str:
     m = re.match(r"conv_igemm<(\d+),(\d+),(\d+)", variant)
     if m:
         return f"conv_igemm_kernel<{m.group(1)},{m.group(2)},{m.group(3)},"
-    return {"row_chain": "row_chain_kernel", "score_head": "score_head_kernel", "stem_c3+pool": "stem_c3_pool_kernel"}.get(variant.split("<")[0], "")
+    return {"row_chain": "row_chain_kernel", "score_head": "score_head_kernel", "stem_c3+pool": "stem_c3_pool8_kernel", "stem_c1+c2": "stem12_kernel"}.get(variant.split("<")[0], "")
 
 
 def per_op_timing(eng, pl, args):

@@ -74,6 +74,7 @@ SIGNATURES = {
     "fx_stem_conv3x3s2": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "fx_resize_bilinear_u8": [_vp, _i, _i, _vp, _i, _i, _vp],
     "fx_maxpool3x3s2_nhwc_bf16": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "fx_stem_conv12_u8_bf16": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "fx_stem_conv_pool_supported": [_i, _i, _i, _i],
     "fx_stem_conv3x3_relu_maxpool_bf16": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "fx_avgpool2x2_nhwc_bf16": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],

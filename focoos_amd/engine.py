@@ -619,10 +619,20 @@ class _PlanBase:
         # and consumed from LDS; FX_PW_CHAIN=0 restores one launch per layer, FX_PW_CHAIN_MAX_STAGE limits the stages covered.
         use_chain = int(os.environ.get("FX_PW_CHAIN", "1")) != 0
         max_stage = int(os.environ.get("FX_PW_CHAIN_MAX_STAGE", "1"))  # res2 + res3: HBM-bound seams; res4 measured neutral (profiles/r02a)
-        c1 = self._new("conv1_1", B, (H + 1) // 2, (W + 1) // 2, 32)   # 3x3 / s2 / p1: ceil(H/2)
-        self._op(lib.fx_stem_conv3x3s2, self.input.data_ptr(), int(self.f32_input), e.stem_w.data_ptr(), e.stem_b.data_ptr(),
-                 e.px_mean.data_ptr(), e.px_inv_std.data_ptr(), c1.ptr, B, H, W, 32)
-        x = self.conv(c1, P[f"{bb}.conv1.conv1_2"], name="conv1_2", act="relu")
+        pc2 = P[f"{bb}.conv1.conv1_2"]
+        if os.environ.get("FX_STEM12_FUSE", "1") != "0" and not self.f32_input and pc2.wf is not None and pc2.N == 32:
+            # normalise + conv1_1 + conv1_2 in one launch from the uint8 batch (csrc/stem12.hip, round 5): the conv1_1 activation is never written
+            x = self._new("conv1_2", B, (H + 1) // 2, (W + 1) // 2, 32)
+            M2 = x.rows
+            self.meta[len(self.ops)] = {"kind": "conv", "variant": "stem_c1+c2", "flops": 2.0 * M2 * 32 * (27 + 288), "flops_executed": 2.0 * M2 * 32 * (32 * 1.29 + 288),
+                                        "bytes": 3.0 * B * H * W + 2.0 * M2 * 32 + 2.0 * 32 * 288, "name": "conv1_1+conv1_2", "M": M2, "N": 32, "K": 288}
+            self._op(lib.fx_stem_conv12_u8_bf16, self.input.data_ptr(), e.stem_w.data_ptr(), e.stem_b.data_ptr(), e.px_mean.data_ptr(), e.px_inv_std.data_ptr(),
+                     pc2.wf.data_ptr(), pc2.b.data_ptr(), x.ptr, x.ld, B, H, W)
+        else:
+            c1 = self._new("conv1_1", B, (H + 1) // 2, (W + 1) // 2, 32)   # 3x3 / s2 / p1: ceil(H/2)
+            self._op(lib.fx_stem_conv3x3s2, self.input.data_ptr(), int(self.f32_input), e.stem_w.data_ptr(), e.stem_b.data_ptr(),
+                     e.px_mean.data_ptr(), e.px_inv_std.data_ptr(), c1.ptr, B, H, W, 32)
+            x = self.conv(c1, pc2, name="conv1_2", act="relu")
         pc3 = P[f"{bb}.conv1.conv1_3"]
         if os.environ.get("FX_STEM_FUSE", "1") != "0" and pc3.wf is not None and lib.fx_stem_conv_pool_supported(x.C, pc3.N, x.H, x.W) == 1:
             # conv1_3 + ReLU + max-pool in one launch (csrc/stem_pool.hip, round 5): the [B,H/2,W/2,64] conv1_3 activation is never written

@@ -136,6 +136,14 @@ int fx_pw_chain_bf16(const fx_pw_chain_desc* d, fx_stream_t stream);
 int fx_stem_conv3x3s2(const void* x, int in_f32, const float* w, const float* bias, const float* mean,
                       const float* inv_std, void* y, int B, int H, int W, int Cout, fx_stream_t stream);
 
+/* The first TWO stem layers in one launch from uint8 images (ABI 7; csrc/stem12.hip): y = relu(conv1_2(relu(conv1_1((x - mean) * inv_std)))) with
+ * conv1_1 = fx_stem_conv3x3s2's layer (same w / bias / mean / inv_std tables) and conv1_2 = the 3x3 / s1 / p1 32 -> 32 layer given as its
+ * fragment-order weights (fx_conv_desc.w_frag, [18][64][8]) and f32 bias - ResNet.conv1's conv1_1, conv1_2 (focoos/nn/backbone/resnet.py:184-196)
+ * behind FAIDetr.forward's normalisation (fai_detr/modelling.py:1349).  x uint8 [B,H,W,3]; y bf16 [B,(H-1)/2+1,(W-1)/2+1,32] (pixel stride ldy).
+ * The [B,H/2,W/2,32] conv1_1 activation is never written; bit-identical to fx_stem_conv3x3s2 followed by fx_conv2d_nhwc_bf16 (act = ReLU). */
+int fx_stem_conv12_u8_bf16(const void* x_u8, const float* w1, const float* b1, const float* mean, const float* inv_std, const void* w2_frag,
+                           const float* b2, void* y, int ldy, int B, int H, int W, fx_stream_t stream);
+
 /* Processor.get_torch_batch resize (focoos/processor/base_processor.py:285-288):
  * F.interpolate(bilinear, align_corners=False) of one HWC uint8 image to [Ho,Wo,3] float32. */
 int fx_resize_bilinear_u8(const uint8_t* x, int H, int W, float* y, int Ho, int Wo, fx_stream_t stream);

@@ -984,3 +984,42 @@ def test_stem_conv_relu_maxpool_fused_four_wave_form():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_kernels.py"), "-q", "-x", "-k", "test_stem_conv_relu_maxpool_fused and not four_wave"],
                        cwd=root, env=dict(os.environ, FX_STEM_POOL_8WAVE="0"), capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "6 passed" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
+
+
+@pytest.mark.parametrize("hw", [(640, 640), (128, 160), (75, 94), (33, 130), (16, 16)])
+def test_stem_conv1_1_conv1_2_fused(lib, hw, flat_small_shapes):
+    """fx_stem_conv12_u8_bf16 (csrc/stem12.hip, round 5): normalise + conv1_1 + conv1_2 from the uint8 image in one launch - BIT-identical to
+    fx_stem_conv3x3s2 followed by fx_conv2d_nhwc_bf16 on the c32 kernel (same operand arithmetic, same K-slot assignment and accumulation order in
+    both layers) and equal to fp32 torch within the bf16 roundings; odd sizes (partial bands / strips, bottom / right zero padding of both layers)."""
+    H, W = hw
+    B = 2
+    g = torch.Generator().manual_seed(40 + H + W)
+    img = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    img[0, :, :, :] = (img[0].float() * torch.linspace(0.2, 1.0, W)[None, :, None]).to(torch.uint8)      # position-dependent content
+    W1 = torch.randn(32, 3, 3, 3, generator=g) * 0.2
+    b1 = torch.randn(32, generator=g) * 0.1
+    W2 = torch.randn(32, 32, 3, 3, generator=g) / math.sqrt(288) + torch.linspace(-0.03, 0.03, 9).view(1, 1, 3, 3)
+    b2 = torch.randn(32, generator=g) * 0.3 - 0.1
+    mean, std = torch.tensor([123.675, 116.28, 103.53]), torch.tensor([58.395, 57.12, 57.375])
+    xin = to_dev(img)
+    H1, W1_ = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    w1d, b1d, md, sd_ = to_dev(W1.permute(2, 3, 1, 0).contiguous()), to_dev(b1), to_dev(mean), to_dev(1.0 / std)
+    wf2 = frag_pack(W2.permute(0, 2, 3, 1).reshape(32, 288))
+    b2d = to_dev(torch.cat([b2, torch.zeros(96)]))
+    y = torch.full((B, H1, W1_, 32), float("nan"), dtype=torch.bfloat16, device=DEV)
+    check(lib.fx_stem_conv12_u8_bf16(xin.data_ptr(), w1d.data_ptr(), b1d.data_ptr(), md.data_ptr(), sd_.data_ptr(), wf2.data_ptr(), b2d.data_ptr(),
+                                     y.data_ptr(), 32, B, H, W, stream()), "stem12")
+    torch.cuda.synchronize()
+    got = y.float().cpu()
+    assert not torch.isnan(got).any()
+    # (1) the two launches it replaces: identical bits
+    c1 = torch.empty(B, H1, W1_, 32, dtype=torch.bfloat16, device=DEV)
+    check(lib.fx_stem_conv3x3s2(xin.data_ptr(), 0, w1d.data_ptr(), b1d.data_ptr(), md.data_ptr(), sd_.data_ptr(), c1.data_ptr(), B, H, W, 32, stream()))
+    torch.cuda.synchronize()
+    two = run_conv(lib, c1.float().cpu(), W2, b2, 1, "relu", frag=True)
+    assert torch.equal(bf(two), bf(got)), (two - got).abs().max()
+    # (2) fp32 torch with the engine's roundings (normalised input, both weights and the conv1_1 activation in bf16)
+    xn = bf((img.float() - mean) / std).float().permute(0, 3, 1, 2)
+    a1 = bf(F.relu(F.conv2d(xn, bf(W1).float(), b1, stride=2, padding=1))).float()
+    ref = F.relu(F.conv2d(a1, bf(W2).float(), b2, padding=1)).permute(0, 2, 3, 1)
+    assert (got - ref).abs().max() <= 1.2e-2 * ref.abs().max(), (got - ref).abs().max()
