@@ -30,6 +30,7 @@ struct Stem12Args {
   bf16_t* y;                // [B,H1,W1,32] (pixel stride ldy)
   int H, W, H1, W1, ldy;
   int nbands, nstrips;
+  unsigned x_bytes;
 };
 
 #define S12_TW 66                       // conv1_1 positions per tile row: 64 + 1 halo each side
@@ -61,20 +62,32 @@ __global__ __launch_bounds__(512, 4) void stem12_kernel(const Stem12Args p) {
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, 18 * 1024, 0x00020000);
     for (int i = wave; i < 18; i += 8) pw_dma16(wr, smem + S12_W_OFF + i * 1024, (unsigned)(i * 1024 + lane * 16));
   }
-  // ---- phase 0: normalised input tile -> LDS (element e of a row = pixel e / 3, channel e % 3)
+  // ---- phase 0: normalised input tile -> LDS (element e of a row = pixel e / 3, channel e % 3).  Thread = one element column e of all 21 rows: the
+  // pixel / channel split, the column validity and the normalisation constants are per-thread constants, a row costs one byte load (all 21 issued
+  // before the first is consumed) + convert + store.  (First form: a flat index per element - two integer divisions and 64-bit address arithmetic
+  // per byte, and load -> convert -> store per iteration: 111 us per part, VALU- and latency-bound in this phase.)
   {
-    const float m0 = p.mean[0], m1 = p.mean[1], m2 = p.mean[2], s0 = p.inv_std[0], s1 = p.inv_std[1], s2 = p.inv_std[2];
     bf16_t* tin = reinterpret_cast<bf16_t*>(smem + S12_IN_OFF);
-    for (int idx = tid; idx < S12_IN_ROWS * 400; idx += 512) {
-      const int row = idx / 400, e = idx - row * 400;
-      const int px = e / 3, c = e - px * 3;
-      const int gy = GY0 + row, gx = GX0 + px;
-      float v = 0.0f;
-      if (e < 399 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W) {
-        const float raw = (float)p.x[((size_t)(b * p.H + gy) * p.W + gx) * 3 + c];
-        v = (raw - (c == 0 ? m0 : (c == 1 ? m1 : m2))) * (c == 0 ? s0 : (c == 1 ? s1 : s2));
+    const __amdgpu_buffer_rsrc_t ir = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
+    const int e = tid;                                   // 400 of the 512 threads carry a column
+    const int px = e / 3, c = e - px * 3;
+    const int gx = GX0 + px;
+    const bool col_ok = e < 399 && (unsigned)gx < (unsigned)p.W;
+    const float mc = c == 0 ? p.mean[0] : (c == 1 ? p.mean[1] : p.mean[2]), sc = c == 0 ? p.inv_std[0] : (c == 1 ? p.inv_std[1] : p.inv_std[2]);
+    const unsigned coff = (unsigned)(gx * 3 + c);
+    unsigned raw[S12_IN_ROWS];
+#pragma unroll
+    for (int r = 0; r < S12_IN_ROWS; ++r) {
+      const int gy = GY0 + r;
+      const bool ok = col_ok && (unsigned)gy < (unsigned)p.H;
+      raw[r] = (unsigned)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(ir, ok ? (unsigned)((b * p.H + gy) * p.W * 3) + coff : FX_OOB, 0, 0);
+    }
+    if (e < 400) {
+#pragma unroll
+      for (int r = 0; r < S12_IN_ROWS; ++r) {
+        const bool ok = col_ok && (unsigned)(GY0 + r) < (unsigned)p.H;
+        tin[r * 400 + e] = f32_to_bf16(ok ? ((float)raw[r] - mc) * sc : 0.0f);
       }
-      tin[row * 400 + e] = f32_to_bf16(v);
     }
   }
   // ---- A fragments of conv1_1 (as stem_mfma_kernel builds them): channel = l32; slot j of the lane's 8 K values -> (image row, byte)
@@ -222,6 +235,7 @@ extern "C" int fx_stem_conv12_u8_bf16(const void* x_u8, const float* w1, const f
   a.nstrips = (a.W1 + 63) / 64;
   const int64_t grid = (int64_t)B * a.nbands * a.nstrips;
   if (grid >= (1ll << 31) || (int64_t)B * H * W * 3 >= (1ll << 31)) return FX_ERR_UNSUPPORTED;
+  a.x_bytes = (unsigned)((int64_t)B * H * W * 3);
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(stem12_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, S12_SMEM) != hipSuccess) return FX_ERR_RUNTIME;

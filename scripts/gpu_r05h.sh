@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5, call H: fused normalise + conv1_1 + conv1_2 kernel (stem12.hip): parity + A/B on the headline
-TAG=r05h
+TAG=r05i
 out=$PWD/gpurun_out/$TAG; mkdir -p $out
 export TMPDIR=/tmp
 timeout 300 python -m pytest tests/test_gpu_kernels.py -q -k "stem_conv1_1_conv1_2_fused" > $out/stem12_tests.txt 2>&1; echo "stem12 kernel tests rc=$?"; tail -6 $out/stem12_tests.txt | cut -c1-500
