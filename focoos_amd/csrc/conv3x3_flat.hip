@@ -354,6 +354,8 @@ int fx_launch_conv3x3_flat(const ConvArgs& c, const bf16_t* w_frag, hipStream_t 
   // register loads of one wave do not retire in order, so counted vmcnt waits over a mixed queue read stale fragments under load.)
   static const int kplane_on = fx_tune("FX_C3_KPLANE", 1);
   if (c.C == 32) return fx_launch_conv3x3_c32(c, w_frag, stream);
+  // round 5: the 64 -> 64 layers (res2 branch2b) on the LDS-resident-filter kernel (conv3x3_c64.hip)
+  if (fx_conv3x3_c64_supported(c.C, c.N, fx_c3_epilogue_mode(c.act, c.res != nullptr, c.res_after)) && !c.y_bstride) return fx_launch_conv3x3_c64(c, w_frag, stream);
   if (kplane_on && fx_conv3x3_kplane_supported(c.C, c.N, c.W)) return fx_launch_conv3x3_kplane(c, w_frag, stream);
   C3Args a;
   c3_fill(a, c, w_frag);

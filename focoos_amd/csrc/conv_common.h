@@ -67,5 +67,8 @@ int fx_launch_pw_kplane(const ConvArgs& c, const bf16_t* w_frag, hipStream_t str
 // conv3x3_c32.hip: 3x3 / s1 with 32 input channels (the ResNet-vd stem layers conv1_2 / conv1_3): one-chunk k-plane kernel, 4 waves, two per CU
 bool fx_conv3x3_c32_supported(int C, int N, int W, int mode);
 int fx_launch_conv3x3_c32(const ConvArgs& c, const bf16_t* w_frag, hipStream_t stream);
+// conv3x3_c64.hip: 3x3 / s1 with 64 input and 64 output channels, no residual (res2 branch2b): 2-D tiles, the whole filter LDS-resident (round 5)
+bool fx_conv3x3_c64_supported(int C, int N, int mode);
+int fx_launch_conv3x3_c64(const ConvArgs& c, const bf16_t* w_frag, hipStream_t stream);
 int fx_c3_epilogue_mode(int act, bool has_res, int res_after);  // epilogue variant (3x3 kernel: 0-3, 5; pointwise: 0, 1, 3-6), -1: none
 int fx_launch_pw_flat(const ConvArgs& c, const bf16_t* w_frag, hipStream_t stream);  // 1x1, C % 256 == 0, N % 256 == 0

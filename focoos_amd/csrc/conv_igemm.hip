@@ -408,7 +408,8 @@ extern "C" int fx_conv2d_variant(const fx_conv_desc* d, char* out, int cap) {
   switch (conv_route(d, a)) {
     case R_C3_FLAT: {   // the same decision fx_launch_conv3x3_flat takes
       static const int kplane_on = fx_tune("FX_C3_KPLANE", 1);
-      const char* fmt = d->C == 32 ? "conv3x3_c32<%d>" : ((kplane_on && fx_conv3x3_kplane_supported(d->C, d->N, d->W)) ? "conv3x3_kplane<%d>" : "conv3x3_flat<%d>");
+      const bool c64 = fx_conv3x3_c64_supported(d->C, d->N, fx_c3_epilogue_mode(d->act, d->residual != nullptr, d->residual_after_act)) && !d->y_batch_stride;
+      const char* fmt = d->C == 32 ? "conv3x3_c32<%d>" : (c64 ? "conv3x3_c64<%d>" : ((kplane_on && fx_conv3x3_kplane_supported(d->C, d->N, d->W)) ? "conv3x3_kplane<%d>" : "conv3x3_flat<%d>"));
       snprintf(out, cap, fmt, d->N);
       break;
     }

@@ -684,6 +684,10 @@ FLAT_CASES = [
     (2, 20, 24, 32, 32, "relu", False, 0),      # 32 input channels (conv3x3_c32.hip): conv1_2 class, several images per 512-pixel tile
     (1, 5, 320, 32, 64, "relu", False, 0),      # conv1_3 at the benchmark's width, M = 1600 (3 full tiles + a tail)
     (1, 3, 400, 32, 64, None, False, 32),       # MaskFormer's 400-wide stem: the 1344-row plane, strided input rows, no activation
+    # round 5: 64 -> 64 layers on the LDS-resident-filter kernel (conv3x3_c64.hip): 16 x 32 tiles - partial bands / strips, several images
+    (2, 33, 47, 64, 64, "relu", False, 8),
+    (1, 40, 200, 64, 64, None, False, 0),       # MaskFormer res2 width, no activation (the input-gradient form of the training graph)
+    (3, 16, 32, 64, 64, "relu", False, 0),      # exactly one tile per image
 ]
 
 
