@@ -137,7 +137,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_c64_kernel(const C64Args p) {
 
 // C = N = 64, 3x3 / s1 / p1, no residual, ReLU or no activation, contiguous batch
 bool fx_conv3x3_c64_supported(int C, int N, int mode) {
-  static const int on = fx_tune("FX_C3_C64", 1);
+  static const int on = fx_tune("FX_C3_C64", 0);   // OFF: measured 55-57 us per res2 layer against 52 us on conv3x3_kplane<2,2,1,4,608,LD=0> (profiles/r05_c64_ab.txt): one 149 KiB workgroup per CU = two waves per SIMD and a 152 KiB fetch in front of every tile
   return on && C == 64 && N == 64 && (mode == 0 || mode == 3);
 }
 
