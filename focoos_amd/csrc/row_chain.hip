@@ -118,12 +118,36 @@ __device__ __forceinline__ void rc_ln_tail(f32x16& acc, const fx_rc_stage& st, u
 // addresses per instruction: broadcasts).  A GEMM stage keeps its bias vector there (no global load per 32-channel pass).
 #define RC_SCRATCH 12288
 #define RC_RING 8    // weight fragments in flight per wave (16 measured the same: the stages are not waiting on this stream's round trips)
-__global__ __launch_bounds__(512, 4) void row_chain_kernel(const fx_rc_stage* __restrict__ prog, int nstages, int M, int bias_off, unsigned long long* dbg) {
+__global__ __launch_bounds__(512, 4) void row_chain_kernel(const fx_rc_stage* __restrict__ prog, int nstages, int M, int bias_off, unsigned long long* dbg,
+                                                              int prefetch) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* biasL = reinterpret_cast<float*>(smem + bias_off);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int m0 = blockIdx.x * 32;
 
+  // Weight prefetch into this XCD's L2 (round 5).  scripts/dev/rc_scaling_probe.py: ONE 32-row workgroup alone on an idle chip takes the same 37 us
+  // for the post-MSDA chain as 150 together (41 us) - the chain is not bound by anything the workgroups share but by its own dependency chain:
+  // a 128 KiB GEMM stage is two ring-fulls per wave = two exposed round trips to wherever the weights live, and a decoder's 14 MB of weights do
+  // not live in a 4 MiB L2 from one launch to the next (5.4-6.7 k cycles per such stage for 0.5 k cycles of MFMA work).  So at kernel start the
+  // workgroups of an XCD (blockIdx % 8: they share one L2) split ALL GEMM weights of the program among themselves and touch them - ~100 KiB each at
+  // 150 workgroups - into one throw-away register, wait once, and every stage's ring then fills from L2.
+  if (prefetch) {
+    const int lane = threadIdx.x & 63;
+    const int wg_in_xcd = blockIdx.x >> 3, n_in_xcd = ((int)gridDim.x - (int)(blockIdx.x & 7) + 7) >> 3;
+    bf16x8 sink = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int si = 0; si < nstages; ++si) {
+      const fx_rc_stage st = prog[si];
+      int chunks = 0;   // 1 KiB pieces (one wave instruction each) of the stage's fragment-order weights
+      if (st.type == RC_GEMM) chunks = (st.N * st.K) >> 9;
+      else if (st.type == RC_GEMM_LN) chunks = (256 * st.K) >> 9;
+      else if (st.type == RC_FFN_LN) chunks = (st.N * 256) >> 9;
+      for (int c = wg_in_xcd + n_in_xcd * wave; c < chunks; c += n_in_xcd * 8) {
+        rc_ldg_async(sink, st.w, (unsigned)(c * 1024 + lane * 16));
+        if (st.type == RC_FFN_LN) rc_ldg_async(sink, st.g1, (unsigned)(c * 1024 + lane * 16));
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink));
+  }
   if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[0] = __builtin_amdgcn_s_memtime();
   for (int si = 0; si < nstages; ++si) {
     // The lane id is made opaque PER STAGE: every per-lane address constant of a stage is derived from it inside the loop body, so the
@@ -497,7 +521,8 @@ extern "C" int fx_row_chain(const fx_rc_stage* program_device, int n_stages, int
   // diagnostic (scripts/dev/rc_stage_stamps.py): FX_RC_DBG = address of a device buffer of 64 x u64 that receives the s_memtime stamps of
   // workgroup 0 at every stage boundary; unset (the product): null, the kernel skips the stamps
   static unsigned long long* const dbg = reinterpret_cast<unsigned long long*>((uintptr_t)strtoull(getenv("FX_RC_DBG") ? getenv("FX_RC_DBG") : "0", nullptr, 0));
+  static const int prefetch = fx_tune("FX_RC_PREFETCH", 1);
   hipLaunchKernelGGL(row_chain_kernel, dim3((rows + 31) / 32), dim3(512), lds_bytes + RC_SCRATCH, reinterpret_cast<hipStream_t>(stream_), program_device, n_stages,
-                     rows, lds_bytes, dbg);
+                     rows, lds_bytes, dbg, prefetch);
   return fx_launch_status();
 }
