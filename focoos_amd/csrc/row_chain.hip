@@ -521,7 +521,7 @@ extern "C" int fx_row_chain(const fx_rc_stage* program_device, int n_stages, int
   // diagnostic (scripts/dev/rc_stage_stamps.py): FX_RC_DBG = address of a device buffer of 64 x u64 that receives the s_memtime stamps of
   // workgroup 0 at every stage boundary; unset (the product): null, the kernel skips the stamps
   static unsigned long long* const dbg = reinterpret_cast<unsigned long long*>((uintptr_t)strtoull(getenv("FX_RC_DBG") ? getenv("FX_RC_DBG") : "0", nullptr, 0));
-  static const int prefetch = fx_tune("FX_RC_PREFETCH", 1);
+  static const int prefetch = fx_tune("FX_RC_PREFETCH", 0);   // OFF: serial 0.92 -> 0.81 ms per RT-DETR step but +0.3 % on the two-queue headline and -2 % on BiSeNetFormer (profiles/r05_rc_prefetch_ab.txt)
   hipLaunchKernelGGL(row_chain_kernel, dim3((rows + 31) / 32), dim3(512), lds_bytes + RC_SCRATCH, reinterpret_cast<hipStream_t>(stream_), program_device, n_stages,
                      rows, lds_bytes, dbg, prefetch);
   return fx_launch_status();
