@@ -168,6 +168,37 @@ _REGISTRY = {
 }
 
 
+def _reference_class_names(name: str, n: int) -> Optional[List[str]]:
+    """Label names of a registry model: they are DATA of the reference's registry (focoos/model_registry/<name>.json, "classes"),
+    not shipped here - where an installed focoos is importable (the integration use) they are read from ITS file (located with find_spec:
+    the package is not imported), so ``FocoosDet.label`` and the ``model_info.json`` a training run writes carry the reference's names; without
+    it the entries keep ``class_<i>``.  A file whose list has another length than the head is ignored."""
+    import importlib.util
+
+    import sys
+
+    roots: List[str] = []
+    mod = sys.modules.get("focoos")
+    if mod is not None:
+        roots = [str(r) for r in getattr(mod, "__path__", [])]
+    else:
+        try:
+            spec = importlib.util.find_spec("focoos")
+            roots = list(spec.submodule_search_locations) if spec is not None and spec.submodule_search_locations else []
+        except (ImportError, ValueError, AttributeError):
+            roots = []
+    for root in roots:
+        path = os.path.join(root, "model_registry", f"{name}.json")
+        if os.path.isfile(path):
+            try:
+                with open(path, encoding="utf-8") as f:
+                    names = json.load(f).get("classes")
+            except (OSError, ValueError):
+                return None
+            return [str(c) for c in names] if isinstance(names, list) and len(names) == n else None
+    return None
+
+
 class ModelRegistry:
     """Mirror of focoos/model_registry/model_registry.py for the engine's entries."""
 
@@ -183,7 +214,11 @@ class ModelRegistry:
     def get_model_info(cls, name: str) -> Dict:
         """model_registry.py:50-71: a registry name, or the path of a ``model_info.json`` (a fine-tuned model's own description)."""
         if name in _REGISTRY:
-            return copy.deepcopy(_REGISTRY[name])
+            d = copy.deepcopy(_REGISTRY[name])
+            names = _reference_class_names(name, len(d["classes"]))
+            if names is not None:
+                d["classes"] = names
+            return d
         if not os.path.exists(name):
             raise ValueError(f"⚠️ Model {name} not found. Available models: {cls.list_models()}")
         with open(name, encoding="utf-8") as f:

@@ -377,3 +377,18 @@ def test_adapters_have_no_stock_graph_fallback():
 
     src = inspect.getsource(fx)
     assert "super().forward" not in src
+
+
+def test_registry_serves_the_reference_label_names_when_focoos_is_installed():
+    """`classes` of a registry entry = the reference registry file's list (read from the installed package's own JSON, located without
+    importing it), so FocoosDet.label and a training run's model_info.json carry 'person' / 'wall' ... - placeholders only where no focoos exists."""
+    import json
+    import os
+
+    ref_import.install()
+    from focoos_amd.registry import ModelRegistry
+
+    for name in ModelRegistry.list_models():
+        ref = json.load(open(os.path.join(ref_import.REFERENCE_ROOT, "focoos", "model_registry", f"{name}.json")))
+        got = ModelRegistry.get_model_info(name)
+        assert got["classes"] == ref["classes"] and len(got["classes"]) == int(got["config"]["num_classes"]), name
