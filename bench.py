@@ -36,6 +36,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--train-graphs", default=None, choices=["auto", "0", "1"],
+                    help="--train: eager launches (0), hipGraph replays (1), or both timed during warm-up and the faster kept (auto, default; FX_TRAIN_GRAPH overrides the default)")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU per step (default 32; 16 for fai-mf-*)")
     ap.add_argument("--size", type=int, default=None, help="square input size (default 640; 800 for fai-mf-*)")
     ap.add_argument("--train", action="store_true",
@@ -375,7 +377,10 @@ def train_measure(args, world, rank, local, with_roofline=True):
         model = FAIMaskFormerTrainable(cfg, norm=args.norm).to(dev)
     model.load_state_dict(synth_state_dict(cfg, 0, family=args.family), strict=True)
     model.train()
-    stepper = TrainStep(model)
+    graphs_mode = getattr(args, "train_graphs", None) or os.environ.get("FX_TRAIN_GRAPH", "auto")
+    stepper = TrainStep(model, graphs=graphs_mode)
+    if str(graphs_mode).lower() == "auto":
+        args.warmup = max(args.warmup, 8)   # TrainStep's own eager / replay comparison takes steps 1-7 (train_detr.TrainStep.__init__): outside the timed region
     imgs = torch.stack([torch.from_numpy(synth_image(rank * B + i, S, S)) for i in range(B)]).to(dev)
 
     def targets(it):
@@ -423,6 +428,7 @@ def train_measure(args, world, rank, local, with_roofline=True):
             "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": dtype, "data": "synthetic",
             "config": {"steps_are": "hipGraph replays (forward graph, backward graph) around an eager criterion + optimizer" if stepper_graphs.on else "eager launches",
+                       "graphs": {"mode": str(graphs_mode), "choice": stepper.graph_choice},   # auto: both forms timed during the warm-up steps, the faster one kept
                        "workload": f"{args.model} training step: forward (train mode, norm={args.norm}) + {crit} "
                                    f"+ backward + gradient all-reduce + fused AdamW/clip, bs={B}/GPU, {S}x{S}, {dtype} activations and gradients"
                                    + (" (fp16 MFMA; dynamic loss scale as torch.amp.GradScaler: init 2**10, unscale / skip-on-inf / scale update "

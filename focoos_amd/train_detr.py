@@ -465,7 +465,16 @@ class TrainStep:
         # the weight-gradient side stream buys the eager step 3.5 ms of overlap but the replayed graph only 1.2 ms (the runtime runs the
         # forked branches of one graph with less concurrency than two live queues).  The capture removes ~20 ms of host work per step,
         # which matters only where the host is the bottleneck (many ranks per host, slow cores).
-        self.use_graphs = bool(int(os.environ.get("FX_TRAIN_GRAPH", "0"))) if graphs is None else bool(graphs)
+        # "auto" (round 5): which of the two wins depends on the BOX (one collection: eager 26.7 ms / replay 24.9 ms where the host cores
+        # are slow, profiles/r05z_train*_bench.json; another: eager 23.4 / replay slower), so the step can time both itself: steps 1-2 eager
+        # (lazy packing), 3-4 eager timed, 5 capture + first replay, 6-7 replay timed, then the faster form stays.  One rank only: under data
+        # parallelism the eager step stays (its all-reduce overlaps the backward; a replayed backward cannot launch collectives from hooks).
+        mode = os.environ.get("FX_TRAIN_GRAPH", "0") if graphs is None else graphs
+        self._auto, self.graph_choice = None, None
+        if isinstance(mode, str) and mode.strip().lower() == "auto":
+            self.use_graphs, self._auto = False, {"phase": 0, "n": 0}
+        else:
+            self.use_graphs = bool(int(mode)) if isinstance(mode, str) else bool(mode)
         self._graph_state, self._eager_steps = None, 0
 
         from .train import dp_segment_of as seg_of
@@ -667,8 +676,50 @@ class TrainStep:
         cur.wait_stream(self.stream)
         return losses
 
+    def _auto_tick(self, images: torch.Tensor) -> None:
+        """State machine of graphs="auto", called before every step (see __init__)."""
+        import time
+
+        import torch.distributed as dist
+
+        a = self._auto
+        # one rank only: under data parallelism the eager step's all-reduce overlaps the backward (hooks), the replayed one's cannot
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        applicable = images.is_cuda and not multi and not any(getattr(m, "norm_mode", None) == "SyncBN" for m in self.model.modules())
+        key = (tuple(images.shape), images.dtype)
+        if not applicable or a.setdefault("key", key) != key:   # CPU / SyncBN / changing shapes: the eager step
+            self.use_graphs, self._auto, self._graph_state = False, None, None
+            self.graph_choice = {"graphs": False, "why": "not applicable"}
+            return
+        dev = images.device
+
+        def now():
+            torch.cuda.synchronize(dev)
+            return time.perf_counter()
+
+        if a["phase"] == 0 and self._eager_steps >= 2:
+            a.update(phase=1, n=0, t0=now())
+        elif a["phase"] == 1 and a["n"] == 2:
+            a["eager_ms"] = (now() - a["t0"]) * 500.0
+            self.use_graphs = True
+            a.update(phase=2, n=0)
+        elif a["phase"] == 2 and a["n"] == 1:
+            a.update(phase=3, n=0, t0=now())
+        elif a["phase"] == 3 and a["n"] == 2:
+            a["graph_ms"] = (now() - a["t0"]) * 500.0
+            eager_ms, graph_ms = a["eager_ms"], a["graph_ms"]
+            self.use_graphs = graph_ms < 0.98 * eager_ms
+            self.graph_choice = {"graphs": self.use_graphs, "eager_ms": round(eager_ms, 3), "graph_ms": round(graph_ms, 3)}
+            if not self.use_graphs:
+                self._graph_state = None   # gives the private pool back
+            self._auto = None
+            return
+        a["n"] += 1
+
     def _step(self, images: torch.Tensor, targets: Sequence) -> Dict[str, torch.Tensor]:
         nn_ = self._nn
+        if self._auto is not None:
+            self._auto_tick(images)
         if self._graphs_applicable(images) and self._eager_steps >= 2:   # two eager steps first: lazy packing + first-use kernel attributes, then the packer's device table
             if self.scheduler is not None:
                 from .train_data import lr_factor

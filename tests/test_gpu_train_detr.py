@@ -283,6 +283,45 @@ def test_train_step_graph_equals_eager(norm):
         assert abs(float(l_graph.sum() - l_eager.sum())) <= 3e-2 * float(l_eager.sum()), (l_graph, l_eager)
 
 
+def test_train_step_graphs_auto_times_both_forms_and_keeps_one():
+    """TrainStep(graphs="auto"): steps 1-4 eager (3-4 timed), step 5 captures, 6-7 replay timed, step 8 keeps the faster form and records both
+    timings; the losses of every step stay those of an eager-only stepper on the same batches (lr = 0, FrozenBN: same kernels, same order).
+    A batch of another shape during the comparison ends it: the eager step stays."""
+    from focoos_amd.train_detr import FAIDetrTrainable, TrainStep
+
+    cfg = ModelRegistry.get_model_info("fai-detr-l-coco")["config"]
+    sd = synth_state_dict(cfg, 8)
+    B = 2
+
+    def batch(it, hw=(160, 192)):
+        imgs = torch.from_numpy(np.stack([synth_image_structured(500 + it * B + i, *hw) for i in range(B)])).to(DEV)
+        labels, boxes = T.synth_targets(90 + it, B, 80, counts=tuple(1 + (i + it) % 5 for i in range(B)))
+        return imgs, [DETRTargets(labels=l.to(DEV), boxes=b.to(DEV)) for l, b in zip(labels, boxes)]
+
+    def vec(losses):
+        return torch.stack([losses[k].detach().float() for k in sorted(losses)]).cpu()
+
+    out = {}
+    for mode in ("auto", False):
+        model = FAIDetrTrainable(cfg, norm="FrozenBN").to(DEV)
+        model.load_state_dict(sd, strict=True)
+        ts = TrainStep(model, lr=0.0, weight_decay=0.0, graphs=mode)
+        out[mode] = [vec(ts.step(*batch(it))) for it in range(9)]
+        torch.cuda.synchronize()
+        if mode == "auto":
+            c = ts.graph_choice
+            assert ts._auto is None and c is not None and c["eager_ms"] > 0 and c["graph_ms"] > 0, c
+            assert c["graphs"] == (c["graph_ms"] < 0.98 * c["eager_ms"]) == ts.use_graphs == (ts._graph_state is not None), c
+    for it, (a, b) in enumerate(zip(out["auto"], out[False])):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-6), (it, a, b)
+    model = FAIDetrTrainable(cfg, norm="FrozenBN").to(DEV)
+    model.load_state_dict(sd, strict=True)
+    ts = TrainStep(model, lr=0.0, weight_decay=0.0, graphs="auto")
+    for it in range(4):
+        ts.step(*batch(it, (160, 192) if it != 3 else (192, 192)))
+    assert ts._auto is None and ts.use_graphs is False and ts.graph_choice == {"graphs": False, "why": "not applicable"}
+
+
 def test_encoder_heads_on_selected_rows_equal_all_rows():
     """TransformerPredictor runs the encoder's score / box heads (and enc_output) on the 300 selected rows of an image, with the selection
     scores of all tokens from the inference plan's fused launch; the reference computes both heads over all tokens and gathers
