@@ -422,8 +422,8 @@ class _PlanBase:
     size_multiple = 32
 
     def __init__(self, eng: _EngineBase, B: int, H: int, W: int, f32_input: bool, parent: Optional["_MultiPlan"] = None, index: int = 0):
-        # RT-DETR runs at its configured square resolution (DETRProcessor.preprocess resizes, fai_detr/processor.py:66-119): multiples of 32.
-        # The mask families run at the image's own size (size_divisibility 0) with ceil(H/2) at every stride-2 layer: size_multiple = 1.
+        # Every family runs at the image's own size with ceil(H/2) at every stride-2 layer (size_multiple = 1 in all three plans; the class
+        # default stays 32 for plans that do not say otherwise).
         if H % self.size_multiple or W % self.size_multiple or H < 32 or W < 32:
             raise _lib.FocoosAmdError(f"input height/width must be multiples of {self.size_multiple} (and at least 32)")
         self.eng, self.B, self.H, self.W, self.f32_input = eng, B, H, W, f32_input
@@ -734,6 +734,8 @@ class _PlanBase:
 class _Plan(StdcPlanMixin, _PlanBase):
     """RT-DETR launch sequence."""
 
+    size_multiple = 1   # round 5: any size >= 32 with enough tokens for the query selection (ragged training batches are padded to the batch maximum)
+
     # -------------------------------------------------------------- the network
     def _build(self):
         e, P, B, lib = self.eng, self.eng.P, self.B, self.lib
@@ -742,7 +744,11 @@ class _Plan(StdcPlanMixin, _PlanBase):
         fd = e.fd
         # ---- hybrid encoder (modelling.py:297-347)
         pd = "pixel_decoder"
-        h8, w8, h16, w16, h32, w32 = H // 8, W // 8, H // 16, W // 16, H // 32, W // 32
+        # level sizes = what the backbone produced (ceil(H/2) at every stride-2 layer, like the reference's: any H, W >= 32 - the reference's
+        # encoder resizes with F.interpolate(size=...) in both directions, modelling.py:334,342, so nothing here needs multiples of 32)
+        (h8, w8), (h16, w16), (h32, w32) = ((feats[k].H, feats[k].W) for k in (3, 4, 5))
+        if h8 * w8 + h16 * w16 + h32 * w32 < e.nq:   # the reference's torch.topk raises "selected index k out of range" (modelling.py:1219)
+            raise _lib.FocoosAmdError(f"input {H}x{W} gives {h8 * w8 + h16 * w16 + h32 * w32} encoder tokens, fewer than the {e.nq} queries to select")
         cat80 = self._new("cat80", B, h8, w8, 2 * fd)     # [up(lat1) | proj(res3)]
         cat40a = self._new("cat40a", B, h16, w16, 2 * fd)  # [up(lat0) | proj(res4)]
         cat40b = self._new("cat40b", B, h16, w16, 2 * fd)  # [downconv0 | lat1]

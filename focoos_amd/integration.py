@@ -34,13 +34,12 @@ def _fx_version_key(module) -> tuple:
         tuple(p.data_ptr() for p in module.parameters())
 
 
-def _require_engine_input(images, size_multiple: int = 32) -> None:
+def _require_engine_input(images, size_multiple: int = 1) -> None:
     """The adapters NEVER run the reference's stock PyTorch graph (a result produced that way says nothing about the engine):
-    inputs the engine has no plan for are refused loudly.  That is (i) for RT-DETR, H or W not a multiple of 32 (``size_multiple``): its
-    processor resizes every image to the configured square resolution (fai_detr/processor.py:66-119), the engine has no plan for anything
-    else; the mask families run at the image's own size with the reference's ceil(H/2) arithmetic at every level (``size_multiple`` 1,
-    tests/test_gpu_odd_sizes.py) - and (ii) a gradient with respect to the input images.  CPU tensors are refused by the engine itself
-    (FocoosAmdError: no CPU path)."""
+    inputs the engine has no plan for are refused loudly.  That is (i) H or W below 32 (all three families run at the image's own size
+    with the reference's ceil(H/2) arithmetic at every level - tests/test_gpu_odd_sizes.py; RT-DETR since round 5: ragged training batches
+    are padded to the batch maximum, not to a multiple of 32, and the reference accepts them) - and (ii) a gradient with respect to the
+    input images.  CPU tensors are refused by the engine itself (FocoosAmdError: no CPU path)."""
     from ._lib import FocoosAmdError
 
     if images.dim() != 4:
@@ -195,7 +194,7 @@ def make_engine_class():
             return g[0]
 
         def forward(self, images, targets=[]):
-            _require_engine_input(images)   # raises: no fallback to the reference's own graph
+            _require_engine_input(images)   # raises for < 32 / input gradients: no fallback to the reference's own graph
             x = images
             if x.dim() == 4 and x.shape[1] == 3 and x.shape[-1] != 3:
                 x = x.permute(0, 2, 3, 1)

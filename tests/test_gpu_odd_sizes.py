@@ -1,4 +1,4 @@
-"""Input sizes that are NOT multiples of 32 through the mask families' engines (VERDICT r3 missing #5 / next #10).
+"""Input sizes that are NOT multiples of 32 through the engines (mask families: VERDICT r3 missing #5 / next #10; RT-DETR: round 5).
 
 The reference hands such images over at their own size (``size_divisibility`` 0; fai_mf/processor.py:96, bisenetformer/processor.py:96)
 and every stride-2 layer produces ceil(H/2): 3x3/s2/p1 convolutions and the 3x3/s2/p1 max-pool (nn/backbone/resnet.py:184-196,254),
@@ -213,16 +213,61 @@ def test_model_manager_surface_at_odd_size(name):
             assert 0 <= x0 <= x1 < w and 0 <= y0 <= y1 < h and det.mask is not None
 
 
-def test_detr_still_needs_multiples_of_32():
-    """RT-DETR runs at its configured square resolution (DETRProcessor.preprocess resizes: fai_detr/processor.py:66-119); the engine refuses
-    anything else loudly instead of guessing."""
+@pytest.mark.parametrize("hw", [(200, 232), (250, 188), (330, 270)])
+def test_detr_odd_size_matches_oracle(hw):
+    """RT-DETR at sizes that are not multiples of 32 (round 5, ADVICE r4: ragged training batches are padded to the batch maximum and the
+    reference accepts them - its encoder resizes with F.interpolate(size=...) in both directions, modelling.py:334,342): levels of
+    ceil(H/8) / ceil(H/16) / ceil(H/32) rows, anchors / valid mask / sampling shapes from those, teacher-forced on the oracle's query
+    selection (at these sizes many anchors are invalid and tie at the masked score; the oracle equals the real reference here when given
+    the reference's selection: tests/test_oracle_vs_reference.py::test_detr_odd_sizes_oracle_matches_reference_live).  Gates of
+    tests/test_gpu_e2e.py::test_stage_parity_teacher_forced."""
+    from focoos_amd.engine import DetrEngine
+    from oracle import detr_oracle as O
+
+    cfg = ModelRegistry.get_model_info("fai-detr-l-coco")["config"]
+    sd = synth_state_dict(cfg, 17)
+    imgs = [synth_image_structured(5 + i, *hw) for i in range(2)]
+    col = {}
+    with torch.no_grad():
+        probs_o, boxes_o = O.detr_forward(sd, cfg, get_torch_batch(imgs, hw), collect=col)
+    eng = DetrEngine(cfg, sd, device=DEV)
+    x = torch.from_numpy(np.stack(imgs)).to(DEV)
+    pl = eng.forward(x, forced_topk=col["topk_ind"].long(), use_graph=False)
+    torch.cuda.synchronize()
+    for k in ("res3", "res4", "res5", "enc_s32", "enc_s16", "enc_s8"):
+        assert tuple(nchw(pl.bufs[k]).shape) == tuple(col[k].shape), (k, nchw(pl.bufs[k]).shape, col[k].shape)
+        e = rel_l2(nchw(pl.bufs[k]), col[k])
+        assert e < 2e-2, (k, e)
+    assert rel_l2(pl.bufs["memory"].t.float().cpu().view(2, -1, 256), col["memory"]) < 2e-2
+    for i in range(6):
+        e = rel_l2(pl.bufs[f"dec{i}.out"].t.float().cpu().view(2, 300, 256), col[f"dec{i}_out"])
+        assert e < 4e-2, (i, e)
+    assert (pl.probs.cpu() - probs_o).abs().max().item() <= 2.5e-2
+    assert (pl.boxes.cpu() - boxes_o).abs().max().item() <= 7e-3
+    # free-running (graph replay, no teacher forcing): the same plan, finite outputs, selection overlapping the oracle's among the tokens
+    # whose score is off the masked value (ties among invalid anchors are broken arbitrarily by both)
+    pl2 = eng.forward(x)
+    torch.cuda.synchronize()
+    assert torch.isfinite(pl2.probs).all() and torch.isfinite(pl2.boxes).all()
+    sc = col["enc_scores"]
+    for b in range(2):
+        thr = sc[b].topk(300).values[-1]
+        sure = set(torch.nonzero(sc[b] > thr + 0.2).flatten().tolist())
+        assert sure <= set(pl2.enc_topk[b].cpu().tolist())
+
+
+def test_detr_refuses_inputs_with_fewer_tokens_than_queries():
+    """64 x 64 gives 8*8 + 4*4 + 2*2 = 84 encoder tokens for 300 queries: the reference's torch.topk raises ("selected index k out of
+    range", modelling.py:1219); the engine raises its own error instead of selecting out of range."""
     from focoos_amd import _lib
     from focoos_amd.engine import DetrEngine
 
     cfg = ModelRegistry.get_model_info("fai-detr-l-coco")["config"]
     eng = DetrEngine(cfg, synth_state_dict(cfg, 3), device=DEV)
+    with pytest.raises(_lib.FocoosAmdError, match="fewer than the 300 queries"):
+        eng.forward(torch.zeros(1, 64, 64, 3, dtype=torch.uint8, device=DEV))
     with pytest.raises(_lib.FocoosAmdError):
-        eng.forward(torch.zeros(1, 150, 200, 3, dtype=torch.uint8, device=DEV))
+        eng.forward(torch.zeros(1, 20, 200, 3, dtype=torch.uint8, device=DEV))
 
 
 @pytest.mark.parametrize("name", ["fai-mf-l-coco-ins", "bisenetformer-l-ade", "bisenetformer-m-ade", "fai-mf-m-ade"])

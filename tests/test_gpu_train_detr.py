@@ -21,10 +21,12 @@ from tests.helpers import rel_l2  # noqa: E402
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("norm", ["FrozenBN", "BN"])
-def test_detr_train_step_losses_and_gradients(norm):
+@pytest.mark.parametrize("norm,size", [("FrozenBN", None), ("BN", None), ("FrozenBN", (150, 200))])
+def test_detr_train_step_losses_and_gradients(norm, size):
     """norm="FrozenBN": BatchNorm on running statistics (freeze_bn); norm="BN": batch statistics + trainable affine +
-    running-statistics update (the reference under plain .train()); the oracle is pinned against the reference in both."""
+    running-statistics update (the reference under plain .train()); the oracle is pinned against the reference in both.
+    size (150, 200): not a multiple of 32 (round 5: a ragged training batch padded to its maximum) - ceil(H/2) levels in the forward and
+    in every adjoint (partial AvgPool2d(ceil_mode) windows, bilinear resizes between levels of non-integer ratio)."""
     from focoos_amd.train_detr import FAIDetrTrainable
 
     cfg = ModelRegistry.get_model_info("fai-detr-l-coco")["config"]
@@ -32,7 +34,7 @@ def test_detr_train_step_losses_and_gradients(norm):
     k_qk = "pixel_decoder.encoder.0.layers.0.self_attn.in_proj_weight"  # see tests/test_gpu_train_conv.py: keep AIFI logits O(1)
     sd[k_qk] = sd[k_qk].clone()
     sd[k_qk][:512] *= 0.05
-    nimg, (ih, iw) = (4, (160, 192)) if norm == "BN" else (2, (128, 160))   # batch statistics want more than 40 samples at stride 32
+    nimg, (ih, iw) = (4, (160, 192)) if norm == "BN" else (2, size or (128, 160))   # batch statistics want more than 40 samples at stride 32
     imgs = [synth_image_structured(80 + i, ih, iw) for i in range(nimg)]
     labels, boxes = T.synth_targets(2, nimg, 80, counts=(4, 6, 2, 5))
     # ---- oracle (free-running; its discrete choices are then forced on the engine)

@@ -170,6 +170,66 @@ def test_odd_sizes_oracle_matches_reference_live(name):
         assert (masks - out.masks).abs().max().item() < 5e-3
 
 
+def test_detr_odd_sizes_oracle_matches_reference_live():
+    """RT-DETR at inputs that are not multiples of 32 (ragged training batches are padded to the batch maximum; the reference's encoder
+    resizes with F.interpolate(size=...) in both directions, modelling.py:334,342): the encoder levels of the restatement equal the real
+    reference's at 200x232, 250x188 and 208x272, and with the reference's own query selection so do the outputs (free-running the two
+    may pick different tokens among the INVALID anchors, which all carry the same masked score - torch.topk's order among ties is
+    unspecified).  What tests/test_gpu_odd_sizes.py::test_detr_odd_size_matches_oracle compares the engine with."""
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.synth import synth_image_structured, synth_state_dict
+    from oracle import detr_oracle as O
+
+    ref_import.install()
+    from focoos.model_manager import ConfigManager
+    from focoos.models.fai_detr.modelling import FAIDetr
+    from focoos.ports import ModelFamily
+
+    cfg = ModelRegistry.get_model_info("fai-detr-l-coco")["config"]
+    model = FAIDetr(ConfigManager.from_dict(ModelFamily.DETR, dict(cfg))).eval()
+    sd = synth_state_dict(cfg, 17)
+    model.load_state_dict(sd, strict=True)
+    for hw in ((200, 232), (250, 188), (208, 272)):
+        x = O.get_torch_batch([synth_image_structured(5 + i, *hw) for i in range(2)], hw)
+        picked, orig = [], torch.topk
+
+        def recording_topk(*a, **k):
+            r = orig(*a, **k)
+            picked.append(r.indices.clone())
+            return r
+
+        torch.topk = recording_topk
+        try:
+            with torch.no_grad():
+                out = model(x)
+                feats = model.pixel_decoder((x - model.pixel_mean) / model.pixel_std)
+        finally:
+            torch.topk = orig
+        col = {}
+        with torch.no_grad():
+            probs, boxes = O.detr_forward(sd, cfg, x, forced_topk=picked[0], collect=col)
+        by_shape = {}
+
+        def walk(o):
+            if isinstance(o, torch.Tensor):
+                by_shape[tuple(o.shape)] = o
+            elif isinstance(o, dict):
+                [walk(v) for v in o.values()]
+            elif isinstance(o, (list, tuple)):
+                [walk(v) for v in o]
+
+        walk(feats)
+        ceil2 = lambda n: -(-n // 2)   # noqa: E731
+        h, w = ceil2(ceil2(ceil2(hw[0]))), ceil2(ceil2(ceil2(hw[1])))
+        for k in ("enc_s8", "enc_s16", "enc_s32"):   # ceil(H/2) at every stride-2 layer
+            assert tuple(col[k].shape[-2:]) == (h, w), (hw, k, col[k].shape)
+            ref_level = by_shape[tuple(col[k].shape)]
+            assert float((ref_level - col[k]).norm() / ref_level.norm()) < 1e-5, (hw, k)
+            h, w = ceil2(h), ceil2(w)
+        np.testing.assert_allclose(probs.numpy(), out.logits.numpy(), atol=1e-4)
+        np.testing.assert_allclose(boxes.numpy(), out.boxes.numpy(), atol=1e-4)
+
+
 def test_bf_oracle_matches_reference_live():
     """BiSeNetFormer (A13): forward + batch-1 postprocess (predict_all_pixels) of the restatement vs the real reference, another
     seed and size than the committed golden; the registry config equals the reference's own registry file."""
