@@ -81,7 +81,7 @@ def lsa_status(device) -> torch.Tensor:
 def raise_if_infeasible(device, all_ranks: bool = False) -> None:
     """Reads (one 4-byte D2H copy: a synchronisation - call it where the host waits anyway) and clears the status word; raises what
     SciPy's ``linear_sum_assignment`` raises inside the reference matcher (fai_detr/modelling.py:749-750) when the costs are inf / NaN.
-    ``all_ranks``: under data parallelism the word is first MAX-all-reduced, so that EVERY rank raises in the same step - a rank raising
+    ``all_ranks``: under data parallelism the word is first OR-all-reduced, so that EVERY rank raises in the same step - a rank raising
     alone would leave the others blocked in the next gradient all-reduce (every rank must make this call at the same point)."""
     import torch.distributed as dist
 
@@ -89,7 +89,7 @@ def raise_if_infeasible(device, all_ranks: bool = False) -> None:
     multi = all_ranks and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     if multi:
         st = lsa_status(device)          # a rank that never matched still takes part in the collective
-        dist.all_reduce(st, op=dist.ReduceOp.MAX)
+        dist.all_reduce(st, op=dist.ReduceOp.BOR)   # a bitfield: bitwise OR (bit 0 infeasible, bit 1 invalid entries - different ranks may set different bits)
     if st is not None:
         bits = int(st.item())
         if bits:

@@ -1,8 +1,12 @@
-// Selection / head kernels of the RT-DETR path (gfx950): row max, exact top-k (radix select + bitonic
+// Selection / head kernels of the RT-DETR path (gfx950): row max, exact top-k (threshold search + rank
 // sort in LDS), row gathers, the tiny K=4 / N=4 linear layers fused with the box update, the output
 // head and the device-side DETRProcessor.postprocess.  Index results are int32 and must be bit-exact
 // with the reference's int64 indices: top-k order is (value descending, index ascending).
+#include <stdlib.h>
+
 #include "common.h"
+
+int fx_tune(const char* env_name, int default_value);  // conv_igemm.hip
 
 // Per-kernel bisection of the two-queue failure (scripts/dev/pk_bisect.sh kernels): when this unit is compiled WITH packed-fp32
 // instructions and -DFX_SELECT_PK_MASK=<bits>, only the kernels whose bit is set keep them.  In the product build (packed fp32 off for the
@@ -76,11 +80,12 @@ extern "C" int fx_rowmax_f32(const float* x, int ldx, float* out, int rows, int 
 
 // ------------------------------------------------------------------------------------------------
 // Exact top-k per row.  One 1024-thread workgroup per row:
-//  1. 4-pass MSB-first radix select (8-bit digits, LDS histogram) finds the key T of the k-th largest
-//     element and how many elements equal to T are needed;
+//  1. the key T of the k-th largest element and how many elements equal to T are needed: rows of <= 12 288 elements keep their keys in
+//     registers and build T three bits per round from compare-and-count (round 5); longer rows stream through a 4-pass MSB-first radix
+//     select (8-bit digits, LDS histogram);
 //  2. every element with key > T plus the needed number of key == T elements (lowest indices first,
 //     ordered block scan only when there are surplus ties) are collected into LDS;
-//  3. a bitonic sort of <= 1024 (key, ~index) pairs orders them (value desc, index asc).
+//  3. the <= 1024 (key, ~index) entries are ordered (value desc, index asc) by rank: place = number of greater entries.
 // Keys are the order-preserving unsigned image of the float bits.
 #define TOPK_THREADS 1024
 #define TOPK_MAXK 1024
@@ -99,12 +104,18 @@ __device__ __forceinline__ float key_f32(uint32_t k) {
 // the two-level form, whose elements are candidates of the first; the sort key and the output use the ORIGINAL index, so ties order
 // exactly as in a single pass (candidates of equal value sit in ascending original-index order: chunks are index ranges, and each
 // chunk's list is (value desc, index asc)).  Slots beyond the row's own length are padded (-inf, INT_MAX).
+// NPT > 0 (round 5): the row's keys live in REGISTERS, NPT per thread (rows of <= 1024 * NPT elements), loaded once with all loads in flight
+// together; the four radix passes, the collection and the tie scan then run on registers and LDS only.  The streaming form (NPT = 0, any
+// length) re-reads the row from L2 in every pass, one dependent load per 1024 elements and pass: 36 us for the encoder's 8 400 scores per
+// image, almost all of it load latency in a single workgroup.
+template <int NPT>
 __global__ FX_SEL_PK(1) __launch_bounds__(TOPK_THREADS) void topk_kernel(const float* __restrict__ scores, int ld, int n_total, int chunk_len, int nchunk, int k_out,
                                                              const int32_t* __restrict__ src_idx, float* __restrict__ out_val,
-                                                             int32_t* __restrict__ out_idx) {
+                                                             int32_t* __restrict__ out_idx, unsigned long long* dbg) {
+#define TOPK_STAMP(slot) do { if (dbg && blockIdx.x == 0 && threadIdx.x == 0) dbg[slot] = __builtin_amdgcn_s_memtime(); } while (0)
   __shared__ uint32_t hist[256];
   __shared__ unsigned long long sel[TOPK_MAXK];
-  __shared__ uint32_t s_prefix, s_remaining, s_count, s_base, s_wave_tot[16];
+  __shared__ uint32_t s_prefix, s_remaining, s_count, s_base, s_wave_tot[16], s_cnt[2][TOPK_THREADS / 64], s_rank[TOPK_MAXK];
   const int tid = threadIdx.x;
   const int img = blockIdx.x / nchunk, ch = blockIdx.x - img * nchunk;
   const int base = ch * chunk_len;
@@ -113,64 +124,122 @@ __global__ FX_SEL_PK(1) __launch_bounds__(TOPK_THREADS) void topk_kernel(const f
   const float* row = scores + (int64_t)img * ld + base;
   const int32_t* sidx = src_idx ? src_idx + (int64_t)img * ld + base : nullptr;
 
-  uint32_t prefix = 0, mask = 0;
-  if (tid == 0) s_remaining = (uint32_t)k;
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = 24 - 8 * pass;
-    if (tid < 256) hist[tid] = 0;
-    __syncthreads();
-    for (int i0 = 0; i0 < n; i0 += TOPK_THREADS) {
-      const int i = i0 + tid;
-      const bool in = i < n;
-      const uint32_t key = in ? f32_key(row[i]) : 0u;
-      bool live = in && (key & mask) == prefix;
-      const uint32_t bin = (key >> shift) & 255u;
-      // scores crowd into one or two bins per digit: one atomic per (wave, bin) for the first few distinct bins of the wave, plain
-      // atomics for whatever is left (same-address LDS atomics serialise per lane otherwise)
-#pragma unroll 1
-      for (int it = 0; it < 4; ++it) {
-        const unsigned long long act = __ballot(live);
-        if (!act) break;
-        const uint32_t lead = __builtin_amdgcn_readlane(bin, (int)__builtin_ctzll(act));
-        const unsigned long long same = __ballot(live && bin == lead);
-        if ((tid & 63) == (int)__builtin_ctzll(act)) atomicAdd(&hist[lead], (uint32_t)__popcll(same));
-        if (bin == lead) live = false;
-      }
-      if (live) atomicAdd(&hist[bin], 1u);
-    }
-    __syncthreads();
-    if (tid < 64) {   // wave 0: lane l owns bins 4l..4l+3; suffix sums over the lanes locate the bin where the count from the top reaches `rem`
-      const uint32_t rem = s_remaining;
-      const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
-      const uint32_t mine = h0 + h1 + h2 + h3;
-      uint32_t suf = mine;   // inclusive suffix sum: bins of lanes >= tid
+  TOPK_STAMP(0);
+  uint32_t kreg[NPT > 0 ? NPT : 1];
+  if constexpr (NPT > 0) {
 #pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t v = __shfl_down(suf, o, 64);
-        if (tid + o < 64) suf += v;
-      }
-      const uint32_t above = suf - mine;   // count in bins above this lane's
-      if (above < rem && suf >= rem) {     // exactly one lane
-        uint32_t c = above;
-        int bin;
-        uint32_t hb;
-        if (c + h3 >= rem) { bin = 4 * tid + 3; hb = h3; }
-        else if ((c += h3) + h2 >= rem) { bin = 4 * tid + 2; hb = h2; }
-        else if ((c += h2) + h1 >= rem) { bin = 4 * tid + 1; hb = h1; }
-        else { c += h1; bin = 4 * tid; hb = h0; }
-        s_remaining = rem - c;  // still needed among keys whose digits so far equal prefix|bin
-        s_prefix = prefix | ((uint32_t)bin << shift);
-        s_count = hb;           // after the last pass: number of elements with key == T
-      }
+    for (int j = 0; j < NPT; ++j) {
+      const int i = j * TOPK_THREADS + tid;
+      kreg[j] = i < n ? f32_key(row[i]) : 0u;
     }
-    __syncthreads();
-    prefix = s_prefix;
-    mask |= 0xffu << shift;
   }
-  const uint32_t T = prefix;
-  const uint32_t need_eq = s_remaining;  // 1..count_eq
-  const uint32_t count_eq = s_count;
+  const int iters = NPT > 0 ? NPT : (n + TOPK_THREADS - 1) / TOPK_THREADS;
+  // key of element j * 1024 + tid (callers test i < n themselves)
+#define TOPK_KEY(j, i) (NPT > 0 ? kreg[(NPT > 0) ? (j) : 0] : ((i) < n ? f32_key(row[(i)]) : 0u))
+#define TOPK_FOR_ELEMENTS(j) _Pragma("unroll") for (int j = 0; j < (NPT > 0 ? NPT : iters); ++j)
+
+  uint32_t T, need_eq, count_eq;   // key of the k-th largest element, how many elements equal to it are needed (1..count_eq), how many there are
+  if constexpr (NPT > 0) {
+    // Keys in registers: T is built bit by bit from the top - T | bit stays iff at least k keys are >= it - with one v_cmp + s_bcnt1 per key
+    // and wave, one LDS word per wave and ONE barrier per bit (the 16 partial counts alternate between two rows, so a wave that is a round
+    // ahead never overwrites what a slower one still reads).  s_memtime stamps (scripts/dev/topk_stamps.py, profiles/r05_topk_ab.txt): a
+    // round costs ~60 ticks per key register (four waves per SIMD issuing the compare + count) + ~250 for the exchange, 26 000 ticks for
+    // 8 400 scores; three bits per round (63 compares, 11 rounds) measured 42 600 - the compares are the cost, not the barriers - and the
+    // 8-bit radix passes of the streaming form (histogram atomics, one ballot round per distinct bin) 4 x ~8 us.
+    const int lane = tid & 63, wv = tid >> 6;
+    auto block_sum = [&](uint32_t wave_total, int buf) -> uint32_t {
+      if (lane == 0) s_cnt[buf][wv] = wave_total;
+      __syncthreads();
+      uint32_t tot = 0;
+#pragma unroll
+      for (int w = 0; w < TOPK_THREADS / 64; ++w) tot += s_cnt[buf][w];
+      return tot;
+    };
+    uint32_t t = 0;
+    if (dbg) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // diagnostic only: the stamp below is taken with the keys loaded
+    TOPK_STAMP(1);
+#pragma unroll 2
+    for (int bit = 31; bit >= 0; --bit) {
+      const uint32_t cand = t | (1u << bit);   // >= 1: the zero keys of the padding slots are never counted
+      uint32_t c = 0;
+#pragma unroll
+      for (int j = 0; j < NPT; ++j) c += (uint32_t)__popcll(__ballot(kreg[j] >= cand));
+      if (block_sum(c, bit & 1) >= (uint32_t)k) t = cand;
+    }
+    uint32_t cg = 0, ce = 0;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+      const bool in = j * TOPK_THREADS + tid < n;
+      cg += (uint32_t)__popcll(__ballot(in && kreg[j] > t));
+      ce += (uint32_t)__popcll(__ballot(in && kreg[j] == t));
+    }
+    // row 1: the round of bit 0 used row 0 and its readers may still be at it; row 1 was last read before that round's barrier.
+    // cg <= k <= 1024, ce <= 12 288: no carry between the two halves
+    const uint32_t both = block_sum((cg << 16) | ce, 1);
+    T = t;
+    need_eq = (uint32_t)k - (both >> 16);
+    count_eq = both & 0xffffu;
+  } else {
+    uint32_t prefix = 0, mask = 0;
+    if (tid == 0) s_remaining = (uint32_t)k;
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      if (tid < 256) hist[tid] = 0;
+      __syncthreads();
+      TOPK_FOR_ELEMENTS(j) {
+        const int i = j * TOPK_THREADS + tid;
+        const bool in = i < n;
+        const uint32_t key = TOPK_KEY(j, i);
+        bool live = in && (key & mask) == prefix;
+        const uint32_t bin = (key >> shift) & 255u;
+        // scores crowd into one or two bins per digit: one atomic per (wave, bin) for the first few distinct bins of the wave, plain
+        // atomics for whatever is left (same-address LDS atomics serialise per lane otherwise)
+  #pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+          const unsigned long long act = __ballot(live);
+          if (!act) break;
+          const uint32_t lead = __builtin_amdgcn_readlane(bin, (int)__builtin_ctzll(act));
+          const unsigned long long same = __ballot(live && bin == lead);
+          if ((tid & 63) == (int)__builtin_ctzll(act)) atomicAdd(&hist[lead], (uint32_t)__popcll(same));
+          if (bin == lead) live = false;
+        }
+        if (live) atomicAdd(&hist[bin], 1u);
+      }
+      __syncthreads();
+      if (tid < 64) {   // wave 0: lane l owns bins 4l..4l+3; suffix sums over the lanes locate the bin where the count from the top reaches `rem`
+        const uint32_t rem = s_remaining;
+        const uint32_t h0 = hist[4 * tid], h1 = hist[4 * tid + 1], h2 = hist[4 * tid + 2], h3 = hist[4 * tid + 3];
+        const uint32_t mine = h0 + h1 + h2 + h3;
+        uint32_t suf = mine;   // inclusive suffix sum: bins of lanes >= tid
+  #pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t v = __shfl_down(suf, o, 64);
+          if (tid + o < 64) suf += v;
+        }
+        const uint32_t above = suf - mine;   // count in bins above this lane's
+        if (above < rem && suf >= rem) {     // exactly one lane
+          uint32_t c = above;
+          int bin;
+          uint32_t hb;
+          if (c + h3 >= rem) { bin = 4 * tid + 3; hb = h3; }
+          else if ((c += h3) + h2 >= rem) { bin = 4 * tid + 2; hb = h2; }
+          else if ((c += h2) + h1 >= rem) { bin = 4 * tid + 1; hb = h1; }
+          else { c += h1; bin = 4 * tid; hb = h0; }
+          s_remaining = rem - c;  // still needed among keys whose digits so far equal prefix|bin
+          s_prefix = prefix | ((uint32_t)bin << shift);
+          s_count = hb;           // after the last pass: number of elements with key == T
+        }
+      }
+      __syncthreads();
+      prefix = s_prefix;
+      mask |= 0xffu << shift;
+    }
+    T = prefix;
+    need_eq = s_remaining;  // 1..count_eq
+    count_eq = s_count;
+  }
   __syncthreads();
+  TOPK_STAMP(2);
   if (tid == 0) {
     s_count = 0;
     s_base = 0;
@@ -179,9 +248,10 @@ __global__ FX_SEL_PK(1) __launch_bounds__(TOPK_THREADS) void topk_kernel(const f
   __syncthreads();
   // strictly greater: all selected (there are exactly k - need_eq of them)
   const bool all_eq = (count_eq == need_eq);
-  for (int i = tid; i < n; i += TOPK_THREADS) {
-    uint32_t key = f32_key(row[i]);
-    if (key > T || (all_eq && key == T)) {
+  TOPK_FOR_ELEMENTS(j) {
+    const int i = j * TOPK_THREADS + tid;
+    const uint32_t key = TOPK_KEY(j, i);
+    if (i < n && (key > T || (all_eq && key == T))) {
       uint32_t pos = atomicAdd(&s_count, 1u);
       if (pos < TOPK_MAXK) sel[pos] = ((unsigned long long)key << 32) | (uint32_t)(0xffffffffu - (uint32_t)(sidx ? sidx[i] : base + i));
     }
@@ -190,9 +260,10 @@ __global__ FX_SEL_PK(1) __launch_bounds__(TOPK_THREADS) void topk_kernel(const f
   if (!all_eq) {
     // surplus ties: take the need_eq lowest indices among key == T (ordered block scan)
     const int lane = tid & 63, wv = tid >> 6;
-    for (int start = 0; start < n; start += TOPK_THREADS) {
-      int i = start + tid;
-      bool flag = (i < n) && (f32_key(row[i]) == T);
+    TOPK_FOR_ELEMENTS(j) {
+      const int i = j * TOPK_THREADS + tid;
+      if (j * TOPK_THREADS >= n) break;   // uniform
+      bool flag = (i < n) && (TOPK_KEY(j, i) == T);
       unsigned long long bal = __ballot(flag);
       uint32_t wexcl = __popcll(bal & ((1ull << lane) - 1ull));
       if (lane == 0) s_wave_tot[wv] = __popcll(bal);
@@ -215,51 +286,63 @@ __global__ FX_SEL_PK(1) __launch_bounds__(TOPK_THREADS) void topk_kernel(const f
     }
     __syncthreads();
   }
-  // bitonic sort, descending, of the smallest power of two >= k entries (zeros pad at the end)
-  int ns = 1;
-  while (ns < k) ns <<= 1;
-  // strides <= 64 keep a compare-exchange pair inside one 128-entry window: wave w runs all of them for window w back to back (LDS
-  // operations of a wave are ordered; no workgroup barrier), only the wider strides are workgroup steps
-  auto cmpx = [&](int t, int size, int stride) {
-    const int lo = (t / stride) * (stride * 2) + (t % stride);
-    const int hi = lo + stride;
-    const bool desc = ((lo & size) == 0);
-    const unsigned long long a = sel[lo], bq = sel[hi];
-    const bool swap = desc ? (a < bq) : (a > bq);
-    if (swap) {
-      sel[lo] = bq;
-      sel[hi] = a;
-    }
-  };
-  const int lane_s = tid & 63, wv_s = tid >> 6;
-  for (int size = 2; size <= ns; size <<= 1) {
-    int stride = size >> 1;
-    for (; stride > 64; stride >>= 1) {
-      for (int t = tid; t < ns / 2; t += TOPK_THREADS) cmpx(t, size, stride);
-      __syncthreads();
-    }
-    for (int w = wv_s; w * 128 < ns; w += TOPK_THREADS / 64) {
-      for (int st = stride; st > 0; st >>= 1) {
-        if (w * 64 + lane_s < ns / 2) cmpx(w * 64 + lane_s, size, st);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      }
-    }
-    __syncthreads();
+  TOPK_STAMP(3);
+  // Order (value descending, index ascending) = descending order of the 64-bit entries, which are DISTINCT (the index is part of them):
+  // an entry's place is the number of entries greater than it.  One thread per (entry, slice of the list) - floor(1024 / k) slices, every
+  // thread on a real entry - and the slice is read with wave-uniform addresses where a wave lies inside one slice (LDS broadcast); nothing
+  // in the loop depends on a previous LDS access: 100 reads + compares per thread for k = 300.  (Until round 5 a bitonic network sorted
+  // the list in LDS: 45 dependent read-compare-write steps of ~500 ticks each, 22 000 of the launch's 55 000 ticks.)
+  const int parts = TOPK_THREADS / k, part = tid / k, e = tid - part * k;
+  const int len = (k + parts - 1) / parts;
+  s_rank[tid] = 0;
+  __syncthreads();
+  const unsigned long long me = sel[e];
+  if (part < parts) {
+    const int j0 = part * len, j1 = min(k, j0 + len);
+    uint32_t r = 0;
+#pragma unroll 4
+    for (int j = j0; j < j1; ++j) r += (sel[j] > me) ? 1u : 0u;
+    if (r) atomicAdd(&s_rank[e], r);
   }
-  for (int i = tid; i < k_out; i += TOPK_THREADS) {
-    unsigned long long e = sel[i];
-    out_val[(int64_t)blockIdx.x * k_out + i] = i < k ? key_f32((uint32_t)(e >> 32)) : -INFINITY;
-    out_idx[(int64_t)blockIdx.x * k_out + i] = i < k ? (int32_t)(0xffffffffu - (uint32_t)(e & 0xffffffffull)) : 0x7fffffff;
+  __syncthreads();
+  TOPK_STAMP(4);
+  if (part == 0) {
+    const uint32_t rank = s_rank[e];
+    out_val[(int64_t)blockIdx.x * k_out + rank] = key_f32((uint32_t)(me >> 32));
+    out_idx[(int64_t)blockIdx.x * k_out + rank] = (int32_t)(0xffffffffu - (uint32_t)(me & 0xffffffffull));
   }
+  for (int i = k + tid; i < k_out; i += TOPK_THREADS) {   // a row shorter than k_out: padded
+    out_val[(int64_t)blockIdx.x * k_out + i] = -INFINITY;
+    out_idx[(int64_t)blockIdx.x * k_out + i] = 0x7fffffff;
+  }
+  TOPK_STAMP(5);
+#undef TOPK_STAMP
+}
+
+#undef TOPK_KEY
+#undef TOPK_FOR_ELEMENTS
+
+// rows (chunks) of <= 5 120 / 9 216 / 12 288 elements keep their keys in registers; longer ones stream (FX_TOPK_REGS=0: always stream)
+static void topk_launch(int grid, hipStream_t stream, const float* scores, int ld, int n_total, int chunk_len, int nchunk, int k_out,
+                        const int32_t* src_idx, float* out_val, int32_t* out_idx) {
+  static const int regs = fx_tune("FX_TOPK_REGS", 1);
+  // diagnostic (scripts/dev/topk_stamps.py): FX_TOPK_DBG = address of 8 x u64 that receive workgroup 0's s_memtime stamps (start, keys loaded,
+  // threshold found, candidates collected, sorted, written)
+  static unsigned long long* const dbg = reinterpret_cast<unsigned long long*>((uintptr_t)strtoull(getenv("FX_TOPK_DBG") ? getenv("FX_TOPK_DBG") : "0", nullptr, 0));
+  const int len = chunk_len < n_total ? chunk_len : n_total;
+  const int npt = !regs ? 0 : (len <= 5 * TOPK_THREADS ? 5 : (len <= 9 * TOPK_THREADS ? 9 : (len <= 12 * TOPK_THREADS ? 12 : 0)));
+#define TOPK_GO(N) hipLaunchKernelGGL(topk_kernel<N>, dim3(grid), dim3(TOPK_THREADS), 0, stream, scores, ld, n_total, chunk_len, nchunk, k_out, src_idx, out_val, out_idx, dbg)
+  if (npt == 5) TOPK_GO(5);
+  else if (npt == 9) TOPK_GO(9);
+  else if (npt == 12) TOPK_GO(12);
+  else TOPK_GO(0);
+#undef TOPK_GO
 }
 
 extern "C" int fx_topk_rows_f32(const float* scores, int ld, int B, int n, int k, float* out_val, int32_t* out_idx, fx_stream_t stream_) {
   FX_CHECK_ARG(scores && out_val && out_idx && B > 0 && n > 0 && k > 0 && k <= n && ld >= n);
   if (k > TOPK_MAXK) return FX_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(TOPK_THREADS), 0, reinterpret_cast<hipStream_t>(stream_), scores, ld, n, n, 1, k,
-                     (const int32_t*)nullptr, out_val, out_idx);
+  topk_launch(B, reinterpret_cast<hipStream_t>(stream_), scores, ld, n, n, 1, k, nullptr, out_val, out_idx);
   return fx_launch_status();
 }
 
@@ -283,9 +366,8 @@ extern "C" int fx_topk_rows_ws_f32(const float* scores, int ld, int B, int n, in
   const int nchunk = (n + TOPK_CHUNK - 1) / TOPK_CHUNK;
   float* cval = reinterpret_cast<float*>(workspace);
   int32_t* cidx = reinterpret_cast<int32_t*>(cval + (size_t)B * nchunk * k);
-  hipLaunchKernelGGL(topk_kernel, dim3(B * nchunk), dim3(TOPK_THREADS), 0, stream, scores, ld, n, TOPK_CHUNK, nchunk, k, (const int32_t*)nullptr, cval, cidx);
-  hipLaunchKernelGGL(topk_kernel, dim3(B), dim3(TOPK_THREADS), 0, stream, (const float*)cval, nchunk * k, nchunk * k, nchunk * k, 1, k,
-                     (const int32_t*)cidx, out_val, out_idx);
+  topk_launch(B * nchunk, stream, scores, ld, n, TOPK_CHUNK, nchunk, k, nullptr, cval, cidx);
+  topk_launch(B, stream, (const float*)cval, nchunk * k, nchunk * k, nchunk * k, 1, k, (const int32_t*)cidx, out_val, out_idx);
   return fx_launch_status();
 }
 

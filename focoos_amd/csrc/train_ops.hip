@@ -617,16 +617,23 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                      const double* __restrict__ partial, int npartial, float max_norm, float beta1, float beta2,
                                                      float eps, float bias_c1, float bias_c2_sqrt, float* __restrict__ total_norm_out) {
   __shared__ float s_clip;
+  __shared__ int s_skip;
   if (threadIdx.x == 0) {
     double tot = 0.0;
     for (int i = 0; i < npartial; ++i) tot += partial[i];
-    const float norm = (float)sqrt(tot);
+    // inf / NaN anywhere in the gradients (a non-finite loss, non-finite matching costs): the update is SKIPPED - parameters and moments stay
+    // as they were, total_norm_out reports inf - instead of writing NaN into every parameter (TrainStep polls the Hungarian status
+    // word only every check_every steps; the reference's default training runs under GradScaler, which skips such steps too, trainer.py:645)
+    const bool finite = tot == tot && tot < 1.7976931348623157e308;
+    const float norm = finite ? (float)sqrt(tot) : __builtin_inff();
     float c = 1.0f;
     if (max_norm > 0.0f) c = fminf(max_norm / (norm + 1e-6f), 1.0f);  // torch.nn.utils.clip_grad_norm_
     s_clip = c;
+    s_skip = finite ? 0 : 1;
     if (blockIdx.x == 0 && total_norm_out) *total_norm_out = norm;
   }
   __syncthreads();
+  if (s_skip) return;
   const float clip = s_clip;
   const int64_t start = chunk_start[blockIdx.x];
   const int len = chunk_len[blockIdx.x];

@@ -804,7 +804,7 @@ class TrainStep:
     def check(self) -> None:
         """Poll and clear the Hungarian solver's device status word (criterion.raise_if_infeasible): a step whose matching costs were
         NaN / inf - where the reference raises from SciPy inside the matcher (fai_detr/modelling.py:749-750) - raises the same ValueError
-        here, on EVERY rank (the word is MAX-all-reduced first: a rank raising alone would leave the others blocked in the next gradient
+        here, on EVERY rank (the word is OR-all-reduced first: a rank raising alone would leave the others blocked in the next gradient
         all-reduce).  One 4-byte D2H read = one host synchronisation, so step() calls it every `check_every` steps (default 16: at most
         15 optimizer steps run on identity assignments before the run ends) instead of every step; direct users of TrainStep that want the
         reference's per-step behaviour pass check_every=1 or call check() themselves."""

@@ -496,7 +496,9 @@ int fx_msda_prep_bwd_bf16(const float* grad_loc, const float* grad_attn, const f
  * The buffer is cut into chunks (chunk_start i64, chunk_len i32 <= 65536) each carrying its tensor's lr / weight_decay;
  * arithmetic of torch.optim.AdamW (decoupled decay, bias correction with `step` >= 1), clip coefficient
  * min(1, max_grad_norm / (||g|| + 1e-6)) computed on the device (max_grad_norm <= 0: no clipping).
- * workspace: fx_adamw_workspace_bytes() bytes, 8-byte aligned; total_norm_out (may be NULL) receives ||g||. */
+ * workspace: fx_adamw_workspace_bytes() bytes, 8-byte aligned; total_norm_out (may be NULL) receives ||g||.
+ * Gradients holding an inf / NaN: the update is skipped (params, exp_avg, exp_avg_sq untouched) and total_norm_out receives +inf -
+ * what GradScaler does for the reference's default amp training (trainer/trainer.py:645,735-773). */
 int fx_adamw_workspace_bytes(void);
 int fx_adamw_step_f32(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, int64_t numel, const int64_t* chunk_start,
                       const int32_t* chunk_len, const float* chunk_lr, const float* chunk_wd, int nchunks, int step, float beta1, float beta2,

@@ -137,3 +137,45 @@ def test_allreduce_overlaps_backward_two_ranks_gloo():
         # when the head's buckets were launched the backbone (and encoder) gradients did not exist yet: backward was still running
         assert state[0] == (False, False, True) and state[1] == (False, True, True)
         assert log == [("segment", 2), ("segment", 1), ("backward_end", -1), ("segment", 0)]   # two of three segments in flight before backward ended
+
+
+def _status_worker(rank, world, port, q):
+    """raise_if_infeasible(all_ranks=True): the Hungarian status word is a BITFIELD (bit 0 infeasible, bit 1 invalid entries) - rank 0 sets
+    bit 0, rank 1 bit 1; after the bitwise-OR all-reduce both ranks hold 3, raise the same error in the same step and clear the word.
+    A second round with nothing pending on rank 0 and bit 0 on rank 1: both raise the 'infeasible' message."""
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from focoos_amd.criterion import lsa_status, raise_if_infeasible
+
+    out = []
+    st = lsa_status("cpu")
+    st.fill_(1 if rank == 0 else 2)
+    try:
+        raise_if_infeasible("cpu", all_ranks=True)
+        out.append(None)
+    except ValueError as e:
+        out.append(str(e))
+    out.append(int(st.item()))
+    if rank == 1:
+        st.fill_(1)
+    try:
+        raise_if_infeasible("cpu", all_ranks=True)
+        out.append(None)
+    except ValueError as e:
+        out.append(str(e))
+    raise_if_infeasible("cpu", all_ranks=True)   # nothing pending anywhere: no error on either rank
+    q.put((rank, tuple(out)))
+    dist.destroy_process_group()
+
+
+def test_status_word_is_or_reduced_across_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_status_worker, args=(r, 2, 29719, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    want = ("matrix contains invalid numeric entries", 0, "cost matrix is infeasible")
+    assert res == [(0, want), (1, want)], res

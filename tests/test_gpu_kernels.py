@@ -338,12 +338,14 @@ def test_msda_core_golden_and_fused(lib):
     assert (out.float().cpu() - ref_f).abs().max() < 1.5e-2
 
 
-@pytest.mark.parametrize("cfg", [(4, 8400, 300), (2, 109500, 300), (3, 1000, 1), (2, 700, 700), (1, 64, 5)])
+@pytest.mark.parametrize("cfg", [(4, 8400, 300), (2, 109500, 300), (3, 1000, 1), (2, 700, 700), (1, 64, 5),
+                                 # round 5: the register-resident forms (5 / 9 / 12 keys per thread) at their boundaries, and the streaming form behind them
+                                 (4, 5120, 300), (4, 5121, 300), (4, 9216, 1024), (4, 9217, 300), (4, 11000, 300), (4, 12288, 256), (4, 12289, 300), (4, 21504, 300)])
 def test_topk_exact(lib, cfg):
     B, n, k = cfg
     g = torch.Generator().manual_seed(n + k)
     s = torch.randn(B, n, generator=g)
-    if n == 8400:
+    if B == 4:
         s[1] = torch.sigmoid(s[1])                       # positive, clustered exponents
         s[2, ::3] = s[2, 0]                               # massive ties straddling the cut
         s[3] = 0.25                                       # all equal: lowest indices win

@@ -59,6 +59,31 @@ def test_flat_adamw_matches_torch_adamw_with_clipping():
             assert (opt.params[name].cpu() - p.detach()).abs().max() < 2e-6, (step, name)
 
 
+def test_flat_adamw_skips_the_update_on_non_finite_gradients():
+    """An inf / NaN anywhere in the flat gradient: parameters and both moments stay bit-identical, the reported norm is inf, and the next
+    finite step updates as usual (what GradScaler does for the reference's default amp training, trainer.py:645,735-773; without a loss
+    scale there is nothing to back off, the step is only dropped)."""
+    g = torch.Generator().manual_seed(1)
+    shapes = [("a.w", (64, 32, 3, 3), 1e-4, 1e-4), ("b.w", (300, 700), 1e-4, 5e-2)]
+    opt = FlatAdamW(shapes, DEV, max_grad_norm=0.1)
+    for name, shape, _, _ in shapes:
+        opt.params[name].copy_(torch.randn(*shape, generator=g))
+        opt.grads[name].copy_(torch.randn(*shape, generator=g) * 1e-2)
+    opt.step()
+    torch.cuda.synchronize()
+    p0, m0, v0 = opt.flat_p.clone(), opt.flat_m.clone(), opt.flat_v.clone()
+    for bad in (float("nan"), float("inf"), -float("inf")):
+        opt.grads["b.w"][17, 3] = bad
+        opt.step()
+        torch.cuda.synchronize()
+        assert torch.equal(opt.flat_p, p0) and torch.equal(opt.flat_m, m0) and torch.equal(opt.flat_v, v0)
+        assert float(opt.total_norm) == float("inf")
+    opt.grads["b.w"][17, 3] = 0.5
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.isfinite(opt.flat_p).all() and not torch.equal(opt.flat_p, p0) and np.isfinite(float(opt.total_norm))
+
+
 def test_box_refine_forward_backward_vs_torch_autograd():
     """sigmoid(delta + inverse_sigmoid(ref)) (fai_detr/modelling.py:1003, 1010; functional.py:4-6) as fx_box_refine_f32 / _bwd vs torch
     autograd of the reference expression on the same bf16 deltas: fp32 both sides -> 1e-6 absolute forward, 1e-5 relative backward.
