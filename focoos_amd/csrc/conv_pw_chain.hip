@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256, ((N2 <= 64 && K1B == 0) ? 4 : ((N2 <= 128 && (
       const int row = q >> 5, lc = q & 31;
       const uint4 v = *reinterpret_cast<const uint4*>(T + row * 512 + ((lc ^ (row & 15)) << 4));
       const int m = pix(row);
-      if (m >= 0) *reinterpret_cast<uint4*>(p.y1 + (size_t)m * p.ldy1 + g * 256 + lc * 8) = v;
+      if (m >= 0 && p.y1) *reinterpret_cast<uint4*>(p.y1 + (size_t)m * p.ldy1 + g * 256 + lc * 8) = v;   // y1 == nullptr (QUAD form only): the block output lives on through y2 and the pooled tensor alone
     }
     if constexpr (QUAD) {
       // AvgPool2d(2, 2) of the y1 tile: quad j = rows 4j .. 4j+3 in the order (dy, dx) = (0,0), (0,1), (1,0), (1,1) - the summation order of
@@ -336,12 +336,13 @@ extern "C" int fx_pw_chain_pool_supported(int K1a, int K1b, int N1, int N2) {
 }
 
 extern "C" int fx_pw_chain_bf16(const fx_pw_chain_desc* d, fx_stream_t stream_) {
-  FX_CHECK_ARG(d && d->x1 && d->w1 && d->bias1 && d->y1 && d->M > 0);
+  FX_CHECK_ARG(d && d->x1 && d->w1 && d->bias1 && d->M > 0);
+  FX_CHECK_ARG(d->y1 || (d->pool && d->N2 > 0));   // y1 may be dropped only where the pooled tensor and y2 carry the block output on (round 5: RT-DETR never reads res2 itself)
   FX_CHECK_ARG(d->K1b == 0 || d->x2);
   FX_CHECK_ARG((d->act1 == FX_ACT_NONE || d->act1 == FX_ACT_RELU) && (d->act2 == FX_ACT_NONE || d->act2 == FX_ACT_RELU));
   FX_CHECK_ARG(d->N2 == 0 || (d->w2 && d->bias2 && d->y2));
   if (!fx_pw_chain_supported(d->K1a, d->K1b, d->N1, d->N2)) return FX_ERR_UNSUPPORTED;
-  FX_CHECK_ARG(d->ldx1 >= d->K1a && d->ldx1 % 8 == 0 && d->ldy1 >= d->N1 && d->ldy1 % 8 == 0);
+  FX_CHECK_ARG(d->ldx1 >= d->K1a && d->ldx1 % 8 == 0 && (!d->y1 || (d->ldy1 >= d->N1 && d->ldy1 % 8 == 0)));
   FX_CHECK_ARG(d->K1b == 0 || (d->ldx2 >= d->K1b && d->ldx2 % 8 == 0));
   FX_CHECK_ARG(!d->residual || (d->ldr >= d->N1 && d->ldr % 8 == 0));
   FX_CHECK_ARG(d->N2 == 0 || (d->ldy2 >= d->N2 && d->ldy2 % 8 == 0));

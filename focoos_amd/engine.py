@@ -420,6 +420,7 @@ class _PlanBase:
     """Buffers + the static launch sequence for one (batch, height, width); helpers shared by the model families."""
 
     size_multiple = 32
+    needed_res = (2, 3, 4, 5)   # backbone stage outputs the plan reads as such (build_backbone drops the store of the others where a fused launch allows it)
 
     def __init__(self, eng: _EngineBase, B: int, H: int, W: int, f32_input: bool, parent: Optional["_MultiPlan"] = None, index: int = 0):
         # Every family runs at the image's own size with ceil(H/2) at every stride-2 layer (size_multiple = 1 in all three plans; the class
@@ -530,18 +531,22 @@ class _PlanBase:
         return out
 
     def pw_chain(self, x1: NT, x2: Optional[NT], residual: Optional[NT], cc: Tuple, ca: Optional[Tuple], name1: str, name2: Optional[str],
-                 pool_name: Optional[str] = None):
+                 pool_name: Optional[str] = None, keep_y1: bool = True):
         """y1 = relu([x1 | x2] W1^T + b1 (+ residual)), y2 = relu(y1 W2^T + b2) in one launch (include/focoos_amd.h, fx_pw_chain_desc):
         BottleNeck branch2c (+ shortcut conv) + add + ReLU and the next block's branch2a + ReLU (resnet.py:107-121)."""
         w1, b1, k1a, k1b, n1 = cc
         assert x1.C == k1a and (x2 is None) == (k1b == 0) and (x2 is None or x2.C == k1b), (name1, x1.C, k1a, k1b)
         M = x1.rows
-        y1 = self._new(name1, x1.B, x1.H, x1.W, n1)
+        # keep_y1=False (with pool_name and ca): the block output is consumed only as the next block's branch2a input (y2) and as the pooled
+        # shortcut input - y1 itself is neither allocated nor written (RT-DETR's res2: 105 MB per 16-image part at 640 x 640)
+        assert keep_y1 or (pool_name is not None and ca is not None)
+        y1 = self._new(name1, x1.B, x1.H, x1.W, n1) if keep_y1 else None
         d = FxPwChainDesc()
         d.x1, d.ldx1, d.K1a = x1.ptr, x1.ld, k1a
         d.x2, d.ldx2, d.K1b = (x2.ptr, x2.ld, k1b) if x2 is not None else (None, 0, 0)
         d.residual, d.ldr = (residual.ptr, residual.ld) if residual is not None else (None, 0)
-        d.w1, d.bias1, d.y1, d.ldy1, d.N1, d.M = w1.data_ptr(), b1.data_ptr(), y1.ptr, y1.ld, n1, M
+        d.w1, d.bias1, d.N1, d.M = w1.data_ptr(), b1.data_ptr(), n1, M
+        d.y1, d.ldy1 = (y1.ptr, y1.ld) if y1 is not None else (None, 0)
         d.act1 = d.act2 = FX_ACT["relu"]
         y2, n2 = None, 0
         if ca is not None:
@@ -554,9 +559,11 @@ class _PlanBase:
             pooled = self._new(pool_name, x1.B, x1.H // 2, x1.W // 2, n1)
             d.pool, d.ldp, d.img_h, d.img_w = pooled.ptr, pooled.ld, x1.H, x1.W
         self.keep.append(d)
-        self.meta[len(self.ops)] = {"kind": "conv", "variant": f"pw_chain<{k1a},{k1b},{n2}>" + ("+pool" if pooled is not None else ""), "flops": 2.0 * M * n1 * (k1a + k1b + n2),
+        self.meta[len(self.ops)] = {"kind": "conv", "variant": f"pw_chain<{k1a},{k1b},{n2}>" + ("+pool" if pooled is not None else "") + ("-y1" if y1 is None else ""),
+                                    "flops": 2.0 * M * n1 * (k1a + k1b + n2),
                                     "name": name1 + ("+" + name2.rsplit("res_layers.", 1)[-1] if name2 else ""), "M": M, "N": n1, "K": k1a + k1b,
-                                    "bytes": 2.0 * M * (k1a + k1b + (n1 if residual is not None else 0) + n1 + n2 + (n1 / 4 if pooled is not None else 0))}
+                                    "bytes": 2.0 * M * (k1a + k1b + (n1 if residual is not None else 0) + (n1 if y1 is not None else 0) + n2
+                                                        + (n1 / 4 if pooled is not None else 0))}
         self._op(self.lib.fx_pw_chain_bf16, C.byref(d))
         if pool_name is not None:
             return y1, y2, pooled
@@ -679,8 +686,10 @@ class _PlanBase:
                 want_pool = (use_pool and nxt is not None and nxt[0] == si + 1 and bi != 0 and bmid.H % 2 == 0 and bmid.W % 2 == 0
                              and lib.fx_pw_chain_pool_supported(cc[2], cc[3], cc[4], n2) == 1)
                 if want_pool:
+                    # a stage output nobody reads as such (RT-DETR's res2: the encoder takes res3..res5) is not written: FX_SKIP_UNUSED_RES=0 keeps it
+                    keep = bool(n2 == 0 or (si + 2) in self.needed_res or os.environ.get("FX_SKIP_UNUSED_RES", "1") == "0")
                     x, a_next, pooled_next = self.pw_chain(bmid, short_in, x, cc, e.chain_a[nxt] if n2 else None, f"{p}.c", nxt_name,
-                                                           pool_name=f"{bb}.res_layers.{nxt[0]}.blocks.0.pool")
+                                                           pool_name=f"{bb}.res_layers.{nxt[0]}.blocks.0.pool", keep_y1=keep)
                 else:
                     x, a_next = self.pw_chain(bmid, short_in, None if bi == 0 else x, cc, e.chain_a[nxt] if n2 else None, f"{p}.c", nxt_name)
             else:
@@ -689,7 +698,8 @@ class _PlanBase:
             if bi == blocks[si] - 1:
                 feats[si + 2] = x
         for k, v in feats.items():
-            self.bufs[f"res{k}"] = v
+            if v is not None:
+                self.bufs[f"res{k}"] = v
         return feats
 
     # -------------------------------------------------------------- execution
@@ -734,6 +744,7 @@ class _PlanBase:
 class _Plan(StdcPlanMixin, _PlanBase):
     """RT-DETR launch sequence."""
 
+    needed_res = (3, 4, 5)   # the hybrid encoder reads res3..res5 (modelling.py:297-347): res2 is only the input of res3's first block
     size_multiple = 1   # round 5: any size >= 32 with enough tokens for the query selection (ragged training batches are padded to the batch maximum)
 
     # -------------------------------------------------------------- the network

@@ -111,7 +111,7 @@ typedef struct fx_pw_chain_desc {
   const void* residual; /* bf16 [M, ldr] or NULL */
   const void* w1;       /* bf16 fragment-packed [N1/32][(K1a+K1b)/16][64][8] */
   const float* bias1;   /* f32 [N1] */
-  void* y1;             /* bf16 [M, ldy1] */
+  void* y1;             /* bf16 [M, ldy1]; may be NULL when `pool` and y2 are given: the block output is then not stored (round 5) */
   const void* w2;       /* bf16 fragment-packed [N2/32][N1/16][64][8] or NULL */
   const float* bias2;   /* f32 [N2] or NULL */
   void* y2;             /* bf16 [M, ldy2] or NULL */

@@ -617,6 +617,17 @@ def test_pw_chain_quad_tiles_with_pooled_output(lib, case):
     # and against torch on the stored bf16 y1
     want = F.avg_pool2d(y1b[:M].float().reshape(B, H, W, N1).permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).reshape(M // 4, N1)
     assert (pool[: M // 4].float() - want).abs().max().item() <= 8e-3 * want.abs().max().item()
+    # round 5: y1 = NULL - the block output is not stored (RT-DETR never reads res2 itself); y2 and the pooled tensor are unchanged
+    y2c = torch.full_like(y2b, float("nan"))
+    poolc = torch.full_like(pool, float("nan"))
+    d.y1, d.ldy1, d.y2, d.pool = None, 0, y2c.data_ptr(), poolc.data_ptr()
+    check(lib.fx_pw_chain_bf16(C.byref(d), stream()), "pw_chain without y1")
+    torch.cuda.synchronize()
+    assert torch.equal(y2c[:M], y2b[:M]) and torch.isnan(y2c[M:].float()).all()
+    assert torch.equal(poolc[: M // 4], pool[: M // 4]) and torch.isnan(poolc[M // 4:].float()).all()
+    d.pool = None            # ... but only where y2 and the pooled tensor carry it on
+    assert lib.fx_pw_chain_bf16(C.byref(d), stream()) == -1
+    d.pool, d.y1, d.ldy1 = poolc.data_ptr(), y1b.data_ptr(), N1
     d.img_h = H + 1   # odd height: refused
     assert lib.fx_pw_chain_bf16(C.byref(d), stream()) == -1
 
