@@ -2,7 +2,7 @@
 # round-5 final numbers (what profiles/r05z_* is copied from): the default bench line (with other_configs and the CPU baseline) + per-op table,
 # rocprofv3 kernel stats and calibrated PMC HBM traffic of the headline, the training steps of the three families (+ kernel stats),
 # MaskFormer / BiSeNetFormer inference with per-op tables
-TAG=r05z
+TAG=${TAG:-r05z}
 out=$PWD/gpurun_out/$TAG; mkdir -p $out
 ROOT=$PWD
 export TMPDIR=/tmp
