@@ -87,18 +87,31 @@ __global__ __launch_bounds__(256, ((N2 <= 64 && K1B == 0) ? 4 : ((N2 <= 128 && (
   const int NG = p.N1 >> 8;
   const int KS2 = p.N1 >> 4;  // k-steps of GEMM2 over all of N1
 
-  // pixel of tile row `row` (-1: beyond the tensor)
-  const int W2 = p.W >> 1, QI = (p.H >> 1) * W2;
+  // pixel of tile row `row` (-1: beyond the tensor).  QUAD: a table of the tile's 64 pixels in LDS, filled once by the first wave (round 5).
+  // The map costs two runtime divisions, and every DMA instruction and every 16-byte store of the kernel asks for it: ~50 divisions per
+  // thread and tile = ~1 700 VALU instructions per wave in front of the addresses, against ~48 MFMAs - the quad launches moved 3.2 TB/s
+  // where the flat form of the same layers moves 4.8.
+  __shared__ int s_pix[QUAD ? BM : 1];
+  if constexpr (QUAD) {
+    if (tid < BM) {
+      const int W2 = p.W >> 1, QI = (p.H >> 1) * W2;
+      const int q = blockIdx.x * (BM / 4) + (tid >> 2), sub = tid & 3;
+      int m = -1;
+      if (q * 4 < p.M) {
+        const int b = q / QI, rem = q - b * QI;
+        const int y2 = rem / W2, x2 = rem - y2 * W2;
+        m = (b * p.H + 2 * y2 + (sub >> 1)) * p.W + 2 * x2 + (sub & 1);
+      }
+      s_pix[tid] = m;
+    }
+    __syncthreads();
+  }
   auto pix = [&](int row) -> int {
     if constexpr (!QUAD) {
       const int m = m0 + row;
       return m < p.M ? m : -1;
     } else {
-      const int q = blockIdx.x * (BM / 4) + (row >> 2), sub = row & 3;
-      if (q * 4 >= p.M) return -1;
-      const int b = q / QI, rem = q - b * QI;
-      const int y2 = rem / W2, x2 = rem - y2 * W2;
-      return (b * p.H + 2 * y2 + (sub >> 1)) * p.W + 2 * x2 + (sub & 1);
+      return s_pix[row];
     }
   };
   const __amdgpu_buffer_rsrc_t x1r = __builtin_amdgcn_make_buffer_rsrc((void*)p.x1, 0, p.x1_bytes, 0x00020000);

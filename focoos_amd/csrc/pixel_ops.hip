@@ -292,44 +292,49 @@ extern "C" int fx_resize_bilinear_u8(const uint8_t* x, int H, int W, float* y, i
   return fx_launch_status();
 }
 
+// One workgroup = 256 consecutive (column, 8-channel vector) slots of ONE output row: the row (image, ho) comes from the block index with two
+// 32-bit divisions per WORKGROUP, a thread's column and vector from one shift (C8 a power of two) or one 32-bit division.  (Until round 5 every
+// thread decomposed a flat 64-bit index with three 64-bit divisions - ~300 VALU instructions in front of four loads and a store: the 40 -> 80
+// up-sampling of the hybrid encoder took 28.8 us for 65 MB.)
 __global__ __launch_bounds__(256) void resize_nhwc_kernel(const bf16_t* __restrict__ x, int ldx, bf16_t* __restrict__ y, int ldy, int B,
-                                                           int H, int W, int C8, int Ho, int Wo, float sh, float sw) {
-  int64_t total = (int64_t)B * Ho * Wo * C8;
+                                                           int H, int W, int C8, int c8_shift, int bpr, int Ho, int Wo, float sh, float sw) {
   // XCD-aware block order (round 5): consecutive blocks are dealt round-robin to the 8 XCDs, each with its own L2, and vertically adjacent
   // output rows share an input row - in launch order every XCD fetched its own copy of it (PMC: 318 MB read for a 210 MB tensor).  With the
   // remap an XCD owns a contiguous band of output rows and the shared rows are re-fetched only at the eight band seams.
-  const int bid = fx_xcd_remap(blockIdx.x, gridDim.x);
-  for (int64_t i = (int64_t)bid * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    int c8 = (int)(i % C8);
-    int64_t p = i / C8;
-    int wo = (int)(p % Wo);
-    int64_t q = p / Wo;
-    int ho = (int)(q % Ho), b = (int)(q / Ho);
-    int h0, h1, w0, w1;
-    float lh0, lh1, lw0, lw1;
-    bilinear_src(ho, sh, H, h0, h1, lh0, lh1);
-    bilinear_src(wo, sw, W, w0, w1, lw0, lw1);
-    const bf16_t* base = x + (int64_t)b * H * W * ldx + c8 * 8;
-    float f00[8], f01[8], f10[8], f11[8], o[8];
-    unpack_bf16x8(*reinterpret_cast<const uint4*>(base + ((int64_t)h0 * W + w0) * ldx), f00);
-    unpack_bf16x8(*reinterpret_cast<const uint4*>(base + ((int64_t)h0 * W + w1) * ldx), f01);
-    unpack_bf16x8(*reinterpret_cast<const uint4*>(base + ((int64_t)h1 * W + w0) * ldx), f10);
-    unpack_bf16x8(*reinterpret_cast<const uint4*>(base + ((int64_t)h1 * W + w1) * ldx), f11);
+  const unsigned bid = (unsigned)fx_xcd_remap(blockIdx.x, gridDim.x);
+  const unsigned row = bid / (unsigned)bpr;                       // (image, output row): uniform
+  const unsigned t = (bid - row * (unsigned)bpr) * 256u + threadIdx.x;
+  if (t >= (unsigned)(Wo * C8)) return;
+  const unsigned b = row / (unsigned)Ho, ho = row - b * (unsigned)Ho;
+  const unsigned wo = c8_shift >= 0 ? t >> c8_shift : t / (unsigned)C8;
+  const unsigned c8 = t - wo * (unsigned)C8;
+  int h0, h1, w0, w1;
+  float lh0, lh1, lw0, lw1;
+  bilinear_src((int)ho, sh, H, h0, h1, lh0, lh1);
+  bilinear_src((int)wo, sw, W, w0, w1, lw0, lw1);
+  const bf16_t* base = x + (int64_t)b * H * W * ldx + c8 * 8;
+  float f00[8], f01[8], f10[8], f11[8], o[8];
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(base + ((int64_t)h0 * W + w0) * ldx), f00);
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(base + ((int64_t)h0 * W + w1) * ldx), f01);
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(base + ((int64_t)h1 * W + w0) * ldx), f10);
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(base + ((int64_t)h1 * W + w1) * ldx), f11);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = lh0 * (lw0 * f00[j] + lw1 * f01[j]) + lh1 * (lw0 * f10[j] + lw1 * f11[j]);
-    *reinterpret_cast<uint4*>(y + p * ldy + c8 * 8) = pack_bf16x8(o);
-  }
+  for (int j = 0; j < 8; ++j) o[j] = lh0 * (lw0 * f00[j] + lw1 * f01[j]) + lh1 * (lw0 * f10[j] + lw1 * f11[j]);
+  *reinterpret_cast<uint4*>(y + ((int64_t)row * Wo + wo) * ldy + c8 * 8) = pack_bf16x8(o);
 }
 
 extern "C" int fx_resize_bilinear_nhwc_bf16(const void* x, int ldx, void* y, int ldy, int B, int H, int W, int C, int Ho, int Wo,
                                             fx_stream_t stream_) {
   FX_CHECK_ARG(x && y && B > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && C > 0 && C % 8 == 0);
   FX_CHECK_ARG(ldx >= C && ldy >= C && ldx % 8 == 0 && ldy % 8 == 0);
-  int64_t total = (int64_t)B * Ho * Wo * (C / 8);
-  int64_t grid = (total + 255) / 256;
-  if (grid > 256 * 32) grid = 256 * 32;
-  hipLaunchKernelGGL(resize_nhwc_kernel, dim3((int)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)x, ldx,
-                     (bf16_t*)y, ldy, B, H, W, C / 8, Ho, Wo, (float)H / (float)Ho, (float)W / (float)Wo);
+  const int C8 = C / 8;
+  const int64_t per_row = (int64_t)Wo * C8;
+  const int64_t bpr = (per_row + 255) / 256;
+  const int64_t grid = (int64_t)B * Ho * bpr;
+  if (per_row >= (1ll << 31) || grid >= (1ll << 31)) return FX_ERR_UNSUPPORTED;
+  const int shift = (C8 & (C8 - 1)) == 0 ? __builtin_ctz((unsigned)C8) : -1;
+  hipLaunchKernelGGL(resize_nhwc_kernel, dim3((unsigned)grid), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)x, ldx,
+                     (bf16_t*)y, ldy, B, H, W, C8, shift, (int)bpr, Ho, Wo, (float)H / (float)Ho, (float)W / (float)Wo);
   return fx_launch_status();
 }
 

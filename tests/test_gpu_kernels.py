@@ -240,7 +240,7 @@ def test_resize_u8(lib, hw):
     assert (y.cpu() - ref).abs().max() < 2e-3  # values 0..255, fp32 arithmetic in both
 
 
-@pytest.mark.parametrize("cfg", [(2, 20, 20, 256, 40, 40), (2, 40, 40, 256, 20, 20), (1, 6, 10, 64, 3, 5), (1, 5, 7, 64, 10, 14)])
+@pytest.mark.parametrize("cfg", [(2, 20, 20, 256, 40, 40), (2, 40, 40, 256, 20, 20), (1, 6, 10, 64, 3, 5), (1, 5, 7, 64, 10, 14), (3, 41, 33, 96, 80, 67)])
 def test_resize_nhwc_and_maxpool(lib, cfg):
     B, H, W, Cc, Ho, Wo = cfg
     g = torch.Generator().manual_seed(2)
