@@ -83,27 +83,54 @@ extern "C" int fx_dwconv3x3s2_nhwc_f32out(const void* x, int ldx, const float* w
 // ------------------------------------------------------------------------------------------------
 // mean[b][c] = (1/P) sum_p x[b,p,c]   (feat.mean(dim=(2,3)) / adaptive_avg_pool2d(feat, 1)); f32 output.  One workgroup per
 // (image, 64-channel group): 8 lanes x 8 channels across, 32 lanes down the pixels, fixed-order LDS tree -> deterministic.
-__global__ __launch_bounds__(256) void global_mean_kernel(const bf16_t* __restrict__ x, int ldx, float* __restrict__ out, int ldo, int P, int C) {
-  __shared__ float part[32][64];
+// 1024 threads per (image, 64-channel group) since round 5: 128 pixel lanes x 8 channel vectors, four independent loads in flight per
+// lane - the 256-thread form walked 6 400 pixels with 32 lanes and one load at a time (56 us for the 105 MB of the feature-fusion mean:
+// 64 workgroups cannot draw more than 0.9 TB/s that way).  Fixed summation order: lane partials (pixels p, p + 128, ... in order, four
+// interleaved accumulators folded ((a0 + a1) + (a2 + a3))), then the 128 lanes in order.
+#define GM_THREADS 1024
+#define GM_LANES (GM_THREADS / 8)
+__global__ __launch_bounds__(GM_THREADS) void global_mean_kernel(const bf16_t* __restrict__ x, int ldx, float* __restrict__ out, int ldo, int P, int C) {
+  __shared__ float part[GM_LANES][64];
   const int b = blockIdx.y, cg = threadIdx.x & 7, pl = threadIdx.x >> 3;
   const int c0 = blockIdx.x * 64 + cg * 8;
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float acc[4][8];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[u][j] = 0.0f;
   if (c0 < C) {
     const bf16_t* xb = x + (int64_t)b * P * ldx + c0;
-    for (int p = pl; p < P; p += 32) {
+    int p = pl;
+    for (; p + 3 * GM_LANES < P; p += 4 * GM_LANES) {
+      uint4 r[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) r[u] = *reinterpret_cast<const uint4*>(xb + (int64_t)(p + u * GM_LANES) * ldx);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float v[8];
+        unpack_bf16x8(r[u], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[u][j] += v[j];
+      }
+    }
+    for (int u = 0; p < P; p += GM_LANES, ++u) {   // at most three left: they continue the interleaving
       float v[8];
       unpack_bf16x8(*reinterpret_cast<const uint4*>(xb + (int64_t)p * ldx), v);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) acc[j] += v[j];
+      for (int j = 0; j < 8; ++j) {
+        if (u == 0) acc[0][j] += v[j];
+        else if (u == 1) acc[1][j] += v[j];
+        else acc[2][j] += v[j];
+      }
     }
   }
 #pragma unroll
-  for (int j = 0; j < 8; ++j) part[pl][cg * 8 + j] = acc[j];
+  for (int j = 0; j < 8; ++j) part[pl][cg * 8 + j] = (acc[0][j] + acc[1][j]) + (acc[2][j] + acc[3][j]);
   __syncthreads();
   if (threadIdx.x < 64) {
     float s = 0.0f;
-#pragma unroll
-    for (int i = 0; i < 32; ++i) s += part[i][threadIdx.x];
+#pragma unroll 8
+    for (int i = 0; i < GM_LANES; ++i) s += part[i][threadIdx.x];
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c < C) out[(int64_t)b * ldo + c] = s / (float)P;
   }
@@ -111,7 +138,7 @@ __global__ __launch_bounds__(256) void global_mean_kernel(const bf16_t* __restri
 
 extern "C" int fx_global_mean_nhwc_bf16(const void* x, int ldx, float* out, int ldo, int B, int P, int C, fx_stream_t stream_) {
   FX_CHECK_ARG(x && out && B > 0 && P > 0 && C > 0 && C % 8 == 0 && ldx >= C && ldx % 8 == 0 && ldo >= C && ((uintptr_t)x % 16) == 0);
-  hipLaunchKernelGGL(global_mean_kernel, dim3((C + 63) / 64, B), dim3(256), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)x, ldx, out,
+  hipLaunchKernelGGL(global_mean_kernel, dim3((C + 63) / 64, B), dim3(GM_THREADS), 0, reinterpret_cast<hipStream_t>(stream_), (const bf16_t*)x, ldx, out,
                      ldo, P, C);
   return fx_launch_status();
 }
