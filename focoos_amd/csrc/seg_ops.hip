@@ -82,7 +82,7 @@ extern "C" int fx_dwconv3x3s2_nhwc_f32out(const void* x, int ldx, const float* w
 
 // ------------------------------------------------------------------------------------------------
 // mean[b][c] = (1/P) sum_p x[b,p,c]   (feat.mean(dim=(2,3)) / adaptive_avg_pool2d(feat, 1)); f32 output.  One workgroup per
-// (image, 64-channel group): 8 lanes x 8 channels across, 32 lanes down the pixels, fixed-order LDS tree -> deterministic.
+// (image, 64-channel group): 8 lanes x 8 channels across, 128 lanes down the pixels, fixed-order LDS tree -> deterministic.
 // 1024 threads per (image, 64-channel group) since round 5: 128 pixel lanes x 8 channel vectors, four independent loads in flight per
 // lane - the 256-thread form walked 6 400 pixels with 32 lanes and one load at a time (56 us for the 105 MB of the feature-fusion mean:
 // 64 workgroups cannot draw more than 0.9 TB/s that way).  Fixed summation order: lane partials (pixels p, p + 128, ... in order, four
