@@ -6,9 +6,14 @@
 
 ``register()`` re-registers ``ModelFamily.DETR`` (and ``ModelFamily.MASKFORMER``) through the reference's own
 ``ModelManager.register_model`` (focoos/model_manager.py:93-105) with a subclass of the reference's ``FAIDetr`` whose
-parameters / ``state_dict()`` / training path are untouched (it still IS the reference module, so checkpoints, EMA, DDP
-wrapping, ``.export()`` keep working) and whose **eval-mode forward** is the HIP engine.  Weights are re-packed lazily
-whenever the module's parameters changed (``load_state_dict``, training steps).
+parameters / ``state_dict()`` are untouched (it still IS the reference module, so checkpoints, EMA and DDP wrapping keep working)
+and whose forward - eval AND train - is the HIP engine.  Weights are re-packed lazily whenever the module's parameters changed
+(``load_state_dict``, training steps).
+``.export()`` (models/focoos_model.py:418-573) needs a graph a tracer can record, and the ctypes engine is opaque to ``torch.jit.trace`` /
+``torch.onnx.export`` (its outputs are fresh tensors with no graph edge to the input).  ``ExportableModel`` (focoos_model.py:40-85) deep-copies
+the model and calls ``switch_to_export`` on the copy: the adapters override that hook to mark the COPY as an export model, and a marked copy
+(or any forward running under a tracer) delegates to the reference's stock module graph - the one legitimate ``super().forward`` of this file
+("export() may internally fall back to stock modules").  The live model the user keeps is never marked.
 The function-pointer seam ``MSDeformableAttention.ms_deformable_attn_core`` (fai_detr/modelling.py:806) can be bound to
 ``fx_msda_bf16`` separately with ``bind_msda_core(model)`` for no-grad use of the stock module graph.
 """
@@ -86,6 +91,20 @@ class _FxAdapterState:
 
     _FX_TRANSIENT = ("_fx_engine", "_fx_version", "_fx_train")
 
+    def switch_to_export(self, test_cfg=None, device="cuda"):
+        """``ExportableModel.__init__`` (models/focoos_model.py:72-74) calls this on its deep copy of the model right before tracing it: from here
+        on THIS object is an export model and its forward is the reference's stock graph (see ``_fx_exporting``)."""
+        self.__dict__["_fx_export"] = True
+        self.__dict__["_fx_engine"] = None       # an export copy never runs the engine: do not keep plans / HBM buffers alive
+        self.__dict__["_fx_version"] = None
+        self.__dict__.pop("_fx_train", None)
+        return super().switch_to_export(test_cfg=test_cfg, device=device)
+
+    def _fx_exporting(self) -> bool:
+        """True when the forward must be recordable by a tracer: the module was marked by ``switch_to_export`` (FocoosModel.export's deep
+        copy) or a TorchScript / ONNX trace is running."""
+        return bool(self.__dict__.get("_fx_export")) or torch.jit.is_tracing() or torch.onnx.is_in_onnx_export()
+
     def __getstate__(self):
         st = self.__dict__.copy()
         st["_fx_engine"] = None
@@ -118,12 +137,14 @@ def __getattr__(name):
     raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
 
 
-def _mask_family_forward(self, images, targets, OutputCls):
+def _mask_family_forward(self, images, targets, OutputCls, stock_forward):
     """Shared forward of the two mask-family adapters - every branch of FAIMaskFormer.forward (fai_mf/modelling.py:712-725) /
     BisenetFormer.forward (bisenetformer/modelling.py:594-621) on the engine, none on the reference's stock graph:
     train + targets -> losses of the HIP training graph + the last head's probabilities (not upsampled); train without targets -> the same
     forward, loss None; eval -> the inference engine (masks at input resolution); eval + targets -> the engine's outputs AND the losses
     of the training graph in eval mode (frozen statistics; MaskFormerHead.forward computes them whenever targets are given, :603-609)."""
+    if self._fx_exporting():
+        return stock_forward(images, targets)     # export copy / tracer running: the reference's own graph (module docstring)
     _require_engine_input(images, 1)   # any size >= 32 (ceil-size arithmetic); raises otherwise
     x = images
     if x.dim() == 4 and x.shape[1] == 3 and x.shape[-1] != 3:
@@ -194,6 +215,8 @@ def make_engine_class():
             return g[0]
 
         def forward(self, images, targets=[]):
+            if self._fx_exporting():
+                return super().forward(images, targets)   # export copy / tracer running: the reference's own graph (module docstring)
             _require_engine_input(images)   # raises for < 32 / input gradients: no fallback to the reference's own graph
             x = images
             if x.dim() == 4 and x.shape[1] == 3 and x.shape[-1] != 3:
@@ -257,7 +280,7 @@ def make_mf_engine_class():
             return g[0]
 
         def forward(self, images, targets=[]):
-            return _mask_family_forward(self, images, targets, MaskFormerModelOutput)
+            return _mask_family_forward(self, images, targets, MaskFormerModelOutput, super().forward)
 
     return _publish(EngineFAIMaskFormer)
 
@@ -303,7 +326,7 @@ def make_bf_engine_class():
             return g[0]
 
         def forward(self, images, targets=[]):
-            return _mask_family_forward(self, images, targets, BisenetFormerOutput)
+            return _mask_family_forward(self, images, targets, BisenetFormerOutput, super().forward)
 
     return _publish(EngineBisenetFormer)
 
