@@ -209,6 +209,22 @@ def set_compute_dtype(name: str) -> str:
     return prev
 
 
+class using_compute_dtype:
+    """Scoped ``set_compute_dtype``: the previous element type is restored on exit, exception or not (a step or a training run
+    that pins its type must not leave the process in it - a later lazy ``load()`` would pick the other library)."""
+
+    def __init__(self, name: str):
+        self.name, self.prev = name, None
+
+    def __enter__(self):
+        self.prev = set_compute_dtype(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        _DTYPE[0] = self.prev
+        return False
+
+
 def act_dtype():
     """torch dtype of activations, packed weight images and activation gradients under the current element type."""
     import torch
@@ -216,8 +232,8 @@ def act_dtype():
     return torch.float16 if _DTYPE[0] == "fp16" else torch.bfloat16
 
 
-def lib_path() -> str:
-    if _DTYPE[0] == "fp16":
+def lib_path(name: str = None) -> str:
+    if (name or _DTYPE[0]) == "fp16":
         return os.environ.get("FOCOOS_AMD_LIB_FP16", LIB_PATH_FP16)
     return os.environ.get("FOCOOS_AMD_LIB", LIB_PATH)
 
@@ -225,13 +241,14 @@ def lib_path() -> str:
 FX_ABI_VERSION = 7   # = include/focoos_amd.h (tests/test_host_cpu.py compares the two)
 
 
-def load() -> C.CDLL:
-    """Load the HIP library of the current element type; raise loudly when it is absent (no fallback)."""
-    name = _DTYPE[0]
+def load(name: str = None) -> C.CDLL:
+    """Load the HIP library of the current element type (or of ``name``: the inference-side processors always bind the bf16 product library,
+    whatever type a training step of the same process pinned); raise loudly when it is absent (no fallback)."""
+    name = name or _DTYPE[0]
     if name in _libs:
         return _libs[name]
     import torch  # noqa: F401  -- must be imported first: it loads the HIP runtime (its bundled libamdhip64) our .so binds to
-    path = lib_path()
+    path = lib_path(name)
     if not os.path.exists(path):
         raise FocoosAmdError(
             f"{path} not found: the gfx950 HIP kernels are not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "

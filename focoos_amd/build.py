@@ -37,7 +37,46 @@ def _pk_units():
 
 
 def _stamp() -> str:
-    return "arch=%s pk_units=%s" % (ARCH, ",".join(sorted(_pk_units())) or "-")
+    return "arch=%s pk_units=%s extra=%s" % (ARCH, ",".join(sorted(_pk_units())) or "-", " ".join(EXTRA_FLAGS) or "-")
+
+
+def _flags_key(flags) -> str:
+    """What an object was compiled with (everything of its command line but the paths) + this recipe's mtime: kept in `<obj>.flags` so that an
+    object left behind by a failed / interrupted build under OTHER flags (FX_PK_F32=1 ...) is never linked into a default library - the
+    stamp of the last COMPLETED build says nothing about such objects; an edit of this recipe recompiles everything."""
+    import hashlib
+
+    with open(os.path.abspath(__file__), "rb") as f:     # content, not mtime: the snapshot on a GPU box need not keep file times
+        return " ".join(flags) + " recipe=" + hashlib.sha1(f.read()).hexdigest()[:12]
+
+
+def _obj_fresh(obj: str, src: str, hdr_t: float, key: str) -> bool:
+    side = obj + ".flags"
+    if not (os.path.exists(obj) and os.path.exists(side)) or os.path.getmtime(obj) < max(os.path.getmtime(src), hdr_t):
+        return False
+    with open(side) as f:
+        return f.read().strip() == key
+
+
+def _compile_jobs(hipcc, objdir, pk, force, hdr_t, fp16):
+    """(objects, jobs, sidecars): one compile job per stale unit; the sidecar of a unit is written only after ITS compile succeeded."""
+    objs, jobs, sides = [], [], []
+    for src in sources():
+        base = os.path.basename(src)
+        obj = os.path.join(objdir, base.replace(".hip", ".o"))
+        objs.append(obj)
+        flags = ([] if base in pk else NO_PK_FLAGS) + (["-DFX_FP16=1"] if fp16 else [])
+        if base == "runtime.hip":
+            flags = flags + [f"-DFX_BUILD_FLAGS={1 if pk else 0}"]
+        flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + flags + EXTRA_FLAGS
+        key = _flags_key(flags)
+        if not force and _obj_fresh(obj, src, hdr_t, key):
+            continue
+        if os.path.exists(obj + ".flags"):
+            os.remove(obj + ".flags")
+        jobs.append([hipcc] + flags + ["-c", src, "-o", obj])
+        sides.append((obj + ".flags", key))
+    return objs, jobs, sides
 
 
 def _hipcc() -> str:
@@ -75,30 +114,17 @@ def build(force: bool = False, verbose: bool = True, out_path: str = None, fp16:
     os.makedirs(LIB_DIR, exist_ok=True)
     objdir = LIB_DIR if out_path is None else (target + ".obj")
     os.makedirs(objdir, exist_ok=True)
-    objs = []
     hipcc = _hipcc()
     pk = _pk_units()
-    # per-unit incremental build: a unit is recompiled when its object is missing or older than its source / any header, or when the
-    # flag stamp changed; stale units compile in parallel (hipcc takes 5-60 s per unit)
+    # per-unit incremental build: a unit is recompiled when its object is missing, older than its source / any header, or was compiled
+    # with other flags (its `.flags` sidecar); stale units compile in parallel (hipcc takes 5-60 s per unit).  The stamp of the product
+    # library is removed BEFORE compiling and written only after a successful link.
     headers = glob.glob(os.path.join(CSRC, "*.h")) + glob.glob(os.path.join(PKG, "..", "include", "*.h"))
     hdr_t = max(os.path.getmtime(h) for h in headers)
-    stamp_ok = False
     if out_path is None and os.path.exists(STAMP_PATH):
-        with open(STAMP_PATH) as f:
-            stamp_ok = f.read().strip() == _stamp()
-    jobs = []
-    for src in sources():
-        base = os.path.basename(src)
-        obj = os.path.join(objdir, base.replace(".hip", ".o"))
-        objs.append(obj)
-        fresh = (not force and stamp_ok and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t))
-        if fresh:
-            continue
-        flags = [] if base in pk else NO_PK_FLAGS
-        if base == "runtime.hip":
-            flags = flags + [f"-DFX_BUILD_FLAGS={1 if pk else 0}"]
-        jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + flags + EXTRA_FLAGS + ["-c", src, "-o", obj])
-    _run_jobs(jobs, verbose)
+        os.remove(STAMP_PATH)
+    objs, jobs, sides = _compile_jobs(hipcc, objdir, pk, force, hdr_t, False)
+    _run_jobs(jobs, verbose, sides)
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", target] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
@@ -123,19 +149,10 @@ def _build_fp16(force: bool, verbose: bool) -> str:
         return LIB_PATH_FP16
     hipcc, pk = _hipcc(), _pk_units()
     hdr_t = max(os.path.getmtime(h) for h in deps if h.endswith(".h"))
-    stamp_ok = os.path.exists(stamp) and open(stamp).read().strip() == _stamp() + " fp16"
-    jobs, objs = [], []
-    for src in sources():
-        base = os.path.basename(src)
-        obj = os.path.join(objdir, base.replace(".hip", ".o"))
-        objs.append(obj)
-        if not force and stamp_ok and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_t):
-            continue
-        flags = ([] if base in pk else NO_PK_FLAGS) + ["-DFX_FP16=1"]
-        if base == "runtime.hip":
-            flags = flags + [f"-DFX_BUILD_FLAGS={1 if pk else 0}"]
-        jobs.append([hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC"] + flags + EXTRA_FLAGS + ["-c", src, "-o", obj])
-    _run_jobs(jobs, verbose)
+    if os.path.exists(stamp):
+        os.remove(stamp)
+    objs, jobs, sides = _compile_jobs(hipcc, objdir, pk, force, hdr_t, True)
+    _run_jobs(jobs, verbose, sides)
     cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH_FP16] + objs
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
@@ -145,7 +162,8 @@ def _build_fp16(force: bool, verbose: bool) -> str:
     return LIB_PATH_FP16
 
 
-def _run_jobs(jobs, verbose):
+def _run_jobs(jobs, verbose, sides=()):
+    sides = dict(zip((tuple(j) for j in jobs), sides))
     running = []
     nproc = max(1, min(int(os.environ.get("FX_BUILD_JOBS", os.cpu_count() or 4)), 16))
     failed = None
@@ -158,8 +176,15 @@ def _run_jobs(jobs, verbose):
         cmd, pr = running.pop(0)
         if pr.wait() != 0:
             failed = cmd
-    for _, pr in running:
-        pr.wait()
+        elif tuple(cmd) in sides:
+            path, key = sides[tuple(cmd)]
+            with open(path, "w") as f:
+                f.write(key + "\n")
+    for cmd, pr in running:
+        if pr.wait() == 0 and tuple(cmd) in sides:
+            path, key = sides[tuple(cmd)]
+            with open(path, "w") as f:
+                f.write(key + "\n")
     if failed is not None:
         raise subprocess.CalledProcessError(1, failed)
 

@@ -215,10 +215,18 @@ __global__ __launch_bounds__((WN* WM + LD) * 64, LD ? 1 : 2) void conv3x3_kplane
       if (cc == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the first chunk (and the ring)
         stamp2();
+      } else if constexpr (!LD) {
+        // loader-less multi-chunk form (round 6): ONE halo buffer, every consumer fetches its share of the next chunk once all of them
+        // are done with the current one; the fetch's round trip is exposed to THIS workgroup and covered by the second workgroup of the
+        // CU (two waves per SIMD).  vmcnt(0) also lands the ring's first fragments of the chunk, so the counted waits of the tap loop
+        // never see an LDS-DMA in the queue (a zero-fill DMA may retire ahead of an older weight load: DESIGN_HISTORY, round 3).
+        __syncthreads();
+        dma_chunk(cc, smem, wave, NW);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
       __syncthreads();  // chunk cc has landed; every consumer is done with chunk cc-1 (the other buffer)
       stamp();
-      const int bufo = (cc & 1) * BUF;
+      const int bufo = LD ? (cc & 1) * BUF : 0;
       const int ccn = cc + 1 < NCH ? cc + 1 : cc;
       const int zaddr = zhalf + bufo;
       int addr[TM], addrn[TM];
@@ -389,8 +397,8 @@ static int launch_c3k(C3KArgs& a, hipStream_t stream) {
   constexpr int PLANE = (HLP + 1) * 16, BUF = 8 * PLANE;
   const int HL = BM + 2 * a.W + 2;
   a.HLp = (HL + 31) / 32 * 32;
-  if (a.HLp > HLP || a.C % 64 != 0 || a.N % BN != 0 || (!LD && a.C != 64)) return FX_ERR_UNSUPPORTED;
-  const int halo = (a.C > 64 ? 2 : 1) * BUF, tile = BM * BN * 2;
+  if (a.HLp > HLP || a.C % 64 != 0 || a.N % BN != 0) return FX_ERR_UNSUPPORTED;
+  const int halo = ((a.C > 64 && LD) ? 2 : 1) * BUF, tile = RESMODE ? BM * BN * 2 : 0;
   const int smem = halo > tile ? halo : tile;
   if (smem > 160 * 1024) return FX_ERR_UNSUPPORTED;
   auto kern = conv3x3_kplane_kernel<TN, TM, WN, WM, HLP, ACT, RESMODE, ABL, LD>;

@@ -287,8 +287,8 @@ __global__ FX_SEL_PK(1) __launch_bounds__(TOPK_THREADS) void topk_kernel(const f
     __syncthreads();
   }
   TOPK_STAMP(3);
-  // Order (value descending, index ascending) = descending order of the 64-bit entries, which are DISTINCT (the index is part of them):
-  // an entry's place is the number of entries greater than it.  One thread per (entry, slice of the list) - floor(1024 / k) slices, every
+  // Order (value descending, index ascending) = descending order of the 64-bit entries, which are distinct for real elements (the index is
+  // part of them): an entry's place is the number of entries greater than it (+ the equal ones in front of it, see the loop).  One thread per (entry, slice of the list) - floor(1024 / k) slices, every
   // thread on a real entry - and the slice is read with wave-uniform addresses where a wave lies inside one slice (LDS broadcast); nothing
   // in the loop depends on a previous LDS access: 100 reads + compares per thread for k = 300.  (Until round 5 a bitonic network sorted
   // the list in LDS: 45 dependent read-compare-write steps of ~500 ticks each, 22 000 of the launch's 55 000 ticks.)
@@ -301,7 +301,7 @@ __global__ FX_SEL_PK(1) __launch_bounds__(TOPK_THREADS) void topk_kernel(const f
     const int j0 = part * len, j1 = min(k, j0 + len);
     uint32_t r = 0;
 #pragma unroll 4
-    for (int j = j0; j < j1; ++j) r += (sel[j] > me) ? 1u : 0u;
+    for (int j = j0; j < j1; ++j) r += (sel[j] > me || (sel[j] == me && j < e)) ? 1u : 0u;   // equal entries (the two-level form's (-inf, INT_MAX) pads): LDS position breaks the tie, the places stay a permutation
     if (r) atomicAdd(&s_rank[e], r);
   }
   __syncthreads();

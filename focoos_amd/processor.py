@@ -100,7 +100,7 @@ class DETRProcessor:
             return batch, []
         if all(a.dtype != torch.uint8 and tuple(a.shape[:2]) == tgt for a in arrs):   # float images already at the target size
             return torch.stack([a.to(torch.float32) for a in arrs], 0).to(device, non_blocking=True), []
-        lib = _lib.load()
+        lib = _lib.load("bf16")   # inference surface: the bf16 product library whatever a training step pinned
         out = torch.empty(len(arrs), tgt[0], tgt[1], 3, dtype=torch.float32, device=device)
         stream = torch.cuda.current_stream(device).cuda_stream
         for i, a in enumerate(arrs):
@@ -141,7 +141,7 @@ class DETRProcessor:
         B, Q, K = output.logits.shape
         assert len(image_sizes) == B, f"Expected image sizes {len(image_sizes)} to match batch size {B}"
         dev = output.logits.device
-        lib = _lib.load()
+        lib = _lib.load("bf16")   # inference surface: the bf16 product library whatever a training step pinned
         probs = output.logits.contiguous()
         boxes = output.boxes.contiguous()
         tk = min(top_k, Q * K)
@@ -174,7 +174,7 @@ class DETRProcessor:
         dev = probs.device
         if dev.type != "cuda":
             raise _lib.FocoosAmdError("eval_postprocess runs the top-k on the GPU (fx_topk_rows_f32); no CPU fallback exists")
-        lib = _lib.load()
+        lib = _lib.load("bf16")   # inference surface: the bf16 product library whatever a training step pinned
         tk = min(top_k, Q * K)
         val = torch.empty(B, tk, dtype=torch.float32, device=dev)
         idx = torch.empty(B, tk, dtype=torch.int32, device=dev)
@@ -393,7 +393,7 @@ class MaskFormerProcessor(DETRProcessor):
         if any(tuple(sz) != (H, W) for sz in image_sizes):
             raise NotImplementedError("mask resize to a different original size is not on the engine path (the processor never resizes)")
         dev = masks.device
-        lib = _lib.load()
+        lib = _lib.load("bf16")   # inference surface: the bf16 product library whatever a training step pinned
         score, label = probs.max(-1)  # processor.py:212
         score, label = score.contiguous(), label.to(torch.int32).contiguous()
         res = _MfDeviceResults(B, Q, H, W, dev)

@@ -666,15 +666,15 @@ class TrainStep:
         return losses
 
     def step(self, images: torch.Tensor, targets: Sequence) -> Dict[str, torch.Tensor]:
-        _lib.set_compute_dtype(self.dtype_name)
-        if self.stream is None or not images.is_cuda:
-            return self._step(images, targets)
-        cur = torch.cuda.current_stream(images.device)
-        self.stream.wait_stream(cur)
-        with torch.cuda.stream(self.stream):
-            losses = self._step(images, targets)
-        cur.wait_stream(self.stream)
-        return losses
+        with _lib.using_compute_dtype(self.dtype_name):     # the step's own element type, restored when it returns or raises
+            if self.stream is None or not images.is_cuda:
+                return self._step(images, targets)
+            cur = torch.cuda.current_stream(images.device)
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                losses = self._step(images, targets)
+            cur.wait_stream(self.stream)
+            return losses
 
     def _auto_tick(self, images: torch.Tensor) -> None:
         """State machine of graphs="auto", called before every step (see __init__)."""
@@ -764,7 +764,7 @@ class TrainStep:
         backward with the gradient kernels accumulating straight into the flat views and the weight gradients on the side stream (joined
         before returning).  ``forced``: teacher-forcing arguments of the model's forward (forced_topk / forced_attn / fixed_matches)."""
         nn_ = self._nn
-        _lib.set_compute_dtype(self.dtype_name)
+        assert _lib.compute_dtype() == self.dtype_name    # pinned by step() / forward_backward()
         self.opt.zero_grad()
         for n, p in self.named:  # gradient kernels / autograd accumulate in place into these views
             p.grad = self.opt.grads[n]
@@ -792,14 +792,15 @@ class TrainStep:
         """``step()`` WITHOUT the all-reduce / optimizer / EMA: the production forward + backward (same routing, streams and buffers) leaving
         the gradients in ``self.opt.grads`` - what the parity tests at the BASELINE shapes compare with the oracle's gradients
         (tests/test_gpu_train_baseline_configs.py)."""
-        if self.stream is None or not images.is_cuda:
-            return self._forward_backward(images, targets, **forced)
-        cur = torch.cuda.current_stream(images.device)
-        self.stream.wait_stream(cur)
-        with torch.cuda.stream(self.stream):
-            losses = self._forward_backward(images, targets, **forced)
-        cur.wait_stream(self.stream)
-        return losses
+        with _lib.using_compute_dtype(self.dtype_name):
+            if self.stream is None or not images.is_cuda:
+                return self._forward_backward(images, targets, **forced)
+            cur = torch.cuda.current_stream(images.device)
+            self.stream.wait_stream(cur)
+            with torch.cuda.stream(self.stream):
+                losses = self._forward_backward(images, targets, **forced)
+            cur.wait_stream(self.stream)
+            return losses
 
     def check(self) -> None:
         """Poll and clear the Hungarian solver's device status word (criterion.raise_if_infeasible): a step whose matching costs were
@@ -811,3 +812,13 @@ class TrainStep:
         from .criterion import raise_if_infeasible
 
         raise_if_infeasible(self.opt.dev, all_ranks=True)
+        # The un-scaled (bf16) optimizer launch SKIPS an update whose gradients hold an inf / NaN and reports total_norm = inf
+        # (fx_adamw_step_f32); nothing else would tell a run that stopped training from one that trains.  Read at the same poll:
+        # the all-reduced gradients - hence the norm - are identical on every rank, so every rank raises together.  Under a loss scale
+        # (fp16) skipped steps are the scaler's normal operation and are counted on the device instead (FlatAdamW.scaler_state()).
+        if self.opt.scaler is None and self.opt.step_count > 0:
+            tn = float(self.opt.total_norm)
+            if tn != tn or tn == float("inf"):
+                raise FloatingPointError(f"focoos_amd.TrainStep: the gradients of optimizer step {self.opt.step_count} hold an inf / NaN (total norm {tn}); "
+                                         "the fused AdamW launch skipped the update (parameters and moments untouched). The run has diverged - "
+                                         "lower the learning rate or train under the fp16 loss scale")

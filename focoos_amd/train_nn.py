@@ -577,7 +577,8 @@ class _StemFn(torch.autograd.Function):
         lib = layer.lib
         layer.sync_packed()
         B, H, W_, _ = images.shape
-        y = torch.empty(B, H // 2, W_ // 2, 32, dtype=_lib.act_dtype(), device=images.device)
+        # ceil(H/2) x ceil(W/2): Conv2d(3, 32, 3, stride 2, padding 1) writes (H - 1) // 2 + 1 rows (pixel_ops.hip stem_launch) - odd sizes included
+        y = torch.empty(B, (H - 1) // 2 + 1, (W_ - 1) // 2 + 1, 32, dtype=_lib.act_dtype(), device=images.device)
         check(lib.fx_stem_conv3x3s2(images.data_ptr(), int(images.dtype == torch.float32), layer.stem_w.data_ptr(), layer.stem_b.data_ptr(),
                                     layer.px_mean.data_ptr(), layer.px_inv_std.data_ptr(), y.data_ptr(), B, H, W_, 32, _stream(images.device)),
               "fx_stem_conv3x3s2")
@@ -592,7 +593,7 @@ class _StemFn(torch.autograd.Function):
         images, y = ctx.saved_tensors
         dev = images.device
         B, H, W_, _ = images.shape
-        Ho, Wo = H // 2, W_ // 2
+        Ho, Wo = (H - 1) // 2 + 1, (W_ - 1) // 2 + 1
         st = _stream(dev)
         dy = dy.contiguous()
         dz = torch.empty_like(y)
@@ -608,7 +609,7 @@ class _StemTrainFn(torch.autograd.Function):
         lib = layer.lib
         layer.sync_packed()
         B, H, W_, _ = images.shape
-        z = torch.empty(B, H // 2, W_ // 2, 32, dtype=_lib.act_dtype(), device=images.device)
+        z = torch.empty(B, (H - 1) // 2 + 1, (W_ - 1) // 2 + 1, 32, dtype=_lib.act_dtype(), device=images.device)
         check(lib.fx_stem_conv3x3s2_linear(images.data_ptr(), int(images.dtype == torch.float32), layer.stem_w.data_ptr(), layer.stem_b.data_ptr(),
                                            layer.px_mean.data_ptr(), layer.px_inv_std.data_ptr(), z.data_ptr(), B, H, W_, 32,
                                            _stream(images.device)), "fx_stem_conv3x3s2_linear")
@@ -633,7 +634,7 @@ def _stem_wgrad(layer, images, dz, scale):
     check(lib.fx_normalize_pad8(images.data_ptr(), int(images.dtype == torch.float32), layer.px_mean.data_ptr(), layer.px_inv_std.data_ptr(),
                                 xn.data_ptr(), B * H * W_, st), "fx_normalize_pad8")
     dw_eff = ARENA.zeros((32, 3, 3, 8), dev)
-    check(lib.fx_conv2d_wgrad_nhwc_bf16(xn.data_ptr(), 8, dz.data_ptr(), 32, dw_eff.data_ptr(), B, H, W_, 8, H // 2, W_ // 2, 32, 3, 3, 2, 1, st),
+    check(lib.fx_conv2d_wgrad_nhwc_bf16(xn.data_ptr(), 8, dz.data_ptr(), 32, dw_eff.data_ptr(), B, H, W_, 8, (H - 1) // 2 + 1, (W_ - 1) // 2 + 1, 32, 3, 3, 2, 1, st),
           "fx_conv2d_wgrad_nhwc_bf16")
     dw = torch.empty(32, 3, 3, 3, dtype=torch.float32, device=dev)
     check(lib.fx_unpack_conv_wgrad_f32(dw_eff.data_ptr(), scale.data_ptr() if scale is not None else None, dw.data_ptr(), 32, 3, 3, 3, 8, 0, st),

@@ -103,33 +103,35 @@ def run_train(args: TrainerArgs, data_train, data_val, model, processor, model_i
 
     dtype = os.environ.get("FX_TRAIN_DTYPE", "bf16") if args.amp_enabled else "bf16"
     prev_dtype = _lib.set_compute_dtype(dtype)
-    net = trainable(model.config, norm=norm).to(dev)
-    net.load_state_dict(model.state_dict(), strict=True)
-    if args.init_checkpoint:
-        state = torch.load(args.init_checkpoint, map_location="cpu", weights_only=True)
-        net.load_state_dict(state.get("model", state), strict=False)
-    net.train()
-    stepper = TrainStep(net, lr=args.learning_rate, backbone_multiplier=args.backbone_multiplier, weight_decay=args.weight_decay,
-                        weight_decay_norm=args.weight_decay_norm, weight_decay_embed=args.weight_decay_embed, max_grad_norm=args.clip_gradients,
-                        ema_decay=args.ema_decay if args.ema_enabled else None, ema_warmups=args.ema_warmup, scheduler=args.scheduler,
-                        max_iters=args.max_iters, scheduler_extra=args.scheduler_extra)
-    bs = per_rank_batch_size(args.batch_size, world)
-    sampler = iter(TrainingSampler(len(data_train), shuffle=True, seed=args.seed, rank=rank, world_size=world))
-    processor.train(True)
-    losses: Dict[str, torch.Tensor] = {}
-    t0 = time.perf_counter()
-    for it in range(args.max_iters):
-        entries = [data_train[next(sampler)] for _ in range(bs)]
-        images, targets = processor.preprocess(entries, device=dev)
-        losses = stepper.step(images, targets)
-        if args.log_period and (it + 1) % args.log_period == 0:
-            stepper.check()    # every rank (MAX-all-reduced status): a diverged step (NaN / inf matching costs) ends the run as SciPy's error does in the reference
-        if rank == 0 and args.log_period and (it + 1) % args.log_period == 0:
-            tot = float(sum(v.detach().float() for v in losses.values()))
-            print(f"[focoos_amd.train] iter {it + 1}/{args.max_iters} total_loss {tot:.4f} {(time.perf_counter() - t0) / (it + 1) * 1e3:.1f} ms/iter", flush=True)
-    torch.cuda.synchronize(dev)
-    stepper.check()
-    _lib.set_compute_dtype(prev_dtype)
+    try:     # the run's element type is restored whatever ends the run (a raising stepper.check() used to leave the process in fp16)
+        net = trainable(model.config, norm=norm).to(dev)
+        net.load_state_dict(model.state_dict(), strict=True)
+        if args.init_checkpoint:
+            state = torch.load(args.init_checkpoint, map_location="cpu", weights_only=True)
+            net.load_state_dict(state.get("model", state), strict=False)
+        net.train()
+        stepper = TrainStep(net, lr=args.learning_rate, backbone_multiplier=args.backbone_multiplier, weight_decay=args.weight_decay,
+                            weight_decay_norm=args.weight_decay_norm, weight_decay_embed=args.weight_decay_embed, max_grad_norm=args.clip_gradients,
+                            ema_decay=args.ema_decay if args.ema_enabled else None, ema_warmups=args.ema_warmup, scheduler=args.scheduler,
+                            max_iters=args.max_iters, scheduler_extra=args.scheduler_extra)
+        bs = per_rank_batch_size(args.batch_size, world)
+        sampler = iter(TrainingSampler(len(data_train), shuffle=True, seed=args.seed, rank=rank, world_size=world))
+        processor.train(True)
+        losses: Dict[str, torch.Tensor] = {}
+        t0 = time.perf_counter()
+        for it in range(args.max_iters):
+            entries = [data_train[next(sampler)] for _ in range(bs)]
+            images, targets = processor.preprocess(entries, device=dev)
+            losses = stepper.step(images, targets)
+            if args.log_period and (it + 1) % args.log_period == 0:
+                stepper.check()    # every rank (MAX-all-reduced status): a diverged step (NaN / inf matching costs) ends the run as SciPy's error does in the reference
+            if rank == 0 and args.log_period and (it + 1) % args.log_period == 0:
+                tot = float(sum(v.detach().float() for v in losses.values()))
+                print(f"[focoos_amd.train] iter {it + 1}/{args.max_iters} total_loss {tot:.4f} {(time.perf_counter() - t0) / (it + 1) * 1e3:.1f} ms/iter", flush=True)
+        torch.cuda.synchronize(dev)
+        stepper.check()
+    finally:
+        _lib.set_compute_dtype(prev_dtype)
     out = {k: float(v.detach().float()) for k, v in losses.items()}
     if rank == 0:
         folder = os.path.join(args.output_dir, args.run_name.strip())

@@ -21,12 +21,14 @@ from tests.helpers import rel_l2  # noqa: E402
 DEV = "cuda:0"
 
 
-@pytest.mark.parametrize("norm,size", [("FrozenBN", None), ("BN", None), ("FrozenBN", (150, 200))])
+@pytest.mark.parametrize("norm,size", [("FrozenBN", None), ("BN", None), ("FrozenBN", (150, 200)), ("FrozenBN", (97, 130))])
 def test_detr_train_step_losses_and_gradients(norm, size):
     """norm="FrozenBN": BatchNorm on running statistics (freeze_bn); norm="BN": batch statistics + trainable affine +
     running-statistics update (the reference under plain .train()); the oracle is pinned against the reference in both.
     size (150, 200): not a multiple of 32 (round 5: a ragged training batch padded to its maximum) - ceil(H/2) levels in the forward and
-    in every adjoint (partial AvgPool2d(ceil_mode) windows, bilinear resizes between levels of non-integer ratio)."""
+    in every adjoint (partial AvgPool2d(ceil_mode) windows, bilinear resizes between levels of non-integer ratio).
+    size (97, 130): odd from the first layer on (the stem's output is ceil(H/2) x ceil(W/2) = 49 x 65 - the training stem used to
+    allocate floor sizes, an out-of-bounds write); 221 + 63 + 20 = 304 encoder tokens for the 300 queries."""
     from focoos_amd.train_detr import FAIDetrTrainable
 
     cfg = ModelRegistry.get_model_info("fai-detr-l-coco")["config"]
