@@ -98,6 +98,16 @@ __device__ __forceinline__ float fx_act(float x, int act) {
   }
 }
 
+// Issue-priority asymmetry between the workgroups that share a CU (round 6).  Kernels whose workgroups run two (or more) per CU start
+// together and, being bound by the same resource, advance in lockstep: load phase beside load phase, MFMA phase beside MFMA phase at half
+// rate each, store phase beside store phase - the co-residency then overlaps nothing.  Giving the wave in the even hardware slot of every
+// SIMD (HW_ID.wave_id, hwreg 4 bits 3:0) the higher priority lets one workgroup run its MFMA phase at full rate while the other fills the
+// gaps and owns the pipes during the first one's load / store phases.  Scalar (wave-uniform) branch, two instructions.
+__device__ __forceinline__ void fx_prio_by_hw_slot() {
+  const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1u;
+  if (slot) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
+}
+
 // XCD-aware bijective remap of a linear workgroup id (guide §5.5 T1): block b runs on XCD b%8;
 // give each XCD a contiguous chunk of the tile space so neighbouring tiles share one L2.
 __device__ __forceinline__ int fx_xcd_remap(int bid, int nwg) {

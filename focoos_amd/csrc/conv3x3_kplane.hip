@@ -126,6 +126,17 @@ __global__ __launch_bounds__((WN* WM + LD) * 64, LD ? 1 : 2) void conv3x3_kplane
     }
   };
 
+  if constexpr (!LD && (ABL & (32 | 128))) {
+    // Two workgroups of this form share a CU (two waves per SIMD).  Started together and both MFMA-bound they advance in lockstep - prologue
+    // beside prologue, K loop beside K loop at half speed each, epilogue beside epilogue - and the matrix pipe idles exactly where it idles
+    // for one workgroup.  A fixed issue priority breaks the symmetry: the favoured wave of a SIMD runs its K loop at full rate, the other
+    // one fills its gaps and owns the pipe during the favoured one's prologue / epilogue.  ABL & 32: by the wave's hardware slot
+    // (HW_ID.wave_id parity); ABL & 128: by the parity of blockIdx.x / 256 (the dispatcher fills every CU once before the second slot).
+    // Measured (profiles/r06_c3_duo_probe.txt): +-1 % either way - the two workgroups are NOT held back by lockstep; the form's 3-4 % over the
+    // loader-wave kernel at M >= 51 200 is all the co-residency gives, and at M = 25 600 (200 tiles: one workgroup per CU) it is 6 % slower.
+    if constexpr (ABL & 32) fx_prio_by_hw_slot();
+    else if ((blockIdx.x >> 8) & 1u) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
+  }
   if (is_loader) {
     // the zero row of every plane of both buffers (published by the first barrier; the DMA never touches row HLP)
     if (lane < (NCH > 1 ? 16 : 8)) *reinterpret_cast<uint4*>(smem + (lane >> 3) * BUF + (lane & 7) * PLANE + HLP * 16) = make_uint4(0, 0, 0, 0);

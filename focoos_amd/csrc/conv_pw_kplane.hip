@@ -33,6 +33,7 @@ struct PWKArgs {
   int HW;             // pixels per image
   int64_t y_bstride;  // elements between images of y (0: contiguous)
   unsigned x_bytes, r_bytes;
+  int rot;            // 1: workgroup i walks its n-tiles starting at tile i % count (round 6, see the kernel)
 };
 
 template <int OFF>
@@ -52,9 +53,13 @@ __device__ __forceinline__ float pwk_act(float v, std::integral_constant<int, FX
 // 128 pixels x 64 channels).  RESMODE: 0 none, 1 act(conv + residual), 3 act(conv) * (residual > 0).  Four waves at <= 256
 // registers, so that TWO workgroups share a CU when the pixel tile is 64 KiB (K = 256): one's epilogue (residual loads, conversion,
 // stores - nothing for the matrix cores) runs beside the other's K loop.
-template <int K, int ACT, int RESMODE>
-__global__ __launch_bounds__(256, 2) void conv_pw_kplane_kernel(const PWKArgs p) {
-  constexpr int TN = 2, TM = 4, NW = 4, BM = 128, BN = 256;
+// TM: 32-pixel blocks per wave = pixel tile / 32.  4 (128 pixels, two workgroups per CU) or - round 6 - 2 (64 pixels: 32 KiB of LDS at
+// K = 256 and <= 168 registers, THREE workgroups per CU: these layers are HBM-bound, and what a CU can keep in flight towards memory is set by
+// the number of waves that are in a load / store phase, not by its MFMA rate - at 64 pixels a wave issues one memory instruction per MFMA,
+// which would cap an MFMA-bound kernel at half rate and costs nothing here).
+template <int K, int ACT, int RESMODE, int TM = 4>
+__global__ __launch_bounds__(256, TM == 4 ? 2 : 3) void conv_pw_kplane_kernel(const PWKArgs p) {
+  constexpr int TN = 2, NW = 4, BM = TM * 32, BN = 256;
   constexpr int NTHR = 256, NDW = NTHR / 64;
   constexpr int KS = K / 16;                 // k16 steps
   constexpr int PLANE = BM * 16, XBYTES = 2 * KS * PLANE;   // = BM * K * 2
@@ -70,6 +75,12 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kplane_kernel(const PWKArgs p)
   const int m0 = fx_xcd_remap(blockIdx.x, gridDim.x) * BM;
   const int nt_first = blockIdx.y * p.ntg;
   const int NT = min(p.N / BN, nt_first + p.ntg);   // this workgroup's n-tiles: [nt_first, NT)
+  // Rotation (round 6): the workgroups of a launch start together and would all walk the n-tiles in the same order - at any moment every
+  // residual read and every store of the chip falls into the same 512-byte column window of the 2-4 KiB output rows, i.e. onto a fraction of
+  // the memory channels.  Workgroup i starts at tile i % count instead.
+  const int cnt = NT - nt_first;
+  const int rot = p.rot ? (int)(blockIdx.x % (unsigned)cnt) : 0;
+  auto tile_of = [&](int k) { const int t = k + rot; return nt_first + (t >= cnt ? t - cnt : t); };
 
   for (int i = tid; i < p.N; i += NTHR) biasL[i] = p.bias ? p.bias[i] : 0.0f;
   // pixel tile: instruction i = (row block i / (K/8), piece i % (K/8)); lane = row.  The pieces of a row block back to back: the 64
@@ -77,6 +88,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kplane_kernel(const PWKArgs p)
   {
     const __amdgpu_buffer_rsrc_t xr = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, p.x_bytes, 0x00020000);
     constexpr int NP = K / 8;
+    static_assert(BM % 64 == 0, "64-row DMA blocks");
     for (int i = wave; i < (BM / 64) * NP; i += NDW) {
       const int blk = i / NP, c = i % NP;
       const int m = m0 + blk * 64 + lane;
@@ -92,7 +104,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kplane_kernel(const PWKArgs p)
   auto w_ptr = [&](int a, int nt, int ks) -> const bf16_t* { return wwave + ((size_t)(nt * 8 + a) * KS + ks) * 512; };
 #pragma unroll
   for (int a = 0; a < TN; ++a) {
-    const bf16_t* w0 = w_ptr(a, nt_first, 0);
+    const bf16_t* w0 = w_ptr(a, tile_of(0), 0);
     c3_static_for<PF>([&](auto ic) {
       constexpr int i = decltype(ic)::value;
       ar[i][a] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
@@ -106,9 +118,10 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kplane_kernel(const PWKArgs p)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the pixel tile (and the ring)
   __syncthreads();   // S
 
-  for (int nt = nt_first; nt < NT; ++nt) {
+  for (int kt = 0; kt < cnt; ++kt) {
+    const int nt = tile_of(kt);
     const int n0 = nt * BN;
-    const int ntn = nt + 1 < NT ? nt + 1 : nt;
+    const int ntn = kt + 1 < cnt ? tile_of(kt + 1) : nt;
 #pragma unroll
     for (int a = 0; a < TN; ++a)
 #pragma unroll
@@ -223,10 +236,10 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kplane_kernel(const PWKArgs p)
   }
 }
 
-template <int K, int ACT, int RESMODE>
+template <int K, int ACT, int RESMODE, int TM = 4>
 static int launch_pwk(PWKArgs& a, hipStream_t stream) {
   static const int one_per_cu = fx_tune("FX_PWK_ONE_PER_CU", 0);   // A/B knob: pad the LDS request so that one workgroup owns a CU
-  constexpr int BM = 128, BN = 256;
+  constexpr int BM = TM * 32, BN = 256;
   int smem = BM * K * 2 + a.N * 4;
   if (smem > 160 * 1024) return FX_ERR_UNSUPPORTED;
   if (one_per_cu && smem < 96 * 1024) smem = 96 * 1024;
@@ -239,7 +252,9 @@ static int launch_pwk(PWKArgs& a, hipStream_t stream) {
   if (groups > NT) groups = NT;
   a.ntg = (NT + groups - 1) / groups;
   groups = (NT + a.ntg - 1) / a.ntg;
-  auto kern = conv_pw_kplane_kernel<K, ACT, RESMODE>;
+  static const int rot = fx_tune("FX_PWK_ROT", 1);
+  a.rot = rot;
+  auto kern = conv_pw_kplane_kernel<K, ACT, RESMODE, TM>;
   static int attr_smem = 0;
   if (smem > attr_smem) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return FX_ERR_RUNTIME;
@@ -265,6 +280,27 @@ int fx_launch_pw_kplane(const ConvArgs& c, const bf16_t* w_frag, hipStream_t str
   a.x = c.x; a.wp = w_frag; a.bias = c.bias; a.res = c.res; a.y = reinterpret_cast<bf16_t*>(c.y);
   a.N = c.N; a.ldx = c.ldx; a.ldy = c.ldy; a.ldr = c.ldr; a.M = c.M;
   a.HW = c.Ho * c.Wo; a.y_bstride = c.y_bstride; a.x_bytes = c.x_bytes; a.r_bytes = c.r_bytes;
+  // 64-pixel tiles (three workgroups per CU) for the layers selected by FX_PWK_BM64: bit 0 = K 256 with a residual (res4's branch2c), bit 1 =
+  // K 256 without, bit 2 = K 512 with a residual (res5's branch2c), bit 3 = K 512 without
+  static const int bm64 = fx_tune("FX_PWK_BM64", 0);
+  const bool has_res = mode >= 4;
+  if (bm64 & (c.C == 256 ? (has_res ? 1 : 2) : (has_res ? 4 : 8))) {
+    if (c.C == 256) {
+      switch (mode) {
+        case 0: return launch_pwk<256, FX_ACT_RELU, 0, 2>(a, stream);
+        case 1: return launch_pwk<256, FX_ACT_SILU, 0, 2>(a, stream);
+        case 3: return launch_pwk<256, FX_ACT_NONE, 0, 2>(a, stream);
+        case 4: return launch_pwk<256, FX_ACT_RELU, 1, 2>(a, stream);
+      }
+    } else {
+      switch (mode) {
+        case 0: return launch_pwk<512, FX_ACT_RELU, 0, 2>(a, stream);
+        case 1: return launch_pwk<512, FX_ACT_SILU, 0, 2>(a, stream);
+        case 3: return launch_pwk<512, FX_ACT_NONE, 0, 2>(a, stream);
+        case 4: return launch_pwk<512, FX_ACT_RELU, 1, 2>(a, stream);
+      }
+    }
+  }
   if (c.C == 256) {
     switch (mode) {
       case 0: return launch_pwk<256, FX_ACT_RELU, 0>(a, stream);

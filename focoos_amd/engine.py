@@ -35,6 +35,7 @@ from .state_spec import RESNET_BLOCKS
 BN_EPS = 1e-5
 DEFAULT_STREAMS = 2   # batch parts per step (two half-batch parts replayed concurrently: +9 %; see _MultiPlan).  FX_STREAMS=1: one part
 MIN_PART_BATCH = 4
+DEFAULT_PIPELINE_DEPTH = 3   # batches in flight of the throughput mode (_Pipeline); 2 / 3 / 4 measured 5 002-5 115 / 5 084-5 112 / 5 095-5 133 img/s in one call
 
 
 class NT:
@@ -392,6 +393,19 @@ class DetrEngine(StdcEngineMixin, _EngineBase):
         key = (B, H, W, f32_input, nsplit)
         if key not in self.plans:
             self.plans[key] = _Plan(self, B, H, W, f32_input) if nsplit <= 1 else _MultiPlan(self, _Plan, B, H, W, f32_input, nsplit)
+        return self.plans[key]
+
+    def pipeline(self, B: int, H: int, W: int, depth: Optional[int] = None, f32_input: bool = False, nsplit: int = 1) -> "_Pipeline":
+        """Throughput mode (round 6): `depth` batches in flight, each on its OWN plan (own activation / output buffers) and its own stream
+        of the device pool - batch i+1's backbone runs beside batch i's decoder tail, and a whole-batch plan (nsplit = 1) launches every
+        layer once at twice the M of a half-batch part.  See _Pipeline.  depth: FX_PIPELINE_DEPTH, default 3."""
+        if depth is None:
+            depth = int(os.environ.get("FX_PIPELINE_DEPTH", str(DEFAULT_PIPELINE_DEPTH)))
+        if not _lib.two_queue_safe():     # a packed-fp32 build must stay on one hardware queue (two-queue hazard, DESIGN 5)
+            depth, nsplit = 1, 1
+        key = ("pipeline", B, H, W, f32_input, nsplit, depth)
+        if key not in self.plans:
+            self.plans[key] = _Pipeline(self, _Plan, B, H, W, f32_input, depth, nsplit)
         return self.plans[key]
 
     def forward(self, images: torch.Tensor, sizes: Optional[torch.Tensor] = None, threshold: Optional[float] = None,
@@ -1046,6 +1060,74 @@ class _Plan(StdcPlanMixin, _PlanBase):
         self.capture_and_launch(stream, thr)
 
 
+class _Pipeline:
+    """`depth` batches in flight (throughput mode; engine.pipeline()).
+
+    ``forward()`` is the latency form: ONE batch at a time, cut into two half-batch parts that run concurrently (_MultiPlan) - its decoder
+    tail (300 row tiles per part, launches of 15-60 us that cannot fill 256 CUs) ends before the next batch may start.  A serving loop
+    that has the next batch ready does not need that: here lane j is a complete plan of the WHOLE batch with its own buffers, replayed on
+    stream j of the device pool; ``submit`` hands batch i to lane i % depth and returns at once, so the backbone of batch i+1 runs beside
+    the encoder / decoder of batch i on the same CUs, and every layer is ONE launch at M = B x H x W instead of two at half of it (sum of
+    kernel time of a bs = 32 RT-DETR step 8.0 ms instead of 9.0 for the two parts).  Measured in one call on one box (profiles/r06_pipeline_ab.txt):
+    forward()-style steps 4 803-4 809 img/s, depth 2 / 3 / 4 with whole-batch plans 5 002-5 133, two-part plans with depth 3 4 940-4 990.
+    The lanes are independent (nothing is shared but the read-only weights), so results are those of a plain plan, bit for bit
+    (tests/test_gpu_e2e.py::test_pipeline_lanes_equal_single_plan).
+
+    A lane's outputs stay valid until the lane is submitted to again (depth submits later); ``host`` buffers (pinned) receive the packed
+    detections on the lane's stream, ``wait(ticket)`` blocks until that batch is complete."""
+
+    def __init__(self, eng: _EngineBase, plan_cls, B: int, H: int, W: int, f32_input: bool, depth: int, nsplit: int = 1, **kw):
+        self.eng, self.B, self.H, self.W, self.depth, self.nsplit = eng, B, H, W, max(1, depth), nsplit
+        self.dev = eng.dev
+        self.lanes = []
+        for j in range(self.depth):
+            if nsplit > 1:
+                pl = _MultiPlan(eng, plan_cls, B, H, W, f32_input, nsplit, stream_offset=nsplit * j, **kw)
+                st = eng.stream if j == 0 else _device_stream(self.dev, nsplit * j)
+            else:
+                pl = plan_cls(eng, B, H, W, f32_input, **kw)
+                st = eng.stream if j == 0 else _device_stream(self.dev, j)
+            self.lanes.append((pl, st))
+        self.tickets = 0
+        self._events = [None] * self.depth
+
+    def lane(self, ticket: int):
+        return self.lanes[ticket % self.depth]
+
+    def submit(self, images: torch.Tensor, sizes: Optional[torch.Tensor] = None, threshold: Optional[float] = None, host: Optional[dict] = None) -> int:
+        """Enqueue one batch (device tensors; `images` must stay untouched until the lane's copy ran - it is read on the lane's stream after
+        the caller's current stream reached this point).  Returns the ticket; the plan is ``lane(ticket)[0]``."""
+        t = self.tickets
+        self.tickets += 1
+        pl, st = self.lanes[t % self.depth]
+        st.wait_stream(torch.cuda.current_stream(self.dev))
+        with torch.cuda.stream(st):
+            pl.input.copy_(images, non_blocking=True)
+            if sizes is None:
+                pl.sizes.copy_(torch.tensor([[self.H, self.W]] * self.B, dtype=torch.int32), non_blocking=False)
+            else:
+                pl.sizes.copy_(sizes, non_blocking=True)
+            pl.run(st.cuda_stream, threshold if threshold is not None else self.eng.threshold, None, True)
+            if host is not None:
+                for k, h in host.items():
+                    h.copy_(getattr(pl, k), non_blocking=True)
+            ev = self._events[t % self.depth]
+            if ev is None:
+                ev = self._events[t % self.depth] = torch.cuda.Event()
+            ev.record(st)
+        return t
+
+    def wait(self, ticket: int):
+        ev = self._events[ticket % self.depth]
+        if ev is not None:
+            ev.synchronize()
+        return self.lanes[ticket % self.depth][0]
+
+    def synchronize(self):
+        for _, st in self.lanes:
+            st.synchronize()
+
+
 class _MultiPlan:
     """One step = `n` batch parts (default 2, FX_STREAMS), each a complete plan of B/n images with its own activation buffers, replayed
     concurrently on `n` streams so that an HBM-bound layer of one part overlaps an MFMA-bound layer of another and fills its tail
@@ -1056,12 +1138,14 @@ class _MultiPlan:
     concurrent replays differ from the serial result (tests/test_gpu_two_streams.py asserts it).
     Inputs and outputs are single full-batch tensors (each part reads / writes its contiguous batch slice)."""
 
-    def __init__(self, eng: _EngineBase, plan_cls, B: int, H: int, W: int, f32_input: bool, n: int, **kw):
+    def __init__(self, eng: _EngineBase, plan_cls, B: int, H: int, W: int, f32_input: bool, n: int, stream_offset: int = 0, **kw):
         self.eng, self.B, self.H, self.W, self.n = eng, B, H, W, n
         self.lib, self.dev = eng.lib, eng.dev
         self._io_full: Dict[str, torch.Tensor] = {}
         self.parts = [plan_cls(eng, B // n, H, W, f32_input, parent=self, index=i, **kw) for i in range(n)]
-        self.side = [_device_stream(self.dev, 1 + i) for i in range(n - 1)]
+        # stream_offset: a second plan of the same shape in flight beside the first one (bench.py --pipeline: batch i+1's backbone beside batch
+        # i's decoder tail) takes its own streams of the pool
+        self.side = [_device_stream(self.dev, 1 + i + stream_offset) for i in range(n - 1)]
         if os.environ.get("FX_PARTS_SERIAL") == "1":   # profiling aid: the same parts back to back on ONE stream (per-kernel durations without overlap)
             self.side = [eng.stream] * (n - 1)
         self.graph = None

@@ -131,6 +131,10 @@ int main(int argc, char** argv) {
   V.push_back(mkk<2, 2, 4, 1, 256, 0, 0>("duo 4w  64x256 HLP 256          "));
   V.push_back(mkk<2, 2, 4, 1, 192, 0, 0>("duo 4w  64x256 HLP 192          "));
   V.push_back(mkk<2, 3, 4, 1, 288, 0, 0>("duo 4w  96x256 HLP 288          "));
+  V.push_back(mkk<2, 4, 4, 1, 320, 32, 0>("duo 128x256 prio by hw slot     "));
+  V.push_back(mkk<2, 4, 4, 1, 320, 128, 0>("duo 128x256 prio by block parity"));
+  V.push_back(mkk<2, 3, 4, 1, 288, 32, 0>("duo  96x256 prio by hw slot     "));
+  V.push_back(mkk<2, 2, 4, 1, 256, 32, 0>("duo  64x256 prio by hw slot     "));
 
   hipStream_t st;
   HIPCHECK(hipStreamCreate(&st));

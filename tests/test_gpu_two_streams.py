@@ -68,3 +68,44 @@ def test_two_concurrent_batch_parts_equal_serial_parts_mask_families(family):
         st.synchronize()
         bad += not all(torch.equal(ref[k], getattr(pl, k)) for k in keys)
     assert bad == 0, f"{bad} of 40 concurrent replays differ from the serial result"
+
+
+def test_pipeline_lanes_equal_single_plan():
+    """Throughput mode (engine.pipeline(), round 6): three DIFFERENT batches in flight on three whole-batch plans, 12 rounds of them
+    back to back without a host synchronisation in between - every batch's probabilities, boxes and packed detections equal the
+    one-batch-at-a-time result of the same images (a single whole-batch plan run alone), bit for bit; the lanes share nothing but the
+    read-only weights, so concurrency must not change a value (the two-queue hazard of DESIGN 5 would show up exactly here)."""
+    from focoos_amd.model import FAIDetr
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.synth import synth_image_structured as sis
+
+    cfg = ModelRegistry.get_model_info("fai-detr-l-obj365")["config"]
+    eng = FAIDetr(cfg, device="cuda:0", seed=0).engine
+    B, depth = 16, 3
+    batches = [torch.from_numpy(np.stack([sis(300 + 40 * j + i) for i in range(B)])).to("cuda:0") for j in range(depth)]
+    sizes = torch.tensor([[640, 640]] * B, dtype=torch.int32, device="cuda:0")
+    keys = ("probs", "boxes", "det_count", "det_scores", "det_labels", "det_boxes")
+    # reference: each batch alone on ONE plan, one stream, synchronised
+    single = eng.plan(B, 640, 640, False, 1)
+    st = eng.stream
+    ref = []
+    for x in batches:
+        with torch.cuda.stream(st):
+            single.input.copy_(x)
+            single.sizes.copy_(sizes)
+            single.run(st.cuda_stream, 0.3, None, True)
+        st.synchronize()
+        ref.append({k: getattr(single, k).clone() for k in keys})
+    pipe = eng.pipeline(B, 640, 640, depth)
+    assert pipe.depth == depth and len({s.cuda_stream for _, s in pipe.lanes}) == depth      # one stream per lane
+    assert len({pl.input.data_ptr() for pl, _ in pipe.lanes}) == depth                           # own buffers per lane
+    bad = 0
+    for rnd in range(12):
+        tickets = [pipe.submit(batches[(j + rnd) % depth], sizes, 0.3) for j in range(depth)]
+        for j, t in enumerate(tickets):
+            pl = pipe.wait(t)
+            want = ref[(j + rnd) % depth]
+            bad += not all(torch.equal(want[k], getattr(pl, k)) for k in keys)
+    pipe.synchronize()
+    assert bad == 0, f"{bad} of 36 pipelined batches differ from the one-batch-at-a-time result"
+    assert int(ref[0]["det_count"].sum()) > 0 and not torch.equal(ref[0]["probs"], ref[1]["probs"])   # the comparison is not vacuous
