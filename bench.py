@@ -49,9 +49,6 @@ def parse():
                     help="--train: 16-bit element type of activations / gradients / weight images (default bf16; bisenetformer-* training: fp16 = "
                          "BASELINE configs[4], the reference's fp16 autocast + GradScaler: fp16 MFMA, fp32 masters, dynamic loss scale with "
                          "skip-on-overflow inside the fused AdamW launch)")
-    ap.add_argument("--pipeline", type=int, default=(int(os.environ["FX_BENCH_PIPELINE"]) if "FX_BENCH_PIPELINE" in os.environ else None),
-                    help="RT-DETR inference: batches in flight (engine.pipeline(); default 3).  1 = one batch at a time as two concurrent half-batch "
-                         "parts (engine.forward()'s form)")
     ap.add_argument("--streams", type=int, default=None, help="concurrent batch parts per step (default: engine default / FX_STREAMS)")
     ap.add_argument("--mf-full-masks", action="store_true", help="fai-mf-*: also write the reference's [B,Q,H,W] fp32 `masks` tensor")
     ap.add_argument("--mf-masks-d2h", action="store_true", help="fai-mf-*: include the D2H copy of the bit-packed mask buffer in the step")
@@ -635,244 +632,6 @@ def infer_measure(args, world, rank, local, light=False):
     for _ in range(args.steps):
         step()
     sync()
-    barrier(world, False)
-    dt = max_over_ranks(time.perf_counter() - t0, world, False)
-    total = float(sum(v.detach().float() for v in losses.values()))
-    value = world * B * args.steps / dt
-    fwd = (ALG_GFLOP_PER_IMAGE_BF_1024 * (S / 1024.0) ** 2 if bf else
-           (ALG_GFLOP_PER_IMAGE_MF_800 * (S / 800.0) ** 2 if args.family == "fai_mf" else ALG_GFLOP_PER_IMAGE * (S / 640.0) ** 2))
-    alg = 3 * fwd  # training ~ 3 x forward (fwd + dgrad + wgrad)
-    # data-parallel consistency: after the timed steps every rank must hold bit-identical fp32 master weights (same all-reduced
-    # gradients, same optimizer arithmetic).  Checked with one MIN and one MAX all-reduce of a float64 checksum.
-    dp_check = None
-    if world > 1:
-        import torch.distributed as dist
-
-        chk = stepper.opt.flat_p.double().sum().reshape(1)
-        lo, hi = chk.clone(), chk.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        dp_check = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "master_weights_identical_across_ranks": bool((lo == hi).item()),
-                    "checksum": float(chk.item())}
-    class stepper_graphs:   # noqa: N801  (tiny record read by the JSON line below)
-        on = stepper._graph_state is not None
-    roof = _wgrad_roofline(train_nn, stepper, imgs, all_targets[0], args.family) if (rank == 0 and with_roofline) else None
-    barrier(world, False)
-    out = None
-    if rank == 0:
-        crit = ("point-sampled mask Hungarian set criterion over 7 prediction sets" if bf else
-                ("point-sampled mask Hungarian set criterion over 10 prediction sets" if args.family == "fai_mf" else "Hungarian set criterion over 7 prediction sets"))
-        out = ({
-            "metric": f"images/sec @ {S}^2 (train bs={B}/GPU" + ("; bf16 variant of BASELINE configs[4], which names fp16" if (bf and dtype != "fp16") else "") + ")", "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": dtype, "data": "synthetic",
-            "config": {"steps_are": "hipGraph replays (forward graph, backward graph) around an eager criterion + optimizer" if stepper_graphs.on else "eager launches",
-                       "graphs": {"mode": str(graphs_mode), "choice": stepper.graph_choice},   # auto: both forms timed during the warm-up steps, the faster one kept
-                       "workload": f"{args.model} training step: forward (train mode, norm={args.norm}) + {crit} "
-                                   f"+ backward + gradient all-reduce + fused AdamW/clip, bs={B}/GPU, {S}x{S}, {dtype} activations and gradients"
-                                   + (" (fp16 MFMA; dynamic loss scale as torch.amp.GradScaler: init 2**10, unscale / skip-on-inf / scale update "
-                                      "inside the fused AdamW launch), " if dtype == "fp16" else ", ")
-                                   + "fp32 master weights; HIP autograd nodes; "
-                                   + ("forward and backward replayed as two hipGraphs around an eager criterion" if getattr(stepper_graphs, "on", False) else "eager launches, no graph")
-                                   + ("; DEVIATION from BASELINE configs[4] ('fp16'): this run computes in bf16 without a GradScaler (--dtype bf16) - on the real "
-                                      "reference the training losses under fp16 autocast deviate 0.66 % from fp32, under bf16 autocast 1.7 % "
-                                      "(tests/test_oracle_vs_reference.py::test_reference_fp16_amp_losses_vs_fp32_and_bf16_autocast)" if (bf and dtype != "fp16") else ""),
-                       "global_batch": B * world, "parallelism": f"dp{world} (RCCL all-reduce of one flat fp32 gradient buffer, 64 MiB buckets, "
-                                                                 "segments launched from backward hooks)"},
-            "alg_gflop_per_image": round(alg, 1), "frac_of_bf16_mfma_roofline_whole_path": round(value / world * alg * 1e9 / (PEAK_BF16_TFLOPS * 1e12), 4),
-            "roofline": roof, "final_total_loss": round(total, 4), "dp_check": dp_check,
-            "loss_scale": stepper.opt.scaler_state() if stepper.opt.scaler is not None else None})
-    del stepper, model
-    torch.cuda.empty_cache()
-    fxlib.set_compute_dtype(prev_dtype)
-    return out
-
-
-def train_main(args, world, rank, local):
-    out = train_measure(args, world, rank, local)
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.destroy_process_group()
-
-
-def _spawned_rank(argv):
-    """Entry of a rank started by focoos_amd.launch (process group already initialised, RANK/LOCAL_RANK/WORLD_SIZE exported)."""
-    sys.argv = [os.path.join(ROOT, "bench.py")] + list(argv)
-    run(parse())
-
-
-def main():
-    args = parse()
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # `python bench.py --gpus N` on its own: spawn the N ranks here, one process per GPU, like the reference's launch()
-        # (focoos/utils/distributed/dist.py:38-95) does for FocoosModel.train(num_gpus=N).  Under torchrun WORLD_SIZE is set
-        # and each rank comes straight through run().
-        from focoos_amd.launch import launch
-
-        launch(_spawned_rank, args.gpus, dist_url="auto", args=(sys.argv[1:],), backend="gloo" if args.dry_run else "nccl")
-        return
-    run(args)
-
-
-def run(args):
-    world, rank, local = dist_setup(args)
-    if args.dry_run:
-        # plumbing only: same sharding / barrier / max-over-ranks / JSON code path with a fake 1 ms step
-        barrier(world, True)
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            time.sleep(0.001)
-        barrier(world, True)
-        dt = max_over_ranks(time.perf_counter() - t0, world, True)
-        if rank == 0:
-            line = {"metric": "dry-run", "value": world * args.batch * args.steps / dt, "unit": "images/s", "n_gpus": world,
-                    "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-                    "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "none", "config": {"workload": "dry-run"}}
-            if args.train:
-                # the per-rank plan of the data-parallel training step this command line would run: batch split, gradient segments and
-                # buckets, bytes all-reduced per step - from the state spec alone (focoos_amd.train.dp_plan; no GPU, no model)
-                from focoos_amd.registry import ModelRegistry
-                from focoos_amd.train import dp_plan
-
-                cfg = ModelRegistry.get_model_info(args.model)["config"]
-                norm = "SyncBN" if (args.norm == "BN" and world > 1 and args.family == "bisenetformer") else args.norm
-                line["dp_plan"] = dp_plan(cfg, args.family, norm, world, args.batch, grad_bytes=2 if os.environ.get("FX_DP_BF16", "0") == "1" else 4)
-                line["dp_plan"]["ranks"] = [{"rank": r, "images": [r * args.batch, (r + 1) * args.batch], "target_seed": f"{r} * 1000 + iteration"}
-                                            for r in range(world)]
-            print(json.dumps(line))
-        return
-
-    if args.train:
-        return train_main(args, world, rank, local)
-    out = infer_measure(args, world, rank, local, light=False)
-    if args.default_run and not args.no_other_configs:
-        other_configs(args, world, rank, local, out)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-
-        dist.destroy_process_group()
-
-
-def other_configs(args, world, rank, local, out):
-    """The other BASELINE.json configs, measured briefly in the same run and nested under `other_configs` of the ONE JSON line (rank 0's
-    dict `out`): config 4 (RT-DETR training step, data-parallel over the same ranks), config 5 (BiSeNetFormer training step at 1024^2),
-    config 3 (MaskFormer inference at 800^2) and BiSeNetFormer inference.  Each leg is the same code as `--train` / `--model ...`
-    with fewer steps and without the per-kernel table.  A watchdog guards the headline: if the legs exceed their budget (or a
-    collective hangs), rank 0 prints the line with what has been measured and every rank exits."""
-    import copy
-    import threading
-
-    legs = {}
-    if rank == 0:
-        out["other_configs"] = legs
-
-    def bail():
-        if rank == 0:
-            legs["watchdog"] = f"extra legs abandoned after {args.other_configs_budget:.0f} s"
-            print(json.dumps(out), flush=True)
-        os._exit(0)
-
-    timer = threading.Timer(args.other_configs_budget + (0 if rank == 0 else 5), bail)
-    timer.daemon = True
-    timer.start()
-    # inference legs first (replicas, no collective), the data-parallel training legs last
-    plan = [("infer_fai-mf-l-coco-ins_bs16_800", dict(train=False, model="fai-mf-l-coco-ins", family="fai_mf", batch=16, size=800, steps=10, warmup=3)),
-            ("infer_bisenetformer-l-ade_bs32_640", dict(train=False, model="bisenetformer-l-ade", family="bisenetformer", batch=32, size=640, steps=10, warmup=3)),
-            ("train_fai-detr-l-obj365_bs16_640_frozenbn", dict(train=True, model="fai-detr-l-obj365", family="fai_detr", batch=16, size=640, norm="FrozenBN", steps=6, warmup=4)),
-            ("train_bisenetformer-l-ade_bs8_1024_bn_fp16", dict(train=True, model="bisenetformer-l-ade", family="bisenetformer", batch=8, size=1024,
-                                                               norm="SyncBN" if world > 1 else "BN", steps=4, warmup=4, dtype="fp16"))]
-    for name, over in plan:
-        a = copy.copy(args)
-        for k, v in over.items():
-            setattr(a, k, v)
-        try:
-            r = train_measure(a, world, rank, local, with_roofline=False) if a.train else infer_measure(a, world, rank, local, light=True)
-            if rank == 0:
-                legs[name] = {k: r[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "dtype", "config", "alg_gflop_per_image",
-                                                "frac_of_bf16_mfma_roofline_whole_path", "loss_scale", "final_total_loss") if k in r}
-        except Exception as e:   # a failed leg must not take the headline with it
-            if rank == 0:
-                legs[name] = {"error": f"{type(e).__name__}: {e}"[:300]}
-            from focoos_amd import _lib as fxlib
-
-            fxlib.set_compute_dtype("bf16")
-    timer.cancel()
-
-
-def infer_measure(args, world, rank, local, light=False):
-    """One inference measurement (the bench contract's timed region); returns rank 0's dict.  ``light``: no CPU baseline, no per-kernel
-    roofline table (the extra legs of the default run)."""
-    import torch
-
-    from focoos_amd.model import BisenetFormer, FAIDetr, FAIMaskFormer
-    from focoos_amd.registry import ModelRegistry
-    from focoos_amd.synth import synth_image
-
-    dev = f"cuda:{local}"
-    cfg = ModelRegistry.get_model_info(args.model)["config"]
-    B = args.batch
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not light:
-        cpu = cpu_baseline(args)
-    bf = args.family == "bisenetformer"
-    mf = args.family == "fai_mf" or bf     # the two mask families share the engine interface (engine_maskdec.py)
-    model = (BisenetFormer if bf else (FAIMaskFormer if mf else FAIDetr))(cfg, device=dev, seed=0)
-    eng = model.engine
-    # image i of rank r = synth_image(r*B + i): seeded uint8 HWC, resident in HBM before the timed region
-    imgs = torch.stack([torch.from_numpy(synth_image(rank * B + i, args.size, args.size)) for i in range(B)]).to(dev)
-    sizes = torch.tensor([[args.size, args.size]] * B, dtype=torch.int32, device=dev)
-    pl = eng.plan(B, args.size, args.size, False, args.mf_full_masks, args.streams) if mf else eng.plan(B, args.size, args.size, False, args.streams)
-    keys = ("det_scores", "det_labels", "det_boxes", "det_count") + (("det_query", "det_area") if mf else ())
-    if mf and args.mf_masks_d2h:
-        keys += ("mask_words",)
-    host = {k: torch.empty_like(getattr(pl, k), device="cpu").pin_memory() for k in keys}
-    st = eng.stream
-    # --pipeline 2 (EXPERIMENT, RT-DETR only): two batches in flight - batch i+1 is handed to a second plan with its own buffers and streams
-    # while batch i's decoder tail still runs; a step is still one batch through the whole path, the timed region is still K steps
-    pipe = []
-    if args.pipeline > 1 and not mf:
-        from focoos_amd.engine import _MultiPlan, _Plan, _device_stream
-
-        nparts = getattr(pl, "n", 1)
-        for j in range(1, args.pipeline):
-            if nparts > 1:
-                plj, stj = _MultiPlan(eng, _Plan, B, args.size, args.size, False, nparts, stream_offset=nparts * j), _device_stream(torch.device(dev), nparts * j)
-            else:
-                plj, stj = _Plan(eng, B, args.size, args.size, False), _device_stream(torch.device(dev), j)
-            pipe.append((plj, stj, {k: torch.empty_like(getattr(plj, k), device="cpu").pin_memory() for k in keys}))
-    lanes = [(pl, st, host)] + pipe
-    turn = [0]
-
-    def step():
-        plx, stx, hostx = lanes[turn[0] % len(lanes)]
-        turn[0] += 1
-        with torch.cuda.stream(stx):
-            plx.input.copy_(imgs, non_blocking=True)       # device->device: hand the batch to the engine's input buffer
-            plx.sizes.copy_(sizes, non_blocking=True)
-            plx.run(stx.cuda_stream, 0.5, None, True)
-            for k, h in hostx.items():                      # D2H of the packed results (<= 300 x 6 per image; MaskFormer: <= 100 x 8)
-                h.copy_(getattr(plx, k), non_blocking=True)
-
-    stagger_us = float(os.environ.get("FX_BENCH_STAGGER_US", "0"))
-    if stagger_us > 0 and len(lanes) > 1:      # EXPERIMENT: lane j starts j * stagger late (spin kernel on its stream), before the warm-up
-        for j, (_, stx, _) in enumerate(lanes):
-            with torch.cuda.stream(stx):
-                torch.cuda._sleep(int(j * stagger_us * 100))     # ~100 MHz sleep clock ticks per microsecond on this part (approximate)
-    for _ in range(max(args.warmup, len(lanes))):
-        step()
-    for _, stx, _ in lanes:
-        stx.synchronize()
-    barrier(world, False)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    for _, stx, _ in lanes:
-        stx.synchronize()
     barrier(world, False)
     dt = max_over_ranks(time.perf_counter() - t0, world, False)
     ms_step = 1e3 * dt / args.steps
