@@ -49,6 +49,9 @@ def parse():
                     help="--train: 16-bit element type of activations / gradients / weight images (default bf16; bisenetformer-* training: fp16 = "
                          "BASELINE configs[4], the reference's fp16 autocast + GradScaler: fp16 MFMA, fp32 masters, dynamic loss scale with "
                          "skip-on-overflow inside the fused AdamW launch)")
+    ap.add_argument("--pipeline", type=int, default=(int(os.environ["FX_BENCH_PIPELINE"]) if "FX_BENCH_PIPELINE" in os.environ else None),
+                    help="RT-DETR inference: batches in flight (engine.pipeline(); default 3).  1 = one batch at a time as two concurrent half-batch "
+                         "parts (engine.forward()'s form)")
     ap.add_argument("--streams", type=int, default=None, help="concurrent batch parts per step (default: engine default / FX_STREAMS)")
     ap.add_argument("--mf-full-masks", action="store_true", help="fai-mf-*: also write the reference's [B,Q,H,W] fp32 `masks` tensor")
     ap.add_argument("--mf-masks-d2h", action="store_true", help="fai-mf-*: include the D2H copy of the bit-packed mask buffer in the step")
