@@ -97,6 +97,53 @@ def _device_stream(dev: torch.device, i: int) -> "torch.cuda.Stream":
     return st
 
 
+_LANE_STREAMS: Dict[Tuple[int, int], List["torch.cuda.Stream"]] = {}
+
+
+def _concurrent_streams(dev: torch.device, n: int) -> List["torch.cuda.Stream"]:
+    """`n` streams of the device pool that were MEASURED to run side by side (throughput mode: one batch per stream).  HIP multiplexes
+    the streams of a process onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and two streams on one queue serialise; which streams
+    share a queue is fixed once they were used, but not a simple function of the creation order (scripts/dev/stream_queue_probe.py: of eight
+    streams (0,5) (1,4) (2,3) (2,7) (3,7) collide; 'first 4 together' take twice the time of one).  So: a ~0.4 ms spin kernel on a candidate
+    and on every stream already chosen, at once - a pair that takes as long as two spins shares a queue and the candidate is dropped.
+    One-time cost ~20 ms per (device, n); the pool's first stream (the engines' main stream) is always lane 0."""
+    key = (dev.index or 0, n)
+    if key in _LANE_STREAMS:
+        return _LANE_STREAMS[key]
+    import time
+
+    ticks = int(1e6)
+
+    def spin(sts):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for s_ in sts:
+            with torch.cuda.stream(s_):
+                torch.cuda._sleep(ticks)
+        for s_ in sts:
+            s_.synchronize()
+        return time.perf_counter() - t0
+
+    chosen = [_device_stream(dev, 0)]
+    spin(chosen)
+    one = min(spin(chosen) for _ in range(3))
+    cand = 1
+    while len(chosen) < n and cand < 12:
+        s_ = _device_stream(dev, cand)
+        cand += 1
+        spin([s_])
+        if all(min(spin([s_, c]) for _ in range(2)) < 1.5 * one for c in chosen):
+            chosen.append(s_)
+    cand = 1
+    while len(chosen) < n:      # fewer concurrent streams than lanes (GPU_MAX_HW_QUEUES too small): the remaining lanes share queues
+        s_ = _device_stream(dev, cand)
+        cand += 1
+        if s_ not in chosen:
+            chosen.append(s_)
+    _LANE_STREAMS[key] = chosen
+    return chosen
+
+
 class _EngineBase:
     """Device handle, weight-packing helpers and the ResNet-vd backbone weights shared by the model families."""
 
@@ -1080,13 +1127,14 @@ class _Pipeline:
         self.eng, self.B, self.H, self.W, self.depth, self.nsplit = eng, B, H, W, max(1, depth), nsplit
         self.dev = eng.dev
         self.lanes = []
+        lane_streams = _concurrent_streams(self.dev, self.depth) if nsplit <= 1 else None
         for j in range(self.depth):
             if nsplit > 1:
                 pl = _MultiPlan(eng, plan_cls, B, H, W, f32_input, nsplit, stream_offset=nsplit * j, **kw)
                 st = eng.stream if j == 0 else _device_stream(self.dev, nsplit * j)
             else:
                 pl = plan_cls(eng, B, H, W, f32_input, **kw)
-                st = eng.stream if j == 0 else _device_stream(self.dev, j)
+                st = lane_streams[j]
             self.lanes.append((pl, st))
         self.tickets = 0
         self._events = [None] * self.depth
