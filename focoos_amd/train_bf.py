@@ -688,6 +688,7 @@ class BisenetFormerTrainable(nn.Module):
         mask_features, msf = self.pixel_decoder.decode(f)
         if self.grad_ready is not None:
             notify_when_all_grads([mask_features, msf[0], msf[1]], self.grad_ready, "head")
+        self.segment_boundaries = {"head": [mask_features, msf[0], msf[1]], "encoder": [f["res3"], f["res4"], f["res5"]]}   # TrainStep._staged_backward
         out = self.head.predictor(msf[:-1], mask_features, forced_attn)
         self.last_outputs = out
         return out

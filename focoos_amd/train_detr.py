@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -425,6 +425,8 @@ class FAIDetrTrainable(nn.Module):
         self._notify_when_all_grads(feats, "encoder")
         enc = self.pixel_decoder(feats)
         self._notify_when_all_grads(list(enc), "head")
+        # the activations that separate the parameter segments [backbone | encoder | head]: TrainStep's staged backward stops and restarts here
+        self.segment_boundaries = {"head": list(enc), "encoder": feats}
         out = self.head.predictor(enc, forced_topk)
         self.last_outputs = out
         return out
@@ -446,7 +448,7 @@ class TrainStep:
     def __init__(self, model: FAIDetrTrainable, lr: float = 1e-4, backbone_multiplier: float = 0.1, weight_decay: float = 1e-4,
                  weight_decay_norm: float = 0.0, weight_decay_embed: float = 0.0, max_grad_norm: float = 0.1, ema_decay: Optional[float] = None, ema_warmups: int = 2000, scheduler: Optional[str] = None,
                  max_iters: int = 0, scheduler_extra: Optional[Dict] = None, check_every: int = 16, graphs: Optional[bool] = None,
-                 loss_scale: Optional[float] = None):
+                 loss_scale: Optional[float] = None, staged: Optional[bool] = None):
         """The step computes in the 16-bit element type that is current when it is built (_lib.compute_dtype(): "bf16", or "fp16" =
         the reference's amp training, trainer/trainer.py:645,735-773) and pins it at the top of every step.  Under fp16 the loss is
         multiplied by a dynamic scale before backward (default initial value 2**10 like the reference's GradScaler; ``loss_scale`` overrides),
@@ -467,8 +469,8 @@ class TrainStep:
         # which matters only where the host is the bottleneck (many ranks per host, slow cores).
         # "auto" (round 5): which of the two wins depends on the BOX (one collection: eager 26.7 ms / replay 24.9 ms where the host cores
         # are slow, profiles/r05z_train*_bench.json; another: eager 23.4 / replay slower), so the step can time both itself: steps 1-2 eager
-        # (lazy packing), 3-4 eager timed, 5 capture + first replay, 6-7 replay timed, then the faster form stays.  One rank only: under data
-        # parallelism the eager step stays (its all-reduce overlaps the backward; a replayed backward cannot launch collectives from hooks).
+        # (lazy packing), 3-4 eager timed, 5 capture + first replay, 6-7 replay timed, then the faster form stays.  Several ranks (round 6): the same, with the timings MAX-all-reduced so
+        # that every rank keeps the same form - the replayed step overlaps its all-reduces as well (one backward graph per stage, _capture).
         mode = os.environ.get("FX_TRAIN_GRAPH", "0") if graphs is None else graphs
         self._auto, self.graph_choice = None, None
         if isinstance(mode, str) and mode.strip().lower() == "auto":
@@ -530,6 +532,12 @@ class TrainStep:
 
             self.stream = _device_stream(torch.device(self.opt.dev), 0)
         self.packer = self._nn.WeightPacker(model)
+        # Staged backward (round 6; FX_DP_STAGED=1 or staged=True): backward runs as three autograd calls head -> encoder -> backbone that stop
+        # at the model's segment boundaries, and a segment's all-reduce is launched BETWEEN two stages instead of from an autograd hook.  It is
+        # the form a CAPTURED step needs (a replayed graph cannot launch a collective from a hook: _capture records one backward graph per
+        # stage) and it is what makes the overlap testable on CPU ranks; gradients are those of the one-call backward, bit for bit.
+        self.staged = bool(int(os.environ.get("FX_DP_STAGED", "0"))) if staged is None else bool(staged)
+        self.stage_log: List[Tuple[str, object]] = []     # ("stage", name) / ("segment", i) in issue order (tests)
         self.reducer.before_collective = self._join_wgrads   # a segment's gradients are final only once its queued wgrads have run
         import os as _os
 
@@ -561,6 +569,59 @@ class TrainStep:
     def _join_wgrads(self):
         self._nn.wgrad_join(self.opt.dev)
 
+    # ------------------------------------------------------------------------------------------------ staged backward
+    STAGES = (("head", 2), ("encoder", 1), ("backbone", 0))
+
+    def _stage_params(self, seg: int) -> List[torch.Tensor]:
+        from .train import dp_segment_of
+
+        return [p for n, p in self.named if dp_segment_of(n) == seg]
+
+    def _staged_backward(self, roots: Sequence[torch.Tensor], root_grads: Sequence[Optional[torch.Tensor]], between=None, wrap=None):
+        """Backward of the model part below ``roots`` as three autograd calls.  Stage k runs from the previous boundary's gradients to the
+        parameters of segment k and to the next boundary: ``torch.autograd.grad(roots, inputs = segment parameters + boundary tensors)`` - the
+        engine executes exactly the nodes that lead to those inputs, and a NON-LEAF input is a capture point: its producer is not executed
+        (``backward(inputs=...)`` would execute and free it - the next stage then finds its saved tensors gone).  Parameter gradients: the HIP
+        nodes write straight into the flat views (``p.grad``, DIRECT_GRAD) and hand autograd nothing; what torch glue does return is added to the
+        view here.  After a stage (and the join of its weight-gradient launches) ``between(name, segment)`` runs - the step launches that
+        segment's all-reduce there, i.e. BEFORE the next stage's kernels are issued: DistributedDataParallel's overlap
+        (utils/distributed/dist.py:138-157) without a hook.  ``wrap(name, fn)`` runs a stage's body (the capture wraps it in a graph
+        capture); default: call it.  Gradients equal the one-call backward's bit for bit (same nodes, same order inside a segment)."""
+        bnd = getattr(self.model, "segment_boundaries", None)
+        carry: Dict[str, List] = {"roots": [t for t, g in zip(roots, root_grads) if t.requires_grad],
+                                  "grads": [g for t, g in zip(roots, root_grads) if t.requires_grad]}
+        if bnd and self._seg_index:
+            cuts = {"head": [t for t in bnd["head"] if t.requires_grad], "encoder": [t for t in bnd["encoder"] if t.requires_grad]}
+            plan = [("head", 2, cuts["head"]), ("encoder", 1, cuts["encoder"]), ("backbone", 0, [])]
+        else:       # no three-segment layout (a model the constructor could not segment): one stage over every parameter
+            plan = [("all", None, [])]
+        for name, seg, stop in plan:
+            def body(stop=stop, seg=seg):
+                params = self._stage_params(seg) if seg is not None else [p for _, p in self.named]
+                r, g = carry["roots"], carry["grads"]
+                if r:
+                    res = torch.autograd.grad(r, params + stop, g, allow_unused=True)
+                    for prm, gr in zip(params, res[:len(params)]):
+                        if gr is not None:      # torch glue (the HIP nodes returned None and accumulated into prm.grad themselves)
+                            if prm.grad is None:
+                                prm.grad = gr
+                            else:
+                                prm.grad.add_(gr)
+                    pairs = [(t, gr) for t, gr in zip(stop, res[len(params):]) if gr is not None]
+                    carry["roots"], carry["grads"] = [t for t, _ in pairs], [gr for _, gr in pairs]
+                self._join_wgrads()
+            self.stage_log.append(("stage", name))
+            if wrap is not None:
+                wrap(name, body)
+            else:
+                body()
+            if between is not None:
+                between(name, seg)
+
+    def _launch_segment_logged(self, name: str, seg: int):
+        self.stage_log.append(("segment", seg))
+        self.reducer.launch_segment(seg)
+
     # ------------------------------------------------------------------------------------------------ captured step
     # TrainerLoop.run_step (trainer/trainer.py:723-773) as TWO hipGraph replays around an eager criterion (VERDICT r3 next #4: the eager
     # step issued ~1 700 launches from Python, 20-22 ms of host time in a 24 ms step; BiSeNetFormer's 1 956 launches were host-bound
@@ -569,8 +630,8 @@ class TrainStep:
     # stream, forked and joined inside the capture).  What depends on the step's TARGETS - Hungarian matching, pair counts, num_boxes,
     # the losses and their gradient w.r.t. the prediction sets - runs eagerly in between on detached leaves (tens of launches instead
     # of ~1 700): no target-dependent host scalar is frozen into a graph.  The optimizer (its bias-correction step count is a host scalar)
-    # and the data-parallel all-reduce stay eager as well: with graphs the all-reduce starts after the backward graph (no overlap with
-    # it; the overlapped hooks are the eager path's).  The mechanism is torch.cuda.make_graphed_callables' (static input / output /
+    # and the data-parallel all-reduce stay eager as well; round 6: the backward is THREE graphs (head | encoder | backbone) and segment k's
+    # all-reduce is enqueued between stage k's and stage k+1's replay, so the collectives overlap the replayed backward as the eager hooks do.  The mechanism is torch.cuda.make_graphed_callables' (static input / output /
     # gradient buffers in one private pool), written out because the step owns state that must sit inside the captures (gradient
     # zero-fill, arena, weight packing, stream pinning, side-stream join).  Falls back to the eager step for SyncBN (collectives inside
     # the forward) and on CPU tensors (the gloo tests).
@@ -611,7 +672,7 @@ class TrainStep:
         hooks, self.model.grad_ready = self.model.grad_ready, None     # the reducer's hooks belong to the eager path (collectives are not captured)
         torch.cuda.synchronize(dev)
         pool = torch.cuda.graph_pool_handle()
-        g_fwd, g_bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        g_fwd = torch.cuda.CUDAGraph()
         nn_.DIRECT_GRAD[0] = True
         if self.wgrad_stream is not None:
             nn_.WGRAD_STREAM[dev] = self.wgrad_stream
@@ -629,17 +690,29 @@ class TrainStep:
             req = [t for t in tensors if t.requires_grad]
             st["gouts"] = [torch.zeros_like(t) for t in req]
             # (the backward is captured on THIS thread - no launches from the autograd engine's worker thread into a capture)
-            with torch.autograd.set_multithreading_enabled(False), torch.cuda.graph(g_bwd, pool=pool, stream=self.stream):
-                nn_.pin_stream(dev, True)
-                torch.autograd.backward(req, st["gouts"])
-                self._join_wgrads()
-                nn_.pin_stream(dev, False)
+            # ONE GRAPH PER STAGE (round 6): head | encoder | backbone, cut at the model's segment boundaries (_staged_backward), each with its
+            # weight-gradient fork / join inside - so that the replayed step can launch segment k's all-reduce between stage k and stage k+1
+            # and the collective runs beside the next stage's replay (the single backward graph of round 4 could only be followed by all of them)
+            stage_graphs: Dict[str, torch.cuda.CUDAGraph] = {}
+
+            def wrap(name, body):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, stream=self.stream):
+                    nn_.pin_stream(dev, True)
+                    body()
+                    nn_.pin_stream(dev, False)
+                stage_graphs[name] = g
+
+            with torch.autograd.set_multithreading_enabled(False):
+                self._staged_backward(req, st["gouts"], wrap=wrap)
+            st["cuts"] = dict(self.model.segment_boundaries)     # the boundary tensors stay alive with the graphs (their gradients live in the pool)
+            del self.stage_log[:]
         finally:
             nn_.DIRECT_GRAD[0] = False
             nn_.pin_stream(dev, False)
             nn_.WGRAD_STREAM.pop(dev, None)
             self.model.grad_ready = hooks
-        st["fwd"], st["bwd"] = g_fwd, g_bwd
+        st["fwd"], st["bwd_stages"] = g_fwd, [(name, seg, stage_graphs[name]) for name, seg in (self.STAGES if "head" in stage_graphs else (("all", None),))]
         self._graph_state = st
 
     def _step_graphed(self, images: torch.Tensor, targets: Sequence) -> Dict[str, torch.Tensor]:
@@ -662,7 +735,12 @@ class TrainStep:
                 g.zero_()
             else:
                 g.copy_(l.grad)
-        st["bwd"].replay()
+        for name, seg, g in st["bwd_stages"]:
+            self.stage_log.append(("stage", name))
+            g.replay()
+            if seg is not None:
+                self._launch_segment_logged(name, seg)      # segment k's all-reduce is enqueued before stage k+1's replay (no-op on one rank)
+        del self.stage_log[:-8]
         return losses
 
     def step(self, images: torch.Tensor, targets: Sequence) -> Dict[str, torch.Tensor]:
@@ -683,9 +761,10 @@ class TrainStep:
         import torch.distributed as dist
 
         a = self._auto
-        # one rank only: under data parallelism the eager step's all-reduce overlaps the backward (hooks), the replayed one's cannot
+        # several ranks (round 6): the replayed step overlaps its all-reduces too (one backward graph per stage, a segment's collective enqueued
+        # between two replays), so it takes part in the comparison; the two timings are MAX-all-reduced so that every rank makes the same choice
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        applicable = images.is_cuda and not multi and not any(getattr(m, "norm_mode", None) == "SyncBN" for m in self.model.modules())
+        applicable = images.is_cuda and not any(getattr(m, "norm_mode", None) == "SyncBN" for m in self.model.modules())
         key = (tuple(images.shape), images.dtype)
         if not applicable or a.setdefault("key", key) != key:   # CPU / SyncBN / changing shapes: the eager step
             self.use_graphs, self._auto, self._graph_state = False, None, None
@@ -708,6 +787,10 @@ class TrainStep:
         elif a["phase"] == 3 and a["n"] == 2:
             a["graph_ms"] = (now() - a["t0"]) * 500.0
             eager_ms, graph_ms = a["eager_ms"], a["graph_ms"]
+            if multi:
+                tm = torch.tensor([eager_ms, graph_ms], dtype=torch.float64, device=dev)
+                dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+                eager_ms, graph_ms = float(tm[0]), float(tm[1])
             self.use_graphs = graph_ms < 0.98 * eager_ms
             self.graph_choice = {"graphs": self.use_graphs, "eager_ms": round(eager_ms, 3), "graph_ms": round(graph_ms, 3)}
             if not self.use_graphs:
@@ -776,11 +859,35 @@ class TrainStep:
         if self.wgrad_stream is not None:
             nn_.WGRAD_STREAM[dev] = self.wgrad_stream   # weight gradients overlap the input-gradient chain (train_nn._wgrad_fork)
         try:
-            losses = self.model(images, targets, **forced)
-            total = torch.stack(list(losses.values())).sum()   # 2 launches instead of one add per loss term
-            if self.opt.scaler is not None:
-                total = total * self.opt.scale.detach()        # GradScaler.scale(loss): the gradients carry the factor until the optimizer launch
-            total.backward()
+            if self.staged and self._seg_index:
+                # staged form: criterion on detached leaves (as the captured step does), then the model's backward in three stages with the
+                # segment all-reduces launched in between; no autograd hooks
+                hooks, self.model.grad_ready = self.model.grad_ready, None
+                try:
+                    out = self.model.forward_outputs(images, **{k: v for k, v in forced.items() if k != "fixed_matches"})
+                finally:
+                    self.model.grad_ready = hooks
+                tensors: List[torch.Tensor] = []
+                spec = self._flatten(out, tensors)
+                leaves = [t.detach().requires_grad_(True) if t.requires_grad else t for t in tensors]
+                lout = self._rebuild(spec, leaves)
+                self.model.last_outputs = lout
+                losses = self.model.head.criterion(lout, targets, forced["fixed_matches"]) if forced.get("fixed_matches") is not None \
+                    else self.model.head.criterion(lout, targets)
+                total = torch.stack(list(losses.values())).sum()
+                if self.opt.scaler is not None:
+                    total = total * self.opt.scale.detach()
+                total.backward()
+                pairs = [(t, l.grad) for t, l in zip(tensors, leaves) if t.requires_grad and l.grad is not None]
+                self._staged_backward([t for t, _ in pairs], [g for _, g in pairs],
+                                      between=lambda name, seg: self._launch_segment_logged(name, seg) if seg is not None else None)
+                del self.stage_log[:-8]
+            else:
+                losses = self.model(images, targets, **forced)
+                total = torch.stack(list(losses.values())).sum()   # 2 launches instead of one add per loss term
+                if self.opt.scaler is not None:
+                    total = total * self.opt.scale.detach()        # GradScaler.scale(loss): the gradients carry the factor until the optimizer launch
+                total.backward()
         finally:
             nn_.DIRECT_GRAD[0] = False
             nn_.pin_stream(self.opt.dev, False)

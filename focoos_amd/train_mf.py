@@ -262,6 +262,7 @@ class FAIMaskFormerTrainable(nn.Module):
         mask_features, msf = self.pixel_decoder.decode(f)
         if self.grad_ready is not None:
             notify_when_all_grads([mask_features] + list(msf), self.grad_ready, "head")
+        self.segment_boundaries = {"head": [mask_features] + list(msf), "encoder": [f["res2"], f["res3"], f["res4"], f["res5"]]}   # TrainStep._staged_backward
         out = self.head.predictor(msf, mask_features, forced_attn)
         self.last_outputs = out
         return out

@@ -138,6 +138,26 @@ def _worker_body(rank, world, port, q):
             losses = stepper.step(images, targets)
         g_avg = stepper.opt.flat_g.clone()
         p_after = stepper.opt.flat_p.clone()
+        # ---- the same step through the STAGED backward (round 6: what a captured step replays - three backward stages, segment k's
+        # all-reduce enqueued between stage k and stage k+1, no autograd hooks): same parameters, same batch -> the same averaged gradient
+        with torch.no_grad():
+            stepper.opt.flat_p.copy_(p_before)
+        stepper.staged = True
+        hook_log = list(red.log)
+        del red.log[:], stepper.stage_log[:]
+        staged_events = []
+
+        def traced2(i):
+            if not red.launched[i]:
+                staged_events.append((i, tuple(bool((stepper.opt.flat_g[a:b] != 0).any()) for a, b in red.segments)))
+            orig_launch(i)
+
+        red.launch_segment = traced2
+        with mock.patch.object(type(stepper.opt), "step", adamw_stub):
+            stepper.step(images, targets)
+        g_staged = stepper.opt.flat_g.clone()
+        staged = {"log": list(stepper.stage_log), "events": staged_events, "red_log": list(red.log),
+                  "equal": bool(torch.equal(g_staged, g_avg)), "p_equal": bool(torch.equal(stepper.opt.flat_p, p_after))}
     # every rank must now hold the SAME gradient and the same parameters; and the gradient must be the mean of the two local ones
     both = [torch.zeros_like(g_avg) for _ in range(world)]
     dist.all_gather(both, g_avg)
@@ -147,8 +167,8 @@ def _worker_body(rank, world, port, q):
     mean_ok = bool(torch.allclose(g_avg, (loc_all[0] + loc_all[1]) / world, rtol=1e-5, atol=1e-8))
     covered = float((g_avg != 0).float().mean())
     upd_ok = bool(torch.allclose(p_after, p_before - 0.1 * g_avg))
-    q.put({"rank": rank, "bcast_ok": bcast_ok, "layout": layout, "events": events, "log": list(red.log), "same_grad": same_grad, "mean_ok": mean_ok,
-           "covered": covered, "upd_ok": upd_ok, "num_boxes": seen_num_boxes[:2], "n_losses": len(losses)})
+    q.put({"rank": rank, "bcast_ok": bcast_ok, "layout": layout, "events": events, "log": hook_log, "same_grad": same_grad, "mean_ok": mean_ok,
+           "covered": covered, "upd_ok": upd_ok, "num_boxes": seen_num_boxes[:2], "n_losses": len(losses), "staged": staged})
     dist.destroy_process_group()
 
 
@@ -178,5 +198,12 @@ def test_trainstep_host_logic_two_ranks_gloo():
         assert r["log"] == [("segment", 2), ("segment", 1), ("backward_end", -1), ("segment", 0)], r["log"]
         assert r["same_grad"] and r["mean_ok"], "averaged gradient must equal the mean of the ranks' local gradients on every rank"
         assert r["covered"] > 0.99 and r["upd_ok"] and r["n_losses"] == 6
+        # staged backward (the captured step's form): stage k, then segment k's collective, then stage k+1 - and every segment's launch sees
+        # only ITS OWN and the later segments' gradients present (the earlier layers' backward has not been issued yet)
+        sg = r["staged"]
+        assert sg["log"] == [("stage", "head"), ("segment", 2), ("stage", "encoder"), ("segment", 1), ("stage", "backbone"), ("segment", 0)], sg["log"]
+        assert [i for i, _ in sg["events"]] == [2, 1, 0] and sg["events"][0][1] == (False, False, True) and sg["events"][1][1] == (False, True, True), sg["events"]
+        assert sg["red_log"] == [("segment", 2), ("segment", 1), ("segment", 0), ("backward_end", -1)], sg["red_log"]
+        assert sg["equal"] and sg["p_equal"], "the staged backward must produce the hooked backward's averaged gradient and update, bit for bit"
         # num_boxes = all-reduced target count / world size (fai_detr/modelling.py:568-570): ranks hold 4 and 8 targets -> 6
         assert r["num_boxes"] == [6.0, 6.0], r["num_boxes"]
