@@ -680,12 +680,16 @@ class BisenetFormerTrainable(nn.Module):
 
     def forward_outputs(self, images: torch.Tensor, forced_attn=None):
         """Everything before the criterion: the prediction sets (static shapes - what a captured training step replays, TrainStep graphs)."""
-        f = self.pixel_decoder.backbone(images)
-        if self.grad_ready is not None:
-            from .train import notify_when_all_grads
+        f = dict(self.pixel_decoder.backbone(images))
+        from .train import notify_when_all_grads
 
+        # segment boundaries as aliases (see train_detr.FAIDetrTrainable.forward_outputs: the raw tensors are not an antichain of the graph)
+        for k in ("res3", "res4", "res5"):
+            f[k] = f[k].view_as(f[k])
+        if self.grad_ready is not None:
             notify_when_all_grads([f["res3"], f["res4"], f["res5"]], self.grad_ready, "encoder")
         mask_features, msf = self.pixel_decoder.decode(f)
+        mask_features, msf = mask_features.view_as(mask_features), [m.view_as(m) for m in msf]
         if self.grad_ready is not None:
             notify_when_all_grads([mask_features, msf[0], msf[1]], self.grad_ready, "head")
         self.segment_boundaries = {"head": [mask_features, msf[0], msf[1]], "encoder": [f["res3"], f["res4"], f["res5"]]}   # TrainStep._staged_backward

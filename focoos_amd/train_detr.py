@@ -421,12 +421,15 @@ class FAIDetrTrainable(nn.Module):
     def forward_outputs(self, images: torch.Tensor, forced_topk=None):
         """Everything before the criterion: the prediction sets (static shapes - what a captured training step replays, TrainStep graphs)."""
         f = self.pixel_decoder.backbone(images)
-        feats = [f["res3"], f["res4"], f["res5"]]
+        # Segment boundaries [backbone | encoder | head].  Each boundary tensor is handed on as an ALIAS (view_as: no kernel, no copy, its own
+        # autograd node): res4 is computed from res3 and the PAN outputs from one another, so the raw tensors are not an antichain of the
+        # graph - a staged backward that stops at them (TrainStep._staged_backward) would have to run the path between two of them in the
+        # earlier stage.  The aliases have no path to one another: stopping at them cuts the graph cleanly.
+        feats = [f[k].view_as(f[k]) for k in ("res3", "res4", "res5")]
         self._notify_when_all_grads(feats, "encoder")
-        enc = self.pixel_decoder(feats)
-        self._notify_when_all_grads(list(enc), "head")
-        # the activations that separate the parameter segments [backbone | encoder | head]: TrainStep's staged backward stops and restarts here
-        self.segment_boundaries = {"head": list(enc), "encoder": feats}
+        enc = [e.view_as(e) for e in self.pixel_decoder(feats)]
+        self._notify_when_all_grads(enc, "head")
+        self.segment_boundaries = {"head": enc, "encoder": feats}
         out = self.head.predictor(enc, forced_topk)
         self.last_outputs = out
         return out

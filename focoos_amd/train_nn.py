@@ -298,20 +298,19 @@ def _bn_sync_group(layer):
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
-def _bn_forward(layer, z: torch.Tensor, residual: Optional[torch.Tensor]):
-    """Batch-statistics BatchNorm + activation on the conv output z [B,Ho,Wo,N]: returns (y, stats[4][N] = mean/rstd/scale/shift, n)."""
+def _bn_local_sums(layer, z: torch.Tensor, sums: torch.Tensor) -> None:
+    """This rank's [sum z, sum z^2] per channel of the conv output z into the zeroed [2][N] fp32 view ``sums``."""
+    N = z.shape[-1]
+    check(layer.lib.fx_bn_stats_bf16(z.data_ptr(), N, int(z.dtype == torch.float32), sums.data_ptr(), z.numel() // N, N, _stream(z.device)), "fx_bn_stats_bf16")
+
+
+def _bn_finish_forward(layer, z: torch.Tensor, residual: Optional[torch.Tensor], sums: torch.Tensor, n: float):
+    """Statistics -> (mean, rstd, scale, shift) + running-statistics update, then y = act(scale z + shift [+ residual])."""
     lib, dev = layer.lib, z.device
     N = z.shape[-1]
     rows = z.numel() // N
     st = _stream(dev)
-    sums = ARENA.zeros((2, N), dev)
     zf = int(z.dtype == torch.float32)   # fp32 pre-normalisation tensor (conv epilogue out_f32): y depends on z - mean
-    check(lib.fx_bn_stats_bf16(z.data_ptr(), N, zf, sums.data_ptr(), rows, N, st), "fx_bn_stats_bf16")
-    world = _bn_sync_group(layer)
-    if world > 1:
-        import torch.distributed as dist
-        dist.all_reduce(sums)
-    n = float(rows * world)
     norm = layer._norm_h
     stats = torch.empty(4, N, dtype=torch.float32, device=dev)
     check(lib.fx_bn_finalize_f32(sums.data_ptr(), n, norm.weight.data_ptr(), norm.bias.data_ptr(), BN_EPS, BN_MOMENTUM,
@@ -321,27 +320,51 @@ def _bn_forward(layer, z: torch.Tensor, residual: Optional[torch.Tensor]):
     y = torch.empty(z.shape, dtype=_lib.act_dtype(), device=dev)
     check(lib.fx_bn_apply_bf16(z.data_ptr(), N, zf, stats[2].data_ptr(), stats[3].data_ptr(), residual.data_ptr() if residual is not None else None, N,
                                FX_ACT[layer.act], y.data_ptr(), N, rows, N, st), "fx_bn_apply_bf16")
+    return y, stats
+
+
+SYNCBN_COLLECTIVES = [0]   # all-reduces issued by the BatchNorm nodes since the counter was last reset (tests / bench census)
+
+
+def _bn_all_reduce(buf: torch.Tensor) -> None:
+    import torch.distributed as dist
+
+    SYNCBN_COLLECTIVES[0] += 1
+    dist.all_reduce(buf)
+
+
+def _bn_forward(layer, z: torch.Tensor, residual: Optional[torch.Tensor]):
+    """Batch-statistics BatchNorm + activation on the conv output z [B,Ho,Wo,N]: returns (y, stats[4][N] = mean/rstd/scale/shift, n)."""
+    N = z.shape[-1]
+    sums = ARENA.zeros((2, N), z.device)
+    _bn_local_sums(layer, z, sums)
+    world = _bn_sync_group(layer)
+    if world > 1:
+        _bn_all_reduce(sums)
+    n = float((z.numel() // N) * world)
+    y, stats = _bn_finish_forward(layer, z, residual, sums, n)
     return y, stats, n
 
 
-def _bn_backward(layer, dy: torch.Tensor, z: torch.Tensor, residual: Optional[torch.Tensor], stats: torch.Tensor, n: float, want_affine: bool):
-    """Returns (dz, da or None): dz = gradient of the conv output, da = gradient of the residual branch.  The affine
-    gradients (dgamma = sum da * xhat, dbeta = sum da; LOCAL sums, data parallelism averages them later) are added to
-    ``norm.weight.grad`` / ``norm.bias.grad`` in place when those exist, else returned through ``layer._affine_grads``."""
+def _bn_bwd_local_sums(layer, dy: torch.Tensor, z: torch.Tensor, residual: Optional[torch.Tensor], stats: torch.Tensor, sums: torch.Tensor) -> None:
+    """This rank's [sum da, sum da xhat] per channel (da = dy act'(.)) into the zeroed [2][N] fp32 view ``sums``."""
+    N = z.shape[-1]
+    rp = residual.data_ptr() if residual is not None else None
+    check(layer.lib.fx_bn_bwd_stats_bf16(dy.data_ptr(), N, z.data_ptr(), N, int(z.dtype == torch.float32), rp, N, stats[2].data_ptr(), stats[3].data_ptr(),
+                                         stats[0].data_ptr(), stats[1].data_ptr(), FX_ACT[layer.act], sums.data_ptr(), z.numel() // N, N, _stream(z.device)),
+          "fx_bn_bwd_stats_bf16")
+
+
+def _bn_finish_backward(layer, dy: torch.Tensor, z: torch.Tensor, residual: Optional[torch.Tensor], stats: torch.Tensor, n: float, want_affine: bool,
+                        sums: torch.Tensor, local: torch.Tensor):
+    """``sums``: the (all-reduced) backward sums, ``local``: this rank's own (the same tensor when nothing was reduced).  Returns
+    (dz, da or None, dgamma, dbeta)."""
     lib, dev = layer.lib, z.device
     N = z.shape[-1]
     rows = z.numel() // N
     st = _stream(dev)
     rp = residual.data_ptr() if residual is not None else None
-    sums = ARENA.zeros((2, N), dev)
     zf = int(z.dtype == torch.float32)
-    check(lib.fx_bn_bwd_stats_bf16(dy.data_ptr(), N, z.data_ptr(), N, zf, rp, N, stats[2].data_ptr(), stats[3].data_ptr(), stats[0].data_ptr(),
-                                   stats[1].data_ptr(), FX_ACT[layer.act], sums.data_ptr(), rows, N, st), "fx_bn_bwd_stats_bf16")
-    local = sums
-    if _bn_sync_group(layer) > 1:
-        import torch.distributed as dist
-        local = sums.clone()
-        dist.all_reduce(sums)
     dz = torch.empty(z.shape, dtype=_lib.act_dtype(), device=dev)
     da = torch.empty(z.shape, dtype=_lib.act_dtype(), device=dev) if residual is not None else None
     norm = layer._norm_h
@@ -359,6 +382,20 @@ def _bn_backward(layer, dy: torch.Tensor, z: torch.Tensor, residual: Optional[to
         else:
             dgamma, dbeta = local[1].clone(), local[0].clone()
     return dz, da, dgamma, dbeta
+
+
+def _bn_backward(layer, dy: torch.Tensor, z: torch.Tensor, residual: Optional[torch.Tensor], stats: torch.Tensor, n: float, want_affine: bool):
+    """Returns (dz, da or None): dz = gradient of the conv output, da = gradient of the residual branch.  The affine
+    gradients (dgamma = sum da * xhat, dbeta = sum da; LOCAL sums, data parallelism averages them later) are added to
+    ``norm.weight.grad`` / ``norm.bias.grad`` in place when those exist, else returned through ``layer._affine_grads``."""
+    N = z.shape[-1]
+    sums = ARENA.zeros((2, N), z.device)
+    _bn_bwd_local_sums(layer, dy, z, residual, stats, sums)
+    local = sums
+    if _bn_sync_group(layer) > 1:
+        local = sums.clone()
+        _bn_all_reduce(sums)
+    return _bn_finish_backward(layer, dy, z, residual, stats, n, want_affine, sums, local)
 
 
 _WGRAD_WS: Dict[torch.device, torch.Tensor] = {}
@@ -448,6 +485,93 @@ class _ConvBnTrainFn(torch.autograd.Function):
         dx = _conv_input_grad(layer, dz, x.shape) if ctx.needs_input_grad[0] else None
         dw = _conv_param_grads(layer, x, dz, None) if ctx.needs_input_grad[1] else None
         return dx, dw, dgamma, dbeta, da, None
+
+
+# SyncBN sibling fusion (round 6).  nn.SyncBatchNorm issues one small all-reduce per layer and direction: 97 BatchNorm layers
+# = 194 serialised, latency-bound collectives per RT-DETR-L step (trainer/trainer.py:333-334).  A layer's statistics are a data
+# dependency of its own output, so only layers whose conv outputs exist TOGETHER can share one: a bottleneck's shortcut conv with branch2a,
+# the conv1 | conv2 halves of a CSP layer (independent outputs: one collective forward, one backward - the node waits for both output
+# gradients), and the 3x3 | 1x1 branches of a RepVGG block (the 1x1's epilogue adds the 3x3's normalised output: one collective forward; in
+# the backward the 3x3 branch's gradient comes out of the 1x1's post-collective pass, so those two stay separate).  The two [2][N] sum
+# vectors lie back to back in ONE buffer that is all-reduced once; every other launch is the per-layer path's, on the same values - the
+# results are bit-identical to two _ConvBnTrainFn nodes (tests/test_gpu_train_conv.py::test_syncbn_sibling_nodes_equal_per_layer_nodes).
+# 20 pairs: 194 -> 166 collectives per step (forward 97 -> 77, backward 97 -> 89).  FX_BN_SIBLINGS=0: per-layer nodes.
+BN_SIBLINGS = [os.environ.get("FX_BN_SIBLINGS", "1") != "0"]
+
+
+def _siblings_on(layer) -> bool:
+    return BN_SIBLINGS[0] and layer.batch_stats and layer.norm_mode == "SyncBN"
+
+
+class _SiblingConvBnFn(torch.autograd.Function):
+    """Two ConvNormLayers under batch statistics whose conv outputs exist together.  chain = False: (ya, yb) = (A(xa), B(xb)), independent.
+    chain = True (RepVGG): returns yb = B(xb, residual = A(xa)) only."""
+
+    @staticmethod
+    def forward(ctx, xa, xb, wa, ga, ba, wb, gb, bb, la: "ConvNormLayer", lb: "ConvNormLayer", chain: bool):
+        la.sync_packed()
+        lb.sync_packed()
+        dev = xa.device
+        Na, Nb = wa.shape[0], wb.shape[0]
+        za = _conv_call(la.lib, xa, la.w_fwd, None, Na, wa.shape[2], wa.shape[3], la.stride, la.pad, None, None, out_f32=True)
+        zb = _conv_call(lb.lib, xb, lb.w_fwd, None, Nb, wb.shape[2], wb.shape[3], lb.stride, lb.pad, None, None, out_f32=True)
+        flat = ARENA.zeros((2 * (Na + Nb),), dev)
+        sa, sb = flat[:2 * Na].view(2, Na), flat[2 * Na:].view(2, Nb)
+        _bn_local_sums(la, za, sa)
+        _bn_local_sums(lb, zb, sb)
+        world = _bn_sync_group(la)
+        if world > 1:
+            _bn_all_reduce(flat)                       # ONE collective for the pair
+        na, nb = float((za.numel() // Na) * world), float((zb.numel() // Nb) * world)
+        ya, stats_a = _bn_finish_forward(la, za, None, sa, na)
+        yb, stats_b = _bn_finish_forward(lb, zb, ya if chain else None, sb, nb)
+        ctx.la, ctx.lb, ctx.na, ctx.nb, ctx.chain = la, lb, na, nb, chain
+        ctx.save_for_backward(xa, xb, za, zb, stats_a, stats_b, ya if chain else None)
+        if chain:
+            return yb
+        return ya, yb
+
+    @staticmethod
+    def backward(ctx, *douts):
+        la, lb = ctx.la, ctx.lb
+        xa, xb, za, zb, stats_a, stats_b, ya = ctx.saved_tensors
+        dev = za.device
+        Na, Nb = za.shape[-1], zb.shape[-1]
+        want_a = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        want_b = ctx.needs_input_grad[6] or ctx.needs_input_grad[7]
+        sync = _bn_sync_group(la) > 1
+        if ctx.chain:
+            (dyb,) = douts
+            dzb, da, dgb, dbb = _bn_backward(lb, dyb.contiguous(), zb, ya, stats_b, ctx.nb, want_b)
+            dza, _, dga, dba = _bn_backward(la, da, za, None, stats_a, ctx.na, want_a)
+        else:
+            dya, dyb = douts
+            dya = dya.contiguous() if dya is not None else torch.zeros_like(za, dtype=_lib.act_dtype())
+            dyb = dyb.contiguous() if dyb is not None else torch.zeros_like(zb, dtype=_lib.act_dtype())
+            flat = ARENA.zeros((2 * (Na + Nb),), dev)
+            sa, sb = flat[:2 * Na].view(2, Na), flat[2 * Na:].view(2, Nb)
+            _bn_bwd_local_sums(la, dya, za, None, stats_a, sa)
+            _bn_bwd_local_sums(lb, dyb, zb, None, stats_b, sb)
+            la_, lb_ = sa, sb
+            if sync:
+                loc = flat.clone()
+                la_, lb_ = loc[:2 * Na].view(2, Na), loc[2 * Na:].view(2, Nb)
+                _bn_all_reduce(flat)                   # ONE collective for the pair
+            dza, _, dga, dba = _bn_finish_backward(la, dya, za, None, stats_a, ctx.na, want_a, sa, la_)
+            dzb, _, dgb, dbb = _bn_finish_backward(lb, dyb, zb, None, stats_b, ctx.nb, want_b, sb, lb_)
+        dxa = _conv_input_grad(la, dza, xa.shape) if ctx.needs_input_grad[0] else None
+        dxb = _conv_input_grad(lb, dzb, xb.shape) if ctx.needs_input_grad[1] else None
+        # (one input tensor given twice: autograd sums the two slots' gradients exactly as it sums those of two separate nodes)
+        dwa = _conv_param_grads(la, xa, dza, None) if ctx.needs_input_grad[2] else None
+        dwb = _conv_param_grads(lb, xb, dzb, None) if ctx.needs_input_grad[5] else None
+        return dxa, dxb, dwa, dga, dba, dwb, dgb, dbb, None, None, None
+
+
+def sibling_conv_bn(la: "ConvNormLayer", lb: "ConvNormLayer", xa: torch.Tensor, xb: torch.Tensor, chain: bool = False):
+    """(la(xa), lb(xb)) - or lb(xb, residual = la(xa)) with chain = True - through ONE autograd node whose two BatchNorm layers share their
+    SyncBN collectives (see _SiblingConvBnFn); the same tensor may be given as xa and xb (autograd sums the two slots' input gradients)."""
+    return _SiblingConvBnFn.apply(xa, xb, la._conv_h.weight, la._norm_h.weight, la._norm_h.bias, lb._conv_h.weight, lb._norm_h.weight, lb._norm_h.bias,
+                                  la, lb, chain)
 
 
 class _Holder(nn.Module):
@@ -827,6 +951,11 @@ class BottleNeck(nn.Module):
             s_l = (self.short.conv if isinstance(self.short, _Short) else self.short) if self.has_short else None
             return _BottleneckFn.apply(x, self.branch2a._conv_h.weight, self.branch2b._conv_h.weight, self.branch2c._conv_h.weight,
                                        s_l._conv_h.weight if s_l is not None else None, self)
+        if self.has_short and _siblings_on(self.branch2a):   # SyncBN: branch2a and the shortcut conv share their collectives
+            pooled = isinstance(self.short, _Short)
+            s_l = self.short.conv if pooled else self.short
+            a_out, short = sibling_conv_bn(self.branch2a, s_l, x, _PoolFn.apply(x, self.short.lib, "avg") if pooled else x)
+            return self.branch2c(self.branch2b(a_out), residual=short)
         out = self.branch2b(self.branch2a(x))
         short = self.short(x) if self.has_short else x
         return self.branch2c(out, residual=short)  # relu(conv + bn + short)
@@ -1400,6 +1529,8 @@ class RepVggBlock(nn.Module):
         self.conv2 = ConvNormLayer(lib, c, c, 1, 1, "silu")  # its epilogue adds conv1's branch, then SiLU
 
     def forward(self, x):
+        if _siblings_on(self.conv1):     # SyncBN: one forward collective for the two branches
+            return sibling_conv_bn(self.conv1, self.conv2, x, x, chain=True)
         return self.conv2(x, residual=self.conv1(x))
 
 
@@ -1414,6 +1545,9 @@ class CSPRepLayer(nn.Module):
         self.bottlenecks = nn.Sequential(*[RepVggBlock(lib, cout) for _ in range(n)])
 
     def forward(self, x):
+        if _siblings_on(self.conv1):     # SyncBN: conv1 | conv2 share their collectives
+            c1, c2 = sibling_conv_bn(self.conv1, self.conv2, x, x)
+            return _AddFn.apply(self.bottlenecks(c1), c2, self.lib)
         return _AddFn.apply(self.bottlenecks(self.conv1(x)), self.conv2(x), self.lib)
 
 

@@ -745,3 +745,66 @@ def test_pack_all_matches_the_per_layer_packing():
         if a is not None:
             assert torch.equal(a, b)
     assert any(c.w_fwd_frag is not None for c in convs) and any(c.w_dgrad_frag is not None for c in convs) and packs[0].w_fwd_frag is not None
+
+
+def test_syncbn_sibling_nodes_equal_per_layer_nodes(lib, monkeypatch):
+    """SyncBN sibling fusion (train_nn._SiblingConvBnFn): a bottleneck with a pooled projection shortcut (variant d: the
+    shortcut conv reads AvgPool(x), branch2a reads x), one with a plain projection shortcut and a CSP layer (conv1 | conv2 + three RepVGG
+    blocks) under norm = "SyncBN" with a data-parallel group of TWO ranks faked on one GPU (the collective is a counting stand-in that
+    doubles the buffer - what two identical ranks would sum to), once through the sibling nodes and once through the per-layer nodes:
+    outputs, input gradient, every parameter gradient and the running statistics are bit-identical, and the collectives drop from two per
+    BatchNorm layer (16 + 16) to 10 forward (two shortcut pairs, the CSP pair, three RepVGG pairs) + 13 backward (the RepVGG pairs stay apart)."""
+    import torch.distributed as dist
+
+    from focoos_amd import train_nn
+    from focoos_amd.train_nn import BottleNeck, CSPRepLayer, _Blocks, set_norm_mode
+
+    calls = []
+
+    def fake_all_reduce(buf, *a, **k):
+        calls.append(buf.numel())
+        buf.mul_(2.0)          # two ranks holding the same batch
+
+    monkeypatch.setattr(train_nn, "_bn_sync_group", lambda layer: 2 if layer.norm_mode == "SyncBN" else 1)
+    monkeypatch.setattr(dist, "all_reduce", fake_all_reduce)
+
+    def build():
+        g = torch.Generator().manual_seed(11)
+        net = torch.nn.Sequential(_Blocks([BottleNeck(lib, 64, 32, 1, False, True), BottleNeck(lib, 128, 64, 2, False, False)]), CSPRepLayer(lib, 256, 256, 3))
+        set_norm_mode(net, "SyncBN")
+        with torch.no_grad():
+            for n, p in net.named_parameters():
+                if n.endswith("conv.weight"):
+                    p.copy_((torch.randn(p.shape, generator=g) / (p.shape[1] * p.shape[2] * p.shape[3]) ** 0.5).bfloat16().float())
+                elif n.endswith("norm.weight"):
+                    p.copy_(torch.rand(p.shape, generator=g) + 0.5)
+                else:
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.3)
+        return net.to(DEV).train()
+
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 24, 28, 64, generator=g).clamp_min(0).bfloat16()
+    cot = torch.randn(2, 12, 14, 256, generator=g).bfloat16()
+    res = {}
+    for on in (True, False):
+        monkeypatch.setattr(train_nn, "BN_SIBLINGS", [on])
+        del calls[:]
+        net = build()
+        n_bn = sum(1 for m in net.modules() if isinstance(m, train_nn.ConvNormLayer))
+        xd = x.to(DEV).requires_grad_(True)
+        y = net(xd)
+        fwd_calls = len(calls)
+        y.backward(cot.to(DEV))
+        torch.cuda.synchronize()
+        res[on] = {"y": y.detach().clone(), "dx": xd.grad.clone(), "grads": {n: p.grad.clone() for n, p in net.named_parameters()},
+                   "state": {k: v.clone() for k, v in net.state_dict().items()}, "fwd": fwd_calls, "bwd": len(calls) - fwd_calls, "n_bn": n_bn}
+    a, b = res[True], res[False]
+    assert b["n_bn"] == 16 and b["fwd"] == 16 and b["bwd"] == 16                       # per layer: one collective each way
+    # pairs: 2 bottleneck shortcuts + CSP conv1|conv2 (both directions) + 3 RepVGG blocks (forward only)
+    assert a["fwd"] == 16 - 6 and a["bwd"] == 16 - 3, (a["fwd"], a["bwd"])
+    assert torch.equal(a["y"], b["y"]) and torch.equal(a["dx"], b["dx"])
+    for n in b["grads"]:
+        assert torch.equal(a["grads"][n], b["grads"][n]), n
+    for k in b["state"]:
+        assert torch.equal(a["state"][k], b["state"][k]), k
+    assert float(b["y"].float().abs().max()) > 0 and float(b["dx"].float().abs().max()) > 0
