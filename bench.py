@@ -65,7 +65,7 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default run only: skip the short extra legs (RT-DETR / BiSeNetFormer training step, MaskFormer / BiSeNetFormer inference) "
                          "reported under `other_configs` of the one JSON line")
-    ap.add_argument("--other-configs-budget", type=float, default=180.0, help="seconds after which the extra legs are abandoned (watchdog)")
+    ap.add_argument("--other-configs-budget", type=float, default=240.0, help="seconds after which the extra legs are abandoned (watchdog)")
     a = ap.parse_args()
     a.default_run = len([x for x in sys.argv[1:] if x.startswith("--model") or x in ("--train", "--dry-run")]) == 0
     mf = a.model.startswith("fai-mf")
@@ -121,7 +121,10 @@ def max_over_ranks(val: float, world: int, dry: bool) -> float:
 
 
 def cpu_baseline(args):
-    """The reference's PyTorch-CPU path as restated by the oracle ("port"), on this host's cores."""
+    """The reference's PyTorch-CPU path on this host's cores.  kind "reference": the REAL reference model + processor (imported through
+    oracle/ref_import where /root/reference exists - the build container; RT-DETR family); kind "port": the oracle's restatement of the same path
+    (the GPU box has no reference tree).  The two are tied together once on the build box: profiles/r06_cpu_baseline_tie.json
+    (scripts/cpu_baseline_tie.py) holds both timings of one run, and a "port" line quotes that ratio as `reference_tie`."""
     import torch
 
     from focoos_amd.registry import ModelRegistry
@@ -136,6 +139,19 @@ def cpu_baseline(args):
     bf = args.family == "bisenetformer"
     if mf:
         args.cpu_batch = 1
+    ref = None
+    if not mf and not bf and not getattr(args, "cpu_force_port", False):
+        try:
+            from oracle import ref_import
+
+            if ref_import.reference_available():
+                rcfg = dict(cfg)
+                rcfg["resolution"] = args.size
+                rmodel, rproc, _ = ref_import.build_reference_detr(rcfg)
+                rmodel.load_state_dict(sd, strict=True)
+                ref = (rmodel, rproc)
+        except Exception:
+            ref = None
     # Thread count actually used (reported as `cores`): PyTorch's CPU convs stop scaling (and at 256 threads collapse:
     # 0.03 img/s measured on the 256-core GPU host) well before a big host's core count.  Round 5: the count is the one that
     # MAXIMISES img/s on this box - one bs=1 pass (after a warm-up) at 8 / 16 / 32 / 64 threads, capped at --cpu-threads (default 64) and at
@@ -150,6 +166,16 @@ def cpu_baseline(args):
         with torch.no_grad():
             for it in range(iters + 1):
                 t0 = time.perf_counter()
+                if ref is not None:     # the real thing: DETRProcessor.preprocess -> FAIDetr.forward -> DETRProcessor.postprocess (focoos_model.py:575-621)
+                    xr, _ = ref[1].preprocess(imgs, device=torch.device("cpu"), dtype=torch.float32)
+                    ref[1].postprocess(ref[0](xr), imgs, threshold=0.5)
+                    dt = time.perf_counter() - t0
+                    if it > 0:
+                        times.append(dt)
+                    elif dt > 15.0:
+                        times.append(dt)
+                        break
+                    continue
                 x = O.get_torch_batch(imgs, (args.size, args.size))
                 if mf:
                     p, m = M.mf_forward(sd, cfg, x)
@@ -178,9 +204,17 @@ def cpu_baseline(args):
     # bs=1 and a batch, warm-up + >= 5 timed passes each, median; bounded to ~20 s of CPU work
     v1, n1 = timed(1, args.cpu_iters)
     vb, nb_ = timed(args.cpu_batch, args.cpu_iters) if args.cpu_batch > 1 else (v1, n1)
-    return {"value": round(max(v1, vb), 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "bs1_images_per_s": round(v1, 3), f"bs{args.cpu_batch}_images_per_s": round(vb, 3),
-            "sample": f"oracle/{'mf' if mf else ('bf' if bf else 'detr')}_oracle.py (CPU fp32 restatement of the reference path) preprocess+forward+postprocess at "
+    tie = None
+    if ref is None:
+        try:
+            tie = json.load(open(os.path.join(ROOT, "profiles", "r06_cpu_baseline_tie.json")))
+            tie = {k: tie[k] for k in ("reference_images_per_s", "port_images_per_s", "port_over_reference", "threads", "host_cores", "where")}
+        except Exception:
+            tie = None
+    return {"value": round(max(v1, vb), 3), "unit": "images/s", "cores": torch.get_num_threads(), "cores_of": os.cpu_count(), "kind": "reference" if ref is not None else "port",
+            "bs1_images_per_s": round(v1, 3), f"bs{args.cpu_batch}_images_per_s": round(vb, 3), "reference_tie": tie,
+            "sample": ("the REAL reference (focoos FAIDetr + DETRProcessor through oracle/ref_import) " if ref is not None else
+                       f"oracle/{'mf' if mf else ('bf' if bf else 'detr')}_oracle.py (CPU fp32 restatement of the reference path) ") + "preprocess+forward+postprocess at "
                       f"{args.size}x{args.size}: bs=1 median of {n1} passes and bs={args.cpu_batch} median of {nb_} passes, each after 1 warm-up; value = the better of the two; "
                       f"{cores} threads of {os.cpu_count()} host cores - the best of the one-pass thread sweep {sweep} (img/s at bs=1)",
             "thread_sweep_bs1_images_per_s": sweep}
@@ -548,6 +582,13 @@ def other_configs(args, world, rank, local, out):
     plan = [("infer_fai-mf-l-coco-ins_bs16_800", dict(train=False, model="fai-mf-l-coco-ins", family="fai_mf", batch=16, size=800, steps=10, warmup=3)),
             ("infer_bisenetformer-l-ade_bs32_640", dict(train=False, model="bisenetformer-l-ade", family="bisenetformer", batch=32, size=640, steps=10, warmup=3)),
             ("train_fai-detr-l-obj365_bs16_640_frozenbn", dict(train=True, model="fai-detr-l-obj365", family="fai_detr", batch=16, size=640, norm="FrozenBN", steps=6, warmup=4)),
+            # config 4 BOTH ways - frozen BatchNorm above, and the reference's own semantics here: live statistics, converted to
+            # SyncBN whenever world_size > 1 (trainer/trainer.py:333-334) - so that a multi-GPU run records the mode the reference would train in
+            (f"train_fai-detr-l-obj365_bs16_640_{'syncbn' if world > 1 else 'bn'}",
+             dict(train=True, model="fai-detr-l-obj365", family="fai_detr", batch=16, size=640, norm="SyncBN" if world > 1 else "BN", steps=6, warmup=4)),
+            # config 3 also WITH the reference's [B,Q,H,W] fp32 `masks` tensor written (4.1 GB per step at bs = 16, 800^2)
+            ("infer_fai-mf-l-coco-ins_bs16_800_fullmasks", dict(train=False, model="fai-mf-l-coco-ins", family="fai_mf", batch=16, size=800, steps=6, warmup=2,
+                                                               mf_full_masks=True)),
             ("train_bisenetformer-l-ade_bs8_1024_bn_fp16", dict(train=True, model="bisenetformer-l-ade", family="bisenetformer", batch=8, size=1024,
                                                                norm="SyncBN" if world > 1 else "BN", steps=4, warmup=4, dtype="fp16"))]
     for name, over in plan:
@@ -740,6 +781,21 @@ def infer_measure(args, world, rank, local, light=False):
                                       "alg_gbs": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1), "launches": v["launches"]}
                                   for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])},
             "sum_of_kernel_ms_per_step": round(total_ms, 4),
+        }
+        # Composite bound of THIS launch structure (SURVEY 8(d) "roofline bound" (ii)): every launch that carries an
+        # algorithmic flop / byte count is charged max(flops / MFMA peak, bytes / HBM peak) at the datasheet peaks; the launches without one
+        # (attention cores, deformable sampling, top-k, row chains, resizes: latency- / gather-bound, no closed form) are charged nothing, so the
+        # bound is optimistic by their share, stated as `kernel_time_share_of_uncharged_launches`.  Progress is visible against BOTH ceilings:
+        # `frac_of_bf16_mfma_roofline_whole_path` (pure MFMA) and `composite.frac` (bound / measured step).
+        comp_s = sum(max(m["flops"] / (PEAK_BF16_TFLOPS * 1e12), m.get("bytes", 0.0) / (PEAK_HBM_GBS * 1e9)) for m in pl.meta.values())
+        charged_ms = sum(ms[i] for i in pl.meta)
+        out["composite_roofline"] = {
+            "bound_ms_per_step": round(comp_s * 1e3, 4), "measured_ms_per_step": round(ms_step, 4), "frac": round(comp_s * 1e3 / ms_step, 4),
+            "bound_images_per_s": round(B / comp_s, 1), "peaks": {"mfma_tflops": PEAK_BF16_TFLOPS, "hbm_gbs": PEAK_HBM_GBS},
+            "mfma_bound_launches": sum(1 for m in pl.meta.values() if m["flops"] / (PEAK_BF16_TFLOPS * 1e12) >= m.get("bytes", 0.0) / (PEAK_HBM_GBS * 1e9)),
+            "hbm_bound_launches": sum(1 for m in pl.meta.values() if m["flops"] / (PEAK_BF16_TFLOPS * 1e12) < m.get("bytes", 0.0) / (PEAK_HBM_GBS * 1e9)),
+            "kernel_time_share_of_uncharged_launches": round(1.0 - charged_ms / max(total_ms, 1e-9), 4),
+            "alg_bytes_per_step_of_charged_launches": round(sum(m.get("bytes", 0.0) for m in pl.meta.values())),
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu

@@ -353,7 +353,7 @@ def dp_plan(config: Dict, family: str, norm: str, world: int, per_rank_batch: in
     # conv1 | conv2 halves of a CSP layer and the 3x3 | 1x1 branches of a RepVGG block, the level projections whose inputs exist together.
     spec = state_spec(config, family)
     bn_layers = [n[: -len(".weight")] for n, (_, kind) in spec.items() if kind == "bn_w"]
-    pairs = 0
+    pairs = repvgg_pairs = 0
     if family == "fai_detr":
         parents = {}
         for n in bn_layers:
@@ -362,12 +362,22 @@ def dp_plan(config: Dict, family: str, norm: str, world: int, per_rank_batch: in
                 i = parts.index("conv1") if "conv1" in parts else parts.index("conv2")
                 if parts[i - 1] != "backbone":
                     parents.setdefault(".".join(parts[:i]), set()).add(parts[i])
-        pairs = sum(1 for v in parents.values() if v == {"conv1", "conv2"}) + sum(1 for n in bn_layers if ".short." in n)
+        full = [k for k, v in parents.items() if v == {"conv1", "conv2"}]
+        repvgg_pairs = sum(1 for k in full if ".bottlenecks." in k)
+        pairs = len(full) + sum(1 for n in bn_layers if ".short." in n)
+    # BUILT (round 6, train_nn._SiblingConvBnFn): every pair shares its FORWARD collective; the shortcut | branch2a and CSP conv1 | conv2 pairs
+    # share the backward one too (the node waits for both output gradients); a RepVGG block's 3x3 branch gets its gradient out of the 1x1
+    # branch's post-collective pass, so its two backward collectives stay apart
+    fwd = len(bn_layers) - pairs
+    bwd = len(bn_layers) - (pairs - repvgg_pairs)
     syncbn = {"batchnorm_layers": len(bn_layers), "collectives_per_step": 2 * len(bn_layers),
               "sibling_pairs_that_could_share_a_collective": pairs,
               "collectives_per_step_with_siblings_coalesced": 2 * (len(bn_layers) - pairs),
-              "note": "one all-reduce per layer and direction today (what nn.SyncBatchNorm issues); siblings = same input (forward) / same output "
-                      "gradient (backward); everything else is a chain of data dependencies and cannot be batched without changing the arithmetic"}
+              "collectives_per_step_as_built": fwd + bwd, "forward_collectives_as_built": fwd, "backward_collectives_as_built": bwd,
+              "note": "nn.SyncBatchNorm issues one all-reduce per layer and direction; siblings = layers whose conv outputs exist together (same "
+                      "input forward / gradients that meet in one autograd node backward) share ONE all-reduce of their concatenated [2, C] sums "
+                      "(FX_BN_SIBLINGS, default on; bit-identical results); everything else is a chain of data dependencies and cannot be batched "
+                      "without changing the arithmetic"}
     # ring all-reduce moves 2 (N-1)/N of the buffer per rank and direction; xGMI is point-to-point (7 links x ~153 GB/s per GPU)
     ring = 2.0 * (world - 1) / max(world, 1) * total * grad_bytes
     return {"world_size": world, "per_rank_batch": per_rank_batch, "global_batch": per_rank_batch * world, "trainable_parameters": total,

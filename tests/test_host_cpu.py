@@ -495,6 +495,8 @@ def test_dp_plan_counts_the_syncbn_collectives_of_the_real_module_tree():
     sb = plan["syncbn"]
     assert sb["batchnorm_layers"] == 97 and sb["collectives_per_step"] == 194
     assert sb["sibling_pairs_that_could_share_a_collective"] == 20 and sb["collectives_per_step_with_siblings_coalesced"] == 154
+    # as built (round 6, train_nn._SiblingConvBnFn): all 20 pairs share the forward collective, the 8 shortcut / CSP pairs the backward one too
+    assert sb["forward_collectives_as_built"] == 77 and sb["backward_collectives_as_built"] == 89 and sb["collectives_per_step_as_built"] == 166
     assert dp_plan(cfg, "fai_detr", "FrozenBN", 8, 16)["syncbn"] is None
     with mock.patch("torch.cuda.is_available", return_value=True), mock.patch("focoos_amd._lib.load", return_value=None):
         from focoos_amd.train_detr import FAIDetrTrainable
