@@ -634,14 +634,15 @@ def infer_measure(args, world, rank, local, light=False):
     keys = ("det_scores", "det_labels", "det_boxes", "det_count") + (("det_query", "det_area") if mf else ())
     if mf and args.mf_masks_d2h:
         keys += ("mask_words",)
-    # RT-DETR: THROUGHPUT mode by default (engine.pipeline(): `depth` batches in flight, each a whole-batch plan on its own stream - batch
+    # THROUGHPUT mode by default, all three families (engine.pipeline(): `depth` batches in flight, each a whole-batch plan on its own stream - batch
     # i+1's backbone beside batch i's decoder tail).  A step is still ONE batch through the whole path (D2D hand-over, graph replay, D2H of
     # the packed detections); the timed region is K such steps between two full synchronisations.  --pipeline 1 = one batch at a time
     # (engine.forward()'s form: two half-batch parts side by side), also measured below and reported as `single_batch_in_flight`.
-    depth = 1 if mf else (args.pipeline if args.pipeline is not None else int(os.environ.get("FX_PIPELINE_DEPTH", "3")))
+    depth = args.pipeline if args.pipeline is not None else int(os.environ.get("FX_PIPELINE_DEPTH", "3"))
     pipe = None
     if depth > 1:
-        pipe = eng.pipeline(B, args.size, args.size, depth, False, args.streams or 1)
+        pipe = (eng.pipeline(B, args.size, args.size, depth, False, args.streams or 1, args.mf_full_masks) if mf
+                else eng.pipeline(B, args.size, args.size, depth, False, args.streams or 1))
         depth = pipe.depth
     if pipe is not None and depth > 1:
         pl = pipe.lanes[0][0]
@@ -684,7 +685,7 @@ def infer_measure(args, world, rank, local, light=False):
     single = None
     if pipe is not None and depth > 1 and not light:
         # the same K steps with ONE batch in flight (engine.forward()'s structure: two half-batch parts side by side, next batch after the join)
-        pl1 = eng.plan(B, args.size, args.size, False, None)
+        pl1 = eng.plan(B, args.size, args.size, False, args.mf_full_masks, None) if mf else eng.plan(B, args.size, args.size, False, None)
         host1 = {k: torch.empty_like(getattr(pl1, k), device="cpu").pin_memory() for k in keys}
         st1 = eng.stream
 

@@ -110,6 +110,20 @@ class BfEngine(StdcEngineMixin, _EngineBase):
                                else _MultiPlan(self, _BfPlan, B, H, W, f32_input, nsplit, full_masks=full))
         return self.plans[key]
 
+    def pipeline(self, B: int, H: int, W: int, depth: Optional[int] = None, f32_input: bool = False, nsplit: int = 1, full_masks: Optional[bool] = None):
+        """Throughput mode: `depth` batches in flight, each on its own whole-batch plan and stream (engine._Pipeline; see DetrEngine.pipeline)."""
+        from .engine import DEFAULT_PIPELINE_DEPTH, _Pipeline
+
+        full = self.full_masks if full_masks is None else bool(full_masks)
+        if depth is None:
+            depth = int(os.environ.get("FX_PIPELINE_DEPTH", str(DEFAULT_PIPELINE_DEPTH)))
+        if not _lib.two_queue_safe():
+            depth, nsplit = 1, 1
+        key = ("pipeline", B, H, W, f32_input, full, nsplit, depth)
+        if key not in self.plans:
+            self.plans[key] = _Pipeline(self, _BfPlan, B, H, W, f32_input, depth, nsplit, full_masks=full)
+        return self.plans[key]
+
     def forward(self, images: torch.Tensor, threshold: Optional[float] = None, forced_attn: Optional[Sequence[torch.Tensor]] = None,
                 use_graph: bool = True, full_masks: Optional[bool] = None) -> "_BfPlan":
         """images: uint8 [B,H,W,3] (fused normalise path) or float32 [B,H,W,3] (0..255 scale) on the engine device; the model runs

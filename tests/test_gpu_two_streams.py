@@ -109,3 +109,43 @@ def test_pipeline_lanes_equal_single_plan():
     pipe.synchronize()
     assert bad == 0, f"{bad} of 36 pipelined batches differ from the one-batch-at-a-time result"
     assert int(ref[0]["det_count"].sum()) > 0 and not torch.equal(ref[0]["probs"], ref[1]["probs"])   # the comparison is not vacuous
+
+
+@pytest.mark.parametrize("family", ["fai_mf", "bisenetformer"])
+def test_pipeline_lanes_equal_single_plan_mask_families(family):
+    """The throughput mode of the MaskFormer (bs=4, 320x384) and BiSeNetFormer (bs=8, 384x512) engines: three different batches in flight,
+    8 rounds, every batch's class probabilities, low-resolution mask probabilities and packed detections equal the one-batch-at-a-time run."""
+    from focoos_amd.model import BisenetFormer, FAIMaskFormer
+    from focoos_amd.registry import ModelRegistry
+    from focoos_amd.synth import synth_image_structured as sis
+
+    if family == "fai_mf":
+        cfg, cls, B, H, W = ModelRegistry.get_model_info("fai-mf-l-coco-ins")["config"], FAIMaskFormer, 4, 320, 384
+    else:
+        cfg, cls, B, H, W = ModelRegistry.get_model_info("bisenetformer-l-ade")["config"], BisenetFormer, 8, 384, 512
+    eng = cls(cfg, device="cuda:0", seed=0).engine
+    depth = 3
+    batches = [torch.from_numpy(np.stack([sis(500 + 20 * j + i, H, W) for i in range(B)])).to("cuda:0") for j in range(depth)]
+    sizes = torch.tensor([[H, W]] * B, dtype=torch.int32, device="cuda:0")
+    keys = ("probs", "mask_probs", "det_count", "det_scores", "det_boxes")
+    single = eng.plan(B, H, W, False, None, 1)
+    st = eng.stream
+    ref = []
+    for x in batches:
+        with torch.cuda.stream(st):
+            single.input.copy_(x)
+            single.sizes.copy_(sizes)
+            single.run(st.cuda_stream, 0.3, None, True)
+        st.synchronize()
+        ref.append({k: getattr(single, k).clone() for k in keys})
+    pipe = eng.pipeline(B, H, W, depth)
+    assert pipe.depth == depth and len({s.cuda_stream for _, s in pipe.lanes}) == depth
+    bad = 0
+    for rnd in range(8):
+        tickets = [pipe.submit(batches[(j + rnd) % depth], sizes, 0.3) for j in range(depth)]
+        for j, t in enumerate(tickets):
+            pl = pipe.wait(t)
+            bad += not all(torch.equal(ref[(j + rnd) % depth][k], getattr(pl, k)) for k in keys)
+    pipe.synchronize()
+    assert bad == 0, f"{bad} of 24 pipelined batches differ from the one-batch-at-a-time result"
+    assert not torch.equal(ref[0]["probs"], ref[1]["probs"])
