@@ -332,3 +332,18 @@ def test_checkpoint_file_roundtrip(setup, tmp_path):
     out_a = model.forward(x_u8)
     out_b = fm.model.forward(x_u8)
     assert torch.equal(out_a.logits, out_b.logits) and torch.equal(out_a.boxes, out_b.boxes)
+
+
+@pytest.mark.parametrize("name,size,nb", [("fai-detr-l-obj365", 640, 4), ("bisenetformer-l-ade", 256, 4)])
+def test_infer_stream_equals_infer_batch(name, size, nb):
+    """FocoosModel.infer_stream (round 6: the engine's throughput mode behind the public surface - up to three batches in flight) yields, batch
+    for batch and in order, exactly what infer_batch returns for the same images (class ids, integer boxes, scores, mask strings)."""
+    fm = ModelManager.get(name, device=DEV, seed=3)
+    batches = [[synth_image_structured(700 + 10 * j + i, size, size) for i in range(nb)] for j in range(5)]
+    want = [fm.infer_batch(b, threshold=0.3) for b in batches]
+    got = list(fm.infer_stream(iter(batches), threshold=0.3))
+    assert len(got) == len(want) == 5 and sum(len(d.detections) for w in want for d in w) > 0
+    for w, g_ in zip(want, got):
+        assert len(w) == len(g_) == nb
+        for dw, dg in zip(w, g_):
+            assert [(d.cls_id, d.bbox, d.conf, d.mask) for d in dw.detections] == [(d.cls_id, d.bbox, d.conf, d.mask) for d in dg.detections]
