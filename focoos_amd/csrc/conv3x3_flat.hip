@@ -401,6 +401,15 @@ int fx_launch_pw_flat(const ConvArgs& c, const bf16_t* w_frag, hipStream_t strea
       default: return FX_ERR_UNSUPPORTED;
     }
   }
+  // round 6: 64-pixel tiles (TM = 2: 64 KiB of chunk buffers, 127 registers) for the SMALL-M deep-K pointwise layers (the 20x20 level: res5's
+  // branch2a / shortcut, the 2048 -> 256 projection; M = 12 800 at bs = 32) - twice the workgroups, two of them per CU.  Measured per launch
+  // (profiles/r06_pw_knobs.txt): 92.6 -> 82.7, 86.1 -> 75.8, 43.1 -> 38.0, 42.5 -> 36.1, 40.7 -> 28.5 us; at M = 51 200 (res4's branch2a) no
+  // change, so the limit stays FX_PWF_BM64_MAX_M (20 000; 0 = off).
+  static const int bm64 = fx_tune("FX_PWF_BM64_MAX_M", 20000);
+  if (c.M <= bm64 && (mode == 0 || mode == 3)) {
+    if (mode == 0) return launch_c3<1, 256, 2, 2, 4, 1, FX_ACT_RELU, 0>(a, stream);
+    return launch_c3<1, 256, 2, 2, 4, 1, FX_ACT_NONE, 0>(a, stream);
+  }
   switch (mode) {
     case 0: return launch_c3<1, 256, 2, 4, 4, 1, FX_ACT_RELU, 0>(a, stream);
     case 1: return launch_c3<1, 256, 2, 4, 4, 1, FX_ACT_SILU, 0>(a, stream);
