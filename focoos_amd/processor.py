@@ -264,8 +264,15 @@ def trim_mask(mask: np.ndarray, bbox) -> np.ndarray:
 
 
 def binary_mask_to_base64(binary_mask: np.ndarray) -> str:
-    """focoos/utils/vision.py:270-293: 8-bit grayscale PNG (0/255) of the mask, base64-encoded.  The reference encodes with
-    cv2.imencode; this host tail writes the PNG container directly (zlib), so the bytes differ but decode to the same image."""
+    """focoos/utils/vision.py:270-293: 8-bit grayscale PNG (0 / 255) of the mask, base64-encoded.
+
+    The reference calls ``cv2.imencode(".png", mask)``; cv2 is not a dependency of this package, so the PNG is written here with the encoder
+    settings OpenCV's PngEncoder uses when no parameter is given (modules/imgcodecs/src/grfmt_png.cpp: filter SUB on every row, zlib level
+    Z_BEST_SPEED, strategy Z_RLE, no ancillary chunks) and libpng's framing (IDAT chunks of 8 192 bytes, the zlib header's window size
+    reduced to the smallest that covers the image - libpng's optimize_cmf).  GUARANTEE: the string decodes to exactly the reference's image
+    (tests/test_host_cpu.py decodes it with PIL).  Byte-equality with cv2's output is what these settings aim at but it cannot be pinned
+    here (no cv2 in this image, and the reference's own test builds its expectation with cv2 at run time, tests/utils/conftest.py:18-26): it
+    additionally depends on the zlib build inside the cv2 wheel.  Where the reference is installed (integration mode) its own function is used."""
     import base64
     import struct
     import zlib
@@ -274,12 +281,29 @@ def binary_mask_to_base64(binary_mask: np.ndarray) -> str:
     if img.ndim != 2:
         raise ValueError("binary_mask must be 2-D")
     h, w = img.shape
-    raw = b"".join(b"\x00" + img[y].tobytes() for y in range(h))
+    # filter type 1 (SUB, bytes per pixel = 1): byte - left neighbour (mod 256), the first byte of a row as it is
+    sub = img.copy()
+    if w > 1:
+        sub[:, 1:] = img[:, 1:] - img[:, :-1]
+    raw = np.concatenate([np.ones((h, 1), dtype=np.uint8), sub], axis=1).tobytes()
+    co = zlib.compressobj(1, zlib.DEFLATED, 15, 8, zlib.Z_RLE)
+    z = bytearray(co.compress(raw) + co.flush())
+    # libpng's optimize_cmf: claim the smallest window >= the uncompressed size in the zlib header (the deflate stream itself is unchanged)
+    if len(z) >= 2 and (z[0] & 0x0F) == 8 and len(raw) <= 16384:
+        cinfo, half = z[0] >> 4, 1 << ((z[0] >> 4) + 7)
+        while len(raw) <= half and cinfo > 0:
+            cinfo -= 1
+            half >>= 1
+        z[0] = (cinfo << 4) | 8
+        z[1] &= 0xE0
+        z[1] += 0x1F - ((z[0] << 8) + z[1]) % 0x1F
+    z = bytes(z)
 
     def chunk(tag: bytes, data: bytes) -> bytes:
         return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
 
-    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b"")
+    idat = b"".join(chunk(b"IDAT", z[i:i + 8192]) for i in range(0, max(len(z), 1), 8192))
+    png = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 0, 0, 0, 0)) + idat + chunk(b"IEND", b"")
     return base64.b64encode(png).decode("utf-8")
 
 

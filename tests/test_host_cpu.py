@@ -506,3 +506,46 @@ def test_dp_plan_counts_the_syncbn_collectives_of_the_real_module_tree():
     live = [m for m in layers if m._norm_h.weight.requires_grad]
     # the dead mask_features conv of RT-DETR is frozen out of the training graph (train_nn.HybridEncoder): every other BatchNorm is live
     assert len(layers) >= 97 and len(live) in (97, 96), (len(layers), len(live))
+
+
+def test_binary_mask_to_base64_decodes_to_the_mask_with_cv2_like_framing():
+    """focoos/utils/vision.py:270-293.  The standalone surface GUARANTEES decode-equality: the base64 string is a PNG that
+    decodes (PIL) to the 0 / 255 image of the mask - 1x1, odd sizes, a mask whose compressed stream spans several 8 192-byte IDAT chunks.  The
+    framing follows cv2.imencode's defaults (SUB filter on every row, zlib level 1 / Z_RLE, 8-bit grayscale, IHDR + IDAT... + IEND only);
+    byte-equality with cv2 cannot be pinned here (no cv2; the reference's own test computes its expectation with cv2 at run time)."""
+    import base64
+    import io
+    import struct
+    import zlib
+
+    from PIL import Image
+
+    from focoos_amd.processor import binary_mask_to_base64
+
+    rng = np.random.RandomState(0)
+    for shape in [(2, 2), (1, 1), (5, 7), (64, 64), (300, 517)]:
+        m = rng.rand(*shape) > 0.5
+        raw = base64.b64decode(binary_mask_to_base64(m))
+        im = np.array(Image.open(io.BytesIO(raw)))
+        assert im.dtype == np.uint8 and np.array_equal(im, m.astype(np.uint8) * 255), shape
+        # container: signature, IHDR (8-bit gray, no interlace), IDAT chunks of at most 8 192 bytes, IEND; every row filtered with SUB (type 1)
+        assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+        pos, tags, idat = 8, [], b""
+        while pos < len(raw):
+            n, tag = struct.unpack(">I", raw[pos:pos + 4])[0], raw[pos + 4:pos + 8]
+            body = raw[pos + 8:pos + 8 + n]
+            assert struct.unpack(">I", raw[pos + 8 + n:pos + 12 + n])[0] == zlib.crc32(tag + body) & 0xFFFFFFFF
+            tags.append((tag, n))
+            if tag == b"IDAT":
+                idat += body
+            if tag == b"IHDR":
+                assert struct.unpack(">IIBBBBB", body) == (shape[1], shape[0], 8, 0, 0, 0, 0)
+            pos += 12 + n
+        assert tags[0][0] == b"IHDR" and tags[-1] == (b"IEND", 0) and all(t == b"IDAT" and n <= 8192 for t, n in tags[1:-1])
+        if shape == (300, 517):
+            assert len(tags) > 4          # several IDAT chunks
+        rows = zlib.decompress(idat)
+        assert len(rows) == shape[0] * (shape[1] + 1) and set(rows[:: shape[1] + 1]) == {1}
+    # the reference's own fixture mask (tests/utils/conftest.py:12-15)
+    s = binary_mask_to_base64(np.array([[1, 0], [0, 1]], dtype=bool))
+    assert np.array_equal(np.array(Image.open(io.BytesIO(base64.b64decode(s)))), np.array([[255, 0], [0, 255]], dtype=np.uint8))
