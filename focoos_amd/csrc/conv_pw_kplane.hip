@@ -57,7 +57,9 @@ __device__ __forceinline__ float pwk_act(float v, std::integral_constant<int, FX
 // K = 256 and <= 168 registers, THREE workgroups per CU: these layers are HBM-bound, and what a CU can keep in flight towards memory is set by
 // the number of waves that are in a load / store phase, not by its MFMA rate - at 64 pixels a wave issues one memory instruction per MFMA,
 // which would cap an MFMA-bound kernel at half rate and costs nothing here).
-template <int K, int ACT, int RESMODE, int TM = 4>
+// ABL: ablation switches of scripts/probes/pw_probe.hip (1: weight ring never refilled, 2: no output stores, 4: residual not read,
+//      8: no MFMAs, 16: pixel tile not fetched); 0 in the product.
+template <int K, int ACT, int RESMODE, int TM = 4, int ABL = 0>
 __global__ __launch_bounds__(256, TM == 4 ? 2 : 3) void conv_pw_kplane_kernel(const PWKArgs p) {
   constexpr int TN = 2, NW = 4, BM = TM * 32, BN = 256;
   constexpr int NTHR = 256, NDW = NTHR / 64;
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256, TM == 4 ? 2 : 3) void conv_pw_kplane_kernel(co
       const int blk = i / NP, c = i % NP;
       const int m = m0 + blk * 64 + lane;
       const int pln = (c & 1) * KS + (c >> 1);
-      pw_dma16(xr, smem + pln * PLANE + blk * 1024, m < p.M ? (unsigned)(m * p.ldx + c * 8) * 2u : FX_OOB);
+      if constexpr (!(ABL & 16)) pw_dma16(xr, smem + pln * PLANE + blk * 1024, m < p.M ? (unsigned)(m * p.ldx + c * 8) * 2u : FX_OOB);
     }
   }
   f32x16 acc[TN][TM];
@@ -151,12 +153,14 @@ __global__ __launch_bounds__(256, TM == 4 ? 2 : 3) void conv_pw_kplane_kernel(co
         for (int a = 0; a < TN; ++a) {
 #pragma unroll
           for (int b = 0; b < TM; ++b) {
-            acc[a][b] = FX_MFMA_32x32x16(ar[j][a], xb[j & 1][b], acc[a][b]);
+            if constexpr (!(ABL & 8)) acc[a][b] = FX_MFMA_32x32x16(ar[j][a], xb[j & 1][b], acc[a][b]);
             if (a == 0) {   // fragment b of the next k-step (behind the last one of the n-tile: k-step 0 again, unused)
               if constexpr (j + 1 < PF) xb[(j + 1) & 1][b] = pwk_lds_read<(j + 1) * PLANE>(addr[b] + aoff);
               else xb[0][b] = pwk_lds_read<PF * PLANE>(addr[b] + (last ? -PF * PLANE : aoff));
             }
-            if (b == TM - 1) pwk_ldg<j * 1024>(ar[j][a], wvoff, wnext[a]);
+            if constexpr (!(ABL & 1)) {
+              if (b == TM - 1) pwk_ldg<j * 1024>(ar[j][a], wvoff, wnext[a]);
+            }
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -167,6 +171,10 @@ __global__ __launch_bounds__(256, TM == 4 ? 2 : 3) void conv_pw_kplane_kernel(co
     // row block ahead of its use.  (Ordinary loads: they are younger than the ring refills in flight, so the compiler's own vmcnt
     // waits stay correct - a wait for them also covers the refills, which the next n-tile needs first thing anyway.)
     uint4 rr[2][TN * 2];
+    if constexpr (ABL & 4) {
+#pragma unroll
+      for (int i = 0; i < 2 * TN * 2; ++i) (&rr[0][0])[i] = make_uint4(0, 0, 0, 0);
+    }
     auto ld_res = [&](int b, uint4* dst) {
       const int m = min(m0 + b * 32 + l32, p.M - 1);
       const bf16_t* rrow = p.res + (size_t)m * p.ldr + n0 + wave * TN * 32 + half * 8;
@@ -175,10 +183,10 @@ __global__ __launch_bounds__(256, TM == 4 ? 2 : 3) void conv_pw_kplane_kernel(co
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2) dst[a * 2 + g2] = *reinterpret_cast<const uint4*>(rrow + a * 32 + g2 * 16);
     };
-    if constexpr (RESMODE != 0) ld_res(0, rr[0]);
+    if constexpr (RESMODE != 0 && !(ABL & 4)) ld_res(0, rr[0]);
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
-      if constexpr (RESMODE != 0) {
+      if constexpr (RESMODE != 0 && !(ABL & 4)) {
         if (b + 1 < TM) ld_res(b + 1, rr[(b + 1) & 1]);
       }
       const int row = b * 32 + l32;
@@ -224,7 +232,7 @@ __global__ __launch_bounds__(256, TM == 4 ? 2 : 3) void conv_pw_kplane_kernel(co
             pk[0][w] = sw[0];
             pk[1][w] = sw[1];
           }
-          if (live) *reinterpret_cast<uint4*>(yrow + a * 32 + g2 * 16) = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
+          if (live && !((ABL & 2) && p.M > 0)) *reinterpret_cast<uint4*>(yrow + a * 32 + g2 * 16) = make_uint4(pk[0][0], pk[0][1], pk[1][0], pk[1][1]);
         }
     }
   }
@@ -236,7 +244,7 @@ __global__ __launch_bounds__(256, TM == 4 ? 2 : 3) void conv_pw_kplane_kernel(co
   }
 }
 
-template <int K, int ACT, int RESMODE, int TM = 4>
+template <int K, int ACT, int RESMODE, int TM = 4, int ABL = 0>
 static int launch_pwk(PWKArgs& a, hipStream_t stream) {
   static const int one_per_cu = fx_tune("FX_PWK_ONE_PER_CU", 0);   // A/B knob: pad the LDS request so that one workgroup owns a CU
   constexpr int BM = TM * 32, BN = 256;
@@ -254,7 +262,7 @@ static int launch_pwk(PWKArgs& a, hipStream_t stream) {
   groups = (NT + a.ntg - 1) / a.ntg;
   static const int rot = fx_tune("FX_PWK_ROT", 1);
   a.rot = rot;
-  auto kern = conv_pw_kplane_kernel<K, ACT, RESMODE, TM>;
+  auto kern = conv_pw_kplane_kernel<K, ACT, RESMODE, TM, ABL>;
   static int attr_smem = 0;
   if (smem > attr_smem) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) return FX_ERR_RUNTIME;
