@@ -467,8 +467,17 @@ int fx_launch_conv3x3_kplane(const ConvArgs& c, const bf16_t* w_frag, hipStream_
     if (mode == 1) return launch_c3k<2, 2, 1, 4, 608, FX_ACT_SILU, 0, 0, 0>(a, stream);
     if (mode == 3) return launch_c3k<2, 2, 1, 4, 608, FX_ACT_NONE, 0, 0, 0>(a, stream);
   }
+  // round 6: the loader-less multi-chunk form (two workgroups per CU) for N % 256 == 0 layers without a residual from FX_C3K_DUO256_MIN_M pixels on
+  // (default 40 000; 0 = never): +3-4 % per launch at M >= 51 200 in the stand-alone probe (profiles/r06_c3_duo_probe.txt; -6 % at M = 25 600,
+  // where 200 tiles leave one workgroup per CU), +1 % on the three-lane headline in one call (5 099 / 5 099 -> 5 142 / 5 159 img/s, `roofline.frac`
+  // 0.408 -> 0.423)
+  static const int duo256_min_m = fx_tune("FX_C3K_DUO256_MIN_M", 40000);
+  const bool duo256 = duo256_min_m > 0 && c.M >= duo256_min_m && !c.res && hlp == 320 && c.N % 256 == 0;
 #define FX_C3K_TILE(ACT_, RM_)                                                             \
   {                                                                                        \
+    if constexpr (RM_ == 0) {                                                              \
+      if (duo256) return launch_c3k<2, 4, 4, 1, 320, ACT_, 0, 0, 0>(a, stream);            \
+    }                                                                                      \
     if (small) return launch_c3k<2, 2, 4, 1, 192, ACT_, RM_>(a, stream);                   \
     if (c.N == 64) return launch_c3k<2, 4, 1, 4, 960, ACT_, RM_>(a, stream);               \
     if (c.N == 128) return launch_c3k<2, 4, 2, 2, 512, ACT_, RM_>(a, stream);              \

@@ -701,6 +701,10 @@ FLAT_CASES = [
     (2, 33, 47, 64, 64, "relu", False, 8),
     (1, 40, 200, 64, 64, None, False, 0),       # MaskFormer res2 width, no activation (the input-gradient form of the training graph)
     (3, 16, 32, 64, 64, "relu", False, 0),      # exactly one tile per image
+    # round 6: M >= 40 000 without a residual = the loader-less multi-chunk form (two workgroups per CU, FX_C3K_DUO256_MIN_M): four channel
+    # chunks through ONE halo buffer, partial last tile (M = 40 960 + 37 rows of a ninth image would not divide - 8 x 64 x 81 = 41 472 does not either)
+    (8, 64, 81, 256, 256, "silu", False, 0),
+    (13, 40, 80, 256, 512, "relu", False, 8),   # N = 512 (two n-tiles per pixel tile), strided input rows, M = 41 600
 ]
 
 
