@@ -65,7 +65,6 @@ __device__ __forceinline__ float c3k_act(float v, std::integral_constant<int, FX
 template <int TN, int TM, int WN, int WM, int HLP, int ACT, int RESMODE, int ABL = 0, int LD = 1>
 __global__ __launch_bounds__((WN* WM + LD) * 64, LD ? 1 : 2) void conv3x3_kplane_kernel(const C3KArgs p) {
   constexpr int NW = WN * WM, NT = (NW + LD) * 64, NDW = NW + LD;
-  static_assert(LD == 1 || RESMODE == 0, "the loader-less form has no residual path");
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int KJ = 4, PF = KJ;
   constexpr int PLANE = (HLP + 1) * 16, BUF = 8 * PLANE;
@@ -472,12 +471,12 @@ int fx_launch_conv3x3_kplane(const ConvArgs& c, const bf16_t* w_frag, hipStream_
   // where 200 tiles leave one workgroup per CU), +1 % on the three-lane headline in one call (5 099 / 5 099 -> 5 142 / 5 159 img/s, `roofline.frac`
   // 0.408 -> 0.423)
   static const int duo256_min_m = fx_tune("FX_C3K_DUO256_MIN_M", 40000);
-  const bool duo256 = duo256_min_m > 0 && c.M >= duo256_min_m && !c.res && hlp == 320 && c.N % 256 == 0;
+  static const int duo256_res = fx_tune("FX_C3K_DUO256_RES", 1);   // also the layers WITH a residual (the output tile goes through LDS: 64 KiB per workgroup)
+  const bool duo256 = duo256_min_m > 0 && c.M >= duo256_min_m && (!c.res || duo256_res) && c.N % 256 == 0;   // hlp 320 (W <= 95) and 576 (MaskFormer's 200-wide level: one 74 KiB buffer, two per CU)
 #define FX_C3K_TILE(ACT_, RM_)                                                             \
   {                                                                                        \
-    if constexpr (RM_ == 0) {                                                              \
-      if (duo256) return launch_c3k<2, 4, 4, 1, 320, ACT_, 0, 0, 0>(a, stream);            \
-    }                                                                                      \
+    if (duo256 && hlp == 320) return launch_c3k<2, 4, 4, 1, 320, ACT_, RM_, 0, 0>(a, stream); \
+    if (duo256) return launch_c3k<2, 4, 4, 1, 576, ACT_, RM_, 0, 0>(a, stream);            \
     if (small) return launch_c3k<2, 2, 4, 1, 192, ACT_, RM_>(a, stream);                   \
     if (c.N == 64) return launch_c3k<2, 4, 1, 4, 960, ACT_, RM_>(a, stream);               \
     if (c.N == 128) return launch_c3k<2, 4, 2, 2, 512, ACT_, RM_>(a, stream);              \

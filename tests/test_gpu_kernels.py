@@ -705,6 +705,7 @@ FLAT_CASES = [
     # chunks through ONE halo buffer, partial last tile (M = 40 960 + 37 rows of a ninth image would not divide - 8 x 64 x 81 = 41 472 does not either)
     (8, 64, 81, 256, 256, "silu", False, 0),
     (13, 40, 80, 256, 512, "relu", False, 8),   # N = 512 (two n-tiles per pixel tile), strided input rows, M = 41 600
+    (7, 80, 80, 256, 256, "silu", True, 0),     # the CSP tail at large M: SiLU then + residual (output tile through LDS; the two-workgroup form under FX_C3K_DUO256_RES=1)
 ]
 
 
