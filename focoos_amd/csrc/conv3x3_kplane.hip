@@ -473,8 +473,11 @@ int fx_launch_conv3x3_kplane(const ConvArgs& c, const bf16_t* w_frag, hipStream_
   static const int duo256_min_m = fx_tune("FX_C3K_DUO256_MIN_M", 40000);
   static const int duo256_res = fx_tune("FX_C3K_DUO256_RES", 1);   // also the layers WITH a residual (the output tile goes through LDS: 64 KiB per workgroup)
   const bool duo256 = duo256_min_m > 0 && c.M >= duo256_min_m && (!c.res || duo256_res) && c.N % 256 == 0;   // hlp 320 (W <= 95) and 576 (MaskFormer's 200-wide level: one 74 KiB buffer, two per CU)
+  static const int duo128_on = fx_tune("FX_C3K_DUO128", 0);   // N = 128 (res3's branch2b): 256 x 128 tiles, one 66 KiB buffer
+  const bool duo128 = duo128_on && duo256_min_m > 0 && c.M >= duo256_min_m && c.N == 128 && (!c.res || duo256_res);
 #define FX_C3K_TILE(ACT_, RM_)                                                             \
   {                                                                                        \
+    if (duo128) return launch_c3k<2, 4, 2, 2, 512, ACT_, RM_, 0, 0>(a, stream);            \
     if (duo256 && hlp == 320) return launch_c3k<2, 4, 4, 1, 320, ACT_, RM_, 0, 0>(a, stream); \
     if (duo256) return launch_c3k<2, 4, 4, 1, 576, ACT_, RM_, 0, 0>(a, stream);            \
     if (small) return launch_c3k<2, 2, 4, 1, 192, ACT_, RM_>(a, stream);                   \
