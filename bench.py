@@ -54,6 +54,7 @@ def parse():
                          "parts (engine.forward()'s form)")
     ap.add_argument("--streams", type=int, default=None, help="concurrent batch parts per step (default: engine default / FX_STREAMS)")
     ap.add_argument("--mf-full-masks", action="store_true", help="fai-mf-*: also write the reference's [B,Q,H,W] fp32 `masks` tensor")
+    ap.add_argument("--mf-masks-dtype", default="fp32", choices=["fp32", "bf16"], help="fai-mf-* with --mf-full-masks: element type of the [B,Q,H,W] masks tensor")
     ap.add_argument("--mf-masks-d2h", action="store_true", help="fai-mf-*: include the D2H copy of the bit-packed mask buffer in the step")
     ap.add_argument("--model", default="fai-detr-l-obj365")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -589,6 +590,8 @@ def other_configs(args, world, rank, local, out):
             # config 3 also WITH the reference's [B,Q,H,W] fp32 `masks` tensor written (4.1 GB per step at bs = 16, 800^2)
             ("infer_fai-mf-l-coco-ins_bs16_800_fullmasks", dict(train=False, model="fai-mf-l-coco-ins", family="fai_mf", batch=16, size=800, steps=6, warmup=2,
                                                                mf_full_masks=True)),
+            ("infer_fai-mf-l-coco-ins_bs16_800_fullmasks_bf16", dict(train=False, model="fai-mf-l-coco-ins", family="fai_mf", batch=16, size=800, steps=6, warmup=2,
+                                                                    mf_full_masks=True, mf_masks_dtype="bf16")),
             ("train_bisenetformer-l-ade_bs8_1024_bn_fp16", dict(train=True, model="bisenetformer-l-ade", family="bisenetformer", batch=8, size=1024,
                                                                norm="SyncBN" if world > 1 else "BN", steps=4, warmup=4, dtype="fp16"))]
     for name, over in plan:
@@ -628,6 +631,8 @@ def infer_measure(args, world, rank, local, light=False):
     mf = args.family == "fai_mf" or bf     # the two mask families share the engine interface (engine_maskdec.py)
     model = (BisenetFormer if bf else (FAIMaskFormer if mf else FAIDetr))(cfg, device=dev, seed=0)
     eng = model.engine
+    if mf and getattr(args, "mf_masks_dtype", "fp32") != "fp32":
+        eng.masks_dtype = args.mf_masks_dtype
     # image i of rank r = synth_image(r*B + i): seeded uint8 HWC, resident in HBM before the timed region
     imgs = torch.stack([torch.from_numpy(synth_image(rank * B + i, args.size, args.size)) for i in range(B)]).to(dev)
     sizes = torch.tensor([[args.size, args.size]] * B, dtype=torch.int32, device=dev)
@@ -721,7 +726,7 @@ def infer_measure(args, world, rank, local, light=False):
         "config": {"workload": f"{args.model} inference, bf16 MFMA, bs={B}/GPU, {args.size}x{args.size}, random-init weights (seed 0), "
                                "uint8 HWC images resident in HBM, device post-process + D2H of packed detections included"
                                + ((", bit-packed binary masks of the detections " + ("copied D2H" if args.mf_masks_d2h else "left in HBM")
-                                   + (", [B,Q,H,W] fp32 masks tensor written" if args.mf_full_masks else ", [B,Q,H,W] fp32 masks tensor not materialised")) if mf else ""),
+                                   + (f", [B,Q,H,W] {getattr(args, 'mf_masks_dtype', 'fp32')} masks tensor written" if args.mf_full_masks else ", [B,Q,H,W] fp32 masks tensor not materialised")) if mf else ""),
                    "global_batch": B * world, "parallelism": f"replicas x{world} (no data-path collective)", "steps_are": "hipGraph replays",
                    "batches_in_flight": depth, "concurrent_batch_parts": getattr(pl, "n", 1)},
         "alg_gflop_per_image": round(alg, 2),

@@ -89,6 +89,7 @@ SIGNATURES = {
     "fx_query_pixel_logits_bf16": [_vp, _i, _vp, _i, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "fx_mf_class_head": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "fx_mf_upsample_probs_f32": [_vp, _i, _i, _vp, _i, _i, _i, _vp],
+    "fx_mf_upsample_probs_bf16": [_vp, _i, _i, _vp, _i, _i, _i, _vp],
     "fx_mf_postprocess_workspace_bytes": [_i, _i, _i],
     "fx_mf_postprocess_workspace_bytes_fused": [_i, _i, _i, _i, _i, _i],
     "fx_mf_postprocess": [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _f, _f, _i, _vp, C.c_size_t, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
@@ -238,7 +239,7 @@ def lib_path(name: str = None) -> str:
     return os.environ.get("FOCOOS_AMD_LIB", LIB_PATH)
 
 
-FX_ABI_VERSION = 7   # = include/focoos_amd.h (tests/test_host_cpu.py compares the two)
+FX_ABI_VERSION = 8   # = include/focoos_amd.h (tests/test_host_cpu.py compares the two)
 
 
 def load(name: str = None) -> C.CDLL:

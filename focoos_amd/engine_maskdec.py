@@ -350,8 +350,14 @@ class MaskDecoderPlanMixin:
         self._op(lib.fx_query_pixel_logits_bf16, emb.ptr, emb.ld, mf_rows.ptr, mf_rows.ld, 1, self.mask_probs.data_ptr(), PL, None, 0, B, Q, PL, md)
         self.masks = None
         if full_masks:
-            self.masks = self._io("masks", (B, Q, H, W), torch.float32)
-            self._op(lib.fx_mf_upsample_probs_f32, self.mask_probs.data_ptr(), hl, wl, self.masks.data_ptr(), H, W, R)
+            # engine.masks_dtype = "bf16" (FX_MF_MASKS_DTYPE / bench.py --mf-masks-dtype): the [B,Q,H,W] tensor in 16 bits - half the bytes of
+            # the reference's fp32 tensor (4.1 GB per bs = 16 800^2 step), same taps, one rounding at the store; "fp32" (default) = the reference's
+            if getattr(e, "masks_dtype", "fp32") == "bf16":
+                self.masks = self._io("masks", (B, Q, H, W), torch.bfloat16)
+                self._op(lib.fx_mf_upsample_probs_bf16, self.mask_probs.data_ptr(), hl, wl, self.masks.data_ptr(), H, W, R)
+            else:
+                self.masks = self._io("masks", (B, Q, H, W), torch.float32)
+                self._op(lib.fx_mf_upsample_probs_f32, self.mask_probs.data_ptr(), hl, wl, self.masks.data_ptr(), H, W, R)
         self.det_count = self._io("det_count", (B,), torch.int32).zero_()
         self.det_query = self._io("det_query", (B, Q), torch.int32).zero_()
         self.det_scores = self._io("det_scores", (B, Q), torch.float32).zero_()

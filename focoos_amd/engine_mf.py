@@ -68,6 +68,7 @@ class MfEngine(StdcEngineMixin, _EngineBase):
         self.use_mask_score = bool(config.get("use_mask_score", False))
         self.cls_sigmoid = bool(config.get("cls_sigmoid", False))
         self.full_masks = bool(full_masks)
+        self.masks_dtype = os.environ.get("FX_MF_MASKS_DTYPE", "fp32")   # "bf16": the [B,Q,H,W] masks tensor in 16 bits (set before the first plan is built)
         self.load_state_dict(state_dict)
 
     # ------------------------------------------------------------------ weight packing

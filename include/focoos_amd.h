@@ -29,7 +29,7 @@ extern "C" {
 /* Bumped whenever a descriptor struct's layout OR the semantics the host relies on change (version 2: fx_conv_desc grew mask / ldm /
  * reserved0 and the library applies the ReLU mask the previous bottleneck skips; version 3: fx_pw_chain_desc grew pool / ldp / img_h / img_w);
  * focoos_amd/_lib.py refuses a library of another version. */
-#define FX_ABI_VERSION 7
+#define FX_ABI_VERSION 8
 
 enum { FX_OK = 0, FX_ERR_INVALID_ARGUMENT = -1, FX_ERR_LAUNCH = -2, FX_ERR_UNSUPPORTED = -3, FX_ERR_RUNTIME = -4 };
 enum { FX_ACT_NONE = 0, FX_ACT_RELU = 1, FX_ACT_SILU = 2, FX_ACT_GELU = 3 };
@@ -322,6 +322,9 @@ int fx_mf_class_head(const float* logits, int ldl, float* probs, float* score, i
 
 /* FAIMaskFormer.forward tail (:723): masks f32 [BQ][H][W] = bilinear(lowres f32 [BQ][h][w], align_corners=False). */
 int fx_mf_upsample_probs_f32(const float* lowres, int h, int w, float* out, int H, int W, int BQ, fx_stream_t stream);
+/* The same tensor in the library's 16-bit element (bf16): the engine's half-size `masks` option (the fp32 tensor is a 4.1 GB
+ * write per bs = 16 800x800 step) - same taps and fp32 arithmetic, one rounding at the store. */
+int fx_mf_upsample_probs_bf16(const float* lowres, int h, int w, void* out, int H, int W, int BQ, fx_stream_t stream);
 
 /* Device side of MaskFormerProcessor.postprocess (fai_mf/processor.py:212-262 + masks_to_xyxy utils/vision.py:344-370),
  * fused with the x4 bilinear upsample so the [B,Q,H,W] tensor is never materialised: binary mask = upsampled prob >=

@@ -187,6 +187,11 @@ def test_mf_postprocess_vs_oracle(lib, cfg):
     torch.cuda.synchronize()
     ref_full = F.interpolate(lo_t, size=(H, W), mode="bilinear", align_corners=False)
     assert (full.cpu() - ref_full).abs().max() < 2e-6
+    # the 16-bit option of the same tensor (round 6, fx_mf_upsample_probs_bf16): the fp32 values rounded once at the store
+    half = torch.empty(B, Q, H, W, dtype=torch.bfloat16, device=DEV)
+    check(lib.fx_mf_upsample_probs_bf16(lod.data_ptr(), h, w, half.data_ptr(), H, W, B * Q, stream()))
+    torch.cuda.synchronize()
+    assert torch.equal(half, full.to(torch.bfloat16))
     sd, ld_ = dev(score), dev(label.int())
     nb = lib.fx_mf_postprocess_workspace_bytes_fused(B, Q, h, w, H, W) if fused_ws else lib.fx_mf_postprocess_workspace_bytes(B, Q, H)
     if fused_ws and H == 4 * h and W == 4 * w and w % 8 == 0:
