@@ -815,6 +815,7 @@ def infer_measure(args, world, rank, local, light=False):
                 for nm, desc, t, tf in names:
                     f.write(f"{t:9.4f} ms  {tf:8.1f} TF/s  {nm}  {desc}\n")
     barrier(world, False)
+    pipe = step = sync = None     # the lanes' plans (8 GB each at bs = 32) go with the engine before the next leg allocates its own
     del pl, eng, model
     torch.cuda.empty_cache()
     return out if rank == 0 else None
