@@ -20,6 +20,10 @@
 
 #include "pw_common.h"
 
+#ifndef FX_PWK_RES_DEPTH
+#define FX_PWK_RES_DEPTH 3
+#endif
+
 int fx_tune(const char* env_name, int default_value);  // conv_igemm.hip
 
 struct PWKArgs {
@@ -170,10 +174,17 @@ __global__ __launch_bounds__(256, TM == 4 ? 2 : 3) void conv_pw_kplane_kernel(co
     // ---- epilogue of n-tile nt.  Residual: rr[.][a*2+g2] = the 16 bytes this lane will store at (row, a*32 + g2*16 + half*8), one
     // row block ahead of its use.  (Ordinary loads: they are younger than the ring refills in flight, so the compiler's own vmcnt
     // waits stay correct - a wait for them also covers the refills, which the next n-tile needs first thing anyway.)
-    uint4 rr[2][TN * 2];
+    // residual prefetch depth (round 6): RD row blocks of the n-tile are requested before the first is consumed.  The cold-buffer probe
+    // (profiles/r06_pw_probe_cold.txt) shows this epilogue's reads as the launch's bound: 79.5 us as shipped, 41.9 without the residual,
+    // against 39.7 for a copy of the output tensor - one block ahead keeps too few bytes in flight per CU.  Depth 1 / 2 / 3 / 4 in that
+    // probe: 77.8 / 74.5 / 68.4 / 70.1 us (M = 51 200) and 44.7 / 42.7 / 39.6 / 39.3 (M = 25 600); depth 3 costs 64 registers of prefetched rows
+    // (256 VGPRs and 7 spilled dwords per lane outside the K loop).
+    constexpr int RD = (FX_PWK_RES_DEPTH < TM) ? FX_PWK_RES_DEPTH : TM;
+    constexpr int RS = RD + 1 > TM ? TM : RD + 1;      // ring slots (block b + RD is requested while block b is being consumed)
+    uint4 rr[RS][TN * 2];
     if constexpr (ABL & 4) {
 #pragma unroll
-      for (int i = 0; i < 2 * TN * 2; ++i) (&rr[0][0])[i] = make_uint4(0, 0, 0, 0);
+      for (int i = 0; i < RS * TN * 2; ++i) (&rr[0][0])[i] = make_uint4(0, 0, 0, 0);
     }
     auto ld_res = [&](int b, uint4* dst) {
       const int m = min(m0 + b * 32 + l32, p.M - 1);
@@ -183,11 +194,14 @@ __global__ __launch_bounds__(256, TM == 4 ? 2 : 3) void conv_pw_kplane_kernel(co
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2) dst[a * 2 + g2] = *reinterpret_cast<const uint4*>(rrow + a * 32 + g2 * 16);
     };
-    if constexpr (RESMODE != 0 && !(ABL & 4)) ld_res(0, rr[0]);
+    if constexpr (RESMODE != 0 && !(ABL & 4)) {
+#pragma unroll
+      for (int b = 0; b < RD && b < TM; ++b) ld_res(b, rr[b % RS]);
+    }
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
       if constexpr (RESMODE != 0 && !(ABL & 4)) {
-        if (b + 1 < TM) ld_res(b + 1, rr[(b + 1) & 1]);
+        if (b + RD < TM) ld_res(b + RD, rr[(b + RD) % RS]);
       }
       const int row = b * 32 + l32;
       const int m = m0 + row;
@@ -204,7 +218,7 @@ __global__ __launch_bounds__(256, TM == 4 ? 2 : 3) void conv_pw_kplane_kernel(co
         for (int g2 = 0; g2 < 2; ++g2) {
           unsigned pk[2][2], rq[2][2] = {{0u, 0u}, {0u, 0u}};
           if constexpr (RESMODE != 0) {   // store layout -> accumulator layout: the inverse of the swaps below
-            const uint4 R = rr[b & 1][a * 2 + g2];
+            const uint4 R = rr[b % RS][a * 2 + g2];
             const auto s0 = __builtin_amdgcn_permlane32_swap(R.x, R.z, false, false);
             const auto s1 = __builtin_amdgcn_permlane32_swap(R.y, R.w, false, false);
             rq[0][0] = s0[0]; rq[1][0] = s0[1];

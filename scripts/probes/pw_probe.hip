@@ -51,16 +51,20 @@ static Variant mk(const char* name) {
 
 template <int K, int RM>
 static void run_shape(const char* title, int M, int N, int rounds, hipStream_t st) {
+  // NSET copies of (x, res, y), used round-robin: every launch finds its tensors in HBM like a layer inside the step does, not in the 256 MB
+  // Infinity Cache (the first version of this probe re-used ONE set: res4's branch2c read 56 us there and 78 us in the plan)
+  const size_t set_bytes = (size_t)M * K * 2 + (size_t)M * N * 2 * (RM ? 2 : 1);
+  const int NSET = (int)std::min<size_t>(8, std::max<size_t>(1, (size_t)900e6 / set_bytes + 1));
   bf16_t *x, *w, *res, *y;
   float* bias;
-  HIPCHECK(hipMalloc(&x, (size_t)M * K * 2));
+  HIPCHECK(hipMalloc(&x, (size_t)NSET * M * K * 2));
   HIPCHECK(hipMalloc(&w, (size_t)N * K * 2));
-  HIPCHECK(hipMalloc(&res, (size_t)M * N * 2));
-  HIPCHECK(hipMalloc(&y, (size_t)M * N * 2));
+  HIPCHECK(hipMalloc(&res, (size_t)NSET * M * N * 2));
+  HIPCHECK(hipMalloc(&y, (size_t)NSET * M * N * 2));
   HIPCHECK(hipMalloc(&bias, N * 4));
-  HIPCHECK(hipMemset(x, 0x3c, (size_t)M * K * 2));
+  HIPCHECK(hipMemset(x, 0x3c, (size_t)NSET * M * K * 2));
   HIPCHECK(hipMemset(w, 0x3c, (size_t)N * K * 2));
-  HIPCHECK(hipMemset(res, 0x3c, (size_t)M * N * 2));
+  HIPCHECK(hipMemset(res, 0x3c, (size_t)NSET * M * N * 2));
   HIPCHECK(hipMemset(bias, 0, N * 4));
   std::vector<Variant> V;
   V.push_back(mk<K, FX_ACT_RELU, RM, 4, 0>("as shipped (128-pixel tiles)      "));
@@ -78,7 +82,7 @@ static void run_shape(const char* title, int M, int N, int rounds, hipStream_t s
   HIPCHECK(hipEventCreate(&e1));
   const double bytes = (double)M * K * 2 + (double)M * N * 2 * (RM ? 2 : 1);
   const double flop = 2.0 * M * N * K;
-  printf("\n== %s: M=%d K=%d N=%d residual=%d   %.1f MB algorithmic, %.1f GFLOP ==\n", title, M, K, N, RM, bytes * 1e-6, flop * 1e-9);
+  printf("\n== %s: M=%d K=%d N=%d residual=%d   %.1f MB algorithmic, %.1f GFLOP, %d buffer sets ==\n", title, M, K, N, RM, bytes * 1e-6, flop * 1e-9, NSET);
   std::vector<std::vector<float>> times(V.size() + 2);
   for (int r = 0; r < rounds; ++r) {
     for (size_t vi = 0; vi < V.size(); ++vi) {
@@ -87,8 +91,14 @@ static void run_shape(const char* title, int M, int N, int rounds, hipStream_t s
       a.x_bytes = (unsigned)((size_t)M * K * 2); a.r_bytes = (unsigned)std::min<size_t>((size_t)M * N * 2, 0xFFFFFFF0u);
       PWKArgs b = a;
       if (V[vi].launch(b, st) != 0) { times[vi].push_back(-1.f); continue; }
+      static int rot = 0;
       HIPCHECK(hipEventRecord(e0, st));
-      for (int i = 0; i < 5; ++i) { b = a; V[vi].launch(b, st); }
+      for (int i = 0; i < 5; ++i) {
+        b = a;
+        const int k = (rot++) % NSET;
+        b.x = x + (size_t)k * M * K; b.res = RM ? res + (size_t)k * M * N : nullptr; b.y = y + (size_t)k * M * N;
+        V[vi].launch(b, st);
+      }
       HIPCHECK(hipEventRecord(e1, st));
       HIPCHECK(hipEventSynchronize(e1));
       float ms;
@@ -100,8 +110,9 @@ static void run_shape(const char* title, int M, int N, int rounds, hipStream_t s
     for (int k = 0; k < 2; ++k) {
       HIPCHECK(hipEventRecord(e0, st));
       for (int i = 0; i < 5; ++i) {
-        if (k == 0) copy_kernel<<<2048, 256, 0, st>>>((const uint4*)res, (uint4*)y, n16);
-        else rw_kernel<<<2048, 256, 0, st>>>((const uint4*)res, (uint4*)y, n16);
+        const size_t off = (size_t)(i % NSET) * M * N * 2 / 16;
+        if (k == 0) copy_kernel<<<2048, 256, 0, st>>>((const uint4*)res + off, (uint4*)y + off, n16);
+        else rw_kernel<<<2048, 256, 0, st>>>((const uint4*)res + off, (uint4*)y + off, n16);
       }
       HIPCHECK(hipEventRecord(e1, st));
       HIPCHECK(hipEventSynchronize(e1));
