@@ -427,9 +427,13 @@ static int launch_c3k(C3KArgs& a, hipStream_t stream) {
 // Plane heights: the smallest instantiated HLP >= BM + 2W + 2 whose buffers fit the 160 KiB LDS.
 // small-M form of the N % 256 tile: 64 pixels x 256 channels (2 x 2 accumulator blocks per wave) - twice the workgroups for the
 // 20x20-level layers (M = 6 400 per 16-image part: 50 -> 100 pixel tiles), each with half the MFMA work
-static bool c3k_small_m(int M, int N, int W) {
+static bool c3k_small_m(int M, int N, int W, int C) {
   static const int thr = fx_tune("FX_C3K_SMALL_M", 16000);
-  return N % 256 == 0 && M <= thr && 64 + 2 * W + 2 <= 192;
+  // round 6: for C <= 256 (the hybrid encoder's 20x20 level: four chunks per tile) the limit can be set apart (FX_C3K_SMALL_M_C256; default = the
+  // general one) - under three batches in flight the 128-pixel tiles were +1 % for RT-DETR at M = 12 800 while BiSeNetFormer's 512-channel
+  // layers of the same M lost 15 % on them
+  static const int thr256 = fx_tune("FX_C3K_SMALL_M_C256", thr);
+  return N % 256 == 0 && M <= (C <= 256 ? thr256 : thr) && 64 + 2 * W + 2 <= 192;
 }
 
 static int c3k_plan(int C, int N, int W) {   // 0: not covered, else HLP
@@ -458,7 +462,7 @@ int fx_launch_conv3x3_kplane(const ConvArgs& c, const bf16_t* w_frag, hipStream_
   a.H = c.H; a.W = c.W; a.C = c.C; a.N = c.N; a.ldx = c.ldx; a.ldy = c.ldy; a.ldr = c.ldr; a.M = c.M;
   a.HW = c.Ho * c.Wo; a.y_bstride = c.y_bstride; a.x_bytes = c.x_bytes; a.r_bytes = c.r_bytes; a.dbg = nullptr;
   const int mode = fx_c3_epilogue_mode(c.act, c.res != nullptr, c.res_after);
-  const bool small = c3k_small_m(c.M, c.N, c.W);
+  const bool small = c3k_small_m(c.M, c.N, c.W, c.C);
   // res2's 3x3 layers (64 -> 64, one chunk, no residual): 256-pixel tiles on four waves, no loader, two workgroups per CU
   static const int duo_on = fx_tune("FX_C3K_DUO", 1);
   if (duo_on && c.N == 64 && c.C == 64 && !c.res && 256 + 2 * c.W + 2 <= 608) {
